@@ -1,0 +1,70 @@
+"""
+Deterministic synthetic frames for tests and bench.py.
+
+The numbers are *inputs*: the WCS cards, camera position and photo time of the
+two real headers the reference ships as test data
+(/root/reference/auromat/test/resources/ISS030-E-102170_dc.wcs and
+ISS029-E-8492.wcs: `CRVAL*`, `CD*`, `POS*[SHIF]`, `DATE-OBS` + `DATESHIF`),
+re-scaled to arbitrary image sizes.  No network, no files.
+"""
+from datetime import datetime, timedelta
+
+import numpy as np
+
+# name -> (CRVAL1, CRVAL2, CD11, CD12, camera xyz [km, GCRS], photo time); CD21 = -CD12, CD22 = CD11;
+# native size 4256 x 2832, CRPIX = (2129, 1417), LONPOLE = 180, LATPOLE = 0
+_POINTINGS = {
+    # northern hemisphere; SM longitudes do not wrap
+    'iss030': (16.0531567459, 23.1148929108, -0.00912247310646, -0.00250608809647,
+               (-4809.524217485676, 524.8117887762777, 4729.265809729493),
+               datetime(2012, 1, 25, 9, 26, 55, 60000)),
+    # southern hemisphere; MLT spans 0..24 h => SM longitude crosses +-180 (discontinuity branch)
+    'iss029': (140.917604745, -25.9728268931, 0.0247522916736, 0.00429015193241,
+               (3631.092688542516, -2155.308046530645, -5284.393739145378),
+               datetime(2011, 9, 18, 11, 54, 56)),
+}
+NATIVE_W, NATIVE_H = 4256, 2832
+
+
+def frame_header(width, height, pointing='iss030'):
+    """
+    WCS header dict (the cards reference wcs.py:80-90 / astrometry.py:260 read)
+    showing the same sky as the native 4256x2832 frame but sampled on
+    width x height pixels.  Returns (header, cameraPosGCRS, photoTime).
+    """
+    ra, dec, cd11, cd12, cam, t = _POINTINGS[pointing]
+    sx = NATIVE_W / float(width)
+    sy = NATIVE_H / float(height)
+    # keep pixels square in angle unless the aspect ratio changes
+    hdr = {
+        'CTYPE1': 'RA---TAN', 'CTYPE2': 'DEC--TAN', 'LONPOLE': 180.0, 'LATPOLE': 0.0,
+        'CRVAL1': ra, 'CRVAL2': dec,
+        'CRPIX1': width / 2.0 + 0.5, 'CRPIX2': height / 2.0 + 0.5,
+        'CD1_1': cd11 * sx, 'CD1_2': cd12 * sy, 'CD2_1': -cd12 * sx, 'CD2_2': cd11 * sy,
+        'IMAGEW': int(width), 'IMAGEH': int(height),
+    }
+    return hdr, np.array(cam, dtype=np.float64), t
+
+
+def frame_image(width, height, seed=0, dtype=np.uint16):
+    """Seeded RGB image, (height, width, 3)."""
+    hi = 65535 if np.dtype(dtype) == np.uint16 else 255
+    return np.random.RandomState(seed).randint(0, hi, (height, width, 3)).astype(dtype)
+
+
+def sequence_frame(k, width=4240, height=2832, pointing='iss030'):
+    """
+    Frame k of a synthetic sequence: pointing drifts by
+    0.05 deg of RA per frame, time advances 1 s per frame and the camera moves
+    along a great-circle arc at 7.66 km/s.  Returns (header, camera, time, image seed).
+    """
+    hdr, cam, t = frame_header(width, height, pointing)
+    hdr['CRVAL1'] = hdr['CRVAL1'] + 0.05 * k
+    r = np.linalg.norm(cam)
+    u = cam / r
+    # fixed in-plane direction perpendicular to the camera position
+    v = np.cross([0.0, 0.0, 1.0], u)
+    v /= np.linalg.norm(v)
+    ang = 7.66 * k / r
+    cam_k = r * (np.cos(ang) * u + np.sin(ang) * v)
+    return hdr, cam_k, t + timedelta(seconds=k), k

@@ -1,0 +1,379 @@
+"""
+TEST INFRASTRUCTURE — generates tests/golden/*.npz|json by running the REAL
+reference (esa/auromat imported from /root/reference via oracle/refshim.py).
+
+Run in the build container only:   python oracle/make_golden.py
+The fixtures are data (inputs + reference outputs); this script is the record
+of how they were made.  Nothing here is imported by the product.
+
+Fixtures
+  host_scalars.npz      et, rotation matrices, dipole pole, WCS rotation for several dates/headers
+  georef_small_*.npz    full arrays of a 128x96 frame (fast + exact centres, 2 pointings)
+  georef_full_*.npz     every 32nd row/col + digests of full 4256x2832 frames (real headers)
+  masks_small.npz       maskedByElevation(10) + sanitisation masks
+  resample_*.npz        `_resample(method='mean')` cases: plain, discontinuity, pole, MLat/MLT
+  histogram_edges.npz   bin-edge micro cases for util.histogram.histogram2d
+  known_answers.json    literal known-answer vectors of the reference's own unit tests
+"""
+import json
+import os
+import sys
+from datetime import datetime
+
+import numpy as np
+import numpy.ma as ma
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import refshim  # noqa: E402
+
+refshim.install_shims()
+
+from auromat.coordinates import transform as T  # noqa: E402
+from auromat.coordinates import intersection as I  # noqa: E402
+from auromat.coordinates.wcs import tan_pix2world  # noqa: E402
+from auromat.coordinates.transformations import euler_matrix  # noqa: E402
+from auromat.mapping.spacecraft import ArraySpacecraftMapping  # noqa: E402
+from auromat.mapping.mapping import BoundingBox, GenericMapping  # noqa: E402
+from auromat.util.histogram import histogram2d  # noqa: E402
+import auromat.resample as R  # noqa: E402
+
+from auromat_amd.synthetic import frame_header, frame_image  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+RES = '/root/reference/auromat/test/resources/'
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print('wrote', name, '%.2f MB' % (os.path.getsize(path) / 1e6))
+
+
+def hdr_arrays(hdr):
+    """numeric header cards as a flat dict of 0-d arrays"""
+    keys = ['LONPOLE', 'LATPOLE', 'CRVAL1', 'CRVAL2', 'CRPIX1', 'CRPIX2',
+            'CD1_1', 'CD1_2', 'CD2_1', 'CD2_2', 'IMAGEW', 'IMAGEH']
+    return {'hdr_' + k: np.float64(hdr[k]) for k in keys}
+
+
+def time_arrays(t):
+    et = T.date2es(t)
+    return dict(time_iso=np.array(t.strftime('%Y-%m-%dT%H:%M:%S.%f')), et=np.float64(et),
+                m_geo=T.mat_j2000_to_geo(et), m_sm=T.mat_j2000_to_sm(et), m_geo_sm=T.mat_geo_to_sm(et))
+
+
+def raw(m, fast):
+    """raw NaN-filled arrays of an astrometry mapping"""
+    mlat, mlt = m.mLatMlt
+    mlatc, mltc = m.mLatMltCenter
+    return dict(
+        dir_corner=m.cameraToPixelCornerDirection, p_corner=m.intersectionInflatedCorner,
+        dir_center=m.cameraToPixelCenterDirection, p_center=m.intersectionInflatedCenter,
+        lat=m.lats.data, lon=m.lons.data, lat_c=m.latsCenter.data, lon_c=m.lonsCenter.data,
+        elev=m.elevation.data, mlat=mlat.data, mlt=mlt.data, mlat_c=mlatc.data, mlt_c=mltc.data)
+
+
+def digest(a):
+    a = np.asarray(a, dtype=np.float64)
+    ok = ~np.isnan(a)
+    return np.array([ok.sum(), a[ok].sum(), a[ok].min(), a[ok].max(),
+                     np.abs(a[ok]).sum()], dtype=np.float64)
+
+
+def host_scalars():
+    dates = [datetime(2012, 1, 25, 9, 26, 55, 60000), datetime(2011, 9, 18, 11, 54, 56),
+             datetime(2012, 1, 25, 9, 26, 55), datetime(2000, 1, 1, 12), datetime(1999, 12, 31, 23, 59, 59),
+             datetime(2015, 3, 17, 22, 10, 5, 123456), datetime(2019, 12, 31, 0, 0, 1), datetime(1985, 6, 1, 3, 4, 5)]
+    out = dict(dates=np.array([d.strftime('%Y-%m-%dT%H:%M:%S.%f') for d in dates]))
+    out['et'] = np.array([T.date2es(d) for d in dates])
+    for name, fn in [('m_geo', T.mat_j2000_to_geo), ('m_sm', T.mat_j2000_to_sm), ('m_geo_sm', T.mat_geo_to_sm),
+                     ('m_P', T.mat_P), ('m_T1', T.mat_T1), ('m_T2', T.mat_T2), ('m_T3', T.mat_T3),
+                     ('m_T4', T.mat_T4)]:
+        out[name] = np.array([fn(e) for e in out['et']])
+    out['mag_lat'] = np.array([T.mag_lat(e) for e in out['et']])
+    out['mag_lon'] = np.array([T.mag_lon(e) for e in out['et']])
+    # WCS native->celestial rotation for a few (RA, Dec, LONPOLE)
+    wcs_in = np.array([[16.0531567459, 23.1148929108, 180.0], [140.917604745, -25.9728268931, 180.0],
+                       [0.0, 0.0, 180.0], [359.5, 89.0, 180.0], [200.0, -60.0, 170.0]])
+    out['wcs_in'] = wcs_in
+    out['wcs_rot'] = np.array([euler_matrix(np.deg2rad(ra + 90), np.deg2rad(90 - dec),
+                                            np.deg2rad(-(lp - 90)), 'rzxz')[:3, :3] for ra, dec, lp in wcs_in])
+    save('host_scalars.npz', **out)
+
+
+def georef_small():
+    for pointing in ('iss030', 'iss029'):
+        hdr, cam, t = frame_header(128, 96, pointing)
+        img = frame_image(128, 96, seed=1)
+        for fast in (True, False):
+            m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'g', fastCenterCalculation=fast)
+            arrs = raw(m, fast)
+            arrs.update(hdr_arrays(hdr))
+            arrs.update(time_arrays(t))
+            arrs.update(cam=cam, altitude=np.float64(110))
+            save('georef_small_%s_%s.npz' % (pointing, 'fast' if fast else 'exact'), **arrs)
+
+
+def georef_full():
+    """Real headers at native size: strided samples + digests of the reference's arrays."""
+    step = 32
+    for fname, tag, modes in [('ISS030-E-102170_dc.wcs', 'iss030', (True, False)),
+                              ('ISS029-E-8492.wcs', 'iss029', (True,))]:
+        hdr = refshim.read_wcs_cards(RES + fname)
+        t, cam = refshim.header_time_and_camera(hdr)
+        img = np.zeros((hdr['IMAGEH'], hdr['IMAGEW'], 3), np.uint8)
+        for fast in modes:
+            m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'g', fastCenterCalculation=fast)
+            arrs = raw(m, fast)
+            out = {}
+            for k, v in arrs.items():
+                if k in ('dir_center', 'p_center', 'dir_corner'):
+                    continue
+                out[k] = np.ascontiguousarray(v[::step, ::step])
+                if v.ndim == 2:
+                    out['digest_' + k] = digest(v)
+            out.update(hdr_arrays(hdr))
+            out.update(time_arrays(t))
+            out.update(cam=cam, altitude=np.float64(110), step=np.int64(step))
+            save('georef_full_%s_%s.npz' % (tag, 'fast' if fast else 'exact'), **out)
+            del m, arrs
+
+
+def masks_small():
+    hdr, cam, t = frame_header(128, 96, 'iss030')
+    img = frame_image(128, 96, seed=1)
+    out = {}
+    for fast in (True, False):
+        tag = 'fast' if fast else 'exact'
+        m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'g', fastCenterCalculation=fast)
+        out[tag + '_corner_mask'] = ma.getmaskarray(m.lats).copy()
+        out[tag + '_center_mask'] = ma.getmaskarray(m.latsCenter).copy()
+        out[tag + '_img_mask'] = ma.getmaskarray(m.img)[:, :, 0].copy()
+        out[tag + '_elev_mask'] = ma.getmaskarray(m.elevation).copy()
+        for min_elev in (10, 25):
+            mm = m.maskedByElevation(min_elev)
+            out['%s_e%d_corner_mask' % (tag, min_elev)] = ma.getmaskarray(mm.lats).copy()
+            out['%s_e%d_center_mask' % (tag, min_elev)] = ma.getmaskarray(mm.latsCenter).copy()
+            out['%s_e%d_img_mask' % (tag, min_elev)] = ma.getmaskarray(mm.img)[:, :, 0].copy()
+            out['%s_e%d_elev_mask' % (tag, min_elev)] = ma.getmaskarray(mm.elevation).copy()
+            mm.checkGuarantees()
+    save('masks_small.npz', **out)
+
+
+def _bbox_from(lats, lons):
+    """nan-min/max bounding box incl. the discontinuity rule of reference mapping.py:726-734"""
+    la = lats.compressed()
+    lo = lons.compressed()
+    lon_min, lon_max = lo.min(), lo.max()
+    if lon_max - lon_min > 180:
+        return BoundingBox(la.min(), lo[lo > 0].min(), la.max(), lo[~(lo > 0)].max())
+    return BoundingBox(la.min(), lon_min, la.max(), lon_max)
+
+
+def _run_resample(lats, lons, lats_c, lons_c, altitude, merged, ppd, pole=False):
+    """lats/lons masked arrays of corners (for bbox + 'outline'), centres NaN-filled"""
+    bb = _bbox_from(lats, lons)
+    outline = np.transpose([lats.compressed(), lons.compressed()])
+    disc = bool(bb.lonWest > bb.lonEast)
+    if pole:
+        bb = BoundingBox(bb.latSouth, -180, 90, 180) if bb.latNorth > 0 else BoundingBox(-90, -180, bb.latNorth, 180)
+    res = R._resample(lats_c, lons_c, altitude, merged, lambda: outline.copy(), bb, ppd,
+                      containsDiscontinuity=disc or pole, containsPole=pole, method='mean')
+    la, lo, lac, loc, data = res
+    return dict(bbox=np.array([bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast]),
+                contains_discontinuity=np.bool_(disc), contains_pole=np.bool_(pole),
+                outline=outline, out_lat=la, out_lon=lo, out_lat_c=lac, out_lon_c=loc, out_data=data)
+
+
+def resample_cases():
+    # (a) geodetic grid, 256x170 frame, elevation >= 10, 0.1 deg
+    for pointing in ('iss030', 'iss029'):
+        w, h = 256, 170
+        hdr, cam, t = frame_header(w, h, pointing)
+        img = frame_image(w, h, seed=3)
+        m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'r', fastCenterCalculation=True)
+        mm = m.maskedByElevation(10)
+        merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+        lats_c, lons_c = mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan)
+        for ppd in ((10, 10), (4, 7)):
+            case = _run_resample(mm.lats, mm.lons, lats_c, lons_c, 110, merged, ppd)
+            # image finalisation as in reference resample.py:128-136
+            rimg, relev = np.dsplit(case['out_data'], [-1])
+            with np.errstate(invalid='ignore'):
+                rimg = np.round(rimg)
+            rimg = np.require(ma.masked_invalid(rimg, copy=False), np.uint16)
+            case.update(out_img=rimg.data, out_img_mask=ma.getmaskarray(rimg))
+            case.update(hdr_arrays(hdr))
+            case.update(time_arrays(t))
+            case.update(cam=cam, altitude=np.float64(110), img=img, min_elev=np.float64(10),
+                        lats_c=lats_c, lons_c=lons_c, elev=mm.elevation.filled(np.nan),
+                        corner_lat=mm.lats.filled(np.nan), corner_lon=mm.lons.filled(np.nan),
+                        ppd=np.array(ppd, dtype=np.float64))
+            save('resample_geo_%s_ppd%dx%d.npz' % (pointing, ppd[0], ppd[1]), **case)
+
+        # (b) MLat/MLT grid (resampleMLatMLT: resample.py:63-71, mapping.py:1519-1559)
+        mlat, mlt = mm.mLatMlt
+        mlat_c, mlt_c = mm.mLatMltCenter
+        mask = ma.getmaskarray(mm.lats)
+        smlon = T.mltToSmLon(mlt.data)
+        smlon_c = T.mltToSmLon(mlt_c.data)
+        sm_lats = ma.masked_array(mlat.data, mask)
+        sm_lons = ma.masked_array(smlon, mask)
+        cmask = ma.getmaskarray(mm.latsCenter)
+        sm_lats_c = np.where(cmask, np.nan, mlat_c.data)
+        sm_lons_c = np.where(cmask, np.nan, smlon_c)
+        case = _run_resample(sm_lats, sm_lons, sm_lats_c, sm_lons_c, 110, merged, (10, 10))
+        glat, glon = T.smToLatLon(case['out_lat'], case['out_lon'], t)
+        glat_c, glon_c = T.smToLatLon(case['out_lat_c'], case['out_lon_c'], t)
+        case.update(geo_lat=glat, geo_lon=glon, geo_lat_c=glat_c, geo_lon_c=glon_c)
+        case.update(hdr_arrays(hdr))
+        case.update(time_arrays(t))
+        case.update(cam=cam, altitude=np.float64(110), img=img, min_elev=np.float64(10),
+                    lats_c=sm_lats_c, lons_c=sm_lons_c, elev=mm.elevation.filled(np.nan),
+                    corner_lat=sm_lats.filled(np.nan), corner_lon=sm_lons.filled(np.nan),
+                    ppd=np.array((10, 10), dtype=np.float64))
+        save('resample_sm_%s.npz' % pointing, **case)
+
+    # (c) synthetic plain / discontinuity / pole grids in the style of reference resample_test.py:21-69
+    rs = np.random.RandomState(7)
+    n = 40
+    lat1 = np.linspace(60, 70, n + 1)
+    lon1 = np.linspace(160, 170, n + 1)
+    lon_g, lat_g = np.meshgrid(lon1, lat1[::-1])
+    lat_gc = (lat_g[:-1, :-1] + lat_g[1:, 1:]) / 2 + rs.uniform(-0.01, 0.01, (n, n))
+    lon_gc = (lon_g[:-1, :-1] + lon_g[1:, 1:]) / 2 + rs.uniform(-0.01, 0.01, (n, n))
+    hole = (np.arange(n)[:, None] - 20) ** 2 + (np.arange(n)[None, :] - 14) ** 2 < 36
+    lat_gc[hole] = np.nan
+    lon_gc[hole] = np.nan
+    data = np.dstack([rs.randint(0, 255, (n, n)).astype(np.float64) for _ in range(3)] + [rs.uniform(0, 90, (n, n))])
+    data[hole] = np.nan
+    for tag, shift, pole in (('plain', 0.0, False), ('disc', 15.0, False), ('pole', 0.0, True)):
+        la, lo, lac, loc = lat_g.copy(), lon_g.copy(), lat_gc.copy(), lon_gc.copy()
+        if shift:
+            from astropy.coordinates import Angle
+            import astropy.units as u
+            lo = Angle((lo + shift) * u.deg).wrap_at(180 * u.deg).degree
+            loc = Angle((loc + shift) * u.deg).wrap_at(180 * u.deg).degree
+        if pole:
+            # move the patch over the north pole: rotate by -25 deg about y after centring on lon 0
+            la2, lo2 = T.rotatePole(np.deg2rad(la.ravel() ), np.deg2rad(lo.ravel() - 165), 110, angle=-25, axis=[0, 1, 0])
+            la, lo = np.rad2deg(la2).reshape(la.shape), np.rad2deg(lo2).reshape(lo.shape)
+            ok = ~np.isnan(lac.ravel())
+            lac2, loc2 = T.rotatePole(np.deg2rad(np.where(ok, lac.ravel(), 0.0)),
+                                      np.deg2rad(np.where(ok, loc.ravel() - 165, 0.0)), 110, angle=-25, axis=[0, 1, 0])
+            lac = np.where(ok, np.rad2deg(lac2), np.nan).reshape(lac.shape)
+            loc = np.where(ok, np.rad2deg(loc2), np.nan).reshape(loc.shape)
+        case = _run_resample(ma.masked_invalid(la), ma.masked_invalid(lo), lac, loc, 110, data, (4, 4), pole=pole)
+        case.update(lats_c=lac, lons_c=loc, data=data, corner_lat=la, corner_lon=lo,
+                    altitude=np.float64(110), ppd=np.array((4, 4), dtype=np.float64))
+        save('resample_synth_%s.npz' % tag, **case)
+
+
+def histogram_edges():
+    edges_cases = {}
+    # uniform bins from a range (the resample case)
+    for tag, nb, rng in (('a', (3, 4), [[0.0, 3.0], [10.0, 12.0]]),
+                         ('b', (103, 63), [[-111.75, -101.45], [47.85, 54.15]]),
+                         ('c', (7, 5), [[-0.35, 0.35], [89.5, 90.0]])):
+        xe = np.linspace(rng[0][0], rng[0][1], nb[0] + 1)
+        ye = np.linspace(rng[1][0], rng[1][1], nb[1] + 1)
+        xs, ys = [], []
+        ymid = 0.5 * (ye[0] + ye[1])
+        xmid = 0.5 * (xe[0] + xe[1])
+        for e in xe:
+            for v in (np.nextafter(e, -np.inf), e, np.nextafter(e, np.inf), e + 4e-8, e - 4e-8, e + 6e-7, e - 6e-7):
+                xs.append(v)
+                ys.append(ymid)
+        for e in ye:
+            for v in (np.nextafter(e, -np.inf), e, np.nextafter(e, np.inf), e + 4e-8, e - 4e-8, e + 6e-7, e - 6e-7):
+                xs.append(xmid)
+                ys.append(v)
+        rs = np.random.RandomState(11)
+        xs += list(rs.uniform(rng[0][0] - 0.2, rng[0][1] + 0.2, 500))
+        ys += list(rs.uniform(rng[1][0] - 0.2, rng[1][1] + 0.2, 500))
+        x, y = np.array(xs), np.array(ys)
+        w1 = rs.randint(0, 65535, len(x)).astype(np.float64)
+        w2 = rs.uniform(0, 90, len(x))
+        hs, xo, yo = histogram2d(x, y, bins=nb, range=rng, weights=[None, w1, w2])
+        edges_cases.update({tag + '_x': x, tag + '_y': y, tag + '_w1': w1, tag + '_w2': w2,
+                            tag + '_bins': np.array(nb), tag + '_range': np.array(rng),
+                            tag + '_xedges': xo, tag + '_yedges': yo,
+                            tag + '_count': hs[0], tag + '_s1': hs[1], tag + '_s2': hs[2]})
+    # explicit (non-uniform) edges
+    xe = np.array([0.0, 1.0, 1.5, 3.0, 5.0])
+    ye = np.array([0.0, 2.0, 3.0, 4.0, 6.0])
+    rs = np.random.RandomState(5)
+    x = np.concatenate([rs.uniform(-1, 6, 300), xe, [np.nextafter(5.0, 6.0), 5.0 + 1e-7]])
+    y = np.concatenate([rs.uniform(-1, 7, 300), ye[::-1], [3.0, 3.0]])
+    w = rs.uniform(-5, 5, len(x))
+    hs, xo, yo = histogram2d(x, y, bins=[xe, ye], weights=[None, w])
+    edges_cases.update(d_x=x, d_y=y, d_w=w, d_xedges=xo, d_yedges=yo, d_count=hs[0], d_s=hs[1])
+    save('histogram_edges.npz', **edges_cases)
+
+
+def known_answers():
+    """
+    Literal known-answer vectors of the reference's own unit tests, as data:
+    intersection_test.py:26-137, transform_test.py:70-129.  Each entry also
+    records what the reference itself returns here ('ref').
+    """
+    ka = {}
+    nan = float('nan')
+    cases = []
+    for a, b, origin, dirs, directed, expect in [
+        (2, 2, [0, 3, 0], [[0, -1, 0], [0, -1, 0], [-1, -1, 0]], True, [[0, 2, 0], [0, 2, 0], [nan, nan, nan]]),
+        (1, 1, [2, 0, 0], [[1, 0, 0]], False, [[1, 0, 0]]),
+        (1, 1, [2, 0, 0], [[1, 0, 0]], True, [[nan, nan, nan]]),
+        (2, 2, [1, 0, 0], [[1, 0, 0]], False, [[2, 0, 0]]),
+        (2, 2, [1, 0, 0], [[1, 0, 0]], True, [[2, 0, 0]]),
+    ]:
+        ref = I._ellipsoidLineIntersection_np(a, b, origin, dirs, directed=directed)
+        hit = I._ellipsoidLineIntersects_np(a, b, origin, dirs, directed=directed)
+        cases.append(dict(a=a, b=b, origin=origin, dirs=dirs, directed=directed, expect=expect,
+                          ref=ref.tolist(), ref_intersects=hit.tolist()))
+    ka['ellipsoid'] = cases
+    # intersection_test.py:44-51 (WGS84 chord, undirected)
+    from auromat.coordinates.geodesic import wgs84A, wgs84B
+    p1 = np.array(T.geodetic2Ecef(np.deg2rad(30), np.deg2rad(60), 0))
+    p2 = np.array(T.geodetic2Ecef(np.deg2rad(-30), np.deg2rad(-60), 0))
+    i1 = I._ellipsoidLineIntersection_np(wgs84A, wgs84B, p1, [p1 - p2], directed=False)
+    ka['wgs84_chord'] = dict(a=wgs84A, b=wgs84B, p1=p1.tolist(), p2=p2.tolist(), ref=i1.tolist(), decimals=6)
+    sph = []
+    for r, origin, dirs, directed, expect in [
+        (2, [0, 3, 0], [0, -1, 0], True, [0, 2, 0]),
+        (1, [2, 0, 0], [[1, 0, 0]], False, [[1, 0, 0]]),
+        (1, [2, 0, 0], [[1, 0, 0]], True, [[nan, nan, nan]]),
+        (1, [-2, 0, 0], [[1, 0, 0]], False, [[-1, 0, 0]]),
+        (1, [-2, 0, 0], [[1, 0, 0]], True, [[-1, 0, 0]]),
+        (1, [-2, 0, 0], [[-1, 0, 0]], False, [[-1, 0, 0]]),
+        (1, [-2, 0, 0], [[-1, 0, 0]], True, [[nan, nan, nan]]),
+        (2, [1, 0, 0], [[1, 0, 0]], False, [[2, 0, 0]]),
+        (2, [1, 0, 0], [[1, 0, 0]], True, [[2, 0, 0]]),
+        (2, [1, 0, 0], [[-1, 0, 0]], False, [[2, 0, 0]]),
+        (2, [1, 0, 0], [[-1, 0, 0]], True, [[-2, 0, 0]]),
+    ]:
+        ref = I.sphereLineIntersection(r, origin, np.asarray(dirs, dtype=float), directed=directed)
+        sph.append(dict(r=r, origin=origin, dirs=dirs, directed=directed, expect=expect, ref=np.asarray(ref).tolist()))
+    ka['sphere'] = sph
+    # transform_test.py:85-129 (SSCWeb vectors, 2 decimals)
+    ka['sscweb'] = dict(date='2012-01-25T09:26:55', decimals=2,
+                        geo=[[-0.11, -0.63, 0.77]], j2000=[[-0.62, 0.16, 0.77]], gei=[[-0.62, 0.16, 0.77]],
+                        gse=[[-0.72, -0.26, 0.64]], gsm=[[-0.72, -0.30, 0.62]], sm=[[-0.43, -0.30, 0.85]])
+    # transform_test.py:70-83: geodetic round trip to 11 decimals (degrees)
+    ka['geodetic_roundtrip'] = dict(decimals=11, lat_linspace=[-89.9, 89.9, 50], lon_linspace=[-179.9, 179.9, 50],
+                                    mgrid=[[-89, 89, 5], [-179, 179, 5]])
+    with open(os.path.join(OUT, 'known_answers.json'), 'w') as fp:
+        json.dump(ka, fp, indent=1)
+    print('wrote known_answers.json')
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ['host_scalars', 'georef_small', 'masks_small', 'resample_cases',
+                             'histogram_edges', 'known_answers', 'georef_full']
+    for name in which:
+        globals()[name]()
