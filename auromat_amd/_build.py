@@ -1,0 +1,51 @@
+"""
+Builds libauromat_hip.so (the C ABI of include/auromat_hip.h) in-tree with hipcc for gfx950.
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
+"""
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, 'csrc')
+LIB_DIR = os.path.join(PKG_DIR, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libauromat_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared',
+         '-Wall', '-Wextra', '-Wno-unused-parameter',
+         # resolve libamdhip64.so.7 from the process (torch ships one with the same SONAME) or from ROCm
+         '-Wl,-rpath,/opt/rocm/lib']
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + [os.path.join(CSRC, 'amt_common.h'),
+                        os.path.join(os.path.dirname(PKG_DIR), 'include', 'auromat_hip.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into auromat_amd/lib/libauromat_hip.so. Returns the library path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    tmp = LIB_PATH + '.tmp.%d' % os.getpid()
+    cmd = [HIPCC] + FLAGS + ['-o', tmp] + sources()
+    if verbose:
+        print(' '.join(cmd))
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise RuntimeError('hipcc failed:\n' + res.stdout)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build(force=True, verbose=True))

@@ -1,0 +1,253 @@
+"""
+ctypes binding of libauromat_hip.so (include/auromat_hip.h) and the per-device context.
+
+There is no CPU fallback: if the shared library is missing or no HIP device is visible, every
+compute entry point raises.  PyTorch is used only for device memory and the current stream.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from ._build import LIB_PATH
+
+c_double_p = C.POINTER(C.c_double)
+c_void_pp = C.POINTER(C.c_void_p)
+
+
+class FrameParams(C.Structure):
+    """amt_frame_params"""
+    _fields_ = [('width', C.c_int32), ('height', C.c_int32), ('fast_center', C.c_int32), ('reserved', C.c_int32),
+                ('cd', C.c_double * 4), ('crpix', C.c_double * 2), ('rot', C.c_double * 9),
+                ('cam', C.c_double * 3), ('a', C.c_double), ('b', C.c_double),
+                ('a0', C.c_double), ('b0', C.c_double), ('m_geo', C.c_double * 9), ('m_sm', C.c_double * 9)]
+
+
+class GeorefOut(C.Structure):
+    """amt_georef_out"""
+    _fields_ = [(k, C.c_void_p) for k in ('lat', 'lon', 'lat_c', 'lon_c', 'elev', 'mlat', 'mlt', 'mlat_c',
+                                          'mlt_c', 'bbox')] + [('bbox_min_elevation', C.c_double)]
+
+
+class Axis(C.Structure):
+    """amt_axis"""
+    _fields_ = [('edges', C.c_void_p), ('nbin', C.c_int32), ('uniform', C.c_int32),
+                ('first', C.c_double), ('last', C.c_double), ('scale', C.c_double), ('last_rounded', C.c_double)]
+
+
+_I, _L, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p
+_SIGNATURES = {
+    'amt_abi_version': ([], _I),
+    'amt_ctx_create': ([_I, _P, c_void_pp], _I),
+    'amt_ctx_destroy': ([_P], _I),
+    'amt_ctx_set_stream': ([_P, _P], _I),
+    'amt_ctx_get_stream': ([_P], _P),
+    'amt_ctx_synchronize': ([_P], _I),
+    'amt_last_error': ([_P], C.c_char_p),
+    'amt_device_info': ([_P, C.c_char_p, C.c_size_t, C.POINTER(_I), C.POINTER(_I), C.POINTER(C.c_size_t)], _I),
+    'amt_malloc': ([_P, C.c_size_t, c_void_pp], _I),
+    'amt_free': ([_P, _P], _I),
+    'amt_memcpy_h2d': ([_P, _P, _P, C.c_size_t], _I),
+    'amt_memcpy_d2h': ([_P, _P, _P, C.c_size_t], _I),
+    'amt_memset': ([_P, _P, _I, C.c_size_t], _I),
+    'amt_event_create': ([_P, c_void_pp], _I),
+    'amt_event_destroy': ([_P, _P], _I),
+    'amt_event_record': ([_P, _P], _I),
+    'amt_event_elapsed_ms': ([_P, _P, _P, C.POINTER(C.c_float)], _I),
+    'amt_directions_tan': ([_P, C.POINTER(FrameParams), _I, _P], _I),
+    'amt_directions_tan_points': ([_P, C.POINTER(FrameParams), _P, _P, _L, _I, _P], _I),
+    'amt_intersect_ellipsoid': ([_P, _D, _D, c_double_p, _P, _L, _I, _P], _I),
+    'amt_intersects_ellipsoid': ([_P, _D, _D, c_double_p, _P, _L, _I, _P], _I),
+    'amt_intersect_sphere': ([_P, _D, c_double_p, _P, _L, _I, _P], _I),
+    'amt_ecef_to_geodetic': ([_P, _P, _P, _P, _L, _D, _D, _P, _P], _I),
+    'amt_geodetic_to_ecef': ([_P, _P, _P, _D, _L, _D, _D, _P, _P, _P], _I),
+    'amt_rotate_to_latlon': ([_P, c_double_p, _P, _L, _D, _D, _P, _P], _I),
+    'amt_rotate_to_mlat_mlt': ([_P, c_double_p, _P, _L, _P, _P], _I),
+    'amt_rotate_vectors': ([_P, c_double_p, _P, _L, _P], _I),
+    'amt_latlon_to_mlat_mlt': ([_P, c_double_p, _P, _P, _D, _L, _D, _D, _P, _P], _I),
+    'amt_sm_to_latlon': ([_P, c_double_p, _P, _P, _L, _D, _D, _P, _P], _I),
+    'amt_rotate_pole': ([_P, c_double_p, _P, _P, _D, _L, _D, _D, _P, _P], _I),
+    'amt_cartesian_to_spherical': ([_P, _P, _P, _P, _L, _P, _P, _P], _I),
+    'amt_spherical_to_cartesian': ([_P, _P, _P, _P, _L, _P, _P, _P], _I),
+    'amt_georef_frame': ([_P, C.POINTER(FrameParams), C.POINTER(GeorefOut)], _I),
+    'amt_georef_frame_dirs': ([_P, C.POINTER(FrameParams), _P, C.POINTER(GeorefOut)], _I),
+    'amt_mask_by_elevation': ([_P, _P, _P, C.c_int32, C.c_int32, _D, _P, _P, _P], _I),
+    'amt_sanitize_masks': ([_P, _P, _P, _P, C.c_int32, C.c_int32, _I], _I),
+    'amt_bbox_corners': ([_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P], _I),
+    'amt_hist2d_accumulate': ([_P, _P, _P, _L, c_void_pp, C.c_int32, C.POINTER(Axis), C.POINTER(Axis), _I, _P,
+                               c_void_pp], _I),
+    'amt_hist2d_finalize_mean': ([_P, _P, c_void_pp, C.c_int32, C.c_int32, C.c_int32, _P], _I),
+    'amt_bin_frame': ([_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _D, C.POINTER(Axis),
+                       C.POINTER(Axis), _I, _P], _I),
+    'amt_bin_frame_finalize': ([_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P], _I),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library (symbols typed). Raises NativeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NativeError('libauromat_hip.so is not built (%s missing); run `python -c "import '
+                                  '__graft_entry__ as g; g.build()"` or `python -m auromat_amd._build`. '
+                                  'There is no CPU fallback.' % LIB_PATH)
+            # torch first: its bundled libamdhip64.so has SONAME libamdhip64.so.7, which satisfies our
+            # DT_NEEDED so that torch tensors and our kernels share one HIP runtime
+            import torch  # noqa: F401
+            handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+            for name, (argtypes, restype) in _SIGNATURES.items():
+                fn = getattr(handle, name)
+                fn.argtypes = argtypes
+                fn.restype = restype
+            if handle.amt_abi_version() != 1:
+                raise NativeError('ABI version mismatch')
+            _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+class Context(object):
+    """One amt_ctx bound to a torch device and to torch's current stream on it."""
+    _cache = {}
+    _cache_lock = threading.Lock()
+
+    def __init__(self, device_index):
+        import torch
+        self._lib = lib()
+        if not torch.cuda.is_available():
+            raise NativeError('no HIP device is visible; auromat_amd has no CPU fallback')
+        self.device = torch.device('cuda', device_index)
+        self.stream_handle = torch.cuda.current_stream(self.device).cuda_stream
+        h = C.c_void_p()
+        rc = self._lib.amt_ctx_create(device_index, C.c_void_p(self.stream_handle), C.byref(h))
+        if rc != 0:
+            raise NativeError('amt_ctx_create failed (%d)' % rc)
+        self.handle = h
+
+    @classmethod
+    def current(cls, device=None):
+        """Context for `device` (default: torch's current device), re-bound to torch's current stream."""
+        import torch
+        if not torch.cuda.is_available():
+            raise NativeError('no HIP device is visible; auromat_amd has no CPU fallback')
+        if device is None:
+            idx = torch.cuda.current_device()
+        else:
+            idx = torch.device(device).index
+            if idx is None:
+                idx = torch.cuda.current_device()
+        key = (os.getpid(), threading.get_ident(), idx)
+        with cls._cache_lock:
+            ctx = cls._cache.get(key)
+            if ctx is None:
+                ctx = cls._cache[key] = cls(idx)
+        stream = torch.cuda.current_stream(ctx.device).cuda_stream
+        if stream != ctx.stream_handle:
+            ctx.check(ctx._lib.amt_ctx_set_stream(ctx.handle, C.c_void_p(stream)))
+            ctx.stream_handle = stream
+        return ctx
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self._lib.amt_last_error(self.handle)
+            raise NativeError('libauromat_hip: %s (code %d)' % (msg.decode() if msg else '?', rc))
+
+    def call(self, name, *args):
+        self.check(getattr(self._lib, name)(self.handle, *args))
+
+    def synchronize(self):
+        self.call('amt_ctx_synchronize')
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, khz, mem = C.c_int(), C.c_int(), C.c_size_t()
+        self.call('amt_device_info', name, 256, C.byref(cus), C.byref(khz), C.byref(mem))
+        return dict(name=name.value.decode(), compute_units=cus.value, clock_khz=khz.value, total_mem=mem.value)
+
+    # -- device arrays (torch tensors) ------------------------------------------------------
+    def empty(self, shape, dtype=None):
+        import torch
+        return torch.empty(shape, dtype=dtype or torch.float64, device=self.device)
+
+    def zeros(self, shape, dtype=None):
+        import torch
+        return torch.zeros(shape, dtype=dtype or torch.float64, device=self.device)
+
+    def to_device(self, array, dtype=np.float64):
+        """Host array (or device tensor) -> contiguous device tensor of `dtype`."""
+        import torch
+        if isinstance(array, torch.Tensor):
+            t = array.to(self.device)
+            want = _torch_dtype(dtype)
+            if t.dtype != want:
+                t = t.to(want)
+            return t.contiguous()
+        a = np.ascontiguousarray(array, dtype=dtype)
+        if a.dtype == np.uint16:   # torch has limited uint16 support: move the bytes
+            t = torch.from_numpy(a.view(np.int16)).to(self.device)
+            return t
+        return torch.from_numpy(a).to(self.device)
+
+    # -- events -------------------------------------------------------------------------------
+    def event(self):
+        e = C.c_void_p()
+        self.call('amt_event_create', C.byref(e))
+        return e
+
+    def record(self, event):
+        self.call('amt_event_record', event)
+
+    def elapsed_ms(self, start, stop):
+        ms = C.c_float()
+        self.call('amt_event_elapsed_ms', start, stop, C.byref(ms))
+        return ms.value
+
+    def destroy_event(self, event):
+        self.call('amt_event_destroy', event)
+
+
+def _torch_dtype(dtype):
+    import torch
+    return {np.dtype(np.float64): torch.float64, np.dtype(np.uint8): torch.uint8,
+            np.dtype(np.int16): torch.int16, np.dtype(np.uint16): torch.int16,
+            np.dtype(np.int64): torch.int64, np.dtype(np.bool_): torch.uint8}[np.dtype(dtype)]
+
+
+def ptr(tensor):
+    """Device pointer of a torch tensor (or None)."""
+    if tensor is None:
+        return None
+    assert tensor.is_contiguous()
+    return C.c_void_p(tensor.data_ptr())
+
+
+def host3(v):
+    return (C.c_double * 3)(*[float(x) for x in np.asarray(v, dtype=np.float64).ravel()])
+
+
+def host9(m):
+    return (C.c_double * 9)(*[float(x) for x in np.asarray(m, dtype=np.float64).ravel()])
+
+
+def to_host(tensor, dtype=None, shape=None):
+    """Device tensor -> numpy array (synchronises)."""
+    a = tensor.cpu().numpy()
+    if dtype is not None and a.dtype != np.dtype(dtype):
+        a = a.view(dtype) if a.dtype.itemsize == np.dtype(dtype).itemsize else a.astype(dtype)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a

@@ -1,0 +1,392 @@
+// Histogram binning for resample(method='mean')
+// (reference auromat/util/histogram.py:57-282, auromat/resample.py:301-351).
+//
+// k_bin_frame: one workgroup bins a BW x BH tile of the image.  Neighbouring pixels fall into
+// neighbouring cells, so the tile's cells form a small window of the output grid: the window is
+// privatised in LDS (u32 count / channel sums, i64 fixed-point elevation), filled with LDS atomics
+// and flushed with one 64-bit global integer atomic per touched cell and plane.  Integer
+// accumulation is exact and order independent, so the result is bit-reproducible.
+// Algorithmic HBM bytes: 24 B (lat, lon, elev) + nchan * sizeof(pixel) per pixel read; the grid is negligible.
+#include "amt_common.h"
+
+namespace {
+
+using namespace amt;
+
+constexpr int kBlock = 256;
+
+struct axis_dev {
+    const double* edges;
+    int nbin;
+    int uniform;
+    double scale, last_rounded;
+    double e0, e_last, inv_step;
+};
+
+// searchsorted(edges, v, 'right') with the right-most-edge rule of histogram.py:209-224.
+// Returns 0..nbin+1; 0 and nbin+1 are outliers (NaN sorts to the end like NumPy does).
+__device__ __forceinline__ int bin_index(const axis_dev& ax, double v) {
+    if (!(v == v)) return ax.nbin + 1;
+    if (v < ax.e0) return 0;
+    if (v >= ax.e_last) {
+        const bool on_edge = rint(v * ax.scale) / ax.scale == ax.last_rounded;
+        return on_edge ? ax.nbin : ax.nbin + 1;
+    }
+    int g;
+    if (ax.uniform) {
+        g = (int)((v - ax.e0) * ax.inv_step);
+        g = g < 0 ? 0 : (g > ax.nbin - 1 ? ax.nbin - 1 : g);
+        while (v < ax.edges[g]) --g;          // e0 <= v < e_last bounds both walks
+        while (v >= ax.edges[g + 1]) ++g;
+    } else {
+        int lo = 0, hi = ax.nbin;             // invariant: edges[lo] <= v < edges[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (v >= ax.edges[mid]) lo = mid; else hi = mid;
+        }
+        g = lo;
+    }
+    return g + 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// generic float64 histogram (operator-level API)
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxWeights = 8;
+
+struct hist_args {
+    const double* x;
+    const double* y;
+    int64_t n;
+    const double* w[kMaxWeights];
+    double* s[kMaxWeights];
+    double* count;
+    int nweights;
+    axis_dev ax, ay;
+    int lon_wrap;
+};
+
+__global__ __launch_bounds__(kBlock) void k_hist2d(hist_args A) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
+        double xv = A.x[i];
+        if (A.lon_wrap) xv = wrap180_shifted(xv);
+        const int ix = bin_index(A.ax, xv);
+        const int iy = bin_index(A.ay, A.y[i]);
+        if (ix < 1 || ix > A.ax.nbin || iy < 1 || iy > A.ay.nbin) continue;
+        const int64_t cell = (int64_t)(ix - 1) * A.ay.nbin + (iy - 1);
+        unsafeAtomicAdd(&A.count[cell], 1.0);
+        for (int k = 0; k < A.nweights; ++k) unsafeAtomicAdd(&A.s[k][cell], A.w[k][i]);
+    }
+}
+
+__global__ void k_hist2d_finalize(const double* __restrict__ count, hist_args A, int nx, int ny,
+                                  double* __restrict__ mean) {
+    const int64_t n = (int64_t)nx * ny;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / nx), c = (int)(i - (int64_t)r * nx);
+        const int64_t cell = (int64_t)c * ny + (ny - 1 - r);
+        const double cnt = count[cell];
+        for (int k = 0; k < A.nweights; ++k)
+            mean[i * A.nweights + k] = cnt == 0.0 ? NAN : A.s[k][cell] / cnt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused frame binning
+// ------------------------------------------------------------------------------------------
+struct bin_args {
+    const double* lat_c;
+    const double* lon_c;
+    const double* elev;
+    const void* img;
+    const uint8_t* mask;
+    int height, width;
+    double min_elev;
+    int use_elev_threshold;
+    axis_dev ax, ay;
+    int lon_wrap;
+    unsigned long long* acc;
+};
+
+constexpr int kBW = 64, kBH = 16, kWCap = 1024;
+constexpr double kFix = 4294967296.0;   // 2^32
+
+template <typename IMG_T, int NCH>
+__global__ __launch_bounds__(kBlock) void k_bin_frame(bin_args A) {
+    constexpr int PPT = kBW * kBH / kBlock;   // pixels per thread
+    __shared__ unsigned int sCnt[kWCap];
+    __shared__ unsigned int sCh[NCH > 0 ? NCH : 1][kWCap];
+    __shared__ unsigned long long sEl[kWCap];
+    __shared__ int sBox[4][kBlock / 64];
+
+    const int tiles_x = (A.width + kBW - 1) / kBW;
+    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int gx = tile_x * kBW + (threadIdx.x & (kBW - 1));
+    const int row0 = tile_y * kBH + (threadIdx.x / kBW);
+    const int64_t ncell = (int64_t)A.ax.nbin * A.ay.nbin;
+    const IMG_T* img = static_cast<const IMG_T*>(A.img);
+
+    int ix[PPT], iy[PPT];
+    unsigned int ch[PPT][NCH > 0 ? NCH : 1];
+    long long el[PPT];
+    int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int gy = row0 + k * (kBlock / kBW);
+        ix[k] = 0;
+        iy[k] = 0;
+        el[k] = 0;
+        if (gx < A.width && gy < A.height) {
+            const int64_t gi = (int64_t)gy * A.width + gx;
+            const double la = A.lat_c[gi];
+            bool ok = la == la;                                            // resample.py:315-321
+            double ev = 0.0;
+            if (A.elev) {
+                ev = A.elev[gi];
+                if (A.use_elev_threshold) ok = ok && (ev >= A.min_elev);   // mapping.py:856
+            }
+            if (A.mask) ok = ok && A.mask[gi] == 0;
+            if (ok) {
+                double xv = A.lon_c[gi];
+                if (A.lon_wrap) xv = wrap180_shifted(xv);
+                const int bx = bin_index(A.ax, xv), by = bin_index(A.ay, la);
+                if (bx >= 1 && bx <= A.ax.nbin && by >= 1 && by <= A.ay.nbin) {
+                    ix[k] = bx;
+                    iy[k] = by;
+                    bx0 = min(bx0, bx);
+                    bx1 = max(bx1, bx);
+                    by0 = min(by0, by);
+                    by1 = max(by1, by);
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) ch[k][c] = img[gi * NCH + c];
+                    // a NaN elevation of a kept pixel poisons nothing here: it contributes 0 (the
+                    // reference would turn the cell's elevation into NaN; masks make this unreachable)
+                    el[k] = (ev == ev) ? __double2ll_rn(ev * kFix) : 0;
+                }
+            }
+        }
+    }
+    // window of cells touched by this tile
+    for (int o = 32; o > 0; o >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, o));
+        bx1 = max(bx1, __shfl_xor(bx1, o));
+        by0 = min(by0, __shfl_xor(by0, o));
+        by1 = max(by1, __shfl_xor(by1, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        sBox[0][w] = bx0;
+        sBox[1][w] = bx1;
+        sBox[2][w] = by0;
+        sBox[3][w] = by1;
+    }
+    __syncthreads();
+    bx0 = sBox[0][0];
+    bx1 = sBox[1][0];
+    by0 = sBox[2][0];
+    by1 = sBox[3][0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) {
+        bx0 = min(bx0, sBox[0][w]);
+        bx1 = max(bx1, sBox[1][w]);
+        by0 = min(by0, sBox[2][w]);
+        by1 = max(by1, sBox[3][w]);
+    }
+    if (bx1 < 0) return;   // no pixel of this tile lands on the grid (uniform across the block)
+    const int wnx = bx1 - bx0 + 1, wny = by1 - by0 + 1;
+    const int64_t wn = (int64_t)wnx * wny;
+
+    if (wn <= kWCap) {
+        for (int i = threadIdx.x; i < (int)wn; i += kBlock) {
+            sCnt[i] = 0;
+            sEl[i] = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) sCh[c][i] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (ix[k] > 0) {
+                const int wi = (ix[k] - bx0) * wny + (iy[k] - by0);
+                atomicAdd(&sCnt[wi], 1u);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) atomicAdd(&sCh[c][wi], ch[k][c]);
+                atomicAdd(&sEl[wi], (unsigned long long)el[k]);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < (int)wn; i += kBlock) {
+            const unsigned int cnt = sCnt[i];
+            if (cnt == 0) continue;
+            const int wx = i / wny, wy = i - wx * wny;
+            const int64_t cell = (int64_t)(bx0 - 1 + wx) * A.ay.nbin + (by0 - 1 + wy);
+            atomicAdd(&A.acc[cell], (unsigned long long)cnt);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) atomicAdd(&A.acc[(int64_t)(1 + c) * ncell + cell], (unsigned long long)sCh[c][i]);
+            atomicAdd(&A.acc[(int64_t)(1 + NCH) * ncell + cell], sEl[i]);
+        }
+    } else {
+        // tile spreads over more cells than the LDS window holds (very fine grids): global atomics
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (ix[k] > 0) {
+                const int64_t cell = (int64_t)(ix[k] - 1) * A.ay.nbin + (iy[k] - 1);
+                atomicAdd(&A.acc[cell], 1ull);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) atomicAdd(&A.acc[(int64_t)(1 + c) * ncell + cell], (unsigned long long)ch[k][c]);
+                atomicAdd(&A.acc[(int64_t)(1 + NCH) * ncell + cell], (unsigned long long)el[k]);
+            }
+        }
+    }
+}
+
+template <typename IMG_T>
+__global__ void k_bin_finalize(const unsigned long long* __restrict__ acc, int nx, int ny, int nch,
+                               double* __restrict__ mean, IMG_T* __restrict__ out_img, uint8_t* __restrict__ out_mask,
+                               double* __restrict__ out_count) {
+    const int64_t n = (int64_t)nx * ny;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / nx), c = (int)(i - (int64_t)r * nx);
+        const int64_t cell = (int64_t)c * ny + (ny - 1 - r);     // transpose + flipud (resample.py:339-349)
+        const unsigned long long cnt = acc[cell];
+        const double dc = (double)cnt;
+        for (int k = 0; k < nch; ++k) {
+            const double m = cnt ? (double)acc[(int64_t)(1 + k) * n + cell] / dc : NAN;
+            if (mean) mean[i * (nch + 1) + k] = m;
+            if (out_img) out_img[i * nch + k] = cnt ? (IMG_T)rint(m) : (IMG_T)0;   // np.round: half to even
+        }
+        if (mean) {
+            const long long fx = (long long)acc[(int64_t)(1 + nch) * n + cell];
+            mean[i * (nch + 1) + nch] = cnt ? ((double)fx / kFix) / dc : NAN;
+        }
+        if (out_mask) out_mask[i] = cnt ? 0 : 1;
+        if (out_count) out_count[i] = dc;
+    }
+}
+
+void make_axis(const amt_axis* a, axis_dev* out) {
+    out->edges = a->edges;
+    out->nbin = a->nbin;
+    out->uniform = a->uniform;
+    out->scale = a->scale;
+    out->last_rounded = a->last_rounded;
+    out->e0 = a->first;
+    out->e_last = a->last;
+    out->inv_step = a->nbin / (a->last - a->first);
+}
+
+inline dim3 grid_for(int64_t n) {
+    int64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    return dim3(static_cast<unsigned>(blocks));
+}
+
+}  // namespace
+
+extern "C" {
+
+int amt_hist2d_accumulate(amt_ctx* ctx, const double* x, const double* y, int64_t n, const double* const* weights,
+                          int32_t nweights, const amt_axis* xaxis, const amt_axis* yaxis, int lon_wrap,
+                          double* count, double* const* sums) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, xaxis && yaxis && count, "NULL argument");
+    AMT_REQUIRE(ctx, n >= 0 && nweights >= 0 && nweights <= kMaxWeights, "bad n or too many weight arrays (max 8)");
+    AMT_REQUIRE(ctx, nweights == 0 || (weights && sums), "weights/sums missing");
+    AMT_REQUIRE(ctx, xaxis->edges && yaxis->edges && xaxis->nbin > 0 && yaxis->nbin > 0 && xaxis->last > xaxis->first &&
+                         yaxis->last > yaxis->first, "bad axis");
+    if (n == 0) return AMT_OK;
+    AMT_REQUIRE(ctx, x && y, "NULL coordinates");
+    hist_args A;
+    A.x = x;
+    A.y = y;
+    A.n = n;
+    A.count = count;
+    A.nweights = nweights;
+    for (int k = 0; k < kMaxWeights; ++k) {
+        A.w[k] = k < nweights ? weights[k] : nullptr;
+        A.s[k] = k < nweights ? sums[k] : nullptr;
+        AMT_REQUIRE(ctx, k >= nweights || (A.w[k] && A.s[k]), "NULL weight or sum array");
+    }
+    make_axis(xaxis, &A.ax);
+    make_axis(yaxis, &A.ay);
+    A.lon_wrap = lon_wrap ? 1 : 0;
+    hipLaunchKernelGGL(k_hist2d, grid_for(n), dim3(kBlock), 0, ctx->stream, A);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_hist2d_finalize_mean(amt_ctx* ctx, const double* count, const double* const* sums, int32_t nweights,
+                             int32_t nx, int32_t ny, double* mean) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, count && mean && (nweights == 0 || sums), "NULL argument");
+    AMT_REQUIRE(ctx, nx > 0 && ny > 0 && nweights >= 0 && nweights <= kMaxWeights, "bad shape");
+    hist_args A = {};
+    A.nweights = nweights;
+    for (int k = 0; k < nweights; ++k) A.s[k] = const_cast<double*>(sums[k]);
+    hipLaunchKernelGGL(k_hist2d_finalize, grid_for((int64_t)nx * ny), dim3(kBlock), 0, ctx->stream, count, A, nx, ny,
+                       mean);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const double* elev, const void* img,
+                  int32_t img_dtype, int32_t nchan, const uint8_t* center_mask, int32_t height, int32_t width,
+                  double min_elevation, const amt_axis* xaxis, const amt_axis* yaxis, int lon_wrap, uint64_t* acc) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, lat_c && lon_c && xaxis && yaxis && acc, "NULL argument");
+    AMT_REQUIRE(ctx, height > 0 && width > 0, "empty frame");
+    AMT_REQUIRE(ctx, nchan >= 0 && nchan <= 4, "nchan must be 0..4");
+    AMT_REQUIRE(ctx, nchan == 0 || (img && (img_dtype == 1 || img_dtype == 2)), "img must be uint8 (1) or uint16 (2)");
+    AMT_REQUIRE(ctx, xaxis->edges && yaxis->edges && xaxis->nbin > 0 && yaxis->nbin > 0 && xaxis->last > xaxis->first &&
+                         yaxis->last > yaxis->first, "bad axis");
+    bin_args A;
+    A.lat_c = lat_c;
+    A.lon_c = lon_c;
+    A.elev = elev;
+    A.img = img;
+    A.mask = center_mask;
+    A.height = height;
+    A.width = width;
+    A.min_elev = min_elevation;
+    A.use_elev_threshold = (elev != nullptr) && !(std::isinf(min_elevation) && min_elevation < 0);
+    make_axis(xaxis, &A.ax);
+    make_axis(yaxis, &A.ay);
+    A.lon_wrap = lon_wrap ? 1 : 0;
+    A.acc = reinterpret_cast<unsigned long long*>(acc);
+    const int tiles_x = (width + kBW - 1) / kBW, tiles_y = (height + kBH - 1) / kBH;
+    const dim3 grid((unsigned)((int64_t)tiles_x * tiles_y)), block(kBlock);
+#define AMT_BIN_CASE(T, N)                                                          \
+    hipLaunchKernelGGL((k_bin_frame<T, N>), grid, block, 0, ctx->stream, A)
+    const bool u8 = img_dtype == 1;
+    switch (nchan) {
+        case 0: AMT_BIN_CASE(uint8_t, 0); break;
+        case 1: if (u8) AMT_BIN_CASE(uint8_t, 1); else AMT_BIN_CASE(uint16_t, 1); break;
+        case 2: if (u8) AMT_BIN_CASE(uint8_t, 2); else AMT_BIN_CASE(uint16_t, 2); break;
+        case 3: if (u8) AMT_BIN_CASE(uint8_t, 3); else AMT_BIN_CASE(uint16_t, 3); break;
+        default: if (u8) AMT_BIN_CASE(uint8_t, 4); else AMT_BIN_CASE(uint16_t, 4); break;
+    }
+#undef AMT_BIN_CASE
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_bin_frame_finalize(amt_ctx* ctx, const uint64_t* acc, int32_t nx, int32_t ny, int32_t nchan,
+                           int32_t img_dtype, double* mean, void* out_img, uint8_t* out_mask, double* out_count) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, acc != nullptr, "NULL argument");
+    AMT_REQUIRE(ctx, nx > 0 && ny > 0 && nchan >= 0 && nchan <= 4, "bad shape");
+    AMT_REQUIRE(ctx, out_img == nullptr || img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
+    const dim3 grid = grid_for((int64_t)nx * ny), block(kBlock);
+    const unsigned long long* a = reinterpret_cast<const unsigned long long*>(acc);
+    if (img_dtype == 1)
+        hipLaunchKernelGGL((k_bin_finalize<uint8_t>), grid, block, 0, ctx->stream, a, nx, ny, nchan, mean,
+                           static_cast<uint8_t*>(out_img), out_mask, out_count);
+    else
+        hipLaunchKernelGGL((k_bin_finalize<uint16_t>), grid, block, 0, ctx->stream, a, nx, ny, nchan, mean,
+                           static_cast<uint16_t*>(out_img), out_mask, out_count);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+// Shared host/device helpers of libauromat_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/auromat_hip.h"
+
+struct amt_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+    double* scratch;        // small device scratch (counters)
+    void* ws;               // grow-only device workspace (per-block partial reductions)
+    size_t ws_bytes;
+    std::string last_error;
+};
+
+// Returns a device workspace of at least `bytes` (grow-only; reallocation synchronises the stream).
+static inline void* amt_workspace(amt_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return ctx->ws;
+    if (ctx->ws) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->ws);
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
+    if (hipMalloc(&ctx->ws, cap) != hipSuccess) {
+        ctx->ws = nullptr;
+        return nullptr;
+    }
+    ctx->ws_bytes = cap;
+    return ctx->ws;
+}
+
+#define AMT_CHECK_CTX(ctx) \
+    if ((ctx) == nullptr) return AMT_EINVAL
+
+#define AMT_REQUIRE(ctx, cond, msg)                           \
+    do {                                                      \
+        if (!(cond)) {                                        \
+            (ctx)->last_error = std::string(__func__) + ": " + (msg); \
+            return AMT_EINVAL;                                \
+        }                                                     \
+    } while (0)
+
+#define AMT_HIP(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t err__ = (call);                                                      \
+        if (err__ != hipSuccess) {                                                      \
+            (ctx)->last_error = std::string(__func__) + ": " #call " -> " + hipGetErrorString(err__); \
+            return AMT_EHIP;                                                            \
+        }                                                                               \
+    } while (0)
+
+#define AMT_LAUNCH_CHECK(ctx) AMT_HIP(ctx, hipGetLastError())
+
+static inline int amt_set_device(amt_ctx* ctx) {
+    AMT_HIP(ctx, hipSetDevice(ctx->device));
+    return AMT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// device math
+// ------------------------------------------------------------------------------------------
+namespace amt {
+
+constexpr double kRad2Deg = 57.29577951308232;     // 180/pi, also the TAN projection constant
+constexpr double kDeg2Rad = 0.017453292519943295;  // pi/180
+
+struct vec3 {
+    double x, y, z;
+};
+
+struct mat3 {
+    double m[9];
+};
+
+__host__ __device__ inline mat3 make_mat3(const double* p) {
+    mat3 r;
+    for (int i = 0; i < 9; ++i) r.m[i] = p[i];
+    return r;
+}
+
+__device__ __forceinline__ vec3 mul(const mat3& a, const vec3& v) {
+    vec3 r;
+    r.x = a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z;
+    r.y = a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z;
+    r.z = a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z;
+    return r;
+}
+
+__device__ __forceinline__ double dot(const vec3& a, const vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// Constants of the ray / ellipsoid quadratic that do not depend on the ray
+// (reference intersection.py:63-74: origin and direction scaled by 1/a, 1/a, 1/b).
+struct ellipsoid_ray {
+    double ia, ib;      // 1/a, 1/b
+    double osx, osy, osz;   // -origin * (1/a,1/a,1/b)
+    double oo;          // |os|^2
+    double ox, oy, oz;  // origin
+    int inside;         // origin inside the ellipsoid (intersection.py:239-241)
+    int directed;
+};
+
+__host__ inline ellipsoid_ray make_ray(double a, double b, const double* origin, int directed) {
+    ellipsoid_ray r;
+    r.ia = 1 / a;
+    r.ib = 1 / b;
+    r.osx = -origin[0] * r.ia;
+    r.osy = -origin[1] * r.ia;
+    r.osz = -origin[2] * r.ib;
+    r.oo = r.osx * r.osx + r.osy * r.osy + r.osz * r.osz;
+    r.ox = origin[0];
+    r.oy = origin[1];
+    r.oz = origin[2];
+    double qx = origin[0] / a, qy = origin[1] / a, qz = origin[2] / b;
+    r.inside = (qx * qx + qy * qy + qz * qz) < 1;
+    r.directed = directed;
+    return r;
+}
+
+// Ray parameter of the chosen intersection (units of |d|), NaN for a miss.
+// reference intersection.py:76-99.
+__device__ __forceinline__ double ray_param(const ellipsoid_ray& e, const vec3& d) {
+    const double dsx = d.x * e.ia, dsy = d.y * e.ia, dsz = d.z * e.ib;
+    const double d_o = dsx * e.osx + dsy * e.osy + dsz * e.osz;
+    const double d_d = dsx * dsx + dsy * dsy + dsz * dsz;
+    const double disc = d_o * d_o - e.oo * d_d + d_d;
+    const double root = sqrt(disc);  // NaN when the line misses
+    double t;
+    if (e.directed) {
+        t = e.inside ? d_o + root : d_o - root;
+        if (t < 0) t = NAN;
+    } else {
+        const double t1 = d_o - root, t2 = d_o + root;
+        t = fabs(t1) < fabs(t2) ? t1 : t2;
+    }
+    return t / d_d;
+}
+
+__device__ __forceinline__ vec3 ray_point(const ellipsoid_ray& e, const vec3& d, double t) {
+    vec3 p;
+    p.x = d.x * t + e.ox;
+    p.y = d.y * t + e.oy;
+    p.z = d.z * t + e.oz;
+    return p;
+}
+
+// Bowring (1985) single-step ECEF -> geodetic, reference transform.py:252-297.
+struct bowring {
+    double a, b, e2a, d;   // e2a = e^2 * a, d = (a^2 - b^2)/b
+};
+
+__host__ __device__ inline bowring make_bowring(double a, double b) {
+    bowring w;
+    w.a = a;
+    w.b = b;
+    w.e2a = ((a * a - b * b) / (a * a)) * a;
+    w.d = (a * a - b * b) / b;
+    return w;
+}
+
+__device__ __forceinline__ void ecef_to_geodetic(const bowring& w, double x, double y, double z, double& lat,
+                                                 double& lon) {
+    const double p2 = x * x + y * y;
+    const double p = sqrt(p2);
+    const double r = sqrt(p2 + z * z);
+    const double tu = w.b * z * (1 + w.d / r) / (w.a * p);
+    const double tu2 = tu * tu;
+    const double c = 1 / sqrt(1 + tu2);
+    const double cu3 = c * c * c;
+    const double su3 = cu3 * tu2 * tu;
+    const double tp = (z + w.d * su3) / (p - w.e2a * cu3);
+    lat = atan(tp);
+    lon = atan2(y, x);
+}
+
+__device__ __forceinline__ void geodetic_to_ecef(const bowring& w, double lat, double lon, double h, double& x,
+                                                 double& y, double& z) {
+    // reference transform.py:156-178
+    const double e2 = w.e2a / w.a;
+    double sl, cl, so, co;
+    sincos(lat, &sl, &cl);
+    sincos(lon, &so, &co);
+    const double n = w.a / sqrt(1 - e2 * sl * sl);
+    const double nh = n + h;
+    x = nh * cl * co;
+    y = nh * cl * so;
+    z = (n * (1 - e2) + h) * sl;
+}
+
+// SM cartesian -> (mlat deg, mlt h), reference transform.py:104-127,373-386,421-427
+__device__ __forceinline__ void sm_to_mlat_mlt(const vec3& s, double& mlat, double& mlt) {
+    const double sxy = sqrt(s.x * s.x + s.y * s.y);
+    mlat = atan2(s.z, sxy) * kRad2Deg;
+    mlt = (atan2(s.y, s.x) * kRad2Deg) * (24.0 / 360.0) + 12.0;
+}
+
+// True when the closed longitude path o00 -> o01 -> o11 -> o10 -> o00 (corner quad of one pixel, degrees)
+// winds once around a geographic pole: the wrapped longitude steps then sum to +-360 instead of 0.
+__device__ __forceinline__ bool quad_winds_pole(double o00, double o01, double o11, double o10) {
+    auto step = [](double a, double b) {
+        const double d = b - a;
+        return d - 360.0 * rint(d * (1.0 / 360.0));
+    };
+    const double w = step(o00, o01) + step(o01, o11) + step(o11, o10) + step(o10, o00);
+    return fabs(w) > 180.0;
+}
+
+// TAN (gnomonic) WCS camera model.
+struct tan_wcs {
+    double cd[4];
+    double crpix[2];
+    mat3 rot;
+};
+
+__host__ inline tan_wcs make_tan_wcs(const amt_frame_params* p) {
+    tan_wcs w;
+    for (int i = 0; i < 4; ++i) w.cd[i] = p->cd[i];
+    w.crpix[0] = p->crpix[0];
+    w.crpix[1] = p->crpix[1];
+    w.rot = make_mat3(p->rot);
+    return w;
+}
+
+// Unit direction of pixel coordinate (x, y) [0-based, pixel centres at integers].
+// reference wcs.py:93-142 evaluates atan2/atan and then cos/sin of those angles; algebraically the
+// native unit vector is (-Y, X, 180/pi) / sqrt(X^2 + Y^2 + (180/pi)^2) with (X, Y) = CD (p - CRPIX + 1),
+// which needs one rsqrt and no trigonometry.
+__device__ __forceinline__ vec3 tan_direction(const tan_wcs& w, double x, double y) {
+    const double px = x - w.crpix[0] + 1.0;
+    const double py = y - w.crpix[1] + 1.0;
+    const double X = w.cd[0] * px + w.cd[1] * py;
+    const double Y = w.cd[2] * px + w.cd[3] * py;
+    const double inv = rsqrt(X * X + Y * Y + kRad2Deg * kRad2Deg);
+    vec3 v = {-Y * inv, X * inv, kRad2Deg * inv};
+    return mul(w.rot, v);
+}
+
+// astropy Angle.wrap_at(180 deg) of (v + 180), reference resample.py:212-218
+__device__ __forceinline__ double wrap180_shifted(double v) {
+    double a = v + 180.0;
+    const double wraps = floor((a + 180.0) / 360.0);
+    a = a - wraps * 360.0;
+    if (a >= 180.0) a -= 360.0;
+    if (a < -180.0) a += 360.0;
+    return a;
+}
+
+}  // namespace amt

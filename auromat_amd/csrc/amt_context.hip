@@ -1,0 +1,165 @@
+// Context, stream, memory and event helpers of the C ABI (include/auromat_hip.h).
+#include "amt_common.h"
+
+extern "C" {
+
+int amt_abi_version(void) { return AMT_ABI_VERSION; }
+
+int amt_ctx_create(int device_id, void* stream, amt_ctx** out_ctx) {
+    if (out_ctx == nullptr) return AMT_EINVAL;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_id < 0 || device_id >= count) return AMT_EHIP;
+    amt_ctx* ctx = new (std::nothrow) amt_ctx();
+    if (ctx == nullptr) return AMT_ENOMEM;
+    ctx->device = device_id;
+    ctx->stream = nullptr;
+    ctx->owns_stream = false;
+    ctx->scratch = nullptr;
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    if (hipSetDevice(device_id) != hipSuccess) {
+        delete ctx;
+        return AMT_EHIP;
+    }
+    if (stream != nullptr) {
+        ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return AMT_EHIP;
+        }
+        ctx->owns_stream = true;
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->scratch), 256) != hipSuccess) {
+        if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return AMT_ENOMEM;
+    }
+    *out_ctx = ctx;
+    return AMT_OK;
+}
+
+int amt_ctx_destroy(amt_ctx* ctx) {
+    AMT_CHECK_CTX(ctx);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->owns_stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+    return AMT_OK;
+}
+
+int amt_ctx_set_stream(amt_ctx* ctx, void* stream) {
+    AMT_CHECK_CTX(ctx);
+    if (ctx->owns_stream) {
+        AMT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        AMT_HIP(ctx, hipStreamDestroy(ctx->stream));
+        ctx->owns_stream = false;
+    }
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    return AMT_OK;
+}
+
+void* amt_ctx_get_stream(amt_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
+
+int amt_ctx_synchronize(amt_ctx* ctx) {
+    AMT_CHECK_CTX(ctx);
+    AMT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AMT_OK;
+}
+
+const char* amt_last_error(amt_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int amt_device_info(amt_ctx* ctx, char* name, size_t name_len, int* compute_units, int* clock_khz,
+                    size_t* total_mem) {
+    AMT_CHECK_CTX(ctx);
+    hipDeviceProp_t prop;
+    AMT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len > 0) {
+        std::string s = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+        std::strncpy(name, s.c_str(), name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    if (total_mem) *total_mem = prop.totalGlobalMem;
+    return AMT_OK;
+}
+
+int amt_malloc(amt_ctx* ctx, size_t bytes, void** out_dptr) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, out_dptr != nullptr, "out_dptr is NULL");
+    if (amt_set_device(ctx)) return AMT_EHIP;
+    hipError_t e = hipMalloc(out_dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("amt_malloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? AMT_ENOMEM : AMT_EHIP;
+    }
+    return AMT_OK;
+}
+
+int amt_free(amt_ctx* ctx, void* dptr) {
+    AMT_CHECK_CTX(ctx);
+    if (dptr == nullptr) return AMT_OK;
+    if (amt_set_device(ctx)) return AMT_EHIP;
+    AMT_HIP(ctx, hipFree(dptr));
+    return AMT_OK;
+}
+
+int amt_memcpy_h2d(amt_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, dst && src, "NULL pointer");
+    AMT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return AMT_OK;
+}
+
+int amt_memcpy_d2h(amt_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, dst && src, "NULL pointer");
+    AMT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AMT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AMT_OK;
+}
+
+int amt_memset(amt_ctx* ctx, void* dst, int value, size_t bytes) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, dst != nullptr, "NULL pointer");
+    AMT_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return AMT_OK;
+}
+
+int amt_event_create(amt_ctx* ctx, void** out_event) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, out_event != nullptr, "out_event is NULL");
+    hipEvent_t ev;
+    AMT_HIP(ctx, hipEventCreate(&ev));
+    *out_event = reinterpret_cast<void*>(ev);
+    return AMT_OK;
+}
+
+int amt_event_destroy(amt_ctx* ctx, void* event) {
+    AMT_CHECK_CTX(ctx);
+    if (event) AMT_HIP(ctx, hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+    return AMT_OK;
+}
+
+int amt_event_record(amt_ctx* ctx, void* event) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, event != nullptr, "event is NULL");
+    AMT_HIP(ctx, hipEventRecord(reinterpret_cast<hipEvent_t>(event), ctx->stream));
+    return AMT_OK;
+}
+
+int amt_event_elapsed_ms(amt_ctx* ctx, void* start, void* stop, float* out_ms) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, start && stop && out_ms, "NULL argument");
+    AMT_HIP(ctx, hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
+    AMT_HIP(ctx, hipEventElapsedTime(out_ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+    return AMT_OK;
+}
+
+}  // extern "C"

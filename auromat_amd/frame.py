@@ -1,0 +1,99 @@
+"""
+Device-resident state of one mapping: the raw coordinate / elevation arrays (NaN = missing), the
+image and the two masks, as torch tensors in HBM.  The mapping classes are thin views over this;
+kernels consume it directly so that georeferencing -> masking -> resampling never leaves the GPU.
+"""
+import copy
+
+import numpy as np
+
+from ._native import Context, ptr, to_host
+
+
+class FrameData(object):
+    COORDS = ('lat', 'lon', 'lat_c', 'lon_c', 'elev', 'mlat', 'mlt', 'mlat_c', 'mlt_c')
+
+    def __init__(self, ctx, height, width):
+        self.ctx = ctx
+        self.height = int(height)
+        self.width = int(width)
+        for k in self.COORDS:
+            setattr(self, k, None)
+        self.img = None            # (H, W, C) uint8 tensor, or int16 tensor holding uint16 bits
+        self.img_dtype = None      # numpy dtype of the image
+        self.corner_mask = None    # (H+1, W+1) uint8, 1 = masked; None = "NaN latitude"
+        self.center_mask = None    # (H, W) uint8
+        self.bbox = None           # 8 doubles on the device, see amt_georef_out.bbox
+
+    # -- construction -------------------------------------------------------------------------
+    @classmethod
+    def from_host(cls, lats, lons, lats_c, lons_c, elev, img, corner_mask=None, center_mask=None, device=None):
+        ctx = Context.current(device)
+        h, w = lats_c.shape
+        fd = cls(ctx, h, w)
+        fd.lat = ctx.to_device(np.asarray(lats, dtype=np.float64))
+        fd.lon = ctx.to_device(np.asarray(lons, dtype=np.float64))
+        fd.lat_c = ctx.to_device(np.asarray(lats_c, dtype=np.float64))
+        fd.lon_c = ctx.to_device(np.asarray(lons_c, dtype=np.float64))
+        if elev is not None:
+            fd.elev = ctx.to_device(np.asarray(elev, dtype=np.float64))
+        if img is not None:
+            fd.set_image(img)
+        if corner_mask is not None:
+            fd.corner_mask = ctx.to_device(np.asarray(corner_mask, dtype=np.uint8), np.uint8)
+        if center_mask is not None:
+            fd.center_mask = ctx.to_device(np.asarray(center_mask, dtype=np.uint8), np.uint8)
+        return fd
+
+    def set_image(self, img):
+        img = np.asarray(img)
+        if img.ndim == 2:
+            img = img[:, :, None]
+        assert img.dtype in (np.uint8, np.uint16), 'image must be uint8 or uint16'
+        assert img.shape[:2] == (self.height, self.width) and img.shape[2] <= 4
+        self.img_dtype = img.dtype
+        self.img = self.ctx.to_device(img, img.dtype)
+
+    @property
+    def nchan(self):
+        return 0 if self.img is None else int(self.img.shape[2])
+
+    @property
+    def img_dtype_code(self):
+        return 0 if self.img is None else (1 if self.img_dtype == np.uint8 else 2)
+
+    def shallow_copy(self):
+        return copy.copy(self)
+
+    # -- masks ----------------------------------------------------------------------------------
+    def corner_mask_tensor(self):
+        import torch
+        if self.corner_mask is None:
+            self.corner_mask = torch.isnan(self.lat).to(torch.uint8)
+        return self.corner_mask
+
+    def center_mask_tensor(self):
+        import torch
+        if self.center_mask is None:
+            self.center_mask = torch.isnan(self.lat_c).to(torch.uint8)
+        return self.center_mask
+
+    # -- host views -----------------------------------------------------------------------------
+    def host(self, name):
+        t = getattr(self, name)
+        return None if t is None else to_host(t)
+
+    def host_image(self):
+        if self.img is None:
+            return None
+        return to_host(self.img, dtype=self.img_dtype)
+
+    def host_mask(self, which):
+        t = self.corner_mask_tensor() if which == 'corner' else self.center_mask_tensor()
+        return to_host(t).astype(bool)
+
+    def host_bbox(self):
+        return None if self.bbox is None else to_host(self.bbox)
+
+
+__all__ = ['FrameData', 'ptr']

@@ -1,0 +1,186 @@
+"""
+Mappings that derive their coordinates from a camera position and a WCS solution
+(reference auromat/mapping/astrometry.py).
+
+The reference chains five lazily cached NumPy stages per frame (pixel directions -> ellipsoid
+intersection -> J2000->GEO -> Bowring -> elevation, astrometry.py:49-212).  Here the first access
+to any coordinate property launches ONE fused kernel (``amt_georef_frame``) that produces corner
+lat/lon, centre lat/lon and elevation together; MLat/MLT is a second launch of the same kernel
+with only the magnetic outputs enabled.
+"""
+from __future__ import division
+
+import ctypes as C
+
+import numpy as np
+import numpy.ma as ma
+
+from ..coordinates.geodesic import wgs84A, wgs84B
+from ..coordinates.transform import date2es, mat_j2000_to_geo, mat_j2000_to_sm
+from ..coordinates.wcs import fill_wcs_params, pix2world
+from ..frame import FrameData
+from .._native import Context, FrameParams, GeorefOut, ptr, to_host
+from .mapping import BaseMapping, GenericMapping, inflatedEarthIntersection
+
+
+def frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fastCenterCalculation):
+    """The amt_frame_params block of one frame: WCS cards + camera + per-frame rotation matrices."""
+    p = fill_wcs_params(FrameParams(), wcsHeader)
+    p.fast_center = 1 if fastCenterCalculation else 0
+    p.cam[:] = [float(v) for v in cameraPosGCRS]
+    p.a, p.b = wgs84A + altitude, wgs84B + altitude          # mapping.py:1498-1501
+    p.a0, p.b0 = wgs84A, wgs84B                              # transform.py:338
+    et = date2es(photoTime)
+    p.m_geo[:] = list(mat_j2000_to_geo(et).ravel())
+    p.m_sm[:] = list(mat_j2000_to_sm(et).ravel())
+    return p
+
+
+def georef_into(fd, params, geo=True, mag=False, bbox_min_elevation=None):
+    """Launch the fused kernel writing the requested output groups into `fd` (allocating them)."""
+    h, w = fd.height, fd.width
+    out = GeorefOut()
+    ctx = fd.ctx
+    if geo:
+        fd.lat, fd.lon = ctx.empty((h + 1, w + 1)), ctx.empty((h + 1, w + 1))
+        fd.lat_c, fd.lon_c, fd.elev = ctx.empty((h, w)), ctx.empty((h, w)), ctx.empty((h, w))
+        out.lat, out.lon, out.lat_c, out.lon_c, out.elev = (t.data_ptr() for t in
+                                                            (fd.lat, fd.lon, fd.lat_c, fd.lon_c, fd.elev))
+    if mag:
+        fd.mlat, fd.mlt = ctx.empty((h + 1, w + 1)), ctx.empty((h + 1, w + 1))
+        fd.mlat_c, fd.mlt_c = ctx.empty((h, w)), ctx.empty((h, w))
+        out.mlat, out.mlt, out.mlat_c, out.mlt_c = (t.data_ptr() for t in (fd.mlat, fd.mlt, fd.mlat_c, fd.mlt_c))
+    if bbox_min_elevation is not None:
+        fd.bbox = ctx.empty((8,))
+        out.bbox = fd.bbox.data_ptr()
+        out.bbox_min_elevation = float(bbox_min_elevation)
+    ctx.call('amt_georef_frame', C.byref(params), C.byref(out))
+    return fd
+
+
+class BaseAstrometryMapping(BaseMapping):
+    """
+    A mapping which calculates its coordinates based on the camera position and its WCS definition
+    (reference astrometry.py:18-218).
+    """
+
+    def __init__(self, wcsHeader, alti, cameraPosGCRS, photoTime, identifier, metadata={},
+                 fastCenterCalculation=False):
+        """
+        :param alti: mapping altitude in km
+        :param fastCenterCalculation: centre coordinates from the mean of the four corner
+                                      intersection points instead of an own ray cast per centre
+        """
+        BaseMapping.__init__(self, alti, cameraPosGCRS, photoTime, identifier, metadata)
+        self._wcsHeader = wcsHeader
+        self.fastCenterCalculation = fastCenterCalculation
+        self._frame = None
+        self._img_array = None
+
+    @property
+    def wcsHeader(self):
+        return self._wcsHeader
+
+    def _params(self):
+        return frame_params(self._wcsHeader, self.altitude, self.cameraPosGCRS, self.photoTime,
+                            self.fastCenterCalculation)
+
+    def frame(self):
+        if self._frame is None:
+            ctx = Context.current()
+            hdr = self._wcsHeader
+            fd = FrameData(ctx, hdr['IMAGEH'], hdr['IMAGEW'])
+            georef_into(fd, self._params(), geo=True)
+            if self._img_array is not None:
+                fd.set_image(self._img_array)
+            if not self.fastCenterCalculation:
+                # exact centres carry their own misses: reconcile corner and centre masks
+                # (sanitize_data, reference mapping.py:1063-1125); fast centres are consistent
+                # by construction (astrometry.py:35-40)
+                ctx.call('amt_sanitize_masks', ptr(fd.corner_mask_tensor()), ptr(fd.center_mask_tensor()), None,
+                         fd.height, fd.width, 0)
+            self._frame = fd
+        return self._frame
+
+    def _mlatmlt_tensors(self, center):
+        """
+        Overrides BaseMapping: J2000 intersection points go straight to SM (reference
+        astrometry.py:170-198) — one more launch of the fused kernel, magnetic outputs only.
+        """
+        fd = self.frame()
+        if fd.mlat is None:
+            georef_into(fd, self._params(), geo=False, mag=True)
+        return (fd.mlat_c, fd.mlt_c) if center else (fd.mlat, fd.mlt)
+
+    # -- debugging helpers of the reference ---------------------------------------------------
+    @property
+    def cameraToPixelCornerDirection(self):
+        """Direction vector for each pixel corner, (h+1, w+1, 3)."""
+        return self._cached('dir_corner', lambda: pixelDirection(self._wcsHeader, corner=True))
+
+    @property
+    def cameraToPixelCenterDirection(self):
+        """Direction vector for each pixel center, (h, w, 3)."""
+        def make():
+            if self.fastCenterCalculation:
+                return self._calcCenters(self.cameraToPixelCornerDirection)
+            return pixelDirection(self._wcsHeader, corner=False)
+        return self._cached('dir_center', make)
+
+    @property
+    def intersectionInflatedCorner(self):
+        """Point of intersection with the inflated earth for each pixel corner, (h+1, w+1, 3)."""
+        def make():
+            d = self.cameraToPixelCornerDirection
+            return inflatedEarthIntersection(d.reshape(-1, 3), self.cameraPosGCRS, self.altitude).reshape(d.shape)
+        return self._cached('p_corner', make)
+
+    @property
+    def intersectionInflatedCenter(self):
+        """Point of intersection with the inflated earth for each pixel center, (h, w, 3)."""
+        def make():
+            if self.fastCenterCalculation:
+                with np.errstate(invalid='ignore'):
+                    return self._calcCenters(self.intersectionInflatedCorner)
+            d = self.cameraToPixelCenterDirection
+            return inflatedEarthIntersection(d.reshape(-1, 3), self.cameraPosGCRS, self.altitude).reshape(d.shape)
+        return self._cached('p_center', make)
+
+    @staticmethod
+    def _calcCenters(corners):
+        centers = corners[:-1, :-1] + corners[:-1, 1:]
+        centers += corners[1:, 1:]
+        centers += corners[1:, :-1]
+        centers /= 4
+        return centers
+
+    @property
+    def ra(self):
+        """Right ascension for each pixel corner. For debugging purposes only!"""
+        ra, _ = pix2world(self._wcsHeader, self._wcsHeader['IMAGEW'], self._wcsHeader['IMAGEH'])
+        return ra
+
+    @property
+    def dec(self):
+        """Declination for each pixel corner. For debugging purposes only!"""
+        _, dec = pix2world(self._wcsHeader, self._wcsHeader['IMAGEW'], self._wcsHeader['IMAGEH'])
+        return dec
+
+    def createResampled(self, lats, lons, latsCenter, lonsCenter, elevation, img):
+        return GenericMapping(lats, lons, latsCenter, lonsCenter, elevation, self.altitude, img,
+                              self.cameraPosGCRS, self.photoTime, self.identifier, metadata=self.metadata)
+
+
+def pixelDirection(fitsWcsHeader, corner=True):
+    """
+    Direction vector in ICRS for each pixel corner or center, given a WCS solution
+    (reference astrometry.py:245-269; ICRS is treated as GCRS, the difference is far below a pixel).
+
+    :param dictionary fitsWcsHeader: must also contain IMAGEW, IMAGEH in pixels
+    :rtype: unit direction vector array of shape (IMAGEH+1, IMAGEW+1, 3) if corner==True,
+            otherwise (IMAGEH, IMAGEW, 3)
+    """
+    w, h = fitsWcsHeader['IMAGEW'], fitsWcsHeader['IMAGEH']
+    dirs = pix2world(fitsWcsHeader, w, h, corner=corner, ascartesian=True)
+    assert tuple(dirs.shape) == (h + corner, w + corner, 3)
+    return dirs

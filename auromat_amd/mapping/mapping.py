@@ -1,0 +1,674 @@
+"""
+Core classes for georeferenced images — the API surface of the reference's
+auromat/mapping/mapping.py (BoundingBox, BaseMapping, GenericMapping, MappingCollection,
+inflatedEarthIntersection, SM<->geo mapping conversion) on top of device-resident arrays.
+
+A mapping owns a :class:`auromat_amd.frame.FrameData` (torch tensors in HBM).  The reference's
+abstract properties (``lats``, ``lons``, ``latsCenter``, ``lonsCenter``, ``elevation``, ``img``,
+``mLatMlt`` ...) are NumPy masked arrays fetched from the device on first access and cached;
+the heavy consumers (``maskedByElevation``, ``boundingBox``, ``auromat_amd.resample.resample``)
+work on the device tensors directly and never round-trip through the host.
+"""
+from __future__ import division
+
+import copy
+import ctypes as C
+from abc import ABCMeta, abstractmethod
+from collections import namedtuple
+
+import numpy as np
+import numpy.ma as ma
+from six import add_metaclass
+
+from ..coordinates.geodesic import Location, wgs84A, wgs84B
+from ..coordinates.intersection import ellipsoidLineIntersection, sphereLineIntersection
+from ..coordinates.transform import (date2es, j2000ToLatLon, j2000ToMLatMLT, mat_geo_to_sm, mltToSmLon,
+                                     smToLatLon)
+from ..frame import FrameData
+from .._native import Context, host9, ptr, to_host
+
+Size = namedtuple('Size', ['width', 'height'])
+MappingProperties = namedtuple('MappingProperties',
+                               'altitude cameraPosGCRS boundingBox photoTime '
+                               'centroid cameraFootpoint identifier')
+
+R_EARTH_KM = 6378.1366  # astropy.constants.R_earth (IAU 2012 nominal), used by earthModel='sphere'
+
+
+def wrap_at_180(deg):
+    """``astropy.coordinates.Angle(deg).wrap_at(180 deg).degree`` — into [-180, 180)."""
+    a = np.array(deg, dtype=np.float64, copy=True)
+    wraps = (a + 180.0) // 360.0
+    a = a - wraps * 360.0
+    a = np.where(a >= 180.0, a - 360.0, a)
+    a = np.where(a < -180.0, a + 360.0, a)
+    return a if a.ndim else float(a)
+
+
+class BoundingBox(object):
+    """
+    Describes a geographical bounding box that can span across the discontinuity
+    (reference mapping.py:44-287; the geodesic-based ``center``/``size`` are not part of the hot path).
+    """
+
+    def __init__(self, latSouth, lonWest, latNorth, lonEast):
+        assert -180 <= lonWest <= 180, 'Longitude: ' + str(lonWest)
+        assert -180 <= lonEast <= 180, 'Longitude: ' + str(lonEast)
+        assert -90 <= latSouth <= 90, 'Latitude: ' + str(latSouth)
+        assert -90 <= latNorth <= 90, 'Latitude: ' + str(latNorth)
+        self._latSouth, self._lonWest, self._latNorth, self._lonEast = latSouth, lonWest, latNorth, lonEast
+
+    latSouth = property(lambda self: self._latSouth)
+    lonWest = property(lambda self: self._lonWest)
+    latNorth = property(lambda self: self._latNorth)
+    lonEast = property(lambda self: self._lonEast)
+    topLeft = property(lambda self: Location(self.latNorth, self.lonWest))
+    bottomLeft = property(lambda self: Location(self.latSouth, self.lonWest))
+    topRight = property(lambda self: Location(self.latNorth, self.lonEast))
+    bottomRight = property(lambda self: Location(self.latSouth, self.lonEast))
+
+    @property
+    def containsDiscontinuity(self):
+        """Whether the bounding box contains the 180 degree discontinuity."""
+        return self.lonWest > self.lonEast or self.containsPole
+
+    @property
+    def containsPole(self):
+        """Whether the bounding box contains the north and/or south pole."""
+        return self.lonWest == -180 and self.lonEast == 180 and (self.latNorth == 90 or self.latSouth == -90)
+
+    @staticmethod
+    def minimumBoundingBox(latLons):
+        return BoundingBox.mergedBoundingBoxes([BoundingBox(lat, lon, lat, lon) for [lat, lon] in latLons])
+
+    @staticmethod
+    def mergedBoundingBoxes(boundingBoxes):
+        boundingBoxes = list(boundingBoxes)
+        lats = [bb.latSouth for bb in boundingBoxes] + [bb.latNorth for bb in boundingBoxes]
+        lonWest, lonEast = BoundingBox._minimumBoundingBoxLons([(bb.lonWest, bb.lonEast) for bb in boundingBoxes])
+        return BoundingBox(np.min(lats), lonWest, np.max(lats), lonEast)
+
+    @staticmethod
+    def _minimumBoundingBoxLons(lons):
+        # biggest uncovered gap on the circle (reference mapping.py:250-277)
+        lons = np.asarray(lons, dtype=np.float64)
+        xs = np.sort(lons.ravel())
+        xs = np.concatenate((xs, [xs[0] + 360]))
+        unwrapped = np.rad2deg(np.unwrap(np.deg2rad(lons)))
+        covered = np.zeros(len(xs) - 1, dtype=bool)
+        for i in range(1, len(xs)):
+            covered[i - 1] = any(bb[0] <= xs[i - 1] and bb[1] >= xs[i] for bb in unwrapped)
+        gaps = ma.masked_array(xs[1:] - xs[:-1], covered)
+        k = int(np.argmax(gaps))
+        return wrap_at_180(xs[k + 1]), wrap_at_180(xs[k])
+
+    def __eq__(self, obj):
+        return isinstance(obj, BoundingBox) and \
+            self.latNorth == obj.latNorth and self.latSouth == obj.latSouth and \
+            self.lonWest == obj.lonWest and self.lonEast == obj.lonEast
+
+    def __ne__(self, obj):
+        return not self == obj
+
+    def __repr__(self):
+        return 'BoundingBox(latSouth={0}, lonWest={1}, latNorth={2}, lonEast={3})'.format(
+            self.latSouth, self.lonWest, self.latNorth, self.lonEast)
+
+
+def bounding_box_from_reduction(red):
+    """
+    BaseMapping.boundingBox decision logic (reference mapping.py:711-741) on the 8 numbers of the
+    device reduction [lat_min, lat_max, lon_min, lon_max, lon_min_positive, lon_max_nonpositive,
+    n_valid, n_pole_quads].
+    """
+    lat_min, lat_max, lon_min, lon_max, lon_pos, lon_neg, n_valid, n_pole = [float(v) for v in red]
+    if n_valid == 0:
+        raise ValueError('The mapping has no valid pixels')
+    if n_pole > 0:
+        lonWest, lonEast = -180, 180
+        if lat_max < 0:
+            latSouth, latNorth = -90, lat_max
+        else:
+            latNorth, latSouth = 90, lat_min
+    else:
+        if lon_max - lon_min > 180:      # mappings are assumed smaller than 180 deg of longitude
+            lonWest, lonEast = lon_pos, lon_neg
+        else:
+            lonWest, lonEast = lon_min, lon_max
+        latNorth, latSouth = lat_max, lat_min
+    return BoundingBox(latSouth, lonWest, latNorth, lonEast)
+
+
+@add_metaclass(ABCMeta)
+class BaseMapping(object):
+    """
+    Base class for all mapping objects: a georeferenced image for a given altitude
+    (reference mapping.py:293-929).  The guarantees of the reference hold:
+
+    - lats[y,x] masked <=> lons[y,x] masked; latsCenter[y,x] masked <=> lonsCenter[y,x] masked.
+    - lats[y,x] not masked => at least one adjacent centre not masked.
+    - latsCenter[y,x] not masked => its four corners not masked.
+    - img[y,x] / elevation[y,x] masked <=> latsCenter[y,x] masked.
+    """
+
+    def __init__(self, altitude, cameraPosGCRS, photoTime, identifier, metadata=None):
+        assert altitude >= 0
+        cameraPosGCRS = np.asarray(cameraPosGCRS)
+        assert cameraPosGCRS.shape == (3,)
+        self._altitude = altitude
+        self._cameraPosGCRS = cameraPosGCRS
+        self._photoTime = photoTime
+        self._identifier = identifier
+        self._metadata = metadata
+        self._host = {}            # cache of host (NumPy masked) views
+        self._boundingBox = None
+
+    # -- device state ------------------------------------------------------------------------
+    @abstractmethod
+    def frame(self):
+        """The device-resident :class:`FrameData` of this mapping (computed / uploaded on first use)."""
+
+    def _cached(self, key, make):
+        if key not in self._host:
+            self._host[key] = make()
+        return self._host[key]
+
+    def _corner_array(self, name):
+        fd = self.frame()
+        return self._cached(name, lambda: ma.masked_array(fd.host(name), mask=fd.host_mask('corner')))
+
+    def _center_array(self, name):
+        fd = self.frame()
+        return self._cached(name, lambda: ma.masked_array(fd.host(name), mask=fd.host_mask('center')))
+
+    # -- simple attributes -------------------------------------------------------------------
+    altitude = property(lambda self: self._altitude, doc='Mapping altitude in km.')
+    cameraPosGCRS = property(lambda self: self._cameraPosGCRS)
+    photoTime = property(lambda self: self._photoTime)
+    identifier = property(lambda self: self._identifier)
+
+    @property
+    def metadata(self):
+        return {} if self._metadata is None else self._metadata
+
+    @property
+    def cameraFootpoint(self):
+        """The camera footpoint in geodetic coordinates (:class:`Location`)."""
+        lat, lon = self._cached('footpoint', lambda: j2000ToLatLon([self.cameraPosGCRS], self.photoTime))
+        return Location(lat[0], lon[0])
+
+    @property
+    def properties(self):
+        return MappingProperties(identifier=self.identifier, altitude=self.altitude,
+                                 cameraPosGCRS=self.cameraPosGCRS, boundingBox=self.boundingBox,
+                                 photoTime=self.photoTime, centroid=self.centroid,
+                                 cameraFootpoint=self.cameraFootpoint)
+
+    # -- coordinate arrays (NumPy masked views) ------------------------------------------------
+    @property
+    def lats(self):
+        """Masked array (h+1, w+1): latitude of every pixel corner, degrees."""
+        return self._corner_array('lat')
+
+    @property
+    def lons(self):
+        """Masked array (h+1, w+1): longitude of every pixel corner, degrees."""
+        return self._corner_array('lon')
+
+    @property
+    def latsCenter(self):
+        """Masked array (h, w): latitude of every pixel centre."""
+        return self._center_array('lat_c')
+
+    @property
+    def lonsCenter(self):
+        """Masked array (h, w): longitude of every pixel centre."""
+        return self._center_array('lon_c')
+
+    @property
+    def elevation(self):
+        """Masked array (h, w): elevation in degrees for each pixel centre (or None)."""
+        fd = self.frame()
+        if fd.elev is None:
+            return None
+
+        def make():
+            elev = fd.host('elev')
+            return ma.masked_array(elev, mask=fd.host_mask('center') | np.isnan(elev))
+        return self._cached('elev', make)
+
+    @property
+    def img_unmasked(self):
+        """Like img but as a normal numpy array."""
+        return self._cached('img_unmasked', lambda: self.frame().host_image())
+
+    @property
+    def img(self):
+        """Masked array of shape (h,w,n) and type uint8/uint16."""
+        def make():
+            data = self.img_unmasked
+            mask = self.frame().host_mask('center')
+            return ma.masked_array(data, mask=np.repeat(mask[:, :, None], data.shape[2], 2))
+        return self._cached('img', make)
+
+    @property
+    def rgb_unmasked(self):
+        """(h,w,3) uint8 RGB representation of img (reference DefaultRGBMixin, mapping.py:980-1007)."""
+        src = self.img_unmasked
+        if src.dtype == np.uint8:
+            img = src
+        elif src.dtype == np.uint16:
+            img = (src * (255 / 65535)).astype(np.uint8)
+        else:
+            raise NotImplementedError
+        if img.shape[2] == 3:
+            return img
+        elif img.shape[2] == 1:
+            return np.repeat(img, 3, 2)
+        raise NotImplementedError('Unknown img format')
+
+    @property
+    def rgb(self):
+        rgbm = self.rgb_unmasked
+        mask = self.frame().host_mask('center')
+        return ma.masked_array(rgbm, mask=np.repeat(mask[:, :, None], rgbm.shape[2], 2))
+
+    # -- geomagnetic coordinates -----------------------------------------------------------------
+    def _mlatmlt_tensors(self, center):
+        """
+        Generic path (reference mapping.py:540-550): geodetic lat/lon at the mapping altitude ->
+        ECEF -> SM -> MLat/MLT, one kernel (amt_latlon_to_mlat_mlt).
+        """
+        fd = self.frame()
+        names = ('mlat_c', 'mlt_c', 'lat_c', 'lon_c') if center else ('mlat', 'mlt', 'lat', 'lon')
+        if getattr(fd, names[0]) is None:
+            lat, lon = getattr(fd, names[2]), getattr(fd, names[3])
+            mlat, mlt = fd.ctx.empty(lat.shape), fd.ctx.empty(lat.shape)
+            fd.ctx.call('amt_latlon_to_mlat_mlt', host9(mat_geo_to_sm(date2es(self.photoTime))), ptr(lat), ptr(lon),
+                        float(self.altitude), lat.numel(), wgs84A, wgs84B, ptr(mlat), ptr(mlt))
+            setattr(fd, names[0], mlat)
+            setattr(fd, names[1], mlt)
+        return getattr(fd, names[0]), getattr(fd, names[1])
+
+    @property
+    def mLatMlt(self):
+        """Tuple (mlat, mlt) of masked arrays (h+1, w+1) for the pixel corners: degrees / hours."""
+        def make():
+            mlat, mlt = self._mlatmlt_tensors(False)
+            mask = self.frame().host_mask('corner')
+            return ma.masked_array(to_host(mlat), mask), ma.masked_array(to_host(mlt), mask)
+        return self._cached('mlatmlt', make)
+
+    @property
+    def mLatMltCenter(self):
+        """Tuple (mlat, mlt) of masked arrays (h, w) for the pixel centres."""
+        def make():
+            mlat, mlt = self._mlatmlt_tensors(True)
+            mask = self.frame().host_mask('center')
+            return ma.masked_array(to_host(mlat), mask), ma.masked_array(to_host(mlt), mask)
+        return self._cached('mlatmlt_c', make)
+
+    # -- plate carree ------------------------------------------------------------------------------
+    @property
+    def isPlateCarree(self):
+        return isPlateCarree(self.lats, self.lons)
+
+    def checkPlateCarree(self):
+        return checkPlateCarree(self.lats, self.lons)
+
+    # -- bounding box (device reduction) -----------------------------------------------------------
+    def _bbox_reduction(self):
+        fd = self.frame()
+        if fd.bbox is None:
+            bbox = fd.ctx.empty((8,))
+            fd.ctx.call('amt_bbox_corners', ptr(fd.lat), ptr(fd.lon), ptr(fd.corner_mask_tensor()),
+                        ptr(fd.center_mask_tensor()), fd.height, fd.width, ptr(bbox))
+            fd.bbox = bbox
+        return fd.host_bbox()
+
+    @property
+    def boundingBox(self):
+        """
+        Smallest lat/lon box around the unmasked corners (reference mapping.py:693-743).  The
+        reference traces the mask outline on the host and asks geographiclib whether it encloses a
+        pole; here one device pass reduces the corner extremes and counts pixels whose corner quad
+        winds around a pole.  In case containsPole is True the box spans the full longitude range.
+        """
+        if self._boundingBox is None:
+            self._boundingBox = bounding_box_from_reduction(self._bbox_reduction())
+        return self._boundingBox
+
+    @property
+    def containsDiscontinuity(self):
+        return self.boundingBox.containsDiscontinuity
+
+    @property
+    def containsPole(self):
+        return self.boundingBox.containsPole
+
+    @property
+    def outline(self):
+        """
+        Coordinates of all unmasked corners as an (n,2) [lat,lon] array.  The reference returns the
+        traced contour (mapping.py:655-680); every consumer on the resampling path only takes
+        min/max of it, for which the full corner set is equivalent.
+        """
+        lats, lons = self.lats, self.lons
+        return np.transpose([lats.compressed(), lons.compressed()])
+
+    @property
+    def centroid(self):
+        """Mean position of the unmasked corners (the reference uses the outline polygon's centroid)."""
+        if self.containsPole:
+            raise NotImplementedError
+        lats, lons = self.lats.compressed(), self.lons.compressed()
+        if self.containsDiscontinuity:
+            return Location(lats.mean(), wrap_at_180(wrap_at_180(lons + 180).mean() + 180))
+        return Location(lats.mean(), lons.mean())
+
+    # -- masking -----------------------------------------------------------------------------------
+    def maskedByElevation(self, minElevation=10):
+        """
+        Return a new mapping with data masked below the given minimum elevation
+        (reference mapping.py:845-864 + the lazy sanitisation of mapping.py:1063-1125,1161-1213).
+        The new mapping shares the device arrays and only gets new masks.
+
+        :param minElevation: 0 to 90, in degrees
+        :raises ValueError: if every pixel would be masked
+        """
+        import torch
+        fd = self.frame()
+        assert fd.elev is not None
+        ctx = fd.ctx
+        center = ctx.empty((fd.height, fd.width), torch.uint8)
+        corner = ctx.empty((fd.height + 1, fd.width + 1), torch.uint8)
+        n_valid = ctx.zeros((1,), torch.int64)
+        if fd.center_mask is None and fd.corner_mask is None:
+            ctx.call('amt_mask_by_elevation', ptr(fd.elev), ptr(fd.lat), fd.height, fd.width, float(minElevation),
+                     ptr(center), ptr(corner), ptr(n_valid))
+            count = int(n_valid.item())
+        else:
+            # keep what is already masked: centre |= previous centre mask, then the corner rule
+            ctx.call('amt_mask_by_elevation', ptr(fd.elev), None, fd.height, fd.width, float(minElevation),
+                     ptr(center), None, None)
+            corner.copy_(fd.corner_mask_tensor())
+            ctx.call('amt_sanitize_masks', ptr(corner), ptr(center), ptr(fd.center_mask_tensor()), fd.height,
+                     fd.width, 1)
+            count = int((center == 0).sum().item())
+        if count == 0:
+            raise ValueError('minElevation=' + str(minElevation) + ' would mask all pixels!')
+        return self.createMasked(center, _corner_mask=corner)
+
+    def createMasked(self, centerMask, _corner_mask=None):
+        """
+        Return a copy of this mapping with the given centre mask applied (True/1 = masked) to img,
+        latsCenter, lonsCenter and elevation; corners without any unmasked neighbour centre get
+        masked as well (reference mapping.py:616-653,1161-1213).
+        """
+        import torch
+        fd = self.frame()
+        new = fd.shallow_copy()
+        if isinstance(centerMask, torch.Tensor):
+            center = centerMask.to(torch.uint8)
+        else:
+            center = fd.ctx.to_device(np.asarray(centerMask, dtype=np.uint8), np.uint8)
+        assert tuple(center.shape) == (fd.height, fd.width)
+        if _corner_mask is None:
+            _corner_mask = fd.corner_mask_tensor().clone()
+            fd.ctx.call('amt_sanitize_masks', ptr(_corner_mask), ptr(center), None, fd.height, fd.width, 1)
+        new.center_mask, new.corner_mask, new.bbox = center, _corner_mask, None
+        m = copy.copy(self)
+        m._frame = new
+        m.setDirty()
+        return m
+
+    def setDirty(self):
+        """Forget every cached host view and derived attribute."""
+        self._host = {}
+        self._boundingBox = None
+
+    # -- testing aid ---------------------------------------------------------------------------------
+    def checkGuarantees(self):
+        """Checks the mask guarantees listed in the class docstring (reference mapping.py:362-428)."""
+        lats, lons = self.lats, self.lons
+        latsCenter, lonsCenter = self.latsCenter, self.lonsCenter
+        mlat, mlt = self.mLatMlt
+        mlatCenter, mltCenter = self.mLatMltCenter
+        img, elevation = self.img, self.elevation
+        assert not np.any(np.isnan(lats.compressed()))
+        assert not np.any(np.isnan(latsCenter.compressed()))
+        assert not np.any(np.isnan(mlat.compressed()))
+        assert not np.any(np.isnan(elevation.compressed()))
+        gm = ma.getmaskarray
+        assert np.array_equal(gm(lats), gm(lons))
+        assert np.array_equal(gm(latsCenter), gm(lonsCenter))
+        ok = np.zeros((latsCenter.shape[0] + 2, latsCenter.shape[1] + 2), bool)
+        ok[1:-1, 1:-1] = ~gm(latsCenter)
+        assert np.all(np.logical_or.reduce((gm(lats), ok[1:, 1:], ok[1:, :-1], ok[:-1, :-1], ok[:-1, 1:])))
+        cok = ~gm(lats)
+        assert np.all(np.logical_or(gm(latsCenter), np.logical_and.reduce(
+            (cok[:-1, :-1], cok[1:, :-1], cok[1:, 1:], cok[:-1, 1:]))))
+        center_ok = ~gm(latsCenter)
+        for d in range(img.shape[2]):
+            assert np.all(np.logical_xor(gm(img)[:, :, d], center_ok))
+        assert np.all(np.logical_xor(gm(elevation), center_ok))
+        assert np.all(np.logical_xor(gm(mlatCenter), center_ok))
+        assert np.all(np.logical_xor(gm(mltCenter), center_ok))
+        assert np.all(np.logical_xor(gm(mlat), cok))
+        assert np.all(np.logical_xor(gm(mlt), cok))
+
+    @abstractmethod
+    def createResampled(self, lats, lons, latsCenter, lonsCenter, elevation, img):
+        """Returns a new mapping object of the appropriate class for resampled data."""
+
+
+def checkPlateCarree(lats, lons):
+    """
+    Checks whether the given 2D coordinate arrays describe a plate carree projection: latitudes
+    (longitudes) evenly spaced and monotonically decreasing (increasing) (reference mapping.py:931-965).
+
+    :raise ValueError: when the projection is not plate carree
+    """
+    if ma.isMaskedArray(lats):
+        lats, lons = lats.data, lons.data
+    if np.any(np.isnan(lats)):
+        raise ValueError('coordinates contains NaNs')
+    lons = np.unwrap(np.deg2rad(lons))
+    if lons[0, -1] - lons[0, 0] <= 0:
+        raise ValueError('longitudes are not monotonically increasing')
+    if lats[0, 0] - lats[-1, 0] <= 0:
+        raise ValueError('latitudes are not monotonically decreasing')
+    eps = 1e-4
+    deltaLon = lons[0, 1:] - lons[0, :-1]
+    if not np.max(deltaLon) - np.min(deltaLon) < eps:
+        raise ValueError('longitudes are not evenly spaced; max delta: {}'.format(np.max(deltaLon) - np.min(deltaLon)))
+    deltaLat = lats[:-1, 0] - lats[1:, 0]
+    if not np.max(deltaLat) - np.min(deltaLat) < eps:
+        raise ValueError('latitudes are not evenly spaced; max delta: {}'.format(np.max(deltaLat) - np.min(deltaLat)))
+
+
+def isPlateCarree(lats, lons):
+    try:
+        checkPlateCarree(lats, lons)
+    except Exception:
+        return False
+    return True
+
+
+class GenericMapping(BaseMapping):
+    """
+    A mapping consisting of precalculated latitudes/longitudes/elevation values
+    (reference mapping.py:1233-1313, including the lazy sanitisation of its ``sanitize_data``
+    decorator, mapping.py:1063-1231, which runs as mask stencils on the device).
+    """
+
+    def __init__(self, lats, lons, latsCenter, lonsCenter, elev, alti, img, cameraPosGCRS, photoTime,
+                 identifier, metadata=None):
+        """
+        :param ndarray lats, lons: (h+1,w+1) in degrees (NaN or masked = missing)
+        :param ndarray latsCenter, lonsCenter: (h,w) in degrees
+        :param ndarray elev: (h,w) in degrees; can also be None
+        :param number alti: the altitude in km onto which the image was mapped (e.g. 110)
+        :param ndarray img: uint8 or uint16 array of shape (h,w) for grayscale or (h,w,3) for RGB
+        :param array-like cameraPosGCRS: [x,y,z] in km
+        :param datetime.datetime photoTime:
+        """
+        h, w = img.shape[0], img.shape[1]
+        assert lats.shape == lons.shape == (h + 1, w + 1)
+        assert latsCenter.shape == lonsCenter.shape == (h, w)
+        assert elev is None or elev.shape == (h, w)
+        if img.ndim == 2:
+            img = img[:, :, None]
+        assert img.ndim == 3
+        assert img.dtype in [np.uint8, np.uint16]
+        BaseMapping.__init__(self, alti, cameraPosGCRS, photoTime, identifier, metadata)
+        self._inputs = (lats, lons, latsCenter, lonsCenter, elev, img)
+        self._frame = None
+
+    def frame(self):
+        if self._frame is None:
+            lats, lons, latsCenter, lonsCenter, elev, img = self._inputs
+            filled = [np.asarray(ma.filled(a.astype(np.float64), np.nan)) if ma.isMA(a)
+                      else np.asarray(a, dtype=np.float64) for a in (lats, lons, latsCenter, lonsCenter)]
+            corner_mask = np.isnan(filled[0]) | np.isnan(filled[1])
+            center_mask = np.isnan(filled[2]) | np.isnan(filled[3])
+            img_mask = ma.getmaskarray(img)[:, :, 0] if ma.isMA(img) else None
+            e = None
+            if elev is not None:
+                e = np.asarray(ma.filled(elev.astype(np.float64), np.nan)) if ma.isMA(elev) \
+                    else np.asarray(elev, dtype=np.float64)
+            fd = FrameData.from_host(filled[0], filled[1], filled[2], filled[3], e, ma.getdata(img),
+                                     corner_mask=corner_mask, center_mask=center_mask)
+            img_mask_t = None if img_mask is None else fd.ctx.to_device(img_mask.astype(np.uint8), np.uint8)
+            # sanitize_data (mapping.py:1063-1125): image mask -> centres, corner/centre consistency
+            fd.ctx.call('amt_sanitize_masks', ptr(fd.corner_mask), ptr(fd.center_mask), ptr(img_mask_t),
+                        fd.height, fd.width, 0)
+            self._frame = fd
+            self._inputs = None
+        return self._frame
+
+    def createResampled(self, lats, lons, latsCenter, lonsCenter, elevation, img):
+        return GenericMapping(lats, lons, latsCenter, lonsCenter, elevation, self.altitude, img,
+                              self.cameraPosGCRS, self.photoTime, self.identifier, metadata=self.metadata)
+
+    @staticmethod
+    def fromMapping(mapping):
+        """Create a :class:`GenericMapping` sharing the device arrays of the given mapping."""
+        m = GenericMapping.__new__(GenericMapping)
+        BaseMapping.__init__(m, mapping.altitude, mapping.cameraPosGCRS, mapping.photoTime, mapping.identifier,
+                             mapping.metadata)
+        m._inputs = None
+        m._frame = mapping.frame()
+        return m
+
+
+class MappingCollection(object):
+    def __init__(self, mappings, identifier, mayOverlap=True):
+        """
+        A collection of mappings for the same photo time (+- a few seconds) (reference mapping.py:1315-1373).
+        """
+        self._mappings = mappings
+        self._identifier = identifier
+        self._mayOverlap = mayOverlap
+
+    identifier = property(lambda self: self._identifier)
+    mappings = property(lambda self: self._mappings)
+    mayOverlap = property(lambda self: self._mayOverlap)
+    empty = property(lambda self: len(self.mappings) == 0)
+
+    def maskedByElevation(self, minElevation=10):
+        return MappingCollection([m.maskedByElevation(minElevation) for m in self.mappings],
+                                 self.identifier, self.mayOverlap)
+
+    @property
+    def boundingBox(self):
+        return BoundingBox.mergedBoundingBoxes([m.boundingBox for m in self.mappings])
+
+    @property
+    def photoTime(self):
+        times = sorted(m.photoTime for m in self.mappings)
+        return times[len(times) // 2]
+
+    def __len__(self):
+        return len(self._mappings)
+
+
+def MaskByElevationProvider(provider, *args, **kw):
+    """Wrap the given mapping provider by masking every returned mapping by elevation (mapping.py:1447-1472)."""
+    def mask(m):
+        return m.maskedByElevation(*args, **kw)
+
+    class MaskingProvider(provider.__class__):
+        def get(self, *a, **k):
+            return mask(super(MaskingProvider, self).get(*a, **k))
+
+        def getById(self, *a, **k):
+            return mask(super(MaskingProvider, self).getById(*a, **k))
+
+        def getSequence(self, *a, **k):
+            return map(mask, super(MaskingProvider, self).getSequence(*a, **k))
+
+    wrapped = copy.copy(provider)
+    wrapped.__class__ = MaskingProvider
+    return wrapped
+
+
+def inflatedEarthIntersection(cameraToPixelDirection, cameraPos, earthInflation=110, earthModel='wgs84'):
+    """
+    Return the intersection points with an inflated earth when shooting rays originating at
+    `cameraPos` and going in the direction `cameraToPixelDirection` (reference mapping.py:1474-1510).
+
+    :param cameraToPixelDirection: direction vectors from camera to pixel/sky location, shape (n,3)
+    :param cameraPos: xyz J2000 coordinates in km
+    :param earthInflation: in km, how much to expand the earth when intersecting
+    :param earthModel: 'wgs84' (ellipsoid a+h, b+h) or 'sphere' (R_earth + h)
+    """
+    shape = cameraToPixelDirection.shape
+    assert (len(shape) == 1 and shape[0] == 3) or (len(shape) == 2 and shape[1] == 3)
+    if earthModel == 'wgs84':
+        return ellipsoidLineIntersection(wgs84A + earthInflation, wgs84B + earthInflation, cameraPos,
+                                         cameraToPixelDirection)
+    elif earthModel == 'sphere':
+        return sphereLineIntersection(R_EARTH_KM + earthInflation, cameraPos, cameraToPixelDirection)
+    raise ValueError('unsupported earth model: ' + earthModel)
+
+
+class _SMMapping(GenericMapping):
+    @property
+    def cameraFootpoint(self):
+        mlat, mlt = j2000ToMLatMLT([self.cameraPosGCRS], self.photoTime)
+        return Location(mlat[0], mltToSmLon(mlt)[0])
+
+
+def convertMappingToSM(mapping):
+    """
+    Return a new mapping with the coordinates transformed to solar magnetic latitudes and
+    longitudes (reference mapping.py:1519-1547).  Device arrays are re-used; nothing is copied to the host.
+    """
+    fd = mapping.frame()
+    mlat, mlt = mapping._mlatmlt_tensors(False)
+    mlat_c, mlt_c = mapping._mlatmlt_tensors(True)
+    new = fd.shallow_copy()
+    new.lat, new.lat_c = mlat, mlat_c
+    new.lon = (mlt - 12) / (24 / 360)          # mltToSmLon (transform.py:388-401)
+    new.lon_c = (mlt_c - 12) / (24 / 360)
+    new.mlat = new.mlt = new.mlat_c = new.mlt_c = None
+    new.bbox = None
+    # masks follow the geodetic masks (astrometry.py:181-182, mapping.py:1540-1546)
+    new.corner_mask = fd.corner_mask_tensor()
+    new.center_mask = fd.center_mask_tensor()
+    sm = _SMMapping.__new__(_SMMapping)
+    BaseMapping.__init__(sm, mapping.altitude, mapping.cameraPosGCRS, mapping.photoTime, mapping.identifier)
+    sm._inputs = None
+    sm._frame = new
+    return sm
+
+
+def convertSMMappingToGeo(mapping):
+    """Inverse operation to :func:`convertMappingToSM` (reference mapping.py:1549-1559)."""
+    smlats, smlons = mapping.lats.data, mapping.lons.data
+    smlatsCenter, smlonsCenter = mapping.latsCenter.data, mapping.lonsCenter.data
+    lats, lons = smToLatLon(smlats, smlons, mapping.photoTime)
+    latsCenter, lonsCenter = smToLatLon(smlatsCenter, smlonsCenter, mapping.photoTime)
+    return GenericMapping(lats, lons, latsCenter, lonsCenter, mapping.elevation, mapping.altitude,
+                          mapping.img, mapping.cameraPosGCRS, mapping.photoTime, mapping.identifier)

@@ -1,0 +1,332 @@
+"""
+Resampling of mappings onto a regular latitude/longitude grid (plate carree), relative to either
+geodetic or MLat/MLT coordinates — mirror of the reference's auromat/resample.py for the
+``method='mean'`` binning.
+
+Host side: the grid definition (global alignment, pole / discontinuity handling, bin edges —
+a few hundred scalars per frame, reference resample.py:159-299).  Device side: bin assignment with
+the reference's ``searchsorted(..., 'right')`` edge semantics, accumulation and mean
+(``amt_bin_frame`` / ``amt_hist2d_accumulate``), reference resample.py:301-351 and
+util/histogram.py:57-282.  Pixel data never leaves the GPU; only the small output grid does.
+"""
+from __future__ import division, print_function
+
+import copy
+import ctypes as C
+from functools import partial
+
+import numpy as np
+import numpy.ma as ma
+
+from .coordinates.transform import rotation_matrix
+from .coordinates.geodesic import wgs84A, wgs84B
+from .mapping.mapping import (BaseMapping, BoundingBox, MappingCollection, bounding_box_from_reduction,
+                              convertMappingToSM, convertSMMappingToGeo, wrap_at_180)
+from .util.histogram import make_axis
+from ._native import Context, host9, ptr, to_host
+
+
+def plateCarreeResolution(boundingBox, arcsecPerPx):
+    """
+    Approximates the latitude and longitude resolution of a plate carree projection from a
+    spherical resolution (reference resample.py:36-61).  The longitude part needs the geodesic
+    arc length between the box's mid-latitude end points, which the reference takes from
+    geographiclib; here it is the great-circle angle on the auxiliary sphere of the WGS84
+    ellipsoid (reduced latitude), which is what geographiclib's ``a12`` is for two points on one
+    parallel up to the ellipsoidal correction of the geodesic (< 0.3 %).
+
+    :rtype: tuple (latPxPerDeg, lonPxPerDeg)
+    """
+    degPerPx = arcsecPerPx / 3600.0
+    latPxPerDeg = 1 / degPerPx
+    latMiddle = (boundingBox.latNorth + boundingBox.latSouth) / 2
+    lonEast = boundingBox.lonEast
+    lons = lonEast + 360 - boundingBox.lonWest if boundingBox.lonWest > lonEast else lonEast - boundingBox.lonWest
+    f = 1 - wgs84B / wgs84A
+    beta = np.arctan((1 - f) * np.tan(np.deg2rad(latMiddle)))          # reduced latitude
+    dlon = np.deg2rad(min(lons, 360 - lons))
+    sigma = 2 * np.arcsin(np.cos(beta) * np.sin(dlon / 2))             # same-parallel great-circle angle
+    px = np.rad2deg(sigma) / degPerPx
+    return latPxPerDeg, px / lons
+
+
+def resampleMLatMLT(mapping, **kw):
+    """Resamples a mapping such that MLat/MLT become regular grids (reference resample.py:63-71).
+
+    See :func:`resample` for parameters.
+    """
+    sm = convertMappingToSM(mapping)
+    smResampled = resample(sm, **kw)
+    return convertSMMappingToGeo(smResampled)
+
+
+def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=None, method='mean'):
+    """
+    Returns a new mapping (or collection) where the colors and elevation are resampled into a
+    regular latitude/longitude grid (plate carree projection) with y=latitude and x=longitude
+    (reference resample.py:73-157).
+
+    With 'mean' binning, holes appear at low elevation angles when the resampling resolution is
+    high, because binning does not interpolate empty bins; mask the mapping by elevation
+    (e.g. 10deg) first.
+
+    :param mappingOrCollection:
+    :param None|number|tuple pxPerDeg: tuple (latPxPerDeg, lonPxPerDeg) or a number if both are the same
+    :param None|number arcsecPerPx: spherical resolution, used to approximate pxPerDeg; has precedence
+    :param None|bool containsPole: specify True|False to skip the pole check
+    :param method: binning: 'mean'.  The reference's interpolating methods ('nearest', 'linear',
+                   'cubic', scipy griddata) are not implemented.
+    :rtype: a subclass of BaseMapping or MappingCollection
+    """
+    if method != 'mean':
+        raise NotImplementedError("only method='mean' is implemented")
+
+    def doResample(mapping, pxPerDeg, arcsecPerPx, containsPole):
+        if containsPole is None:
+            containsPole = mapping.containsPole
+        if arcsecPerPx:
+            pxPerDeg = plateCarreeResolution(mapping.boundingBox, arcsecPerPx)
+        else:
+            try:
+                _, _ = pxPerDeg
+            except TypeError:
+                assert pxPerDeg is not None
+                pxPerDeg = (pxPerDeg, pxPerDeg)
+        res = resample_frame(mapping.frame(), mapping.altitude, mapping.boundingBox, pxPerDeg,
+                             mapping.containsDiscontinuity, containsPole)
+        img = ma.masked_array(res['img'], mask=np.repeat(res['mask'][:, :, None], res['img'].shape[2], 2))
+        elevation = ma.masked_invalid(res['mean'][:, :, -1], copy=False) if res['has_elev'] else None
+        return mapping.createResampled(res['lat'], res['lon'], res['lat_c'], res['lon_c'], elevation, img)
+
+    if isinstance(mappingOrCollection, BaseMapping):
+        return doResample(mappingOrCollection, pxPerDeg, arcsecPerPx, containsPole)
+    elif isinstance(mappingOrCollection, MappingCollection):
+        mappings = [doResample(m, pxPerDeg, arcsecPerPx, containsPole) for m in mappingOrCollection.mappings]
+        # (the reference forgets the identifier here and raises TypeError, resample.py:151)
+        return MappingCollection(mappings, mappingOrCollection.identifier,
+                                 mayOverlap=mappingOrCollection.mayOverlap)
+    raise ValueError('First argument must be a mapping or a mapping collection, but is: {}'.
+                     format(type(mappingOrCollection)))
+
+
+def fixedGrid(pxPerDeg, latMin, latMax, lonMin, lonMax):
+    """
+    Aligns the given bounding box to a fixed plate carree grid as defined by `pxPerDeg`
+    (reference resample.py:281-299).
+
+    :param lonMin,lonMax: must NOT contain the discontinuity
+    """
+    latPxPerDeg, lonPxPerDeg = pxPerDeg
+    latSpaceAll = np.linspace(-90, 90, int(round(latPxPerDeg * 180 + 1)))
+    lonSpaceAll = np.linspace(-180, 180, int(round(lonPxPerDeg * 360 + 1)))
+    latMinInGrid = latSpaceAll[np.argmax(latSpaceAll > latMin) - 1]
+    latMaxInGrid = latSpaceAll[np.argmax(latSpaceAll >= latMax)]
+    lonMinInGrid = lonSpaceAll[np.argmax(lonSpaceAll > lonMin) - 1]
+    lonMaxInGrid = lonSpaceAll[np.argmax(lonSpaceAll >= lonMax)]
+    nLat = int(round(latPxPerDeg * (latMaxInGrid - latMinInGrid) + 1))
+    nLon = int(round(lonPxPerDeg * (lonMaxInGrid - lonMinInGrid) + 1))
+    return nLat, nLon, latMinInGrid, latMaxInGrid, lonMinInGrid, lonMaxInGrid
+
+
+class _Grid(object):
+    """Output grid of one resampling (reference resample.py:220-241,330-334)."""
+
+    def __init__(self, pxPerDeg, latMin, latMax, lonMin, lonMax):
+        latPxPerDeg, lonPxPerDeg = pxPerDeg
+        assert latPxPerDeg > 0 and lonPxPerDeg > 0
+        nLat, nLon, latLo, latHi, lonLo, lonHi = fixedGrid(pxPerDeg, latMin, latMax, lonMin, lonMax)
+        assert nLat > 1, 'nlat={}, latMax={}, latMin={}, pxperdeg={}'.format(nLat, latHi, latLo, pxPerDeg)
+        assert nLon > 1, 'nlon={}, lonMax={}, lonMin={}, pxperdeg={}'.format(nLon, lonHi, lonLo, pxPerDeg)
+        latSpaceCenter, latStep = np.linspace(latHi, latLo, num=nLat, retstep=True)
+        lonSpaceCenter, lonStep = np.linspace(lonLo, lonHi, num=nLon, retstep=True)
+        # first and last centre are dropped so that no corner lies outside the determined range
+        latSpace = latSpaceCenter[:-1] + latStep / 2
+        lonSpace = lonSpaceCenter[:-1] + lonStep / 2
+        self.latCenters = latSpaceCenter[1:-1]
+        self.lonCenters = lonSpaceCenter[1:-1]
+        self.latStep, self.lonStep = latStep, lonStep
+        self.lat, self.lon = np.dstack(np.meshgrid(latSpace, lonSpace)).T
+        self.lat_c, self.lon_c = np.dstack(np.meshgrid(self.latCenters, self.lonCenters)).T
+        self.nx, self.ny = len(self.lonCenters), len(self.latCenters)
+        # histogram ranges; latitude edges ascend, the output is flipped afterwards
+        self.xrange = [self.lonCenters[0] - lonStep / 2, self.lonCenters[-1] + lonStep / 2]
+        self.yrange = [self.latCenters[-1] + latStep / 2, self.latCenters[0] - latStep / 2]
+        self.xedges = np.linspace(self.xrange[0], self.xrange[1], self.nx + 1)
+        self.yedges = np.linspace(self.yrange[0], self.yrange[1], self.ny + 1)
+
+
+def _rot_x(angle):
+    return rotation_matrix(np.deg2rad(angle), [1, 0, 0])[:3, :3]
+
+
+def _rotate_pole_dev(ctx, lat_deg, lon_deg, altitude, angle):
+    """rotatePole (reference transform.py:301-322) on device tensors in degrees."""
+    import torch
+    la, lo = torch.deg2rad(lat_deg).reshape(-1), torch.deg2rad(lon_deg).reshape(-1)
+    ola, olo = ctx.empty(la.shape), ctx.empty(lo.shape)
+    ctx.call('amt_rotate_pole', host9(_rot_x(angle)), ptr(la), ptr(lo), float(altitude), la.numel(), wgs84A, wgs84B,
+             ptr(ola), ptr(olo))
+    return torch.rad2deg(ola).reshape(lat_deg.shape), torch.rad2deg(olo).reshape(lon_deg.shape)
+
+
+def _rotate_pole_host(lat_deg, lon_deg, altitude, angle):
+    ctx = Context.current()
+    la, lo = _rotate_pole_dev(ctx, ctx.to_device(np.ascontiguousarray(lat_deg)),
+                              ctx.to_device(np.ascontiguousarray(lon_deg)), altitude, angle)
+    return to_host(la), to_host(lo)
+
+
+def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=False, containsPole=False,
+                   min_elevation=None, keep_on_device=False):
+    """
+    ``_resample`` + ``_resampleCenterData(method='mean')`` + the image finalisation of ``resample``
+    (reference resample.py:119-136,159-279,301-351) on a device-resident frame.
+
+    :param FrameData fd: centre lat/lon, elevation (optional), image and masks in HBM
+    :param min_elevation: fuse ``maskedByElevation(min_elevation)`` into the binning pass (the frame's
+                          own centre mask is applied in addition)
+    :return: dict(lat, lon, lat_c, lon_c [grid coordinates, host], mean (ny,nx,C+1), img (ny,nx,C),
+                  mask (ny,nx), count (ny,nx), has_elev)
+    """
+    import torch
+    ctx = fd.ctx
+    latMin, latMax = boundingBox.latSouth, boundingBox.latNorth
+    lonMin, lonMax = boundingBox.lonWest, boundingBox.lonEast
+    lat_c, lon_c = fd.lat_c, fd.lon_c
+    lon_wrap = 0
+    if containsPole:
+        # rotate the pole out of the data by +90 deg about x (reference resample.py:176-201)
+        rla, rlo = _rotate_pole_dev(ctx, fd.lat, fd.lon, altitude, 90)
+        red = ctx.empty((8,))
+        ctx.call('amt_bbox_corners', ptr(rla), ptr(rlo), ptr(fd.corner_mask_tensor()), ptr(fd.center_mask_tensor()),
+                 fd.height, fd.width, ptr(red))
+        r = to_host(red)
+        latMin, latMax, lonMin, lonMax = r[0], r[1], r[2], r[3]
+        lat_c, lon_c = _rotate_pole_dev(ctx, fd.lat_c, fd.lon_c, altitude, 90)
+    elif containsDiscontinuity:
+        # rotate longitudes out of the 180 deg discontinuity (reference resample.py:203-218); the outline's
+        # extremes are the box's west/east edge, and the wrap is monotonic on each side
+        lonMin, lonMax = wrap_at_180(lonMin + 180), wrap_at_180(lonMax + 180)
+        lon_wrap = 1
+
+    grid = _Grid(pxPerDeg, latMin, latMax, lonMin, lonMax)
+    xaxis, xkeep = make_axis(ctx, grid.xedges, uniform=True)
+    yaxis, ykeep = make_axis(ctx, grid.yedges, uniform=True)
+    nch = fd.nchan
+    acc = ctx.zeros((nch + 2, grid.nx * grid.ny), torch.int64)
+    min_el = float('-inf') if min_elevation is None else float(min_elevation)
+    ctx.call('amt_bin_frame', ptr(lat_c), ptr(lon_c), ptr(fd.elev), ptr(fd.img), fd.img_dtype_code, nch,
+             ptr(fd.center_mask), fd.height, fd.width, min_el, C.byref(xaxis), C.byref(yaxis), lon_wrap, ptr(acc))
+    mean = ctx.empty((grid.ny, grid.nx, nch + 1))
+    img = ctx.empty((grid.ny, grid.nx, max(nch, 1)), torch.uint8 if fd.img_dtype_code != 2 else torch.int16)
+    mask = ctx.empty((grid.ny, grid.nx), torch.uint8)
+    count = ctx.empty((grid.ny, grid.nx))
+    ctx.call('amt_bin_frame_finalize', ptr(acc), grid.nx, grid.ny, nch, fd.img_dtype_code or 1, ptr(mean),
+             ptr(img) if nch else None, ptr(mask), ptr(count))
+
+    lat, lon, lat_gc, lon_gc = grid.lat, grid.lon, grid.lat_c, grid.lon_c
+    if containsPole:
+        lat, lon = _rotate_pole_host(lat, lon, altitude, -90)            # reference resample.py:262-273
+        lat_gc, lon_gc = _rotate_pole_host(lat_gc, lon_gc, altitude, -90)
+    elif containsDiscontinuity:
+        lon = wrap_at_180(lon + 180)                                     # reference resample.py:274-277
+        lon_gc = wrap_at_180(lon_gc + 180)
+    out = dict(lat=lat, lon=lon, lat_c=lat_gc, lon_c=lon_gc, has_elev=fd.elev is not None, grid=grid)
+    if keep_on_device:
+        out.update(mean=mean, img=img, mask=mask, count=count)
+    else:
+        out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype if nch else np.uint8),
+                   mask=to_host(mask).astype(bool), count=to_host(count))
+    return out
+
+
+def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingBox, pxPerDeg,
+              containsDiscontinuity=False, containsPole=False, method='mean'):
+    """
+    Array-level resampling with the reference's signature (resample.py:159-279): every channel of
+    `data` (float, NaN = missing) is binned on its own.
+
+    :param latsCenter, lonsCenter: (h,w), NaN = not mapped
+    :param data: float data for each pixel center, (h,w,n) with n>0, or (h,w)
+    :param outlineLatLonFn: callable returning (n,2) [lat,lon] points whose min/max bound the data
+                            (only used in the pole / discontinuity branches)
+    :param pxPerDeg: tuple (latPxPerDeg, lonPxPerDeg)
+    :rtype: tuple (lat, lon, latCenter, lonCenter, data)
+    """
+    if method != 'mean':
+        raise NotImplementedError("only method='mean' is implemented")
+    ctx = Context.current()
+    latMin, latMax = boundingBox.latSouth, boundingBox.latNorth
+    lonMin, lonMax = boundingBox.lonWest, boundingBox.lonEast
+    lat_c = ctx.to_device(np.asarray(latsCenter, dtype=np.float64))
+    lon_c = ctx.to_device(np.asarray(lonsCenter, dtype=np.float64))
+    lon_wrap = 0
+    if containsPole:
+        outline = np.asarray(outlineLatLonFn(), dtype=np.float64)
+        ola, olo = _rotate_pole_host(outline[:, 0], outline[:, 1], altitude, 90)
+        latMin, latMax, lonMin, lonMax = np.min(ola), np.max(ola), np.min(olo), np.max(olo)
+        lat_c, lon_c = _rotate_pole_dev(ctx, lat_c, lon_c, altitude, 90)
+    elif containsDiscontinuity:
+        outlineLons = wrap_at_180(np.asarray(outlineLatLonFn(), dtype=np.float64)[:, 1] + 180)
+        lonMin, lonMax = np.min(outlineLons), np.max(outlineLons)
+        lon_wrap = 1
+    grid = _Grid(pxPerDeg, latMin, latMax, lonMin, lonMax)
+    scalar = np.ndim(data) == 2
+    d = np.asarray(data, dtype=np.float64)
+    if scalar:
+        d = d[..., None]
+    mean = _resampleCenterData(lat_c, lon_c, d, grid, lon_wrap)
+    lat, lon, lat_gc, lon_gc = grid.lat, grid.lon, grid.lat_c, grid.lon_c
+    if containsPole:
+        lat, lon = _rotate_pole_host(lat, lon, altitude, -90)
+        lat_gc, lon_gc = _rotate_pole_host(lat_gc, lon_gc, altitude, -90)
+    elif containsDiscontinuity:
+        lon = wrap_at_180(lon + 180)
+        lon_gc = wrap_at_180(lon_gc + 180)
+    if scalar:
+        mean = mean.reshape(mean.shape[0], mean.shape[1])
+    return lat, lon, lat_gc, lon_gc, mean
+
+
+def _resampleCenterData(lat_c, lon_c, centerData, grid, lon_wrap):
+    """Binned mean of float channels (reference resample.py:301-368, method='mean')."""
+    ctx = Context.current()
+    n = lat_c.numel()
+    nchan = centerData.shape[2]
+    assert nchan <= 8, 'at most 8 channels per call'
+    chans = [ctx.to_device(np.ascontiguousarray(centerData[:, :, k])) for k in range(nchan)]
+    xaxis, xkeep = make_axis(ctx, grid.xedges, uniform=True)
+    yaxis, ykeep = make_axis(ctx, grid.yedges, uniform=True)
+    count = ctx.zeros((grid.nx * grid.ny,))
+    sums = [ctx.zeros((grid.nx * grid.ny,)) for _ in range(nchan)]
+    wptr = (C.c_void_p * nchan)(*[t.data_ptr() for t in chans])
+    sptr = (C.c_void_p * nchan)(*[t.data_ptr() for t in sums])
+    # pixels without coordinates are outliers of the histogram (NaN latitude, resample.py:315-321)
+    ctx.call('amt_hist2d_accumulate', ptr(lon_c.reshape(-1)), ptr(lat_c.reshape(-1)), n, wptr, nchan,
+             C.byref(xaxis), C.byref(yaxis), lon_wrap, ptr(count), sptr)
+    mean = ctx.empty((grid.ny, grid.nx, nchan))
+    ctx.call('amt_hist2d_finalize_mean', ptr(count), sptr, nchan, grid.nx, grid.ny, ptr(mean))
+    return to_host(mean)
+
+
+def ResampleProvider(provider, **kw):
+    """
+    Wrap the given mapping provider by resampling every returned mapping (reference resample.py:370-394).
+
+    See :func:`resample` for parameters.
+    """
+    resampleFn = partial(resample, **kw)
+
+    class ResamplingProvider(provider.__class__):
+        def get(self, *a, **k):
+            return resampleFn(super(ResamplingProvider, self).get(*a, **k))
+
+        def getById(self, *a, **k):
+            return resampleFn(super(ResamplingProvider, self).getById(*a, **k))
+
+        def getSequence(self, *a, **k):
+            return map(resampleFn, super(ResamplingProvider, self).getSequence(*a, **k))
+
+    wrapped = copy.copy(provider)
+    wrapped.__class__ = ResamplingProvider
+    return wrapped

@@ -1,0 +1,263 @@
+/*
+ * auromat_hip.h — C ABI of libauromat_hip.so
+ *
+ * MI355X (gfx950) implementation of the per-pixel georeferencing + resampling
+ * hot path of esa/auromat.  The reference is pure Python with an import-time
+ * two-backend switch (`_np` / `_ne`, e.g. auromat/coordinates/intersection.py:160-163);
+ * this library is the third backend.  Each entry point names the reference
+ * function(s) it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative AMT_E* code otherwise and
+ *    never throws; amt_last_error() gives the message of the last failure on a context;
+ *  - all array arguments are DEVICE pointers (hipMalloc'ed / torch .data_ptr()),
+ *    C-contiguous, float64 unless stated; small fixed-size parameter blocks
+ *    (3-vectors, 3x3 matrices, amt_frame_params) are HOST pointers;
+ *  - kernels are enqueued on the context's stream and the call returns without
+ *    synchronising unless documented ("synchronises");
+ *  - the caller owns every buffer; the library keeps no global state and contexts
+ *    may be used from different threads (one thread per context at a time);
+ *  - missing data is NaN (reference convention: intersection.py:50-56), never an error.
+ */
+#ifndef AUROMAT_HIP_H
+#define AUROMAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMT_ABI_VERSION 1
+
+#define AMT_OK 0
+#define AMT_EINVAL (-1)   /* bad argument (NULL pointer, negative size, unsupported dtype ...) */
+#define AMT_EHIP (-2)     /* a HIP runtime call failed; see amt_last_error */
+#define AMT_ENOMEM (-3)
+#define AMT_EEMPTY (-4)   /* operation would leave no valid pixel (mapping.py:858-859 -> ValueError) */
+
+typedef struct amt_ctx amt_ctx;
+
+/* ---- context & memory --------------------------------------------------------------- */
+
+int amt_abi_version(void);
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = the
+   library creates and owns a non-blocking stream. */
+int amt_ctx_create(int device_id, void* stream, amt_ctx** out_ctx);
+int amt_ctx_destroy(amt_ctx* ctx);
+int amt_ctx_set_stream(amt_ctx* ctx, void* stream);
+void* amt_ctx_get_stream(amt_ctx* ctx);
+int amt_ctx_synchronize(amt_ctx* ctx);                 /* synchronises */
+const char* amt_last_error(amt_ctx* ctx);
+/* Device properties the host side prints next to roofline numbers. */
+int amt_device_info(amt_ctx* ctx, char* name, size_t name_len, int* compute_units, int* clock_khz,
+                    size_t* total_mem);
+
+/* Plain device-memory helpers so that a host without torch can drive the library. */
+int amt_malloc(amt_ctx* ctx, size_t bytes, void** out_dptr);
+int amt_free(amt_ctx* ctx, void* dptr);
+int amt_memcpy_h2d(amt_ctx* ctx, void* dst, const void* src, size_t bytes);   /* async on the stream */
+int amt_memcpy_d2h(amt_ctx* ctx, void* dst, const void* src, size_t bytes);   /* synchronises */
+int amt_memset(amt_ctx* ctx, void* dst, int value, size_t bytes);
+/* HIP-event timing on the context's stream (bench.py measures kernels with these). */
+int amt_event_create(amt_ctx* ctx, void** out_event);
+int amt_event_destroy(amt_ctx* ctx, void* event);
+int amt_event_record(amt_ctx* ctx, void* event);
+int amt_event_elapsed_ms(amt_ctx* ctx, void* start, void* stop, float* out_ms);   /* synchronises on stop */
+
+/* ---- per-frame parameter block --------------------------------------------------------
+ * Host scalars the reference derives once per frame:
+ *   cd, crpix, rot   auromat/coordinates/wcs.py:80-99,135-139 (TAN WCS; rot = euler_matrix(...,'rzxz')[:3,:3])
+ *   cam              BaseMapping.cameraPosGCRS, auromat/mapping/mapping.py:318-337
+ *   a, b             wgs84A/B + altitude, auromat/mapping/mapping.py:1498-1501
+ *   a0, b0           wgs84A/B for ECEF->geodetic, auromat/coordinates/transform.py:338
+ *   m_geo, m_sm      mat_j2000_to_geo / mat_j2000_to_sm, auromat/coordinates/transform.py:683-691
+ */
+typedef struct amt_frame_params {
+    int32_t width;        /* IMAGEW */
+    int32_t height;       /* IMAGEH */
+    int32_t fast_center;  /* BaseAstrometryMapping.fastCenterCalculation, astrometry.py:23-40 */
+    int32_t reserved;
+    double cd[4];         /* CD1_1 CD1_2 CD2_1 CD2_2 [deg/px] */
+    double crpix[2];      /* CRPIX1 CRPIX2 (1-based FITS convention) */
+    double rot[9];        /* native -> celestial rotation, row major */
+    double cam[3];        /* camera position, km, J2000/GCRS */
+    double a, b;          /* inflated ellipsoid axes, km */
+    double a0, b0;        /* geodetic reference ellipsoid axes, km */
+    double m_geo[9];      /* J2000 -> GEO, row major */
+    double m_sm[9];       /* J2000 -> SM, row major */
+} amt_frame_params;
+
+/* Output block of amt_georef_frame.  Any pointer may be NULL (that array is not written).
+ * Corner arrays have (height+1)*(width+1) elements, centre arrays height*width.
+ * bbox (optional, 8 doubles, device): [lat_min, lat_max, lon_min, lon_max, lon_min_positive,
+ * lon_max_nonpositive, n_valid_centres, n_pole_quads] over the corners of centres with
+ * elevation >= bbox_min_elevation — the inputs of BaseMapping.boundingBox
+ * (auromat/mapping/mapping.py:693-743) for a mapping that was maskedByElevation()'d
+ * (mapping.py:845-864).  n_pole_quads counts valid pixels whose corner quadrilateral winds once
+ * around a geographic pole (sum of wrapped longitude steps = +-360 deg): non-zero <=> the mapping
+ * contains a pole (what geodesic.py:183 containsOrCrossesPole decides from the outline). */
+typedef struct amt_georef_out {
+    double* lat;      /* corners, deg   (BaseAstrometryMapping.lats,  astrometry.py:118-144) */
+    double* lon;      /* corners, deg */
+    double* lat_c;    /* centres, deg   (latsCenter / lonsCenter, astrometry.py:128-152) */
+    double* lon_c;
+    double* elev;     /* centres, deg   (elevation, astrometry.py:200-212) */
+    double* mlat;     /* corners, deg   (mLatMlt, astrometry.py:170-183) */
+    double* mlt;      /* corners, hours */
+    double* mlat_c;   /* centres        (mLatMltCenter, astrometry.py:185-198) */
+    double* mlt_c;
+    double* bbox;
+    double bbox_min_elevation;
+} amt_georef_out;
+
+/* ---- building blocks (auromat.coordinates) ------------------------------------------- */
+
+/* auromat/coordinates/wcs.py:18-64,66-144 pix2world(..., ascartesian=True) for TAN headers and
+ * auromat/mapping/astrometry.py:245-269 pixelDirection: unit direction of every pixel corner
+ * (corner=1: (height+1, width+1, 3)) or centre (corner=0: (height, width, 3)), AoS. */
+int amt_directions_tan(amt_ctx* ctx, const amt_frame_params* p, int corner, double* out_dirs);
+/* auromat/coordinates/wcs.py:66-144 tan_pix2world(header, px, py, origin, ascartesian=True) for arbitrary
+ * pixel coordinates (origin 0 or 1 as in FITS/astropy); out (n,3) AoS.  Uses cd, crpix, rot of p only. */
+int amt_directions_tan_points(amt_ctx* ctx, const amt_frame_params* p, const double* px, const double* py,
+                              int64_t n, int origin, double* out_dirs);
+
+/* auromat/coordinates/intersection.py:144-163 ellipsoidLineIntersection (and
+ * auromat/mapping/mapping.py:1474-1510 inflatedEarthIntersection with a=wgs84A+h, b=wgs84B+h).
+ * origin: host double[3]; dirs/out: (n,3) AoS.  Misses / points behind a directed ray are NaN. */
+int amt_intersect_ellipsoid(amt_ctx* ctx, double a, double b, const double* origin, const double* dirs,
+                            int64_t n, int directed, double* out_xyz);
+/* auromat/coordinates/intersection.py:229-237 ellipsoidLineIntersects -> uint8 (0/1). */
+int amt_intersects_ellipsoid(amt_ctx* ctx, double a, double b, const double* origin, const double* dirs,
+                             int64_t n, int directed, uint8_t* out_hit);
+/* auromat/coordinates/intersection.py:12-48 sphereLineIntersection (earthModel='sphere'). */
+int amt_intersect_sphere(amt_ctx* ctx, double radius, const double* origin, const double* dirs,
+                         int64_t n, int directed, double* out_xyz);
+
+/* auromat/coordinates/transform.py:199-297 ecef2Geodetic (Bowring 1985) -> radians. */
+int amt_ecef_to_geodetic(amt_ctx* ctx, const double* x, const double* y, const double* z, int64_t n,
+                         double a, double b, double* out_lat, double* out_lon);
+/* auromat/coordinates/transform.py:156-178 geodetic2Ecef (radians in, scalar height). */
+int amt_geodetic_to_ecef(amt_ctx* ctx, const double* lat, const double* lon, double h, int64_t n,
+                         double a, double b, double* out_x, double* out_y, double* out_z);
+/* auromat/coordinates/transform.py:324-343 j2000ToLatLon with the 3x3 (host, row major) given:
+ * rotate (n,3) AoS points, Bowring, degrees out.  Also serves x_to_y-based geo helpers. */
+int amt_rotate_to_latlon(amt_ctx* ctx, const double* m, const double* xyz, int64_t n, double a0, double b0,
+                         double* out_lat_deg, double* out_lon_deg);
+/* auromat/coordinates/transform.py:403-459 j2000ToMLatMLT / geoToMLatMLT: rotate into SM,
+ * mlat = deg(atan2(z, hypot(x,y))), mlt = deg(atan2(y,x))*24/360 + 12. */
+int amt_rotate_to_mlat_mlt(amt_ctx* ctx, const double* m, const double* xyz, int64_t n,
+                           double* out_mlat_deg, double* out_mlt_h);
+/* auromat/coordinates/transform.py:728-738 x_to_y: out = m @ v for (n,3) AoS vectors. */
+int amt_rotate_vectors(amt_ctx* ctx, const double* m, const double* xyz, int64_t n, double* out_xyz);
+/* auromat/mapping/mapping.py:540-550 BaseMapping._mLatMlt: geodetic (deg) at height h -> ECEF ->
+ * SM (m = mat_geo_to_sm) -> MLat/MLT.  NaN in, NaN out. */
+int amt_latlon_to_mlat_mlt(amt_ctx* ctx, const double* m, const double* lat_deg, const double* lon_deg,
+                           double h, int64_t n, double a0, double b0, double* out_mlat_deg, double* out_mlt_h);
+/* auromat/coordinates/transform.py:461-485 smToLatLon: SM lat/lon (deg) on the unit sphere ->
+ * GEO (m = transpose of mat_geo_to_sm, passed already transposed) -> geodetic deg. */
+int amt_sm_to_latlon(amt_ctx* ctx, const double* m_sm_to_geo, const double* smlat_deg, const double* smlon_deg,
+                     int64_t n, double a0, double b0, double* out_lat_deg, double* out_lon_deg);
+/* auromat/coordinates/transform.py:301-322 rotatePole: geodetic (rad) at `altitude` rotated by the
+ * 3x3 `rot` (host) about the origin, back to geodetic (rad). */
+int amt_rotate_pole(amt_ctx* ctx, const double* rot, const double* lat, const double* lon, double altitude,
+                    int64_t n, double a0, double b0, double* out_lat, double* out_lon);
+/* auromat/coordinates/transform.py:142-154 cartesian_to_spherical -> (r, lat, lon) radians; out_r may be NULL. */
+int amt_cartesian_to_spherical(amt_ctx* ctx, const double* x, const double* y, const double* z, int64_t n,
+                               double* out_r, double* out_lat, double* out_lon);
+/* auromat/coordinates/transform.py:89-102 spherical_to_cartesian; r may be NULL (unit sphere). */
+int amt_spherical_to_cartesian(amt_ctx* ctx, const double* r, const double* lat, const double* lon, int64_t n,
+                               double* out_x, double* out_y, double* out_z);
+
+/* ---- fused frame kernel ------------------------------------------------------------- */
+
+/* All lazy arrays of a BaseAstrometryMapping in one launch
+ * (auromat/mapping/astrometry.py:49-212: cameraToPixel*Direction -> intersectionInflated* ->
+ * _latsLonsCorner/_latsLonsCenter -> elevation -> mLatMlt[Center]).  Directions are generated
+ * in-kernel from the WCS; fast_center selects the corner-mean centres (astrometry.py:100-101,154-160)
+ * or the exact per-centre ray cast (:103-105). */
+int amt_georef_frame(amt_ctx* ctx, const amt_frame_params* p, const amt_georef_out* out);
+/* Same with caller-supplied corner directions ((height+1, width+1, 3) AoS, e.g. from another
+ * camera model; SURVEY.md §8d "directions-in" variant).  fast_center must be 1. */
+int amt_georef_frame_dirs(amt_ctx* ctx, const amt_frame_params* p, const double* corner_dirs,
+                          const amt_georef_out* out);
+
+/* ---- mask rules ---------------------------------------------------------------------- */
+
+/* auromat/mapping/mapping.py:845-864 maskedByElevation + the lazy _doSanitize(afterMasking=True)
+ * of mapping.py:1063-1125,1161-1213.  Masks are uint8, 1 = masked.
+ * center_mask[h*w] = !(elev >= min_elevation) (NaN counts as masked);
+ * corner_mask[(h+1)*(w+1)] = isnan(corner_lat) | all adjacent centres masked.
+ * n_valid (device int64, optional) receives the number of unmasked centres; the host raises
+ * ValueError when it is 0 (AMT_EEMPTY is not raised here because the call does not synchronise). */
+int amt_mask_by_elevation(amt_ctx* ctx, const double* elev, const double* corner_lat, int32_t height,
+                          int32_t width, double min_elevation, uint8_t* center_mask, uint8_t* corner_mask,
+                          int64_t* n_valid);
+/* auromat/mapping/mapping.py:1063-1125 _doSanitize on boolean masks (in place).
+ * img_mask may be NULL; after_masking as in the reference. */
+int amt_sanitize_masks(amt_ctx* ctx, uint8_t* corner_mask, uint8_t* center_mask, const uint8_t* img_mask,
+                       int32_t height, int32_t width, int after_masking);
+/* Inputs of BaseMapping.boundingBox (mapping.py:693-743) for arbitrary corner grids:
+ * bbox[0..5] = min/max over unmasked corners as in amt_georef_out.bbox, bbox[6] = number of unmasked
+ * corners, bbox[7] = number of unmasked centres whose corner quad winds around a pole.
+ * corner_mask / center_mask may be NULL (then NaN latitude = masked; a centre is unmasked when its
+ * four corners are). lat/lon: (height+1, width+1) degrees. */
+int amt_bbox_corners(amt_ctx* ctx, const double* lat, const double* lon, const uint8_t* corner_mask,
+                     const uint8_t* center_mask, int32_t height, int32_t width, double* bbox);
+
+/* ---- histogram binning / plate-carree resampling ------------------------------------- */
+
+/* Bin-edge description of one axis, reference semantics of auromat/util/histogram.py:178-224:
+ * index = searchsorted(edges, v, 'right') (0 and nbin+1 are outliers), and values v >= edges[nbin]
+ * with rint(v*scale)/scale == last_rounded fall into the last bin.  `edges` is a DEVICE array of
+ * nbin+1 ascending doubles (np.linspace output for uniform grids); `scale` = 10**decimal and
+ * `last_rounded` = around(edges[-1], decimal) are computed by the host exactly as the reference does. */
+typedef struct amt_axis {
+    const double* edges;
+    int32_t nbin;
+    int32_t uniform;      /* 1: edges are (numerically) evenly spaced -> O(1) guess + exact fix-up */
+    double first, last;   /* host copies of edges[0] and edges[nbin] */
+    double scale;
+    double last_rounded;
+} amt_axis;
+
+/* auromat/util/histogram.py:284-417,57-282 histogram2d(x, y, bins, range, weights=[None, w0, ...]).
+ * Accumulates into count[nx*ny] and sums[k][nx*ny] (k < nweights; device pointers in the HOST array
+ * `weights` / `sums`), all float64, row major (ix*ny + iy), which must be zeroed by the caller
+ * (they may be accumulated over several calls).  NaN x or y are outliers; NaN weights poison
+ * their cell (np.bincount behaviour).  lon_wrap != 0 bins wrap_at(x + 180, 180) instead of x
+ * (auromat/resample.py:212-218, discontinuity branch). */
+int amt_hist2d_accumulate(amt_ctx* ctx, const double* x, const double* y, int64_t n,
+                          const double* const* weights, int32_t nweights, const amt_axis* xaxis,
+                          const amt_axis* yaxis, int lon_wrap, double* count, double* const* sums);
+
+/* Fused binning of one frame for resample(method='mean') (auromat/resample.py:95-142,301-351):
+ * pixels with finite lat_c, elev >= min_elevation (pass -inf to disable; NaN elev is dropped when a
+ * finite threshold is given) and center_mask == 0 (mask may be NULL) add 1, their image channels
+ * and their elevation to cell (ix, iy), x = lon_c, y = lat_c.
+ * img: (n, nchan) interleaved uint8 (img_dtype=1) or uint16 (img_dtype=2), nchan <= 4.
+ * acc: device uint64[(nchan+2) * nx*ny] workspace, zeroed by the caller:
+ *   plane 0 = count, planes 1..nchan = exact integer channel sums,
+ *   plane nchan+1 = elevation sum in signed 31.32 fixed point (|error| <= 2^-33 deg per sample;
+ *   order independent, so results are bit-reproducible). */
+int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const double* elev,
+                  const void* img, int32_t img_dtype, int32_t nchan, const uint8_t* center_mask,
+                  int32_t height, int32_t width, double min_elevation, const amt_axis* xaxis,
+                  const amt_axis* yaxis, int lon_wrap, uint64_t* acc);
+/* Mean + layout of auromat/resample.py:339-351 and :128-136: for out row r (lat descending) and
+ * column c: cell (ix=c, iy=ny-1-r).  mean: (ny, nx, nchan+1) float64, NaN where count == 0;
+ * out_img (optional): (ny, nx, nchan) of img_dtype, round-half-even of the mean (0 where empty);
+ * out_mask (optional): (ny, nx) uint8, 1 where count == 0; out_count (optional): (ny, nx) float64. */
+int amt_bin_frame_finalize(amt_ctx* ctx, const uint64_t* acc, int32_t nx, int32_t ny, int32_t nchan,
+                           int32_t img_dtype, double* mean, void* out_img, uint8_t* out_mask,
+                           double* out_count);
+/* Same for float accumulators of amt_hist2d_accumulate: mean[k] = sums[k]/count, NaN where empty,
+ * transposed + flipped to (ny, nx, nweights). */
+int amt_hist2d_finalize_mean(amt_ctx* ctx, const double* count, const double* const* sums, int32_t nweights,
+                             int32_t nx, int32_t ny, double* mean);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUROMAT_HIP_H */

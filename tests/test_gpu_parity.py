@@ -1,0 +1,319 @@
+"""
+GPU parity tests: the HIP path (through the C ABI, via the reference-named Python mirrors) against
+the golden fixtures made from the real reference and against the CPU oracle on seeded inputs.
+
+Tolerances (BASELINE.json north star): lat / lon / elevation / MLat within 1e-6 deg, MLT within
+1e-6 * 24/360 h, identical NaN masks; bin counts and integer image sums exact; resampled means of
+float channels within a float32 ulp.
+"""
+import json
+import os
+from datetime import datetime
+
+import numpy as np
+import numpy.ma as ma
+import pytest
+
+from conftest import GOLDEN, header_from, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL_DEG = 1e-6
+TOL_MLT = 1e-6 * 24 / 360
+
+
+def parse(s):
+    return datetime.strptime(str(s), '%Y-%m-%dT%H:%M:%S.%f')
+
+
+def close(a, b, tol, max_mask_mismatch=0):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    mism = int((np.isnan(a) != np.isnan(b)).sum())
+    assert mism <= max_mask_mismatch, 'NaN masks differ in %d places' % mism
+    ok = ~np.isnan(a) & ~np.isnan(b)
+    err = np.max(np.abs(a[ok] - b[ok]), initial=0.0)
+    assert err <= tol, 'max abs error %.3e > %.1e' % (err, tol)
+    return err
+
+
+@pytest.fixture(scope='module')
+def native():
+    from auromat_amd import _native
+    lib = _native.lib()   # raises when the extension is missing: no fallback
+    ctx = _native.Context.current()
+    return ctx
+
+
+def test_library_is_the_hip_extension(native):
+    info = native.device_info()
+    assert 'gfx950' in info['name'], info
+    with open('/proc/self/maps') as fp:
+        assert 'libauromat_hip.so' in fp.read()
+
+
+def test_smoke_entry():
+    import __graft_entry__
+    __graft_entry__.smoke()
+
+
+SMALL = [(p, m) for p in ('iss030', 'iss029') for m in ('fast', 'exact')]
+
+
+@pytest.mark.parametrize('pointing,mode', SMALL)
+def test_mapping_georef_vs_reference(native, pointing, mode):
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    z = load_golden('georef_small_%s_%s.npz' % (pointing, mode))
+    hdr = header_from(z)
+    img = np.zeros((hdr['IMAGEH'], hdr['IMAGEW'], 3), np.uint8)
+    m = ArraySpacecraftMapping(hdr, float(z['altitude']), img, z['cam'], parse(z['time_iso']), 'g',
+                               fastCenterCalculation=(mode == 'fast'))
+    fd = m.frame()
+    close(fd.host('lat'), z['lat'], TOL_DEG)
+    close(fd.host('lon'), z['lon'], TOL_DEG)
+    close(fd.host('lat_c'), z['lat_c'], TOL_DEG)
+    close(fd.host('lon_c'), z['lon_c'], TOL_DEG)
+    close(fd.host('elev'), z['elev'], TOL_DEG)
+    mlat, mlt = m.mLatMlt
+    mlat_c, mlt_c = m.mLatMltCenter
+    close(mlat.data, z['mlat'], TOL_DEG)
+    close(mlt.data, z['mlt'], TOL_MLT)
+    close(mlat_c.data, z['mlat_c'], TOL_DEG)
+    close(mlt_c.data, z['mlt_c'], TOL_MLT)
+    # host-side set-up reproduces the reference's matrices bit for bit
+    from auromat_amd.coordinates import transform as T
+    et = T.date2es(parse(z['time_iso']))
+    assert et == float(z['et'])
+    assert np.array_equal(T.mat_j2000_to_geo(et), z['m_geo'])
+    assert np.array_equal(T.mat_j2000_to_sm(et), z['m_sm'])
+    assert np.array_equal(T.mat_geo_to_sm(et), z['m_geo_sm'])
+    # masked-array surface
+    assert np.array_equal(ma.getmaskarray(m.lats), ma.getmaskarray(m.lons))
+    m.checkGuarantees()
+
+
+def test_building_blocks_vs_reference(native):
+    from auromat_amd.coordinates import intersection as I, transform as T, wcs as W
+    from auromat_amd.coordinates.geodesic import wgs84A, wgs84B
+    from auromat_amd.mapping.mapping import inflatedEarthIntersection
+    from auromat_amd.mapping.astrometry import pixelDirection
+    z = load_golden('georef_small_iss030_exact.npz')
+    hdr = header_from(z)
+    t = parse(z['time_iso'])
+    dirs = pixelDirection(hdr, corner=True)
+    close(dirs, z['dir_corner'], 1e-14)
+    close(pixelDirection(hdr, corner=False), z['dir_center'], 1e-14)
+    p = inflatedEarthIntersection(z['dir_corner'].reshape(-1, 3), z['cam'], float(z['altitude']))
+    close(p, z['p_corner'].reshape(-1, 3), 1e-7)      # km; 1e-7 km = 0.1 mm
+    valid = ~np.isnan(z['p_corner'].reshape(-1, 3)[:, 0])
+    pts = z['p_corner'].reshape(-1, 3)[valid]
+    lat, lon = T.j2000ToLatLon(pts, t)
+    close(lat, z['lat'].ravel()[valid], 1e-10)
+    close(lon, z['lon'].ravel()[valid], 1e-10)
+    mlat, mlt = T.j2000ToMLatMLT(pts, t)
+    close(mlat, z['mlat'].ravel()[valid], 1e-10)
+    close(mlt, z['mlt'].ravel()[valid], 1e-11)
+    hit = I.ellipsoidLineIntersects(wgs84A + 110, wgs84B + 110, z['cam'], z['dir_corner'].reshape(-1, 3))
+    assert np.array_equal(hit, valid)
+    # ra/dec surface
+    ra, dec = W.pix2world(hdr, hdr['IMAGEW'], hdr['IMAGEH'])
+    d = z['dir_corner']
+    close(dec, np.rad2deg(np.arcsin(d[..., 2])), 1e-9)
+    close(np.mod(ra - np.rad2deg(np.arctan2(d[..., 1], d[..., 0])) + 180, 360) - 180, np.zeros(ra.shape), 1e-9)
+    x = np.arange(0, hdr['IMAGEW'], 7.0)
+    y = np.arange(0, hdr['IMAGEW'], 7.0) * 0.5
+    close(W.tan_pix2world(hdr, x, y, 0, ascartesian=True), W.tan_pix2world(hdr, x + 1, y + 1, 1, ascartesian=True), 0)
+
+
+def test_known_answers_of_the_reference_tests(native):
+    from auromat_amd.coordinates import intersection as I, transform as T
+    with open(os.path.join(GOLDEN, 'known_answers.json')) as fp:
+        ka = json.load(fp)
+    for c in ka['ellipsoid']:
+        res = I.ellipsoidLineIntersection(c['a'], c['b'], c['origin'], c['dirs'], directed=c['directed'])
+        np.testing.assert_array_equal(res, np.array(c['expect'], dtype=float))
+        hit = I.ellipsoidLineIntersects(c['a'], c['b'], c['origin'], c['dirs'], directed=c['directed'])
+        assert hit.tolist() == c['ref_intersects']
+    w = ka['wgs84_chord']
+    p1, p2 = np.array(w['p1']), np.array(w['p2'])
+    i1 = I.ellipsoidLineIntersection(w['a'], w['b'], p1, [p1 - p2], directed=False)
+    np.testing.assert_array_almost_equal(i1, [p1], w['decimals'])
+    for c in ka['sphere']:
+        res = I.sphereLineIntersection(c['r'], c['origin'], np.asarray(c['dirs'], dtype=float), c['directed'])
+        np.testing.assert_array_equal(res, np.array(c['expect'], dtype=float))
+    s = ka['sscweb']
+    date = datetime.strptime(s['date'], '%Y-%m-%dT%H:%M:%S')
+    aae = np.testing.assert_array_almost_equal
+    aae(T.gei_to_geo(date, s['gei']), s['geo'], s['decimals'])
+    aae(T.gei_to_gse(date, s['gei']), s['gse'], s['decimals'])
+    aae(T.gse_to_gsm(date, s['gse']), s['gsm'], s['decimals'])
+    aae(T.gsm_to_sm(date, s['gsm']), s['sm'], s['decimals'])
+    aae(T.geo_to_gei(date, s['geo']), s['gei'], s['decimals'])
+    aae(T.j2000_to_geo(date, s['j2000']), s['geo'], s['decimals'])
+    aae(T.j2000_to_sm(date, s['j2000']), s['sm'], s['decimals'])
+    aae(T.geo_to_sm(date, s['geo']), s['sm'], s['decimals'])
+    g = ka['geodetic_roundtrip']
+    (a0, a1, astep), (b0, b1, bstep) = g['mgrid']
+    lat, lon = np.mgrid[a0:a1:astep, b0:b1:bstep]
+    x, y, zz = T.geodetic2EcefZero(np.deg2rad(lat), np.deg2rad(lon))
+    la, lo = T.ecef2Geodetic(x, y, zz)
+    aae(np.rad2deg(la), lat, g['decimals'])
+    aae(np.rad2deg(lo), lon, g['decimals'])
+    for la0 in np.linspace(*g['lat_linspace'][:2], num=7):
+        for lo0 in np.linspace(*g['lon_linspace'][:2], num=7):
+            x, y, zz = T.geodetic2EcefZero(np.deg2rad(la0), np.deg2rad(lo0))
+            aae(np.rad2deg(T.ecef2Geodetic(x, y, zz)), [la0, lo0], g['decimals'])
+    # cartesian <-> spherical round trip (transform_test.py:18-31)
+    rs = np.random.RandomState(0)
+    x, y, zz = rs.rand(20, 10), rs.rand(20, 10), rs.rand(20, 10)
+    r, lat, lon = T.cartesian_to_spherical(x, y, zz)
+    xr, yr, zr = T.spherical_to_cartesian(r, lat, lon)
+    aae(xr, x)
+    aae(yr, y)
+    aae(zr, zz)
+    aae(T.spherical_to_cartesian(r, lat, lon, astuple=False), np.dstack((x, y, zz)))
+
+
+def test_masks_vs_reference(native):
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    g = load_golden('masks_small.npz')
+    for mode in ('fast', 'exact'):
+        z = load_golden('georef_small_iss030_%s.npz' % mode)
+        hdr = header_from(z)
+        img = np.zeros((hdr['IMAGEH'], hdr['IMAGEW'], 3), np.uint16)
+        m = ArraySpacecraftMapping(hdr, 110, img, z['cam'], parse(z['time_iso']), 'g',
+                                   fastCenterCalculation=(mode == 'fast'))
+        assert np.array_equal(ma.getmaskarray(m.lats), g[mode + '_corner_mask'])
+        assert np.array_equal(ma.getmaskarray(m.latsCenter), g[mode + '_center_mask'])
+        assert np.array_equal(ma.getmaskarray(m.elevation), g[mode + '_elev_mask'])
+        for e in (10, 25):
+            mm = m.maskedByElevation(e)
+            assert np.array_equal(ma.getmaskarray(mm.lats), g['%s_e%d_corner_mask' % (mode, e)])
+            assert np.array_equal(ma.getmaskarray(mm.latsCenter), g['%s_e%d_center_mask' % (mode, e)])
+            assert np.array_equal(ma.getmaskarray(mm.img)[:, :, 0], g['%s_e%d_img_mask' % (mode, e)])
+            assert np.array_equal(ma.getmaskarray(mm.elevation), g['%s_e%d_elev_mask' % (mode, e)])
+            mm.checkGuarantees()
+            # masking twice keeps what is masked (mapping.py:856: masked elevation stays masked)
+            m2 = mm.maskedByElevation(e - 5)
+            assert np.array_equal(ma.getmaskarray(m2.latsCenter), g['%s_e%d_center_mask' % (mode, e)])
+        with pytest.raises(ValueError):
+            m.maskedByElevation(89.99)
+
+
+def test_histogram2d_edge_semantics(native):
+    from auromat_amd.util.histogram import histogram2d
+    z = load_golden('histogram_edges.npz')
+    for tag in 'abc':
+        hs, xe, ye = histogram2d(z[tag + '_x'], z[tag + '_y'], bins=tuple(int(b) for b in z[tag + '_bins']),
+                                 range=z[tag + '_range'].tolist(), weights=[None, z[tag + '_w1'], z[tag + '_w2']])
+        assert np.array_equal(xe, z[tag + '_xedges']) and np.array_equal(ye, z[tag + '_yedges'])
+        assert np.array_equal(hs[0], z[tag + '_count'])
+        assert np.array_equal(hs[1], z[tag + '_s1'])          # integer-valued weights: exact
+        np.testing.assert_allclose(hs[2], z[tag + '_s2'], rtol=1e-12, atol=1e-9)
+    hs, xe, ye = histogram2d(z['d_x'], z['d_y'], bins=[z['d_xedges'], z['d_yedges']], weights=[None, z['d_w']])
+    assert np.array_equal(hs[0], z['d_count'])
+    np.testing.assert_allclose(hs[1], z['d_s'], rtol=1e-12, atol=1e-12)
+    x = np.array([0.0, 1.0, 3.0, np.nextafter(3, 4), np.nextafter(0, -1), np.nan])
+    h, _, _ = histogram2d(x, np.full(6, 0.5), bins=(3, 1), range=[[0, 3], [0, 1]])
+    assert h[:, 0].tolist() == [1.0, 1.0, 2.0]
+    h, _, _ = histogram2d(np.zeros(0), np.zeros(0), bins=(3, 2), range=[[0, 3], [0, 1]])
+    assert h.shape == (3, 2) and not h.any()
+
+
+RESAMPLE_GEO = ['resample_geo_%s_ppd%s.npz' % (p, r) for p in ('iss030', 'iss029') for r in ('10x10', '4x7')]
+
+
+@pytest.mark.parametrize('name', RESAMPLE_GEO + ['resample_sm_iss030.npz', 'resample_sm_iss029.npz'])
+def test_resample_generic_mapping_vs_reference(native, name):
+    """GenericMapping built from the reference's own coordinate arrays -> resample(): binning is exact."""
+    from auromat_amd.mapping.mapping import GenericMapping
+    from auromat_amd.resample import resample
+    z = load_golden(name)
+    t = parse(z['time_iso'])
+    m = GenericMapping(z['corner_lat'], z['corner_lon'], z['lats_c'], z['lons_c'], z['elev'], float(z['altitude']),
+                       z['img'], z['cam'], t, 'r')
+    bb = m.boundingBox
+    assert np.array_equal([bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast], z['bbox'])
+    assert m.containsDiscontinuity == bool(z['contains_discontinuity']) and not m.containsPole
+    r = resample(m, pxPerDeg=tuple(z['ppd']))
+    r.checkPlateCarree() if not z['contains_discontinuity'] else None
+    for k, ref in (('lats', 'out_lat'), ('lons', 'out_lon'), ('latsCenter', 'out_lat_c'), ('lonsCenter', 'out_lon_c')):
+        assert np.array_equal(getattr(r, k).data, z[ref]), k
+    want = z['out_data']
+    mask = np.isnan(want[..., 0])
+    assert np.array_equal(ma.getmaskarray(r.img)[..., 0], mask)
+    assert np.array_equal(ma.getmaskarray(r.elevation), mask)
+    if 'out_img' in z.files:
+        assert np.array_equal(r.img.data[~mask], z['out_img'][~mask])
+    else:
+        with np.errstate(invalid='ignore'):
+            assert np.array_equal(r.img.data[~mask], np.round(want[..., :3])[~mask].astype(np.uint16))
+    err = np.max(np.abs(r.elevation.data[~mask] - want[..., 3][~mask]))
+    assert err < 1e-9, err      # fixed-point elevation sums: <= 2^-33 deg per sample
+
+
+@pytest.mark.parametrize('name', ['resample_synth_plain.npz', 'resample_synth_disc.npz', 'resample_synth_pole.npz'])
+def test_resample_arrays_vs_reference(native, name):
+    """Array-level _resample() with the reference's signature incl. discontinuity and pole branches."""
+    from auromat_amd.mapping.mapping import BoundingBox
+    from auromat_amd.resample import _resample
+    z = load_golden(name)
+    bb = BoundingBox(*[float(v) for v in z['bbox']])
+    lat, lon, lat_c, lon_c, data = _resample(z['lats_c'], z['lons_c'], float(z['altitude']), z['data'],
+                                             lambda: z['outline'].copy(), bb, tuple(z['ppd']),
+                                             bool(z['contains_discontinuity']), bool(z['contains_pole']))
+    tol = 1e-9 if z['contains_pole'] else 0.0    # pole branch: grid rotated back on the device
+    close(lat, z['out_lat'], tol)
+    close(lon, z['out_lon'], tol)
+    close(lat_c, z['out_lat_c'], tol)
+    close(lon_c, z['out_lon_c'], tol)
+    want = z['out_data']
+    assert np.array_equal(np.isnan(data), np.isnan(want))
+    ok = ~np.isnan(want)
+    np.testing.assert_allclose(data[ok], want[ok], rtol=1e-13, atol=1e-11)
+
+
+def test_resample_pipeline_end_to_end_vs_reference(native):
+    """WCS header -> fused georef -> elevation mask -> resample, against the reference's grid."""
+    from auromat_amd.pipeline import FramePipeline
+    for pointing in ('iss030', 'iss029'):
+        z = load_golden('resample_geo_%s_ppd10x10.npz' % pointing)
+        hdr = header_from(z)
+        pipe = FramePipeline(hdr['IMAGEW'], hdr['IMAGEH'])
+        res = pipe.run(hdr, 110, z['cam'], parse(z['time_iso']), img=z['img'], fast=True, min_elevation=10,
+                       pxPerDeg=10)
+        bb = pipe.bounding_box()
+        np.testing.assert_allclose([bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast], z['bbox'], rtol=0, atol=1e-9)
+        assert np.array_equal(res['lat'], z['out_lat']) and np.array_equal(res['lon_c'], z['out_lon_c'])
+        want = z['out_data']
+        want_mask = np.isnan(want[..., 0])
+        # coordinates agree to ~1e-12 deg, so a pixel can change cell only if it sits that close to an edge
+        assert (res['mask'] != want_mask).sum() <= 1
+        both = ~res['mask'] & ~want_mask
+        diff = np.abs(res['mean'][both] - want[both])
+        assert (diff[..., :3].max(axis=-1) > 0).sum() <= 2
+        assert np.median(diff) == 0.0
+
+
+def test_mlat_mlt_resample_vs_reference(native):
+    """resampleMLatMLT (resample.py:63-71) incl. the natural discontinuity of the southern fixture."""
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.resample import resampleMLatMLT
+    for pointing in ('iss030', 'iss029'):
+        z = load_golden('resample_sm_%s.npz' % pointing)
+        hdr = header_from(z)
+        m = ArraySpacecraftMapping(hdr, 110, z['img'], z['cam'], parse(z['time_iso']), 's',
+                                   fastCenterCalculation=True).maskedByElevation(10)
+        r = resampleMLatMLT(m, pxPerDeg=10)
+        assert r.lats.shape == z['geo_lat'].shape
+        close(r.lats.data, z['geo_lat'], 1e-9)
+        close(r.lons.data, z['geo_lon'], 1e-9)
+        close(r.latsCenter.data, z['geo_lat_c'], 1e-9, max_mask_mismatch=2)
+        want = z['out_data']
+        want_mask = np.isnan(want[..., 0])
+        got_mask = ma.getmaskarray(r.img)[..., 0]
+        assert (got_mask != want_mask).sum() <= 1
+        both = ~got_mask & ~want_mask
+        with np.errstate(invalid='ignore'):
+            ref_img = np.round(want[..., :3]).astype(np.int64)
+        assert (np.abs(r.img.data.astype(np.int64) - ref_img)[both].max(axis=-1) > 0).sum() <= 3

@@ -1,0 +1,132 @@
+"""
+CPU-only checks of the product's host side: the C ABI library builds/loads and exports every
+symbol of include/auromat_hip.h; per-frame host scalars equal the reference's (golden fixtures);
+grid layout logic; no compute entry point works without a GPU (there is no CPU fallback).
+"""
+import os
+import re
+from datetime import datetime
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def parse(s):
+    return datetime.strptime(str(s), '%Y-%m-%dT%H:%M:%S.%f')
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__
+    __graft_entry__.build()
+    from auromat_amd import _native
+    return _native.lib()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from auromat_amd import _native
+    with open(os.path.join(ROOT, 'include', 'auromat_hip.h')) as fp:
+        text = fp.read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    declared = set(re.findall(r'\b(amt_[a-z0-9_]+)\s*\(', text))
+    assert len(declared) >= 40
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'library does not export ' + name
+    assert declared == set(_native.exported_symbols()), declared ^ set(_native.exported_symbols())
+    assert lib.amt_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from auromat_amd._native import Axis, FrameParams, GeorefOut
+    assert C.sizeof(FrameParams) == 16 + 8 * (4 + 2 + 9 + 3 + 4 + 9 + 9)
+    assert C.sizeof(GeorefOut) == 8 * 11
+    assert C.sizeof(Axis) == 8 + 8 + 8 * 4
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from auromat_amd._native import NativeError
+    from auromat_amd.coordinates.intersection import ellipsoidLineIntersection
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.synthetic import frame_header, frame_image
+    with pytest.raises(NativeError):
+        ellipsoidLineIntersection(2, 2, [0, 3, 0], [[0, -1, 0]])
+    hdr, cam, t = frame_header(32, 24)
+    m = ArraySpacecraftMapping(hdr, 110, frame_image(32, 24), cam, t, 'x', fastCenterCalculation=True)
+    with pytest.raises(NativeError):
+        m.lats
+
+
+def test_host_scalars_equal_reference():
+    from auromat_amd.coordinates import transform as T
+    from auromat_amd.coordinates.wcs import celestial_rotation
+    z = load_golden('host_scalars.npz')
+    for i, d in enumerate(z['dates']):
+        et = T.date2es(parse(d))
+        assert et == z['et'][i]
+        for name, fn in [('m_geo', T.mat_j2000_to_geo), ('m_sm', T.mat_j2000_to_sm), ('m_geo_sm', T.mat_geo_to_sm),
+                         ('m_P', T.mat_P), ('m_T1', T.mat_T1), ('m_T2', T.mat_T2), ('m_T3', T.mat_T3),
+                         ('m_T4', T.mat_T4)]:
+            assert np.array_equal(fn(et), z[name][i]), name
+        assert T.mag_lat(et) == z['mag_lat'][i] and T.mag_lon(et) == z['mag_lon'][i]
+    for (ra, dec, lp), rot in zip(z['wcs_in'], z['wcs_rot']):
+        assert np.array_equal(celestial_rotation({'CRVAL1': ra, 'CRVAL2': dec, 'LONPOLE': lp}), rot)
+    with pytest.raises(ValueError):
+        T.mag_lat(T.date2es(datetime(2020, 1, 2)))          # igrf.py:55-58
+    loc = T.northGeomagneticPoleLocation(datetime(2012, 1, 25))
+    assert 79 < loc.lat < 81 and -73 < loc.lon < -71
+
+
+def test_grid_layout_equals_reference():
+    from auromat_amd.resample import _Grid, fixedGrid
+    for name in ('resample_geo_iss030_ppd10x10.npz', 'resample_geo_iss029_ppd4x7.npz', 'resample_synth_plain.npz'):
+        z = load_golden(name)
+        lat_s, lon_w, lat_n, lon_e = z['bbox']
+        g = _Grid(tuple(z['ppd']), lat_s, lat_n, lon_w, lon_e)
+        assert np.array_equal(g.lat, z['out_lat']) and np.array_equal(g.lon, z['out_lon'])
+        assert np.array_equal(g.lat_c, z['out_lat_c']) and np.array_equal(g.lon_c, z['out_lon_c'])
+        assert (g.ny, g.nx) == z['out_data'].shape[:2]
+    # survey probe: lat 60..70, lon 160..170 at 1 px/deg -> 9x9 cells centred 61..69 / 161..169
+    g = _Grid((1, 1), 60, 70, 160, 170)
+    assert g.latCenters.tolist() == list(range(69, 60, -1)) and g.lonCenters.tolist() == list(range(161, 170))
+    assert fixedGrid((1, 1), 60, 70, 160, 170) == (11, 11, 60.0, 70.0, 160.0, 170.0)
+
+
+def test_bounding_box_logic():
+    from auromat_amd.mapping.mapping import BoundingBox, bounding_box_from_reduction, wrap_at_180
+    bb = bounding_box_from_reduction([10, 20, -30, 40, 5, -2, 100, 0])
+    assert (bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast) == (10, -30, 20, 40)
+    assert not bb.containsDiscontinuity and not bb.containsPole
+    bb = bounding_box_from_reduction([10, 20, -179, 178, 170, -175, 100, 0])
+    assert (bb.lonWest, bb.lonEast) == (170, -175) and bb.containsDiscontinuity and not bb.containsPole
+    bb = bounding_box_from_reduction([80, 89.9, -179, 178, 1, -1, 100, 3])
+    assert bb.containsPole and bb.latNorth == 90 and bb.latSouth == 80
+    bb = bounding_box_from_reduction([-89, -80, -179, 178, 1, -1, 100, 1])
+    assert bb.containsPole and bb.latSouth == -90 and bb.latNorth == -80
+    with pytest.raises(ValueError):
+        bounding_box_from_reduction([np.inf, -np.inf, np.inf, -np.inf, np.inf, -np.inf, 0, 0])
+    assert wrap_at_180(190.0) == -170.0 and wrap_at_180(-180.0) == -180.0 and wrap_at_180(180.0) == -180.0
+    m = BoundingBox.mergedBoundingBoxes([BoundingBox(0, 170, 10, 175), BoundingBox(-5, -178, 5, -170)])
+    assert (m.latSouth, m.lonWest, m.latNorth, m.lonEast) == (-5, 170, 10, -170)
+    assert BoundingBox(0, 1, 2, 3) == BoundingBox(0, 1, 2, 3) and BoundingBox(0, 1, 2, 3) != BoundingBox(0, 1, 2, 4)
+
+
+def test_header_helpers_and_synthetic_frames():
+    from auromat_amd.mapping.spacecraft import getPhotoTime, getShiftedSpacecraftPosition, getSpacecraftPosition
+    from auromat_amd.synthetic import frame_header, sequence_frame
+    hdr = {'DATE-OBS': '2012-01-25T09:27:08.060000', 'POSX': 1.0, 'POSY': 2.0, 'POSZ': 3.0,
+           'POSXSHIF': 4.0, 'POSYSHIF': 5.0, 'POSZSHIF': 6.0, 'DATESHIF': -13.0}
+    assert getPhotoTime(hdr) == datetime(2012, 1, 25, 9, 27, 8, 60000)
+    xyz, date, delta = getShiftedSpacecraftPosition(hdr)
+    assert xyz.tolist() == [4.0, 5.0, 6.0] and date == datetime(2012, 1, 25, 9, 26, 55, 60000)
+    assert getSpacecraftPosition(hdr)[0].tolist() == [1.0, 2.0, 3.0]
+    assert getShiftedSpacecraftPosition({'DATE-OBS': '2011-09-18T11:54:56'}) == (None, None, None)
+    h0, cam0, t0 = frame_header(4240, 2832)
+    h5, cam5, t5, seed = sequence_frame(5)
+    assert abs(np.linalg.norm(cam5) - np.linalg.norm(cam0)) < 1e-9 and (t5 - t0).total_seconds() == 5
+    assert abs(np.linalg.norm(cam5 - cam0) - 5 * 7.66) < 0.01 and h5['CRVAL1'] == h0['CRVAL1'] + 0.25
