@@ -39,7 +39,7 @@ class Axis(C.Structure):
 _I, _L, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p
 _SIGNATURES = {
     'amt_abi_version': ([], _I),
-    'amt_ctx_create': ([_I, _P, c_void_pp], _I),
+    'amt_ctx_create': ([_I, _P, _I, c_void_pp], _I),
     'amt_ctx_destroy': ([_P], _I),
     'amt_ctx_set_stream': ([_P, _P], _I),
     'amt_ctx_get_stream': ([_P], _P),
@@ -133,7 +133,7 @@ class Context(object):
         self.device = torch.device('cuda', device_index)
         self.stream_handle = torch.cuda.current_stream(self.device).cuda_stream
         h = C.c_void_p()
-        rc = self._lib.amt_ctx_create(device_index, C.c_void_p(self.stream_handle), C.byref(h))
+        rc = self._lib.amt_ctx_create(device_index, C.c_void_p(self.stream_handle), 0, C.byref(h))
         if rc != 0:
             raise NativeError('amt_ctx_create failed (%d)' % rc)
         self.handle = h

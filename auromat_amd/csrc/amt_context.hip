@@ -5,7 +5,7 @@ extern "C" {
 
 int amt_abi_version(void) { return AMT_ABI_VERSION; }
 
-int amt_ctx_create(int device_id, void* stream, amt_ctx** out_ctx) {
+int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ctx) {
     if (out_ctx == nullptr) return AMT_EINVAL;
     *out_ctx = nullptr;
     int count = 0;
@@ -22,8 +22,8 @@ int amt_ctx_create(int device_id, void* stream, amt_ctx** out_ctx) {
         delete ctx;
         return AMT_EHIP;
     }
-    if (stream != nullptr) {
-        ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    if (!own_stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(stream);   // NULL = default stream
     } else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
             delete ctx;

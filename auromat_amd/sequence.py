@@ -1,0 +1,119 @@
+"""
+Sequences of frames across the GPUs of one node.
+
+Whole frames are independent units (the reference iterates them with a plain ``map``,
+auromat/mapping/spacecraft.py:326-332, cli/convert.py:178-185), so the path shards by frame with
+no data-path collective: one process per GPU (``torch.distributed``; backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in CPU tests), each rank runs :class:`auromat_amd.pipeline.FramePipeline`
+over its contiguous block of frames and the per-frame output grids — a few hundred KB each — are
+gathered to rank 0 in one padded ``gather`` (point-to-point to the root; a ring is pointless at
+this size).
+"""
+import numpy as np
+
+
+def shard(n_frames, rank, world_size):
+    """Contiguous block of frame indices for `rank` (sizes differ by at most one)."""
+    base, extra = divmod(n_frames, world_size)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
+DESC_LEN = 8   # ny, nx, nchan+1, lat of first row centre, lon of first column centre, dlat, dlon, frame index
+
+
+def pack_results(results, indices, device):
+    """
+    Flatten per-frame results (dicts of resample_frame with keep_on_device=True or host arrays)
+    into one float64 payload + one descriptor table.  Layout per frame: mean (ny*nx*(C+1)) then
+    count (ny*nx).
+    """
+    import torch
+    descs = torch.zeros((len(results), DESC_LEN), dtype=torch.float64)
+    parts = []
+    for i, (res, idx) in enumerate(zip(results, indices)):
+        mean, count = res['mean'], res['count']
+        if not isinstance(mean, torch.Tensor):
+            mean, count = torch.from_numpy(np.ascontiguousarray(mean)), torch.from_numpy(np.ascontiguousarray(count))
+        ny, nx, nc = mean.shape
+        g = res['grid']
+        descs[i] = torch.tensor([ny, nx, nc, g.latCenters[0], g.lonCenters[0], g.latStep, g.lonStep, idx],
+                                dtype=torch.float64)
+        parts += [mean.reshape(-1).to(device), count.reshape(-1).to(device)]
+    payload = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.float64, device=device)
+    return descs.to(device), payload
+
+
+def unpack_results(descs, payload):
+    """Inverse of :func:`pack_results` on host tensors -> list of dict(index, mean, count, lat0, lon0, dlat, dlon)."""
+    out, off = [], 0
+    descs = descs.cpu().numpy()
+    payload = payload.cpu().numpy()
+    for d in descs:
+        ny, nx, nc = int(d[0]), int(d[1]), int(d[2])
+        if ny == 0:
+            continue
+        n_mean, n_cnt = ny * nx * nc, ny * nx
+        mean = payload[off:off + n_mean].reshape(ny, nx, nc)
+        count = payload[off + n_mean:off + n_mean + n_cnt].reshape(ny, nx)
+        off += n_mean + n_cnt
+        out.append(dict(index=int(d[7]), mean=mean, count=count, lat0=d[3], lon0=d[4], dlat=d[5], dlon=d[6]))
+    return out
+
+
+def gather_results(results, indices, device, dst=0, group=None):
+    """
+    Gather every rank's per-frame grids on rank `dst`.  Two collectives: an all_gather of the
+    (frames, payload length) pair, then one gather of [descriptors | payload] padded to the longest.
+    Returns the list of unpacked frame results (sorted by frame index) on `dst`, None elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    descs, payload = pack_results(results, indices, device)
+    sizes = torch.tensor([descs.shape[0], payload.numel()], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    all_sizes = torch.stack(all_sizes).cpu().numpy()
+    max_frames, max_payload = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
+    buf = torch.zeros(max_frames * DESC_LEN + max_payload, dtype=torch.float64, device=device)
+    buf[:descs.numel()] = descs.reshape(-1)
+    buf[max_frames * DESC_LEN:max_frames * DESC_LEN + payload.numel()] = payload
+    if rank == dst:
+        bufs = [torch.zeros_like(buf) for _ in range(world)]
+        dist.gather(buf, bufs, dst=dst, group=group)
+        out = []
+        for r in range(world):
+            nf, npay = int(all_sizes[r, 0]), int(all_sizes[r, 1])
+            d = bufs[r][:nf * DESC_LEN].reshape(nf, DESC_LEN)
+            p = bufs[r][max_frames * DESC_LEN:max_frames * DESC_LEN + npay]
+            out += unpack_results(d, p)
+        return sorted(out, key=lambda f: f['index'])
+    dist.gather(buf, None, dst=dst, group=group)
+    return None
+
+
+def run_sequence(frames, width, height, altitude=110, fast=True, min_elevation=10.0, pxPerDeg=10,
+                 magnetic=False, gather=True, device=None):
+    """
+    Process this rank's share of `frames` — a list of (wcsHeader, cameraPosGCRS, photoTime, image)
+    tuples, identical on every rank — and gather the grids on rank 0.  Works without an initialised
+    process group (single GPU).
+    """
+    import torch
+    import torch.distributed as dist
+    from .pipeline import FramePipeline
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if distributed else 0
+    world = dist.get_world_size() if distributed else 1
+    mine = shard(len(frames), rank, world)
+    pipe = FramePipeline(width, height, device=device, with_mag=magnetic)
+    results = []
+    for k in mine:
+        hdr, cam, t, img = frames[k]
+        results.append(pipe.run(hdr, altitude, cam, t, img=img, fast=fast, min_elevation=min_elevation,
+                                pxPerDeg=pxPerDeg, magnetic=magnetic, keep_on_device=True))
+    if not distributed or not gather:
+        descs, payload = pack_results(results, mine, pipe.ctx.device)
+        return unpack_results(descs, payload)
+    return gather_results(results, mine, pipe.ctx.device)

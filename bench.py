@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""
+bench.py — georef + resample throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one synthetic 4240x2832 ISS-like frame through the whole hot path on one GPU:
+fused georeferencing (WCS -> ray -> inflated-WGS84 hit -> geodetic lat/lon of corners and centres,
+elevation), maskedByElevation(10), bounding box, 0.1 deg plate-carree grid, binned mean of the
+uint16 RGB image + elevation (BASELINE.json configs[2]; configs[1] is its first kernel).  The image
+is resident in HBM before the timed region; per-frame host set-up (matrices, grid) is inside it.
+With N > 1 every rank processes its own frames (weak scaling) and the per-frame grids are gathered
+on rank 0 over RCCL inside the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT = 4240, 2832
+ALTITUDE, MIN_ELEV, PPD = 110, 10.0, 10
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(width, height, nchan=3, pix_bytes=2):
+    """SURVEY.md §8d contract figures (f64 coordinates)."""
+    nc, npx = (width + 1) * (height + 1), width * height
+    return dict(georef=16 * nc + 24 * npx,              # WCS-fused: lat, lon corners + latC, lonC, elev written
+                georef_dirs_in=40 * nc + 24 * npx,      # + 24 B/corner direction read (contract row "directions-in")
+                resample=(24 + nchan * pix_bytes) * npx)
+
+
+def cpu_baseline(sample_rows):
+    """Oracle (NumPy restatement of the reference) on the same workload, 1 core, rows [0, sample_rows)."""
+    from oracle import ref_numpy as O
+    from auromat_amd.synthetic import frame_header, frame_image
+    from auromat_amd.coordinates import transform as T
+    hdr, cam, t = frame_header(WIDTH, HEIGHT, 'iss030')
+    # crop: same pixels as the top `sample_rows` rows of the full frame
+    hdr = dict(hdr, IMAGEH=sample_rows)
+    img = frame_image(WIDTH, HEIGHT, seed=0)[:sample_rows]
+    t0 = time.time()
+    et = T.date2es(t)
+    g = O.georef_frame(hdr, ALTITUDE, cam, O.mat_j2000_to_geo(et), None, fast=True)
+    t1 = time.time()
+    corner_mask, center_mask = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), MIN_ELEV)
+    bbox, disc = O.bbox_of_corners(g['lat'], g['lon'], corner_mask)
+    data = np.dstack((img.astype(np.float64), g['elev']))
+    data[center_mask] = np.nan
+    O.resample_mean(np.where(center_mask, np.nan, g['lat_c']), np.where(center_mask, np.nan, g['lon_c']), ALTITUDE,
+                    data, None, bbox, (PPD, PPD), disc, False)
+    t2 = time.time()
+    npx = WIDTH * sample_rows
+    return dict(value=npx / 1e6 / (t2 - t0), unit='Mpixels/s', cores=1, kind='port',
+                sample='rows 0..%d of the %dx%d frame (%.1f Mpx): georef %.1f s + mask/resample %.1f s, NumPy, 1 thread'
+                       % (sample_rows, WIDTH, HEIGHT, npx / 1e6, t1 - t0, t2 - t1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--cpu-rows', type=int, default=2832, help='rows of the frame the CPU baseline processes (0 = skip)')
+    ap.add_argument('--exact', action='store_true', help='exact centre rays instead of fast centres')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.sequence import gather_results
+    from auromat_amd.synthetic import sequence_frame, frame_image
+
+    pipe = FramePipeline(WIDTH, HEIGHT)
+    ctx = pipe.ctx
+    pipe.set_image(frame_image(WIDTH, HEIGHT, seed=rank))      # resident before the timed region
+    fast = not args.exact
+    total = args.warmup + args.steps
+
+    def step(k, ev=None):
+        hdr, cam, t, _ = sequence_frame(rank * total + k, WIDTH, HEIGHT)
+        p = frame_params(hdr, ALTITUDE, cam, t, fast)
+        if ev is not None:
+            ctx.record(ev[0])
+        pipe.georef(None, ALTITUDE, cam, t, fast, MIN_ELEV, params=p)
+        if ev is not None:
+            ctx.record(ev[1])
+        return pipe.resample(PPD, containsPole=False, keep_on_device=True)
+
+    for k in range(args.warmup):
+        step(k)
+    events = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    results = [step(args.warmup + k, events[k]) for k in range(args.steps)]
+    gathered = None
+    if world > 1:
+        gathered = gather_results(results, [rank * total + args.warmup + k for k in range(args.steps)], ctx.device)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        if rank == 0:
+            assert len(gathered) == world * args.steps
+
+    georef_ms = float(np.mean([ctx.elapsed_ms(a, b) for a, b in events]))
+
+    # stage timings of the binning kernels (outside the timed region, same inputs)
+    bb = pipe.bounding_box()
+    e0, e1 = ctx.event(), ctx.event()
+    from auromat_amd.resample import resample_frame
+    reps = 10
+    torch.cuda.synchronize()
+    ctx.record(e0)
+    for _ in range(reps):
+        resample_frame(pipe.fd, ALTITUDE, bb, (PPD, PPD), False, False, min_elevation=MIN_ELEV, keep_on_device=True)
+    ctx.record(e1)
+    bin_ms = ctx.elapsed_ms(e0, e1) / reps
+
+    if rank == 0:
+        npx = WIDTH * HEIGHT
+        ab = algorithmic_bytes(WIDTH, HEIGHT)
+        achieved = ab['georef'] / (georef_ms * 1e-3) / 1e9
+        info = ctx.device_info()
+        res = results[-1]
+        out = {
+            'metric': 'Mpixels/s georef+resample, 4240x2832 frame',
+            'value': world * args.steps * npx / 1e6 / elapsed,
+            'unit': 'Mpixels/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'configs[2]: 4240x2832 ISS-like frame, WCS ray cast + WGS84(+110 km) '
+                                   'intersection + geodetic transform + elevation (%s centres), '
+                                   'maskedByElevation(10), mean-resample to 0.1 deg plate-carree, uint16 RGB'
+                                   % ('fast' if fast else 'exact'),
+                       'frame': [WIDTH, HEIGHT], 'px_per_deg': PPD, 'grid': list(res['mean'].shape),
+                       'parallelism': 'frames sharded over %d GPU(s), RCCL gather of grids' % world,
+                       'device': info['name']},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_georef (amt_georef_frame)', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'algorithmic_bytes': ab['georef'], 'ms_per_launch': georef_ms},
+            'kernels': {
+                'georef_ms': georef_ms,
+                'georef_frac_directions_in_accounting': ab['georef_dirs_in'] / (georef_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'resample_ms_incl_grid_host_work': bin_ms,
+                'pipeline_frac_1129MB_contract': (ab['georef_dirs_in'] + ab['resample'])
+                / ((georef_ms + bin_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            },
+        }
+        if world == 1 and args.cpu_rows > 0:
+            out['cpu_baseline'] = cpu_baseline(min(args.cpu_rows, HEIGHT))
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

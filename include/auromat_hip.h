@@ -42,9 +42,10 @@ typedef struct amt_ctx amt_ctx;
 /* ---- context & memory --------------------------------------------------------------- */
 
 int amt_abi_version(void);
-/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = the
-   library creates and owns a non-blocking stream. */
-int amt_ctx_create(int device_id, void* stream, amt_ctx** out_ctx);
+/* stream: the hipStream_t to enqueue on, used as given — NULL is the device's default (null)
+   stream, which is also what torch.cuda.current_stream().cuda_stream reports unless a side stream
+   is active.  own_stream != 0: ignore `stream`, create and own a non-blocking stream instead. */
+int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ctx);
 int amt_ctx_destroy(amt_ctx* ctx);
 int amt_ctx_set_stream(amt_ctx* ctx, void* stream);
 void* amt_ctx_get_stream(amt_ctx* ctx);

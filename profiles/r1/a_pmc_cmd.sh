@@ -1,0 +1,8 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS"; do
+  tag=$(echo $set | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_r1a/$tag -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-rows 0 > $R/gpurun_out/pmc_r1a_$tag.log 2>&1
+  tail -1 $R/gpurun_out/pmc_r1a_$tag.log | cut -c1-200
+done
+find $R/gpurun_out/pmc_r1a -name "*counter_collection.csv" | head
