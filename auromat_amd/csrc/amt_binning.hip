@@ -108,12 +108,25 @@ struct bin_args {
     unsigned long long* acc;
 };
 
-constexpr int kBW = 64, kBH = 16, kWCap = 1024;
+constexpr int kPPT = 4;                      // consecutive pixels (along x) per thread
+constexpr int kBW = 64 * kPPT, kBH = kBlock / 64, kWCap = 1024;   // tile: 256 x 4 pixels, one image row per wave
 constexpr double kFix = 4294967296.0;   // 2^32
 
-template <typename IMG_T, int NCH>
+// Loads `kPPT` consecutive values; VEC promises 16-byte alignment and a full group inside the row.
+template <bool VEC>
+__device__ __forceinline__ void load_run(const double* __restrict__ p, int n_ok, double (&v)[kPPT]) {
+    if (VEC) {
+        const double2 a = *reinterpret_cast<const double2*>(p);
+        const double2 b = *reinterpret_cast<const double2*>(p + 2);
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kPPT; ++j) v[j] = j < n_ok ? p[j] : NAN;
+    }
+}
+
+template <typename IMG_T, int NCH, bool VEC>
 __global__ __launch_bounds__(kBlock) void k_bin_frame(bin_args A) {
-    constexpr int PPT = kBW * kBH / kBlock;   // pixels per thread
     __shared__ unsigned int sCnt[kWCap];
     __shared__ unsigned int sCh[NCH > 0 ? NCH : 1][kWCap];
     __shared__ unsigned long long sEl[kWCap];
@@ -121,48 +134,79 @@ __global__ __launch_bounds__(kBlock) void k_bin_frame(bin_args A) {
 
     const int tiles_x = (A.width + kBW - 1) / kBW;
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
-    const int gx = tile_x * kBW + (threadIdx.x & (kBW - 1));
-    const int row0 = tile_y * kBH + (threadIdx.x / kBW);
+    const int gx = tile_x * kBW + (threadIdx.x & 63) * kPPT;
+    const int gy = tile_y * kBH + (threadIdx.x >> 6);
     const int64_t ncell = (int64_t)A.ax.nbin * A.ay.nbin;
     const IMG_T* img = static_cast<const IMG_T*>(A.img);
+    const int n_ok = (gy < A.height) ? min(kPPT, A.width - gx) : 0;   // pixels of this thread inside the image
 
-    int ix[PPT], iy[PPT];
-    unsigned int ch[PPT][NCH > 0 ? NCH : 1];
-    long long el[PPT];
+    // ---- all loads first (one memory latency per tile), then arithmetic --------------------------
+    double la[kPPT], lo[kPPT], ev[kPPT];
+    unsigned int ch[kPPT][NCH > 0 ? NCH : 1];
+    unsigned char mk[kPPT];
+#pragma unroll
+    for (int j = 0; j < kPPT; ++j) {
+        la[j] = NAN; lo[j] = NAN; ev[j] = 0.0; mk[j] = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) ch[j][c] = 0;
+    }
+    if (n_ok > 0) {
+        const int64_t gi = (int64_t)gy * A.width + gx;
+        load_run<VEC>(A.lat_c + gi, n_ok, la);
+        load_run<VEC>(A.lon_c + gi, n_ok, lo);
+        if (A.elev) load_run<VEC>(A.elev + gi, n_ok, ev);
+        if (A.mask) {
+#pragma unroll
+            for (int j = 0; j < kPPT; ++j) mk[j] = j < n_ok ? A.mask[gi + j] : 1;
+        }
+        if (NCH > 0) {
+            const IMG_T* q = img + gi * NCH;
+            constexpr int kBytes = kPPT * NCH * (int)sizeof(IMG_T);
+            if (VEC && kBytes % 4 == 0) {
+                // the 4 pixels of a thread are kBytes contiguous, 4-byte aligned bytes: fetch them as dwords
+                constexpr int kWords = kBytes / 4;
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
+                uint32_t buf[kWords > 0 ? kWords : 1];
+#pragma unroll
+                for (int i = 0; i < kWords; ++i) buf[i] = w[i];
+#pragma unroll
+                for (int j = 0; j < kPPT; ++j)
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const int e = j * NCH + c;     // element index within the thread's run
+                        if (sizeof(IMG_T) == 2)
+                            ch[j][c] = (buf[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                        else
+                            ch[j][c] = (buf[e >> 2] >> ((e & 3) * 8)) & 0xffu;
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < kPPT; ++j)
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) ch[j][c] = (VEC || j < n_ok) ? q[j * NCH + c] : 0;
+            }
+        }
+    }
+
+    int cellx[kPPT], celly[kPPT];
     int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int gy = row0 + k * (kBlock / kBW);
-        ix[k] = 0;
-        iy[k] = 0;
-        el[k] = 0;
-        if (gx < A.width && gy < A.height) {
-            const int64_t gi = (int64_t)gy * A.width + gx;
-            const double la = A.lat_c[gi];
-            bool ok = la == la;                                            // resample.py:315-321
-            double ev = 0.0;
-            if (A.elev) {
-                ev = A.elev[gi];
-                if (A.use_elev_threshold) ok = ok && (ev >= A.min_elev);   // mapping.py:856
-            }
-            if (A.mask) ok = ok && A.mask[gi] == 0;
-            if (ok) {
-                double xv = A.lon_c[gi];
-                if (A.lon_wrap) xv = wrap180_shifted(xv);
-                const int bx = bin_index(A.ax, xv), by = bin_index(A.ay, la);
-                if (bx >= 1 && bx <= A.ax.nbin && by >= 1 && by <= A.ay.nbin) {
-                    ix[k] = bx;
-                    iy[k] = by;
-                    bx0 = min(bx0, bx);
-                    bx1 = max(bx1, bx);
-                    by0 = min(by0, by);
-                    by1 = max(by1, by);
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) ch[k][c] = img[gi * NCH + c];
-                    // a NaN elevation of a kept pixel poisons nothing here: it contributes 0 (the
-                    // reference would turn the cell's elevation into NaN; masks make this unreachable)
-                    el[k] = (ev == ev) ? __double2ll_rn(ev * kFix) : 0;
-                }
+    for (int j = 0; j < kPPT; ++j) {
+        bool ok = la[j] == la[j];                                          // resample.py:315-321
+        if (A.use_elev_threshold) ok = ok && (ev[j] >= A.min_elev);        // mapping.py:856
+        ok = ok && mk[j] == 0;
+        cellx[j] = 0;
+        celly[j] = 0;
+        if (ok) {
+            const double xv = A.lon_wrap ? wrap180_shifted(lo[j]) : lo[j];
+            const int bx = bin_index(A.ax, xv), by = bin_index(A.ay, la[j]);
+            if (bx >= 1 && bx <= A.ax.nbin && by >= 1 && by <= A.ay.nbin) {
+                cellx[j] = bx;
+                celly[j] = by;
+                bx0 = min(bx0, bx);
+                bx1 = max(bx1, bx);
+                by0 = min(by0, by);
+                by1 = max(by1, by);
             }
         }
     }
@@ -195,8 +239,9 @@ __global__ __launch_bounds__(kBlock) void k_bin_frame(bin_args A) {
     if (bx1 < 0) return;   // no pixel of this tile lands on the grid (uniform across the block)
     const int wnx = bx1 - bx0 + 1, wny = by1 - by0 + 1;
     const int64_t wn = (int64_t)wnx * wny;
+    const bool use_lds = wn <= kWCap;
 
-    if (wn <= kWCap) {
+    if (use_lds) {
         for (int i = threadIdx.x; i < (int)wn; i += kBlock) {
             sCnt[i] = 0;
             sEl[i] = 0;
@@ -204,16 +249,51 @@ __global__ __launch_bounds__(kBlock) void k_bin_frame(bin_args A) {
             for (int c = 0; c < NCH; ++c) sCh[c][i] = 0;
         }
         __syncthreads();
+    }
+    // consecutive pixels of a thread mostly share a cell: sum runs in registers, one atomic set per run.
+    // (a NaN elevation of a kept pixel contributes 0; the reference would poison the cell — the mask
+    //  invariants of mapping.py:299-316 make that unreachable)
+    int run_cell = -1;
+    unsigned int rcnt = 0, rch[NCH > 0 ? NCH : 1];
+    long long rel = 0;
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            if (ix[k] > 0) {
-                const int wi = (ix[k] - bx0) * wny + (iy[k] - by0);
-                atomicAdd(&sCnt[wi], 1u);
+    for (int c = 0; c < NCH; ++c) rch[c] = 0;
+    auto flush = [&](int cell_w) {
+        if (use_lds) {
+            atomicAdd(&sCnt[cell_w], rcnt);
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) atomicAdd(&sCh[c][wi], ch[k][c]);
-                atomicAdd(&sEl[wi], (unsigned long long)el[k]);
-            }
+            for (int c = 0; c < NCH; ++c) atomicAdd(&sCh[c][cell_w], rch[c]);
+            atomicAdd(&sEl[cell_w], (unsigned long long)rel);
+        } else {
+            // tile spreads over more cells than the LDS window holds (very fine grids): global atomics
+            const int wx = cell_w / wny, wy = cell_w - wx * wny;
+            const int64_t cell = (int64_t)(bx0 - 1 + wx) * A.ay.nbin + (by0 - 1 + wy);
+            atomicAdd(&A.acc[cell], (unsigned long long)rcnt);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) atomicAdd(&A.acc[(int64_t)(1 + c) * ncell + cell], (unsigned long long)rch[c]);
+            atomicAdd(&A.acc[(int64_t)(1 + NCH) * ncell + cell], (unsigned long long)rel);
         }
+    };
+#pragma unroll
+    for (int j = 0; j < kPPT; ++j) {
+        if (cellx[j] == 0) continue;
+        const int wi = (cellx[j] - bx0) * wny + (celly[j] - by0);
+        if (wi != run_cell) {
+            if (run_cell >= 0) flush(run_cell);
+            run_cell = wi;
+            rcnt = 0;
+            rel = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) rch[c] = 0;
+        }
+        rcnt += 1;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) rch[c] += ch[j][c];
+        rel += (ev[j] == ev[j]) ? __double2ll_rn(ev[j] * kFix) : 0;
+    }
+    if (run_cell >= 0) flush(run_cell);
+
+    if (use_lds) {
         __syncthreads();
         for (int i = threadIdx.x; i < (int)wn; i += kBlock) {
             const unsigned int cnt = sCnt[i];
@@ -224,18 +304,6 @@ __global__ __launch_bounds__(kBlock) void k_bin_frame(bin_args A) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) atomicAdd(&A.acc[(int64_t)(1 + c) * ncell + cell], (unsigned long long)sCh[c][i]);
             atomicAdd(&A.acc[(int64_t)(1 + NCH) * ncell + cell], sEl[i]);
-        }
-    } else {
-        // tile spreads over more cells than the LDS window holds (very fine grids): global atomics
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            if (ix[k] > 0) {
-                const int64_t cell = (int64_t)(ix[k] - 1) * A.ay.nbin + (iy[k] - 1);
-                atomicAdd(&A.acc[cell], 1ull);
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) atomicAdd(&A.acc[(int64_t)(1 + c) * ncell + cell], (unsigned long long)ch[k][c]);
-                atomicAdd(&A.acc[(int64_t)(1 + NCH) * ncell + cell], (unsigned long long)el[k]);
-            }
         }
     }
 }
@@ -356,8 +424,14 @@ int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const 
     A.acc = reinterpret_cast<unsigned long long*>(acc);
     const int tiles_x = (width + kBW - 1) / kBW, tiles_y = (height + kBH - 1) / kBH;
     const dim3 grid((unsigned)((int64_t)tiles_x * tiles_y)), block(kBlock);
-#define AMT_BIN_CASE(T, N)                                                          \
-    hipLaunchKernelGGL((k_bin_frame<T, N>), grid, block, 0, ctx->stream, A)
+    auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    // vector path: rows start 16-byte aligned and consist of whole 4-pixel groups
+    const bool vec = (width % kPPT == 0) && aligned16(lat_c) && aligned16(lon_c) && (elev == nullptr || aligned16(elev));
+#define AMT_BIN_CASE(T, N)                                                                  \
+    do {                                                                                    \
+        if (vec) hipLaunchKernelGGL((k_bin_frame<T, N, true>), grid, block, 0, ctx->stream, A);  \
+        else hipLaunchKernelGGL((k_bin_frame<T, N, false>), grid, block, 0, ctx->stream, A);     \
+    } while (0)
     const bool u8 = img_dtype == 1;
     switch (nchan) {
         case 0: AMT_BIN_CASE(uint8_t, 0); break;

@@ -203,6 +203,128 @@ __device__ __forceinline__ void sm_to_mlat_mlt(const vec3& s, double& mlat, doub
     mlt = (atan2(s.y, s.x) * kRad2Deg) * (24.0 / 360.0) + 12.0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Reduced-cost f64 math for the fused frame kernel.
+//
+// The frame kernel is FP64-VALU bound (93 % VALU-busy in profiles/r1), and the contract is
+// 1e-6 deg, not 0.5 ulp.  IEEE division / sqrt expand to 10-15 VALU instructions each and the
+// libm inverse trigonometry carries special-case handling the frame kernel never needs, so
+// it uses hardware seeds (v_rcp_f64 / v_rsq_f64: 4.6e-8 / 5.2e-8 relative on gfx950, measured with
+// tools/probe_f64_approx.hip) plus ONE Newton step (2.1e-15 / 4.1e-15) and a 9-term odd minimax
+// polynomial for atan (1.1e-13 relative).  Inputs must be finite (callers branch on hit/miss first).
+// ------------------------------------------------------------------------------------------
+namespace fm {
+
+__device__ __forceinline__ double rcp(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
+}
+
+// (sqrt(x), 1/sqrt(x)) from one v_rsq_f64 + one coupled Newton step; x > 0
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    s = fma(g, r, g);
+    rs = 2.0 * fma(h, r, h);
+}
+
+__device__ __forceinline__ double rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * y;
+    const double r = fma(-h, x * y, 0.5);
+    return 2.0 * fma(h, r, h);
+}
+
+// NaN for x < 0 (a missed ray), as sqrt() would give
+__device__ __forceinline__ double sqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y, h = 0.5 * y;
+    return fma(g, fma(-h, g, 0.5), g);
+}
+
+// atan(t) in DEGREES for |t| <= tan(pi/8): t * P(t^2), least-squares minimax fit (rel. error 1.1e-13)
+__device__ __forceinline__ double atan_core_deg(double t) {
+    const double s = t * t;
+    double p = 1.8906869702149334;
+    p = fma(p, s, -3.454838730079989);
+    p = fma(p, s, 4.3575716232982611);
+    p = fma(p, s, -5.2048471660339564);
+    p = fma(p, s, 6.3660331903476619);
+    p = fma(p, s, -8.1851078904860763);
+    p = fma(p, s, 11.45915587463822);
+    p = fma(p, s, -19.098593170990291);
+    p = fma(p, s, 57.295779513082323);
+    return p * t;
+}
+
+constexpr double kTanPi8 = 0.41421356237309503;
+
+// atan2(n, d) in degrees for d > 0 (result in (-90, 90))
+__device__ __forceinline__ double atan_pos_deg(double n, double d) {
+    const double an = fabs(n);
+    const bool flip = an > d;
+    const double mx = flip ? an : d, mn = flip ? d : an;
+    const bool big = mn > kTanPi8 * mx;
+    const double num = big ? mn - mx : mn;
+    const double den = big ? mn + mx : mx;
+    double r = atan_core_deg(num * rcp(den)) + (big ? 45.0 : 0.0);
+    r = flip ? 90.0 - r : r;
+    return copysign(r, n);
+}
+
+// atan2(y, x) in degrees, all quadrants; (0, 0) gives NaN instead of 0
+__device__ __forceinline__ double atan2_deg(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    const bool flip = ay > ax;
+    const double mx = flip ? ay : ax, mn = flip ? ax : ay;
+    const bool big = mn > kTanPi8 * mx;
+    const double num = big ? mn - mx : mn;
+    const double den = big ? mn + mx : mx;
+    double r = atan_core_deg(num * rcp(den)) + (big ? 45.0 : 0.0);
+    r = flip ? 90.0 - r : r;
+    r = x < 0 ? 180.0 - r : r;
+    return copysign(r, y);
+}
+
+// asin(c) in degrees, |c| <= 1
+__device__ __forceinline__ double asin_deg(double c) {
+    const double q = (1.0 - c) * (1.0 + c);
+    const double d = q > 0 ? sqrt_pos(q) : 0.0;
+    return atan_pos_deg(c, d);
+}
+
+}  // namespace fm
+
+// Bowring single step as in ecef_to_geodetic, degrees out, with the reduced-cost primitives:
+// 3 rsqrt + 2 rcp instead of 3 sqrt + 4 div + atan + atan2.
+struct bowring_fast {
+    double b_over_a, d, e2a;
+};
+
+__host__ inline bowring_fast make_bowring_fast(double a, double b) {
+    bowring_fast w;
+    w.b_over_a = b / a;
+    w.d = (a * a - b * b) / b;
+    w.e2a = ((a * a - b * b) / (a * a)) * a;
+    return w;
+}
+
+__device__ __forceinline__ void ecef_to_geodetic_deg_fast(const bowring_fast& w, double x, double y, double z,
+                                                          double& lat_deg, double& lon_deg) {
+    const double p2 = x * x + y * y;
+    double p, ip;
+    fm::sqrt_rsqrt(p2, p, ip);
+    const double ir = fm::rsqrt(p2 + z * z);
+    const double tu = w.b_over_a * z * fma(w.d, ir, 1.0) * ip;
+    const double tu2 = tu * tu;
+    const double c = fm::rsqrt(1.0 + tu2);
+    const double cu3 = c * c * c;
+    const double su3 = cu3 * tu2 * tu;
+    lat_deg = fm::atan_pos_deg(fma(w.d, su3, z), fma(-w.e2a, cu3, p));
+    lon_deg = fm::atan2_deg(y, x);
+}
+
 // True when the closed longitude path o00 -> o01 -> o11 -> o10 -> o00 (corner quad of one pixel, degrees)
 // winds once around a geographic pole: the wrapped longitude steps then sum to +-360 instead of 0.
 __device__ __forceinline__ bool quad_winds_pole(double o00, double o01, double o11, double o10) {

@@ -23,8 +23,12 @@ from .._native import Context, FrameParams, GeorefOut, ptr, to_host
 from .mapping import BaseMapping, GenericMapping, inflatedEarthIntersection
 
 
-def frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fastCenterCalculation):
-    """The amt_frame_params block of one frame: WCS cards + camera + per-frame rotation matrices."""
+def frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fastCenterCalculation, magnetic=True):
+    """
+    The amt_frame_params block of one frame: WCS cards + camera + per-frame rotation matrices.
+    magnetic=False skips the J2000->SM matrix (IGRF dipole, four more rotations) when no MLat/MLT
+    output is requested.
+    """
     p = fill_wcs_params(FrameParams(), wcsHeader)
     p.fast_center = 1 if fastCenterCalculation else 0
     p.cam[:] = [float(v) for v in cameraPosGCRS]
@@ -32,8 +36,56 @@ def frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fastCenterCalcul
     p.a0, p.b0 = wgs84A, wgs84B                              # transform.py:338
     et = date2es(photoTime)
     p.m_geo[:] = list(mat_j2000_to_geo(et).ravel())
-    p.m_sm[:] = list(mat_j2000_to_sm(et).ravel())
+    if magnetic:
+        p.m_sm[:] = list(mat_j2000_to_sm(et).ravel())
     return p
+
+
+def pole_in_view(params, min_elevation=None, magnetic=False):
+    """
+    Host-side pole test for camera mappings: is the geographic (or, with magnetic=True, the SM) north
+    or south pole of the mapping shell imaged by a valid pixel?  The pole point is projected through
+    the inverse TAN model; it counts when it falls inside the frame, is the *first* hit of its ray
+    and lies above the elevation threshold.  Replaces, for frames with a known camera model, the
+    outline-based geodesic test of the reference (geodesic.py:183, mapping.py:705-721) at zero
+    per-pixel cost.  Returns +1 (north), -1 (south) or 0.
+    """
+    rot = np.array(params.rot[:]).reshape(3, 3)
+    cd = np.array(params.cd[:]).reshape(2, 2)
+    cam = np.array(params.cam[:])
+    m = np.array(params.m_sm[:] if magnetic else params.m_geo[:]).reshape(3, 3)
+    a, b = params.a, params.b
+    scale = np.array([1 / a, 1 / a, 1 / b])
+    for sign in (1, -1):
+        u = m.T.dot([0.0, 0.0, float(sign)])                 # pole axis in J2000
+        pole = u / np.sqrt(np.sum((u * scale) ** 2))          # point of the shell on that axis
+        los = pole - cam
+        dist = np.sqrt(los.dot(los))
+        d = los / dist
+        # first intersection of the ray with the shell (same quadratic as intersection.py:58-104)
+        ds, os_ = d * scale, -cam * scale
+        d_o, d_d, o_o = ds.dot(os_), ds.dot(ds), os_.dot(os_)
+        disc = d_o * d_o - o_o * d_d + d_d
+        if disc < 0:
+            continue
+        inside = np.sum((cam * scale) ** 2) < 1
+        t = ((d_o + np.sqrt(disc)) if inside else (d_o - np.sqrt(disc))) / d_d
+        if abs(t - dist) > 1e-6 * dist:
+            continue                                           # the pole is on the far side
+        v = rot.T.dot(d)                                       # native (projection) frame
+        if v[2] <= 0:
+            continue
+        k = 180 / np.pi
+        px, py = np.linalg.solve(cd, [k * v[1] / v[2], -k * v[0] / v[2]])
+        x, y = px + params.crpix[0] - 1, py + params.crpix[1] - 1
+        if not (-0.5 <= x <= params.width - 0.5 and -0.5 <= y <= params.height - 0.5):
+            continue
+        if min_elevation is not None:
+            elev = np.rad2deg(np.arcsin(np.clip(-d.dot(pole) / np.sqrt(pole.dot(pole)), -1, 1)))
+            if not elev >= min_elevation:
+                continue
+        return sign
+    return 0
 
 
 def georef_into(fd, params, geo=True, mag=False, bbox_min_elevation=None):

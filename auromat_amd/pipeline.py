@@ -19,7 +19,7 @@ import ctypes as C
 import numpy as np
 
 from .frame import FrameData
-from .mapping.astrometry import frame_params
+from .mapping.astrometry import frame_params, pole_in_view
 from .mapping.mapping import bounding_box_from_reduction
 from .resample import resample_frame
 from ._native import Context, GeorefOut, ptr, to_host
@@ -41,6 +41,8 @@ class FramePipeline(object):
         fd.img_dtype = np.dtype(img_dtype)
         fd.img = ctx.empty((h, w, nchan), torch.uint8 if fd.img_dtype == np.uint8 else torch.int16)
         self.with_mag = with_mag
+        self._bbox_host = torch.empty(8, dtype=torch.float64, pin_memory=True)
+        self._bbox_event = torch.cuda.Event()
         self.params = None
         self.altitude = None
         self.min_elevation = None
@@ -56,7 +58,8 @@ class FramePipeline(object):
     def georef(self, wcsHeader, altitude, cameraPosGCRS, photoTime, fast=True, min_elevation=10.0, params=None):
         """Stage 1.  `params` (an amt_frame_params made by :func:`frame_params`) skips the host set-up."""
         assert wcsHeader is None or (wcsHeader['IMAGEW'], wcsHeader['IMAGEH']) == (self.width, self.height)
-        p = params if params is not None else frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fast)
+        p = params if params is not None else frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fast,
+                                                           magnetic=self.with_mag)
         fd = self.fd
         out = GeorefOut()
         out.lat, out.lon, out.lat_c, out.lon_c, out.elev = (t.data_ptr() for t in
@@ -67,14 +70,21 @@ class FramePipeline(object):
         out.bbox = fd.bbox.data_ptr()
         out.bbox_min_elevation = float('-inf') if min_elevation is None else float(min_elevation)
         self.ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
+        # the 8 reduction doubles travel to pinned host memory right behind the kernel; the event lets
+        # bounding_box() wait for exactly this point while later launches keep the GPU busy
+        self._bbox_host.copy_(fd.bbox, non_blocking=True)
+        self._bbox_event.record()
         self.params, self.altitude, self.min_elevation = p, altitude, min_elevation
         return fd
 
     def bounding_box(self):
-        """Reads the fused reduction (synchronises) -> BoundingBox; ValueError if nothing is valid."""
-        red = to_host(self.fd.bbox)
+        """Waits for the fused reduction of the last georef() -> BoundingBox; ValueError if nothing is valid."""
+        self._bbox_event.synchronize()
+        red = self._bbox_host.numpy().copy()
         if red[6] == 0:
             raise ValueError('minElevation=' + str(self.min_elevation) + ' would mask all pixels!')
+        # pole containment from the camera model (the fused kernel does not count pole quads)
+        red[7] = 1.0 if pole_in_view(self.params, self.min_elevation) else 0.0
         return bounding_box_from_reduction(red)
 
     def resample(self, pxPerDeg=10, containsPole=None, magnetic=False, keep_on_device=False):

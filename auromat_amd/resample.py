@@ -117,8 +117,8 @@ def fixedGrid(pxPerDeg, latMin, latMax, lonMin, lonMax):
     :param lonMin,lonMax: must NOT contain the discontinuity
     """
     latPxPerDeg, lonPxPerDeg = pxPerDeg
-    latSpaceAll = np.linspace(-90, 90, int(round(latPxPerDeg * 180 + 1)))
-    lonSpaceAll = np.linspace(-180, 180, int(round(lonPxPerDeg * 360 + 1)))
+    latSpaceAll = _global_axis(-90, 90, int(round(latPxPerDeg * 180 + 1)))
+    lonSpaceAll = _global_axis(-180, 180, int(round(lonPxPerDeg * 360 + 1)))
     latMinInGrid = latSpaceAll[np.argmax(latSpaceAll > latMin) - 1]
     latMaxInGrid = latSpaceAll[np.argmax(latSpaceAll >= latMax)]
     lonMinInGrid = lonSpaceAll[np.argmax(lonSpaceAll > lonMin) - 1]
@@ -126,6 +126,18 @@ def fixedGrid(pxPerDeg, latMin, latMax, lonMin, lonMax):
     nLat = int(round(latPxPerDeg * (latMaxInGrid - latMinInGrid) + 1))
     nLon = int(round(lonPxPerDeg * (lonMaxInGrid - lonMinInGrid) + 1))
     return nLat, nLon, latMinInGrid, latMaxInGrid, lonMinInGrid, lonMaxInGrid
+
+
+_GLOBAL_AXES = {}
+
+
+def _global_axis(lo, hi, n):
+    key = (lo, hi, n)
+    if key not in _GLOBAL_AXES:
+        if len(_GLOBAL_AXES) > 64:
+            _GLOBAL_AXES.clear()
+        _GLOBAL_AXES[key] = np.linspace(lo, hi, n)
+    return _GLOBAL_AXES[key]
 
 
 class _Grid(object):
@@ -145,14 +157,30 @@ class _Grid(object):
         self.latCenters = latSpaceCenter[1:-1]
         self.lonCenters = lonSpaceCenter[1:-1]
         self.latStep, self.lonStep = latStep, lonStep
-        self.lat, self.lon = np.dstack(np.meshgrid(latSpace, lonSpace)).T
-        self.lat_c, self.lon_c = np.dstack(np.meshgrid(self.latCenters, self.lonCenters)).T
+        self._latSpace, self._lonSpace = latSpace, lonSpace
+        self._corner_grid = self._center_grid = None
         self.nx, self.ny = len(self.lonCenters), len(self.latCenters)
         # histogram ranges; latitude edges ascend, the output is flipped afterwards
         self.xrange = [self.lonCenters[0] - lonStep / 2, self.lonCenters[-1] + lonStep / 2]
         self.yrange = [self.latCenters[-1] + latStep / 2, self.latCenters[0] - latStep / 2]
         self.xedges = np.linspace(self.xrange[0], self.xrange[1], self.nx + 1)
         self.yedges = np.linspace(self.yrange[0], self.yrange[1], self.ny + 1)
+
+    # 2-D coordinate arrays of the output mapping (reference resample.py:239-241), built on first use
+    def _corners(self):
+        if self._corner_grid is None:
+            self._corner_grid = np.dstack(np.meshgrid(self._latSpace, self._lonSpace)).T
+        return self._corner_grid
+
+    def _centers(self):
+        if self._center_grid is None:
+            self._center_grid = np.dstack(np.meshgrid(self.latCenters, self.lonCenters)).T
+        return self._center_grid
+
+    lat = property(lambda self: self._corners()[0])
+    lon = property(lambda self: self._corners()[1])
+    lat_c = property(lambda self: self._centers()[0])
+    lon_c = property(lambda self: self._centers()[1])
 
 
 def _rot_x(angle):
@@ -224,20 +252,29 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
     ctx.call('amt_bin_frame_finalize', ptr(acc), grid.nx, grid.ny, nch, fd.img_dtype_code or 1, ptr(mean),
              ptr(img) if nch else None, ptr(mask), ptr(count))
 
-    lat, lon, lat_gc, lon_gc = grid.lat, grid.lon, grid.lat_c, grid.lon_c
-    if containsPole:
-        lat, lon = _rotate_pole_host(lat, lon, altitude, -90)            # reference resample.py:262-273
-        lat_gc, lon_gc = _rotate_pole_host(lat_gc, lon_gc, altitude, -90)
-    elif containsDiscontinuity:
-        lon = wrap_at_180(lon + 180)                                     # reference resample.py:274-277
-        lon_gc = wrap_at_180(lon_gc + 180)
-    out = dict(lat=lat, lon=lon, lat_c=lat_gc, lon_c=lon_gc, has_elev=fd.elev is not None, grid=grid)
+    out = dict(has_elev=fd.elev is not None, grid=grid, contains_pole=bool(containsPole),
+               contains_discontinuity=bool(containsDiscontinuity), altitude=altitude)
     if keep_on_device:
+        # sequence mode: the grid is described by `grid` (first centre + step); coordinate arrays on demand
         out.update(mean=mean, img=img, mask=mask, count=count)
-    else:
-        out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype if nch else np.uint8),
-                   mask=to_host(mask).astype(bool), count=to_host(count))
+        return out
+    out.update(grid_coordinates(out))
+    out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype if nch else np.uint8),
+               mask=to_host(mask).astype(bool), count=to_host(count))
     return out
+
+
+def grid_coordinates(res):
+    """Corner / centre coordinate arrays of a resample_frame result (reference resample.py:239-241,261-277)."""
+    grid = res['grid']
+    lat, lon, lat_gc, lon_gc = grid.lat, grid.lon, grid.lat_c, grid.lon_c
+    if res['contains_pole']:
+        lat, lon = _rotate_pole_host(lat, lon, res['altitude'], -90)            # reference resample.py:262-273
+        lat_gc, lon_gc = _rotate_pole_host(lat_gc, lon_gc, res['altitude'], -90)
+    elif res['contains_discontinuity']:
+        lon = wrap_at_180(lon + 180)                                             # reference resample.py:274-277
+        lon_gc = wrap_at_180(lon_gc + 180)
+    return dict(lat=lat, lon=lon, lat_c=lat_gc, lon_c=lon_gc)
 
 
 def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingBox, pxPerDeg,

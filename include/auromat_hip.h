@@ -93,12 +93,12 @@ typedef struct amt_frame_params {
 /* Output block of amt_georef_frame.  Any pointer may be NULL (that array is not written).
  * Corner arrays have (height+1)*(width+1) elements, centre arrays height*width.
  * bbox (optional, 8 doubles, device): [lat_min, lat_max, lon_min, lon_max, lon_min_positive,
- * lon_max_nonpositive, n_valid_centres, n_pole_quads] over the corners of centres with
+ * lon_max_nonpositive, n_valid_centres, 0] over the corners of centres with
  * elevation >= bbox_min_elevation — the inputs of BaseMapping.boundingBox
  * (auromat/mapping/mapping.py:693-743) for a mapping that was maskedByElevation()'d
- * (mapping.py:845-864).  n_pole_quads counts valid pixels whose corner quadrilateral winds once
- * around a geographic pole (sum of wrapped longitude steps = +-360 deg): non-zero <=> the mapping
- * contains a pole (what geodesic.py:183 containsOrCrossesPole decides from the outline). */
+ * (mapping.py:845-864).  Slot 7 (pole containment, what geodesic.py:183 containsOrCrossesPole decides
+ * from the outline) is left 0 here: with a camera model the host projects the pole into the frame
+ * instead; amt_bbox_corners fills it for arbitrary grids. */
 typedef struct amt_georef_out {
     double* lat;      /* corners, deg   (BaseAstrometryMapping.lats,  astrometry.py:118-144) */
     double* lon;      /* corners, deg */
