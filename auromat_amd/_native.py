@@ -33,7 +33,8 @@ class GeorefOut(C.Structure):
 class Axis(C.Structure):
     """amt_axis"""
     _fields_ = [('edges', C.c_void_p), ('nbin', C.c_int32), ('uniform', C.c_int32),
-                ('first', C.c_double), ('last', C.c_double), ('scale', C.c_double), ('last_rounded', C.c_double)]
+                ('first', C.c_double), ('last', C.c_double), ('step', C.c_double), ('scale', C.c_double),
+                ('last_rounded', C.c_double)]
 
 
 _I, _L, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p

@@ -20,8 +20,18 @@ struct axis_dev {
     int nbin;
     int uniform;
     double scale, last_rounded;
-    double e0, e_last, inv_step;
+    double e0, e_last, step, inv_step;
 };
+
+// Edge i of a uniform axis, bit-identical to np.linspace(e0, e_last, nbin+1)[i]:
+// arange(num)*step + start with two roundings (contraction to an FMA would change the last bit),
+// and the end point stored exactly (numpy/_core/function_base.py: y = y*step + start; y[-1] = stop).
+__device__ __forceinline__ double linspace_edge(const axis_dev& ax, int i) {
+#pragma clang fp contract(off)
+    const double m = (double)i * ax.step;
+    const double e = m + ax.e0;
+    return i >= ax.nbin ? ax.e_last : e;
+}
 
 // searchsorted(edges, v, 'right') with the right-most-edge rule of histogram.py:209-224.
 // Returns 0..nbin+1; 0 and nbin+1 are outliers (NaN sorts to the end like NumPy does).
@@ -36,8 +46,11 @@ __device__ __forceinline__ int bin_index(const axis_dev& ax, double v) {
     if (ax.uniform) {
         g = (int)((v - ax.e0) * ax.inv_step);
         g = g < 0 ? 0 : (g > ax.nbin - 1 ? ax.nbin - 1 : g);
-        while (v < ax.edges[g]) --g;          // e0 <= v < e_last bounds both walks
-        while (v >= ax.edges[g + 1]) ++g;
+        // the guess is off by at most one; e0 <= v < e_last bounds both corrections
+        if (v < linspace_edge(ax, g)) --g;
+        else if (v >= linspace_edge(ax, g + 1)) ++g;
+        while (v < linspace_edge(ax, g)) --g;
+        while (v >= linspace_edge(ax, g + 1)) ++g;
     } else {
         int lo = 0, hi = ax.nbin;             // invariant: edges[lo] <= v < edges[hi]
         while (hi - lo > 1) {
@@ -340,7 +353,14 @@ void make_axis(const amt_axis* a, axis_dev* out) {
     out->last_rounded = a->last_rounded;
     out->e0 = a->first;
     out->e_last = a->last;
+    out->step = a->uniform ? a->step : 0.0;
     out->inv_step = a->nbin / (a->last - a->first);
+}
+
+bool axis_ok(const amt_axis* a) {
+    if (a == nullptr || a->nbin <= 0 || !(a->last > a->first)) return false;
+    if (a->uniform) return a->step > 0;
+    return a->edges != nullptr;
 }
 
 inline dim3 grid_for(int64_t n) {
@@ -361,8 +381,7 @@ int amt_hist2d_accumulate(amt_ctx* ctx, const double* x, const double* y, int64_
     AMT_REQUIRE(ctx, xaxis && yaxis && count, "NULL argument");
     AMT_REQUIRE(ctx, n >= 0 && nweights >= 0 && nweights <= kMaxWeights, "bad n or too many weight arrays (max 8)");
     AMT_REQUIRE(ctx, nweights == 0 || (weights && sums), "weights/sums missing");
-    AMT_REQUIRE(ctx, xaxis->edges && yaxis->edges && xaxis->nbin > 0 && yaxis->nbin > 0 && xaxis->last > xaxis->first &&
-                         yaxis->last > yaxis->first, "bad axis");
+    AMT_REQUIRE(ctx, axis_ok(xaxis) && axis_ok(yaxis), "bad axis");
     if (n == 0) return AMT_OK;
     AMT_REQUIRE(ctx, x && y, "NULL coordinates");
     hist_args A;
@@ -406,8 +425,7 @@ int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const 
     AMT_REQUIRE(ctx, height > 0 && width > 0, "empty frame");
     AMT_REQUIRE(ctx, nchan >= 0 && nchan <= 4, "nchan must be 0..4");
     AMT_REQUIRE(ctx, nchan == 0 || (img && (img_dtype == 1 || img_dtype == 2)), "img must be uint8 (1) or uint16 (2)");
-    AMT_REQUIRE(ctx, xaxis->edges && yaxis->edges && xaxis->nbin > 0 && yaxis->nbin > 0 && xaxis->last > xaxis->first &&
-                         yaxis->last > yaxis->first, "bad axis");
+    AMT_REQUIRE(ctx, axis_ok(xaxis) && axis_ok(yaxis), "bad axis");
     bin_args A;
     A.lat_c = lat_c;
     A.lon_c = lon_c;

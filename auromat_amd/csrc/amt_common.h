@@ -366,6 +366,17 @@ __device__ __forceinline__ vec3 tan_direction(const tan_wcs& w, double x, double
     return mul(w.rot, v);
 }
 
+// Same with the reduced-cost reciprocal square root (|d| = 1 to 4e-15), for the fused frame kernel.
+__device__ __forceinline__ vec3 tan_direction_fast(const tan_wcs& w, double x, double y) {
+    const double px = x - w.crpix[0] + 1.0;
+    const double py = y - w.crpix[1] + 1.0;
+    const double X = w.cd[0] * px + w.cd[1] * py;
+    const double Y = w.cd[2] * px + w.cd[3] * py;
+    const double inv = fm::rsqrt(X * X + Y * Y + kRad2Deg * kRad2Deg);
+    vec3 v = {-Y * inv, X * inv, kRad2Deg * inv};
+    return mul(w.rot, v);
+}
+
 // astropy Angle.wrap_at(180 deg) of (v + 180), reference resample.py:212-218
 __device__ __forceinline__ double wrap180_shifted(double v) {
     double a = v + 180.0;

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void k_georef(georef_args A) {
                 d.y = A.dirs_in[3 * gi + 1];
                 d.z = A.dirs_in[3 * gi + 2];
             } else {
-                d = tan_direction(A.wcs, gx - 0.5, gy - 0.5);
+                d = tan_direction_fast(A.wcs, gx - 0.5, gy - 0.5);
             }
             const double t = ray_param_fast(A.ray, d);
             const bool hit = t == t;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void k_georef(georef_args A) {
                 d.y = (((sD[1][c00] + sD[1][c01]) + sD[1][c11]) + sD[1][c10]) * 0.25;
                 d.z = (((sD[2][c00] + sD[2][c01]) + sD[2][c11]) + sD[2][c10]) * 0.25;
             } else {
-                d = tan_direction(A.wcs, (double)gx, (double)gy);
+                d = tan_direction_fast(A.wcs, (double)gx, (double)gy);
                 p = ray_point(A.ray, d, ray_param_fast(A.ray, d));
                 if (want_bbox) {
                     // after sanitisation a centre also needs its 4 corners (reference mapping.py:1093-1101)
@@ -246,6 +246,179 @@ __global__ __launch_bounds__(kThreads) void k_georef(georef_args A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Row-marching variant: no LDS, no workgroup barriers.
+//
+// One WAVE owns a strip of 63 pixel columns (64 corner columns, one per lane) and marches down
+// `rows` pixel rows.  Each lane casts the ray of its corner column once per corner row and keeps the
+// previous row's hit in registers; a pixel's four corners are then (own previous, own current) plus
+// the same two of lane+1, fetched with DPP wave shifts.  Redundancy: 64/63 horizontally, (rows+1)/rows
+// vertically.  The bounding box is accumulated from the corner side with a one-row delay (a corner
+// row is final once the centre row below it has been classified).
+// ------------------------------------------------------------------------------------------
+constexpr int kDppWaveShl1 = 0x130;   // lane i <- lane i+1
+constexpr int kDppWaveShr1 = 0x138;   // lane i <- lane i-1
+
+__device__ __forceinline__ double from_next_lane(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), kDppWaveShl1, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), kDppWaveShl1, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ int from_next_lane(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, kDppWaveShl1, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int from_prev_lane(int v) {   // lane 0 receives 0
+    return __builtin_amdgcn_update_dpp(0, v, kDppWaveShr1, 0xf, 0xf, false);
+}
+
+template <bool FAST, bool DIRS_IN, bool MAG>
+__global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int rows_per_chunk, int strips_x,
+                                                           int n_items) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);      // one work item per wave
+    if (item >= n_items) return;                                            // wave-uniform
+    const int chunk = item / strips_x, strip = item - chunk * strips_x;
+    const int x0 = strip * 63, y0 = chunk * rows_per_chunk;
+    const int rows = min(rows_per_chunk, A.height - y0);
+    const int gx = x0 + lane;
+    const int W1 = A.width + 1;
+    const bool col_ok = gx <= A.width;                 // this lane's corner column exists
+    const bool px_ok = lane < 63 && gx < A.width;      // this lane's pixel column exists (and is owned)
+    const bool want_bbox = A.bbox_partials != nullptr;
+
+    vec3 p_prev = {NAN, NAN, NAN}, d_prev = {NAN, NAN, NAN};
+    double la_prev = NAN, lo_prev = NAN;
+    int flag_prev = 0;
+    double v[8] = {kInf, -kInf, kInf, -kInf, kInf, -kInf, 0, 0};
+
+    for (int r = 0; r <= rows; ++r) {
+        const int gy = y0 + r;
+        // ---- corner (gy, gx) ------------------------------------------------------------------
+        vec3 d = {NAN, NAN, NAN}, p = {NAN, NAN, NAN};
+        double la = NAN, lo = NAN;
+        if (col_ok) {
+            const int64_t gi = (int64_t)gy * W1 + gx;
+            if (DIRS_IN) {
+                d.x = A.dirs_in[3 * gi];
+                d.y = A.dirs_in[3 * gi + 1];
+                d.z = A.dirs_in[3 * gi + 2];
+            } else {
+                d = tan_direction_fast(A.wcs, gx - 0.5, gy - 0.5);
+            }
+            const double t = ray_param_fast(A.ray, d);
+            const bool hit = t == t;
+            if (hit) {
+                p = ray_point(A.ray, d, t);
+                const vec3 g = mul(A.m_geo, p);
+                ecef_to_geodetic_deg_fast(A.bw, g.x, g.y, g.z, la, lo);
+            }
+            // the last corner row of a chunk is the first of the next one (which owns it) unless it is
+            // the image's last; lane 63's column likewise belongs to the next strip unless it is the last
+            const bool owner = (lane < 63 || gx == A.width) && (r < rows || gy == A.height);
+            if (owner) {
+                if (A.lat) A.lat[gi] = la;
+                if (A.lon) A.lon[gi] = lo;
+                if (MAG && A.mlat) {
+                    double ml = NAN, mt = NAN;
+                    if (hit) sm_to_mlat_mlt_fast(mul(A.m_sm, p), ml, mt);
+                    A.mlat[gi] = ml;
+                    A.mlt[gi] = mt;
+                }
+            }
+        }
+        int flag_cur = 0;
+        if (r > 0) {
+            // ---- centre (gy-1, gx): corners own/next lane x previous/current row -----------------
+            vec3 pc, dc;
+            bool corners_ok = true;
+            if (FAST) {
+                // mean of the 4 corner hits / directions (reference astrometry.py:154-160); the summation
+                // order differs from the reference's by rounding only (<= 1e-12 deg)
+                const double sx = p_prev.x + p.x, sy = p_prev.y + p.y, sz = p_prev.z + p.z;
+                const double tx = d_prev.x + d.x, ty = d_prev.y + d.y, tz = d_prev.z + d.z;
+                pc.x = (sx + from_next_lane(sx)) * 0.25;
+                pc.y = (sy + from_next_lane(sy)) * 0.25;
+                pc.z = (sz + from_next_lane(sz)) * 0.25;
+                dc.x = (tx + from_next_lane(tx)) * 0.25;
+                dc.y = (ty + from_next_lane(ty)) * 0.25;
+                dc.z = (tz + from_next_lane(tz)) * 0.25;
+            } else {
+                dc = tan_direction_fast(A.wcs, (double)gx, (double)(gy - 1));
+                pc = ray_point(A.ray, dc, ray_param_fast(A.ray, dc));
+                if (want_bbox) {
+                    // after sanitisation a centre also needs its 4 corners (reference mapping.py:1093-1101)
+                    const int h = (p_prev.x == p_prev.x) && (p.x == p.x);
+                    corners_ok = h && from_next_lane(h);
+                }
+            }
+            bool valid = false;
+            if (px_ok) {
+                const int64_t gi = (int64_t)(gy - 1) * A.width + gx;
+                double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN;
+                if (pc.x == pc.x) {
+                    const vec3 g = mul(A.m_geo, pc);
+                    ecef_to_geodetic_deg_fast(A.bw, g.x, g.y, g.z, lac, loc);
+                    // reference astrometry.py:200-212, utils.py:33-46: 90 - angle(-d, P/|P|) = asin(-d.P/|P|)
+                    double c = -(dc.x * pc.x + dc.y * pc.y + dc.z * pc.z) * fm::rsqrt(dot(pc, pc));
+                    c = fmin(1.0, fmax(-1.0, c));
+                    el = fm::asin_deg(c);
+                    if (MAG && A.mlat_c) sm_to_mlat_mlt_fast(mul(A.m_sm, pc), ml, mt);
+                }
+                if (A.lat_c) A.lat_c[gi] = lac;
+                if (A.lon_c) A.lon_c[gi] = loc;
+                if (A.elev) A.elev[gi] = el;
+                if (MAG && A.mlat_c) {
+                    A.mlat_c[gi] = ml;
+                    A.mlt_c[gi] = mt;
+                }
+                valid = (el >= A.bbox_min_elev) && corners_ok;
+            }
+            if (want_bbox) {
+                // corner row gy-1 is final now: it keeps a corner when a centre above (flag_prev) or below
+                // (this row: own pixel or the left neighbour's) is valid
+                const int vi = valid ? 1 : 0;
+                flag_cur = vi | from_prev_lane(vi);
+                v[6] += vi;
+                if ((flag_prev | flag_cur) && la_prev == la_prev) {
+                    v[0] = fmin(v[0], la_prev);
+                    v[1] = fmax(v[1], la_prev);
+                    v[2] = fmin(v[2], lo_prev);
+                    v[3] = fmax(v[3], lo_prev);
+                    if (lo_prev > 0) v[4] = fmin(v[4], lo_prev); else v[5] = fmax(v[5], lo_prev);
+                }
+            }
+        }
+        p_prev = p;
+        d_prev = d;
+        la_prev = la;
+        lo_prev = lo;
+        flag_prev = flag_cur;
+    }
+    if (want_bbox) {
+        // the chunk's last corner row only has centres above it inside this chunk
+        if (flag_prev && la_prev == la_prev) {
+            v[0] = fmin(v[0], la_prev);
+            v[1] = fmax(v[1], la_prev);
+            v[2] = fmin(v[2], lo_prev);
+            v[3] = fmax(v[3], lo_prev);
+            if (lo_prev > 0) v[4] = fmin(v[4], lo_prev); else v[5] = fmax(v[5], lo_prev);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            v[0] = fmin(v[0], __shfl_xor(v[0], o));
+            v[1] = fmax(v[1], __shfl_xor(v[1], o));
+            v[2] = fmin(v[2], __shfl_xor(v[2], o));
+            v[3] = fmax(v[3], __shfl_xor(v[3], o));
+            v[4] = fmin(v[4], __shfl_xor(v[4], o));
+            v[5] = fmax(v[5], __shfl_xor(v[5], o));
+            v[6] += __shfl_xor(v[6], o);
+        }
+        if (lane < 8) A.bbox_partials[(int64_t)item * 8 + lane] = lane == 0 ? v[0] : lane == 1 ? v[1] : lane == 2 ? v[2]
+                                                                  : lane == 3 ? v[3] : lane == 4 ? v[4]
+                                                                  : lane == 5 ? v[5] : lane == 6 ? v[6] : 0.0;
+    }
+}
+
 // Folds bbox partials ([n][8]) into gridDim.x rows of out ([gridDim.x][8]); launched twice (n -> 64 -> 1).
 __global__ __launch_bounds__(kThreads) void k_bbox_fold(const double* __restrict__ partials, int n,
                                                          double* __restrict__ out) {
@@ -277,6 +450,15 @@ void launch_variant(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag) {
         hipLaunchKernelGGL((k_georef<kTW, kTH, FAST, DIRS_IN, false>), grid, block, 0, ctx->stream, A);
 }
 
+template <bool FAST, bool DIRS_IN>
+void launch_rows(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, int rows, int strips_x, int n_items) {
+    const dim3 block(kThreads);
+    if (mag)
+        hipLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, true>), grid, block, 0, ctx->stream, A, rows, strips_x, n_items);
+    else
+        hipLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, false>), grid, block, 0, ctx->stream, A, rows, strips_x, n_items);
+}
+
 int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, const amt_georef_out* out) {
     AMT_REQUIRE(ctx, p && out, "NULL argument");
     AMT_REQUIRE(ctx, p->width > 0 && p->height > 0, "empty frame");
@@ -303,31 +485,54 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     A.mlat_c = out->mlat_c;
     A.mlt_c = out->mlt_c;
     A.bbox_min_elev = out->bbox_min_elevation;
+    // kernel selection: row-marching waves (default) or LDS tiles (AMT_GEOREF_KERNEL=tile), for A/B runs
+    static const bool use_tiles = [] {
+        const char* e = std::getenv("AMT_GEOREF_KERNEL");
+        return e != nullptr && std::strcmp(e, "tile") == 0;
+    }();
+    static const int rows_per_chunk = [] {
+        const char* e = std::getenv("AMT_GEOREF_ROWS");
+        const int v = e ? std::atoi(e) : 0;
+        return v > 0 ? v : 16;
+    }();
     const int tiles_x = (p->width + kTW - 1) / kTW, tiles_y = (p->height + kTH - 1) / kTH;
-    const int64_t nblocks = (int64_t)tiles_x * tiles_y;
-    AMT_REQUIRE(ctx, nblocks < (1ll << 31), "frame too large");
+    const int strips_x = (p->width + 1 + 62) / 63;                       // 64 corner columns, 63 owned, per strip
+    const int chunks_y = (p->height + rows_per_chunk - 1) / rows_per_chunk;
+    const int64_t n_items = use_tiles ? (int64_t)tiles_x * tiles_y : (int64_t)strips_x * chunks_y;
+    const int64_t nblocks = use_tiles ? n_items : (n_items + kThreads / 64 - 1) / (kThreads / 64);
+    AMT_REQUIRE(ctx, n_items < (1ll << 31), "frame too large");
     A.bbox_partials = nullptr;
     double* fold = nullptr;
     if (out->bbox) {
-        A.bbox_partials = static_cast<double*>(amt_workspace(ctx, (size_t)(nblocks + kFoldBlocks) * 8 * sizeof(double)));
+        A.bbox_partials = static_cast<double*>(amt_workspace(ctx, (size_t)(n_items + kFoldBlocks) * 8 * sizeof(double)));
         if (A.bbox_partials == nullptr) {
             ctx->last_error = "amt_georef_frame: workspace allocation failed";
             return AMT_ENOMEM;
         }
-        fold = A.bbox_partials + nblocks * 8;
+        fold = A.bbox_partials + n_items * 8;
     }
     const dim3 grid((unsigned)nblocks);
     const bool mag = out->mlat != nullptr || out->mlat_c != nullptr;
-    if (dirs) {
-        launch_variant<true, true>(ctx, A, grid, mag);
-    } else if (p->fast_center) {
-        launch_variant<true, false>(ctx, A, grid, mag);
+    if (use_tiles) {
+        if (dirs) {
+            launch_variant<true, true>(ctx, A, grid, mag);
+        } else if (p->fast_center) {
+            launch_variant<true, false>(ctx, A, grid, mag);
+        } else {
+            launch_variant<false, false>(ctx, A, grid, mag);
+        }
     } else {
-        launch_variant<false, false>(ctx, A, grid, mag);
+        if (dirs) {
+            launch_rows<true, true>(ctx, A, grid, mag, rows_per_chunk, strips_x, (int)n_items);
+        } else if (p->fast_center) {
+            launch_rows<true, false>(ctx, A, grid, mag, rows_per_chunk, strips_x, (int)n_items);
+        } else {
+            launch_rows<false, false>(ctx, A, grid, mag, rows_per_chunk, strips_x, (int)n_items);
+        }
     }
     AMT_LAUNCH_CHECK(ctx);
     if (out->bbox) {
-        hipLaunchKernelGGL(k_bbox_fold, dim3(kFoldBlocks), dim3(kThreads), 0, ctx->stream, A.bbox_partials, (int)nblocks,
+        hipLaunchKernelGGL(k_bbox_fold, dim3(kFoldBlocks), dim3(kThreads), 0, ctx->stream, A.bbox_partials, (int)n_items,
                            fold);
         AMT_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, ctx->stream, fold, kFoldBlocks, out->bbox);

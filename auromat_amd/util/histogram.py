@@ -23,11 +23,22 @@ def make_axis(ctx, edges, uniform=False):
         raise ValueError("Found bin edge of size <= 0. Did you specify `bins` with"
                          "non-monotonic sequence?")
     ax = Axis()
-    dev = ctx.to_device(edges)
-    ax.edges = dev.data_ptr()
-    ax.nbin = len(edges) - 1
-    ax.uniform = 1 if uniform else 0
+    ax.nbin = nbin = len(edges) - 1
     ax.first, ax.last = float(edges[0]), float(edges[-1])
+    dev = None
+    if uniform:
+        # np.linspace builds arange(n)*step + start and stores the end point; when the given edges
+        # are exactly that, the kernel evaluates them in registers and no table is uploaded
+        step = (edges[-1] - edges[0]) / nbin
+        rebuilt = np.arange(0, nbin + 1) * step + edges[0]
+        rebuilt[-1] = edges[-1]
+        uniform = step > 0 and np.array_equal(rebuilt, edges)
+        if uniform:
+            ax.step = float(step)
+    ax.uniform = 1 if uniform else 0
+    if not uniform:
+        dev = ctx.to_device(edges)
+        ax.edges = dev.data_ptr()
     mindiff = dedges.min()
     if np.isinf(mindiff):
         ax.scale, ax.last_rounded = 1.0, float('nan')       # rule disabled (histogram.py:218)

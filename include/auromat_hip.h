@@ -211,14 +211,19 @@ int amt_bbox_corners(amt_ctx* ctx, const double* lat, const double* lon, const u
 
 /* Bin-edge description of one axis, reference semantics of auromat/util/histogram.py:178-224:
  * index = searchsorted(edges, v, 'right') (0 and nbin+1 are outliers), and values v >= edges[nbin]
- * with rint(v*scale)/scale == last_rounded fall into the last bin.  `edges` is a DEVICE array of
- * nbin+1 ascending doubles (np.linspace output for uniform grids); `scale` = 10**decimal and
- * `last_rounded` = around(edges[-1], decimal) are computed by the host exactly as the reference does. */
+ * with rint(v*scale)/scale == last_rounded fall into the last bin.  `scale` = 10**decimal and
+ * `last_rounded` = around(edges[-1], decimal) are computed by the host exactly as the reference does.
+ * uniform = 0: `edges` is a DEVICE array of nbin+1 ascending doubles, searched by bisection.
+ * uniform = 1: the edges are exactly what np.linspace(first, last, nbin+1) produces, i.e.
+ *   edges[i] = fl(fl(i*step) + first) for i < nbin (two roundings, no FMA), edges[nbin] = last, with
+ *   step = (last-first)/nbin; the kernel evaluates them in registers (O(1) guess + exact fix-up) and
+ *   `edges` may be NULL.  The host must have verified that identity for its edge array. */
 typedef struct amt_axis {
     const double* edges;
     int32_t nbin;
-    int32_t uniform;      /* 1: edges are (numerically) evenly spaced -> O(1) guess + exact fix-up */
-    double first, last;   /* host copies of edges[0] and edges[nbin] */
+    int32_t uniform;
+    double first, last;   /* edges[0] and edges[nbin] */
+    double step;          /* uniform axes: (last-first)/nbin */
     double scale;
     double last_rounded;
 } amt_axis;

@@ -43,7 +43,7 @@ def test_struct_layouts_match_header():
     from auromat_amd._native import Axis, FrameParams, GeorefOut
     assert C.sizeof(FrameParams) == 16 + 8 * (4 + 2 + 9 + 3 + 4 + 9 + 9)
     assert C.sizeof(GeorefOut) == 8 * 11
-    assert C.sizeof(Axis) == 8 + 8 + 8 * 4
+    assert C.sizeof(Axis) == 8 + 8 + 8 * 5
 
 
 def test_no_cpu_fallback(lib):
