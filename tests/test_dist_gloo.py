@@ -1,0 +1,86 @@
+"""
+Multi-process (world_size 2, gloo, CPU tensors) test of the frame sharding and the padded gather of
+per-frame grids used for sequences (auromat_amd/sequence.py).  The GPU run uses the same code with
+backend "nccl" (= RCCL) and device tensors.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _fake_result(k):
+    """Deterministic stand-in for a resample_frame(keep_on_device=True) result of frame k (shape varies with k)."""
+    from auromat_amd.resample import _Grid
+    grid = _Grid((4, 5), 40.0 + 0.3 * k, 43.0 + 0.37 * k, -100.0 + k, -96.5 + 1.2 * k)
+    rs = np.random.RandomState(k)
+    mean = rs.uniform(0, 65535, (grid.ny, grid.nx, 4))
+    mean[rs.rand(grid.ny, grid.nx) < 0.2] = np.nan
+    count = rs.randint(0, 50, (grid.ny, grid.nx)).astype(np.float64)
+    return dict(mean=torch.from_numpy(mean), count=torch.from_numpy(count), grid=grid)
+
+
+def _worker(rank, world, port, n_frames, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from auromat_amd.sequence import gather_results, shard
+    mine = shard(n_frames, rank, world)
+    results = [_fake_result(k) for k in mine]
+    got = gather_results(results, mine, torch.device('cpu'))
+    if rank == 0:
+        assert [f['index'] for f in got] == list(range(n_frames))
+        for f in got:
+            ref = _fake_result(f['index'])
+            np.testing.assert_array_equal(f['mean'], ref['mean'].numpy())
+            np.testing.assert_array_equal(f['count'], ref['count'].numpy())
+            assert f['lat0'] == ref['grid'].latCenters[0] and f['lon0'] == ref['grid'].lonCenters[0]
+            assert f['dlat'] == ref['grid'].latStep and f['dlon'] == ref['grid'].lonStep
+        open(os.path.join(out_dir, 'ok'), 'w').write('ok')
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_frames', [5, 2, 1])
+def test_gather_of_frame_grids_world2(tmp_path, n_frames):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_frames, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / 'ok').exists()
+
+
+def test_shard_is_a_contiguous_partition():
+    from auromat_amd.sequence import shard
+    for n in (0, 1, 7, 8, 256, 257):
+        for world in (1, 2, 3, 8):
+            parts = [shard(n, r, world) for r in range(world)]
+            assert sum(parts, []) == list(range(n))
+            sizes = [len(p) for p in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    from auromat_amd.sequence import pack_results, unpack_results
+    results = [_fake_result(k) for k in (3, 9)]
+    descs, payload = pack_results(results, [3, 9], torch.device('cpu'))
+    out = unpack_results(descs, payload)
+    assert [f['index'] for f in out] == [3, 9]
+    for f, r in zip(out, results):
+        np.testing.assert_array_equal(f['mean'], r['mean'].numpy())

@@ -1,0 +1,289 @@
+"""
+GPU parity tests at frame level: awkward frame sizes, the directions-in variant, exact centres end to
+end, uint8 images, full-size frames against the reference's strided samples + digests, and
+size-independent properties at BASELINE.json's full size (pixel conservation, determinism, linearity
+of the sums in the image, agreement of the fused pipeline with the mapping classes).
+"""
+from datetime import datetime
+
+import numpy as np
+import numpy.ma as ma
+import pytest
+
+from conftest import header_from, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL_DEG = 1e-6
+
+
+def parse(s):
+    return datetime.strptime(str(s), '%Y-%m-%dT%H:%M:%S.%f')
+
+
+def nan_close(a, b, tol, max_mask_mismatch=0):
+    mism = int((np.isnan(a) != np.isnan(b)).sum())
+    assert mism <= max_mask_mismatch, 'NaN masks differ in %d places' % mism
+    ok = ~np.isnan(a) & ~np.isnan(b)
+    err = np.max(np.abs(a[ok] - b[ok]), initial=0.0)
+    assert err <= tol, 'max abs error %.3e > %.1e' % (err, tol)
+
+
+def oracle_frame(hdr, cam, t, fast, alt=110):
+    from oracle import ref_numpy as O
+    et = O.date2es(t)
+    return O.georef_frame(hdr, alt, cam, O.mat_j2000_to_geo(et), O.mat_j2000_to_sm(et), fast=fast)
+
+
+def oracle_resample(g, img, min_elev, ppd, alt=110):
+    from oracle import ref_numpy as O
+    corner_mask, center_mask = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), min_elev)
+    bbox, disc = O.bbox_of_corners(g['lat'], g['lon'], corner_mask)
+    data = np.dstack((img.astype(np.float64), g['elev']))
+    data[center_mask] = np.nan
+    res = O.resample_mean(np.where(center_mask, np.nan, g['lat_c']), np.where(center_mask, np.nan, g['lon_c']), alt,
+                          data, None, bbox, (ppd, ppd), disc, False)
+    return res, bbox
+
+
+@pytest.mark.parametrize('width,height,pointing,fast', [
+    (253, 171, 'iss030', True),    # not a multiple of 4 / 63 / 16: scalar bin path, partial strips and chunks
+    (61, 35, 'iss029', True),      # narrower than one strip
+    (130, 97, 'iss030', False),    # exact centres
+    (64, 16, 'iss030', True),      # exactly one tile of the LDS variant
+])
+def test_awkward_sizes_vs_oracle(width, height, pointing, fast):
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_header, frame_image
+    hdr, cam, t = frame_header(width, height, pointing)
+    img = frame_image(width, height, seed=5)
+    pipe = FramePipeline(width, height, with_mag=True)
+    res = pipe.run(hdr, 110, cam, t, img=img, fast=fast, min_elevation=10, pxPerDeg=7)
+    got = pipe.host_arrays()
+    g = oracle_frame(hdr, cam, t, fast)
+    for k in ('lat', 'lon', 'lat_c', 'lon_c', 'elev', 'mlat', 'mlat_c'):
+        nan_close(got[k], g[k], TOL_DEG)
+    for k in ('mlt', 'mlt_c'):
+        nan_close(got[k], g[k], TOL_DEG * 24 / 360)
+    if not fast:
+        # the reference sanitises exact-mode mappings: centres lose pixels whose corners miss
+        from oracle import ref_numpy as O
+        cm, ce = O.sanitize_masks(np.isnan(g['lat']), np.isnan(g['lat_c']))
+        g = dict(g, lat=np.where(cm, np.nan, g['lat']), lon=np.where(cm, np.nan, g['lon']),
+                 lat_c=np.where(ce, np.nan, g['lat_c']), lon_c=np.where(ce, np.nan, g['lon_c']),
+                 elev=np.where(ce, np.nan, g['elev']))
+    want, bbox = oracle_resample(g, img, 10, 7)
+    bb = pipe.bounding_box()
+    np.testing.assert_allclose([bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast], bbox, rtol=0, atol=1e-9)
+    assert want['data'].shape == res['mean'].shape
+    assert (want['count'] != res['count']).sum() <= 2
+    same = (want['count'] == res['count']) & (want['count'] > 0)
+    assert np.array_equal(res['mean'][..., :3][same], want['data'][..., :3][same])
+
+
+def test_directions_in_variant_matches_wcs_fused():
+    """amt_georef_frame_dirs (caller-supplied corner directions) == amt_georef_frame on the same rays."""
+    import ctypes as C
+    from auromat_amd._native import Context, GeorefOut, to_host
+    from auromat_amd.coordinates.wcs import pix2world
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.synthetic import frame_header
+    w, h = 200, 150
+    hdr, cam, t = frame_header(w, h)
+    ctx = Context.current()
+    p = frame_params(hdr, 110, cam, t, True)
+    dirs = pix2world(hdr, w, h, corner=True, ascartesian=True, device=ctx.device)
+    outs = []
+    for use_dirs in (False, True):
+        o = GeorefOut()
+        bufs = dict(lat=ctx.empty((h + 1, w + 1)), lon=ctx.empty((h + 1, w + 1)), lat_c=ctx.empty((h, w)),
+                    lon_c=ctx.empty((h, w)), elev=ctx.empty((h, w)))
+        for k, v in bufs.items():
+            setattr(o, k, v.data_ptr())
+        if use_dirs:
+            ctx.call('amt_georef_frame_dirs', C.byref(p), C.c_void_p(dirs.data_ptr()), C.byref(o))
+        else:
+            ctx.call('amt_georef_frame', C.byref(p), C.byref(o))
+        outs.append({k: to_host(v) for k, v in bufs.items()})
+    for k in outs[0]:
+        nan_close(outs[0][k], outs[1][k], 1e-9)
+
+
+def test_uint8_image_and_generic_mapping_roundtrip():
+    from auromat_amd.mapping.spacecraft import getMapping
+    from auromat_amd.resample import resample
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 240, 160
+    hdr, cam, t = frame_header(w, h)
+    hdr = dict(hdr, **{'DATE-OBS': t.strftime('%Y-%m-%dT%H:%M:%S.%f'), 'POSX': cam[0], 'POSY': cam[1], 'POSZ': cam[2]})
+    img = frame_image(w, h, seed=9, dtype=np.uint8)
+    m = getMapping(img, hdr, altitude=110, fastCenterCalculation=True)
+    assert m.photoTime == t and np.array_equal(m.cameraPosGCRS, cam)
+    mm = m.maskedByElevation(10)
+    r = resample(mm, pxPerDeg=5)
+    assert r.img.dtype == np.uint8 and r.img.shape[2] == 3
+    r.checkPlateCarree()
+    r.checkGuarantees()
+    g = oracle_frame(hdr, cam, t, True)
+    want, _ = oracle_resample(g, img, 10, 5)
+    mask = np.isnan(want['data'][..., 0])
+    assert np.array_equal(ma.getmaskarray(r.img)[..., 0], mask)
+    with np.errstate(invalid='ignore'):
+        assert np.array_equal(r.img.data[~mask], np.round(want['data'][..., :3])[~mask].astype(np.uint8))
+    # resampling the resampled mapping again at a coarser resolution works on the uploaded GenericMapping
+    r2 = resample(r, pxPerDeg=2)
+    r2.checkPlateCarree()
+    assert r2.img.count() > 0
+
+
+@pytest.mark.parametrize('name', ['georef_full_iss030_fast.npz', 'georef_full_iss030_exact.npz',
+                                  'georef_full_iss029_fast.npz'])
+def test_full_size_frames_vs_reference_samples(name):
+    """Real 4256x2832 headers: every 32nd row/col and whole-array digests of the reference's arrays."""
+    from auromat_amd.pipeline import FramePipeline
+    z = load_golden(name)
+    hdr = header_from(z)
+    step = int(z['step'])
+    pipe = FramePipeline(hdr['IMAGEW'], hdr['IMAGEH'], with_mag=True)
+    pipe.georef(hdr, float(z['altitude']), z['cam'], parse(z['time_iso']), fast=name.endswith('fast.npz'),
+                min_elevation=10)
+    got = pipe.host_arrays()
+    for k in ('lat', 'lon', 'lat_c', 'lon_c', 'elev', 'mlat', 'mlat_c'):
+        nan_close(got[k][::step, ::step], z[k], TOL_DEG)
+    for k in ('mlt', 'mlt_c'):
+        nan_close(got[k][::step, ::step], z[k], TOL_DEG * 24 / 360)
+    for k in ('lat', 'lon', 'lat_c', 'lon_c', 'elev'):
+        n, s, lo, hi, sabs = z['digest_' + k]
+        a = got[k]
+        ok = ~np.isnan(a)
+        assert abs(int(ok.sum()) - int(n)) <= 2, k          # rays within rounding of tangency
+        assert abs(a[ok].min() - lo) < TOL_DEG and abs(a[ok].max() - hi) < TOL_DEG
+        assert abs(a[ok].sum() - s) <= 1e-9 * sabs + 400.0  # <= 2 extra/missing values of |x| <= 180
+
+
+@pytest.fixture(scope='module')
+def full_frame():
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 4240, 2832
+    hdr, cam, t = frame_header(w, h)
+    img = frame_image(w, h, seed=0)
+    pipe = FramePipeline(w, h)
+    res = pipe.run(hdr, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10)
+    return dict(pipe=pipe, res=res, hdr=hdr, cam=cam, t=t, img=img)
+
+
+def test_full_size_properties(full_frame):
+    """BASELINE.json size (4240x2832): properties that do not need the oracle."""
+    pipe, res, img = full_frame['pipe'], full_frame['res'], full_frame['img']
+    a = pipe.host_arrays()
+    # fast centres: valid <=> all four corners valid; elevation within [0, 90]
+    cn = np.isnan(a['lat'])
+    all4 = ~(cn[:-1, :-1] | cn[:-1, 1:] | cn[1:, :-1] | cn[1:, 1:])
+    assert np.array_equal(~np.isnan(a['lat_c']), all4)
+    assert np.array_equal(np.isnan(a['lat_c']), np.isnan(a['elev']))
+    e = a['elev'][~np.isnan(a['elev'])]
+    assert e.min() >= 0 and e.max() <= 90
+    # conservation: every pixel above the threshold lands in exactly one cell of the (superset) grid,
+    # except those in the discarded half-cell ring (reference resample.py:232-237)
+    keep = a['elev'] >= 10
+    g = res['grid']
+    inside = keep & (a['lon_c'] >= g.xrange[0]) & (a['lon_c'] < g.xrange[1]) & \
+        (a['lat_c'] >= g.yrange[0]) & (a['lat_c'] < g.yrange[1])
+    assert int(res['count'].sum()) == int(inside.sum())
+    assert 0 < inside.sum() <= keep.sum()
+    # sum of sums: mean * count summed over cells == sum of the binned pixels (exact integers)
+    filled = res['count'] > 0
+    total = (res['mean'][..., :3][filled] * res['count'][filled][:, None]).sum(axis=0)
+    want = img[inside].astype(np.float64).sum(axis=0)
+    np.testing.assert_allclose(total, want, rtol=1e-12)
+    # bounding box equals the extremes of the corners adjacent to a kept pixel
+    kc = np.zeros(cn.shape, bool)
+    kc[:-1, :-1] |= keep
+    kc[:-1, 1:] |= keep
+    kc[1:, :-1] |= keep
+    kc[1:, 1:] |= keep
+    bb = pipe.bounding_box()
+    assert bb.latSouth == a['lat'][kc].min() and bb.latNorth == a['lat'][kc].max()
+    assert bb.lonWest == a['lon'][kc].min() and bb.lonEast == a['lon'][kc].max()
+
+
+def test_full_size_determinism_and_linearity(full_frame):
+    pipe, res = full_frame['pipe'], full_frame['res']
+    again = pipe.run(full_frame['hdr'], 110, full_frame['cam'], full_frame['t'], fast=True, min_elevation=10, pxPerDeg=10)
+    for k in ('mean', 'count', 'img', 'mask'):
+        assert np.array_equal(again[k], res[k], equal_nan=True), k     # integer accumulation: bit reproducible
+    half = (full_frame['img'] // 2).astype(np.uint16)
+    r2 = pipe.run(full_frame['hdr'], 110, full_frame['cam'], full_frame['t'], img=half, fast=True, min_elevation=10,
+                  pxPerDeg=10)
+    r3 = pipe.run(full_frame['hdr'], 110, full_frame['cam'], full_frame['t'], img=(full_frame['img'] - half),
+                  fast=True, min_elevation=10, pxPerDeg=10)
+    filled = res['count'] > 0
+    np.testing.assert_allclose((r2['mean'] + r3['mean'])[..., :3][filled], res['mean'][..., :3][filled], rtol=1e-14)
+    pipe.set_image(full_frame['img'])
+
+
+def test_mapping_classes_agree_with_fused_pipeline(full_frame):
+    """getMapping(...).maskedByElevation(10) -> resample(): the lazy class path equals the fused pipeline."""
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.resample import resample
+    m = ArraySpacecraftMapping(full_frame['hdr'], 110, full_frame['img'], full_frame['cam'], full_frame['t'], 'f',
+                               fastCenterCalculation=True)
+    mm = m.maskedByElevation(10)
+    bb, pb = mm.boundingBox, full_frame['pipe'].bounding_box()
+    assert (bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast) == (pb.latSouth, pb.lonWest, pb.latNorth, pb.lonEast)
+    assert not mm.containsPole and not mm.containsDiscontinuity
+    r = resample(mm, pxPerDeg=10)
+    res = full_frame['res']
+    assert np.array_equal(r.img.data, res['img']) and np.array_equal(ma.getmaskarray(r.img)[..., 0], res['mask'])
+    assert np.array_equal(r.elevation.data, res['mean'][..., 3], equal_nan=True)
+    assert np.array_equal(r.lats.data, res['lat']) and np.array_equal(r.lonsCenter.data, res['lon_c'])
+
+
+def test_sequence_single_gpu_equals_frame_by_frame():
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.sequence import run_sequence
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    w, h = 320, 214
+    frames = []
+    for k in range(3):
+        hdr, cam, t, seed = sequence_frame(k, w, h)
+        frames.append((hdr, cam, t, frame_image(w, h, seed=seed)))
+    out = run_sequence(frames, w, h, pxPerDeg=5)
+    assert [f['index'] for f in out] == [0, 1, 2]
+    pipe = FramePipeline(w, h)
+    for f, (hdr, cam, t, img) in zip(out, frames):
+        res = pipe.run(hdr, 110, cam, t, img=img, pxPerDeg=5)
+        assert np.array_equal(f['mean'], res['mean'], equal_nan=True) and np.array_equal(f['count'], res['count'])
+        assert f['lat0'] == res['grid'].latCenters[0] and f['lon0'] == res['grid'].lonCenters[0]
+
+
+def test_pole_detection_camera_model_and_winding():
+    """A camera above the pole: host projection test (fused path) and quad winding (generic path) agree."""
+    from auromat_amd.mapping.astrometry import frame_params, pole_in_view
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.coordinates import transform as T
+    from auromat_amd.resample import resample
+    t = datetime(2012, 1, 25, 9, 26, 55)
+    w, h = 96, 96
+    # camera 400 km above the geographic north pole, looking straight down: boresight = -z_GEO in J2000
+    m_geo = T.mat_j2000_to_geo(T.date2es(t))
+    zen = m_geo.T.dot([0.0, 0.0, 1.0])
+    cam = zen * (6356.75 + 400.0)
+    bore = -zen
+    ra = np.rad2deg(np.arctan2(bore[1], bore[0])) % 360
+    dec = np.rad2deg(np.arcsin(bore[2]))
+    hdr = {'CTYPE1': 'RA---TAN', 'CTYPE2': 'DEC--TAN', 'LONPOLE': 180.0, 'LATPOLE': 0.0, 'CRVAL1': ra, 'CRVAL2': dec,
+           'CRPIX1': w / 2 + 0.5, 'CRPIX2': h / 2 + 0.5, 'CD1_1': -0.5, 'CD1_2': 0.0, 'CD2_1': 0.0, 'CD2_2': 0.5,
+           'IMAGEW': w, 'IMAGEH': h}
+    p = frame_params(hdr, 110, cam, t, True)
+    assert pole_in_view(p, 10.0) == 1
+    m = ArraySpacecraftMapping(hdr, 110, np.full((h, w, 3), 1000, np.uint16), cam, t, 'pole', fastCenterCalculation=True)
+    assert m.containsPole and m.boundingBox.latNorth == 90 and m.boundingBox.lonWest == -180
+    r = resample(m, pxPerDeg=2)
+    assert r.img.count() > 0 and np.all(r.img.compressed() == 1000)
+    assert float(r.latsCenter.max()) > 89.0
+    # the usual ISS frames do not contain a pole
+    from auromat_amd.synthetic import frame_header
+    hdr2, cam2, t2 = frame_header(128, 96)
+    assert pole_in_view(frame_params(hdr2, 110, cam2, t2, True), 10.0) == 0
