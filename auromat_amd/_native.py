@@ -56,6 +56,8 @@ _SIGNATURES = {
     'amt_event_destroy': ([_P, _P], _I),
     'amt_event_record': ([_P, _P], _I),
     'amt_event_elapsed_ms': ([_P, _P, _P, C.POINTER(C.c_float)], _I),
+    'amt_timing_enable': ([_P, _I], _I),
+    'amt_timing_read': ([_P, _I, C.POINTER(C.c_double), C.POINTER(_I)], _I),
     'amt_directions_tan': ([_P, C.POINTER(FrameParams), _I, _P], _I),
     'amt_directions_tan_points': ([_P, C.POINTER(FrameParams), _P, _P, _L, _I, _P], _I),
     'amt_intersect_ellipsoid': ([_P, _D, _D, c_double_p, _P, _L, _I, _P], _I),
@@ -202,6 +204,16 @@ class Context(object):
             t = torch.from_numpy(a.view(np.int16)).to(self.device)
             return t
         return torch.from_numpy(a).to(self.device)
+
+    # -- per-kernel timing ----------------------------------------------------------------------
+    def timing_enable(self, enable=True):
+        self.call('amt_timing_enable', 1 if enable else 0)
+
+    def timing_read(self, kernel):
+        """(total ms, launches) of kernel 0 (georef) / 1 (bin) since timing was enabled. Synchronises."""
+        ms, n = C.c_double(), C.c_int()
+        self.call('amt_timing_read', kernel, C.byref(ms), C.byref(n))
+        return ms.value, n.value
 
     # -- events -------------------------------------------------------------------------------
     def event(self):

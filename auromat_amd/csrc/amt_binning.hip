@@ -451,6 +451,7 @@ int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const 
         else hipLaunchKernelGGL((k_bin_frame<T, N, false>), grid, block, 0, ctx->stream, A);     \
     } while (0)
     const bool u8 = img_dtype == 1;
+    amt_timing_mark(ctx, AMT_KERNEL_BIN);
     switch (nchan) {
         case 0: AMT_BIN_CASE(uint8_t, 0); break;
         case 1: if (u8) AMT_BIN_CASE(uint8_t, 1); else AMT_BIN_CASE(uint16_t, 1); break;
@@ -459,6 +460,7 @@ int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const 
         default: if (u8) AMT_BIN_CASE(uint8_t, 4); else AMT_BIN_CASE(uint16_t, 4); break;
     }
 #undef AMT_BIN_CASE
+    amt_timing_mark(ctx, AMT_KERNEL_BIN);
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/auromat_hip.h"
 
@@ -19,7 +20,26 @@ struct amt_ctx {
     void* ws;               // grow-only device workspace (per-block partial reductions)
     size_t ws_bytes;
     std::string last_error;
+    // optional per-kernel timing (amt_timing_*): event pairs recorded around the dominant kernels
+    bool timing;
+    std::vector<hipEvent_t> tev[2];   // [kernel kind] start0, stop0, start1, stop1, ...
+    size_t tused[2];
 };
+
+constexpr int kTimingMaxLaunches = 4096;
+
+// Records an event on the stream for kernel kind `kind` (0 georef, 1 bin) when timing is enabled.
+// Call once before and once after the launch; events are created lazily and reused.
+static inline void amt_timing_mark(amt_ctx* ctx, int kind) {
+    if (!ctx->timing) return;
+    if (ctx->tused[kind] >= (size_t)2 * kTimingMaxLaunches) return;
+    if (ctx->tused[kind] >= ctx->tev[kind].size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        ctx->tev[kind].push_back(e);
+    }
+    (void)hipEventRecord(ctx->tev[kind][ctx->tused[kind]++], ctx->stream);
+}
 
 // Returns a device workspace of at least `bytes` (grow-only; reallocation synchronises the stream).
 static inline void* amt_workspace(amt_ctx* ctx, size_t bytes) {

@@ -18,6 +18,8 @@ int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ct
     ctx->scratch = nullptr;
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
+    ctx->timing = false;
+    ctx->tused[0] = ctx->tused[1] = 0;
     if (hipSetDevice(device_id) != hipSuccess) {
         delete ctx;
         return AMT_EHIP;
@@ -45,6 +47,8 @@ int amt_ctx_destroy(amt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    for (int k = 0; k < 2; ++k)
+        for (hipEvent_t e : ctx->tev[k]) (void)hipEventDestroy(e);
     if (ctx->owns_stream) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
@@ -159,6 +163,29 @@ int amt_event_elapsed_ms(amt_ctx* ctx, void* start, void* stop, float* out_ms) {
     AMT_REQUIRE(ctx, start && stop && out_ms, "NULL argument");
     AMT_HIP(ctx, hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
     AMT_HIP(ctx, hipEventElapsedTime(out_ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+    return AMT_OK;
+}
+
+int amt_timing_enable(amt_ctx* ctx, int enable) {
+    AMT_CHECK_CTX(ctx);
+    ctx->timing = enable != 0;
+    ctx->tused[0] = ctx->tused[1] = 0;
+    return AMT_OK;
+}
+
+int amt_timing_read(amt_ctx* ctx, int kernel, double* total_ms, int* launches) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, (kernel == AMT_KERNEL_GEOREF || kernel == AMT_KERNEL_BIN) && total_ms && launches, "bad argument");
+    const size_t n = ctx->tused[kernel] / 2;
+    double sum = 0;
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0;
+        AMT_HIP(ctx, hipEventSynchronize(ctx->tev[kernel][2 * i + 1]));
+        AMT_HIP(ctx, hipEventElapsedTime(&ms, ctx->tev[kernel][2 * i], ctx->tev[kernel][2 * i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int)n;
     return AMT_OK;
 }
 

@@ -513,6 +513,7 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     }
     const dim3 grid((unsigned)nblocks);
     const bool mag = out->mlat != nullptr || out->mlat_c != nullptr;
+    amt_timing_mark(ctx, AMT_KERNEL_GEOREF);
     if (use_tiles) {
         if (dirs) {
             launch_variant<true, true>(ctx, A, grid, mag);
@@ -530,6 +531,7 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
             launch_rows<false, false>(ctx, A, grid, mag, rows_per_chunk, strips_x, (int)n_items);
         }
     }
+    amt_timing_mark(ctx, AMT_KERNEL_GEOREF);
     AMT_LAUNCH_CHECK(ctx);
     if (out->bbox) {
         hipLaunchKernelGGL(k_bbox_fold, dim3(kFoldBlocks), dim3(kThreads), 0, ctx->stream, A.bbox_partials, (int)n_items,

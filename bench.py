@@ -119,6 +119,7 @@ def main():
 
     run(0, args.warmup)
     events = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
+    ctx.timing_enable(True)
 
     def fence():
         torch.cuda.synchronize()
@@ -141,20 +142,14 @@ def main():
         if rank == 0:
             assert len(gathered) == world * args.steps
 
-    georef_ms = float(np.mean([ctx.elapsed_ms(a, b) for a, b in events]))
-
-    # stage timings of the binning kernels (outside the timed region, same inputs)
-    pipe = pipes[(total - 1) % 2]
-    bb = pipe.bounding_box()
-    e0, e1 = ctx.event(), ctx.event()
-    from auromat_amd.resample import resample_frame
-    reps = 10
-    torch.cuda.synchronize()
-    ctx.record(e0)
-    for _ in range(reps):
-        resample_frame(pipe.fd, ALTITUDE, bb, (PPD, PPD), False, False, min_elevation=MIN_ELEV, keep_on_device=True)
-    ctx.record(e1)
-    bin_ms = ctx.elapsed_ms(e0, e1) / reps
+    # kernel durations measured live over the timed region: HIP events recorded by the library directly
+    # around each k_georef_rows / k_bin_frame launch, on the stream they run on
+    stage_ms = float(np.mean([ctx.elapsed_ms(a, b) for a, b in events]))   # amt_georef_frame incl. bbox folds
+    g_total, g_n = ctx.timing_read(0)
+    b_total, b_n = ctx.timing_read(1)
+    assert g_n == args.steps and b_n == args.steps, (g_n, b_n)
+    georef_ms, bin_ms = g_total / g_n, b_total / b_n
+    ctx.timing_enable(False)
 
     if rank == 0:
         npx = WIDTH * HEIGHT
@@ -162,6 +157,12 @@ def main():
         achieved = ab['georef'] / (georef_ms * 1e-3) / 1e9
         info = ctx.device_info()
         res = results[-1]
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as fp:
+                traffic = json.load(fp)
+        except (IOError, ValueError):
+            pass
         out = {
             'metric': 'Mpixels/s georef+resample, 4240x2832 frame',
             'value': world * args.steps * npx / 1e6 / elapsed,
@@ -177,13 +178,21 @@ def main():
                        'frame': [WIDTH, HEIGHT], 'px_per_deg': PPD, 'grid': list(res['mean'].shape),
                        'parallelism': 'frames sharded over %d GPU(s), RCCL gather of grids' % world,
                        'device': info['name']},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_georef (amt_georef_frame)', 'achieved': achieved,
+            # dominant kernel: k_georef_rows writes 16 B/corner + 24 B/pixel and reads nothing (WCS-fused row of
+            # SURVEY.md §8d); it is FP64-VALU bound, so frac understates how busy the chip is
+            'roofline': {'bound': 'hbm', 'kernel': 'k_georef_rows (amt_georef_frame)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'algorithmic_bytes': ab['georef'], 'ms_per_launch': georef_ms},
+                         'traffic': traffic.get('k_georef_rows', {}).get('hbm_bytes'),
+                         'algorithmic_bytes': ab['georef'], 'ms_per_launch': georef_ms},
             'kernels': {
-                'georef_ms': georef_ms,
-                'georef_frac_directions_in_accounting': ab['georef_dirs_in'] / (georef_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                'resample_ms_incl_grid_host_work': bin_ms,
+                'k_georef_rows': {'ms': georef_ms, 'algorithmic_bytes': ab['georef'],
+                                  'frac_hbm_peak': ab['georef'] / (georef_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  'frac_directions_in_accounting_768.8MB':
+                                      ab['georef_dirs_in'] / (georef_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                'k_bin_frame': {'ms': bin_ms, 'algorithmic_bytes': ab['resample'],
+                                'frac_hbm_peak': ab['resample'] / (bin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                'traffic': traffic.get('k_bin_frame', {}).get('hbm_bytes')},
+                'georef_stage_ms_incl_bbox_folds': stage_ms,
                 'pipeline_frac_1129MB_contract': (ab['georef_dirs_in'] + ab['resample'])
                 / ((georef_ms + bin_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },

@@ -66,6 +66,13 @@ int amt_event_create(amt_ctx* ctx, void** out_event);
 int amt_event_destroy(amt_ctx* ctx, void* event);
 int amt_event_record(amt_ctx* ctx, void* event);
 int amt_event_elapsed_ms(amt_ctx* ctx, void* start, void* stop, float* out_ms);   /* synchronises on stop */
+/* Per-kernel timing: while enabled, amt_georef_frame[_dirs] and amt_bin_frame bracket their main kernel
+ * launch (k_georef_rows / k_bin_frame, not the small fold / finalize kernels) with HIP events on the
+ * context's stream.  amt_timing_read sums the recorded launches (synchronises); enabling resets. */
+#define AMT_KERNEL_GEOREF 0
+#define AMT_KERNEL_BIN 1
+int amt_timing_enable(amt_ctx* ctx, int enable);
+int amt_timing_read(amt_ctx* ctx, int kernel, double* total_ms, int* launches);
 
 /* ---- per-frame parameter block --------------------------------------------------------
  * Host scalars the reference derives once per frame:
