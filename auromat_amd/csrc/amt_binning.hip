@@ -121,203 +121,217 @@ struct bin_args {
     unsigned long long* acc;
 };
 
-constexpr int kPPT = 4;                      // consecutive pixels (along x) per thread
+constexpr int kPPT = 4;                      // pixels per thread and row: two pairs, 128 pixels apart
 constexpr int kBW = 64 * kPPT, kBH = kBlock / 64, kWCap = 1024;   // tile: 256 x 4 pixels, one image row per wave
+// Pixel j of lane l sits at column 128*(j/2) + 2*l + (j%2) of the tile row: every 16-byte load of a
+// wave is then one contiguous 1 KiB segment (lane i at base + 16 i), the coalescing sweet spot.
+__device__ __forceinline__ int tile_col(int lane, int j) { return 128 * (j >> 1) + 2 * lane + (j & 1); }
 constexpr double kFix = 4294967296.0;   // 2^32
 
-// Loads `kPPT` consecutive values; VEC promises 16-byte alignment and a full group inside the row.
+// Loads the thread's two pixel pairs of one row; `row` points at the tile's first pixel of that row, `n_row`
+// is the number of pixels of the tile row inside the image.  VEC promises 16-byte alignment of `row`.
 template <bool VEC>
-__device__ __forceinline__ void load_run(const double* __restrict__ p, int n_ok, double (&v)[kPPT]) {
-    if (VEC) {
-        const double2 a = *reinterpret_cast<const double2*>(p);
-        const double2 b = *reinterpret_cast<const double2*>(p + 2);
-        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
-    } else {
+__device__ __forceinline__ void load_run(const double* __restrict__ row, int lane, int n_row, double (&v)[kPPT]) {
 #pragma unroll
-        for (int j = 0; j < kPPT; ++j) v[j] = j < n_ok ? p[j] : NAN;
+    for (int k = 0; k < kPPT / 2; ++k) {
+        const int c = tile_col(lane, 2 * k);
+        if (VEC && c + 1 < n_row) {
+            const double2 a = *reinterpret_cast<const double2*>(row + c);
+            v[2 * k] = a.x;
+            v[2 * k + 1] = a.y;
+        } else {
+            v[2 * k] = c < n_row ? row[c] : NAN;
+            v[2 * k + 1] = c + 1 < n_row ? row[c + 1] : NAN;
+        }
     }
 }
+
+constexpr int kWX = 32, kWY = 32;            // LDS window of kWX x kWY cells centred on the tile's anchor cell
+constexpr int kRowIters = 4;                 // a workgroup walks kRowIters x kBH image rows (16) with one window
+static_assert(kWX * kWY == kWCap, "window size");
 
 template <typename IMG_T, int NCH, bool VEC>
 __global__ __launch_bounds__(kBlock) void k_bin_frame(bin_args A) {
     __shared__ unsigned int sCnt[kWCap];
     __shared__ unsigned int sCh[NCH > 0 ? NCH : 1][kWCap];
     __shared__ unsigned long long sEl[kWCap];
-    __shared__ int sBox[4][kBlock / 64];
+    __shared__ int sCand[kBlock / 64];
 
     const int tiles_x = (A.width + kBW - 1) / kBW;
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
-    const int gx = tile_x * kBW + (threadIdx.x & 63) * kPPT;
-    const int gy = tile_y * kBH + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gx0 = tile_x * kBW;
     const int64_t ncell = (int64_t)A.ax.nbin * A.ay.nbin;
     const IMG_T* img = static_cast<const IMG_T*>(A.img);
-    const int n_ok = (gy < A.height) ? min(kPPT, A.width - gx) : 0;   // pixels of this thread inside the image
 
-    // ---- all loads first (one memory latency per tile), then arithmetic --------------------------
-    double la[kPPT], lo[kPPT], ev[kPPT];
-    unsigned int ch[kPPT][NCH > 0 ? NCH : 1];
-    unsigned char mk[kPPT];
+    for (int i = threadIdx.x; i < kWCap; i += kBlock) {
+        sCnt[i] = 0;
+        sEl[i] = 0;
 #pragma unroll
-    for (int j = 0; j < kPPT; ++j) {
-        la[j] = NAN; lo[j] = NAN; ev[j] = 0.0; mk[j] = 0;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) ch[j][c] = 0;
+        for (int c = 0; c < NCH; ++c) sCh[c][i] = 0;
     }
-    if (n_ok > 0) {
-        const int64_t gi = (int64_t)gy * A.width + gx;
-        load_run<VEC>(A.lat_c + gi, n_ok, la);
-        load_run<VEC>(A.lon_c + gi, n_ok, lo);
-        if (A.elev) load_run<VEC>(A.elev + gi, n_ok, ev);
-        if (A.mask) {
-#pragma unroll
-            for (int j = 0; j < kPPT; ++j) mk[j] = j < n_ok ? A.mask[gi + j] : 1;
-        }
-        if (NCH > 0) {
-            const IMG_T* q = img + gi * NCH;
-            constexpr int kBytes = kPPT * NCH * (int)sizeof(IMG_T);
-            if (VEC && kBytes % 4 == 0) {
-                // the 4 pixels of a thread are kBytes contiguous, 4-byte aligned bytes: fetch them as dwords
-                constexpr int kWords = kBytes / 4;
-                const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
-                uint32_t buf[kWords > 0 ? kWords : 1];
-#pragma unroll
-                for (int i = 0; i < kWords; ++i) buf[i] = w[i];
-#pragma unroll
-                for (int j = 0; j < kPPT; ++j)
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        const int e = j * NCH + c;     // element index within the thread's run
-                        if (sizeof(IMG_T) == 2)
-                            ch[j][c] = (buf[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-                        else
-                            ch[j][c] = (buf[e >> 2] >> ((e & 3) * 8)) & 0xffu;
-                    }
-            } else {
-#pragma unroll
-                for (int j = 0; j < kPPT; ++j)
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) ch[j][c] = (VEC || j < n_ok) ? q[j * NCH + c] : 0;
-            }
-        }
-    }
-
-    int cellx[kPPT], celly[kPPT];
-    int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
-#pragma unroll
-    for (int j = 0; j < kPPT; ++j) {
-        bool ok = la[j] == la[j];                                          // resample.py:315-321
-        if (A.use_elev_threshold) ok = ok && (ev[j] >= A.min_elev);        // mapping.py:856
-        ok = ok && mk[j] == 0;
-        cellx[j] = 0;
-        celly[j] = 0;
-        if (ok) {
-            const double xv = A.lon_wrap ? wrap180_shifted(lo[j]) : lo[j];
-            const int bx = bin_index(A.ax, xv), by = bin_index(A.ay, la[j]);
-            if (bx >= 1 && bx <= A.ax.nbin && by >= 1 && by <= A.ay.nbin) {
-                cellx[j] = bx;
-                celly[j] = by;
-                bx0 = min(bx0, bx);
-                bx1 = max(bx1, bx);
-                by0 = min(by0, by);
-                by1 = max(by1, by);
-            }
-        }
-    }
-    // window of cells touched by this tile
-    for (int o = 32; o > 0; o >>= 1) {
-        bx0 = min(bx0, __shfl_xor(bx0, o));
-        bx1 = max(bx1, __shfl_xor(bx1, o));
-        by0 = min(by0, __shfl_xor(by0, o));
-        by1 = max(by1, __shfl_xor(by1, o));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        const int w = threadIdx.x >> 6;
-        sBox[0][w] = bx0;
-        sBox[1][w] = bx1;
-        sBox[2][w] = by0;
-        sBox[3][w] = by1;
-    }
+    // anchor cell (block-uniform): the window covers cells [ax0, ax0 + kWX) x [ay0, ay0 + kWY)
+    int ax0 = 0, ay0 = 0;
+    bool have_anchor = false;
     __syncthreads();
-    bx0 = sBox[0][0];
-    bx1 = sBox[1][0];
-    by0 = sBox[2][0];
-    by1 = sBox[3][0];
-#pragma unroll
-    for (int w = 1; w < kBlock / 64; ++w) {
-        bx0 = min(bx0, sBox[0][w]);
-        bx1 = max(bx1, sBox[1][w]);
-        by0 = min(by0, sBox[2][w]);
-        by1 = max(by1, sBox[3][w]);
-    }
-    if (bx1 < 0) return;   // no pixel of this tile lands on the grid (uniform across the block)
-    const int wnx = bx1 - bx0 + 1, wny = by1 - by0 + 1;
-    const int64_t wn = (int64_t)wnx * wny;
-    const bool use_lds = wn <= kWCap;
 
-    if (use_lds) {
-        for (int i = threadIdx.x; i < (int)wn; i += kBlock) {
-            sCnt[i] = 0;
-            sEl[i] = 0;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) sCh[c][i] = 0;
-        }
-        __syncthreads();
-    }
-    // consecutive pixels of a thread mostly share a cell: sum runs in registers, one atomic set per run.
-    // (a NaN elevation of a kept pixel contributes 0; the reference would poison the cell — the mask
-    //  invariants of mapping.py:299-316 make that unreachable)
-    int run_cell = -1;
-    unsigned int rcnt = 0, rch[NCH > 0 ? NCH : 1];
-    long long rel = 0;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) rch[c] = 0;
-    auto flush = [&](int cell_w) {
-        if (use_lds) {
-            atomicAdd(&sCnt[cell_w], rcnt);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) atomicAdd(&sCh[c][cell_w], rch[c]);
-            atomicAdd(&sEl[cell_w], (unsigned long long)rel);
-        } else {
-            // tile spreads over more cells than the LDS window holds (very fine grids): global atomics
-            const int wx = cell_w / wny, wy = cell_w - wx * wny;
-            const int64_t cell = (int64_t)(bx0 - 1 + wx) * A.ay.nbin + (by0 - 1 + wy);
-            atomicAdd(&A.acc[cell], (unsigned long long)rcnt);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) atomicAdd(&A.acc[(int64_t)(1 + c) * ncell + cell], (unsigned long long)rch[c]);
-            atomicAdd(&A.acc[(int64_t)(1 + NCH) * ncell + cell], (unsigned long long)rel);
-        }
-    };
-#pragma unroll
-    for (int j = 0; j < kPPT; ++j) {
-        if (cellx[j] == 0) continue;
-        const int wi = (cellx[j] - bx0) * wny + (celly[j] - by0);
-        if (wi != run_cell) {
-            if (run_cell >= 0) flush(run_cell);
-            run_cell = wi;
-            rcnt = 0;
-            rel = 0;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) rch[c] = 0;
-        }
-        rcnt += 1;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) rch[c] += ch[j][c];
-        rel += (ev[j] == ev[j]) ? __double2ll_rn(ev[j] * kFix) : 0;
-    }
-    if (run_cell >= 0) flush(run_cell);
+    for (int it = 0; it < kRowIters; ++it) {
+        const int gy = (tile_y * kRowIters + it) * kBH + wave;
+        const int n_row = (gy < A.height) ? min(kBW, A.width - gx0) : 0;   // pixels of this tile row inside the image
 
-    if (use_lds) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < (int)wn; i += kBlock) {
-            const unsigned int cnt = sCnt[i];
-            if (cnt == 0) continue;
-            const int wx = i / wny, wy = i - wx * wny;
-            const int64_t cell = (int64_t)(bx0 - 1 + wx) * A.ay.nbin + (by0 - 1 + wy);
-            atomicAdd(&A.acc[cell], (unsigned long long)cnt);
+        // ---- all loads first (one memory latency per row group), then arithmetic ---------------------
+        double la[kPPT], lo[kPPT], ev[kPPT];
+        unsigned int ch[kPPT][NCH > 0 ? NCH : 1];
+        unsigned char mk[kPPT];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) atomicAdd(&A.acc[(int64_t)(1 + c) * ncell + cell], (unsigned long long)sCh[c][i]);
-            atomicAdd(&A.acc[(int64_t)(1 + NCH) * ncell + cell], sEl[i]);
+        for (int j = 0; j < kPPT; ++j) {
+            la[j] = NAN; lo[j] = NAN; ev[j] = 0.0; mk[j] = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) ch[j][c] = 0;
         }
+        if (n_row > 0) {
+            const int64_t g0 = (int64_t)gy * A.width + gx0;
+            load_run<VEC>(A.lat_c + g0, lane, n_row, la);
+            load_run<VEC>(A.lon_c + g0, lane, n_row, lo);
+            if (A.elev) load_run<VEC>(A.elev + g0, lane, n_row, ev);
+            if (A.mask) {
+#pragma unroll
+                for (int j = 0; j < kPPT; ++j) mk[j] = tile_col(lane, j) < n_row ? A.mask[g0 + tile_col(lane, j)] : 1;
+            }
+            if (NCH > 0) {
+                constexpr int kPairBytes = 2 * NCH * (int)sizeof(IMG_T);
+#pragma unroll
+                for (int k = 0; k < kPPT / 2; ++k) {
+                    const int c0 = tile_col(lane, 2 * k);
+                    const IMG_T* q = img + (g0 + c0) * NCH;
+                    if (VEC && kPairBytes % 4 == 0 && c0 + 1 < n_row) {
+                        // a pixel pair is kPairBytes contiguous, 4-byte aligned bytes (even column, even width)
+                        constexpr int kWords = kPairBytes / 4;
+                        const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
+                        uint32_t buf[kWords > 0 ? kWords : 1];
+#pragma unroll
+                        for (int i = 0; i < kWords; ++i) buf[i] = w[i];
+#pragma unroll
+                        for (int e = 0; e < 2 * NCH; ++e) {
+                            const unsigned int val = sizeof(IMG_T) == 2 ? (buf[e >> 1] >> ((e & 1) * 16)) & 0xffffu
+                                                                        : (buf[e >> 2] >> ((e & 3) * 8)) & 0xffu;
+                            ch[2 * k + e / NCH][e % NCH] = val;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+#pragma unroll
+                            for (int c = 0; c < NCH; ++c) ch[2 * k + e][c] = c0 + e < n_row ? q[e * NCH + c] : 0;
+                    }
+                }
+            }
+        }
+
+        int cellx[kPPT], celly[kPPT];
+        int first = 0;                                  // first valid cell of this thread, packed (x << 16 | y) + 1
+#pragma unroll
+        for (int j = kPPT - 1; j >= 0; --j) {
+            bool ok = la[j] == la[j];                                          // resample.py:315-321
+            if (A.use_elev_threshold) ok = ok && (ev[j] >= A.min_elev);        // mapping.py:856
+            ok = ok && mk[j] == 0;
+            cellx[j] = 0;
+            celly[j] = 0;
+            if (ok) {
+                const double xv = A.lon_wrap ? wrap180_shifted(lo[j]) : lo[j];
+                const int bx = bin_index(A.ax, xv), by = bin_index(A.ay, la[j]);
+                if (bx >= 1 && bx <= A.ax.nbin && by >= 1 && by <= A.ay.nbin) {
+                    cellx[j] = bx;
+                    celly[j] = by;
+                    first = -1 - j;   // the loop runs downwards: the smallest valid j wins
+                }
+            }
+        }
+        if (!have_anchor) {
+            // elect the anchor: cell of the first valid pixel of the lowest wave that has one
+            const unsigned long long m = __ballot(first < 0);
+            int cand = 0;
+            if (m) {
+                const int src = __builtin_ctzll(m);
+                const int j = -1 - __shfl(first, src);
+                int cx = 0, cy = 0;
+#pragma unroll
+                for (int k = 0; k < kPPT; ++k) {
+                    cx = (k == j) ? cellx[k] : cx;
+                    cy = (k == j) ? celly[k] : cy;
+                }
+                cx = __shfl(cx, src);
+                cy = __shfl(cy, src);
+                cand = ((cx & 0xffff) << 16 | (cy & 0xffff)) + 1;     // grids have < 65535 bins per axis here
+            }
+            if (lane == 0) sCand[wave] = cand;
+            __syncthreads();
+            int chosen = 0;
+#pragma unroll
+            for (int w = kBlock / 64 - 1; w >= 0; --w) chosen = sCand[w] ? sCand[w] : chosen;
+            __syncthreads();
+            if (chosen) {
+                have_anchor = true;
+                ax0 = (((chosen - 1) >> 16) & 0xffff) - kWX / 2;
+                ay0 = ((chosen - 1) & 0xffff) - kWY / 2;
+            }
+        }
+
+        // consecutive pixels of a thread mostly share a cell: sum runs in registers, one atomic set per run.
+        // (a NaN elevation of a kept pixel contributes 0; the reference would poison the cell — the mask
+        //  invariants of mapping.py:299-316 make that unreachable)
+        int run_x = 0, run_y = 0;
+        unsigned int rcnt = 0, rch[NCH > 0 ? NCH : 1];
+        long long rel = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) rch[c] = 0;
+        auto flush = [&]() {
+            const int dx = run_x - ax0, dy = run_y - ay0;
+            if (dx >= 0 && dx < kWX && dy >= 0 && dy < kWY) {
+                const int wi = dx * kWY + dy;
+                atomicAdd(&sCnt[wi], rcnt);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) atomicAdd(&sCh[c][wi], rch[c]);
+                atomicAdd(&sEl[wi], (unsigned long long)rel);
+            } else {
+                // outside the LDS window (very fine grids or strongly stretched tiles): global atomics
+                const int64_t cell = (int64_t)(run_x - 1) * A.ay.nbin + (run_y - 1);
+                atomicAdd(&A.acc[cell], (unsigned long long)rcnt);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) atomicAdd(&A.acc[(int64_t)(1 + c) * ncell + cell], (unsigned long long)rch[c]);
+                atomicAdd(&A.acc[(int64_t)(1 + NCH) * ncell + cell], (unsigned long long)rel);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < kPPT; ++j) {
+            if (cellx[j] == 0) continue;
+            if (cellx[j] != run_x || celly[j] != run_y) {
+                if (run_x > 0) flush();
+                run_x = cellx[j];
+                run_y = celly[j];
+                rcnt = 0;
+                rel = 0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) rch[c] = 0;
+            }
+            rcnt += 1;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) rch[c] += ch[j][c];
+            rel += (ev[j] == ev[j]) ? __double2ll_rn(ev[j] * kFix) : 0;
+        }
+        if (run_x > 0) flush();
+    }
+
+    if (!have_anchor) return;      // nothing of this tile landed on the grid (block-uniform)
+    __syncthreads();
+    for (int i = threadIdx.x; i < kWCap; i += kBlock) {
+        const unsigned int cnt = sCnt[i];
+        if (cnt == 0) continue;
+        const int dx = i / kWY, dy = i - dx * kWY;
+        const int64_t cell = (int64_t)(ax0 + dx - 1) * A.ay.nbin + (ay0 + dy - 1);
+        atomicAdd(&A.acc[cell], (unsigned long long)cnt);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) atomicAdd(&A.acc[(int64_t)(1 + c) * ncell + cell], (unsigned long long)sCh[c][i]);
+        atomicAdd(&A.acc[(int64_t)(1 + NCH) * ncell + cell], sEl[i]);
     }
 }
 
@@ -426,6 +440,7 @@ int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const 
     AMT_REQUIRE(ctx, nchan >= 0 && nchan <= 4, "nchan must be 0..4");
     AMT_REQUIRE(ctx, nchan == 0 || (img && (img_dtype == 1 || img_dtype == 2)), "img must be uint8 (1) or uint16 (2)");
     AMT_REQUIRE(ctx, axis_ok(xaxis) && axis_ok(yaxis), "bad axis");
+    AMT_REQUIRE(ctx, xaxis->nbin < 65535 && yaxis->nbin < 65535, "at most 65534 bins per axis");
     bin_args A;
     A.lat_c = lat_c;
     A.lon_c = lon_c;
@@ -440,11 +455,11 @@ int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const 
     make_axis(yaxis, &A.ay);
     A.lon_wrap = lon_wrap ? 1 : 0;
     A.acc = reinterpret_cast<unsigned long long*>(acc);
-    const int tiles_x = (width + kBW - 1) / kBW, tiles_y = (height + kBH - 1) / kBH;
+    const int tiles_x = (width + kBW - 1) / kBW, tiles_y = (height + kBH * kRowIters - 1) / (kBH * kRowIters);
     const dim3 grid((unsigned)((int64_t)tiles_x * tiles_y)), block(kBlock);
     auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    // vector path: rows start 16-byte aligned and consist of whole 4-pixel groups
-    const bool vec = (width % kPPT == 0) && aligned16(lat_c) && aligned16(lon_c) && (elev == nullptr || aligned16(elev));
+    // vector path: rows start 16-byte aligned (even width) so that every pixel pair is one aligned 16-byte load
+    const bool vec = (width % 2 == 0) && aligned16(lat_c) && aligned16(lon_c) && (elev == nullptr || aligned16(elev));
 #define AMT_BIN_CASE(T, N)                                                                  \
     do {                                                                                    \
         if (vec) hipLaunchKernelGGL((k_bin_frame<T, N, true>), grid, block, 0, ctx->stream, A);  \

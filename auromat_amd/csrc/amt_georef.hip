@@ -272,6 +272,32 @@ __device__ __forceinline__ int from_prev_lane(int v) {   // lane 0 receives 0
     return __builtin_amdgcn_update_dpp(0, v, kDppWaveShr1, 0xf, 0xf, false);
 }
 
+// Scalar re-loads of the per-frame constants.  The ~60 constant doubles plus the 64-bit literals of the
+// polynomials exceed the 102 SGPRs of a wave; held for the whole loop they are spilled to VGPR lanes
+// (v_writelane / v_readlane, 12 % of the kernel's VALU instructions in the first version).  Instead each
+// phase of the loop body re-reads the few blocks it needs from the kernel-argument segment through the
+// scalar cache; the empty asm makes the base pointer opaque so that the loads cannot be hoisted.
+typedef const __attribute__((address_space(4))) unsigned long long* karg_ptr;
+
+__device__ __forceinline__ karg_ptr karg_fresh() {
+    karg_ptr p = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+template <typename T>
+__device__ __forceinline__ T karg_load(karg_ptr base, size_t byte_offset) {
+    static_assert(sizeof(T) % 8 == 0, "constant blocks are multiples of 8 bytes");
+    union {
+        T value;
+        unsigned long long words[sizeof(T) / 8];
+    } u;
+    karg_ptr q = base + byte_offset / 8;
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 8; ++i) u.words[i] = q[i];
+    return u.value;
+}
+
 template <bool FAST, bool DIRS_IN, bool MAG>
 __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int rows_per_chunk, int strips_x,
                                                            int n_items) {
@@ -299,19 +325,22 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
         double la = NAN, lo = NAN;
         if (col_ok) {
             const int64_t gi = (int64_t)gy * W1 + gx;
+            karg_ptr K = karg_fresh();
+            const ellipsoid_ray ray = karg_load<ellipsoid_ray>(K, offsetof(georef_args, ray));
             if (DIRS_IN) {
                 d.x = A.dirs_in[3 * gi];
                 d.y = A.dirs_in[3 * gi + 1];
                 d.z = A.dirs_in[3 * gi + 2];
             } else {
-                d = tan_direction_fast(A.wcs, gx - 0.5, gy - 0.5);
+                d = tan_direction_fast(karg_load<tan_wcs>(K, offsetof(georef_args, wcs)), gx - 0.5, gy - 0.5);
             }
-            const double t = ray_param_fast(A.ray, d);
+            const double t = ray_param_fast(ray, d);
             const bool hit = t == t;
             if (hit) {
-                p = ray_point(A.ray, d, t);
-                const vec3 g = mul(A.m_geo, p);
-                ecef_to_geodetic_deg_fast(A.bw, g.x, g.y, g.z, la, lo);
+                p = ray_point(ray, d, t);
+                K = karg_fresh();
+                const vec3 g = mul(karg_load<mat3>(K, offsetof(georef_args, m_geo)), p);
+                ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), g.x, g.y, g.z, la, lo);
             }
             // the last corner row of a chunk is the first of the next one (which owns it) unless it is
             // the image's last; lane 63's column likewise belongs to the next strip unless it is the last
@@ -321,7 +350,7 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
                 if (A.lon) A.lon[gi] = lo;
                 if (MAG && A.mlat) {
                     double ml = NAN, mt = NAN;
-                    if (hit) sm_to_mlat_mlt_fast(mul(A.m_sm, p), ml, mt);
+                    if (hit) sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(), offsetof(georef_args, m_sm)), p), ml, mt);
                     A.mlat[gi] = ml;
                     A.mlt[gi] = mt;
                 }
@@ -344,8 +373,10 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
                 dc.y = (ty + from_next_lane(ty)) * 0.25;
                 dc.z = (tz + from_next_lane(tz)) * 0.25;
             } else {
-                dc = tan_direction_fast(A.wcs, (double)gx, (double)(gy - 1));
-                pc = ray_point(A.ray, dc, ray_param_fast(A.ray, dc));
+                karg_ptr K = karg_fresh();
+                const ellipsoid_ray ray = karg_load<ellipsoid_ray>(K, offsetof(georef_args, ray));
+                dc = tan_direction_fast(karg_load<tan_wcs>(K, offsetof(georef_args, wcs)), (double)gx, (double)(gy - 1));
+                pc = ray_point(ray, dc, ray_param_fast(ray, dc));
                 if (want_bbox) {
                     // after sanitisation a centre also needs its 4 corners (reference mapping.py:1093-1101)
                     const int h = (p_prev.x == p_prev.x) && (p.x == p.x);
@@ -357,13 +388,15 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
                 const int64_t gi = (int64_t)(gy - 1) * A.width + gx;
                 double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN;
                 if (pc.x == pc.x) {
-                    const vec3 g = mul(A.m_geo, pc);
-                    ecef_to_geodetic_deg_fast(A.bw, g.x, g.y, g.z, lac, loc);
+                    karg_ptr K = karg_fresh();
+                    const vec3 g = mul(karg_load<mat3>(K, offsetof(georef_args, m_geo)), pc);
+                    ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), g.x, g.y, g.z, lac, loc);
                     // reference astrometry.py:200-212, utils.py:33-46: 90 - angle(-d, P/|P|) = asin(-d.P/|P|)
                     double c = -(dc.x * pc.x + dc.y * pc.y + dc.z * pc.z) * fm::rsqrt(dot(pc, pc));
                     c = fmin(1.0, fmax(-1.0, c));
                     el = fm::asin_deg(c);
-                    if (MAG && A.mlat_c) sm_to_mlat_mlt_fast(mul(A.m_sm, pc), ml, mt);
+                    if (MAG && A.mlat_c)
+                        sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(), offsetof(georef_args, m_sm)), pc), ml, mt);
                 }
                 if (A.lat_c) A.lat_c[gi] = lac;
                 if (A.lon_c) A.lon_c[gi] = loc;

@@ -61,6 +61,7 @@ class FramePipeline(object):
         p = params if params is not None else frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fast,
                                                            magnetic=self.with_mag)
         fd = self.fd
+        Context.current(self.ctx.device)      # enqueue on whatever stream torch has current now
         out = GeorefOut()
         out.lat, out.lon, out.lat_c, out.lon_c, out.elev = (t.data_ptr() for t in
                                                             (fd.lat, fd.lon, fd.lat_c, fd.lon_c, fd.elev))
@@ -94,6 +95,7 @@ class FramePipeline(object):
         except TypeError:
             pxPerDeg = (pxPerDeg, pxPerDeg)
         fd = self.fd
+        Context.current(self.ctx.device)
         if magnetic:
             assert self.with_mag
             sm = fd.shallow_copy()

@@ -71,6 +71,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--cpu-rows', type=int, default=2832, help='rows of the frame the CPU baseline processes (0 = skip)')
     ap.add_argument('--exact', action='store_true', help='exact centre rays instead of fast centres')
+    ap.add_argument('--streams', type=int, default=2, choices=(1, 2),
+                    help='2: bin frame k beside the ray casting of frame k+1 on a second HIP stream')
     args = ap.parse_args()
 
     import torch
@@ -83,6 +85,7 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
+    from auromat_amd._native import Context
     from auromat_amd.pipeline import FramePipeline
     from auromat_amd.mapping.astrometry import frame_params
     from auromat_amd.sequence import gather_results
@@ -97,15 +100,34 @@ def main():
     fast = not args.exact
     total = args.warmup + args.steps
 
+    # two HIP streams: the georeferencing kernel is FP64-VALU bound and leaves HBM mostly idle, the binning
+    # kernel is memory bound and leaves the VALUs idle, so frame k's binning runs beside frame k+1's ray casting
+    s_geo = torch.cuda.Stream()
+    s_bin = torch.cuda.Stream() if args.streams == 2 else s_geo
+    geo_done = [torch.cuda.Event(), torch.cuda.Event()]
+    bin_done = [None, None]
+
     def launch_georef(k, ev=None):
         hdr, cam, t, _ = sequence_frame(rank * total + k, WIDTH, HEIGHT)
         p = frame_params(hdr, ALTITUDE, cam, t, fast, magnetic=False)
         q = pipes[k % 2]
-        if ev is not None:
-            ctx.record(ev[0])
-        q.georef(None, ALTITUDE, cam, t, fast, MIN_ELEV, params=p)
-        if ev is not None:
-            ctx.record(ev[1])
+        with torch.cuda.stream(s_geo):
+            if bin_done[k % 2] is not None:
+                s_geo.wait_event(bin_done[k % 2])        # frame k-2's binning still reads this buffer
+            if ev is not None:
+                Context.current().record(ev[0])
+            q.georef(None, ALTITUDE, cam, t, fast, MIN_ELEV, params=p)
+            if ev is not None:
+                ctx.record(ev[1])
+            geo_done[k % 2].record(s_geo)
+
+    def launch_resample(k):
+        with torch.cuda.stream(s_bin):
+            s_bin.wait_event(geo_done[k % 2])
+            res = pipes[k % 2].resample(PPD, containsPole=False, keep_on_device=True)
+            bin_done[k % 2] = torch.cuda.Event()
+            bin_done[k % 2].record(s_bin)
+        return res
 
     def run(first, count, events=None):
         """Frames first .. first+count-1, software-pipelined; returns their results."""
@@ -114,7 +136,7 @@ def main():
         for i in range(count):
             if i + 1 < count:
                 launch_georef(first + i + 1, events[i + 1] if events else None)
-            out.append(pipes[(first + i) % 2].resample(PPD, containsPole=False, keep_on_device=True))
+            out.append(launch_resample(first + i))
         return out
 
     run(0, args.warmup)
@@ -132,6 +154,7 @@ def main():
     results = run(args.warmup, args.steps, events)
     gathered = None
     if world > 1:
+        torch.cuda.current_stream().wait_stream(s_bin)     # the gather runs on the default stream
         gathered = gather_results(results, [rank * total + args.warmup + k for k in range(args.steps)], ctx.device)
     fence()
     elapsed = time.perf_counter() - t0
