@@ -27,7 +27,9 @@ class FrameParams(C.Structure):
 class GeorefOut(C.Structure):
     """amt_georef_out"""
     _fields_ = [(k, C.c_void_p) for k in ('lat', 'lon', 'lat_c', 'lon_c', 'elev', 'mlat', 'mlt', 'mlat_c',
-                                          'mlt_c', 'bbox')] + [('bbox_min_elevation', C.c_double)]
+                                          'mlt_c', 'bbox')] + [('bbox_min_elevation', C.c_double)] + \
+               [(k, C.c_void_p) for k in ('bin_xaxis', 'bin_yaxis', 'bin_img', 'bin_acc')] + \
+               [(k, C.c_int32) for k in ('bin_img_dtype', 'bin_lon_wrap', 'bin_magnetic', 'bin_reserved')]
 
 
 class Axis(C.Structure):
@@ -35,6 +37,19 @@ class Axis(C.Structure):
     _fields_ = [('edges', C.c_void_p), ('nbin', C.c_int32), ('uniform', C.c_int32),
                 ('first', C.c_double), ('last', C.c_double), ('step', C.c_double), ('scale', C.c_double),
                 ('last_rounded', C.c_double)]
+
+
+class Grid(C.Structure):
+    """amt_grid"""
+    _fields_ = [('nx', C.c_int32), ('ny', C.c_int32), ('n_lat_nodes', C.c_int32), ('n_lon_nodes', C.c_int32)] + \
+               [(k, C.c_double) for k in ('lat_lo', 'lat_hi', 'lon_lo', 'lon_hi', 'lat_step', 'lon_step',
+                                          'lat_center_first', 'lat_center_last', 'lon_center_first',
+                                          'lon_center_last')] + [('xaxis', Axis), ('yaxis', Axis)]
+
+
+class PipeResult(C.Structure):
+    """amt_pipe_result"""
+    _fields_ = [('status', C.c_int32), ('fused', C.c_int32), ('bbox', C.c_double * 8), ('grid', Grid)]
 
 
 _I, _L, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p
@@ -75,6 +90,7 @@ _SIGNATURES = {
     'amt_spherical_to_cartesian': ([_P, _P, _P, _P, _L, _P, _P, _P], _I),
     'amt_georef_frame': ([_P, C.POINTER(FrameParams), C.POINTER(GeorefOut)], _I),
     'amt_georef_frame_dirs': ([_P, C.POINTER(FrameParams), _P, C.POINTER(GeorefOut)], _I),
+    'amt_georef_coarse_bbox': ([_P, C.POINTER(FrameParams), C.c_int32, _D, _I, _P], _I),
     'amt_mask_by_elevation': ([_P, _P, _P, C.c_int32, C.c_int32, _D, _P, _P, _P], _I),
     'amt_sanitize_masks': ([_P, _P, _P, _P, C.c_int32, C.c_int32, _I], _I),
     'amt_bbox_corners': ([_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P], _I),
@@ -84,6 +100,14 @@ _SIGNATURES = {
     'amt_bin_frame': ([_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _D, C.POINTER(Axis),
                        C.POINTER(Axis), _I, _P], _I),
     'amt_bin_frame_finalize': ([_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P], _I),
+    'amt_bin_frame_finalize_window': ([_P, _P] + [C.c_int32] * 8 + [_P, _P, _P, _P], _I),
+    'amt_grid_layout': ([_D, _D, _D, _D, _D, _D, C.POINTER(Grid)], _I),
+    'amt_pipe_create': ([_P, c_void_pp], _I),
+    'amt_pipe_destroy': ([_P], _I),
+    'amt_pipe_coarse': ([_P, C.POINTER(FrameParams), _D], _I),
+    'amt_pipe_launch': ([_P, C.POINTER(FrameParams), C.POINTER(GeorefOut), _P, C.c_int32, _D, _D, _D, _I], _I),
+    'amt_pipe_wait': ([_P, C.POINTER(PipeResult)], _I),
+    'amt_pipe_finalize': ([_P, _P, _P, _P, _P], _I),
 }
 
 _lib = None

@@ -15,53 +15,6 @@ using namespace amt;
 
 constexpr int kBlock = 256;
 
-struct axis_dev {
-    const double* edges;
-    int nbin;
-    int uniform;
-    double scale, last_rounded;
-    double e0, e_last, step, inv_step;
-};
-
-// Edge i of a uniform axis, bit-identical to np.linspace(e0, e_last, nbin+1)[i]:
-// arange(num)*step + start with two roundings (contraction to an FMA would change the last bit),
-// and the end point stored exactly (numpy/_core/function_base.py: y = y*step + start; y[-1] = stop).
-__device__ __forceinline__ double linspace_edge(const axis_dev& ax, int i) {
-#pragma clang fp contract(off)
-    const double m = (double)i * ax.step;
-    const double e = m + ax.e0;
-    return i >= ax.nbin ? ax.e_last : e;
-}
-
-// searchsorted(edges, v, 'right') with the right-most-edge rule of histogram.py:209-224.
-// Returns 0..nbin+1; 0 and nbin+1 are outliers (NaN sorts to the end like NumPy does).
-__device__ __forceinline__ int bin_index(const axis_dev& ax, double v) {
-    if (!(v == v)) return ax.nbin + 1;
-    if (v < ax.e0) return 0;
-    if (v >= ax.e_last) {
-        const bool on_edge = rint(v * ax.scale) / ax.scale == ax.last_rounded;
-        return on_edge ? ax.nbin : ax.nbin + 1;
-    }
-    int g;
-    if (ax.uniform) {
-        g = (int)((v - ax.e0) * ax.inv_step);
-        g = g < 0 ? 0 : (g > ax.nbin - 1 ? ax.nbin - 1 : g);
-        // the guess is off by at most one; e0 <= v < e_last bounds both corrections
-        if (v < linspace_edge(ax, g)) --g;
-        else if (v >= linspace_edge(ax, g + 1)) ++g;
-        while (v < linspace_edge(ax, g)) --g;
-        while (v >= linspace_edge(ax, g + 1)) ++g;
-    } else {
-        int lo = 0, hi = ax.nbin;             // invariant: edges[lo] <= v < edges[hi]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (v >= ax.edges[mid]) lo = mid; else hi = mid;
-        }
-        g = lo;
-    }
-    return g + 1;
-}
-
 // ------------------------------------------------------------------------------------------
 // generic float64 histogram (operator-level API)
 // ------------------------------------------------------------------------------------------
@@ -121,12 +74,11 @@ struct bin_args {
     unsigned long long* acc;
 };
 
-constexpr int kPPT = 4;                      // pixels per thread and row: two pairs, 128 pixels apart
+constexpr int kPPT = 4;                      // consecutive pixels (along x) per thread and row, loaded as two pairs
 constexpr int kBW = 64 * kPPT, kBH = kBlock / 64, kWCap = 1024;   // tile: 256 x 4 pixels, one image row per wave
-// Pixel j of lane l sits at column 128*(j/2) + 2*l + (j%2) of the tile row: every 16-byte load of a
-// wave is then one contiguous 1 KiB segment (lane i at base + 16 i), the coalescing sweet spot.
-__device__ __forceinline__ int tile_col(int lane, int j) { return 128 * (j >> 1) + 2 * lane + (j & 1); }
-constexpr double kFix = 4294967296.0;   // 2^32
+// Column of pixel j of lane l inside the tile row.  (A layout with the two pairs 128 pixels apart, which makes
+// every 16-byte wave load one contiguous 1 KiB segment, measured 25 % slower: 146 vs 118 us per frame.)
+__device__ __forceinline__ int tile_col(int lane, int j) { return kPPT * lane + j; }
 
 // Loads the thread's two pixel pairs of one row; `row` points at the tile's first pixel of that row, `n_row`
 // is the number of pixels of the tile row inside the image.  VEC promises 16-byte alignment of `row`.
@@ -336,45 +288,29 @@ __global__ __launch_bounds__(kBlock) void k_bin_frame(bin_args A) {
 }
 
 template <typename IMG_T>
-__global__ void k_bin_finalize(const unsigned long long* __restrict__ acc, int nx, int ny, int nch,
-                               double* __restrict__ mean, IMG_T* __restrict__ out_img, uint8_t* __restrict__ out_mask,
+__global__ void k_bin_finalize(const unsigned long long* __restrict__ acc, int acc_nx, int acc_ny, int off_x,
+                               int off_y, int nx, int ny, int nch, double* __restrict__ mean,
+                               IMG_T* __restrict__ out_img, uint8_t* __restrict__ out_mask,
                                double* __restrict__ out_count) {
-    const int64_t n = (int64_t)nx * ny;
+    const int64_t n = (int64_t)nx * ny, plane = (int64_t)acc_nx * acc_ny;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / nx), c = (int)(i - (int64_t)r * nx);
-        const int64_t cell = (int64_t)c * ny + (ny - 1 - r);     // transpose + flipud (resample.py:339-349)
+        // transpose + flipud (resample.py:339-349), inside the [off_x, off_x+nx) x [off_y, off_y+ny) window
+        const int64_t cell = (int64_t)(off_x + c) * acc_ny + (off_y + ny - 1 - r);
         const unsigned long long cnt = acc[cell];
         const double dc = (double)cnt;
         for (int k = 0; k < nch; ++k) {
-            const double m = cnt ? (double)acc[(int64_t)(1 + k) * n + cell] / dc : NAN;
+            const double m = cnt ? (double)acc[(int64_t)(1 + k) * plane + cell] / dc : NAN;
             if (mean) mean[i * (nch + 1) + k] = m;
             if (out_img) out_img[i * nch + k] = cnt ? (IMG_T)rint(m) : (IMG_T)0;   // np.round: half to even
         }
         if (mean) {
-            const long long fx = (long long)acc[(int64_t)(1 + nch) * n + cell];
+            const long long fx = (long long)acc[(int64_t)(1 + nch) * plane + cell];
             mean[i * (nch + 1) + nch] = cnt ? ((double)fx / kFix) / dc : NAN;
         }
         if (out_mask) out_mask[i] = cnt ? 0 : 1;
         if (out_count) out_count[i] = dc;
     }
-}
-
-void make_axis(const amt_axis* a, axis_dev* out) {
-    out->edges = a->edges;
-    out->nbin = a->nbin;
-    out->uniform = a->uniform;
-    out->scale = a->scale;
-    out->last_rounded = a->last_rounded;
-    out->e0 = a->first;
-    out->e_last = a->last;
-    out->step = a->uniform ? a->step : 0.0;
-    out->inv_step = a->nbin / (a->last - a->first);
-}
-
-bool axis_ok(const amt_axis* a) {
-    if (a == nullptr || a->nbin <= 0 || !(a->last > a->first)) return false;
-    if (a->uniform) return a->step > 0;
-    return a->edges != nullptr;
 }
 
 inline dim3 grid_for(int64_t n) {
@@ -480,22 +416,31 @@ int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const 
     return AMT_OK;
 }
 
-int amt_bin_frame_finalize(amt_ctx* ctx, const uint64_t* acc, int32_t nx, int32_t ny, int32_t nchan,
-                           int32_t img_dtype, double* mean, void* out_img, uint8_t* out_mask, double* out_count) {
+int amt_bin_frame_finalize_window(amt_ctx* ctx, const uint64_t* acc, int32_t acc_nx, int32_t acc_ny, int32_t off_x,
+                                  int32_t off_y, int32_t nx, int32_t ny, int32_t nchan, int32_t img_dtype,
+                                  double* mean, void* out_img, uint8_t* out_mask, double* out_count) {
     AMT_CHECK_CTX(ctx);
     AMT_REQUIRE(ctx, acc != nullptr, "NULL argument");
     AMT_REQUIRE(ctx, nx > 0 && ny > 0 && nchan >= 0 && nchan <= 4, "bad shape");
+    AMT_REQUIRE(ctx, off_x >= 0 && off_y >= 0 && off_x + nx <= acc_nx && off_y + ny <= acc_ny,
+                "window outside the accumulator grid");
     AMT_REQUIRE(ctx, out_img == nullptr || img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
     const dim3 grid = grid_for((int64_t)nx * ny), block(kBlock);
     const unsigned long long* a = reinterpret_cast<const unsigned long long*>(acc);
     if (img_dtype == 1)
-        hipLaunchKernelGGL((k_bin_finalize<uint8_t>), grid, block, 0, ctx->stream, a, nx, ny, nchan, mean,
-                           static_cast<uint8_t*>(out_img), out_mask, out_count);
+        hipLaunchKernelGGL((k_bin_finalize<uint8_t>), grid, block, 0, ctx->stream, a, acc_nx, acc_ny, off_x, off_y, nx, ny,
+                           nchan, mean, static_cast<uint8_t*>(out_img), out_mask, out_count);
     else
-        hipLaunchKernelGGL((k_bin_finalize<uint16_t>), grid, block, 0, ctx->stream, a, nx, ny, nchan, mean,
-                           static_cast<uint16_t*>(out_img), out_mask, out_count);
+        hipLaunchKernelGGL((k_bin_finalize<uint16_t>), grid, block, 0, ctx->stream, a, acc_nx, acc_ny, off_x, off_y, nx, ny,
+                           nchan, mean, static_cast<uint16_t*>(out_img), out_mask, out_count);
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
+}
+
+int amt_bin_frame_finalize(amt_ctx* ctx, const uint64_t* acc, int32_t nx, int32_t ny, int32_t nchan,
+                           int32_t img_dtype, double* mean, void* out_img, uint8_t* out_mask, double* out_count) {
+    return amt_bin_frame_finalize_window(ctx, acc, nx, ny, 0, 0, nx, ny, nchan, img_dtype, mean, out_img, out_mask,
+                                         out_count);
 }
 
 }  // extern "C"

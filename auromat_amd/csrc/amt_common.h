@@ -407,4 +407,75 @@ __device__ __forceinline__ double wrap180_shifted(double v) {
     return a;
 }
 
+// ------------------------------------------------------------------------------------------
+// Histogram axis with the reference's bin-edge semantics (auromat/util/histogram.py:178-224)
+// ------------------------------------------------------------------------------------------
+struct axis_dev {
+    const double* edges;
+    int nbin;
+    int uniform;
+    double scale, last_rounded;
+    double e0, e_last, step, inv_step;
+};
+
+// Edge i of a uniform axis, bit-identical to np.linspace(e0, e_last, nbin+1)[i]:
+// arange(num)*step + start with two roundings (contraction to an FMA would change the last bit),
+// and the end point stored exactly (numpy/_core/function_base.py: y = y*step + start; y[-1] = stop).
+__device__ __forceinline__ double linspace_edge(const axis_dev& ax, int i) {
+#pragma clang fp contract(off)
+    const double m = (double)i * ax.step;
+    const double e = m + ax.e0;
+    return i >= ax.nbin ? ax.e_last : e;
+}
+
+// searchsorted(edges, v, 'right') with the right-most-edge rule of histogram.py:209-224.
+// Returns 0..nbin+1; 0 and nbin+1 are outliers (NaN sorts to the end like NumPy does).
+__device__ __forceinline__ int bin_index(const axis_dev& ax, double v) {
+    if (!(v == v)) return ax.nbin + 1;
+    if (v < ax.e0) return 0;
+    if (v >= ax.e_last) {
+        const bool on_edge = rint(v * ax.scale) / ax.scale == ax.last_rounded;
+        return on_edge ? ax.nbin : ax.nbin + 1;
+    }
+    int g;
+    if (ax.uniform) {
+        g = (int)((v - ax.e0) * ax.inv_step);
+        g = g < 0 ? 0 : (g > ax.nbin - 1 ? ax.nbin - 1 : g);
+        // the guess is off by at most one; e0 <= v < e_last bounds both corrections
+        if (v < linspace_edge(ax, g)) --g;
+        else if (v >= linspace_edge(ax, g + 1)) ++g;
+        while (v < linspace_edge(ax, g)) --g;
+        while (v >= linspace_edge(ax, g + 1)) ++g;
+    } else {
+        int lo = 0, hi = ax.nbin;             // invariant: edges[lo] <= v < edges[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (v >= ax.edges[mid]) lo = mid; else hi = mid;
+        }
+        g = lo;
+    }
+    return g + 1;
+}
+
+constexpr double kFix = 4294967296.0;   // 2^32: elevation sums are kept in signed 31.32 fixed point
+
+inline void make_axis(const amt_axis* a, axis_dev* out) {
+    out->edges = a->edges;
+    out->nbin = a->nbin;
+    out->uniform = a->uniform;
+    out->scale = a->scale;
+    out->last_rounded = a->last_rounded;
+    out->e0 = a->first;
+    out->e_last = a->last;
+    out->step = a->uniform ? a->step : 0.0;
+    out->inv_step = a->nbin / (a->last - a->first);
+}
+
+inline bool axis_ok(const amt_axis* a) {
+    if (a == nullptr || a->nbin <= 0 || !(a->last > a->first)) return false;
+    if (a->uniform) return a->step > 0;
+    return a->edges != nullptr;
+}
+
+
 }  // namespace amt

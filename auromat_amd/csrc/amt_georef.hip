@@ -40,6 +40,11 @@ struct georef_args {
     double* mlt_c;
     double* bbox_partials;   // [nblocks][8] or NULL
     double bbox_min_elev;
+    // fused binning (row-marching kernel only)
+    axis_dev bax, bay;
+    const void* bin_img;
+    unsigned long long* bin_acc;
+    int bin_lon_wrap, bin_magnetic;
 };
 
 constexpr int kThreads = 256;
@@ -298,12 +303,60 @@ __device__ __forceinline__ T karg_load(karg_ptr base, size_t byte_offset) {
     return u.value;
 }
 
-template <bool FAST, bool DIRS_IN, bool MAG>
+// Fused binning: every wave keeps a private kBinW x kBinW-cell window of the output grid in LDS, anchored
+// at the cell of its first kept pixel (a 63 x 16-pixel strip spans a few cells only).  Pixels add to it with
+// LDS atomics as soon as their coordinates exist; pixels outside the window go straight to global atomics;
+// the window is flushed with global 64-bit integer atomics when the wave is done.
+constexpr int kBinW = 16, kBinCells = kBinW * kBinW;
+
+// BIN: 0 = no fused binning, 1 = uint8 RGB image, 2 = uint16 RGB image
+template <bool FAST, bool DIRS_IN, bool MAG, int BIN>
 __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int rows_per_chunk, int strips_x,
                                                            int n_items) {
+    constexpr int kBinWaves = BIN ? kThreads / 64 : 1, kBinSlots = BIN ? kBinCells : 1;
+    __shared__ unsigned int sCnt[kBinWaves][kBinSlots];
+    __shared__ unsigned int sCh[kBinWaves][3][kBinSlots];
+    __shared__ unsigned long long sEl[kBinWaves][kBinSlots];
     const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);      // one work item per wave
+    const int wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * (kThreads / 64) + wave;                   // one work item per wave
     if (item >= n_items) return;                                            // wave-uniform
+    int bin_ax0 = 0, bin_ay0 = 0;
+    bool bin_anchor = false;                                                // wave-uniform
+    if (BIN) {
+#pragma unroll
+        for (int i = lane; i < kBinCells; i += 64) {
+            sCnt[wave][i] = 0;
+            sEl[wave][i] = 0;
+            sCh[wave][0][i] = 0;
+            sCh[wave][1][i] = 0;
+            sCh[wave][2][i] = 0;
+        }
+    }
+    int run_key = 0;                                    // (bin_x << 16 | bin_y) of the lane's current run, 0 = none
+    unsigned int run_cnt = 0, run_c0 = 0, run_c1 = 0, run_c2 = 0;
+    long long run_el = 0;
+    auto bin_flush = [&](int key, unsigned int cnt, unsigned int c0, unsigned int c1, unsigned int c2, long long el) {
+        const int bx = key >> 16, by = key & 0xffff;
+        const int dx = bx - bin_ax0, dy = by - bin_ay0;
+        if (dx >= 0 && dx < kBinW && dy >= 0 && dy < kBinW) {
+            const int slot = dx * kBinW + dy;
+            atomicAdd(&sCnt[wave][slot], cnt);
+            atomicAdd(&sCh[wave][0][slot], c0);
+            atomicAdd(&sCh[wave][1][slot], c1);
+            atomicAdd(&sCh[wave][2][slot], c2);
+            atomicAdd(&sEl[wave][slot], (unsigned long long)el);
+        } else {
+            // outside the wave's window (very fine grids): straight to the global accumulators
+            const int64_t ncell = (int64_t)A.bax.nbin * A.bay.nbin;
+            const int64_t cell = (int64_t)(bx - 1) * A.bay.nbin + (by - 1);
+            atomicAdd(&A.bin_acc[cell], (unsigned long long)cnt);
+            atomicAdd(&A.bin_acc[ncell + cell], (unsigned long long)c0);
+            atomicAdd(&A.bin_acc[2 * ncell + cell], (unsigned long long)c1);
+            atomicAdd(&A.bin_acc[3 * ncell + cell], (unsigned long long)c2);
+            atomicAdd(&A.bin_acc[4 * ncell + cell], (unsigned long long)el);
+        }
+    };
     const int chunk = item / strips_x, strip = item - chunk * strips_x;
     const int x0 = strip * 63, y0 = chunk * rows_per_chunk;
     const int rows = min(rows_per_chunk, A.height - y0);
@@ -384,8 +437,18 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
                 }
             }
             bool valid = false;
+            int bin_x = 0, bin_y = 0;            // 1-based bin indices of this pixel, 0 = not binned
+            unsigned int ch0 = 0, ch1 = 0, ch2 = 0;
+            long long el_fix = 0;
             if (px_ok) {
                 const int64_t gi = (int64_t)(gy - 1) * A.width + gx;
+                if (BIN == 1) {                  // issue the image loads ahead of the arithmetic
+                    const unsigned char* q = static_cast<const unsigned char*>(A.bin_img) + gi * 3;
+                    ch0 = q[0], ch1 = q[1], ch2 = q[2];
+                } else if (BIN == 2) {
+                    const unsigned short* q = static_cast<const unsigned short*>(A.bin_img) + gi * 3;
+                    ch0 = q[0], ch1 = q[1], ch2 = q[2];
+                }
                 double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN;
                 if (pc.x == pc.x) {
                     karg_ptr K = karg_fresh();
@@ -395,7 +458,7 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
                     double c = -(dc.x * pc.x + dc.y * pc.y + dc.z * pc.z) * fm::rsqrt(dot(pc, pc));
                     c = fmin(1.0, fmax(-1.0, c));
                     el = fm::asin_deg(c);
-                    if (MAG && A.mlat_c)
+                    if (MAG && (A.mlat_c || (BIN && A.bin_magnetic)))
                         sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(), offsetof(georef_args, m_sm)), pc), ml, mt);
                 }
                 if (A.lat_c) A.lat_c[gi] = lac;
@@ -406,6 +469,48 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
                     A.mlt_c[gi] = mt;
                 }
                 valid = (el >= A.bbox_min_elev) && corners_ok;
+                if (BIN && valid) {
+                    // reference resample.py:301-351 on (lon, lat) or, for resampleMLatMLT, on
+                    // (SM longitude = mltToSmLon(mlt), MLat) (mapping.py:1519-1547, transform.py:388-401)
+                    double bxv = (MAG && A.bin_magnetic) ? (mt - 12.0) / (24.0 / 360.0) : loc;
+                    const double byv = (MAG && A.bin_magnetic) ? ml : lac;
+                    if (A.bin_lon_wrap) bxv = wrap180_shifted(bxv);
+                    karg_ptr K = karg_fresh();
+                    const int bx = bin_index(karg_load<axis_dev>(K, offsetof(georef_args, bax)), bxv);
+                    const axis_dev bay = karg_load<axis_dev>(K, offsetof(georef_args, bay));
+                    const int by = bin_index(bay, byv);
+                    if (bx >= 1 && bx <= A.bax.nbin && by >= 1 && by <= bay.nbin) {
+                        bin_x = bx;
+                        bin_y = by;
+                        el_fix = __double2ll_rn(el * kFix);
+                    }
+                }
+            }
+            if (BIN) {
+                const unsigned long long m = __ballot(bin_x > 0);
+                if (m && !bin_anchor) {          // first kept pixel of this wave: centre the window on its cell
+                    const int src = __builtin_ctzll(m);
+                    bin_ax0 = __shfl(bin_x, src) - kBinW / 2;
+                    bin_ay0 = __shfl(bin_y, src) - kBinW / 2;
+                    bin_anchor = true;
+                }
+                // A lane walks down one pixel column: consecutive rows mostly stay in one cell, so the lane sums
+                // that run in registers and only touches the (conflict-prone) LDS window when the cell changes.
+                if (bin_x > 0) {
+                    const int key = (bin_x << 16) | bin_y;
+                    if (key != run_key) {
+                        if (run_key) bin_flush(run_key, run_cnt, run_c0, run_c1, run_c2, run_el);
+                        run_key = key;
+                        run_cnt = 0;
+                        run_c0 = run_c1 = run_c2 = 0;
+                        run_el = 0;
+                    }
+                    run_cnt += 1;
+                    run_c0 += ch0;
+                    run_c1 += ch1;
+                    run_c2 += ch2;
+                    run_el += el_fix;
+                }
             }
             if (want_bbox) {
                 // corner row gy-1 is final now: it keeps a corner when a centre above (flag_prev) or below
@@ -427,6 +532,24 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
         la_prev = la;
         lo_prev = lo;
         flag_prev = flag_cur;
+    }
+    if (BIN && bin_anchor) {
+        if (run_key) bin_flush(run_key, run_cnt, run_c0, run_c1, run_c2, run_el);
+        // flush this wave's window: one 64-bit integer atomic per touched cell and plane
+        __threadfence_block();
+        const int64_t ncell = (int64_t)A.bax.nbin * A.bay.nbin;
+#pragma unroll
+        for (int i = lane; i < kBinCells; i += 64) {
+            const unsigned int cnt = sCnt[wave][i];
+            if (cnt == 0) continue;
+            const int dx = i / kBinW, dy = i - dx * kBinW;
+            const int64_t cell = (int64_t)(bin_ax0 + dx - 1) * A.bay.nbin + (bin_ay0 + dy - 1);
+            atomicAdd(&A.bin_acc[cell], (unsigned long long)cnt);
+            atomicAdd(&A.bin_acc[ncell + cell], (unsigned long long)sCh[wave][0][i]);
+            atomicAdd(&A.bin_acc[2 * ncell + cell], (unsigned long long)sCh[wave][1][i]);
+            atomicAdd(&A.bin_acc[3 * ncell + cell], (unsigned long long)sCh[wave][2][i]);
+            atomicAdd(&A.bin_acc[4 * ncell + cell], sEl[wave][i]);
+        }
     }
     if (want_bbox) {
         // the chunk's last corner row only has centres above it inside this chunk
@@ -483,13 +606,62 @@ void launch_variant(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag) {
         hipLaunchKernelGGL((k_georef<kTW, kTH, FAST, DIRS_IN, false>), grid, block, 0, ctx->stream, A);
 }
 
-template <bool FAST, bool DIRS_IN>
-void launch_rows(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, int rows, int strips_x, int n_items) {
+template <bool FAST, bool DIRS_IN, int BIN>
+void launch_rows_bin(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, int rows, int strips_x, int n_items) {
     const dim3 block(kThreads);
     if (mag)
-        hipLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, true>), grid, block, 0, ctx->stream, A, rows, strips_x, n_items);
+        hipLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, true, BIN>), grid, block, 0, ctx->stream, A, rows, strips_x,
+                           n_items);
     else
-        hipLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, false>), grid, block, 0, ctx->stream, A, rows, strips_x, n_items);
+        hipLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, false, BIN>), grid, block, 0, ctx->stream, A, rows, strips_x,
+                           n_items);
+}
+
+template <bool FAST, bool DIRS_IN>
+void launch_rows(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, int bin, int rows, int strips_x, int n_items) {
+    if (bin == 1)
+        launch_rows_bin<FAST, DIRS_IN, 1>(ctx, A, grid, mag, rows, strips_x, n_items);
+    else if (bin == 2)
+        launch_rows_bin<FAST, DIRS_IN, 2>(ctx, A, grid, mag, rows, strips_x, n_items);
+    else
+        launch_rows_bin<FAST, DIRS_IN, 0>(ctx, A, grid, mag, rows, strips_x, n_items);
+}
+
+// One thread per lattice corner (every `stride`-th pixel corner): bounding box of the corners whose own ray
+// has an elevation >= min_elev, in (lat, lon) or (MLat, SM longitude).  Partials per workgroup.
+__global__ __launch_bounds__(kThreads) void k_coarse_bbox(georef_args A, int stride, int magnetic, double min_elev,
+                                                           double* __restrict__ partials) {
+    __shared__ double sRed[8][kThreads / 64];
+    const int nxl = (A.width + stride - 1) / stride + 1, nyl = (A.height + stride - 1) / stride + 1;
+    double v[8] = {kInf, -kInf, kInf, -kInf, kInf, -kInf, 0, 0};
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < nxl * nyl) {
+        const int iy = i / nxl, ix = i - iy * nxl;
+        const int gx = min(ix * stride, A.width), gy = min(iy * stride, A.height);
+        const vec3 d = tan_direction_fast(A.wcs, gx - 0.5, gy - 0.5);
+        const double t = ray_param_fast(A.ray, d);
+        if (t == t) {
+            const vec3 p = ray_point(A.ray, d, t);
+            double c = -(d.x * p.x + d.y * p.y + d.z * p.z) * fm::rsqrt(dot(p, p));
+            c = fmin(1.0, fmax(-1.0, c));
+            if (fm::asin_deg(c) >= min_elev) {
+                double la, lo;
+                if (magnetic) {
+                    double mt;
+                    sm_to_mlat_mlt_fast(mul(A.m_sm, p), la, mt);
+                    lo = (mt - 12.0) / (24.0 / 360.0);
+                } else {
+                    const vec3 g = mul(A.m_geo, p);
+                    ecef_to_geodetic_deg_fast(A.bw, g.x, g.y, g.z, la, lo);
+                }
+                v[0] = v[1] = la;
+                v[2] = v[3] = lo;
+                if (lo > 0) v[4] = lo; else v[5] = lo;
+                v[6] = 1;
+            }
+        }
+    }
+    block_reduce8<kThreads>(v, partials + (int64_t)blockIdx.x * 8, sRed);
 }
 
 int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, const amt_georef_out* out) {
@@ -518,6 +690,26 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     A.mlat_c = out->mlat_c;
     A.mlt_c = out->mlt_c;
     A.bbox_min_elev = out->bbox_min_elevation;
+    int bin = 0;
+    A.bin_img = nullptr;
+    A.bin_acc = nullptr;
+    A.bin_lon_wrap = A.bin_magnetic = 0;
+    std::memset(&A.bax, 0, sizeof(A.bax));
+    std::memset(&A.bay, 0, sizeof(A.bay));
+    if (out->bin_acc != nullptr) {
+        AMT_REQUIRE(ctx, out->bin_img && (out->bin_img_dtype == 1 || out->bin_img_dtype == 2),
+                    "fused binning needs a uint8 (1) or uint16 (2) RGB image");
+        AMT_REQUIRE(ctx, axis_ok(out->bin_xaxis) && axis_ok(out->bin_yaxis) && out->bin_xaxis->uniform &&
+                             out->bin_yaxis->uniform, "fused binning needs two uniform axes");
+        AMT_REQUIRE(ctx, out->bin_xaxis->nbin < 65535 && out->bin_yaxis->nbin < 65535, "at most 65534 bins per axis");
+        make_axis(out->bin_xaxis, &A.bax);
+        make_axis(out->bin_yaxis, &A.bay);
+        A.bin_img = out->bin_img;
+        A.bin_acc = reinterpret_cast<unsigned long long*>(out->bin_acc);
+        A.bin_lon_wrap = out->bin_lon_wrap ? 1 : 0;
+        A.bin_magnetic = out->bin_magnetic ? 1 : 0;
+        bin = out->bin_img_dtype;
+    }
     // kernel selection: row-marching waves (default) or LDS tiles (AMT_GEOREF_KERNEL=tile), for A/B runs
     static const bool use_tiles = [] {
         const char* e = std::getenv("AMT_GEOREF_KERNEL");
@@ -545,7 +737,8 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
         fold = A.bbox_partials + n_items * 8;
     }
     const dim3 grid((unsigned)nblocks);
-    const bool mag = out->mlat != nullptr || out->mlat_c != nullptr;
+    const bool mag = out->mlat != nullptr || out->mlat_c != nullptr || A.bin_magnetic;
+    AMT_REQUIRE(ctx, !(bin && use_tiles), "fused binning is implemented by the row-marching kernel only");
     amt_timing_mark(ctx, AMT_KERNEL_GEOREF);
     if (use_tiles) {
         if (dirs) {
@@ -557,11 +750,11 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
         }
     } else {
         if (dirs) {
-            launch_rows<true, true>(ctx, A, grid, mag, rows_per_chunk, strips_x, (int)n_items);
+            launch_rows<true, true>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items);
         } else if (p->fast_center) {
-            launch_rows<true, false>(ctx, A, grid, mag, rows_per_chunk, strips_x, (int)n_items);
+            launch_rows<true, false>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items);
         } else {
-            launch_rows<false, false>(ctx, A, grid, mag, rows_per_chunk, strips_x, (int)n_items);
+            launch_rows<false, false>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items);
         }
     }
     amt_timing_mark(ctx, AMT_KERNEL_GEOREF);
@@ -583,6 +776,35 @@ extern "C" {
 int amt_georef_frame(amt_ctx* ctx, const amt_frame_params* p, const amt_georef_out* out) {
     AMT_CHECK_CTX(ctx);
     return launch_georef(ctx, p, nullptr, out);
+}
+
+int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stride, double min_elevation,
+                           int magnetic, double* bbox) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, p && bbox, "NULL argument");
+    AMT_REQUIRE(ctx, p->width > 0 && p->height > 0 && stride > 0, "bad frame or stride");
+    georef_args A;
+    std::memset(&A, 0, sizeof(A));
+    A.wcs = make_tan_wcs(p);
+    A.ray = make_ray(p->a, p->b, p->cam, 1);
+    A.m_geo = make_mat3(p->m_geo);
+    A.m_sm = make_mat3(p->m_sm);
+    A.bw = make_bowring_fast(p->a0, p->b0);
+    A.width = p->width;
+    A.height = p->height;
+    const int nxl = (p->width + stride - 1) / stride + 1, nyl = (p->height + stride - 1) / stride + 1;
+    const int nblocks = (nxl * nyl + kThreads - 1) / kThreads;
+    double* partials = static_cast<double*>(amt_workspace(ctx, (size_t)nblocks * 8 * sizeof(double)));
+    if (partials == nullptr) {
+        ctx->last_error = "amt_georef_coarse_bbox: workspace allocation failed";
+        return AMT_ENOMEM;
+    }
+    hipLaunchKernelGGL(k_coarse_bbox, dim3(nblocks), dim3(kThreads), 0, ctx->stream, A, stride, magnetic ? 1 : 0,
+                       min_elevation, partials);
+    AMT_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, ctx->stream, partials, nblocks, bbox);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
 }
 
 int amt_georef_frame_dirs(amt_ctx* ctx, const amt_frame_params* p, const double* corner_dirs,

@@ -1,0 +1,289 @@
+// Single-pass frame driver (see include/auromat_hip.h, "grid layout and the single-pass frame driver").
+// Host orchestration only: every kernel it launches lives in amt_georef.hip / amt_binning.hip.
+#include <algorithm>
+#include <new>
+
+#include "amt_common.h"
+#include "amt_grid.h"
+
+struct amt_pipe {
+    amt_ctx* ctx;
+    hipStream_t pre_stream;        // coarse pre-pass: must not queue behind the previous frame's kernels
+    hipEvent_t coarse_done, bbox_done;
+    double* dev_small;             // [0..7] coarse bbox, [8..15] exact bbox (device)
+    double* host_small;            // pinned mirror
+    uint64_t* acc;                 // superset accumulators (device), 5 planes
+    size_t acc_cells;              // capacity per plane
+    void* coarse_ws;               // workspace of the pre-pass (the context's belongs to the main stream)
+    size_t coarse_ws_bytes;
+    // state of the frame in flight
+    bool coarse_pending, launched, fused, ready;
+    amt_grid super, exact;
+    int32_t off_x, off_y;          // window of the exact grid inside the superset
+    double lat_ppd, lon_ppd, min_elev;
+    int pole;
+    int img_dtype;
+};
+
+namespace {
+
+constexpr int kCoarseStride = 16;      // every 16th pixel corner at most; >= 128 lattice points on the short side
+constexpr double kMarginDeg = 1.0;     // safety margin around the coarse box (> 3 lattice steps on the ground)
+
+int ensure_acc(amt_pipe* pipe, size_t cells) {
+    if (cells <= pipe->acc_cells) return AMT_OK;
+    amt_ctx* ctx = pipe->ctx;
+    if (pipe->acc) {
+        AMT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        AMT_HIP(ctx, hipFree(pipe->acc));
+        pipe->acc = nullptr;
+        pipe->acc_cells = 0;
+    }
+    const size_t cap = cells < (1u << 16) ? (1u << 16) : cells + cells / 4;
+    AMT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&pipe->acc), cap * 5 * sizeof(uint64_t)));
+    pipe->acc_cells = cap;
+    return AMT_OK;
+}
+
+// Is the north or south pole of the mapping shell imaged by a valid pixel?  The pole point is projected
+// through the inverse TAN model; it counts when it falls inside the frame, is the first hit of its ray and
+// lies above the elevation threshold (host mirror: auromat_amd/mapping/astrometry.py pole_in_view; replaces
+// the outline-based test of the reference, geodesic.py:183 / mapping.py:705-721, for known camera models).
+bool pole_visible(const amt_frame_params* p, double min_elevation) {
+    const double* m = p->m_geo;
+    const double* r = p->rot;
+    const double sc[3] = {1 / p->a, 1 / p->a, 1 / p->b};
+    for (int sign = 1; sign >= -1; sign -= 2) {
+        double u[3], pole[3], los[3], d[3], n2 = 0;
+        for (int i = 0; i < 3; ++i) u[i] = m[6 + i] * sign;              // m^T (0,0,sign): pole axis in J2000
+        for (int i = 0; i < 3; ++i) n2 += u[i] * sc[i] * u[i] * sc[i];
+        double dist2 = 0;
+        for (int i = 0; i < 3; ++i) {
+            pole[i] = u[i] / std::sqrt(n2);
+            los[i] = pole[i] - p->cam[i];
+            dist2 += los[i] * los[i];
+        }
+        const double dist = std::sqrt(dist2);
+        double d_o = 0, d_d = 0, o_o = 0;
+        for (int i = 0; i < 3; ++i) {
+            d[i] = los[i] / dist;
+            const double ds = d[i] * sc[i], os = -p->cam[i] * sc[i];
+            d_o += ds * os;
+            d_d += ds * ds;
+            o_o += os * os;
+        }
+        const double disc = d_o * d_o - o_o * d_d + d_d;
+        if (disc < 0) continue;
+        const double t = (o_o < 1 ? d_o + std::sqrt(disc) : d_o - std::sqrt(disc)) / d_d;
+        if (std::fabs(t - dist) > 1e-6 * dist) continue;                  // the pole is on the far side
+        double v[3];
+        for (int i = 0; i < 3; ++i) v[i] = r[i] * d[0] + r[3 + i] * d[1] + r[6 + i] * d[2];   // rot^T d
+        if (v[2] <= 0) continue;
+        const double k = 180.0 / M_PI, bx = k * v[1] / v[2], by = -k * v[0] / v[2];
+        const double det = p->cd[0] * p->cd[3] - p->cd[1] * p->cd[2];
+        const double px = (bx * p->cd[3] - p->cd[1] * by) / det, py = (p->cd[0] * by - p->cd[2] * bx) / det;
+        const double x = px + p->crpix[0] - 1, y = py + p->crpix[1] - 1;
+        if (!(x >= -0.5 && x <= p->width - 0.5 && y >= -0.5 && y <= p->height - 0.5)) continue;
+        if (!std::isinf(min_elevation)) {
+            double dp = 0, pp = 0;
+            for (int i = 0; i < 3; ++i) {
+                dp += d[i] * pole[i];
+                pp += pole[i] * pole[i];
+            }
+            double sn = -dp / std::sqrt(pp);
+            sn = sn < -1 ? -1 : (sn > 1 ? 1 : sn);
+            if (!(std::asin(sn) * k >= min_elevation)) continue;
+        }
+        return true;
+    }
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amt_grid_layout(double lat_px_per_deg, double lon_px_per_deg, double lat_min, double lat_max, double lon_min,
+                    double lon_max, amt_grid* out) {
+    if (out == nullptr) return AMT_EINVAL;
+    std::memset(out, 0, sizeof(*out));
+    return amt_gl::layout(lat_px_per_deg, lon_px_per_deg, lat_min, lat_max, lon_min, lon_max, out) ? AMT_OK
+                                                                                                       : AMT_EINVAL;
+}
+
+int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, out_pipe != nullptr, "out_pipe is NULL");
+    *out_pipe = nullptr;
+    if (amt_set_device(ctx)) return AMT_EHIP;
+    amt_pipe* pipe = new (std::nothrow) amt_pipe();
+    if (pipe == nullptr) return AMT_ENOMEM;
+    std::memset(pipe, 0, sizeof(*pipe));
+    pipe->ctx = ctx;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    bool ok = hipStreamCreateWithPriority(&pipe->pre_stream, hipStreamNonBlocking, hi) == hipSuccess &&
+              hipEventCreateWithFlags(&pipe->coarse_done, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&pipe->bbox_done, hipEventDisableTiming) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&pipe->dev_small), 16 * sizeof(double)) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&pipe->host_small), 16 * sizeof(double), hipHostMallocDefault) ==
+                  hipSuccess;
+    if (!ok) {
+        ctx->last_error = "amt_pipe_create: resource allocation failed";
+        amt_pipe_destroy(pipe);
+        return AMT_EHIP;
+    }
+    *out_pipe = pipe;
+    return AMT_OK;
+}
+
+int amt_pipe_destroy(amt_pipe* pipe) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    if (pipe->pre_stream) {
+        (void)hipStreamSynchronize(pipe->pre_stream);
+        (void)hipStreamDestroy(pipe->pre_stream);
+    }
+    if (pipe->coarse_done) (void)hipEventDestroy(pipe->coarse_done);
+    if (pipe->bbox_done) (void)hipEventDestroy(pipe->bbox_done);
+    if (pipe->dev_small) (void)hipFree(pipe->dev_small);
+    if (pipe->host_small) (void)hipHostFree(pipe->host_small);
+    if (pipe->acc) (void)hipFree(pipe->acc);
+    if (pipe->coarse_ws) (void)hipFree(pipe->coarse_ws);
+    delete pipe;
+    return AMT_OK;
+}
+
+int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipe->ctx;
+    AMT_REQUIRE(ctx, p != nullptr, "NULL argument");
+    // the pre-pass runs on the driver's own stream with its own workspace: the context's stream and workspace
+    // are in use by the previous frame's kernels
+    hipStream_t saved = ctx->stream;
+    void* saved_ws = ctx->ws;
+    size_t saved_ws_bytes = ctx->ws_bytes;
+    ctx->stream = pipe->pre_stream;
+    ctx->ws = pipe->coarse_ws;
+    ctx->ws_bytes = pipe->coarse_ws_bytes;
+    const double thr = std::isinf(min_elevation) ? min_elevation : min_elevation - 0.5;
+    const int shorter = p->width < p->height ? p->width : p->height;
+    const int stride = std::max(1, std::min(kCoarseStride, shorter / 128));
+    int rc = amt_georef_coarse_bbox(ctx, p, stride, thr, 0, pipe->dev_small);
+    pipe->coarse_ws = ctx->ws;
+    pipe->coarse_ws_bytes = ctx->ws_bytes;
+    ctx->stream = saved;
+    ctx->ws = saved_ws;
+    ctx->ws_bytes = saved_ws_bytes;
+    if (rc != AMT_OK) return rc;
+    AMT_HIP(ctx, hipMemcpyAsync(pipe->host_small, pipe->dev_small, 8 * sizeof(double), hipMemcpyDeviceToHost,
+                                pipe->pre_stream));
+    AMT_HIP(ctx, hipEventRecord(pipe->coarse_done, pipe->pre_stream));
+    pipe->coarse_pending = true;
+    return AMT_OK;
+}
+
+int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
+                    int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
+                    int pole_in_view) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipe->ctx;
+    AMT_REQUIRE(ctx, p && out && img, "NULL argument");
+    AMT_REQUIRE(ctx, img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
+    if (!pipe->coarse_pending) {
+        if (int rc = amt_pipe_coarse(pipe, p, min_elevation)) return rc;
+    }
+    AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
+    pipe->coarse_pending = false;
+    pipe->lat_ppd = lat_px_per_deg;
+    pipe->lon_ppd = lon_px_per_deg;
+    pipe->min_elev = min_elevation;
+    pipe->pole = pole_in_view < 0 ? (pole_visible(p, min_elevation) ? 1 : 0) : (pole_in_view ? 1 : 0);
+    pipe->img_dtype = img_dtype;
+    pipe->fused = false;
+
+    amt_georef_out o = *out;
+    o.bbox = pipe->dev_small + 8;
+    o.bbox_min_elevation = min_elevation;
+    o.bin_acc = nullptr;
+    o.bin_xaxis = o.bin_yaxis = nullptr;
+    o.bin_img = nullptr;
+    o.bin_img_dtype = o.bin_lon_wrap = o.bin_magnetic = o.bin_reserved = 0;
+
+    const double* c = pipe->host_small;     // coarse [lat_min, lat_max, lon_min, lon_max, ..., n]
+    bool fuse = c[6] > 0 && !(c[3] - c[2] > 180) && !pipe->pole;
+    if (fuse) {
+        const double lat_abs = std::fmax(std::fabs(c[0]), std::fabs(c[1]));
+        const double lon_margin = std::fmin(10.0, kMarginDeg / std::fmax(0.1, std::cos(lat_abs * amt::kDeg2Rad)));
+        const double lat_lo = std::fmax(-89.0, c[0] - kMarginDeg), lat_hi = std::fmin(89.0, c[1] + kMarginDeg);
+        const double lon_lo = c[2] - lon_margin, lon_hi = c[3] + lon_margin;
+        fuse = lon_lo > -179.0 && lon_hi < 179.0 &&
+               amt_gl::layout(lat_px_per_deg, lon_px_per_deg, lat_lo, lat_hi, lon_lo, lon_hi, &pipe->super);
+    }
+    if (fuse) {
+        const size_t cells = (size_t)pipe->super.nx * pipe->super.ny;
+        if (int rc = ensure_acc(pipe, cells)) return rc;
+        AMT_HIP(ctx, hipMemsetAsync(pipe->acc, 0, cells * 5 * sizeof(uint64_t), ctx->stream));
+        o.bin_xaxis = &pipe->super.xaxis;
+        o.bin_yaxis = &pipe->super.yaxis;
+        o.bin_img = img;
+        o.bin_img_dtype = img_dtype;
+        o.bin_acc = pipe->acc;
+        pipe->fused = true;
+    }
+    if (int rc = amt_georef_frame(ctx, p, &o)) return rc;
+    AMT_HIP(ctx, hipMemcpyAsync(pipe->host_small + 8, pipe->dev_small + 8, 8 * sizeof(double), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    AMT_HIP(ctx, hipEventRecord(pipe->bbox_done, ctx->stream));
+    pipe->launched = true;
+    return AMT_OK;
+}
+
+int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipe->ctx;
+    AMT_REQUIRE(ctx, result != nullptr, "result is NULL");
+    AMT_REQUIRE(ctx, pipe->launched, "amt_pipe_launch has not been called for this frame");
+    pipe->launched = false;
+    pipe->ready = false;
+    AMT_HIP(ctx, hipEventSynchronize(pipe->bbox_done));
+    std::memset(result, 0, sizeof(*result));
+    const double* b = pipe->host_small + 8;
+    for (int i = 0; i < 8; ++i) result->bbox[i] = b[i];
+    result->bbox[7] = pipe->pole ? 1.0 : 0.0;      // pole containment comes from the camera model
+    result->fused = pipe->fused ? 1 : 0;
+    if (b[6] == 0) {
+        result->status = 2;
+        return AMT_OK;
+    }
+    result->status = 1;
+    if (!pipe->fused || pipe->pole || b[3] - b[2] > 180) return AMT_OK;
+    amt_grid& g = result->grid;
+    if (!amt_gl::layout(pipe->lat_ppd, pipe->lon_ppd, b[0], b[1], b[2], b[3], &g)) return AMT_OK;
+    const amt_grid& s = pipe->super;
+    // window of the exact grid inside the superset (same global nodes => integer offsets)
+    const long off_x = std::lround((g.lon_center_first - s.lon_center_first) / s.lon_step);
+    const long off_y = std::lround((g.lat_center_last - s.lat_center_last) / std::fabs(s.lat_step));
+    if (off_x < 0 || off_y < 0 || off_x + g.nx > s.nx || off_y + g.ny > s.ny) return AMT_OK;
+    const double lon_at = s.lon_center_first + off_x * s.lon_step;
+    const double lat_at = s.lat_center_last + off_y * std::fabs(s.lat_step);
+    if (std::fabs(lon_at - g.lon_center_first) > 1e-9 || std::fabs(lat_at - g.lat_center_last) > 1e-9) return AMT_OK;
+    pipe->exact = g;
+    pipe->off_x = (int32_t)off_x;
+    pipe->off_y = (int32_t)off_y;
+    pipe->ready = true;
+    result->status = 0;
+    return AMT_OK;
+}
+
+int amt_pipe_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_mask, double* out_count) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipe->ctx;
+    AMT_REQUIRE(ctx, pipe->ready, "amt_pipe_wait has not returned status 0 for this frame");
+    pipe->ready = false;
+    const amt_grid& s = pipe->super;
+    const amt_grid& g = pipe->exact;
+    return amt_bin_frame_finalize_window(ctx, pipe->acc, s.nx, s.ny, pipe->off_x, pipe->off_y, g.nx, g.ny, 3,
+                                         pipe->img_dtype, mean, out_img, out_mask, out_count);
+}
+
+}  // extern "C"

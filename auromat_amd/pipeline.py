@@ -1,18 +1,27 @@
 """
 Device-resident frame pipeline: georeference -> (mask by elevation) -> bounding box -> grid ->
 binned mean, i.e. what ``resample(getMapping(...).maskedByElevation(e), pxPerDeg=...)`` does in the
-reference (spacecraft.py:380-426, mapping.py:845-864, resample.py:73-157), as three kernel launches
-per frame on pre-allocated HBM buffers:
+reference (spacecraft.py:380-426, mapping.py:845-864, resample.py:73-157) on pre-allocated HBM buffers.
 
-  1. amt_georef_frame   corner/centre lat, lon, elevation (+ MLat/MLT) and the bounding-box reduction
-                        of the corners that survive the elevation mask
-  2. amt_bin_frame      bin assignment + LDS-privatised integer accumulation (the elevation mask is
-                        applied on the fly, no mask array is materialised)
-  3. amt_bin_frame_finalize  mean / rounding / flip into the output layout
+Two execution plans give identical results:
 
-Between 1 and 2 the host reads the 8 bounding-box doubles and lays out the grid
-(reference resample.py:220-241,281-299).  This is the path bench.py times and that
-``auromat_amd.sequence`` shards over GPUs; the mapping classes give the same results lazily.
+* two-pass (always available):
+    1. amt_georef_frame        corner/centre lat, lon, elevation (+ MLat/MLT) and the bounding-box reduction
+                               of the corners that survive the elevation mask
+    2. amt_bin_frame           re-reads centre lat/lon/elevation + image, bins (elevation mask on the fly)
+    3. amt_bin_frame_finalize  mean / rounding / flip into the output layout
+  The host reads the 8 bounding-box doubles between 1 and 2 and lays out the grid
+  (reference resample.py:220-241,281-299).
+
+* single-pass (``fuse=True``; geodetic grids without pole / discontinuity): the binning happens inside the
+  georeferencing kernel, so nothing is read back.  Because the grid depends on the bounding box the kernel
+  itself produces, a cheap pre-pass (amt_georef_coarse_bbox, every 16th corner) estimates the box, the
+  kernel bins into a *superset* grid aligned to the same global nodes, and the exact window is cropped in
+  amt_bin_frame_finalize_window once the exact box is known.  If the exact box is not inside the superset
+  (never observed; the margin is > 3 lattice steps) the two-pass plan runs instead.
+
+This is the path bench.py times and that ``auromat_amd.sequence`` shards over GPUs; the mapping classes
+give the same results lazily.
 """
 import ctypes as C
 
@@ -21,8 +30,31 @@ import numpy as np
 from .frame import FrameData
 from .mapping.astrometry import frame_params, pole_in_view
 from .mapping.mapping import bounding_box_from_reduction
-from .resample import resample_frame
-from ._native import Context, GeorefOut, ptr, to_host
+from .resample import cached_grid, grid_coordinates, resample_frame
+from ._native import Context, GeorefOut, PipeResult, ptr, to_host
+
+NEG_INF = float('-inf')
+
+
+class _GridView(object):
+    """
+    Output grid as laid out by the native driver (amt_grid): sizes, steps and first centres are available
+    at once; everything else (coordinate arrays) comes from the equal :class:`auromat_amd.resample._Grid`,
+    built when first asked for.
+    """
+
+    def __init__(self, g, pxPerDeg, box):
+        self.nx, self.ny = g.nx, g.ny
+        self.latStep, self.lonStep = g.lat_step, g.lon_step
+        self.lat0, self.lon0 = g.lat_center_first, g.lon_center_first
+        self._pxPerDeg, self._box, self._full = pxPerDeg, box, None
+
+    def __getattr__(self, name):
+        if name.startswith('_'):
+            raise AttributeError(name)
+        if self._full is None:
+            self._full = cached_grid(self._pxPerDeg, *self._box)
+        return getattr(self._full, name)
 
 
 class FramePipeline(object):
@@ -43,10 +75,27 @@ class FramePipeline(object):
         self.with_mag = with_mag
         self._bbox_host = torch.empty(8, dtype=torch.float64, pin_memory=True)
         self._bbox_event = torch.cuda.Event()
+        self._driver = None         # amt_pipe handle of the single-pass plan (created on first use)
+        self._fused = None          # single-pass launch in flight: its px/deg, later its amt_pipe_result
+        self._pole = 0
+        self.last_plan = None       # 'single-pass' or 'two-pass': what the last resample() did
         self.params = None
         self.altitude = None
         self.min_elevation = None
-        self.events = None
+        out = self._out = GeorefOut()
+        out.lat, out.lon, out.lat_c, out.lon_c, out.elev = (t.data_ptr() for t in
+                                                            (fd.lat, fd.lon, fd.lat_c, fd.lon_c, fd.elev))
+        if with_mag:
+            out.mlat, out.mlt, out.mlat_c, out.mlt_c = (t.data_ptr() for t in (fd.mlat, fd.mlt, fd.mlat_c, fd.mlt_c))
+        out.bbox = fd.bbox.data_ptr()
+
+    def __del__(self):
+        if getattr(self, '_driver', None):
+            try:
+                self.ctx._lib.amt_pipe_destroy(self._driver)
+            except Exception:
+                pass
+            self._driver = None
 
     # -- inputs ---------------------------------------------------------------------------------
     def set_image(self, img):
@@ -54,39 +103,101 @@ class FramePipeline(object):
         t = self.ctx.to_device(img, self.fd.img_dtype)
         self.fd.img.copy_(t.reshape(self.fd.img.shape))
 
+    # -- single-pass plan (native driver, include/auromat_hip.h amt_pipe_*) ----------------------
+    def _pipe(self):
+        if self._driver is None:
+            handle = C.c_void_p()
+            self.ctx.call('amt_pipe_create', C.byref(handle))
+            self._driver = handle
+        return self._driver
+
+    def _pcall(self, name, *args):
+        # amt_pipe_* take the driver handle (not the context) as their first argument
+        self.ctx.check(getattr(self.ctx._lib, name)(self._pipe(), *args))
+
+    def start_coarse(self, params, min_elevation):
+        """Enqueue the coarse bounding-box pre-pass for `params` (asynchronous, on the driver's own stream)."""
+        self._pcall('amt_pipe_coarse', C.byref(params),
+                      NEG_INF if min_elevation is None else float(min_elevation))
+
+    def _wait_fused(self):
+        """amt_pipe_wait once per launch -> the amt_pipe_result."""
+        f = self._fused
+        if f['result'] is None:
+            res = PipeResult()
+            self._pcall('amt_pipe_wait', C.byref(res))
+            f['result'] = res
+        return f['result']
+
     # -- stages ---------------------------------------------------------------------------------
-    def georef(self, wcsHeader, altitude, cameraPosGCRS, photoTime, fast=True, min_elevation=10.0, params=None):
-        """Stage 1.  `params` (an amt_frame_params made by :func:`frame_params`) skips the host set-up."""
+    def georef(self, wcsHeader, altitude, cameraPosGCRS, photoTime, fast=True, min_elevation=10.0, params=None,
+               fuse_pxPerDeg=None, coarse_started=False):
+        """
+        Stage 1.  `params` (an amt_frame_params made by :func:`frame_params`) skips the host set-up.
+        `fuse_pxPerDeg` = (latPxPerDeg, lonPxPerDeg) selects the single-pass plan for that resolution.
+        """
         assert wcsHeader is None or (wcsHeader['IMAGEW'], wcsHeader['IMAGEH']) == (self.width, self.height)
         p = params if params is not None else frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fast,
                                                            magnetic=self.with_mag)
         fd = self.fd
         Context.current(self.ctx.device)      # enqueue on whatever stream torch has current now
-        out = GeorefOut()
-        out.lat, out.lon, out.lat_c, out.lon_c, out.elev = (t.data_ptr() for t in
-                                                            (fd.lat, fd.lon, fd.lat_c, fd.lon_c, fd.elev))
-        if self.with_mag:
-            out.mlat, out.mlt, out.mlat_c, out.mlt_c = (t.data_ptr() for t in
-                                                        (fd.mlat, fd.mlt, fd.mlat_c, fd.mlt_c))
-        out.bbox = fd.bbox.data_ptr()
-        out.bbox_min_elevation = float('-inf') if min_elevation is None else float(min_elevation)
+        out = self._out
+        min_elev = NEG_INF if min_elevation is None else float(min_elevation)
+        self.params, self.altitude, self.min_elevation = p, altitude, min_elevation
+        if fuse_pxPerDeg is not None and fd.nchan == 3:
+            # coarse pre-pass (unless already enqueued), superset grid, fused kernel, bbox copy: all in the driver
+            if not coarse_started:
+                self.start_coarse(p, min_elevation)
+            self._pcall('amt_pipe_launch', C.byref(p), C.byref(out), fd.img.data_ptr(),
+                          fd.img_dtype_code, min_elev, float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1)
+            self._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), result=None)
+            return fd
+        self._fused = None
+        self._pole = None                                # decided lazily in bounding_box()
+        out.bbox_min_elevation = min_elev
         self.ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
         # the 8 reduction doubles travel to pinned host memory right behind the kernel; the event lets
         # bounding_box() wait for exactly this point while later launches keep the GPU busy
         self._bbox_host.copy_(fd.bbox, non_blocking=True)
         self._bbox_event.record()
-        self.params, self.altitude, self.min_elevation = p, altitude, min_elevation
         return fd
 
     def bounding_box(self):
         """Waits for the fused reduction of the last georef() -> BoundingBox; ValueError if nothing is valid."""
-        self._bbox_event.synchronize()
-        red = self._bbox_host.numpy().copy()
+        if self._fused is not None:
+            red = np.array(self._wait_fused().bbox[:])
+        else:
+            self._bbox_event.synchronize()
+            red = self._bbox_host.numpy().copy()
+            if self._pole is None:
+                # pole containment from the camera model (the kernel does not count pole quads)
+                self._pole = pole_in_view(self.params, self.min_elevation)
+            red[7] = 1.0 if self._pole else 0.0
         if red[6] == 0:
             raise ValueError('minElevation=' + str(self.min_elevation) + ' would mask all pixels!')
-        # pole containment from the camera model (the fused kernel does not count pole quads)
-        red[7] = 1.0 if pole_in_view(self.params, self.min_elevation) else 0.0
         return bounding_box_from_reduction(red)
+
+    def _finalize_fused(self, res, pxPerDeg, keep_on_device):
+        """Crop the superset accumulators to the exact grid laid out by amt_pipe_wait."""
+        import torch
+        ctx, fd = self.ctx, self.fd
+        g = res.grid
+        b = res.bbox
+        grid = _GridView(g, pxPerDeg, (b[0], b[1], b[2], b[3]))
+        mean = ctx.empty((g.ny, g.nx, 4))
+        img = ctx.empty((g.ny, g.nx, 3), torch.uint8 if fd.img_dtype_code != 2 else torch.int16)
+        mask = ctx.empty((g.ny, g.nx), torch.uint8)
+        count = ctx.empty((g.ny, g.nx))
+        self._pcall('amt_pipe_finalize', ptr(mean), ptr(img), ptr(mask), ptr(count))
+        out = dict(has_elev=True, grid=grid, contains_pole=False, contains_discontinuity=False,
+                   altitude=self.altitude)
+        if keep_on_device:
+            out.update(mean=mean, img=img, mask=mask, count=count)
+            return out
+        out.update(grid_coordinates(out))
+        out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype), mask=to_host(mask).astype(bool),
+                   count=to_host(count))
+        return out
 
     def resample(self, pxPerDeg=10, containsPole=None, magnetic=False, keep_on_device=False):
         """Stages 2 + 3.  magnetic=True bins on the (MLat, SM longitude) grid (resampleMLatMLT)."""
@@ -96,6 +207,11 @@ class FramePipeline(object):
             pxPerDeg = (pxPerDeg, pxPerDeg)
         fd = self.fd
         Context.current(self.ctx.device)
+        if not magnetic and self._fused is not None and self._fused['pxPerDeg'] == tuple(pxPerDeg):
+            res = self._wait_fused()
+            if res.status == 0 and not containsPole:       # status 0: neither pole nor discontinuity in the frame
+                self.last_plan = 'single-pass'
+                return self._finalize_fused(res, tuple(pxPerDeg), keep_on_device)
         if magnetic:
             assert self.with_mag
             sm = fd.shallow_copy()
@@ -104,7 +220,7 @@ class FramePipeline(object):
             red = self.ctx.empty((8,))
             # corners of centres that pass the elevation threshold, in SM coordinates
             import torch
-            cmask = (~(fd.elev >= (float('-inf') if self.min_elevation is None else self.min_elevation))).to(torch.uint8)
+            cmask = (~(fd.elev >= (NEG_INF if self.min_elevation is None else self.min_elevation))).to(torch.uint8)
             corner = torch.isnan(fd.lat).to(torch.uint8)
             self.ctx.call('amt_sanitize_masks', ptr(corner), ptr(cmask), None, fd.height, fd.width, 1)
             self.ctx.call('amt_bbox_corners', ptr(sm.lat), ptr(sm.lon), ptr(corner), ptr(cmask), fd.height, fd.width,
@@ -114,15 +230,21 @@ class FramePipeline(object):
         else:
             bb = self.bounding_box()
         pole = bb.containsPole if containsPole is None else containsPole
+        self.last_plan = 'two-pass'
         return resample_frame(fd, self.altitude, bb, pxPerDeg, bb.containsDiscontinuity, pole,
                               min_elevation=self.min_elevation, keep_on_device=keep_on_device)
 
     def run(self, wcsHeader, altitude, cameraPosGCRS, photoTime, img=None, fast=True, min_elevation=10.0,
-            pxPerDeg=10, containsPole=None, magnetic=False, params=None, keep_on_device=False):
+            pxPerDeg=10, containsPole=None, magnetic=False, params=None, keep_on_device=False, fuse=False):
         """One frame end to end; returns the dict of :func:`auromat_amd.resample.resample_frame`."""
         if img is not None:
             self.set_image(img)
-        self.georef(wcsHeader, altitude, cameraPosGCRS, photoTime, fast, min_elevation, params=params)
+        try:
+            _, _ = pxPerDeg
+        except TypeError:
+            pxPerDeg = (pxPerDeg, pxPerDeg)
+        self.georef(wcsHeader, altitude, cameraPosGCRS, photoTime, fast, min_elevation, params=params,
+                    fuse_pxPerDeg=pxPerDeg if (fuse and not magnetic) else None)
         return self.resample(pxPerDeg, containsPole, magnetic, keep_on_device=keep_on_device)
 
     def host_arrays(self):

@@ -119,10 +119,20 @@ def fixedGrid(pxPerDeg, latMin, latMax, lonMin, lonMax):
     latPxPerDeg, lonPxPerDeg = pxPerDeg
     latSpaceAll = _global_axis(-90, 90, int(round(latPxPerDeg * 180 + 1)))
     lonSpaceAll = _global_axis(-180, 180, int(round(lonPxPerDeg * 360 + 1)))
-    latMinInGrid = latSpaceAll[np.argmax(latSpaceAll > latMin) - 1]
-    latMaxInGrid = latSpaceAll[np.argmax(latSpaceAll >= latMax)]
-    lonMinInGrid = lonSpaceAll[np.argmax(lonSpaceAll > lonMin) - 1]
-    lonMaxInGrid = lonSpaceAll[np.argmax(lonSpaceAll >= lonMax)]
+    # np.argmax(axis > v) / np.argmax(axis >= v) of the reference, as binary searches on the sorted axis
+    # (an all-False comparison gives index 0 there, i.e. the searchsorted result n wraps to 0)
+    def first_gt(axis, v):
+        i = int(np.searchsorted(axis, v, side='right'))
+        return i if i < len(axis) else 0
+
+    def first_ge(axis, v):
+        i = int(np.searchsorted(axis, v, side='left'))
+        return i if i < len(axis) else 0
+
+    latMinInGrid = latSpaceAll[first_gt(latSpaceAll, latMin) - 1]
+    latMaxInGrid = latSpaceAll[first_ge(latSpaceAll, latMax)]
+    lonMinInGrid = lonSpaceAll[first_gt(lonSpaceAll, lonMin) - 1]
+    lonMaxInGrid = lonSpaceAll[first_ge(lonSpaceAll, lonMax)]
     nLat = int(round(latPxPerDeg * (latMaxInGrid - latMinInGrid) + 1))
     nLon = int(round(lonPxPerDeg * (lonMaxInGrid - lonMinInGrid) + 1))
     return nLat, nLon, latMinInGrid, latMaxInGrid, lonMinInGrid, lonMaxInGrid
@@ -140,13 +150,33 @@ def _global_axis(lo, hi, n):
     return _GLOBAL_AXES[key]
 
 
+_GRID_CACHE = {}
+
+
+def cached_grid(pxPerDeg, latMin, latMax, lonMin, lonMax):
+    """
+    The :class:`_Grid` for a bounding box.  Grids only depend on the global nodes the box is rounded out
+    to, and consecutive frames of a sequence mostly round to the same nodes, so the arrays (and the device
+    axis descriptors attached to them) are kept and re-used.
+    """
+    nodes = fixedGrid(pxPerDeg, latMin, latMax, lonMin, lonMax)
+    key = (tuple(pxPerDeg),) + nodes
+    g = _GRID_CACHE.get(key)
+    if g is None:
+        if len(_GRID_CACHE) > 512:
+            _GRID_CACHE.clear()
+        g = _GRID_CACHE[key] = _Grid(pxPerDeg, latMin, latMax, lonMin, lonMax, _nodes=nodes)
+    return g
+
+
 class _Grid(object):
     """Output grid of one resampling (reference resample.py:220-241,330-334)."""
 
-    def __init__(self, pxPerDeg, latMin, latMax, lonMin, lonMax):
+    def __init__(self, pxPerDeg, latMin, latMax, lonMin, lonMax, _nodes=None):
         latPxPerDeg, lonPxPerDeg = pxPerDeg
         assert latPxPerDeg > 0 and lonPxPerDeg > 0
-        nLat, nLon, latLo, latHi, lonLo, lonHi = fixedGrid(pxPerDeg, latMin, latMax, lonMin, lonMax)
+        nLat, nLon, latLo, latHi, lonLo, lonHi = _nodes or fixedGrid(pxPerDeg, latMin, latMax, lonMin, lonMax)
+        self._axes = {}
         assert nLat > 1, 'nlat={}, latMax={}, latMin={}, pxperdeg={}'.format(nLat, latHi, latLo, pxPerDeg)
         assert nLon > 1, 'nlon={}, lonMax={}, lonMin={}, pxperdeg={}'.format(nLon, lonHi, lonLo, pxPerDeg)
         latSpaceCenter, latStep = np.linspace(latHi, latLo, num=nLat, retstep=True)
@@ -157,6 +187,8 @@ class _Grid(object):
         self.latCenters = latSpaceCenter[1:-1]
         self.lonCenters = lonSpaceCenter[1:-1]
         self.latStep, self.lonStep = latStep, lonStep
+        self.lat0, self.lon0 = (float(self.latCenters[0]), float(self.lonCenters[0])) if nLat > 2 and nLon > 2 \
+            else (np.nan, np.nan)
         self._latSpace, self._lonSpace = latSpace, lonSpace
         self._corner_grid = self._center_grid = None
         self.nx, self.ny = len(self.lonCenters), len(self.latCenters)
@@ -165,6 +197,14 @@ class _Grid(object):
         self.yrange = [self.latCenters[-1] + latStep / 2, self.latCenters[0] - latStep / 2]
         self.xedges = np.linspace(self.xrange[0], self.xrange[1], self.nx + 1)
         self.yedges = np.linspace(self.yrange[0], self.yrange[1], self.ny + 1)
+
+    def axes(self, ctx):
+        """(amt_axis x, amt_axis y) of this grid on `ctx`'s device (built once, kept alive with the grid)."""
+        key = ctx.device.index
+        if key not in self._axes:
+            self._axes[key] = (make_axis(ctx, self.xedges, uniform=True), make_axis(ctx, self.yedges, uniform=True))
+        (xaxis, _), (yaxis, _) = self._axes[key]
+        return xaxis, yaxis
 
     # 2-D coordinate arrays of the output mapping (reference resample.py:239-241), built on first use
     def _corners(self):
@@ -237,9 +277,8 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
         lonMin, lonMax = wrap_at_180(lonMin + 180), wrap_at_180(lonMax + 180)
         lon_wrap = 1
 
-    grid = _Grid(pxPerDeg, latMin, latMax, lonMin, lonMax)
-    xaxis, xkeep = make_axis(ctx, grid.xedges, uniform=True)
-    yaxis, ykeep = make_axis(ctx, grid.yedges, uniform=True)
+    grid = cached_grid(pxPerDeg, latMin, latMax, lonMin, lonMax)
+    xaxis, yaxis = grid.axes(ctx)
     nch = fd.nchan
     acc = ctx.zeros((nch + 2, grid.nx * grid.ny), torch.int64)
     min_el = float('-inf') if min_elevation is None else float(min_elevation)

@@ -37,7 +37,7 @@ def pack_results(results, indices, device):
             mean, count = torch.from_numpy(np.ascontiguousarray(mean)), torch.from_numpy(np.ascontiguousarray(count))
         ny, nx, nc = mean.shape
         g = res['grid']
-        descs[i] = torch.tensor([ny, nx, nc, g.latCenters[0], g.lonCenters[0], g.latStep, g.lonStep, idx],
+        descs[i] = torch.tensor([ny, nx, nc, g.lat0, g.lon0, g.latStep, g.lonStep, idx],
                                 dtype=torch.float64)
         parts += [mean.reshape(-1).to(device), count.reshape(-1).to(device)]
     payload = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.float64, device=device)

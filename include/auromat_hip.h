@@ -106,6 +106,8 @@ typedef struct amt_frame_params {
  * (mapping.py:845-864).  Slot 7 (pole containment, what geodesic.py:183 containsOrCrossesPole decides
  * from the outline) is left 0 here: with a camera model the host projects the pole into the frame
  * instead; amt_bbox_corners fills it for arbitrary grids. */
+typedef struct amt_axis amt_axis;   /* defined in the binning section below */
+
 typedef struct amt_georef_out {
     double* lat;      /* corners, deg   (BaseAstrometryMapping.lats,  astrometry.py:118-144) */
     double* lon;      /* corners, deg */
@@ -118,6 +120,22 @@ typedef struct amt_georef_out {
     double* mlt_c;
     double* bbox;
     double bbox_min_elevation;
+    /* Optional fused binning (single-pass resample(method='mean'), auromat/resample.py:301-351): when
+     * bin_acc != NULL every pixel with elevation >= bbox_min_elevation is binned right where it is
+     * computed — x = lon_c, y = lat_c, or (SM longitude, MLat) with bin_magnetic — into the uint64
+     * accumulator planes of amt_bin_frame (count, 3 channel sums, fixed-point elevation), so the centre
+     * arrays need not be read back (and need not be written at all: lat_c/lon_c/elev may be NULL).
+     * The grid must be known before the launch: callers use a superset of the final grid, aligned to the
+     * same global nodes (amt_georef_coarse_bbox), and crop in amt_bin_frame_finalize_window.
+     * Both axes must be uniform; bin_img is (height, width, 3) uint8 (dtype 1) or uint16 (dtype 2). */
+    const amt_axis* bin_xaxis;     /* host pointers */
+    const amt_axis* bin_yaxis;
+    const void* bin_img;
+    uint64_t* bin_acc;
+    int32_t bin_img_dtype;
+    int32_t bin_lon_wrap;
+    int32_t bin_magnetic;
+    int32_t bin_reserved;
 } amt_georef_out;
 
 /* ---- building blocks (auromat.coordinates) ------------------------------------------- */
@@ -190,6 +208,13 @@ int amt_georef_frame(amt_ctx* ctx, const amt_frame_params* p, const amt_georef_o
  * camera model; SURVEY.md §8d "directions-in" variant).  fast_center must be 1. */
 int amt_georef_frame_dirs(amt_ctx* ctx, const amt_frame_params* p, const double* corner_dirs,
                           const amt_georef_out* out);
+/* Cheap estimate of the same bbox[0..6] from every `stride`-th pixel corner in both directions (a
+ * 1/stride^2 sample of the rays): a corner counts when the elevation of its own ray is >= min_elevation.
+ * With magnetic != 0 the box is in (MLat, SM longitude) instead of (lat, lon).  Used to lay out a superset
+ * grid for the fused binning before the full kernel runs; the caller adds a safety margin and checks the
+ * exact box afterwards. */
+int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stride, double min_elevation,
+                           int magnetic, double* bbox);
 
 /* ---- mask rules ---------------------------------------------------------------------- */
 
@@ -265,10 +290,68 @@ int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const 
 int amt_bin_frame_finalize(amt_ctx* ctx, const uint64_t* acc, int32_t nx, int32_t ny, int32_t nchan,
                            int32_t img_dtype, double* mean, void* out_img, uint8_t* out_mask,
                            double* out_count);
+/* Same on a window of a larger accumulator: acc has acc_nx x acc_ny cells per plane (the superset grid of
+ * a fused amt_georef_frame launch); the output covers its cells [off_x, off_x+nx) x [off_y, off_y+ny). */
+int amt_bin_frame_finalize_window(amt_ctx* ctx, const uint64_t* acc, int32_t acc_nx, int32_t acc_ny,
+                                  int32_t off_x, int32_t off_y, int32_t nx, int32_t ny, int32_t nchan,
+                                  int32_t img_dtype, double* mean, void* out_img, uint8_t* out_mask,
+                                  double* out_count);
 /* Same for float accumulators of amt_hist2d_accumulate: mean[k] = sums[k]/count, NaN where empty,
  * transposed + flipped to (ny, nx, nweights). */
 int amt_hist2d_finalize_mean(amt_ctx* ctx, const double* count, const double* const* sums, int32_t nweights,
                              int32_t nx, int32_t ny, double* mean);
+
+/* ---- grid layout and the single-pass frame driver ------------------------------------------ */
+
+/* Output grid of resample(method='mean') for a bounding box: auromat/resample.py:281-299 fixedGrid (global
+ * alignment to +-90/+-180 with 1/pxPerDeg spacing), :220-241 (centres; first and last dropped) and
+ * :330-334 + util/histogram.py:186,215-224 (histogram ranges, edges, right-edge rounding).  Pure host
+ * arithmetic, bit-identical to the NumPy expressions (np.linspace, round, argmax); no GPU needed. */
+typedef struct amt_grid {
+    int32_t nx, ny;                      /* output cells along longitude / latitude */
+    int32_t n_lat_nodes, n_lon_nodes;    /* fixedGrid's nLat, nLon */
+    double lat_lo, lat_hi, lon_lo, lon_hi;   /* global grid nodes enclosing the box */
+    double lat_step, lon_step;           /* centre spacing; lat_step < 0 (rows run north -> south) */
+    double lat_center_first, lat_center_last, lon_center_first, lon_center_last;
+    amt_axis xaxis, yaxis;               /* uniform histogram axes (edges == NULL); y edges ascend */
+} amt_grid;
+/* Returns AMT_OK, or AMT_EINVAL when the box yields no output cell (the reference asserts nLat, nLon > 1). */
+int amt_grid_layout(double lat_px_per_deg, double lon_px_per_deg, double lat_min, double lat_max,
+                    double lon_min, double lon_max, amt_grid* out);
+
+/* Single-pass driver: georeference + mask by elevation + bounding box + grid + binned mean of one frame with
+ * the binning fused into the georeferencing kernel (see amt_georef_out.bin_*), for geodetic grids that contain
+ * neither a pole nor the 180 deg discontinuity.  Three calls per frame so that frames can be software
+ * pipelined by one host thread:
+ *   amt_pipe_coarse   enqueue the coarse bounding-box pre-pass (own high-priority stream), any time earlier
+ *   amt_pipe_launch   wait for it, lay out the superset grid, zero the accumulators, launch the fused kernel
+ *                     on the context's stream, start the copy of the exact bounding box
+ *   amt_pipe_wait     wait for the exact box (the only host synchronisation), lay out the exact grid
+ *   amt_pipe_finalize crop + finalise into arrays the caller sized from the grid amt_pipe_wait returned
+ * status in amt_pipe_result: 0 = ready to finalise; 1 = this frame needs the general path (pole in view,
+ * discontinuity, exact box outside the superset) — the coordinate arrays and bbox are valid, nothing else;
+ * 2 = no pixel above the elevation threshold (mapping.py:858-859 -> ValueError). */
+typedef struct amt_pipe amt_pipe;
+typedef struct amt_pipe_result {
+    int32_t status;
+    int32_t fused;          /* 1 when the fused kernel was launched for this frame */
+    double bbox[8];         /* exact reduction of amt_georef_frame; [7] = 1 when a pole is in view */
+    amt_grid grid;          /* exact output grid (valid for status 0) */
+} amt_pipe_result;
+int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe);
+int amt_pipe_destroy(amt_pipe* pipe);
+int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation);
+/* out: arrays to write (lat .. mlt_c as in amt_georef_frame; bbox / bin_* fields are managed by the driver).
+ * img: (height, width, 3) uint8 (img_dtype 1) or uint16 (2).  min_elevation: -inf disables the mask.
+ * pole_in_view: 0 / 1 = the caller's decision, < 0 = decide from the camera model (is a pole of the mapping
+ * shell imaged by a valid pixel; replaces geodesic.py:183 / mapping.py:705-721 for camera mappings). */
+int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
+                    int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
+                    int pole_in_view);
+int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result);
+/* mean (ny,nx,4) f64, out_img (ny,nx,3) of img_dtype, out_mask (ny,nx) u8, out_count (ny,nx) f64: device
+ * buffers for result->grid of the preceding amt_pipe_wait (any may be NULL). */
+int amt_pipe_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_mask, double* out_count);
 
 #ifdef __cplusplus
 }

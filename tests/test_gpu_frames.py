@@ -287,3 +287,48 @@ def test_pole_detection_camera_model_and_winding():
     from auromat_amd.synthetic import frame_header
     hdr2, cam2, t2 = frame_header(128, 96)
     assert pole_in_view(frame_params(hdr2, 110, cam2, t2, True), 10.0) == 0
+
+
+@pytest.mark.parametrize('width,height,pointing', [(256, 170, 'iss030'), (253, 171, 'iss029'), (4240, 2832, 'iss030')])
+def test_single_pass_plan_equals_two_pass(width, height, pointing):
+    """Binning fused into the georeferencing kernel (superset grid + crop) == separate binning kernel."""
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_header, frame_image
+    hdr, cam, t = frame_header(width, height, pointing)
+    img = frame_image(width, height, seed=11)
+    pipe = FramePipeline(width, height)
+    two = pipe.run(hdr, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, fuse=False)
+    assert pipe.last_plan == 'two-pass'
+    one = pipe.run(hdr, 110, cam, t, fast=True, min_elevation=10, pxPerDeg=10, fuse=True)
+    assert pipe.last_plan == 'single-pass', 'single-pass plan was not taken'
+    for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon', 'lat_c', 'lon_c'):
+        assert np.array_equal(one[k], two[k], equal_nan=True), k
+    # uint8 image and another resolution
+    img8 = frame_image(width, height, seed=12, dtype=np.uint8)
+    p8 = FramePipeline(width, height, img_dtype=np.uint8)
+    a = p8.run(hdr, 110, cam, t, img=img8, min_elevation=15, pxPerDeg=(4, 7), fuse=False)
+    b = p8.run(hdr, 110, cam, t, min_elevation=15, pxPerDeg=(4, 7), fuse=True)
+    assert p8.last_plan == 'single-pass'
+    for k in ('mean', 'count', 'img', 'mask'):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_single_pass_plan_falls_back_on_pole():
+    """Frames with a pole (or the discontinuity) take the two-pass plan even when fusing is requested."""
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.coordinates import transform as T
+    t = datetime(2012, 1, 25, 9, 26, 55)
+    w, h = 96, 96
+    m_geo = T.mat_j2000_to_geo(T.date2es(t))
+    zen = m_geo.T.dot([0.0, 0.0, 1.0])
+    cam = zen * (6356.75 + 400.0)
+    bore = -zen
+    hdr = {'CTYPE1': 'RA---TAN', 'CTYPE2': 'DEC--TAN', 'LONPOLE': 180.0, 'LATPOLE': 0.0,
+           'CRVAL1': np.rad2deg(np.arctan2(bore[1], bore[0])) % 360, 'CRVAL2': np.rad2deg(np.arcsin(bore[2])),
+           'CRPIX1': w / 2 + 0.5, 'CRPIX2': h / 2 + 0.5, 'CD1_1': -0.5, 'CD1_2': 0.0, 'CD2_1': 0.0, 'CD2_2': 0.5,
+           'IMAGEW': w, 'IMAGEH': h}
+    pipe = FramePipeline(w, h)
+    img = np.full((h, w, 3), 777, np.uint16)
+    res = pipe.run(hdr, 110, cam, t, img=img, min_elevation=10, pxPerDeg=2, fuse=True)
+    assert pipe.last_plan == 'two-pass' and res['contains_pole']
+    assert np.all(res['img'][~res['mask']] == 777)

@@ -40,10 +40,12 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_struct_layouts_match_header():
     import ctypes as C
-    from auromat_amd._native import Axis, FrameParams, GeorefOut
+    from auromat_amd._native import Axis, FrameParams, GeorefOut, Grid, PipeResult
     assert C.sizeof(FrameParams) == 16 + 8 * (4 + 2 + 9 + 3 + 4 + 9 + 9)
-    assert C.sizeof(GeorefOut) == 8 * 11
+    assert C.sizeof(GeorefOut) == 8 * 11 + 8 * 4 + 4 * 4
     assert C.sizeof(Axis) == 8 + 8 + 8 * 5
+    assert C.sizeof(Grid) == 16 + 8 * 10 + 2 * C.sizeof(Axis)
+    assert C.sizeof(PipeResult) == 8 + 8 * 8 + C.sizeof(Grid)
 
 
 def test_no_cpu_fallback(lib):
@@ -95,6 +97,40 @@ def test_grid_layout_equals_reference():
     g = _Grid((1, 1), 60, 70, 160, 170)
     assert g.latCenters.tolist() == list(range(69, 60, -1)) and g.lonCenters.tolist() == list(range(161, 170))
     assert fixedGrid((1, 1), 60, 70, 160, 170) == (11, 11, 60.0, 70.0, 160.0, 170.0)
+
+
+def test_native_grid_layout_equals_python_layout(lib):
+    """amt_grid_layout (C++, used by the single-pass driver) == _Grid / make_axis (NumPy, pinned to the reference)."""
+    import ctypes as C
+    from auromat_amd._native import Grid
+    from auromat_amd.resample import _Grid
+    from auromat_amd.util.histogram import make_axis
+    rng = np.random.RandomState(7)
+    g = Grid()
+    n_checked = 0
+    for ppd in [(10, 10), (4, 7), (1, 1), (20, 20), (3, 5), (10, 20), (2.5, 2.5)]:
+        for _ in range(300):
+            lat_c, lon_c = rng.uniform(-80, 80), rng.uniform(-150, 150)
+            dlat, dlon = rng.uniform(0.7, 9), rng.uniform(0.7, 25)
+            box = (lat_c - dlat, lat_c + dlat, lon_c - dlon, lon_c + dlon)
+            if rng.rand() < 0.2:                 # boxes that sit exactly on grid nodes
+                box = tuple(np.round(np.array(box) * ppd[0]) / ppd[0])
+            rc = lib.amt_grid_layout(ppd[0], ppd[1], box[0], box[1], box[2], box[3], C.byref(g))
+            py = _Grid(ppd, *box)
+            assert rc == 0
+            assert (g.nx, g.ny) == (py.nx, py.ny), (ppd, box)
+            assert (g.lat_step, g.lon_step) == (py.latStep, py.lonStep)
+            assert (g.lat_center_first, g.lat_center_last) == (py.latCenters[0], py.latCenters[-1])
+            assert (g.lon_center_first, g.lon_center_last) == (py.lonCenters[0], py.lonCenters[-1])
+            for ax, edges in ((g.xaxis, py.xedges), (g.yaxis, py.yedges)):
+                ref, _ = make_axis(None, edges, uniform=True)
+                assert ref.uniform == 1 and ax.uniform == 1 and not ax.edges
+                for k in ('nbin', 'first', 'last', 'step', 'scale', 'last_rounded'):
+                    assert getattr(ax, k) == getattr(ref, k), (k, ppd, box)
+            n_checked += 1
+    assert n_checked == 2100
+    # a box inside one cell gives no output cell: the reference asserts (resample.py:225-226), the C side says EINVAL
+    assert lib.amt_grid_layout(1.0, 1.0, 10.2, 10.3, 20.2, 20.3, C.byref(g)) != 0
 
 
 def test_bounding_box_logic():
