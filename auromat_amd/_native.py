@@ -108,6 +108,7 @@ _SIGNATURES = {
     'amt_pipe_launch': ([_P, C.POINTER(FrameParams), C.POINTER(GeorefOut), _P, C.c_int32, _D, _D, _D, _I], _I),
     'amt_pipe_wait': ([_P, C.POINTER(PipeResult)], _I),
     'amt_pipe_finalize': ([_P, _P, _P, _P, _P], _I),
+    'amt_pipe_join': ([_P], _I),
 }
 
 _lib = None
@@ -231,7 +232,8 @@ class Context(object):
 
     # -- per-kernel timing ----------------------------------------------------------------------
     def timing_enable(self, enable=True):
-        self.call('amt_timing_enable', 1 if enable else 0)
+        """True / n: bracket every (n-th) launch of the dominant kernels with HIP events; False / 0: off."""
+        self.call('amt_timing_enable', int(enable))
 
     def timing_read(self, kernel):
         """(total ms, launches) of kernel 0 (georef) / 1 (bin) since timing was enabled. Synchronises."""

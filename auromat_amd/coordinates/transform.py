@@ -339,6 +339,20 @@ def rotation_matrix(angle, direction):
     (the part of the vendored transformations.py:295-336 the reference uses).
     """
     s, c = math.sin(angle), math.cos(angle)
+    d0, d1, d2 = direction[:3]
+    if abs(d0) + abs(d1) + abs(d2) == 1 and (d0 * d0 + d1 * d1 + d2 * d2) == 1:
+        # a coordinate axis (all the frame transforms use these): the same floating-point operations as the
+        # array expressions below, on scalars (per-frame host set-up is on the critical path of a sequence)
+        a0, a1, a2 = d0 / 1.0, d1 / 1.0, d2 / 1.0
+        k = 1.0 - c
+        r00, r01, r02 = c + (a0 * a0) * k, 0.0 + (a0 * a1) * k, 0.0 + (a0 * a2) * k
+        r10, r11, r12 = 0.0 + (a1 * a0) * k, c + (a1 * a1) * k, 0.0 + (a1 * a2) * k
+        r20, r21, r22 = 0.0 + (a2 * a0) * k, 0.0 + (a2 * a1) * k, c + (a2 * a2) * k
+        a0, a1, a2 = a0 * s, a1 * s, a2 * s
+        return np.array([[r00 + 0.0, r01 + -a2, r02 + a1, 0.0],
+                         [r10 + a2, r11 + 0.0, r12 + -a0, 0.0],
+                         [r20 + -a1, r21 + a0, r22 + 0.0, 0.0],
+                         [0.0, 0.0, 0.0, 1.0]])
     axis = np.array(direction[:3], dtype=np.float64)
     axis /= math.sqrt(np.dot(axis, axis))
     rot = np.diag([c, c, c])

@@ -288,10 +288,10 @@ __global__ __launch_bounds__(kBlock) void k_bin_frame(bin_args A) {
 }
 
 template <typename IMG_T>
-__global__ void k_bin_finalize(const unsigned long long* __restrict__ acc, int acc_nx, int acc_ny, int off_x,
+__global__ void k_bin_finalize(unsigned long long* __restrict__ acc, int acc_nx, int acc_ny, int off_x,
                                int off_y, int nx, int ny, int nch, double* __restrict__ mean,
                                IMG_T* __restrict__ out_img, uint8_t* __restrict__ out_mask,
-                               double* __restrict__ out_count) {
+                               double* __restrict__ out_count, int clear) {
     const int64_t n = (int64_t)nx * ny, plane = (int64_t)acc_nx * acc_ny;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / nx), c = (int)(i - (int64_t)r * nx);
@@ -311,6 +311,20 @@ __global__ void k_bin_finalize(const unsigned long long* __restrict__ acc, int a
         if (out_mask) out_mask[i] = cnt ? 0 : 1;
         if (out_count) out_count[i] = dc;
     }
+    if (clear) {
+        // leave the whole accumulator grid zeroed for the next frame (every thread clears only cells whose
+        // values it read itself above, or cells outside the window that nobody reads)
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const int r = (int)(i / nx), c = (int)(i - (int64_t)r * nx);
+            const int64_t cell = (int64_t)(off_x + c) * acc_ny + (off_y + ny - 1 - r);
+            for (int k = 0; k < nch + 2; ++k) acc[(int64_t)k * plane + cell] = 0;
+        }
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < plane; i += (int64_t)gridDim.x * blockDim.x) {
+            const int cx = (int)(i / acc_ny), cy = (int)(i - (int64_t)cx * acc_ny);
+            if (cx >= off_x && cx < off_x + nx && cy >= off_y && cy < off_y + ny) continue;
+            for (int k = 0; k < nch + 2; ++k) acc[(int64_t)k * plane + i] = 0;
+        }
+    }
 }
 
 inline dim3 grid_for(int64_t n) {
@@ -321,6 +335,26 @@ inline dim3 grid_for(int64_t n) {
 }
 
 }  // namespace
+
+int amt_bin_finalize_on(amt_ctx* ctx, hipStream_t stream, uint64_t* acc, int32_t acc_nx, int32_t acc_ny, int32_t off_x,
+                        int32_t off_y, int32_t nx, int32_t ny, int32_t nchan, int32_t img_dtype, double* mean,
+                        void* out_img, uint8_t* out_mask, double* out_count, int clear) {
+    AMT_REQUIRE(ctx, acc != nullptr, "NULL argument");
+    AMT_REQUIRE(ctx, nx > 0 && ny > 0 && nchan >= 0 && nchan <= 4, "bad shape");
+    AMT_REQUIRE(ctx, off_x >= 0 && off_y >= 0 && off_x + nx <= acc_nx && off_y + ny <= acc_ny,
+                "window outside the accumulator grid");
+    AMT_REQUIRE(ctx, out_img == nullptr || img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
+    const dim3 grid = grid_for(clear ? (int64_t)acc_nx * acc_ny : (int64_t)nx * ny), block(kBlock);
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(acc);
+    if (img_dtype == 1)
+        hipLaunchKernelGGL((k_bin_finalize<uint8_t>), grid, block, 0, stream, a, acc_nx, acc_ny, off_x, off_y, nx, ny,
+                           nchan, mean, static_cast<uint8_t*>(out_img), out_mask, out_count, clear);
+    else
+        hipLaunchKernelGGL((k_bin_finalize<uint16_t>), grid, block, 0, stream, a, acc_nx, acc_ny, off_x, off_y, nx, ny,
+                           nchan, mean, static_cast<uint16_t*>(out_img), out_mask, out_count, clear);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
 
 extern "C" {
 
@@ -420,21 +454,9 @@ int amt_bin_frame_finalize_window(amt_ctx* ctx, const uint64_t* acc, int32_t acc
                                   int32_t off_y, int32_t nx, int32_t ny, int32_t nchan, int32_t img_dtype,
                                   double* mean, void* out_img, uint8_t* out_mask, double* out_count) {
     AMT_CHECK_CTX(ctx);
-    AMT_REQUIRE(ctx, acc != nullptr, "NULL argument");
-    AMT_REQUIRE(ctx, nx > 0 && ny > 0 && nchan >= 0 && nchan <= 4, "bad shape");
-    AMT_REQUIRE(ctx, off_x >= 0 && off_y >= 0 && off_x + nx <= acc_nx && off_y + ny <= acc_ny,
-                "window outside the accumulator grid");
-    AMT_REQUIRE(ctx, out_img == nullptr || img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
-    const dim3 grid = grid_for((int64_t)nx * ny), block(kBlock);
-    const unsigned long long* a = reinterpret_cast<const unsigned long long*>(acc);
-    if (img_dtype == 1)
-        hipLaunchKernelGGL((k_bin_finalize<uint8_t>), grid, block, 0, ctx->stream, a, acc_nx, acc_ny, off_x, off_y, nx, ny,
-                           nchan, mean, static_cast<uint8_t*>(out_img), out_mask, out_count);
-    else
-        hipLaunchKernelGGL((k_bin_finalize<uint16_t>), grid, block, 0, ctx->stream, a, acc_nx, acc_ny, off_x, off_y, nx, ny,
-                           nchan, mean, static_cast<uint16_t*>(out_img), out_mask, out_count);
-    AMT_LAUNCH_CHECK(ctx);
-    return AMT_OK;
+    // clear == 0: the accumulators are only read
+    return amt_bin_finalize_on(ctx, ctx->stream, const_cast<uint64_t*>(acc), acc_nx, acc_ny, off_x, off_y, nx, ny, nchan,
+                               img_dtype, mean, out_img, out_mask, out_count, 0);
 }
 
 int amt_bin_frame_finalize(amt_ctx* ctx, const uint64_t* acc, int32_t nx, int32_t ny, int32_t nchan,

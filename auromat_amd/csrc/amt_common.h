@@ -21,7 +21,10 @@ struct amt_ctx {
     size_t ws_bytes;
     std::string last_error;
     // optional per-kernel timing (amt_timing_*): event pairs recorded around the dominant kernels
-    bool timing;
+    int timing;                       // 0 = off, n = bracket every n-th launch of each kind
+    size_t tlaunch[2];                // launches seen per kind since timing was enabled
+    bool tactive[2];                  // the launch in progress is being timed
+    bool tinside[2];                  // between the two marks of a launch
     std::vector<hipEvent_t> tev[2];   // [kernel kind] start0, stop0, start1, stop1, ...
     size_t tused[2];
 };
@@ -32,14 +35,41 @@ constexpr int kTimingMaxLaunches = 4096;
 // Call once before and once after the launch; events are created lazily and reused.
 static inline void amt_timing_mark(amt_ctx* ctx, int kind) {
     if (!ctx->timing) return;
-    if (ctx->tused[kind] >= (size_t)2 * kTimingMaxLaunches) return;
+    const bool before = !ctx->tinside[kind];
+    ctx->tinside[kind] = before;
+    if (before) {
+        ctx->tactive[kind] = (ctx->tlaunch[kind]++ % (size_t)ctx->timing) == 0 &&
+                             ctx->tused[kind] < (size_t)2 * kTimingMaxLaunches;
+    }
+    if (!ctx->tactive[kind]) return;
     if (ctx->tused[kind] >= ctx->tev[kind].size()) {
         hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return;
+        if (hipEventCreate(&e) != hipSuccess) {
+            ctx->tactive[kind] = false;
+            if (!before) --ctx->tused[kind];      // drop the unmatched start event
+            return;
+        }
         ctx->tev[kind].push_back(e);
     }
     (void)hipEventRecord(ctx->tev[kind][ctx->tused[kind]++], ctx->stream);
 }
+
+// ---- internal interfaces between translation units (not part of the C ABI) ---------------------------
+// Where the bounding-box folds of a georeferencing launch run.  The frame driver (amt_pipe.hip) keeps them
+// off the context's stream so that the next frame's kernel follows the previous one without a gap.
+struct amt_georef_tail {
+    hipStream_t stream;        // the folds run here, after `kernel_done` (recorded on the context's stream)
+    hipEvent_t kernel_done;
+    double* partials;          // buffer of the per-wave partial boxes, amt_georef_partials_bytes() large
+    size_t partials_bytes;
+};
+size_t amt_georef_partials_bytes(const amt_frame_params* p);
+int amt_georef_launch(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, const amt_georef_out* out,
+                      const amt_georef_tail* tail);
+// amt_bin_frame_finalize_window on `stream`; clear != 0 also zeroes every cell of the accumulator grid.
+int amt_bin_finalize_on(amt_ctx* ctx, hipStream_t stream, uint64_t* acc, int32_t acc_nx, int32_t acc_ny, int32_t off_x,
+                        int32_t off_y, int32_t nx, int32_t ny, int32_t nchan, int32_t img_dtype, double* mean,
+                        void* out_img, uint8_t* out_mask, double* out_count, int clear);
 
 // Returns a device workspace of at least `bytes` (grow-only; reallocation synchronises the stream).
 static inline void* amt_workspace(amt_ctx* ctx, size_t bytes) {
@@ -430,6 +460,8 @@ __device__ __forceinline__ double linspace_edge(const axis_dev& ax, int i) {
 
 // searchsorted(edges, v, 'right') with the right-most-edge rule of histogram.py:209-224.
 // Returns 0..nbin+1; 0 and nbin+1 are outliers (NaN sorts to the end like NumPy does).
+// UNIFORM_ONLY: the caller guarantees ax.uniform (drops the bisection over an edge table from the code).
+template <bool UNIFORM_ONLY = false>
 __device__ __forceinline__ int bin_index(const axis_dev& ax, double v) {
     if (!(v == v)) return ax.nbin + 1;
     if (v < ax.e0) return 0;
@@ -438,7 +470,7 @@ __device__ __forceinline__ int bin_index(const axis_dev& ax, double v) {
         return on_edge ? ax.nbin : ax.nbin + 1;
     }
     int g;
-    if (ax.uniform) {
+    if (UNIFORM_ONLY || ax.uniform) {
         g = (int)((v - ax.e0) * ax.inv_step);
         g = g < 0 ? 0 : (g > ax.nbin - 1 ? ax.nbin - 1 : g);
         // the guess is off by at most one; e0 <= v < e_last bounds both corrections

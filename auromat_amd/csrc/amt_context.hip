@@ -18,7 +18,10 @@ int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ct
     ctx->scratch = nullptr;
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
-    ctx->timing = false;
+    ctx->timing = 0;
+    ctx->tlaunch[0] = ctx->tlaunch[1] = 0;
+    ctx->tactive[0] = ctx->tactive[1] = false;
+    ctx->tinside[0] = ctx->tinside[1] = false;
     ctx->tused[0] = ctx->tused[1] = 0;
     if (hipSetDevice(device_id) != hipSuccess) {
         delete ctx;
@@ -168,8 +171,11 @@ int amt_event_elapsed_ms(amt_ctx* ctx, void* start, void* stop, float* out_ms) {
 
 int amt_timing_enable(amt_ctx* ctx, int enable) {
     AMT_CHECK_CTX(ctx);
-    ctx->timing = enable != 0;
+    ctx->timing = enable > 0 ? enable : 0;
     ctx->tused[0] = ctx->tused[1] = 0;
+    ctx->tlaunch[0] = ctx->tlaunch[1] = 0;
+    ctx->tactive[0] = ctx->tactive[1] = false;
+    ctx->tinside[0] = ctx->tinside[1] = false;
     return AMT_OK;
 }
 

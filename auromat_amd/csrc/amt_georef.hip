@@ -370,9 +370,36 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
     double la_prev = NAN, lo_prev = NAN;
     int flag_prev = 0;
     double v[8] = {kInf, -kInf, kInf, -kInf, kInf, -kInf, 0, 0};
+    // image pixel of the NEXT iteration's centre row, loaded one iteration ahead: the value is first touched at
+    // the top of the loop, so the wait for it does not also wait for the stores issued just before (loads and
+    // stores share one counter and the compiler waits for all of them when both kinds are in flight)
+    unsigned int raw0 = 0, raw1 = 0;                  // raw words as loaded; unpacked only after the wait
 
     for (int r = 0; r <= rows; ++r) {
         const int gy = y0 + r;
+        unsigned int ch0 = 0, ch1 = 0, ch2 = 0;          // image pixel (gy-1, gx)
+        if (BIN) {
+            asm volatile("" : "+v"(raw0), "+v"(raw1));   // the prefetched words are consumed here
+            if (BIN == 1) {
+                ch0 = raw0 & 0xffu, ch1 = (raw0 >> 8) & 0xffu, ch2 = raw1;
+            } else {
+                ch0 = raw0 & 0xffffu, ch1 = raw0 >> 16, ch2 = raw1;
+            }
+            if (px_ok && r < rows) {
+                const int64_t gi = (int64_t)gy * A.width + gx;
+                if (BIN == 1) {
+                    const unsigned char* q = static_cast<const unsigned char*>(A.bin_img) + gi * 3;
+                    unsigned short w;
+                    __builtin_memcpy(&w, q, 2);
+                    raw0 = w;
+                    raw1 = q[2];
+                } else {
+                    const unsigned short* q = static_cast<const unsigned short*>(A.bin_img) + gi * 3;
+                    __builtin_memcpy(&raw0, q, 4);
+                    raw1 = q[2];
+                }
+            }
+        }
         // ---- corner (gy, gx) ------------------------------------------------------------------
         vec3 d = {NAN, NAN, NAN}, p = {NAN, NAN, NAN};
         double la = NAN, lo = NAN;
@@ -438,17 +465,9 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
             }
             bool valid = false;
             int bin_x = 0, bin_y = 0;            // 1-based bin indices of this pixel, 0 = not binned
-            unsigned int ch0 = 0, ch1 = 0, ch2 = 0;
             long long el_fix = 0;
             if (px_ok) {
                 const int64_t gi = (int64_t)(gy - 1) * A.width + gx;
-                if (BIN == 1) {                  // issue the image loads ahead of the arithmetic
-                    const unsigned char* q = static_cast<const unsigned char*>(A.bin_img) + gi * 3;
-                    ch0 = q[0], ch1 = q[1], ch2 = q[2];
-                } else if (BIN == 2) {
-                    const unsigned short* q = static_cast<const unsigned short*>(A.bin_img) + gi * 3;
-                    ch0 = q[0], ch1 = q[1], ch2 = q[2];
-                }
                 double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN;
                 if (pc.x == pc.x) {
                     karg_ptr K = karg_fresh();
@@ -476,9 +495,9 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
                     const double byv = (MAG && A.bin_magnetic) ? ml : lac;
                     if (A.bin_lon_wrap) bxv = wrap180_shifted(bxv);
                     karg_ptr K = karg_fresh();
-                    const int bx = bin_index(karg_load<axis_dev>(K, offsetof(georef_args, bax)), bxv);
+                    const int bx = bin_index<true>(karg_load<axis_dev>(K, offsetof(georef_args, bax)), bxv);
                     const axis_dev bay = karg_load<axis_dev>(K, offsetof(georef_args, bay));
-                    const int by = bin_index(bay, byv);
+                    const int by = bin_index<true>(bay, byv);
                     if (bx >= 1 && bx <= A.bax.nbin && by >= 1 && by <= bay.nbin) {
                         bin_x = bx;
                         bin_y = by;
@@ -664,7 +683,37 @@ __global__ __launch_bounds__(kThreads) void k_coarse_bbox(georef_args A, int str
     block_reduce8<kThreads>(v, partials + (int64_t)blockIdx.x * 8, sRed);
 }
 
-int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, const amt_georef_out* out) {
+// items (waves) of the row-marching launch / tiles of the tile kernel, and the rows per chunk
+struct launch_shape {
+    bool use_tiles;
+    int rows_per_chunk, tiles_x, tiles_y, strips_x, chunks_y;
+    int64_t n_items;
+};
+
+launch_shape shape_of(const amt_frame_params* p) {
+    // kernel selection: row-marching waves (default) or LDS tiles (AMT_GEOREF_KERNEL=tile), for A/B runs
+    static const bool use_tiles = [] {
+        const char* e = std::getenv("AMT_GEOREF_KERNEL");
+        return e != nullptr && std::strcmp(e, "tile") == 0;
+    }();
+    static const int rows_per_chunk = [] {
+        const char* e = std::getenv("AMT_GEOREF_ROWS");
+        const int v = e ? std::atoi(e) : 0;
+        return v > 0 ? v : 16;
+    }();
+    launch_shape s;
+    s.use_tiles = use_tiles;
+    s.rows_per_chunk = rows_per_chunk;
+    s.tiles_x = (p->width + kTW - 1) / kTW;
+    s.tiles_y = (p->height + kTH - 1) / kTH;
+    s.strips_x = (p->width + 1 + 62) / 63;                       // 64 corner columns, 63 owned, per strip
+    s.chunks_y = (p->height + rows_per_chunk - 1) / rows_per_chunk;
+    s.n_items = use_tiles ? (int64_t)s.tiles_x * s.tiles_y : (int64_t)s.strips_x * s.chunks_y;
+    return s;
+}
+
+int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, const amt_georef_out* out,
+                  const amt_georef_tail* tail = nullptr) {
     AMT_REQUIRE(ctx, p && out, "NULL argument");
     AMT_REQUIRE(ctx, p->width > 0 && p->height > 0, "empty frame");
     AMT_REQUIRE(ctx, p->a > 0 && p->b > 0 && p->a0 > 0 && p->b0 > 0, "ellipsoid axes must be positive");
@@ -710,26 +759,22 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
         A.bin_magnetic = out->bin_magnetic ? 1 : 0;
         bin = out->bin_img_dtype;
     }
-    // kernel selection: row-marching waves (default) or LDS tiles (AMT_GEOREF_KERNEL=tile), for A/B runs
-    static const bool use_tiles = [] {
-        const char* e = std::getenv("AMT_GEOREF_KERNEL");
-        return e != nullptr && std::strcmp(e, "tile") == 0;
-    }();
-    static const int rows_per_chunk = [] {
-        const char* e = std::getenv("AMT_GEOREF_ROWS");
-        const int v = e ? std::atoi(e) : 0;
-        return v > 0 ? v : 16;
-    }();
-    const int tiles_x = (p->width + kTW - 1) / kTW, tiles_y = (p->height + kTH - 1) / kTH;
-    const int strips_x = (p->width + 1 + 62) / 63;                       // 64 corner columns, 63 owned, per strip
-    const int chunks_y = (p->height + rows_per_chunk - 1) / rows_per_chunk;
-    const int64_t n_items = use_tiles ? (int64_t)tiles_x * tiles_y : (int64_t)strips_x * chunks_y;
+    const launch_shape sh = shape_of(p);
+    const bool use_tiles = sh.use_tiles;
+    const int rows_per_chunk = sh.rows_per_chunk, strips_x = sh.strips_x;
+    const int64_t n_items = sh.n_items;
     const int64_t nblocks = use_tiles ? n_items : (n_items + kThreads / 64 - 1) / (kThreads / 64);
     AMT_REQUIRE(ctx, n_items < (1ll << 31), "frame too large");
     A.bbox_partials = nullptr;
     double* fold = nullptr;
     if (out->bbox) {
-        A.bbox_partials = static_cast<double*>(amt_workspace(ctx, (size_t)(n_items + kFoldBlocks) * 8 * sizeof(double)));
+        const size_t need = (size_t)(n_items + kFoldBlocks) * 8 * sizeof(double);
+        if (tail) {
+            AMT_REQUIRE(ctx, tail->partials != nullptr && tail->partials_bytes >= need, "partials buffer too small");
+            A.bbox_partials = tail->partials;
+        } else {
+            A.bbox_partials = static_cast<double*>(amt_workspace(ctx, need));
+        }
         if (A.bbox_partials == nullptr) {
             ctx->last_error = "amt_georef_frame: workspace allocation failed";
             return AMT_ENOMEM;
@@ -760,16 +805,31 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     amt_timing_mark(ctx, AMT_KERNEL_GEOREF);
     AMT_LAUNCH_CHECK(ctx);
     if (out->bbox) {
-        hipLaunchKernelGGL(k_bbox_fold, dim3(kFoldBlocks), dim3(kThreads), 0, ctx->stream, A.bbox_partials, (int)n_items,
-                           fold);
+        hipStream_t fs = ctx->stream;
+        if (tail) {
+            AMT_HIP(ctx, hipEventRecord(tail->kernel_done, ctx->stream));
+            AMT_HIP(ctx, hipStreamWaitEvent(tail->stream, tail->kernel_done, 0));
+            fs = tail->stream;
+        }
+        hipLaunchKernelGGL(k_bbox_fold, dim3(kFoldBlocks), dim3(kThreads), 0, fs, A.bbox_partials, (int)n_items, fold);
         AMT_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, ctx->stream, fold, kFoldBlocks, out->bbox);
+        hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, fs, fold, kFoldBlocks, out->bbox);
         AMT_LAUNCH_CHECK(ctx);
     }
     return AMT_OK;
 }
 
 }  // namespace
+
+size_t amt_georef_partials_bytes(const amt_frame_params* p) {
+    return (size_t)(shape_of(p).n_items + kFoldBlocks) * 8 * sizeof(double);
+}
+
+int amt_georef_launch(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, const amt_georef_out* out,
+                      const amt_georef_tail* tail) {
+    AMT_CHECK_CTX(ctx);
+    return launch_georef(ctx, p, dirs, out, tail);
+}
 
 extern "C" {
 

@@ -8,16 +8,21 @@
 
 struct amt_pipe {
     amt_ctx* ctx;
-    hipStream_t pre_stream;        // coarse pre-pass: must not queue behind the previous frame's kernels
-    hipEvent_t coarse_done, bbox_done;
-    double* dev_small;             // [0..7] coarse bbox, [8..15] exact bbox (device)
-    double* host_small;            // pinned mirror
+    // The context's stream carries only the big kernel of each frame.  Everything small runs beside it:
+    hipStream_t pre_stream;        // coarse pre-pass of a later frame (must not queue behind the running kernel)
+    hipStream_t tail_stream;       // bounding-box folds and the crop/finalise kernel of this frame
+    hipEvent_t coarse_done, kernel_done, bbox_done, tail_done;
+    double* host_small;            // pinned host memory: [0..7] coarse bbox, [8..15] exact bbox
+    double* host_small_dev;        // the same 16 doubles as the kernels address them (the folds write them directly)
     uint64_t* acc;                 // superset accumulators (device), 5 planes
     size_t acc_cells;              // capacity per plane
+    bool acc_zero;                 // the accumulators are known to be all zero
     void* coarse_ws;               // workspace of the pre-pass (the context's belongs to the main stream)
     size_t coarse_ws_bytes;
+    double* partials;              // per-wave partial boxes of the big kernel (read by the folds on tail_stream)
+    size_t partials_bytes;
     // state of the frame in flight
-    bool coarse_pending, launched, fused, ready;
+    bool coarse_pending, launched, fused, ready, tail_pending;
     amt_grid super, exact;
     int32_t off_x, off_y;          // window of the exact grid inside the superset
     double lat_ppd, lon_ppd, min_elev;
@@ -35,6 +40,7 @@ int ensure_acc(amt_pipe* pipe, size_t cells) {
     amt_ctx* ctx = pipe->ctx;
     if (pipe->acc) {
         AMT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        AMT_HIP(ctx, hipStreamSynchronize(pipe->tail_stream));
         AMT_HIP(ctx, hipFree(pipe->acc));
         pipe->acc = nullptr;
         pipe->acc_cells = 0;
@@ -42,6 +48,22 @@ int ensure_acc(amt_pipe* pipe, size_t cells) {
     const size_t cap = cells < (1u << 16) ? (1u << 16) : cells + cells / 4;
     AMT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&pipe->acc), cap * 5 * sizeof(uint64_t)));
     pipe->acc_cells = cap;
+    pipe->acc_zero = false;
+    return AMT_OK;
+}
+
+int ensure_partials(amt_pipe* pipe, size_t bytes) {
+    if (bytes <= pipe->partials_bytes) return AMT_OK;
+    amt_ctx* ctx = pipe->ctx;
+    if (pipe->partials) {
+        AMT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        AMT_HIP(ctx, hipStreamSynchronize(pipe->tail_stream));
+        AMT_HIP(ctx, hipFree(pipe->partials));
+        pipe->partials = nullptr;
+        pipe->partials_bytes = 0;
+    }
+    AMT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&pipe->partials), bytes));
+    pipe->partials_bytes = bytes;
     return AMT_OK;
 }
 
@@ -123,11 +145,14 @@ int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     bool ok = hipStreamCreateWithPriority(&pipe->pre_stream, hipStreamNonBlocking, hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&pipe->tail_stream, hipStreamNonBlocking, hi) == hipSuccess &&
               hipEventCreateWithFlags(&pipe->coarse_done, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&pipe->kernel_done, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&pipe->bbox_done, hipEventDisableTiming) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&pipe->dev_small), 16 * sizeof(double)) == hipSuccess &&
-              hipHostMalloc(reinterpret_cast<void**>(&pipe->host_small), 16 * sizeof(double), hipHostMallocDefault) ==
-                  hipSuccess;
+              hipEventCreateWithFlags(&pipe->tail_done, hipEventDisableTiming) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&pipe->host_small), 16 * sizeof(double), hipHostMallocMapped) ==
+                  hipSuccess &&
+              hipHostGetDevicePointer(reinterpret_cast<void**>(&pipe->host_small_dev), pipe->host_small, 0) == hipSuccess;
     if (!ok) {
         ctx->last_error = "amt_pipe_create: resource allocation failed";
         amt_pipe_destroy(pipe);
@@ -143,9 +168,15 @@ int amt_pipe_destroy(amt_pipe* pipe) {
         (void)hipStreamSynchronize(pipe->pre_stream);
         (void)hipStreamDestroy(pipe->pre_stream);
     }
+    if (pipe->tail_stream) {
+        (void)hipStreamSynchronize(pipe->tail_stream);
+        (void)hipStreamDestroy(pipe->tail_stream);
+    }
     if (pipe->coarse_done) (void)hipEventDestroy(pipe->coarse_done);
+    if (pipe->kernel_done) (void)hipEventDestroy(pipe->kernel_done);
     if (pipe->bbox_done) (void)hipEventDestroy(pipe->bbox_done);
-    if (pipe->dev_small) (void)hipFree(pipe->dev_small);
+    if (pipe->tail_done) (void)hipEventDestroy(pipe->tail_done);
+    if (pipe->partials) (void)hipFree(pipe->partials);
     if (pipe->host_small) (void)hipHostFree(pipe->host_small);
     if (pipe->acc) (void)hipFree(pipe->acc);
     if (pipe->coarse_ws) (void)hipFree(pipe->coarse_ws);
@@ -168,15 +199,13 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
     const double thr = std::isinf(min_elevation) ? min_elevation : min_elevation - 0.5;
     const int shorter = p->width < p->height ? p->width : p->height;
     const int stride = std::max(1, std::min(kCoarseStride, shorter / 128));
-    int rc = amt_georef_coarse_bbox(ctx, p, stride, thr, 0, pipe->dev_small);
+    int rc = amt_georef_coarse_bbox(ctx, p, stride, thr, 0, pipe->host_small_dev);
     pipe->coarse_ws = ctx->ws;
     pipe->coarse_ws_bytes = ctx->ws_bytes;
     ctx->stream = saved;
     ctx->ws = saved_ws;
     ctx->ws_bytes = saved_ws_bytes;
     if (rc != AMT_OK) return rc;
-    AMT_HIP(ctx, hipMemcpyAsync(pipe->host_small, pipe->dev_small, 8 * sizeof(double), hipMemcpyDeviceToHost,
-                                pipe->pre_stream));
     AMT_HIP(ctx, hipEventRecord(pipe->coarse_done, pipe->pre_stream));
     pipe->coarse_pending = true;
     return AMT_OK;
@@ -201,8 +230,17 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
     pipe->img_dtype = img_dtype;
     pipe->fused = false;
 
+    // the folds / finalise of the previous frame on this driver still use the partials and the accumulators
+    if (pipe->tail_pending) {
+        // usually long finished (the host saw the frame's bounding box): then no packet goes on the stream
+        if (hipEventQuery(pipe->tail_done) != hipSuccess)
+            AMT_HIP(ctx, hipStreamWaitEvent(ctx->stream, pipe->tail_done, 0));
+        pipe->tail_pending = false;
+    }
+    if (int rc = ensure_partials(pipe, amt_georef_partials_bytes(p))) return rc;
+
     amt_georef_out o = *out;
-    o.bbox = pipe->dev_small + 8;
+    o.bbox = pipe->host_small_dev + 8;          // the last fold writes straight into pinned host memory
     o.bbox_min_elevation = min_elevation;
     o.bin_acc = nullptr;
     o.bin_xaxis = o.bin_yaxis = nullptr;
@@ -222,18 +260,28 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
     if (fuse) {
         const size_t cells = (size_t)pipe->super.nx * pipe->super.ny;
         if (int rc = ensure_acc(pipe, cells)) return rc;
-        AMT_HIP(ctx, hipMemsetAsync(pipe->acc, 0, cells * 5 * sizeof(uint64_t), ctx->stream));
+        if (!pipe->acc_zero) {
+            // first use / after a frame that was not finalised; otherwise the finalise kernel leaves zeros behind
+            AMT_HIP(ctx, hipMemsetAsync(pipe->acc, 0, pipe->acc_cells * 5 * sizeof(uint64_t), ctx->stream));
+            pipe->acc_zero = true;
+        }
         o.bin_xaxis = &pipe->super.xaxis;
         o.bin_yaxis = &pipe->super.yaxis;
         o.bin_img = img;
         o.bin_img_dtype = img_dtype;
         o.bin_acc = pipe->acc;
         pipe->fused = true;
+        pipe->acc_zero = false;
     }
-    if (int rc = amt_georef_frame(ctx, p, &o)) return rc;
-    AMT_HIP(ctx, hipMemcpyAsync(pipe->host_small + 8, pipe->dev_small + 8, 8 * sizeof(double), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    AMT_HIP(ctx, hipEventRecord(pipe->bbox_done, ctx->stream));
+    amt_georef_tail tail;
+    tail.stream = pipe->tail_stream;
+    tail.kernel_done = pipe->kernel_done;
+    tail.partials = pipe->partials;
+    tail.partials_bytes = pipe->partials_bytes;
+    if (int rc = amt_georef_launch(ctx, p, nullptr, &o, &tail)) return rc;
+    AMT_HIP(ctx, hipEventRecord(pipe->bbox_done, pipe->tail_stream));
+    AMT_HIP(ctx, hipEventRecord(pipe->tail_done, pipe->tail_stream));
+    pipe->tail_pending = true;
     pipe->launched = true;
     return AMT_OK;
 }
@@ -282,8 +330,22 @@ int amt_pipe_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_
     pipe->ready = false;
     const amt_grid& s = pipe->super;
     const amt_grid& g = pipe->exact;
-    return amt_bin_frame_finalize_window(ctx, pipe->acc, s.nx, s.ny, pipe->off_x, pipe->off_y, g.nx, g.ny, 3,
-                                         pipe->img_dtype, mean, out_img, out_mask, out_count);
+    // on the tail stream (behind this frame's folds), zeroing the accumulators for the next frame on the way
+    if (int rc = amt_bin_finalize_on(ctx, pipe->tail_stream, pipe->acc, s.nx, s.ny, pipe->off_x, pipe->off_y, g.nx, g.ny,
+                                     3, pipe->img_dtype, mean, out_img, out_mask, out_count, 1))
+        return rc;
+    pipe->acc_zero = true;
+    AMT_HIP(ctx, hipEventRecord(pipe->tail_done, pipe->tail_stream));
+    pipe->tail_pending = true;
+    return AMT_OK;
+}
+
+int amt_pipe_join(amt_pipe* pipe) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipe->ctx;
+    if (pipe->tail_pending && hipEventQuery(pipe->tail_done) != hipSuccess)
+        AMT_HIP(ctx, hipStreamWaitEvent(ctx->stream, pipe->tail_done, 0));
+    return AMT_OK;
 }
 
 }  // extern "C"

@@ -79,6 +79,10 @@ class FramePipeline(object):
         self._fused = None          # single-pass launch in flight: its px/deg, later its amt_pipe_result
         self._pole = 0
         self.last_plan = None       # 'single-pass' or 'two-pass': what the last resample() did
+        # keep_on_device results of the single-pass plan are produced on the driver's own stream; by default the
+        # current stream is ordered behind them at once.  A pipelined caller sets defer_join and calls join()
+        # once before it consumes the results, which keeps the stream of big kernels free of wait packets.
+        self.defer_join = False
         self.params = None
         self.altitude = None
         self.min_elevation = None
@@ -114,6 +118,12 @@ class FramePipeline(object):
     def _pcall(self, name, *args):
         # amt_pipe_* take the driver handle (not the context) as their first argument
         self.ctx.check(getattr(self.ctx._lib, name)(self._pipe(), *args))
+
+    def join(self):
+        """Order the current stream behind the single-pass driver's finalise kernels (see amt_pipe_join)."""
+        if self._driver is not None:
+            Context.current(self.ctx.device)
+            self._pcall('amt_pipe_join')
 
     def start_coarse(self, params, min_elevation):
         """Enqueue the coarse bounding-box pre-pass for `params` (asynchronous, on the driver's own stream)."""
@@ -189,6 +199,8 @@ class FramePipeline(object):
         mask = ctx.empty((g.ny, g.nx), torch.uint8)
         count = ctx.empty((g.ny, g.nx))
         self._pcall('amt_pipe_finalize', ptr(mean), ptr(img), ptr(mask), ptr(count))
+        if not (keep_on_device and self.defer_join):
+            self.join()
         out = dict(has_elev=True, grid=grid, contains_pole=False, contains_discontinuity=False,
                    altitude=self.altitude)
         if keep_on_device:

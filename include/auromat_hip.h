@@ -68,7 +68,9 @@ int amt_event_record(amt_ctx* ctx, void* event);
 int amt_event_elapsed_ms(amt_ctx* ctx, void* start, void* stop, float* out_ms);   /* synchronises on stop */
 /* Per-kernel timing: while enabled, amt_georef_frame[_dirs] and amt_bin_frame bracket their main kernel
  * launch (k_georef_rows / k_bin_frame, not the small fold / finalize kernels) with HIP events on the
- * context's stream.  amt_timing_read sums the recorded launches (synchronises); enabling resets. */
+ * context's stream.  enable = n > 0 brackets every n-th launch of each kind (the two event packets sit between
+ * consecutive kernels on the stream, so a pipelined caller samples instead of timing every launch); 0 = off.
+ * amt_timing_read sums the recorded launches and returns how many there were (synchronises); enabling resets. */
 #define AMT_KERNEL_GEOREF 0
 #define AMT_KERNEL_BIN 1
 int amt_timing_enable(amt_ctx* ctx, int enable);
@@ -321,7 +323,7 @@ int amt_grid_layout(double lat_px_per_deg, double lon_px_per_deg, double lat_min
 
 /* Single-pass driver: georeference + mask by elevation + bounding box + grid + binned mean of one frame with
  * the binning fused into the georeferencing kernel (see amt_georef_out.bin_*), for geodetic grids that contain
- * neither a pole nor the 180 deg discontinuity.  Three calls per frame so that frames can be software
+ * neither a pole nor the 180 deg discontinuity.  Separate calls per stage so that frames can be software
  * pipelined by one host thread:
  *   amt_pipe_coarse   enqueue the coarse bounding-box pre-pass (own high-priority stream), any time earlier
  *   amt_pipe_launch   wait for it, lay out the superset grid, zero the accumulators, launch the fused kernel
@@ -350,8 +352,12 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
                     int pole_in_view);
 int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result);
 /* mean (ny,nx,4) f64, out_img (ny,nx,3) of img_dtype, out_mask (ny,nx) u8, out_count (ny,nx) f64: device
- * buffers for result->grid of the preceding amt_pipe_wait (any may be NULL). */
+ * buffers for result->grid of the preceding amt_pipe_wait (any may be NULL).  The kernel runs on the driver's
+ * own stream so that it does not sit between two frames' big kernels on the context's stream. */
 int amt_pipe_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_mask, double* out_count);
+/* Orders the context's stream behind the last amt_pipe_finalize (no-op when it already completed): call it
+ * before work on the context's stream — or, after amt_ctx_synchronize, the host — reads the outputs. */
+int amt_pipe_join(amt_pipe* pipe);
 
 #ifdef __cplusplus
 }
