@@ -8,7 +8,8 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_DIR = os.path.join(PKG_DIR, 'lib')
-LIB_PATH = os.path.join(LIB_DIR, 'libauromat_hip.so')
+# AMT_LIB_PATH: load another build of the same sources (A/B experiments with compile-time variants)
+LIB_PATH = os.environ.get('AMT_LIB_PATH') or os.path.join(LIB_DIR, 'libauromat_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared',
          '-Wall', '-Wextra', '-Wno-unused-parameter',

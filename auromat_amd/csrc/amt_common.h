@@ -473,11 +473,13 @@ __device__ __forceinline__ int bin_index(const axis_dev& ax, double v) {
     if (UNIFORM_ONLY || ax.uniform) {
         g = (int)((v - ax.e0) * ax.inv_step);
         g = g < 0 ? 0 : (g > ax.nbin - 1 ? ax.nbin - 1 : g);
-        // the guess is off by at most one; e0 <= v < e_last bounds both corrections
-        if (v < linspace_edge(ax, g)) --g;
-        else if (v >= linspace_edge(ax, g + 1)) ++g;
-        while (v < linspace_edge(ax, g)) --g;
-        while (v >= linspace_edge(ax, g + 1)) ++g;
+        // the guess is almost always right and otherwise off by one: two edge evaluations on the common path,
+        // the loops (bounded by e0 <= v < e_last) only when it was wrong
+        if (v < linspace_edge(ax, g)) {
+            do { --g; } while (v < linspace_edge(ax, g));
+        } else if (v >= linspace_edge(ax, g + 1)) {
+            do { ++g; } while (v >= linspace_edge(ax, g + 1));
+        }
     } else {
         int lo = 0, hi = ax.nbin;             // invariant: edges[lo] <= v < edges[hi]
         while (hi - lo > 1) {
@@ -487,6 +489,37 @@ __device__ __forceinline__ int bin_index(const axis_dev& ax, double v) {
         g = lo;
     }
     return g + 1;
+}
+
+// The five scalars of a uniform axis that the common path of the fused binning needs.
+struct axis_lin {
+    double e0, e_last, step, inv_step;
+    int nbin, pad;
+};
+
+inline axis_lin make_axis_lin(const axis_dev& a) {
+    axis_lin l;
+    l.e0 = a.e0;
+    l.e_last = a.e_last;
+    l.step = a.step;
+    l.inv_step = a.inv_step;
+    l.nbin = a.nbin;
+    l.pad = 0;
+    return l;
+}
+
+// Common path of bin_index for a uniform axis: 1-based bin, or 0 for an outlier / NaN.  `slow` is set when the
+// value needs the general routine (first guess off by one, or v >= last edge where the right-edge rule decides).
+__device__ __forceinline__ int bin_fast(const axis_lin& ax, double v, bool& slow) {
+#pragma clang fp contract(off)
+    int g = (int)((v - ax.e0) * ax.inv_step);
+    g = g < 0 ? 0 : (g > ax.nbin - 1 ? ax.nbin - 1 : g);
+    const double lo = (double)g * ax.step + ax.e0;
+    const double hi_lin = (double)(g + 1) * ax.step + ax.e0;
+    const double hi = g + 1 >= ax.nbin ? ax.e_last : hi_lin;
+    const bool in = (v >= lo) && (v < hi);
+    slow = !in && (v >= ax.e0);
+    return in ? g + 1 : 0;
 }
 
 constexpr double kFix = 4294967296.0;   // 2^32: elevation sums are kept in signed 31.32 fixed point

@@ -41,7 +41,8 @@ struct georef_args {
     double* bbox_partials;   // [nblocks][8] or NULL
     double bbox_min_elev;
     // fused binning (row-marching kernel only)
-    axis_dev bax, bay;
+    axis_dev bax, bay;       // full descriptions (rare paths: right-most edge rule, wrong first guess)
+    axis_lin bxl, byl;       // what the common path needs: 5 scalars per axis
     const void* bin_img;
     unsigned long long* bin_acc;
     int bin_lon_wrap, bin_magnetic;
@@ -307,16 +308,24 @@ __device__ __forceinline__ T karg_load(karg_ptr base, size_t byte_offset) {
 // at the cell of its first kept pixel (a 63 x 16-pixel strip spans a few cells only).  Pixels add to it with
 // LDS atomics as soon as their coordinates exist; pixels outside the window go straight to global atomics;
 // the window is flushed with global 64-bit integer atomics when the wave is done.
-constexpr int kBinW = 16, kBinCells = kBinW * kBinW;
+constexpr int kBinW = 8, kBinCells = kBinW * kBinW;
 
 // BIN: 0 = no fused binning, 1 = uint8 RGB image, 2 = uint16 RGB image
+// Minimum waves per SIMD the register allocator must reach: with the bounding-box state in LDS the fused
+// variants fit 96 VGPRs (5 waves) without spilling; the magnetic + fused variant would spill and is exempt.
+#ifndef AMT_ROWS_MIN_WAVES
+#define AMT_ROWS_MIN_WAVES 5
+#endif
 template <bool FAST, bool DIRS_IN, bool MAG, int BIN>
-__global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int rows_per_chunk, int strips_x,
+__global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) void k_georef_rows(georef_args A, int rows_per_chunk, int strips_x,
                                                            int n_items) {
     constexpr int kBinWaves = BIN ? kThreads / 64 : 1, kBinSlots = BIN ? kBinCells : 1;
     __shared__ unsigned int sCnt[kBinWaves][kBinSlots];
     __shared__ unsigned int sCh[kBinWaves][3][kBinSlots];
     __shared__ unsigned long long sEl[kBinWaves][kBinSlots];
+    // per-lane bounding-box accumulators live in LDS (ds_min_f64 / ds_max_f64 on the lane's own slots: no
+    // conflicts, no return value to wait for) instead of 12 VGPRs that would be live across the whole loop
+    __shared__ double sBox[kThreads / 64][6][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int item = blockIdx.x * (kThreads / 64) + wave;                   // one work item per wave
@@ -348,13 +357,16 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
             atomicAdd(&sEl[wave][slot], (unsigned long long)el);
         } else {
             // outside the wave's window (very fine grids): straight to the global accumulators
-            const int64_t ncell = (int64_t)A.bax.nbin * A.bay.nbin;
-            const int64_t cell = (int64_t)(bx - 1) * A.bay.nbin + (by - 1);
-            atomicAdd(&A.bin_acc[cell], (unsigned long long)cnt);
-            atomicAdd(&A.bin_acc[ncell + cell], (unsigned long long)c0);
-            atomicAdd(&A.bin_acc[2 * ncell + cell], (unsigned long long)c1);
-            atomicAdd(&A.bin_acc[3 * ncell + cell], (unsigned long long)c2);
-            atomicAdd(&A.bin_acc[4 * ncell + cell], (unsigned long long)el);
+            karg_ptr K = karg_fresh();
+            const int nby = karg_load<axis_lin>(K, offsetof(georef_args, byl)).nbin;
+            const int64_t ncell = (int64_t)karg_load<axis_lin>(K, offsetof(georef_args, bxl)).nbin * nby;
+            unsigned long long* acc = karg_load<unsigned long long*>(K, offsetof(georef_args, bin_acc));
+            const int64_t cell = (int64_t)(bx - 1) * nby + (by - 1);
+            atomicAdd(&acc[cell], (unsigned long long)cnt);
+            atomicAdd(&acc[ncell + cell], (unsigned long long)c0);
+            atomicAdd(&acc[2 * ncell + cell], (unsigned long long)c1);
+            atomicAdd(&acc[3 * ncell + cell], (unsigned long long)c2);
+            atomicAdd(&acc[4 * ncell + cell], (unsigned long long)el);
         }
     };
     const int chunk = item / strips_x, strip = item - chunk * strips_x;
@@ -369,37 +381,29 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
     vec3 p_prev = {NAN, NAN, NAN}, d_prev = {NAN, NAN, NAN};
     double la_prev = NAN, lo_prev = NAN;
     int flag_prev = 0;
-    double v[8] = {kInf, -kInf, kInf, -kInf, kInf, -kInf, 0, 0};
-    // image pixel of the NEXT iteration's centre row, loaded one iteration ahead: the value is first touched at
-    // the top of the loop, so the wait for it does not also wait for the stores issued just before (loads and
-    // stores share one counter and the compiler waits for all of them when both kinds are in flight)
+    int n_valid = 0;
+    auto box_add = [&](double la_v, double lo_v) {
+        __hip_atomic_fetch_min(&sBox[wave][0][lane], la_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&sBox[wave][1][lane], la_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_min(&sBox[wave][2][lane], lo_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&sBox[wave][3][lane], lo_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lo_v > 0)
+            __hip_atomic_fetch_min(&sBox[wave][4][lane], lo_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+            __hip_atomic_fetch_max(&sBox[wave][5][lane], lo_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if (want_bbox) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sBox[wave][k][lane] = (k & 1) ? -kInf : kInf;
+    }
+    // Image pixel of the NEXT iteration's centre row, loaded one iteration ahead.  Loads and stores share one
+    // counter and the compiler waits for all of them when both kinds are in flight, so where the loaded words
+    // are first touched decides how long the wave waits for its own earlier stores (see below).
     unsigned int raw0 = 0, raw1 = 0;                  // raw words as loaded; unpacked only after the wait
 
     for (int r = 0; r <= rows; ++r) {
         const int gy = y0 + r;
         unsigned int ch0 = 0, ch1 = 0, ch2 = 0;          // image pixel (gy-1, gx)
-        if (BIN) {
-            asm volatile("" : "+v"(raw0), "+v"(raw1));   // the prefetched words are consumed here
-            if (BIN == 1) {
-                ch0 = raw0 & 0xffu, ch1 = (raw0 >> 8) & 0xffu, ch2 = raw1;
-            } else {
-                ch0 = raw0 & 0xffffu, ch1 = raw0 >> 16, ch2 = raw1;
-            }
-            if (px_ok && r < rows) {
-                const int64_t gi = (int64_t)gy * A.width + gx;
-                if (BIN == 1) {
-                    const unsigned char* q = static_cast<const unsigned char*>(A.bin_img) + gi * 3;
-                    unsigned short w;
-                    __builtin_memcpy(&w, q, 2);
-                    raw0 = w;
-                    raw1 = q[2];
-                } else {
-                    const unsigned short* q = static_cast<const unsigned short*>(A.bin_img) + gi * 3;
-                    __builtin_memcpy(&raw0, q, 4);
-                    raw1 = q[2];
-                }
-            }
-        }
         // ---- corner (gy, gx) ------------------------------------------------------------------
         vec3 d = {NAN, NAN, NAN}, p = {NAN, NAN, NAN};
         double la = NAN, lo = NAN;
@@ -421,6 +425,31 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
                 K = karg_fresh();
                 const vec3 g = mul(karg_load<mat3>(K, offsetof(georef_args, m_geo)), p);
                 ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), g.x, g.y, g.z, la, lo);
+            }
+            if (BIN) {
+                // The wait for the prefetched pixel sits here, right before this iteration's first store: the
+                // counter also covers stores, and the youngest one (the centre row of the previous iteration)
+                // was issued a whole corner computation ago.
+                asm volatile("" : "+v"(raw0), "+v"(raw1));
+                if (BIN == 1) {
+                    ch0 = raw0 & 0xffu, ch1 = (raw0 >> 8) & 0xffu, ch2 = raw1;
+                } else {
+                    ch0 = raw0 & 0xffffu, ch1 = raw0 >> 16, ch2 = raw1;
+                }
+                if (px_ok && r < rows) {
+                    const int64_t gp = (int64_t)gy * A.width + gx;
+                    if (BIN == 1) {
+                        const unsigned char* q = static_cast<const unsigned char*>(A.bin_img) + gp * 3;
+                        unsigned short w;
+                        __builtin_memcpy(&w, q, 2);
+                        raw0 = w;
+                        raw1 = q[2];
+                    } else {
+                        const unsigned short* q = static_cast<const unsigned short*>(A.bin_img) + gp * 3;
+                        __builtin_memcpy(&raw0, q, 4);
+                        raw1 = q[2];
+                    }
+                }
             }
             // the last corner row of a chunk is the first of the next one (which owns it) unless it is
             // the image's last; lane 63's column likewise belongs to the next strip unless it is the last
@@ -493,12 +522,25 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
                     // (SM longitude = mltToSmLon(mlt), MLat) (mapping.py:1519-1547, transform.py:388-401)
                     double bxv = (MAG && A.bin_magnetic) ? (mt - 12.0) / (24.0 / 360.0) : loc;
                     const double byv = (MAG && A.bin_magnetic) ? ml : lac;
-                    if (A.bin_lon_wrap) bxv = wrap180_shifted(bxv);
                     karg_ptr K = karg_fresh();
-                    const int bx = bin_index<true>(karg_load<axis_dev>(K, offsetof(georef_args, bax)), bxv);
-                    const axis_dev bay = karg_load<axis_dev>(K, offsetof(georef_args, bay));
-                    const int by = bin_index<true>(bay, byv);
-                    if (bx >= 1 && bx <= A.bax.nbin && by >= 1 && by <= bay.nbin) {
+                    if (karg_load<long long>(K, offsetof(georef_args, bin_lon_wrap)) & 0xffffffffll) bxv = wrap180_shifted(bxv);
+                    bool slow_x, slow_y;
+                    int bx = bin_fast(karg_load<axis_lin>(K, offsetof(georef_args, bxl)), bxv, slow_x);
+                    int by = bin_fast(karg_load<axis_lin>(K, offsetof(georef_args, byl)), byv, slow_y);
+                    if (__ballot(slow_x || slow_y)) {          // wave-uniform and rare
+                        K = karg_fresh();
+                        if (slow_x) {
+                            const axis_dev ax = karg_load<axis_dev>(K, offsetof(georef_args, bax));
+                            bx = bin_index<true>(ax, bxv);
+                            bx = bx > ax.nbin ? 0 : bx;
+                        }
+                        if (slow_y) {
+                            const axis_dev ay = karg_load<axis_dev>(K, offsetof(georef_args, bay));
+                            by = bin_index<true>(ay, byv);
+                            by = by > ay.nbin ? 0 : by;
+                        }
+                    }
+                    if (bx > 0 && by > 0) {
                         bin_x = bx;
                         bin_y = by;
                         el_fix = __double2ll_rn(el * kFix);
@@ -536,14 +578,8 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
                 // (this row: own pixel or the left neighbour's) is valid
                 const int vi = valid ? 1 : 0;
                 flag_cur = vi | from_prev_lane(vi);
-                v[6] += vi;
-                if ((flag_prev | flag_cur) && la_prev == la_prev) {
-                    v[0] = fmin(v[0], la_prev);
-                    v[1] = fmax(v[1], la_prev);
-                    v[2] = fmin(v[2], lo_prev);
-                    v[3] = fmax(v[3], lo_prev);
-                    if (lo_prev > 0) v[4] = fmin(v[4], lo_prev); else v[5] = fmax(v[5], lo_prev);
-                }
+                n_valid += vi;
+                if ((flag_prev | flag_cur) && la_prev == la_prev) box_add(la_prev, lo_prev);
             }
         }
         p_prev = p;
@@ -556,29 +592,31 @@ __global__ __launch_bounds__(kThreads) void k_georef_rows(georef_args A, int row
         if (run_key) bin_flush(run_key, run_cnt, run_c0, run_c1, run_c2, run_el);
         // flush this wave's window: one 64-bit integer atomic per touched cell and plane
         __threadfence_block();
-        const int64_t ncell = (int64_t)A.bax.nbin * A.bay.nbin;
+        karg_ptr K = karg_fresh();
+        const int nby = karg_load<axis_lin>(K, offsetof(georef_args, byl)).nbin;
+        const int64_t ncell = (int64_t)karg_load<axis_lin>(K, offsetof(georef_args, bxl)).nbin * nby;
+        unsigned long long* acc = karg_load<unsigned long long*>(K, offsetof(georef_args, bin_acc));
 #pragma unroll
         for (int i = lane; i < kBinCells; i += 64) {
             const unsigned int cnt = sCnt[wave][i];
             if (cnt == 0) continue;
             const int dx = i / kBinW, dy = i - dx * kBinW;
-            const int64_t cell = (int64_t)(bin_ax0 + dx - 1) * A.bay.nbin + (bin_ay0 + dy - 1);
-            atomicAdd(&A.bin_acc[cell], (unsigned long long)cnt);
-            atomicAdd(&A.bin_acc[ncell + cell], (unsigned long long)sCh[wave][0][i]);
-            atomicAdd(&A.bin_acc[2 * ncell + cell], (unsigned long long)sCh[wave][1][i]);
-            atomicAdd(&A.bin_acc[3 * ncell + cell], (unsigned long long)sCh[wave][2][i]);
-            atomicAdd(&A.bin_acc[4 * ncell + cell], sEl[wave][i]);
+            const int64_t cell = (int64_t)(bin_ax0 + dx - 1) * nby + (bin_ay0 + dy - 1);
+            atomicAdd(&acc[cell], (unsigned long long)cnt);
+            atomicAdd(&acc[ncell + cell], (unsigned long long)sCh[wave][0][i]);
+            atomicAdd(&acc[2 * ncell + cell], (unsigned long long)sCh[wave][1][i]);
+            atomicAdd(&acc[3 * ncell + cell], (unsigned long long)sCh[wave][2][i]);
+            atomicAdd(&acc[4 * ncell + cell], sEl[wave][i]);
         }
     }
     if (want_bbox) {
         // the chunk's last corner row only has centres above it inside this chunk
-        if (flag_prev && la_prev == la_prev) {
-            v[0] = fmin(v[0], la_prev);
-            v[1] = fmax(v[1], la_prev);
-            v[2] = fmin(v[2], lo_prev);
-            v[3] = fmax(v[3], lo_prev);
-            if (lo_prev > 0) v[4] = fmin(v[4], lo_prev); else v[5] = fmax(v[5], lo_prev);
-        }
+        if (flag_prev && la_prev == la_prev) box_add(la_prev, lo_prev);
+        double v[7];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            v[k] = __hip_atomic_load(&sBox[wave][k][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        v[6] = (double)n_valid;
         for (int o = 32; o > 0; o >>= 1) {
             v[0] = fmin(v[0], __shfl_xor(v[0], o));
             v[1] = fmax(v[1], __shfl_xor(v[1], o));
@@ -745,6 +783,8 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     A.bin_lon_wrap = A.bin_magnetic = 0;
     std::memset(&A.bax, 0, sizeof(A.bax));
     std::memset(&A.bay, 0, sizeof(A.bay));
+    std::memset(&A.bxl, 0, sizeof(A.bxl));
+    std::memset(&A.byl, 0, sizeof(A.byl));
     if (out->bin_acc != nullptr) {
         AMT_REQUIRE(ctx, out->bin_img && (out->bin_img_dtype == 1 || out->bin_img_dtype == 2),
                     "fused binning needs a uint8 (1) or uint16 (2) RGB image");
@@ -753,6 +793,8 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
         AMT_REQUIRE(ctx, out->bin_xaxis->nbin < 65535 && out->bin_yaxis->nbin < 65535, "at most 65534 bins per axis");
         make_axis(out->bin_xaxis, &A.bax);
         make_axis(out->bin_yaxis, &A.bay);
+        A.bxl = make_axis_lin(A.bax);
+        A.byl = make_axis_lin(A.bay);
         A.bin_img = out->bin_img;
         A.bin_acc = reinterpret_cast<unsigned long long*>(out->bin_acc);
         A.bin_lon_wrap = out->bin_lon_wrap ? 1 : 0;
