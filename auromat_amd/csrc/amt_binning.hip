@@ -432,11 +432,12 @@ int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const 
     const bool vec = (width % 2 == 0) && aligned16(lat_c) && aligned16(lon_c) && (elev == nullptr || aligned16(elev));
 #define AMT_BIN_CASE(T, N)                                                                  \
     do {                                                                                    \
-        if (vec) hipLaunchKernelGGL((k_bin_frame<T, N, true>), grid, block, 0, ctx->stream, A);  \
-        else hipLaunchKernelGGL((k_bin_frame<T, N, false>), grid, block, 0, ctx->stream, A);     \
+        if (vec) hipExtLaunchKernelGGL((k_bin_frame<T, N, true>), grid, block, 0, ctx->stream, t0, t1, 0, A);  \
+        else hipExtLaunchKernelGGL((k_bin_frame<T, N, false>), grid, block, 0, ctx->stream, t0, t1, 0, A);     \
     } while (0)
     const bool u8 = img_dtype == 1;
-    amt_timing_mark(ctx, AMT_KERNEL_BIN);
+    hipEvent_t t0, t1;
+    amt_timing_pair(ctx, AMT_KERNEL_BIN, &t0, &t1);
     switch (nchan) {
         case 0: AMT_BIN_CASE(uint8_t, 0); break;
         case 1: if (u8) AMT_BIN_CASE(uint8_t, 1); else AMT_BIN_CASE(uint16_t, 1); break;
@@ -445,7 +446,6 @@ int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const 
         default: if (u8) AMT_BIN_CASE(uint8_t, 4); else AMT_BIN_CASE(uint16_t, 4); break;
     }
 #undef AMT_BIN_CASE
-    amt_timing_mark(ctx, AMT_KERNEL_BIN);
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -23,35 +24,28 @@ struct amt_ctx {
     // optional per-kernel timing (amt_timing_*): event pairs recorded around the dominant kernels
     int timing;                       // 0 = off, n = bracket every n-th launch of each kind
     size_t tlaunch[2];                // launches seen per kind since timing was enabled
-    bool tactive[2];                  // the launch in progress is being timed
-    bool tinside[2];                  // between the two marks of a launch
     std::vector<hipEvent_t> tev[2];   // [kernel kind] start0, stop0, start1, stop1, ...
     size_t tused[2];
 };
 
 constexpr int kTimingMaxLaunches = 4096;
 
-// Records an event on the stream for kernel kind `kind` (0 georef, 1 bin) when timing is enabled.
-// Call once before and once after the launch; events are created lazily and reused.
-static inline void amt_timing_mark(amt_ctx* ctx, int kind) {
+// Event pair for the next launch of kernel kind `kind` (0 georef, 1 bin) when that launch is to be timed,
+// else two NULLs.  The events are attached to the dispatch itself (hipExtLaunchKernelGGL start/stop events),
+// so timing puts no extra packet on the stream; they are created lazily and reused.
+static inline void amt_timing_pair(amt_ctx* ctx, int kind, hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
     if (!ctx->timing) return;
-    const bool before = !ctx->tinside[kind];
-    ctx->tinside[kind] = before;
-    if (before) {
-        ctx->tactive[kind] = (ctx->tlaunch[kind]++ % (size_t)ctx->timing) == 0 &&
-                             ctx->tused[kind] < (size_t)2 * kTimingMaxLaunches;
-    }
-    if (!ctx->tactive[kind]) return;
-    if (ctx->tused[kind] >= ctx->tev[kind].size()) {
+    if ((ctx->tlaunch[kind]++ % (size_t)ctx->timing) != 0) return;
+    if (ctx->tused[kind] + 2 > (size_t)2 * kTimingMaxLaunches) return;
+    while (ctx->tused[kind] + 2 > ctx->tev[kind].size()) {
         hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) {
-            ctx->tactive[kind] = false;
-            if (!before) --ctx->tused[kind];      // drop the unmatched start event
-            return;
-        }
+        if (hipEventCreate(&e) != hipSuccess) return;
         ctx->tev[kind].push_back(e);
     }
-    (void)hipEventRecord(ctx->tev[kind][ctx->tused[kind]++], ctx->stream);
+    *start = ctx->tev[kind][ctx->tused[kind]];
+    *stop = ctx->tev[kind][ctx->tused[kind] + 1];
+    ctx->tused[kind] += 2;
 }
 
 // ---- internal interfaces between translation units (not part of the C ABI) ---------------------------

@@ -20,8 +20,6 @@ int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ct
     ctx->ws_bytes = 0;
     ctx->timing = 0;
     ctx->tlaunch[0] = ctx->tlaunch[1] = 0;
-    ctx->tactive[0] = ctx->tactive[1] = false;
-    ctx->tinside[0] = ctx->tinside[1] = false;
     ctx->tused[0] = ctx->tused[1] = 0;
     if (hipSetDevice(device_id) != hipSuccess) {
         delete ctx;
@@ -174,8 +172,6 @@ int amt_timing_enable(amt_ctx* ctx, int enable) {
     ctx->timing = enable > 0 ? enable : 0;
     ctx->tused[0] = ctx->tused[1] = 0;
     ctx->tlaunch[0] = ctx->tlaunch[1] = 0;
-    ctx->tactive[0] = ctx->tactive[1] = false;
-    ctx->tinside[0] = ctx->tinside[1] = false;
     return AMT_OK;
 }
 

@@ -400,6 +400,7 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
     // counter and the compiler waits for all of them when both kinds are in flight, so where the loaded words
     // are first touched decides how long the wave waits for its own earlier stores (see below).
     unsigned int raw0 = 0, raw1 = 0;                  // raw words as loaded; unpacked only after the wait
+    int img_shift = 0;
 
     for (int r = 0; r <= rows; ++r) {
         const int gy = y0 + r;
@@ -431,24 +432,28 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
                 // counter also covers stores, and the youngest one (the centre row of the previous iteration)
                 // was issued a whole corner computation ago.
                 asm volatile("" : "+v"(raw0), "+v"(raw1));
-                if (BIN == 1) {
-                    ch0 = raw0 & 0xffu, ch1 = (raw0 >> 8) & 0xffu, ch2 = raw1;
-                } else {
-                    ch0 = raw0 & 0xffffu, ch1 = raw0 >> 16, ch2 = raw1;
+                {
+                    // the pixel's bytes sit `img_shift` bits into the 8 aligned bytes that were loaded
+                    const unsigned long long w = (((unsigned long long)raw1 << 32) | raw0) >> img_shift;
+                    if (BIN == 1) {
+                        ch0 = (unsigned int)w & 0xffu, ch1 = ((unsigned int)w >> 8) & 0xffu, ch2 = ((unsigned int)w >> 16) & 0xffu;
+                    } else {
+                        ch0 = (unsigned int)w & 0xffffu, ch1 = (unsigned int)w >> 16, ch2 = (unsigned int)(w >> 32) & 0xffffu;
+                    }
                 }
                 if (px_ok && r < rows) {
-                    const int64_t gp = (int64_t)gy * A.width + gx;
-                    if (BIN == 1) {
-                        const unsigned char* q = static_cast<const unsigned char*>(A.bin_img) + gp * 3;
-                        unsigned short w;
-                        __builtin_memcpy(&w, q, 2);
-                        raw0 = w;
-                        raw1 = q[2];
-                    } else {
-                        const unsigned short* q = static_cast<const unsigned short*>(A.bin_img) + gp * 3;
-                        __builtin_memcpy(&raw0, q, 4);
-                        raw1 = q[2];
-                    }
+                    // one aligned 8-byte load covers the 3 (uint8) or 6 (uint16) bytes of the pixel wherever it
+                    // starts; the address is clamped so that the load never reaches past the image
+                    const int64_t pix_bytes = BIN == 1 ? 3 : 6;
+                    const int64_t b = ((int64_t)gy * A.width + gx) * pix_bytes;
+                    const int64_t last = (int64_t)A.width * A.height * pix_bytes - 8;
+                    int64_t a = b & ~(int64_t)3;
+                    a = a > last ? last : a;
+                    img_shift = (int)(b - a) * 8;
+                    uint2 w2;
+                    __builtin_memcpy(&w2, static_cast<const unsigned char*>(A.bin_img) + a, 8);
+                    raw0 = w2.x;
+                    raw1 = w2.y;
                 }
             }
             // the last corner row of a chunk is the first of the next one (which owns it) unless it is
@@ -654,34 +659,41 @@ __global__ __launch_bounds__(kThreads) void k_bbox_fold(const double* __restrict
 constexpr int kTW = 64, kTH = 8;
 constexpr int kFoldBlocks = 64;
 
+// start / stop: events attached to the dispatch (timing, and the hand-over to the driver's tail stream) or NULL
+struct launch_events {
+    hipEvent_t start, stop;
+};
+
 template <bool FAST, bool DIRS_IN>
-void launch_variant(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag) {
+void launch_variant(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, launch_events ev) {
     const dim3 block(kThreads);
     if (mag)
-        hipLaunchKernelGGL((k_georef<kTW, kTH, FAST, DIRS_IN, true>), grid, block, 0, ctx->stream, A);
+        hipExtLaunchKernelGGL((k_georef<kTW, kTH, FAST, DIRS_IN, true>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, A);
     else
-        hipLaunchKernelGGL((k_georef<kTW, kTH, FAST, DIRS_IN, false>), grid, block, 0, ctx->stream, A);
+        hipExtLaunchKernelGGL((k_georef<kTW, kTH, FAST, DIRS_IN, false>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, A);
 }
 
 template <bool FAST, bool DIRS_IN, int BIN>
-void launch_rows_bin(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, int rows, int strips_x, int n_items) {
+void launch_rows_bin(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, int rows, int strips_x, int n_items,
+                     launch_events ev) {
     const dim3 block(kThreads);
     if (mag)
-        hipLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, true, BIN>), grid, block, 0, ctx->stream, A, rows, strips_x,
-                           n_items);
+        hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, true, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, A,
+                              rows, strips_x, n_items);
     else
-        hipLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, false, BIN>), grid, block, 0, ctx->stream, A, rows, strips_x,
-                           n_items);
+        hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, false, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, A,
+                              rows, strips_x, n_items);
 }
 
 template <bool FAST, bool DIRS_IN>
-void launch_rows(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, int bin, int rows, int strips_x, int n_items) {
+void launch_rows(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, int bin, int rows, int strips_x, int n_items,
+                 launch_events ev) {
     if (bin == 1)
-        launch_rows_bin<FAST, DIRS_IN, 1>(ctx, A, grid, mag, rows, strips_x, n_items);
+        launch_rows_bin<FAST, DIRS_IN, 1>(ctx, A, grid, mag, rows, strips_x, n_items, ev);
     else if (bin == 2)
-        launch_rows_bin<FAST, DIRS_IN, 2>(ctx, A, grid, mag, rows, strips_x, n_items);
+        launch_rows_bin<FAST, DIRS_IN, 2>(ctx, A, grid, mag, rows, strips_x, n_items, ev);
     else
-        launch_rows_bin<FAST, DIRS_IN, 0>(ctx, A, grid, mag, rows, strips_x, n_items);
+        launch_rows_bin<FAST, DIRS_IN, 0>(ctx, A, grid, mag, rows, strips_x, n_items, ev);
 }
 
 // One thread per lattice corner (every `stride`-th pixel corner): bounding box of the corners whose own ray
@@ -788,6 +800,7 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     if (out->bin_acc != nullptr) {
         AMT_REQUIRE(ctx, out->bin_img && (out->bin_img_dtype == 1 || out->bin_img_dtype == 2),
                     "fused binning needs a uint8 (1) or uint16 (2) RGB image");
+        AMT_REQUIRE(ctx, (int64_t)p->width * p->height >= 3, "fused binning needs at least 3 pixels");
         AMT_REQUIRE(ctx, axis_ok(out->bin_xaxis) && axis_ok(out->bin_yaxis) && out->bin_xaxis->uniform &&
                              out->bin_yaxis->uniform, "fused binning needs two uniform axes");
         AMT_REQUIRE(ctx, out->bin_xaxis->nbin < 65535 && out->bin_yaxis->nbin < 65535, "at most 65534 bins per axis");
@@ -826,31 +839,33 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     const dim3 grid((unsigned)nblocks);
     const bool mag = out->mlat != nullptr || out->mlat_c != nullptr || A.bin_magnetic;
     AMT_REQUIRE(ctx, !(bin && use_tiles), "fused binning is implemented by the row-marching kernel only");
-    amt_timing_mark(ctx, AMT_KERNEL_GEOREF);
+    // events ride on the dispatch packet itself: the timing pair when this launch is sampled, otherwise the
+    // driver's hand-over event as the stop event; nothing is recorded between consecutive big kernels
+    launch_events ev;
+    amt_timing_pair(ctx, AMT_KERNEL_GEOREF, &ev.start, &ev.stop);
+    if (ev.stop == nullptr && tail != nullptr && out->bbox) ev.stop = tail->kernel_done;
     if (use_tiles) {
         if (dirs) {
-            launch_variant<true, true>(ctx, A, grid, mag);
+            launch_variant<true, true>(ctx, A, grid, mag, ev);
         } else if (p->fast_center) {
-            launch_variant<true, false>(ctx, A, grid, mag);
+            launch_variant<true, false>(ctx, A, grid, mag, ev);
         } else {
-            launch_variant<false, false>(ctx, A, grid, mag);
+            launch_variant<false, false>(ctx, A, grid, mag, ev);
         }
     } else {
         if (dirs) {
-            launch_rows<true, true>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items);
+            launch_rows<true, true>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
         } else if (p->fast_center) {
-            launch_rows<true, false>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items);
+            launch_rows<true, false>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
         } else {
-            launch_rows<false, false>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items);
+            launch_rows<false, false>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
         }
     }
-    amt_timing_mark(ctx, AMT_KERNEL_GEOREF);
     AMT_LAUNCH_CHECK(ctx);
     if (out->bbox) {
         hipStream_t fs = ctx->stream;
         if (tail) {
-            AMT_HIP(ctx, hipEventRecord(tail->kernel_done, ctx->stream));
-            AMT_HIP(ctx, hipStreamWaitEvent(tail->stream, tail->kernel_done, 0));
+            AMT_HIP(ctx, hipStreamWaitEvent(tail->stream, ev.stop, 0));
             fs = tail->stream;
         }
         hipLaunchKernelGGL(k_bbox_fold, dim3(kFoldBlocks), dim3(kThreads), 0, fs, A.bbox_partials, (int)n_items, fold);

@@ -1,6 +1,7 @@
 // Single-pass frame driver (see include/auromat_hip.h, "grid layout and the single-pass frame driver").
 // Host orchestration only: every kernel it launches lives in amt_georef.hip / amt_binning.hip.
 #include <algorithm>
+#include <cstdlib>
 #include <new>
 
 #include "amt_common.h"
@@ -147,7 +148,7 @@ int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe) {
     bool ok = hipStreamCreateWithPriority(&pipe->pre_stream, hipStreamNonBlocking, hi) == hipSuccess &&
               hipStreamCreateWithPriority(&pipe->tail_stream, hipStreamNonBlocking, hi) == hipSuccess &&
               hipEventCreateWithFlags(&pipe->coarse_done, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&pipe->kernel_done, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreate(&pipe->kernel_done) == hipSuccess &&
               hipEventCreateWithFlags(&pipe->bbox_done, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&pipe->tail_done, hipEventDisableTiming) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&pipe->host_small), 16 * sizeof(double), hipHostMallocMapped) ==
@@ -198,7 +199,8 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
     ctx->ws_bytes = pipe->coarse_ws_bytes;
     const double thr = std::isinf(min_elevation) ? min_elevation : min_elevation - 0.5;
     const int shorter = p->width < p->height ? p->width : p->height;
-    const int stride = std::max(1, std::min(kCoarseStride, shorter / 128));
+    static const int max_stride = std::getenv("AMT_COARSE_STRIDE") ? std::atoi(std::getenv("AMT_COARSE_STRIDE")) : kCoarseStride;
+    const int stride = std::max(1, std::min(max_stride, shorter / 128));
     int rc = amt_georef_coarse_bbox(ctx, p, stride, thr, 0, pipe->host_small_dev);
     pipe->coarse_ws = ctx->ws;
     pipe->coarse_ws_bytes = ctx->ws_bytes;

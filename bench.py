@@ -27,14 +27,15 @@ if ROOT not in sys.path:
 
 WIDTH, HEIGHT = 4240, 2832
 ALTITUDE, MIN_ELEV, PPD = 110, 10.0, 10
-TIMING_EVERY = 4        # HIP events around every 4th launch of each kernel (they cost stream packets)
+TIMING_EVERY = 1        # events ride on the dispatch packets (hipExtLaunchKernelGGL): every launch is timed
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
 
 def algorithmic_bytes(width, height, nchan=3, pix_bytes=2):
     """SURVEY.md §8d contract figures (f64 coordinates)."""
     nc, npx = (width + 1) * (height + 1), width * height
-    return dict(georef=16 * nc + 24 * npx,              # WCS-fused: lat, lon corners + latC, lonC, elev written
+    return dict(image=nchan * pix_bytes * npx,
+                georef=16 * nc + 24 * npx,              # WCS-fused: lat, lon corners + latC, lonC, elev written
                 georef_dirs_in=40 * nc + 24 * npx,      # + 24 B/corner direction read (contract row "directions-in")
                 resample=(24 + nchan * pix_bytes) * npx)
 
@@ -115,6 +116,7 @@ def main():
     bin_done = [None, None]
 
     prepared = {}
+    plans = []
     # the synthetic sequence (what a reader would hand over: WCS cards, camera position, time) exists before
     # the timed region, like the image; everything derived from it (matrices, grids) is computed inside
     headers = [sequence_frame(rank * total + k, WIDTH, HEIGHT)[:3] for k in range(total)]
@@ -143,6 +145,7 @@ def main():
             if s_bin is not s_geo:
                 s_bin.wait_event(geo_done[k % 2])
             res = pipes[k % 2].resample(PPD, containsPole=False, keep_on_device=True)
+            plans.append(pipes[k % 2].last_plan)
             if s_bin is not s_geo:
                 bin_done[k % 2] = torch.cuda.Event()
                 bin_done[k % 2].record(s_bin)
@@ -191,6 +194,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
+    del plans[:]
     results = run(args.warmup, args.steps)
     gathered = None
     if world > 1:
@@ -220,7 +224,6 @@ def main():
     if rank == 0:
         npx = WIDTH * HEIGHT
         ab = algorithmic_bytes(WIDTH, HEIGHT)
-        achieved = ab['georef'] / (georef_ms * 1e-3) / 1e9
         info = ctx.device_info()
         res = results[-1]
         traffic = {}
@@ -229,6 +232,19 @@ def main():
                 traffic = json.load(fp)
         except (IOError, ValueError):
             pass
+
+        def frac(nbytes, ms):
+            return nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+        if fused:
+            # one kernel does both stages: it writes the five coordinate arrays (480.4 MB) and reads the image
+            # (6 B/pixel, 72.0 MB); the centre arrays are never read back
+            kname, tkey = 'k_georef_rows<BIN> (amt_georef_frame with fused binning, via amt_pipe_launch)', 'k_georef_rows_fused'
+            kbytes = ab['georef'] + ab['image']
+        else:
+            kname, tkey = 'k_georef_rows (amt_georef_frame)', 'k_georef_rows'
+            kbytes = ab['georef']
+        achieved = kbytes / (georef_ms * 1e-3) / 1e9
         out = {
             'metric': 'Mpixels/s georef+resample, 4240x2832 frame',
             'value': world * args.steps * npx / 1e6 / elapsed,
@@ -242,36 +258,28 @@ def main():
                                    'maskedByElevation(10), mean-resample to 0.1 deg plate-carree, uint16 RGB'
                                    % ('fast' if fast else 'exact'),
                        'frame': [WIDTH, HEIGHT], 'px_per_deg': PPD, 'grid': list(res['mean'].shape),
+                       'plan': args.plan,
+                       'single_pass_frames': sum(1 for q in plans if q == 'single-pass'),
                        'parallelism': 'frames sharded over %d GPU(s), RCCL gather of grids' % world,
                        'device': info['name']},
-            # dominant kernel: k_georef_rows writes 16 B/corner + 24 B/pixel and reads nothing (WCS-fused row of
-            # SURVEY.md §8d); it is FP64-VALU bound, so frac understates how busy the chip is
-            'roofline': {'bound': 'hbm', 'kernel': 'k_georef_rows (amt_georef_frame)', 'achieved': achieved,
+            # dominant kernel.  It is FP64-VALU bound (about 400 VALU instructions per pixel row and lane, see
+            # DESIGN.md and profiles/), so the HBM fraction understates how busy the chip is.
+            'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic.get('k_georef_rows', {}).get('hbm_bytes'),
-                         'algorithmic_bytes': ab['georef'], 'ms_per_launch': georef_ms},
+                         'traffic': traffic.get(tkey, {}).get('hbm_bytes'),
+                         'algorithmic_bytes': kbytes, 'ms_per_launch': georef_ms,
+                         'launches_timed': g_n, 'valu_busy': traffic.get(tkey, {}).get('valu_busy')},
             'kernels': {
-                'k_georef_rows': {'ms': georef_ms, 'algorithmic_bytes': ab['georef'],
-                                  'frac_hbm_peak': ab['georef'] / (georef_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  'frac_directions_in_accounting_768.8MB':
-                                      ab['georef_dirs_in'] / (georef_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                'k_georef_rows': {'ms': georef_ms, 'algorithmic_bytes': kbytes, 'frac_hbm_peak': frac(kbytes, georef_ms)},
                 'k_bin_frame': ({'ms': bin_ms, 'algorithmic_bytes': ab['resample'],
-                                 'frac_hbm_peak': ab['resample'] / (bin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 'frac_hbm_peak': frac(ab['resample'], bin_ms),
                                  'traffic': traffic.get('k_bin_frame', {}).get('hbm_bytes')} if bin_ms else
                                 'not launched: binning is fused into k_georef_rows (plan=fused)'),
-                'pipeline_frac_1129MB_contract': (ab['georef_dirs_in'] + ab['resample'])
-                / ((georef_ms + bin_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                # SURVEY.md 8d contract figures for the whole pipeline against the time of the kernel(s) that do it
+                'pipeline_frac_wcs_fused_840.6MB': frac(ab['georef'] + ab['resample'], georef_ms + bin_ms),
+                'pipeline_frac_directions_in_1129.0MB': frac(ab['georef_dirs_in'] + ab['resample'], georef_ms + bin_ms),
             },
         }
-        out['config']['plan'] = args.plan
-        if fused:
-            # the fused kernel also reads the image (6 B/pixel) on top of the 480.4 MB it writes
-            extra = 3 * 2 * npx
-            out['roofline']['algorithmic_bytes'] = ab['georef'] + extra
-            out['roofline']['achieved'] = (ab['georef'] + extra) / (georef_ms * 1e-3) / 1e9
-            out['roofline']['frac'] = out['roofline']['achieved'] / HBM_PEAK_GBS
-            out['roofline']['kernel'] = 'k_georef_rows with fused binning (amt_georef_frame)'
-            out['roofline']['traffic'] = traffic.get('k_georef_rows_fused', {}).get('hbm_bytes')
         if world == 1 and args.cpu_rows > 0:
             out['cpu_baseline'] = cpu_baseline(min(args.cpu_rows, HEIGHT))
         else:
