@@ -378,9 +378,14 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
     const bool px_ok = lane < 63 && gx < A.width;      // this lane's pixel column exists (and is owned)
     const bool want_bbox = A.bbox_partials != nullptr;
 
-    vec3 p_prev = {NAN, NAN, NAN}, d_prev = {NAN, NAN, NAN};
-    double la_prev = NAN, lo_prev = NAN;
-    int flag_prev = 0;
+    // State of the previous corner row.  The row loop is unrolled by two with the roles of S0 / S1 swapped, so
+    // that no prev <- cur register moves are needed (they were ~30 of ~400 VALU instructions per row).
+    struct row_state {
+        vec3 p, d;
+        double la, lo;
+        int flag;
+    };
+    row_state S0 = {{NAN, NAN, NAN}, {NAN, NAN, NAN}, NAN, NAN, 0}, S1 = S0;
     int n_valid = 0;
     auto box_add = [&](double la_v, double lo_v) {
         __hip_atomic_fetch_min(&sBox[wave][0][lane], la_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
     unsigned int raw0 = 0, raw1 = 0;                  // raw words as loaded; unpacked only after the wait
     int img_shift = 0;
 
-    for (int r = 0; r <= rows; ++r) {
+    auto step = [&](const int r, const row_state& prev, row_state& cur) {
         const int gy = y0 + r;
         unsigned int ch0 = 0, ch1 = 0, ch2 = 0;          // image pixel (gy-1, gx)
         // ---- corner (gy, gx) ------------------------------------------------------------------
@@ -478,8 +483,8 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
             if (FAST) {
                 // mean of the 4 corner hits / directions (reference astrometry.py:154-160); the summation
                 // order differs from the reference's by rounding only (<= 1e-12 deg)
-                const double sx = p_prev.x + p.x, sy = p_prev.y + p.y, sz = p_prev.z + p.z;
-                const double tx = d_prev.x + d.x, ty = d_prev.y + d.y, tz = d_prev.z + d.z;
+                const double sx = prev.p.x + p.x, sy = prev.p.y + p.y, sz = prev.p.z + p.z;
+                const double tx = prev.d.x + d.x, ty = prev.d.y + d.y, tz = prev.d.z + d.z;
                 pc.x = (sx + from_next_lane(sx)) * 0.25;
                 pc.y = (sy + from_next_lane(sy)) * 0.25;
                 pc.z = (sz + from_next_lane(sz)) * 0.25;
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
                 pc = ray_point(ray, dc, ray_param_fast(ray, dc));
                 if (want_bbox) {
                     // after sanitisation a centre also needs its 4 corners (reference mapping.py:1093-1101)
-                    const int h = (p_prev.x == p_prev.x) && (p.x == p.x);
+                    const int h = (prev.p.x == prev.p.x) && (p.x == p.x);
                     corners_ok = h && from_next_lane(h);
                 }
             }
@@ -579,19 +584,23 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
                 }
             }
             if (want_bbox) {
-                // corner row gy-1 is final now: it keeps a corner when a centre above (flag_prev) or below
+                // corner row gy-1 is final now: it keeps a corner when a centre above (prev.flag) or below
                 // (this row: own pixel or the left neighbour's) is valid
                 const int vi = valid ? 1 : 0;
                 flag_cur = vi | from_prev_lane(vi);
                 n_valid += vi;
-                if ((flag_prev | flag_cur) && la_prev == la_prev) box_add(la_prev, lo_prev);
+                if ((prev.flag | flag_cur) && prev.la == prev.la) box_add(prev.la, prev.lo);
             }
         }
-        p_prev = p;
-        d_prev = d;
-        la_prev = la;
-        lo_prev = lo;
-        flag_prev = flag_cur;
+        cur.p = p;
+        cur.d = d;
+        cur.la = la;
+        cur.lo = lo;
+        cur.flag = flag_cur;
+    };
+    for (int r = 0; r <= rows; r += 2) {
+        step(r, S0, S1);
+        if (r + 1 <= rows) step(r + 1, S1, S0); else S0 = S1;      // the last row's state ends up in S0
     }
     if (BIN && bin_anchor) {
         if (run_key) bin_flush(run_key, run_cnt, run_c0, run_c1, run_c2, run_el);
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
     }
     if (want_bbox) {
         // the chunk's last corner row only has centres above it inside this chunk
-        if (flag_prev && la_prev == la_prev) box_add(la_prev, lo_prev);
+        if (S0.flag && S0.la == S0.la) box_add(S0.la, S0.lo);
         double v[7];
 #pragma unroll
         for (int k = 0; k < 6; ++k)
