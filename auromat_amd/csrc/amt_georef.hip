@@ -21,12 +21,81 @@ namespace {
 
 using namespace amt;
 
+// The same ray / shell intersection with everything expressed in the GEO frame (k_georef_rows).  The shell is
+// aligned with the J2000 axes (reference intersection.py:63-74 scales J2000 components by 1/a, 1/a, 1/b), so in
+// GEO coordinates it is the general quadric x^T Q x = 1 with Q = M diag(1/a^2, 1/a^2, 1/b^2) M^T.  Intersecting
+// there costs 6 multiply-adds more per ray than the axis-aligned form but the hit comes out in GEO coordinates:
+// the 3x3 rotation of every corner point and of every centre point (18 multiply-adds per pixel) disappears, and
+// the centre of the fast mode, a mean of corner hits, needs none either because rotations are linear.
+struct quadric_ray {
+    double qxx, qyy, qzz, qxy, qxz, qyz;   // Q
+    double qox, qoy, qoz;                  // Q o
+    double c0;                             // o^T Q o - 1
+    double ox, oy, oz;                     // camera in GEO
+    long long inside;                      // camera inside the shell (intersection.py:239-241)
+};
+
+__host__ inline void mat_mul3(const double* a, const double* b, double* out) {     // out = a b (row major 3x3)
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) out[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+
+__host__ inline quadric_ray make_quadric_ray(double a, double b, const double* cam, const double* m) {
+    const double w[3] = {1 / (a * a), 1 / (a * a), 1 / (b * b)};
+    double q[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            q[3 * i + j] = 0;
+            for (int k = 0; k < 3; ++k) q[3 * i + j] += m[3 * i + k] * w[k] * m[3 * j + k];
+        }
+    quadric_ray r;
+    r.qxx = q[0], r.qyy = q[4], r.qzz = q[8];
+    r.qxy = 0.5 * (q[1] + q[3]), r.qxz = 0.5 * (q[2] + q[6]), r.qyz = 0.5 * (q[5] + q[7]);
+    r.ox = m[0] * cam[0] + m[1] * cam[1] + m[2] * cam[2];
+    r.oy = m[3] * cam[0] + m[4] * cam[1] + m[5] * cam[2];
+    r.oz = m[6] * cam[0] + m[7] * cam[1] + m[8] * cam[2];
+    r.qox = r.qxx * r.ox + r.qxy * r.oy + r.qxz * r.oz;
+    r.qoy = r.qxy * r.ox + r.qyy * r.oy + r.qyz * r.oz;
+    r.qoz = r.qxz * r.ox + r.qyz * r.oy + r.qzz * r.oz;
+    const double qx = cam[0] / a, qy = cam[1] / a, qz = cam[2] / b;
+    const double oo = qx * qx + qy * qy + qz * qz;       // axis-aligned form: exact decision, and a better c0
+    r.c0 = oo - 1;
+    r.inside = oo < 1;
+    return r;
+}
+
+// t of the first hit of x = o + t d (d in GEO), NaN for a miss or a hit behind the camera.
+__device__ __forceinline__ double quadric_param(const quadric_ray& e, const vec3& d) {
+    const double ux = e.qxx * d.x + e.qxy * d.y + e.qxz * d.z;
+    const double uy = e.qxy * d.x + e.qyy * d.y + e.qyz * d.z;
+    const double uz = e.qxz * d.x + e.qyz * d.y + e.qzz * d.z;
+    const double a2 = d.x * ux + d.y * uy + d.z * uz;
+    const double nb = -(d.x * e.qox + d.y * e.qoy + d.z * e.qoz);       // = d_o of the axis-aligned form
+    const double disc = nb * nb - a2 * e.c0;
+    const double root = fm::sqrt_pos(disc);          // NaN when the line misses
+    double t = e.inside ? nb + root : nb - root;
+    if (t < 0) t = NAN;
+    return t * fm::rcp(a2);
+}
+
+__device__ __forceinline__ vec3 quadric_point(const quadric_ray& e, const vec3& d, double t) {
+    vec3 p;
+    p.x = d.x * t + e.ox;
+    p.y = d.y * t + e.oy;
+    p.z = d.z * t + e.oz;
+    return p;
+}
+
 struct georef_args {
     tan_wcs wcs;
     ellipsoid_ray ray;
     mat3 m_geo;
     mat3 m_sm;
     bowring_fast bw;
+    // k_georef_rows works in the GEO frame: camera model rotated into GEO, shell as a general quadric, GEO -> SM
+    tan_wcs wcs_geo;
+    quadric_ray qray;
+    mat3 m_geo_sm;
     int width, height;
     const double* dirs_in;   // optional (H+1, W+1, 3)
     double* lat;
@@ -416,21 +485,19 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
         if (col_ok) {
             const int64_t gi = (int64_t)gy * W1 + gx;
             karg_ptr K = karg_fresh();
-            const ellipsoid_ray ray = karg_load<ellipsoid_ray>(K, offsetof(georef_args, ray));
             if (DIRS_IN) {
-                d.x = A.dirs_in[3 * gi];
-                d.y = A.dirs_in[3 * gi + 1];
-                d.z = A.dirs_in[3 * gi + 2];
+                const vec3 dj = {A.dirs_in[3 * gi], A.dirs_in[3 * gi + 1], A.dirs_in[3 * gi + 2]};
+                d = mul(karg_load<mat3>(K, offsetof(georef_args, m_geo)), dj);       // J2000 -> GEO
             } else {
-                d = tan_direction_fast(karg_load<tan_wcs>(K, offsetof(georef_args, wcs)), gx - 0.5, gy - 0.5);
+                d = tan_direction_fast(karg_load<tan_wcs>(K, offsetof(georef_args, wcs_geo)), gx - 0.5, gy - 0.5);
             }
-            const double t = ray_param_fast(ray, d);
+            const quadric_ray ray = karg_load<quadric_ray>(K, offsetof(georef_args, qray));
+            const double t = quadric_param(ray, d);
             const bool hit = t == t;
             if (hit) {
-                p = ray_point(ray, d, t);
+                p = quadric_point(ray, d, t);        // already in GEO
                 K = karg_fresh();
-                const vec3 g = mul(karg_load<mat3>(K, offsetof(georef_args, m_geo)), p);
-                ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), g.x, g.y, g.z, la, lo);
+                ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), p.x, p.y, p.z, la, lo);
             }
             if (BIN) {
                 // The wait for the prefetched pixel sits here, right before this iteration's first store: the
@@ -469,7 +536,7 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
                 if (A.lon) A.lon[gi] = lo;
                 if (MAG && A.mlat) {
                     double ml = NAN, mt = NAN;
-                    if (hit) sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(), offsetof(georef_args, m_sm)), p), ml, mt);
+                    if (hit) sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(), offsetof(georef_args, m_geo_sm)), p), ml, mt);
                     A.mlat[gi] = ml;
                     A.mlt[gi] = mt;
                 }
@@ -493,9 +560,9 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
                 dc.z = (tz + from_next_lane(tz)) * 0.25;
             } else {
                 karg_ptr K = karg_fresh();
-                const ellipsoid_ray ray = karg_load<ellipsoid_ray>(K, offsetof(georef_args, ray));
-                dc = tan_direction_fast(karg_load<tan_wcs>(K, offsetof(georef_args, wcs)), (double)gx, (double)(gy - 1));
-                pc = ray_point(ray, dc, ray_param_fast(ray, dc));
+                dc = tan_direction_fast(karg_load<tan_wcs>(K, offsetof(georef_args, wcs_geo)), (double)gx, (double)(gy - 1));
+                const quadric_ray ray = karg_load<quadric_ray>(K, offsetof(georef_args, qray));
+                pc = quadric_point(ray, dc, quadric_param(ray, dc));
                 if (want_bbox) {
                     // after sanitisation a centre also needs its 4 corners (reference mapping.py:1093-1101)
                     const int h = (prev.p.x == prev.p.x) && (p.x == p.x);
@@ -510,14 +577,14 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
                 double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN;
                 if (pc.x == pc.x) {
                     karg_ptr K = karg_fresh();
-                    const vec3 g = mul(karg_load<mat3>(K, offsetof(georef_args, m_geo)), pc);
-                    ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), g.x, g.y, g.z, lac, loc);
+                    ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), pc.x, pc.y, pc.z, lac, loc);
                     // reference astrometry.py:200-212, utils.py:33-46: 90 - angle(-d, P/|P|) = asin(-d.P/|P|)
+                    // (dot products do not depend on the frame the two vectors are expressed in)
                     double c = -(dc.x * pc.x + dc.y * pc.y + dc.z * pc.z) * fm::rsqrt(dot(pc, pc));
                     c = fmin(1.0, fmax(-1.0, c));
                     el = fm::asin_deg(c);
                     if (MAG && (A.mlat_c || (BIN && A.bin_magnetic)))
-                        sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(), offsetof(georef_args, m_sm)), pc), ml, mt);
+                        sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(), offsetof(georef_args, m_geo_sm)), pc), ml, mt);
                 }
                 if (A.lat_c) A.lat_c[gi] = lac;
                 if (A.lon_c) A.lon_c[gi] = loc;
@@ -784,6 +851,18 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     A.ray = make_ray(p->a, p->b, p->cam, 1);
     A.m_geo = make_mat3(p->m_geo);
     A.m_sm = make_mat3(p->m_sm);
+    {
+        // GEO-frame constants of k_georef_rows: camera model and SM rotation composed with M = J2000 -> GEO
+        double rot_geo[9], mt[9], geo_sm[9];
+        mat_mul3(p->m_geo, p->rot, rot_geo);
+        A.wcs_geo = A.wcs;
+        A.wcs_geo.rot = make_mat3(rot_geo);
+        A.qray = make_quadric_ray(p->a, p->b, p->cam, p->m_geo);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) mt[3 * i + j] = p->m_geo[3 * j + i];
+        mat_mul3(p->m_sm, mt, geo_sm);               // M_sm M^T: GEO -> SM
+        A.m_geo_sm = make_mat3(geo_sm);
+    }
     A.bw = make_bowring_fast(p->a0, p->b0);
     A.width = p->width;
     A.height = p->height;
