@@ -225,6 +225,8 @@ class Context(object):
                 t = t.to(want)
             return t.contiguous()
         a = np.ascontiguousarray(array, dtype=dtype)
+        if not a.flags.writeable:          # torch refuses to wrap read-only memory silently (e.g. np.load results)
+            a = a.copy()
         if a.dtype == np.uint16:   # torch has limited uint16 support: move the bytes
             t = torch.from_numpy(a.view(np.int16)).to(self.device)
             return t

@@ -104,7 +104,14 @@ class FramePipeline(object):
     # -- inputs ---------------------------------------------------------------------------------
     def set_image(self, img):
         """Copy an (h, w, c) host image (or device tensor of the same bytes) into the frame buffer."""
-        t = self.ctx.to_device(img, self.fd.img_dtype)
+        import torch
+        if isinstance(img, torch.Tensor):
+            t = self.ctx.to_device(img, self.fd.img_dtype)
+        else:
+            a = np.ascontiguousarray(img, dtype=self.fd.img_dtype)
+            if not a.flags.writeable:
+                a = a.copy()
+            t = torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)     # one H2D copy, no staging
         self.fd.img.copy_(t.reshape(self.fd.img.shape))
 
     # -- single-pass plan (native driver, include/auromat_hip.h amt_pipe_*) ----------------------
@@ -263,3 +270,121 @@ class FramePipeline(object):
         """Raw (NaN = missing) coordinate arrays of the last frame as NumPy arrays."""
         names = ['lat', 'lon', 'lat_c', 'lon_c', 'elev'] + (['mlat', 'mlt', 'mlat_c', 'mlt_c'] if self.with_mag else [])
         return {k: self.fd.host(k) for k in names}
+
+
+class SequencePipeline(object):
+    """
+    Software-pipelined processing of a sequence of equally sized frames on one GPU — what the reference does
+    with ``map`` over ``getMappingSequence`` followed by ``resample`` (spacecraft.py:326-332, cli/convert.py:185-220).
+
+    Two frame buffers alternate.  While the GPU georeferences + bins frame k+1, the host finishes frame k
+    (waits for its bounding box, lays out its grid, enqueues the crop/finalise) and prepares frame k+2 (rotation
+    matrices, coarse bounding-box pre-pass).  plan='single-pass' uses the native frame driver (amt_pipe_*) and
+    falls back per frame to the two-pass plan where it does not apply; plan='two-pass' bins with a separate
+    kernel, optionally on a second stream beside the next frame's ray casting.
+    """
+
+    def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, altitude=110, fast=True,
+                 min_elevation=10.0, pxPerDeg=10, plan='single-pass', bin_stream=True, shared_image=None):
+        import torch
+        assert plan in ('single-pass', 'two-pass')
+        try:
+            _, _ = pxPerDeg
+        except TypeError:
+            pxPerDeg = (pxPerDeg, pxPerDeg)
+        self.pxPerDeg = tuple(pxPerDeg)
+        self.altitude, self.fast, self.min_elevation = altitude, fast, min_elevation
+        self.single_pass = plan == 'single-pass' and nchan == 3
+        self.pipes = [FramePipeline(width, height, nchan, img_dtype, device), FramePipeline(width, height, nchan, img_dtype, device)]
+        self.ctx = self.pipes[0].ctx
+        if shared_image is not None:
+            # every frame shows the same image (synthetic benchmarks): upload it once, both buffers alias it
+            self.pipes[0].set_image(shared_image)
+            self.pipes[1].fd.img = self.pipes[0].fd.img
+        for q in self.pipes:
+            q.defer_join = True             # joined once per process() call
+        self.s_main = torch.cuda.Stream(device=self.ctx.device)
+        # two-pass plan: the binning kernel is memory bound and the ray casting FP64 bound, so frame k's binning
+        # runs beside frame k+1's ray casting on a second stream
+        self.s_bin = torch.cuda.Stream(device=self.ctx.device) if (bin_stream and not self.single_pass) else self.s_main
+        self._geo_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._bin_done = [None, None]
+        self.plans = []                     # plan taken by each frame of the last process() call
+
+    def _prepare(self, k, frame):
+        hdr, cam, t, img = frame
+        p = hdr if not isinstance(hdr, dict) else frame_params(hdr, self.altitude, cam, t, self.fast, magnetic=False)
+        if self.single_pass:
+            self.pipes[k % 2].start_coarse(p, self.min_elevation)     # tiny kernel on the driver's own stream
+        return p, cam, t, img
+
+    def _launch(self, k, prepared):
+        import torch
+        p, cam, t, img = prepared
+        q = self.pipes[k % 2]
+        two_streams = self.s_bin is not self.s_main
+        with torch.cuda.stream(self.s_main):
+            if two_streams and self._bin_done[k % 2] is not None:
+                self.s_main.wait_event(self._bin_done[k % 2])         # frame k-2's binning still reads this buffer
+            if img is not None:
+                q.set_image(img)
+            q.georef(None, self.altitude, cam, t, self.fast, self.min_elevation, params=p,
+                     fuse_pxPerDeg=self.pxPerDeg if self.single_pass else None, coarse_started=True)
+            if two_streams:
+                self._geo_done[k % 2].record(self.s_main)
+
+    def _finish(self, k, keep_on_device):
+        import torch
+        q = self.pipes[k % 2]
+        two_streams = self.s_bin is not self.s_main
+        with torch.cuda.stream(self.s_bin):
+            if two_streams:
+                self.s_bin.wait_event(self._geo_done[k % 2])
+            res = q.resample(self.pxPerDeg, keep_on_device=keep_on_device)
+            if two_streams:
+                self._bin_done[k % 2] = torch.cuda.Event()
+                self._bin_done[k % 2].record(self.s_bin)
+        self.plans.append(q.last_plan)
+        return res
+
+    def process(self, frames, keep_on_device=True):
+        """
+        frames: iterable of (wcsHeader | amt_frame_params, cameraPosGCRS, photoTime, image | None).
+        Returns the list of per-frame result dicts (see :func:`auromat_amd.resample.resample_frame`) in order;
+        with keep_on_device the arrays are device tensors that are valid for work on the current stream.
+        """
+        import torch
+        del self.plans[:]
+        out = []
+        it = iter(frames)
+        window = []                          # prepared frames k+1, k+2 (at most two ahead)
+        k = 0
+        first = next(it, None)
+        if first is None:
+            return out
+        self._launch(0, self._prepare(0, first))
+        nxt = next(it, None)
+        if nxt is not None:
+            window.append(self._prepare(1, nxt))
+        while True:
+            if window:
+                self._launch(k + 1, window.pop(0))
+                nxt = next(it, None)
+                if nxt is not None:
+                    window.append(self._prepare(k + 2, nxt))
+                more = True
+            else:
+                more = False
+            out.append(self._finish(k, keep_on_device))
+            k += 1
+            if not more:
+                break
+        # order the caller's stream behind everything this call enqueued
+        with torch.cuda.stream(self.s_main):
+            for q in self.pipes:
+                q.join()
+        cur = torch.cuda.current_stream(self.ctx.device)
+        cur.wait_stream(self.s_main)
+        if self.s_bin is not self.s_main:
+            cur.wait_stream(self.s_bin)
+        return out

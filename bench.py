@@ -90,100 +90,26 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-    from auromat_amd._native import Context
-    from auromat_amd.pipeline import FramePipeline
-    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.pipeline import SequencePipeline
     from auromat_amd.sequence import gather_results
     from auromat_amd.synthetic import sequence_frame, frame_image
 
-    # two frame buffers: while the host lays out frame k's grid, the GPU already georeferences frame k+1
-    pipes = [FramePipeline(WIDTH, HEIGHT), FramePipeline(WIDTH, HEIGHT)]
-    pipe = pipes[0]
-    ctx = pipe.ctx
-    pipe.set_image(frame_image(WIDTH, HEIGHT, seed=rank))      # resident before the timed region
-    pipes[1].fd.img = pipe.fd.img                                # same synthetic image for every frame
-    for q in pipes:
-        q.defer_join = True                                      # joined once after the loop (see run())
+    # The product's own sequence loop (auromat_amd/pipeline.py): two frame buffers, frame k+1 is georeferenced
+    # while the host finishes frame k and prepares frame k+2.  plan=fused: binning inside the georeferencing
+    # kernel via the native frame driver; plan=two-pass: separate binning kernel, on a second HIP stream beside
+    # the next frame's ray casting when --streams 2.
     fast = not args.exact
     total = args.warmup + args.steps
-
-    # two HIP streams: the georeferencing kernel is FP64-VALU bound and leaves HBM mostly idle, the binning
-    # kernel is memory bound and leaves the VALUs idle, so frame k's binning runs beside frame k+1's ray casting
-    s_geo = torch.cuda.Stream()
     fused = args.plan == 'fused'
-    s_bin = torch.cuda.Stream() if (args.streams == 2 and not fused) else s_geo
-    geo_done = [torch.cuda.Event(), torch.cuda.Event()]
-    bin_done = [None, None]
+    seq = SequencePipeline(WIDTH, HEIGHT, altitude=ALTITUDE, fast=fast, min_elevation=MIN_ELEV, pxPerDeg=PPD,
+                           plan='single-pass' if fused else 'two-pass', bin_stream=args.streams == 2,
+                           shared_image=frame_image(WIDTH, HEIGHT, seed=rank))     # resident before the timed region
+    ctx = seq.ctx
+    # the synthetic sequence (what a reader would hand over: WCS cards, camera position, time) exists before the
+    # timed region, like the image; everything derived from it (matrices, grids) is computed inside
+    frames = [sequence_frame(rank * total + k, WIDTH, HEIGHT)[:3] + (None,) for k in range(total)]
 
-    prepared = {}
-    plans = []
-    # the synthetic sequence (what a reader would hand over: WCS cards, camera position, time) exists before
-    # the timed region, like the image; everything derived from it (matrices, grids) is computed inside
-    headers = [sequence_frame(rank * total + k, WIDTH, HEIGHT)[:3] for k in range(total)]
-
-    def prepare(k):
-        """Host set-up of frame k; in the single-pass plan also its coarse bbox pre-pass (own stream)."""
-        hdr, cam, t = headers[k]
-        p = frame_params(hdr, ALTITUDE, cam, t, fast, magnetic=False)
-        if fused:
-            pipes[k % 2].start_coarse(p, MIN_ELEV)      # tiny kernel on the driver's own high-priority stream
-        prepared[k] = (p, cam, t)
-
-    def launch_georef(k):
-        p, cam, t = prepared.pop(k)
-        q = pipes[k % 2]
-        with torch.cuda.stream(s_geo):
-            if bin_done[k % 2] is not None and s_bin is not s_geo:
-                s_geo.wait_event(bin_done[k % 2])        # frame k-2's binning still reads this buffer
-            q.georef(None, ALTITUDE, cam, t, fast, MIN_ELEV, params=p,
-                     fuse_pxPerDeg=(PPD, PPD) if fused else None, coarse_started=True)
-            if s_bin is not s_geo:
-                geo_done[k % 2].record(s_geo)
-
-    def launch_resample(k):
-        with torch.cuda.stream(s_bin):
-            if s_bin is not s_geo:
-                s_bin.wait_event(geo_done[k % 2])
-            res = pipes[k % 2].resample(PPD, containsPole=False, keep_on_device=True)
-            plans.append(pipes[k % 2].last_plan)
-            if s_bin is not s_geo:
-                bin_done[k % 2] = torch.cuda.Event()
-                bin_done[k % 2].record(s_bin)
-        return res
-
-    host = {'prepare': 0.0, 'launch': 0.0, 'resample': 0.0}
-
-    def timed(name, fn):
-        def wrapper(*a):
-            t = time.perf_counter()
-            r = fn(*a)
-            host[name] += time.perf_counter() - t
-            return r
-        return wrapper
-
-    if os.environ.get('AMT_BENCH_HOST_TIMES'):      # host seconds per phase -> stderr (diagnostics)
-        prepare, launch_georef, launch_resample = (timed('prepare', prepare), timed('launch', launch_georef),
-                                                   timed('resample', launch_resample))
-
-    def run(first, count):
-        """Frames first .. first+count-1, software-pipelined; returns their results."""
-        out = []
-        prepare(first)
-        launch_georef(first)
-        if count > 1:
-            prepare(first + 1)
-        for i in range(count):
-            if i + 1 < count:
-                launch_georef(first + i + 1)
-            if i + 2 < count:
-                prepare(first + i + 2)
-            out.append(launch_resample(first + i))
-        with torch.cuda.stream(s_geo):
-            for q in pipes:
-                q.join()
-        return out
-
-    run(0, args.warmup)
+    seq.process(frames[:args.warmup])
     ctx.timing_enable(TIMING_EVERY)
 
     def fence():
@@ -194,17 +120,13 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    del plans[:]
-    results = run(args.warmup, args.steps)
+    results = seq.process(frames[args.warmup:])
+    plans = list(seq.plans)
     gathered = None
     if world > 1:
-        torch.cuda.current_stream().wait_stream(s_bin)     # the gather runs on the default stream
         gathered = gather_results(results, [rank * total + args.warmup + k for k in range(args.steps)], ctx.device)
     fence()
     elapsed = time.perf_counter() - t0
-    if os.environ.get('AMT_BENCH_HOST_TIMES'):
-        sys.stderr.write('host us/frame (incl. warmup frames): %s\n'
-                         % {k: round(v / total * 1e6, 1) for k, v in host.items()})
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

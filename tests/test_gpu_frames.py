@@ -332,3 +332,28 @@ def test_single_pass_plan_falls_back_on_pole():
     res = pipe.run(hdr, 110, cam, t, img=img, min_elevation=10, pxPerDeg=2, fuse=True)
     assert pipe.last_plan == 'two-pass' and res['contains_pole']
     assert np.all(res['img'][~res['mask']] == 777)
+
+
+def test_sequence_pipeline_plans_agree_with_frame_by_frame():
+    """Software-pipelined sequences (both plans, buffers reused every second frame) == one frame at a time."""
+    from auromat_amd.pipeline import FramePipeline, SequencePipeline
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    w, h = 250, 168
+    frames = []
+    for k in range(7):
+        hdr, cam, t, seed = sequence_frame(k, w, h)
+        frames.append((hdr, cam, t, frame_image(w, h, seed=seed)))
+    ref_pipe = FramePipeline(w, h)
+    ref = [ref_pipe.run(hdr, 110, cam, t, img=img, pxPerDeg=8) for hdr, cam, t, img in frames]
+    for plan, streams in (('single-pass', True), ('two-pass', True), ('two-pass', False)):
+        seq = SequencePipeline(w, h, pxPerDeg=8, plan=plan, bin_stream=streams)
+        for rep in range(2):                       # a second call re-uses the buffers and the driver state
+            out = seq.process(frames, keep_on_device=False)
+            assert len(out) == len(frames)
+            assert seq.plans == [plan] * len(frames)
+            for a, b in zip(out, ref):
+                for key in ('mean', 'count', 'img', 'mask', 'lat', 'lon', 'lat_c', 'lon_c'):
+                    assert np.array_equal(a[key], b[key], equal_nan=True), (plan, key)
+    assert SequencePipeline(w, h).process([]) == []
+    one = SequencePipeline(w, h, pxPerDeg=8).process(frames[:1], keep_on_device=False)
+    assert np.array_equal(one[0]['mean'], ref[0]['mean'], equal_nan=True)
