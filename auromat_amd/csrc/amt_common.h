@@ -354,12 +354,14 @@ __host__ inline bowring_fast make_bowring_fast(double a, double b) {
     return w;
 }
 
+// inv_r (optional out): 1 / |(x, y, z)|, a by-product the caller's elevation needs as well.
 __device__ __forceinline__ void ecef_to_geodetic_deg_fast(const bowring_fast& w, double x, double y, double z,
-                                                          double& lat_deg, double& lon_deg) {
+                                                          double& lat_deg, double& lon_deg, double* inv_r = nullptr) {
     const double p2 = x * x + y * y;
     double p, ip;
     fm::sqrt_rsqrt(p2, p, ip);
     const double ir = fm::rsqrt(p2 + z * z);
+    if (inv_r) *inv_r = ir;
     const double tu = w.b_over_a * z * fma(w.d, ir, 1.0) * ip;
     const double tu2 = tu * tu;
     const double c = fm::rsqrt(1.0 + tu2);

@@ -476,6 +476,10 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
     unsigned int raw0 = 0, raw1 = 0;                  // raw words as loaded; unpacked only after the wait
     int img_shift = 0;
 
+    // element indices of this lane's corner (row gy) and pixel (row gy-1), advanced by one row per step: keeps
+    // the quarter-rate 64-bit multiplies out of the loop
+    int64_t gi_corner = (int64_t)y0 * W1 + gx;
+    int64_t gi_pixel = (int64_t)(y0 - 1) * A.width + gx;
     auto step = [&](const int r, const row_state& prev, row_state& cur) {
         const int gy = y0 + r;
         unsigned int ch0 = 0, ch1 = 0, ch2 = 0;          // image pixel (gy-1, gx)
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
         vec3 d = {NAN, NAN, NAN}, p = {NAN, NAN, NAN};
         double la = NAN, lo = NAN;
         if (col_ok) {
-            const int64_t gi = (int64_t)gy * W1 + gx;
+            const int64_t gi = gi_corner;
             karg_ptr K = karg_fresh();
             if (DIRS_IN) {
                 const vec3 dj = {A.dirs_in[3 * gi], A.dirs_in[3 * gi + 1], A.dirs_in[3 * gi + 2]};
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
                     // one aligned 8-byte load covers the 3 (uint8) or 6 (uint16) bytes of the pixel wherever it
                     // starts; the address is clamped so that the load never reaches past the image
                     const int64_t pix_bytes = BIN == 1 ? 3 : 6;
-                    const int64_t b = ((int64_t)gy * A.width + gx) * pix_bytes;
+                    const int64_t b = (gi_pixel + A.width) * pix_bytes;       // pixel (gy, gx): next step's centre row
                     const int64_t last = (int64_t)A.width * A.height * pix_bytes - 8;
                     int64_t a = b & ~(int64_t)3;
                     a = a > last ? last : a;
@@ -573,14 +577,16 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
             int bin_x = 0, bin_y = 0;            // 1-based bin indices of this pixel, 0 = not binned
             long long el_fix = 0;
             if (px_ok) {
-                const int64_t gi = (int64_t)(gy - 1) * A.width + gx;
+                const int64_t gi = gi_pixel;
                 double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN;
                 if (pc.x == pc.x) {
                     karg_ptr K = karg_fresh();
-                    ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), pc.x, pc.y, pc.z, lac, loc);
+                    double inv_r;
+                    ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), pc.x, pc.y, pc.z, lac, loc,
+                                              &inv_r);
                     // reference astrometry.py:200-212, utils.py:33-46: 90 - angle(-d, P/|P|) = asin(-d.P/|P|)
-                    // (dot products do not depend on the frame the two vectors are expressed in)
-                    double c = -(dc.x * pc.x + dc.y * pc.y + dc.z * pc.z) * fm::rsqrt(dot(pc, pc));
+                    // (dot products do not depend on the frame; 1/|P| is a by-product of the Bowring step)
+                    double c = -(dc.x * pc.x + dc.y * pc.y + dc.z * pc.z) * inv_r;
                     c = fmin(1.0, fmax(-1.0, c));
                     el = fm::asin_deg(c);
                     if (MAG && (A.mlat_c || (BIN && A.bin_magnetic)))
@@ -659,6 +665,8 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
                 if ((prev.flag | flag_cur) && prev.la == prev.la) box_add(prev.la, prev.lo);
             }
         }
+        gi_corner += W1;
+        gi_pixel += A.width;
         cur.p = p;
         cur.d = d;
         cur.la = la;
