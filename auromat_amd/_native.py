@@ -29,7 +29,7 @@ class GeorefOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ('lat', 'lon', 'lat_c', 'lon_c', 'elev', 'mlat', 'mlt', 'mlat_c',
                                           'mlt_c', 'bbox')] + [('bbox_min_elevation', C.c_double)] + \
                [(k, C.c_void_p) for k in ('bin_xaxis', 'bin_yaxis', 'bin_img', 'bin_acc')] + \
-               [(k, C.c_int32) for k in ('bin_img_dtype', 'bin_lon_wrap', 'bin_magnetic', 'bin_reserved')]
+               [(k, C.c_int32) for k in ('bin_img_dtype', 'bin_lon_wrap', 'bin_magnetic', 'item_order')]
 
 
 class Axis(C.Structure):

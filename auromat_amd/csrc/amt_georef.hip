@@ -115,6 +115,7 @@ struct georef_args {
     const void* bin_img;
     unsigned long long* bin_acc;
     int bin_lon_wrap, bin_magnetic;
+    int item_order, pad_;       // amt_georef_out.item_order
 };
 
 constexpr int kThreads = 256;
@@ -438,7 +439,18 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
             atomicAdd(&acc[4 * ncell + cell], (unsigned long long)el);
         }
     };
-    const int chunk = item / strips_x, strip = item - chunk * strips_x;
+    // item -> (chunk of rows, strip of columns); the order only decides which items the dispatcher starts first
+    const int chunks_y = n_items / strips_x;
+    int chunk, strip;
+    if (A.item_order < 2) {
+        chunk = item / strips_x;
+        strip = item - chunk * strips_x;
+        if (A.item_order == 1) chunk = chunks_y - 1 - chunk;
+    } else {
+        strip = item / chunks_y;
+        chunk = item - strip * chunks_y;
+        if (A.item_order == 3) strip = strips_x - 1 - strip;
+    }
     const int x0 = strip * 63, y0 = chunk * rows_per_chunk;
     const int rows = min(rows_per_chunk, A.height - y0);
     const int gx = x0 + lane;
@@ -794,6 +806,8 @@ __global__ __launch_bounds__(kThreads) void k_coarse_bbox(georef_args A, int str
         const vec3 d = tan_direction_fast(A.wcs, gx - 0.5, gy - 0.5);
         const double t = ray_param_fast(A.ray, d);
         if (t == t) {
+            // where the expensive rays are, relative to the frame centre (scheduling hint for the full kernel)
+            v[7] = (double)(((2 * gx > A.width) - (2 * gx < A.width)) * (1 << 20) + ((2 * gy > A.height) - (2 * gy < A.height)));
             const vec3 p = ray_point(A.ray, d, t);
             double c = -(d.x * p.x + d.y * p.y + d.z * p.z) * fm::rsqrt(dot(p, p));
             c = fmin(1.0, fmax(-1.0, c));
@@ -889,6 +903,8 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     A.bin_img = nullptr;
     A.bin_acc = nullptr;
     A.bin_lon_wrap = A.bin_magnetic = 0;
+    A.item_order = out->item_order >= 0 && out->item_order <= 3 ? out->item_order : 0;
+    A.pad_ = 0;
     std::memset(&A.bax, 0, sizeof(A.bax));
     std::memset(&A.bay, 0, sizeof(A.bay));
     std::memset(&A.bxl, 0, sizeof(A.bxl));

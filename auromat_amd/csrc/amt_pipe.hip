@@ -247,7 +247,16 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
     o.bin_acc = nullptr;
     o.bin_xaxis = o.bin_yaxis = nullptr;
     o.bin_img = nullptr;
-    o.bin_img_dtype = o.bin_lon_wrap = o.bin_magnetic = o.bin_reserved = 0;
+    o.bin_img_dtype = o.bin_lon_wrap = o.bin_magnetic = 0;
+    {
+        // start with the side of the frame where the coarse pass found the hits (see amt_georef_out.item_order)
+        const long long packed = (long long)pipe->host_small[7];
+        long long sy = ((packed % (1 << 20)) + (1 << 20)) % (1 << 20);
+        if (sy >= (1 << 19)) sy -= (1 << 20);
+        const long long sx = (packed - sy) / (1 << 20);
+        const long long ax = sx < 0 ? -sx : sx, ay = sy < 0 ? -sy : sy;
+        o.item_order = ay >= ax ? (sy > 0 ? 1 : 0) : (sx > 0 ? 3 : 2);
+    }
 
     const double* c = pipe->host_small;     // coarse [lat_min, lat_max, lon_min, lon_max, ..., n]
     bool fuse = c[6] > 0 && !(c[3] - c[2] > 180) && !pipe->pole;

@@ -137,7 +137,11 @@ typedef struct amt_georef_out {
     int32_t bin_img_dtype;
     int32_t bin_lon_wrap;
     int32_t bin_magnetic;
-    int32_t bin_reserved;
+    /* Scheduling hint, no effect on results: order in which the frame's work items are dispatched.
+     * 0 = rows top to bottom, 1 = bottom to top, 2 = columns left to right, 3 = right to left.  Rays that miss
+     * the shell are cheap, hits are expensive; starting with the side of the frame where the Earth is lets the
+     * cheap items fill the end of the launch (4-5 % shorter kernel).  amt_georef_coarse_bbox reports that side. */
+    int32_t item_order;
 } amt_georef_out;
 
 /* ---- building blocks (auromat.coordinates) ------------------------------------------- */
@@ -214,7 +218,8 @@ int amt_georef_frame_dirs(amt_ctx* ctx, const amt_frame_params* p, const double*
  * 1/stride^2 sample of the rays): a corner counts when the elevation of its own ray is >= min_elevation.
  * With magnetic != 0 the box is in (MLat, SM longitude) instead of (lat, lon).  Used to lay out a superset
  * grid for the fused binning before the full kernel runs; the caller adds a safety margin and checks the
- * exact box afterwards. */
+ * exact box afterwards.  bbox[7] = sx * 2^20 + sy, where sx (sy) is the number of sampled rays that hit the
+ * shell right of (below) the frame centre minus those left of (above) it: the input of amt_georef_out.item_order. */
 int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stride, double min_elevation,
                            int magnetic, double* bbox);
 

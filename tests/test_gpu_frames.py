@@ -357,3 +357,23 @@ def test_sequence_pipeline_plans_agree_with_frame_by_frame():
     assert SequencePipeline(w, h).process([]) == []
     one = SequencePipeline(w, h, pxPerDeg=8).process(frames[:1], keep_on_device=False)
     assert np.array_equal(one[0]['mean'], ref[0]['mean'], equal_nan=True)
+
+
+def test_item_order_is_a_pure_scheduling_hint():
+    """amt_georef_out.item_order changes the dispatch order of the work items, never the results."""
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 253, 171
+    hdr, cam, t = frame_header(w, h, 'iss029')
+    pipe = FramePipeline(w, h)
+    img = frame_image(w, h, seed=3)
+    base = None
+    for order in (0, 1, 2, 3, 7):                 # 7: out of range -> treated as 0
+        pipe._out.item_order = order
+        res = pipe.run(hdr, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, fuse=False)
+        arrays = dict(pipe.host_arrays(), mean=res['mean'], count=res['count'])
+        if base is None:
+            base = arrays
+        for k, v in arrays.items():
+            assert np.array_equal(v, base[k], equal_nan=True), (order, k)
+    pipe._out.item_order = 0
