@@ -442,15 +442,9 @@ __global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) vo
     // item -> (chunk of rows, strip of columns); the order only decides which items the dispatcher starts first
     const int chunks_y = n_items / strips_x;
     int chunk, strip;
-    if (A.item_order < 2) {
-        chunk = item / strips_x;
-        strip = item - chunk * strips_x;
-        if (A.item_order == 1) chunk = chunks_y - 1 - chunk;
-    } else {
-        strip = item / chunks_y;
-        chunk = item - strip * chunks_y;
-        if (A.item_order == 3) strip = strips_x - 1 - strip;
-    }
+    chunk = item / strips_x;
+    strip = item - chunk * strips_x;
+    if (A.item_order == 2) chunk = chunks_y - 1 - chunk;
     const int x0 = strip * 63, y0 = chunk * rows_per_chunk;
     const int rows = min(rows_per_chunk, A.height - y0);
     const int gx = x0 + lane;
@@ -831,6 +825,22 @@ __global__ __launch_bounds__(kThreads) void k_coarse_bbox(georef_args A, int str
     block_reduce8<kThreads>(v, partials + (int64_t)blockIdx.x * 8, sRed);
 }
 
+// amt_georef_out.item_order = 0: towards which side of the frame the nadir (the direction of the Earth's centre)
+// lies.  In-plane direction of the TAN projection of -cam: native vector v = rot^T d, intermediate coordinates
+// proportional to (v_y, -v_x) (no division by v_z, so it also works when the nadir is behind the image plane),
+// pixel offsets by the inverse CD matrix.
+int nadir_side(const amt_frame_params* p) {
+    const double d[3] = {-p->cam[0], -p->cam[1], -p->cam[2]};
+    const double* r = p->rot;
+    const double vx = r[0] * d[0] + r[3] * d[1] + r[6] * d[2], vy = r[1] * d[0] + r[4] * d[1] + r[7] * d[2];
+    const double bx = vy, by = -vx;
+    const double det = p->cd[0] * p->cd[3] - p->cd[1] * p->cd[2];
+    if (!(det != 0)) return 1;
+    const double px = (bx * p->cd[3] - p->cd[1] * by) / det, py = (p->cd[0] * by - p->cd[2] * bx) / det;
+    // Earth to the left or right: every row of items mixes cheap and expensive ones, any row order does
+    return (std::fabs(py) >= std::fabs(px) && py > 0) ? 2 : 1;
+}
+
 // items (waves) of the row-marching launch / tiles of the tile kernel, and the rows per chunk
 struct launch_shape {
     bool use_tiles;
@@ -903,7 +913,7 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     A.bin_img = nullptr;
     A.bin_acc = nullptr;
     A.bin_lon_wrap = A.bin_magnetic = 0;
-    A.item_order = out->item_order >= 0 && out->item_order <= 3 ? out->item_order : 0;
+    A.item_order = out->item_order >= 1 && out->item_order <= 2 ? out->item_order : (dirs ? 1 : nadir_side(p));
     A.pad_ = 0;
     std::memset(&A.bax, 0, sizeof(A.bax));
     std::memset(&A.bay, 0, sizeof(A.bay));

@@ -255,7 +255,7 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
         if (sy >= (1 << 19)) sy -= (1 << 20);
         const long long sx = (packed - sy) / (1 << 20);
         const long long ax = sx < 0 ? -sx : sx, ay = sy < 0 ? -sy : sy;
-        o.item_order = ay >= ax ? (sy > 0 ? 1 : 0) : (sx > 0 ? 3 : 2);
+        o.item_order = (ax | ay) == 0 ? 0 : ((ay >= ax && sy > 0) ? 2 : 1);
     }
 
     const double* c = pipe->host_small;     // coarse [lat_min, lat_max, lon_min, lon_max, ..., n]

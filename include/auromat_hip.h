@@ -137,10 +137,12 @@ typedef struct amt_georef_out {
     int32_t bin_img_dtype;
     int32_t bin_lon_wrap;
     int32_t bin_magnetic;
-    /* Scheduling hint, no effect on results: order in which the frame's work items are dispatched.
-     * 0 = rows top to bottom, 1 = bottom to top, 2 = columns left to right, 3 = right to left.  Rays that miss
-     * the shell are cheap, hits are expensive; starting with the side of the frame where the Earth is lets the
-     * cheap items fill the end of the launch (4-5 % shorter kernel).  amt_georef_coarse_bbox reports that side. */
+    /* Scheduling hint, no effect on results: order in which the frame's work items (strips of 63 columns x 16
+     * rows, row-major) are dispatched.  1 = rows top to bottom, 2 = bottom to top; 0 = automatic: bottom to top
+     * when the nadir lies below the frame centre (camera model; top to bottom for caller-supplied directions).
+     * Rays that miss the shell are cheap, hits are expensive; starting with the rows where the Earth is lets the
+     * cheap items fill the end of the launch (4-5 % shorter kernel; when the Earth is to the left or right every
+     * row mixes both kinds anyway).  amt_georef_coarse_bbox reports the side from actual hits (bbox[7]). */
     int32_t item_order;
 } amt_georef_out;
 

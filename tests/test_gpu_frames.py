@@ -368,7 +368,7 @@ def test_item_order_is_a_pure_scheduling_hint():
     pipe = FramePipeline(w, h)
     img = frame_image(w, h, seed=3)
     base = None
-    for order in (0, 1, 2, 3, 7):                 # 7: out of range -> treated as 0
+    for order in (1, 0, 2, 7):                    # 0 and out of range: decided from the camera model
         pipe._out.item_order = order
         res = pipe.run(hdr, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, fuse=False)
         arrays = dict(pipe.host_arrays(), mean=res['mean'], count=res['count'])
