@@ -119,6 +119,12 @@ struct georef_args {
 };
 
 constexpr int kThreads = 256;
+// Workgroup of the row-marching kernel.  Its waves never synchronise with each other (each has private LDS), so
+// the size only sets the granularity at which the dispatcher places and retires work.
+#ifndef AMT_ROWS_THREADS
+#define AMT_ROWS_THREADS 256
+#endif
+constexpr int kRowsThreads = AMT_ROWS_THREADS;
 constexpr double kInf = __builtin_huge_val();
 
 // Ray parameter with the reduced-cost primitives (same algebra as amt::ray_param, directed, camera
@@ -387,18 +393,18 @@ constexpr int kBinW = 8, kBinCells = kBinW * kBinW;
 #define AMT_ROWS_MIN_WAVES 5
 #endif
 template <bool FAST, bool DIRS_IN, bool MAG, int BIN>
-__global__ __launch_bounds__(kThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) void k_georef_rows(georef_args A, int rows_per_chunk, int strips_x,
+__global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) void k_georef_rows(georef_args A, int rows_per_chunk, int strips_x,
                                                            int n_items) {
-    constexpr int kBinWaves = BIN ? kThreads / 64 : 1, kBinSlots = BIN ? kBinCells : 1;
+    constexpr int kBinWaves = BIN ? kRowsThreads / 64 : 1, kBinSlots = BIN ? kBinCells : 1;
     __shared__ unsigned int sCnt[kBinWaves][kBinSlots];
     __shared__ unsigned int sCh[kBinWaves][3][kBinSlots];
     __shared__ unsigned long long sEl[kBinWaves][kBinSlots];
     // per-lane bounding-box accumulators live in LDS (ds_min_f64 / ds_max_f64 on the lane's own slots: no
     // conflicts, no return value to wait for) instead of 12 VGPRs that would be live across the whole loop
-    __shared__ double sBox[kThreads / 64][6][64];
+    __shared__ double sBox[kRowsThreads / 64][6][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int item = blockIdx.x * (kThreads / 64) + wave;                   // one work item per wave
+    const int item = blockIdx.x * (kRowsThreads / 64) + wave;               // one work item per wave
     if (item >= n_items) return;                                            // wave-uniform
     int bin_ax0 = 0, bin_ay0 = 0;
     bool bin_anchor = false;                                                // wave-uniform
@@ -766,7 +772,7 @@ void launch_variant(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, lau
 template <bool FAST, bool DIRS_IN, int BIN>
 void launch_rows_bin(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, int rows, int strips_x, int n_items,
                      launch_events ev) {
-    const dim3 block(kThreads);
+    const dim3 block(kRowsThreads);
     if (mag)
         hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, true, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, A,
                               rows, strips_x, n_items);
@@ -940,7 +946,7 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     const bool use_tiles = sh.use_tiles;
     const int rows_per_chunk = sh.rows_per_chunk, strips_x = sh.strips_x;
     const int64_t n_items = sh.n_items;
-    const int64_t nblocks = use_tiles ? n_items : (n_items + kThreads / 64 - 1) / (kThreads / 64);
+    const int64_t nblocks = use_tiles ? n_items : (n_items + kRowsThreads / 64 - 1) / (kRowsThreads / 64);
     AMT_REQUIRE(ctx, n_items < (1ll << 31), "frame too large");
     A.bbox_partials = nullptr;
     double* fold = nullptr;

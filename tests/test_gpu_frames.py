@@ -377,3 +377,49 @@ def test_item_order_is_a_pure_scheduling_hint():
         for k, v in arrays.items():
             assert np.array_equal(v, base[k], equal_nan=True), (order, k)
     pipe._out.item_order = 0
+
+
+@pytest.mark.parametrize('altitude', [100, 110, 120])
+def test_config4_mlat_mlt_three_shells_full_size(altitude):
+    """
+    BASELINE.json configs[3]: geomagnetic transform + MLat/MLT resample on three altitude shells at full size.
+    The oracle is run on two windows of the frame (a header whose reference pixel is shifted describes exactly the
+    same pixels), the resampling is checked through the class path and through conservation properties.
+    """
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.resample import resampleMLatMLT
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 4240, 2832
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    img = frame_image(w, h, seed=altitude)
+    pipe = FramePipeline(w, h, with_mag=True)
+    res = pipe.run(hdr, altitude, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, magnetic=True)
+    got = pipe.host_arrays()
+    # windows: one across the limb (mixed hits / misses), one deep inside the Earth part of the frame
+    hit_rows = np.where(~np.isnan(got['lat'][:, w // 2]))[0]
+    assert len(hit_rows) > 300
+    for x0, y0, ww, wh in ((w // 2 - 60, max(int(hit_rows[0]) - 40, 0), 120, 80), (w - 150, h - 100, 150, 100)):
+        sub = dict(hdr, IMAGEW=ww, IMAGEH=wh, CRPIX1=hdr['CRPIX1'] - x0, CRPIX2=hdr['CRPIX2'] - y0)
+        g = oracle_frame(sub, cam, t, True, alt=altitude)
+        for k in ('lat', 'lon', 'mlat'):
+            nan_close(got[k][y0:y0 + wh + 1, x0:x0 + ww + 1], g[k], TOL_DEG)
+        nan_close(got['mlt'][y0:y0 + wh + 1, x0:x0 + ww + 1], g['mlt'], TOL_DEG * 24 / 360)
+        for k in ('lat_c', 'lon_c', 'elev', 'mlat_c'):
+            nan_close(got[k][y0:y0 + wh, x0:x0 + ww], g[k], TOL_DEG)
+        nan_close(got['mlt_c'][y0:y0 + wh, x0:x0 + ww], g['mlt_c'], TOL_DEG * 24 / 360)
+    # resampled MLat/MLT grid: pixel conservation and exact integer sums
+    keep = got['elev'] >= 10
+    smlon = (got['mlt_c'] - 12) / (24 / 360)
+    g = res['grid']
+    inside = keep & (smlon >= g.xrange[0]) & (smlon < g.xrange[1]) & (got['mlat_c'] >= g.yrange[0]) & \
+        (got['mlat_c'] < g.yrange[1])
+    assert int(res['count'].sum()) == int(inside.sum()) > 1000000
+    filled = res['count'] > 0
+    total = (res['mean'][..., :3][filled] * res['count'][filled][:, None]).sum(axis=0)
+    np.testing.assert_allclose(total, img[inside].astype(np.float64).sum(axis=0), rtol=1e-12)
+    if altitude == 110:
+        # the reference's own call sequence (resample.py:63-71) gives the same grid
+        m = ArraySpacecraftMapping(hdr, altitude, img, cam, t, 'c4', fastCenterCalculation=True).maskedByElevation(10)
+        r = resampleMLatMLT(m, pxPerDeg=10)
+        assert np.array_equal(r.img.data, res['img']) and np.array_equal(ma.getmaskarray(r.img)[..., 0], res['mask'])
