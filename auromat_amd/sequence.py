@@ -29,7 +29,7 @@ def pack_results(results, indices, device):
     count (ny*nx).
     """
     import torch
-    descs = torch.zeros((len(results), DESC_LEN), dtype=torch.float64)
+    descs = np.zeros((len(results), DESC_LEN), dtype=np.float64)
     parts = []
     for i, (res, idx) in enumerate(zip(results, indices)):
         mean, count = res['mean'], res['count']
@@ -37,11 +37,10 @@ def pack_results(results, indices, device):
             mean, count = torch.from_numpy(np.ascontiguousarray(mean)), torch.from_numpy(np.ascontiguousarray(count))
         ny, nx, nc = mean.shape
         g = res['grid']
-        descs[i] = torch.tensor([ny, nx, nc, g.lat0, g.lon0, g.latStep, g.lonStep, idx],
-                                dtype=torch.float64)
+        descs[i] = [ny, nx, nc, g.lat0, g.lon0, g.latStep, g.lonStep, idx]
         parts += [mean.reshape(-1).to(device), count.reshape(-1).to(device)]
     payload = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.float64, device=device)
-    return descs.to(device), payload
+    return torch.from_numpy(descs).to(device), payload
 
 
 def unpack_results(descs, payload):
@@ -61,11 +60,34 @@ def unpack_results(descs, payload):
     return out
 
 
-def gather_results(results, indices, device, dst=0, group=None):
+class Gathered(object):
     """
-    Gather every rank's per-frame grids on rank `dst`.  Two collectives: an all_gather of the
+    What :func:`gather_device` leaves on the destination rank: one [descriptors | payload] buffer per rank, still
+    in the memory of `device`, plus the sizes.  :meth:`unpack` copies to the host and splits into frames.
+    """
+
+    def __init__(self, bufs, sizes, max_frames):
+        self.bufs, self.sizes, self.max_frames = bufs, sizes, max_frames
+
+    @property
+    def n_frames(self):
+        return int(self.sizes[:, 0].sum())
+
+    def unpack(self):
+        out = []
+        for r, buf in enumerate(self.bufs):
+            nf, npay = int(self.sizes[r, 0]), int(self.sizes[r, 1])
+            d = buf[:nf * DESC_LEN].reshape(nf, DESC_LEN)
+            p = buf[self.max_frames * DESC_LEN:self.max_frames * DESC_LEN + npay]
+            out += unpack_results(d, p)
+        return sorted(out, key=lambda f: f['index'])
+
+
+def gather_device(results, indices, device, dst=0, group=None):
+    """
+    Gather every rank's per-frame grids on rank `dst`, device to device.  Two collectives: an all_gather of the
     (frames, payload length) pair, then one gather of [descriptors | payload] padded to the longest.
-    Returns the list of unpacked frame results (sorted by frame index) on `dst`, None elsewhere.
+    Returns a :class:`Gathered` on `dst`, None elsewhere.
     """
     import torch
     import torch.distributed as dist
@@ -76,21 +98,23 @@ def gather_results(results, indices, device, dst=0, group=None):
     dist.all_gather(all_sizes, sizes, group=group)
     all_sizes = torch.stack(all_sizes).cpu().numpy()
     max_frames, max_payload = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
-    buf = torch.zeros(max_frames * DESC_LEN + max_payload, dtype=torch.float64, device=device)
+    buf = torch.empty(max_frames * DESC_LEN + max_payload, dtype=torch.float64, device=device)
     buf[:descs.numel()] = descs.reshape(-1)
+    buf[descs.numel():max_frames * DESC_LEN] = 0
     buf[max_frames * DESC_LEN:max_frames * DESC_LEN + payload.numel()] = payload
+    buf[max_frames * DESC_LEN + payload.numel():] = 0
     if rank == dst:
-        bufs = [torch.zeros_like(buf) for _ in range(world)]
+        bufs = [torch.empty_like(buf) for _ in range(world)]
         dist.gather(buf, bufs, dst=dst, group=group)
-        out = []
-        for r in range(world):
-            nf, npay = int(all_sizes[r, 0]), int(all_sizes[r, 1])
-            d = bufs[r][:nf * DESC_LEN].reshape(nf, DESC_LEN)
-            p = bufs[r][max_frames * DESC_LEN:max_frames * DESC_LEN + npay]
-            out += unpack_results(d, p)
-        return sorted(out, key=lambda f: f['index'])
+        return Gathered(bufs, all_sizes, max_frames)
     dist.gather(buf, None, dst=dst, group=group)
     return None
+
+
+def gather_results(results, indices, device, dst=0, group=None):
+    """:func:`gather_device` + unpacking on the host: the list of frame results sorted by frame index on `dst`."""
+    g = gather_device(results, indices, device, dst, group)
+    return g.unpack() if g is not None else None
 
 
 def run_sequence(frames, width, height, altitude=110, fast=True, min_elevation=10.0, pxPerDeg=10,
