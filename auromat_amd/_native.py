@@ -104,8 +104,8 @@ _SIGNATURES = {
     'amt_grid_layout': ([_D, _D, _D, _D, _D, _D, C.POINTER(Grid)], _I),
     'amt_pipe_create': ([_P, c_void_pp], _I),
     'amt_pipe_destroy': ([_P], _I),
-    'amt_pipe_coarse': ([_P, C.POINTER(FrameParams), _D], _I),
-    'amt_pipe_launch': ([_P, C.POINTER(FrameParams), C.POINTER(GeorefOut), _P, C.c_int32, _D, _D, _D, _I], _I),
+    'amt_pipe_coarse': ([_P, C.POINTER(FrameParams), _D, _I], _I),
+    'amt_pipe_launch': ([_P, C.POINTER(FrameParams), C.POINTER(GeorefOut), _P, C.c_int32, _D, _D, _D, _I, _I], _I),
     'amt_pipe_wait': ([_P, C.POINTER(PipeResult)], _I),
     'amt_pipe_finalize': ([_P, _P, _P, _P, _P], _I),
     'amt_pipe_join': ([_P], _I),

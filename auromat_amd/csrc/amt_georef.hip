@@ -550,11 +550,21 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
             if (owner) {
                 if (A.lat) A.lat[gi] = la;
                 if (A.lon) A.lon[gi] = lo;
-                if (MAG && A.mlat) {
+            }
+            if (MAG) {
+                // with bin_magnetic the bounding box is reduced over (MLat, SM longitude) as well
+                const bool magbox = BIN && A.bin_magnetic;
+                if ((owner && A.mlat) || magbox) {
                     double ml = NAN, mt = NAN;
                     if (hit) sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(), offsetof(georef_args, m_geo_sm)), p), ml, mt);
-                    A.mlat[gi] = ml;
-                    A.mlt[gi] = mt;
+                    if (owner && A.mlat) {
+                        A.mlat[gi] = ml;
+                        A.mlt[gi] = mt;
+                    }
+                    if (magbox) {
+                        la = ml;                                  // from here on only the bounding box reads them
+                        lo = (mt - 12.0) / (24.0 / 360.0);        // mltToSmLon, reference transform.py:388-401
+                    }
                 }
             }
         }

@@ -24,6 +24,7 @@ struct amt_pipe {
     size_t partials_bytes;
     // state of the frame in flight
     bool coarse_pending, launched, fused, ready, tail_pending;
+    int coarse_magnetic;           // coordinates of the pending coarse box (0 geodetic, 1 MLat / SM longitude)
     amt_grid super, exact;
     int32_t off_x, off_y;          // window of the exact grid inside the superset
     double lat_ppd, lon_ppd, min_elev;
@@ -72,8 +73,8 @@ int ensure_partials(amt_pipe* pipe, size_t bytes) {
 // through the inverse TAN model; it counts when it falls inside the frame, is the first hit of its ray and
 // lies above the elevation threshold (host mirror: auromat_amd/mapping/astrometry.py pole_in_view; replaces
 // the outline-based test of the reference, geodesic.py:183 / mapping.py:705-721, for known camera models).
-bool pole_visible(const amt_frame_params* p, double min_elevation) {
-    const double* m = p->m_geo;
+bool pole_visible(const amt_frame_params* p, double min_elevation, int magnetic) {
+    const double* m = magnetic ? p->m_sm : p->m_geo;
     const double* r = p->rot;
     const double sc[3] = {1 / p->a, 1 / p->a, 1 / p->b};
     for (int sign = 1; sign >= -1; sign -= 2) {
@@ -185,7 +186,7 @@ int amt_pipe_destroy(amt_pipe* pipe) {
     return AMT_OK;
 }
 
-int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation) {
+int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation, int magnetic) {
     if (pipe == nullptr) return AMT_EINVAL;
     amt_ctx* ctx = pipe->ctx;
     AMT_REQUIRE(ctx, p != nullptr, "NULL argument");
@@ -201,7 +202,7 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
     const int shorter = p->width < p->height ? p->width : p->height;
     static const int max_stride = std::getenv("AMT_COARSE_STRIDE") ? std::atoi(std::getenv("AMT_COARSE_STRIDE")) : kCoarseStride;
     const int stride = std::max(1, std::min(max_stride, shorter / 128));
-    int rc = amt_georef_coarse_bbox(ctx, p, stride, thr, 0, pipe->host_small_dev);
+    int rc = amt_georef_coarse_bbox(ctx, p, stride, thr, magnetic ? 1 : 0, pipe->host_small_dev);
     pipe->coarse_ws = ctx->ws;
     pipe->coarse_ws_bytes = ctx->ws_bytes;
     ctx->stream = saved;
@@ -210,25 +211,27 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
     if (rc != AMT_OK) return rc;
     AMT_HIP(ctx, hipEventRecord(pipe->coarse_done, pipe->pre_stream));
     pipe->coarse_pending = true;
+    pipe->coarse_magnetic = magnetic ? 1 : 0;
     return AMT_OK;
 }
 
 int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
                     int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
-                    int pole_in_view) {
+                    int pole_in_view, int magnetic) {
     if (pipe == nullptr) return AMT_EINVAL;
     amt_ctx* ctx = pipe->ctx;
     AMT_REQUIRE(ctx, p && out && img, "NULL argument");
     AMT_REQUIRE(ctx, img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
-    if (!pipe->coarse_pending) {
-        if (int rc = amt_pipe_coarse(pipe, p, min_elevation)) return rc;
+    magnetic = magnetic ? 1 : 0;
+    if (!pipe->coarse_pending || pipe->coarse_magnetic != magnetic) {
+        if (int rc = amt_pipe_coarse(pipe, p, min_elevation, magnetic)) return rc;
     }
     AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
     pipe->coarse_pending = false;
     pipe->lat_ppd = lat_px_per_deg;
     pipe->lon_ppd = lon_px_per_deg;
     pipe->min_elev = min_elevation;
-    pipe->pole = pole_in_view < 0 ? (pole_visible(p, min_elevation) ? 1 : 0) : (pole_in_view ? 1 : 0);
+    pipe->pole = pole_in_view < 0 ? (pole_visible(p, min_elevation, magnetic) ? 1 : 0) : (pole_in_view ? 1 : 0);
     pipe->img_dtype = img_dtype;
     pipe->fused = false;
 
@@ -281,6 +284,7 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
         o.bin_img = img;
         o.bin_img_dtype = img_dtype;
         o.bin_acc = pipe->acc;
+        o.bin_magnetic = magnetic;
         pipe->fused = true;
         pipe->acc_zero = false;
     }

@@ -132,10 +132,10 @@ class FramePipeline(object):
             Context.current(self.ctx.device)
             self._pcall('amt_pipe_join')
 
-    def start_coarse(self, params, min_elevation):
+    def start_coarse(self, params, min_elevation, magnetic=False):
         """Enqueue the coarse bounding-box pre-pass for `params` (asynchronous, on the driver's own stream)."""
         self._pcall('amt_pipe_coarse', C.byref(params),
-                      NEG_INF if min_elevation is None else float(min_elevation))
+                    NEG_INF if min_elevation is None else float(min_elevation), 1 if magnetic else 0)
 
     def _wait_fused(self):
         """amt_pipe_wait once per launch -> the amt_pipe_result."""
@@ -148,10 +148,11 @@ class FramePipeline(object):
 
     # -- stages ---------------------------------------------------------------------------------
     def georef(self, wcsHeader, altitude, cameraPosGCRS, photoTime, fast=True, min_elevation=10.0, params=None,
-               fuse_pxPerDeg=None, coarse_started=False):
+               fuse_pxPerDeg=None, coarse_started=False, fuse_magnetic=False):
         """
         Stage 1.  `params` (an amt_frame_params made by :func:`frame_params`) skips the host set-up.
-        `fuse_pxPerDeg` = (latPxPerDeg, lonPxPerDeg) selects the single-pass plan for that resolution.
+        `fuse_pxPerDeg` = (latPxPerDeg, lonPxPerDeg) selects the single-pass plan for that resolution, on the
+        geodetic grid or, with `fuse_magnetic`, on the (MLat, SM longitude) grid of resampleMLatMLT.
         """
         assert wcsHeader is None or (wcsHeader['IMAGEW'], wcsHeader['IMAGEH']) == (self.width, self.height)
         p = params if params is not None else frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fast,
@@ -161,13 +162,14 @@ class FramePipeline(object):
         out = self._out
         min_elev = NEG_INF if min_elevation is None else float(min_elevation)
         self.params, self.altitude, self.min_elevation = p, altitude, min_elevation
-        if fuse_pxPerDeg is not None and fd.nchan == 3:
+        if fuse_pxPerDeg is not None and fd.nchan == 3 and (self.with_mag or not fuse_magnetic):
             # coarse pre-pass (unless already enqueued), superset grid, fused kernel, bbox copy: all in the driver
+            mag = 1 if fuse_magnetic else 0
             if not coarse_started:
-                self.start_coarse(p, min_elevation)
+                self.start_coarse(p, min_elevation, mag)
             self._pcall('amt_pipe_launch', C.byref(p), C.byref(out), fd.img.data_ptr(),
-                          fd.img_dtype_code, min_elev, float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1)
-            self._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), result=None)
+                        fd.img_dtype_code, min_elev, float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1, mag)
+            self._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
             return fd
         self._fused = None
         self._pole = None                                # decided lazily in bounding_box()
@@ -181,8 +183,12 @@ class FramePipeline(object):
 
     def bounding_box(self):
         """Waits for the fused reduction of the last georef() -> BoundingBox; ValueError if nothing is valid."""
-        if self._fused is not None:
+        if self._fused is not None and not self._fused['magnetic']:
             red = np.array(self._wait_fused().bbox[:])
+        elif self._fused is not None:
+            # the driver reduced the box over (MLat, SM longitude); the geodetic one comes from the corner arrays
+            red = self._reduce_bbox(self.fd.lat, self.fd.lon)
+            red[7] = 1.0 if pole_in_view(self.params, self.min_elevation) else 0.0
         else:
             self._bbox_event.synchronize()
             red = self._bbox_host.numpy().copy()
@@ -193,6 +199,19 @@ class FramePipeline(object):
         if red[6] == 0:
             raise ValueError('minElevation=' + str(self.min_elevation) + ' would mask all pixels!')
         return bounding_box_from_reduction(red)
+
+    def _reduce_bbox(self, lat, lon):
+        """8-number bounding-box reduction (see amt_bbox_corners) of corner arrays `lat`, `lon` of this frame over
+        the corners that survive maskedByElevation(min_elevation); host array."""
+        import torch
+        fd = self.fd
+        thr = NEG_INF if self.min_elevation is None else self.min_elevation
+        cmask = (~(fd.elev >= thr)).to(torch.uint8)
+        corner = torch.isnan(fd.lat).to(torch.uint8)
+        red = self.ctx.empty((8,))
+        self.ctx.call('amt_sanitize_masks', ptr(corner), ptr(cmask), None, fd.height, fd.width, 1)
+        self.ctx.call('amt_bbox_corners', ptr(lat), ptr(lon), ptr(corner), ptr(cmask), fd.height, fd.width, ptr(red))
+        return to_host(red)
 
     def _finalize_fused(self, res, pxPerDeg, keep_on_device):
         """Crop the superset accumulators to the exact grid laid out by amt_pipe_wait."""
@@ -226,7 +245,8 @@ class FramePipeline(object):
             pxPerDeg = (pxPerDeg, pxPerDeg)
         fd = self.fd
         Context.current(self.ctx.device)
-        if not magnetic and self._fused is not None and self._fused['pxPerDeg'] == tuple(pxPerDeg):
+        if self._fused is not None and self._fused['pxPerDeg'] == tuple(pxPerDeg) and \
+                self._fused['magnetic'] == bool(magnetic):
             res = self._wait_fused()
             if res.status == 0 and not containsPole:       # status 0: neither pole nor discontinuity in the frame
                 self.last_plan = 'single-pass'
@@ -236,15 +256,9 @@ class FramePipeline(object):
             sm = fd.shallow_copy()
             sm.lat, sm.lat_c = fd.mlat, fd.mlat_c
             sm.lon, sm.lon_c = (fd.mlt - 12) / (24 / 360), (fd.mlt_c - 12) / (24 / 360)
-            red = self.ctx.empty((8,))
             # corners of centres that pass the elevation threshold, in SM coordinates
-            import torch
-            cmask = (~(fd.elev >= (NEG_INF if self.min_elevation is None else self.min_elevation))).to(torch.uint8)
-            corner = torch.isnan(fd.lat).to(torch.uint8)
-            self.ctx.call('amt_sanitize_masks', ptr(corner), ptr(cmask), None, fd.height, fd.width, 1)
-            self.ctx.call('amt_bbox_corners', ptr(sm.lat), ptr(sm.lon), ptr(corner), ptr(cmask), fd.height, fd.width,
-                          ptr(red))
-            bb = bounding_box_from_reduction(to_host(red))
+            red = self._reduce_bbox(sm.lat, sm.lon)
+            bb = bounding_box_from_reduction(red)
             fd = sm
         else:
             bb = self.bounding_box()
@@ -263,7 +277,7 @@ class FramePipeline(object):
         except TypeError:
             pxPerDeg = (pxPerDeg, pxPerDeg)
         self.georef(wcsHeader, altitude, cameraPosGCRS, photoTime, fast, min_elevation, params=params,
-                    fuse_pxPerDeg=pxPerDeg if (fuse and not magnetic) else None)
+                    fuse_pxPerDeg=pxPerDeg if fuse else None, fuse_magnetic=bool(magnetic))
         return self.resample(pxPerDeg, containsPole, magnetic, keep_on_device=keep_on_device)
 
     def host_arrays(self):
@@ -285,7 +299,8 @@ class SequencePipeline(object):
     """
 
     def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, altitude=110, fast=True,
-                 min_elevation=10.0, pxPerDeg=10, plan='single-pass', bin_stream=True, shared_image=None):
+                 min_elevation=10.0, pxPerDeg=10, plan='single-pass', bin_stream=True, shared_image=None,
+                 magnetic=False):
         import torch
         assert plan in ('single-pass', 'two-pass')
         try:
@@ -295,7 +310,8 @@ class SequencePipeline(object):
         self.pxPerDeg = tuple(pxPerDeg)
         self.altitude, self.fast, self.min_elevation = altitude, fast, min_elevation
         self.single_pass = plan == 'single-pass' and nchan == 3
-        self.pipes = [FramePipeline(width, height, nchan, img_dtype, device), FramePipeline(width, height, nchan, img_dtype, device)]
+        self.magnetic = bool(magnetic)          # grids in (MLat, SM longitude): resampleMLatMLT
+        self.pipes = [FramePipeline(width, height, nchan, img_dtype, device, with_mag=self.magnetic) for _ in range(2)]
         self.ctx = self.pipes[0].ctx
         if shared_image is not None:
             # every frame shows the same image (synthetic benchmarks): upload it once, both buffers alias it
@@ -313,9 +329,11 @@ class SequencePipeline(object):
 
     def _prepare(self, k, frame):
         hdr, cam, t, img = frame
-        p = hdr if not isinstance(hdr, dict) else frame_params(hdr, self.altitude, cam, t, self.fast, magnetic=False)
+        p = hdr if not isinstance(hdr, dict) else frame_params(hdr, self.altitude, cam, t, self.fast,
+                                                               magnetic=self.magnetic)
         if self.single_pass:
-            self.pipes[k % 2].start_coarse(p, self.min_elevation)     # tiny kernel on the driver's own stream
+            # tiny kernel on the driver's own stream
+            self.pipes[k % 2].start_coarse(p, self.min_elevation, self.magnetic)
         return p, cam, t, img
 
     def _launch(self, k, prepared):
@@ -329,7 +347,8 @@ class SequencePipeline(object):
             if img is not None:
                 q.set_image(img)
             q.georef(None, self.altitude, cam, t, self.fast, self.min_elevation, params=p,
-                     fuse_pxPerDeg=self.pxPerDeg if self.single_pass else None, coarse_started=True)
+                     fuse_pxPerDeg=self.pxPerDeg if self.single_pass else None, coarse_started=self.single_pass,
+                     fuse_magnetic=self.magnetic)
             if two_streams:
                 self._geo_done[k % 2].record(self.s_main)
 
@@ -340,7 +359,7 @@ class SequencePipeline(object):
         with torch.cuda.stream(self.s_bin):
             if two_streams:
                 self.s_bin.wait_event(self._geo_done[k % 2])
-            res = q.resample(self.pxPerDeg, keep_on_device=keep_on_device)
+            res = q.resample(self.pxPerDeg, magnetic=self.magnetic, keep_on_device=keep_on_device)
             if two_streams:
                 self._bin_done[k % 2] = torch.cuda.Event()
                 self._bin_done[k % 2].record(self.s_bin)

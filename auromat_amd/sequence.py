@@ -125,27 +125,18 @@ def run_sequence(frames, width, height, altitude=110, fast=True, min_elevation=1
     process group (single GPU).
     """
     import torch.distributed as dist
-    from .pipeline import FramePipeline, SequencePipeline
+    from .pipeline import SequencePipeline
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
     world = dist.get_world_size() if distributed else 1
     mine = shard(len(frames), rank, world)
-    if magnetic:
-        # MLat/MLT grids: one frame at a time through the two-pass plan
-        pipe = FramePipeline(width, height, device=device, with_mag=True)
-        results = []
-        for k in mine:
-            hdr, cam, t, img = frames[k]
-            results.append(pipe.run(hdr, altitude, cam, t, img=img, fast=fast, min_elevation=min_elevation,
-                                    pxPerDeg=pxPerDeg, magnetic=True, keep_on_device=True))
-        dev = pipe.ctx.device
-    else:
-        first = frames[mine[0]][3] if len(mine) else None
-        seq = SequencePipeline(width, height, nchan=first.shape[2] if first is not None else 3,
-                               img_dtype=first.dtype if first is not None else np.uint16, device=device,
-                               altitude=altitude, fast=fast, min_elevation=min_elevation, pxPerDeg=pxPerDeg)
-        results = seq.process([frames[k] for k in mine])
-        dev = seq.ctx.device
+    first = frames[mine[0]][3] if len(mine) else None
+    seq = SequencePipeline(width, height, nchan=first.shape[2] if first is not None else 3,
+                           img_dtype=first.dtype if first is not None else np.uint16, device=device,
+                           altitude=altitude, fast=fast, min_elevation=min_elevation, pxPerDeg=pxPerDeg,
+                           magnetic=magnetic)
+    results = seq.process([frames[k] for k in mine])
+    dev = seq.ctx.device
     if not distributed or not gather:
         descs, payload = pack_results(results, mine, dev)
         return unpack_results(descs, payload)

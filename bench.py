@@ -35,6 +35,7 @@ def algorithmic_bytes(width, height, nchan=3, pix_bytes=2):
     """SURVEY.md §8d contract figures (f64 coordinates)."""
     nc, npx = (width + 1) * (height + 1), width * height
     return dict(image=nchan * pix_bytes * npx,
+                mag=16 * nc + 16 * npx,                  # mlat, mlt corners + mlat_c, mlt_c centres written
                 georef=16 * nc + 24 * npx,              # WCS-fused: lat, lon corners + latC, lonC, elev written
                 georef_dirs_in=40 * nc + 24 * npx,      # + 24 B/corner direction read (contract row "directions-in")
                 resample=(24 + nchan * pix_bytes) * npx)
@@ -73,6 +74,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--cpu-rows', type=int, default=2832, help='rows of the frame the CPU baseline processes (0 = skip)')
     ap.add_argument('--exact', action='store_true', help='exact centre rays instead of fast centres')
+    ap.add_argument('--magnetic', action='store_true',
+                    help='configs[3] instead of configs[2]: MLat/MLT outputs and the (MLat, SM longitude) grid of '
+                         'resampleMLatMLT; the three altitude shells 100/110/120 km alternate frame by frame')
     ap.add_argument('--plan', default='fused', choices=('fused', 'two-pass'),
                     help='fused: binning inside the georeferencing kernel (superset grid + crop); '
                          'two-pass: separate binning kernel that re-reads the centre arrays')
@@ -103,11 +107,18 @@ def main():
     fused = args.plan == 'fused'
     seq = SequencePipeline(WIDTH, HEIGHT, altitude=ALTITUDE, fast=fast, min_elevation=MIN_ELEV, pxPerDeg=PPD,
                            plan='single-pass' if fused else 'two-pass', bin_stream=args.streams == 2,
-                           shared_image=frame_image(WIDTH, HEIGHT, seed=rank))     # resident before the timed region
+                           shared_image=frame_image(WIDTH, HEIGHT, seed=rank),     # resident before the timed region
+                           magnetic=args.magnetic)
     ctx = seq.ctx
     # the synthetic sequence (what a reader would hand over: WCS cards, camera position, time) exists before the
     # timed region, like the image; everything derived from it (matrices, grids) is computed inside
     frames = [sequence_frame(rank * total + k, WIDTH, HEIGHT)[:3] + (None,) for k in range(total)]
+    if args.magnetic:
+        # per-frame shells: the matrices are made here (outside the timed region only in this variant, because the
+        # sequence loop takes one altitude); 100 / 110 / 120 km alternate
+        from auromat_amd.mapping.astrometry import frame_params
+        frames = [(frame_params(h, (100, 110, 120)[k % 3], c, t, fast, magnetic=True), c, t, None)
+                  for k, (h, c, t, _) in enumerate(frames)]
 
     seq.process(frames[:args.warmup])
     ctx.timing_enable(TIMING_EVERY)
@@ -167,6 +178,9 @@ def main():
         else:
             kname, tkey = 'k_georef_rows (amt_georef_frame)', 'k_georef_rows'
             kbytes = ab['georef']
+        if args.magnetic:
+            kbytes += ab['mag']
+            tkey += '_mag'               # no PMC pass of this variant under profiles/ yet: traffic = null
         achieved = kbytes / (georef_ms * 1e-3) / 1e9
         out = {
             'metric': 'Mpixels/s georef+resample, 4240x2832 frame',
@@ -176,10 +190,13 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'configs[2]: 4240x2832 ISS-like frame, WCS ray cast + WGS84(+110 km) '
-                                   'intersection + geodetic transform + elevation (%s centres), '
-                                   'maskedByElevation(10), mean-resample to 0.1 deg plate-carree, uint16 RGB'
-                                   % ('fast' if fast else 'exact'),
+            'config': {'workload': ('configs[3]: as configs[2] on shells 100/110/120 km + MLat/MLT of corners and centres, '
+                                    'mean-resample on the 0.1 deg (MLat, SM longitude) grid (resampleMLatMLT)'
+                                    if args.magnetic else
+                                    'configs[2]: 4240x2832 ISS-like frame, WCS ray cast + WGS84(+110 km) '
+                                    'intersection + geodetic transform + elevation (%s centres), '
+                                    'maskedByElevation(10), mean-resample to 0.1 deg plate-carree, uint16 RGB'
+                                    % ('fast' if fast else 'exact')),
                        'frame': [WIDTH, HEIGHT], 'px_per_deg': PPD, 'grid': list(res['mean'].shape),
                        'plan': args.plan,
                        'single_pass_frames': sum(1 for q in plans if q == 'single-pass'),

@@ -136,7 +136,7 @@ typedef struct amt_georef_out {
     uint64_t* bin_acc;
     int32_t bin_img_dtype;
     int32_t bin_lon_wrap;
-    int32_t bin_magnetic;
+    int32_t bin_magnetic;          /* != 0: x = SM longitude (mltToSmLon(mlt)), y = MLat; bbox[0..6] then refer to these too */
     /* Scheduling hint, no effect on results: order in which the frame's work items (strips of 63 columns x 16
      * rows, row-major) are dispatched.  1 = rows top to bottom, 2 = bottom to top; 0 = automatic: bottom to top
      * when the nadir lies below the frame centre (camera model; top to bottom for caller-supplied directions).
@@ -329,8 +329,8 @@ int amt_grid_layout(double lat_px_per_deg, double lon_px_per_deg, double lat_min
                     double lon_min, double lon_max, amt_grid* out);
 
 /* Single-pass driver: georeference + mask by elevation + bounding box + grid + binned mean of one frame with
- * the binning fused into the georeferencing kernel (see amt_georef_out.bin_*), for geodetic grids that contain
- * neither a pole nor the 180 deg discontinuity.  Separate calls per stage so that frames can be software
+ * the binning fused into the georeferencing kernel (see amt_georef_out.bin_*), for geodetic or MLat/MLT grids that
+ * contain neither a pole nor the 180 deg discontinuity.  Separate calls per stage so that frames can be software
  * pipelined by one host thread:
  *   amt_pipe_coarse   enqueue the coarse bounding-box pre-pass (own high-priority stream), any time earlier
  *   amt_pipe_launch   wait for it, lay out the superset grid, zero the accumulators, launch the fused kernel
@@ -349,14 +349,16 @@ typedef struct amt_pipe_result {
 } amt_pipe_result;
 int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe);
 int amt_pipe_destroy(amt_pipe* pipe);
-int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation);
+int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation, int magnetic);
 /* out: arrays to write (lat .. mlt_c as in amt_georef_frame; bbox / bin_* fields are managed by the driver).
  * img: (height, width, 3) uint8 (img_dtype 1) or uint16 (2).  min_elevation: -inf disables the mask.
  * pole_in_view: 0 / 1 = the caller's decision, < 0 = decide from the camera model (is a pole of the mapping
- * shell imaged by a valid pixel; replaces geodesic.py:183 / mapping.py:705-721 for camera mappings). */
+ * shell imaged by a valid pixel; replaces geodesic.py:183 / mapping.py:705-721 for camera mappings).
+ * magnetic != 0 (same value as given to amt_pipe_coarse): grid, bounding box and pole refer to (MLat, SM
+ * longitude), i.e. resampleMLatMLT (resample.py:63-71, mapping.py:1519-1547); p->m_sm must be set. */
 int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
                     int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
-                    int pole_in_view);
+                    int pole_in_view, int magnetic);
 int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result);
 /* mean (ny,nx,4) f64, out_img (ny,nx,3) of img_dtype, out_mask (ny,nx) u8, out_count (ny,nx) f64: device
  * buffers for result->grid of the preceding amt_pipe_wait (any may be NULL).  The kernel runs on the driver's

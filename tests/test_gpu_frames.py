@@ -423,3 +423,33 @@ def test_config4_mlat_mlt_three_shells_full_size(altitude):
         m = ArraySpacecraftMapping(hdr, altitude, img, cam, t, 'c4', fastCenterCalculation=True).maskedByElevation(10)
         r = resampleMLatMLT(m, pxPerDeg=10)
         assert np.array_equal(r.img.data, res['img']) and np.array_equal(ma.getmaskarray(r.img)[..., 0], res['mask'])
+
+
+@pytest.mark.parametrize('width,height,pointing,altitude', [(256, 170, 'iss030', 110), (253, 171, 'iss029', 110),
+                                                             (4240, 2832, 'iss030', 100), (4240, 2832, 'iss030', 120)])
+def test_single_pass_magnetic_equals_two_pass(width, height, pointing, altitude):
+    """resampleMLatMLT through the frame driver (MLat / SM-longitude grid fused into the kernel) == two-pass plan."""
+    from auromat_amd.pipeline import FramePipeline, SequencePipeline
+    from auromat_amd.synthetic import frame_header, frame_image
+    hdr, cam, t = frame_header(width, height, pointing)
+    img = frame_image(width, height, seed=21)
+    pipe = FramePipeline(width, height, with_mag=True)
+    two = pipe.run(hdr, altitude, cam, t, img=img, min_elevation=10, pxPerDeg=10, magnetic=True, fuse=False)
+    arrays_two = pipe.host_arrays()
+    one = pipe.run(hdr, altitude, cam, t, min_elevation=10, pxPerDeg=10, magnetic=True, fuse=True)
+    if pointing == 'iss030':
+        assert pipe.last_plan == 'single-pass'
+    for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon', 'lat_c', 'lon_c'):
+        assert np.array_equal(one[k], two[k], equal_nan=True), k
+    for k, v in pipe.host_arrays().items():
+        assert np.array_equal(v, arrays_two[k], equal_nan=True), k
+    # the geodetic box is still available after a magnetic single-pass launch, and equals the geodetic plan's
+    geo = FramePipeline(width, height)
+    geo.run(hdr, altitude, cam, t, img=img, min_elevation=10, pxPerDeg=10, fuse=True)
+    a, b = pipe.bounding_box(), geo.bounding_box()
+    assert (a.latSouth, a.lonWest, a.latNorth, a.lonEast) == (b.latSouth, b.lonWest, b.latNorth, b.lonEast)
+    if width < 1000:
+        seq = SequencePipeline(width, height, altitude=altitude, pxPerDeg=10, magnetic=True)
+        out = seq.process([(hdr, cam, t, img)] * 3, keep_on_device=False)
+        for r in out:
+            assert np.array_equal(r['mean'], two['mean'], equal_nan=True) and np.array_equal(r['count'], two['count'])
