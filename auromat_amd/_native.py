@@ -49,7 +49,8 @@ class Grid(C.Structure):
 
 class PipeResult(C.Structure):
     """amt_pipe_result"""
-    _fields_ = [('status', C.c_int32), ('fused', C.c_int32), ('bbox', C.c_double * 8), ('grid', Grid)]
+    _fields_ = [('status', C.c_int32), ('fused', C.c_int32), ('lon_wrapped', C.c_int32), ('reserved', C.c_int32),
+                ('bbox', C.c_double * 8), ('grid', Grid)]
 
 
 _I, _L, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p

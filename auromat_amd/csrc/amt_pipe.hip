@@ -25,6 +25,7 @@ struct amt_pipe {
     // state of the frame in flight
     bool coarse_pending, launched, fused, ready, tail_pending;
     int coarse_magnetic;           // coordinates of the pending coarse box (0 geodetic, 1 MLat / SM longitude)
+    int lon_wrap;                  // the frame straddles the 180 deg discontinuity: longitudes are binned shifted by 180
     amt_grid super, exact;
     int32_t off_x, off_y;          // window of the exact grid inside the superset
     double lat_ppd, lon_ppd, min_elev;
@@ -67,6 +68,16 @@ int ensure_partials(amt_pipe* pipe, size_t bytes) {
     AMT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&pipe->partials), bytes));
     pipe->partials_bytes = bytes;
     return AMT_OK;
+}
+
+// astropy Angle.wrap_at(180 deg), as auromat_amd/mapping/mapping.py wrap_at_180 computes it (reference
+// resample.py:212-218): into [-180, 180)
+double wrap_at_180(double v) {
+    const double wraps = std::floor((v + 180.0) / 360.0);
+    double a = v - wraps * 360.0;
+    if (a >= 180.0) a -= 360.0;
+    if (a < -180.0) a += 360.0;
+    return a;
 }
 
 // Is the north or south pole of the mapping shell imaged by a valid pixel?  The pole point is projected
@@ -261,13 +272,26 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
         o.item_order = (ax | ay) == 0 ? 0 : ((ay >= ax && sy > 0) ? 2 : 1);
     }
 
-    const double* c = pipe->host_small;     // coarse [lat_min, lat_max, lon_min, lon_max, ..., n]
-    bool fuse = c[6] > 0 && !(c[3] - c[2] > 180) && !pipe->pole;
+    // coarse [lat_min, lat_max, lon_min, lon_max, lon_min_positive, lon_max_nonpositive, n, hint]
+    const double* c = pipe->host_small;
+    bool fuse = c[6] > 0 && !pipe->pole;
+    pipe->lon_wrap = 0;
+    double box_lo = c[2], box_hi = c[3];
+    if (fuse && c[3] - c[2] > 180) {
+        // the box straddles the 180 deg discontinuity (mappings are narrower than 180 deg, mapping.py:722-737):
+        // west = smallest positive, east = largest non-positive longitude; bin longitudes shifted by 180 deg
+        // (reference resample.py:203-218)
+        fuse = std::isfinite(c[4]) && std::isfinite(c[5]);
+        box_lo = wrap_at_180(c[4] + 180.0);
+        box_hi = wrap_at_180(c[5] + 180.0);
+        pipe->lon_wrap = 1;
+        fuse = fuse && box_hi > box_lo;
+    }
     if (fuse) {
         const double lat_abs = std::fmax(std::fabs(c[0]), std::fabs(c[1]));
         const double lon_margin = std::fmin(10.0, kMarginDeg / std::fmax(0.1, std::cos(lat_abs * amt::kDeg2Rad)));
         const double lat_lo = std::fmax(-89.0, c[0] - kMarginDeg), lat_hi = std::fmin(89.0, c[1] + kMarginDeg);
-        const double lon_lo = c[2] - lon_margin, lon_hi = c[3] + lon_margin;
+        const double lon_lo = box_lo - lon_margin, lon_hi = box_hi + lon_margin;
         fuse = lon_lo > -179.0 && lon_hi < 179.0 &&
                amt_gl::layout(lat_px_per_deg, lon_px_per_deg, lat_lo, lat_hi, lon_lo, lon_hi, &pipe->super);
     }
@@ -285,6 +309,7 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
         o.bin_img_dtype = img_dtype;
         o.bin_acc = pipe->acc;
         o.bin_magnetic = magnetic;
+        o.bin_lon_wrap = pipe->lon_wrap;
         pipe->fused = true;
         pipe->acc_zero = false;
     }
@@ -319,9 +344,18 @@ int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result) {
         return AMT_OK;
     }
     result->status = 1;
-    if (!pipe->fused || pipe->pole || b[3] - b[2] > 180) return AMT_OK;
+    if (!pipe->fused || pipe->pole) return AMT_OK;
+    const bool straddles = b[3] - b[2] > 180;
+    if (straddles != (pipe->lon_wrap != 0)) return AMT_OK;      // the coarse pass judged the discontinuity differently
+    double lon_lo = b[2], lon_hi = b[3];
+    if (straddles) {
+        if (!(std::isfinite(b[4]) && std::isfinite(b[5]))) return AMT_OK;
+        lon_lo = wrap_at_180(b[4] + 180.0);
+        lon_hi = wrap_at_180(b[5] + 180.0);
+    }
+    result->lon_wrapped = straddles ? 1 : 0;
     amt_grid& g = result->grid;
-    if (!amt_gl::layout(pipe->lat_ppd, pipe->lon_ppd, b[0], b[1], b[2], b[3], &g)) return AMT_OK;
+    if (!amt_gl::layout(pipe->lat_ppd, pipe->lon_ppd, b[0], b[1], lon_lo, lon_hi, &g)) return AMT_OK;
     const amt_grid& s = pipe->super;
     // window of the exact grid inside the superset (same global nodes => integer offsets)
     const long off_x = std::lround((g.lon_center_first - s.lon_center_first) / s.lon_step);

@@ -29,7 +29,7 @@ import numpy as np
 
 from .frame import FrameData
 from .mapping.astrometry import frame_params, pole_in_view
-from .mapping.mapping import bounding_box_from_reduction
+from .mapping.mapping import bounding_box_from_reduction, wrap_at_180
 from .resample import cached_grid, grid_coordinates, resample_frame
 from ._native import Context, GeorefOut, PipeResult, ptr, to_host
 
@@ -219,7 +219,13 @@ class FramePipeline(object):
         ctx, fd = self.ctx, self.fd
         g = res.grid
         b = res.bbox
-        grid = _GridView(g, pxPerDeg, (b[0], b[1], b[2], b[3]))
+        wrapped = bool(res.lon_wrapped)
+        if wrapped:
+            # straddles the 180 deg discontinuity: the grid is laid out for longitudes shifted by 180 deg
+            box = (b[0], b[1], wrap_at_180(b[4] + 180), wrap_at_180(b[5] + 180))
+        else:
+            box = (b[0], b[1], b[2], b[3])
+        grid = _GridView(g, pxPerDeg, box)
         mean = ctx.empty((g.ny, g.nx, 4))
         img = ctx.empty((g.ny, g.nx, 3), torch.uint8 if fd.img_dtype_code != 2 else torch.int16)
         mask = ctx.empty((g.ny, g.nx), torch.uint8)
@@ -227,7 +233,7 @@ class FramePipeline(object):
         self._pcall('amt_pipe_finalize', ptr(mean), ptr(img), ptr(mask), ptr(count))
         if not (keep_on_device and self.defer_join):
             self.join()
-        out = dict(has_elev=True, grid=grid, contains_pole=False, contains_discontinuity=False,
+        out = dict(has_elev=True, grid=grid, contains_pole=False, contains_discontinuity=wrapped,
                    altitude=self.altitude)
         if keep_on_device:
             out.update(mean=mean, img=img, mask=mask, count=count)

@@ -330,7 +330,7 @@ int amt_grid_layout(double lat_px_per_deg, double lon_px_per_deg, double lat_min
 
 /* Single-pass driver: georeference + mask by elevation + bounding box + grid + binned mean of one frame with
  * the binning fused into the georeferencing kernel (see amt_georef_out.bin_*), for geodetic or MLat/MLT grids that
- * contain neither a pole nor the 180 deg discontinuity.  Separate calls per stage so that frames can be software
+ * do not contain a pole (frames that straddle the 180 deg discontinuity are binned with shifted longitudes).  Separate calls per stage so that frames can be software
  * pipelined by one host thread:
  *   amt_pipe_coarse   enqueue the coarse bounding-box pre-pass (own high-priority stream), any time earlier
  *   amt_pipe_launch   wait for it, lay out the superset grid, zero the accumulators, launch the fused kernel
@@ -338,12 +338,16 @@ int amt_grid_layout(double lat_px_per_deg, double lon_px_per_deg, double lat_min
  *   amt_pipe_wait     wait for the exact box (the only host synchronisation), lay out the exact grid
  *   amt_pipe_finalize crop + finalise into arrays the caller sized from the grid amt_pipe_wait returned
  * status in amt_pipe_result: 0 = ready to finalise; 1 = this frame needs the general path (pole in view,
- * discontinuity, exact box outside the superset) — the coordinate arrays and bbox are valid, nothing else;
+ * exact box outside the superset) — the coordinate arrays and bbox are valid, nothing else;
  * 2 = no pixel above the elevation threshold (mapping.py:858-859 -> ValueError). */
 typedef struct amt_pipe amt_pipe;
 typedef struct amt_pipe_result {
     int32_t status;
     int32_t fused;          /* 1 when the fused kernel was launched for this frame */
+    int32_t lon_wrapped;    /* 1: the frame straddles the 180 deg discontinuity; `grid` is laid out for longitudes
+                             * shifted by 180 deg (wrap_at_180(lon + 180)) and the caller shifts the output
+                             * coordinates back (reference resample.py:203-218,274-277) */
+    int32_t reserved;
     double bbox[8];         /* exact reduction of amt_georef_frame; [7] = 1 when a pole is in view */
     amt_grid grid;          /* exact output grid (valid for status 0) */
 } amt_pipe_result;

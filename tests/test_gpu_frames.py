@@ -437,8 +437,7 @@ def test_single_pass_magnetic_equals_two_pass(width, height, pointing, altitude)
     two = pipe.run(hdr, altitude, cam, t, img=img, min_elevation=10, pxPerDeg=10, magnetic=True, fuse=False)
     arrays_two = pipe.host_arrays()
     one = pipe.run(hdr, altitude, cam, t, min_elevation=10, pxPerDeg=10, magnetic=True, fuse=True)
-    if pointing == 'iss030':
-        assert pipe.last_plan == 'single-pass'
+    assert pipe.last_plan == 'single-pass'        # the southern frame straddles SM longitude 180: shifted binning
     for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon', 'lat_c', 'lon_c'):
         assert np.array_equal(one[k], two[k], equal_nan=True), k
     for k, v in pipe.host_arrays().items():
@@ -453,3 +452,23 @@ def test_single_pass_magnetic_equals_two_pass(width, height, pointing, altitude)
         out = seq.process([(hdr, cam, t, img)] * 3, keep_on_device=False)
         for r in out:
             assert np.array_equal(r['mean'], two['mean'], equal_nan=True) and np.array_equal(r['count'], two['count'])
+
+
+@pytest.mark.parametrize('width,height', [(253, 171), (4240, 2832)])
+def test_single_pass_plan_across_the_dateline(width, height):
+    """A frame that straddles the 180 deg discontinuity is binned with shifted longitudes (resample.py:203-218)."""
+    from datetime import timedelta
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_header, frame_image
+    hdr, cam, t = frame_header(width, height, 'iss029')        # longitudes 142 .. 168 E at the fixture's time
+    t = t - timedelta(minutes=80)                               # same inertial geometry, the Earth 20 deg further west
+    img = frame_image(width, height, seed=31)
+    pipe = FramePipeline(width, height)
+    two = pipe.run(hdr, 110, cam, t, img=img, min_elevation=10, pxPerDeg=10, fuse=False)
+    bb = pipe.bounding_box()
+    assert bb.containsDiscontinuity and not bb.containsPole and two['contains_discontinuity']
+    one = pipe.run(hdr, 110, cam, t, min_elevation=10, pxPerDeg=10, fuse=True)
+    assert pipe.last_plan == 'single-pass' and one['contains_discontinuity']
+    for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon', 'lat_c', 'lon_c'):
+        assert np.array_equal(one[k], two[k], equal_nan=True), k
+    assert one['lon_c'].min() < -170 and one['lon_c'].max() > 170

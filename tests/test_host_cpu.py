@@ -45,7 +45,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(GeorefOut) == 8 * 11 + 8 * 4 + 4 * 4
     assert C.sizeof(Axis) == 8 + 8 + 8 * 5
     assert C.sizeof(Grid) == 16 + 8 * 10 + 2 * C.sizeof(Axis)
-    assert C.sizeof(PipeResult) == 8 + 8 * 8 + C.sizeof(Grid)
+    assert C.sizeof(PipeResult) == 16 + 8 * 8 + C.sizeof(Grid)
 
 
 def test_no_cpu_fallback(lib):
