@@ -317,3 +317,73 @@ def test_mlat_mlt_resample_vs_reference(native):
         with np.errstate(invalid='ignore'):
             ref_img = np.round(want[..., :3]).astype(np.int64)
         assert (np.abs(r.img.data.astype(np.int64) - ref_img)[both].max(axis=-1) > 0).sum() <= 3
+
+
+def test_c_abi_error_behaviour(native):
+    """Status codes instead of exceptions or crashes: bad arguments are rejected on the host before any launch."""
+    import ctypes as C
+    import torch
+    from auromat_amd._native import Axis, Context, FrameParams, GeorefOut, Grid, NativeError, PipeResult, ptr
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.synthetic import frame_header
+    ctx = Context.current()
+    lib = ctx._lib
+    hdr, cam, t = frame_header(64, 48)
+    p = frame_params(hdr, 110, cam, t, True)
+    out = GeorefOut()
+    lat = ctx.empty((49, 65))
+    out.lat = out.lon = lat.data_ptr()
+    # NULL context / NULL arguments
+    assert lib.amt_georef_frame(None, C.byref(p), C.byref(out)) < 0
+    assert lib.amt_georef_frame(ctx.handle, None, C.byref(out)) < 0
+    assert b'NULL' in lib.amt_last_error(ctx.handle)
+    # mlat without mlt, empty frame, non-positive ellipsoid
+    out.mlat = lat.data_ptr()
+    with pytest.raises(NativeError, match='mlat and mlt'):
+        ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
+    out.mlat = None
+    bad = frame_params(hdr, 110, cam, t, True)
+    bad.width = 0
+    with pytest.raises(NativeError, match='empty frame'):
+        ctx.call('amt_georef_frame', C.byref(bad), C.byref(out))
+    bad = frame_params(hdr, 110, cam, t, True)
+    bad.a0 = -1.0
+    with pytest.raises(NativeError, match='ellipsoid'):
+        ctx.call('amt_georef_frame', C.byref(bad), C.byref(out))
+    # fused binning needs uniform axes and a uint8 / uint16 image
+    ax = Axis()
+    ax.nbin, ax.uniform, ax.first, ax.last, ax.step = 4, 0, 0.0, 4.0, 1.0
+    acc = ctx.zeros((5, 16), torch.int64)
+    out.bin_xaxis = out.bin_yaxis = C.addressof(ax)
+    out.bin_acc, out.bin_img, out.bin_img_dtype = acc.data_ptr(), lat.data_ptr(), 2
+    with pytest.raises(NativeError, match='uniform'):
+        ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
+    ax.uniform = 1
+    out.bin_img_dtype = 7
+    with pytest.raises(NativeError, match='uint8'):
+        ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
+    # finalize window outside the accumulator grid; too many histogram weights; bad timing selector
+    with pytest.raises(NativeError, match='window'):
+        ctx.call('amt_bin_frame_finalize_window', ptr(acc), 4, 4, 3, 0, 2, 2, 3, 2, None, None, None, None)
+    assert lib.amt_timing_read(ctx.handle, 5, C.byref(C.c_double()), C.byref(C.c_int())) < 0
+    # grid layout: no output cell, non-positive resolution (host only)
+    g = Grid()
+    assert lib.amt_grid_layout(10.0, 10.0, 10.01, 10.02, 20.01, 20.02, C.byref(g)) < 0
+    assert lib.amt_grid_layout(0.0, 10.0, 10.0, 20.0, 20.0, 40.0, C.byref(g)) < 0
+    assert lib.amt_grid_layout(10.0, 10.0, 10.0, 20.0, 20.0, 40.0, None) < 0
+    # frame driver: stages out of order, NULL handles
+    pipe = C.c_void_p()
+    ctx.call('amt_pipe_create', C.byref(pipe))
+    res = PipeResult()
+    assert lib.amt_pipe_wait(pipe, C.byref(res)) < 0           # nothing launched
+    assert lib.amt_pipe_finalize(pipe, None, None, None, None) < 0
+    assert lib.amt_pipe_wait(None, C.byref(res)) < 0 and lib.amt_pipe_join(None) < 0
+    assert lib.amt_pipe_launch(pipe, C.byref(p), C.byref(out), None, 2, 10.0, 10.0, 10.0, -1, 0) < 0   # no image
+    assert lib.amt_pipe_destroy(pipe) == 0
+    ctx.synchronize()
+    # the context still works after all of that
+    good = GeorefOut()
+    good.lat = good.lon = lat.data_ptr()
+    ctx.call('amt_georef_frame', C.byref(p), C.byref(good))
+    ctx.synchronize()
+    assert torch.isfinite(lat).any()
