@@ -437,7 +437,7 @@ int amt_bin_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const 
     } while (0)
     const bool u8 = img_dtype == 1;
     hipEvent_t t0, t1;
-    amt_timing_pair(ctx, AMT_KERNEL_BIN, &t0, &t1);
+    amt_timing_pair(ctx, AMT_KERNEL_BIN, 1, &t0, &t1);
     switch (nchan) {
         case 0: AMT_BIN_CASE(uint8_t, 0); break;
         case 1: if (u8) AMT_BIN_CASE(uint8_t, 1); else AMT_BIN_CASE(uint16_t, 1); break;

@@ -24,6 +24,7 @@ struct amt_ctx {
     // optional per-kernel timing (amt_timing_*): event pairs recorded around the dominant kernels
     int timing;                       // 0 = off, n = bracket every n-th launch of each kind
     size_t tlaunch[2];                // launches seen per kind since timing was enabled
+    int tframes[2];                   // frames covered by the timed launches
     std::vector<hipEvent_t> tev[2];   // [kernel kind] start0, stop0, start1, stop1, ...
     size_t tused[2];
 };
@@ -33,7 +34,7 @@ constexpr int kTimingMaxLaunches = 4096;
 // Event pair for the next launch of kernel kind `kind` (0 georef, 1 bin) when that launch is to be timed,
 // else two NULLs.  The events are attached to the dispatch itself (hipExtLaunchKernelGGL start/stop events),
 // so timing puts no extra packet on the stream; they are created lazily and reused.
-static inline void amt_timing_pair(amt_ctx* ctx, int kind, hipEvent_t* start, hipEvent_t* stop) {
+static inline void amt_timing_pair(amt_ctx* ctx, int kind, int frames, hipEvent_t* start, hipEvent_t* stop) {
     *start = *stop = nullptr;
     if (!ctx->timing) return;
     if ((ctx->tlaunch[kind]++ % (size_t)ctx->timing) != 0) return;
@@ -46,6 +47,7 @@ static inline void amt_timing_pair(amt_ctx* ctx, int kind, hipEvent_t* start, hi
     *start = ctx->tev[kind][ctx->tused[kind]];
     *stop = ctx->tev[kind][ctx->tused[kind] + 1];
     ctx->tused[kind] += 2;
+    ctx->tframes[kind] += frames;      // a launch can cover several frames (amt_pipe_launch_many)
 }
 
 // ---- internal interfaces between translation units (not part of the C ABI) ---------------------------
@@ -60,6 +62,10 @@ struct amt_georef_tail {
 size_t amt_georef_partials_bytes(const amt_frame_params* p);
 int amt_georef_launch(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, const amt_georef_out* out,
                       const amt_georef_tail* tail);
+// n <= AMT_MAX_BATCH equally sized frames in ONE launch of the big kernel (falls back to n launches otherwise)
+#define AMT_MAX_BATCH 2
+int amt_georef_launch_many(amt_ctx* ctx, int n, const amt_frame_params* const* p, const amt_georef_out* const* out,
+                           const amt_georef_tail* const* tail);
 // amt_bin_frame_finalize_window on `stream`; clear != 0 also zeroes every cell of the accumulator grid.
 int amt_bin_finalize_on(amt_ctx* ctx, hipStream_t stream, uint64_t* acc, int32_t acc_nx, int32_t acc_ny, int32_t off_x,
                         int32_t off_y, int32_t nx, int32_t ny, int32_t nchan, int32_t img_dtype, double* mean,

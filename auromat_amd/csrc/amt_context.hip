@@ -20,6 +20,7 @@ int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ct
     ctx->ws_bytes = 0;
     ctx->timing = 0;
     ctx->tlaunch[0] = ctx->tlaunch[1] = 0;
+    ctx->tframes[0] = ctx->tframes[1] = 0;
     ctx->tused[0] = ctx->tused[1] = 0;
     if (hipSetDevice(device_id) != hipSuccess) {
         delete ctx;
@@ -172,6 +173,7 @@ int amt_timing_enable(amt_ctx* ctx, int enable) {
     ctx->timing = enable > 0 ? enable : 0;
     ctx->tused[0] = ctx->tused[1] = 0;
     ctx->tlaunch[0] = ctx->tlaunch[1] = 0;
+    ctx->tframes[0] = ctx->tframes[1] = 0;
     return AMT_OK;
 }
 
@@ -187,7 +189,7 @@ int amt_timing_read(amt_ctx* ctx, int kernel, double* total_ms, int* launches) {
         sum += ms;
     }
     *total_ms = sum;
-    *launches = (int)n;
+    *launches = ctx->tframes[kernel];     // frames: a launch of the frame driver can cover more than one
     return AMT_OK;
 }
 

@@ -118,6 +118,13 @@ struct georef_args {
     int item_order, pad_;       // amt_georef_out.item_order
 };
 
+// Frames of one launch of k_georef_rows (the kernel-argument segment holds their constants side by side)
+constexpr int kMaxBatch = 2;
+struct georef_batch {
+    georef_args f[kMaxBatch];
+};
+static_assert(sizeof(georef_args) % 8 == 0 && sizeof(georef_batch) <= 4096, "kernel-argument segment");
+
 constexpr int kThreads = 256;
 // Workgroup of the row-marching kernel.  Its waves never synchronise with each other (each has private LDS), so
 // the size only sets the granularity at which the dispatcher places and retires work.
@@ -361,8 +368,9 @@ __device__ __forceinline__ int from_prev_lane(int v) {   // lane 0 receives 0
 // scalar cache; the empty asm makes the base pointer opaque so that the loads cannot be hoisted.
 typedef const __attribute__((address_space(4))) unsigned long long* karg_ptr;
 
-__device__ __forceinline__ karg_ptr karg_fresh() {
-    karg_ptr p = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+// word_offset: where this wave's georef_args starts inside the kernel-argument segment (frames of a batch)
+__device__ __forceinline__ karg_ptr karg_fresh(int word_offset = 0) {
+    karg_ptr p = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + word_offset;
     asm volatile("" : "+s"(p));
     return p;
 }
@@ -393,8 +401,8 @@ constexpr int kBinW = 8, kBinCells = kBinW * kBinW;
 #define AMT_ROWS_MIN_WAVES 5
 #endif
 template <bool FAST, bool DIRS_IN, bool MAG, int BIN>
-__global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) void k_georef_rows(georef_args A, int rows_per_chunk, int strips_x,
-                                                           int n_items) {
+__global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
+                                                           int n_items, int n_frames) {
     constexpr int kBinWaves = BIN ? kRowsThreads / 64 : 1, kBinSlots = BIN ? kBinCells : 1;
     __shared__ unsigned int sCnt[kBinWaves][kBinSlots];
     __shared__ unsigned int sCh[kBinWaves][3][kBinSlots];
@@ -403,9 +411,14 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
     // conflicts, no return value to wait for) instead of 12 VGPRs that would be live across the whole loop
     __shared__ double sBox[kRowsThreads / 64][6][64];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int item = blockIdx.x * (kRowsThreads / 64) + wave;               // one work item per wave
-    if (item >= n_items) return;                                            // wave-uniform
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: keep it scalar
+    const int item_all = blockIdx.x * (kRowsThreads / 64) + wave;           // one work item per wave
+    if (item_all >= n_items * n_frames) return;                             // wave-uniform
+    // several equally sized frames can share one launch: n_items items each, frame after frame
+    const int frame = item_all / n_items;
+    const int item = item_all - frame * n_items;
+    const georef_args& A = B.f[frame];
+    const int koff = frame * (int)(sizeof(georef_args) / 8);                // this frame's block of constants
     int bin_ax0 = 0, bin_ay0 = 0;
     bool bin_anchor = false;                                                // wave-uniform
     if (BIN) {
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
             atomicAdd(&sEl[wave][slot], (unsigned long long)el);
         } else {
             // outside the wave's window (very fine grids): straight to the global accumulators
-            karg_ptr K = karg_fresh();
+            karg_ptr K = karg_fresh(koff);
             const int nby = karg_load<axis_lin>(K, offsetof(georef_args, byl)).nbin;
             const int64_t ncell = (int64_t)karg_load<axis_lin>(K, offsetof(georef_args, bxl)).nbin * nby;
             unsigned long long* acc = karg_load<unsigned long long*>(K, offsetof(georef_args, bin_acc));
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
         double la = NAN, lo = NAN;
         if (col_ok) {
             const int64_t gi = gi_corner;
-            karg_ptr K = karg_fresh();
+            karg_ptr K = karg_fresh(koff);
             if (DIRS_IN) {
                 const vec3 dj = {A.dirs_in[3 * gi], A.dirs_in[3 * gi + 1], A.dirs_in[3 * gi + 2]};
                 d = mul(karg_load<mat3>(K, offsetof(georef_args, m_geo)), dj);       // J2000 -> GEO
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
             const bool hit = t == t;
             if (hit) {
                 p = quadric_point(ray, d, t);        // already in GEO
-                K = karg_fresh();
+                K = karg_fresh(koff);
                 ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), p.x, p.y, p.z, la, lo);
             }
             if (BIN) {
@@ -556,7 +569,7 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
                 const bool magbox = BIN && A.bin_magnetic;
                 if ((owner && A.mlat) || magbox) {
                     double ml = NAN, mt = NAN;
-                    if (hit) sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(), offsetof(georef_args, m_geo_sm)), p), ml, mt);
+                    if (hit) sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(koff), offsetof(georef_args, m_geo_sm)), p), ml, mt);
                     if (owner && A.mlat) {
                         A.mlat[gi] = ml;
                         A.mlt[gi] = mt;
@@ -585,7 +598,7 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
                 dc.y = (ty + from_next_lane(ty)) * 0.25;
                 dc.z = (tz + from_next_lane(tz)) * 0.25;
             } else {
-                karg_ptr K = karg_fresh();
+                karg_ptr K = karg_fresh(koff);
                 dc = tan_direction_fast(karg_load<tan_wcs>(K, offsetof(georef_args, wcs_geo)), (double)gx, (double)(gy - 1));
                 const quadric_ray ray = karg_load<quadric_ray>(K, offsetof(georef_args, qray));
                 pc = quadric_point(ray, dc, quadric_param(ray, dc));
@@ -602,7 +615,7 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
                 const int64_t gi = gi_pixel;
                 double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN;
                 if (pc.x == pc.x) {
-                    karg_ptr K = karg_fresh();
+                    karg_ptr K = karg_fresh(koff);
                     double inv_r;
                     ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), pc.x, pc.y, pc.z, lac, loc,
                                               &inv_r);
@@ -612,7 +625,7 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
                     c = fmin(1.0, fmax(-1.0, c));
                     el = fm::asin_deg(c);
                     if (MAG && (A.mlat_c || (BIN && A.bin_magnetic)))
-                        sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(), offsetof(georef_args, m_geo_sm)), pc), ml, mt);
+                        sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(koff), offsetof(georef_args, m_geo_sm)), pc), ml, mt);
                 }
                 if (A.lat_c) A.lat_c[gi] = lac;
                 if (A.lon_c) A.lon_c[gi] = loc;
@@ -627,13 +640,13 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
                     // (SM longitude = mltToSmLon(mlt), MLat) (mapping.py:1519-1547, transform.py:388-401)
                     double bxv = (MAG && A.bin_magnetic) ? (mt - 12.0) / (24.0 / 360.0) : loc;
                     const double byv = (MAG && A.bin_magnetic) ? ml : lac;
-                    karg_ptr K = karg_fresh();
+                    karg_ptr K = karg_fresh(koff);
                     if (karg_load<long long>(K, offsetof(georef_args, bin_lon_wrap)) & 0xffffffffll) bxv = wrap180_shifted(bxv);
                     bool slow_x, slow_y;
                     int bx = bin_fast(karg_load<axis_lin>(K, offsetof(georef_args, bxl)), bxv, slow_x);
                     int by = bin_fast(karg_load<axis_lin>(K, offsetof(georef_args, byl)), byv, slow_y);
                     if (__ballot(slow_x || slow_y)) {          // wave-uniform and rare
-                        K = karg_fresh();
+                        K = karg_fresh(koff);
                         if (slow_x) {
                             const axis_dev ax = karg_load<axis_dev>(K, offsetof(georef_args, bax));
                             bx = bin_index<true>(ax, bxv);
@@ -703,7 +716,7 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
         if (run_key) bin_flush(run_key, run_cnt, run_c0, run_c1, run_c2, run_el);
         // flush this wave's window: one 64-bit integer atomic per touched cell and plane
         __threadfence_block();
-        karg_ptr K = karg_fresh();
+        karg_ptr K = karg_fresh(koff);
         const int nby = karg_load<axis_lin>(K, offsetof(georef_args, byl)).nbin;
         const int64_t ncell = (int64_t)karg_load<axis_lin>(K, offsetof(georef_args, bxl)).nbin * nby;
         unsigned long long* acc = karg_load<unsigned long long*>(K, offsetof(georef_args, bin_acc));
@@ -780,26 +793,26 @@ void launch_variant(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, lau
 }
 
 template <bool FAST, bool DIRS_IN, int BIN>
-void launch_rows_bin(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, int rows, int strips_x, int n_items,
-                     launch_events ev) {
+void launch_rows_bin(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 grid, bool mag, int rows, int strips_x,
+                     int n_items, launch_events ev) {
     const dim3 block(kRowsThreads);
     if (mag)
-        hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, true, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, A,
-                              rows, strips_x, n_items);
+        hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, true, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
+                              rows, strips_x, n_items, n_frames);
     else
-        hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, false, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, A,
-                              rows, strips_x, n_items);
+        hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, false, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
+                              rows, strips_x, n_items, n_frames);
 }
 
 template <bool FAST, bool DIRS_IN>
-void launch_rows(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, int bin, int rows, int strips_x, int n_items,
-                 launch_events ev) {
+void launch_rows(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 grid, bool mag, int bin, int rows, int strips_x,
+                 int n_items, launch_events ev) {
     if (bin == 1)
-        launch_rows_bin<FAST, DIRS_IN, 1>(ctx, A, grid, mag, rows, strips_x, n_items, ev);
+        launch_rows_bin<FAST, DIRS_IN, 1>(ctx, B, n_frames, grid, mag, rows, strips_x, n_items, ev);
     else if (bin == 2)
-        launch_rows_bin<FAST, DIRS_IN, 2>(ctx, A, grid, mag, rows, strips_x, n_items, ev);
+        launch_rows_bin<FAST, DIRS_IN, 2>(ctx, B, n_frames, grid, mag, rows, strips_x, n_items, ev);
     else
-        launch_rows_bin<FAST, DIRS_IN, 0>(ctx, A, grid, mag, rows, strips_x, n_items, ev);
+        launch_rows_bin<FAST, DIRS_IN, 0>(ctx, B, n_frames, grid, mag, rows, strips_x, n_items, ev);
 }
 
 // One thread per lattice corner (every `stride`-th pixel corner): bounding box of the corners whose own ray
@@ -886,15 +899,28 @@ launch_shape shape_of(const amt_frame_params* p) {
     return s;
 }
 
-int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, const amt_georef_out* out,
-                  const amt_georef_tail* tail = nullptr) {
+// One frame of a launch, validated and with its kernel arguments assembled
+struct prepared_frame {
+    georef_args A;
+    launch_shape sh;
+    const amt_frame_params* p;
+    const double* dirs;
+    const amt_georef_out* out;
+    const amt_georef_tail* tail;
+    double* fold;       // scratch of the first fold stage (behind the partials)
+    bool mag;
+    int bin;
+};
+
+int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, const amt_georef_out* out,
+                   const amt_georef_tail* tail, prepared_frame* F) {
     AMT_REQUIRE(ctx, p && out, "NULL argument");
     AMT_REQUIRE(ctx, p->width > 0 && p->height > 0, "empty frame");
     AMT_REQUIRE(ctx, p->a > 0 && p->b > 0 && p->a0 > 0 && p->b0 > 0, "ellipsoid axes must be positive");
     AMT_REQUIRE(ctx, (out->mlat == nullptr) == (out->mlt == nullptr), "mlat and mlt must be given together");
     AMT_REQUIRE(ctx, (out->mlat_c == nullptr) == (out->mlt_c == nullptr), "mlat_c and mlt_c must be given together");
     AMT_REQUIRE(ctx, dirs == nullptr || p->fast_center, "caller-supplied directions need fast_center");
-    georef_args A;
+    georef_args& A = F->A;
     A.wcs = make_tan_wcs(p);
     A.ray = make_ray(p->a, p->b, p->cam, 1);
     A.m_geo = make_mat3(p->m_geo);
@@ -954,9 +980,7 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
     }
     const launch_shape sh = shape_of(p);
     const bool use_tiles = sh.use_tiles;
-    const int rows_per_chunk = sh.rows_per_chunk, strips_x = sh.strips_x;
     const int64_t n_items = sh.n_items;
-    const int64_t nblocks = use_tiles ? n_items : (n_items + kRowsThreads / 64 - 1) / (kRowsThreads / 64);
     AMT_REQUIRE(ctx, n_items < (1ll << 31), "frame too large");
     A.bbox_partials = nullptr;
     double* fold = nullptr;
@@ -974,14 +998,48 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
         }
         fold = A.bbox_partials + n_items * 8;
     }
-    const dim3 grid((unsigned)nblocks);
-    const bool mag = out->mlat != nullptr || out->mlat_c != nullptr || A.bin_magnetic;
     AMT_REQUIRE(ctx, !(bin && use_tiles), "fused binning is implemented by the row-marching kernel only");
+    F->sh = sh;
+    F->p = p;
+    F->dirs = dirs;
+    F->out = out;
+    F->tail = tail;
+    F->fold = fold;
+    F->mag = out->mlat != nullptr || out->mlat_c != nullptr || A.bin_magnetic;
+    F->bin = bin;
+    return AMT_OK;
+}
+
+// Launches n prepared frames: one k_georef_rows launch for all of them when they are equally sized and need the
+// same kernel variant (their constants sit side by side in the kernel-argument segment), else one after the other.
+int launch_prepared(amt_ctx* ctx, int n, prepared_frame* F) {
+    AMT_REQUIRE(ctx, n >= 1 && n <= kMaxBatch, "bad batch size");
+    bool together = n > 1;
+    for (int i = 1; i < n && together; ++i)
+        together = !F[0].sh.use_tiles && F[i].p->width == F[0].p->width && F[i].p->height == F[0].p->height &&
+                   F[i].p->fast_center == F[0].p->fast_center && F[i].mag == F[0].mag && F[i].bin == F[0].bin &&
+                   F[i].dirs == nullptr && F[0].dirs == nullptr;
+    if (n > 1 && !together) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = launch_prepared(ctx, 1, F + i)) return rc;
+        return AMT_OK;
+    }
+    const georef_args& A = F[0].A;
+    const amt_frame_params* p = F[0].p;
+    const double* dirs = F[0].dirs;
+    const launch_shape& sh = F[0].sh;
+    const bool use_tiles = sh.use_tiles, mag = F[0].mag;
+    const int bin = F[0].bin, rows_per_chunk = sh.rows_per_chunk, strips_x = sh.strips_x;
+    const int64_t n_items = sh.n_items;
+    const int64_t nblocks = use_tiles ? n_items : ((int64_t)n * n_items + kRowsThreads / 64 - 1) / (kRowsThreads / 64);
+    AMT_REQUIRE(ctx, (int64_t)n * n_items < (1ll << 31), "launch too large");
+    const dim3 grid((unsigned)nblocks);
     // events ride on the dispatch packet itself: the timing pair when this launch is sampled, otherwise the
     // driver's hand-over event as the stop event; nothing is recorded between consecutive big kernels
     launch_events ev;
-    amt_timing_pair(ctx, AMT_KERNEL_GEOREF, &ev.start, &ev.stop);
-    if (ev.stop == nullptr && tail != nullptr && out->bbox) ev.stop = tail->kernel_done;
+    amt_timing_pair(ctx, AMT_KERNEL_GEOREF, n, &ev.start, &ev.stop);
+    for (int i = 0; i < n && ev.stop == nullptr; ++i)
+        if (F[i].tail != nullptr && F[i].out->bbox) ev.stop = F[i].tail->kernel_done;
     if (use_tiles) {
         if (dirs) {
             launch_variant<true, true>(ctx, A, grid, mag, ev);
@@ -991,28 +1049,40 @@ int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, c
             launch_variant<false, false>(ctx, A, grid, mag, ev);
         }
     } else {
+        georef_batch B;
+        for (int i = 0; i < kMaxBatch; ++i) B.f[i] = F[i < n ? i : 0].A;
         if (dirs) {
-            launch_rows<true, true>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
+            launch_rows<true, true>(ctx, B, n, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
         } else if (p->fast_center) {
-            launch_rows<true, false>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
+            launch_rows<true, false>(ctx, B, n, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
         } else {
-            launch_rows<false, false>(ctx, A, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
+            launch_rows<false, false>(ctx, B, n, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
         }
     }
     AMT_LAUNCH_CHECK(ctx);
-    if (out->bbox) {
+    for (int i = 0; i < n; ++i) {
+        if (!F[i].out->bbox) continue;
         hipStream_t fs = ctx->stream;
-        if (tail) {
-            AMT_HIP(ctx, hipStreamWaitEvent(tail->stream, ev.stop, 0));
-            fs = tail->stream;
+        if (F[i].tail) {
+            AMT_HIP(ctx, hipStreamWaitEvent(F[i].tail->stream, ev.stop, 0));
+            fs = F[i].tail->stream;
         }
-        hipLaunchKernelGGL(k_bbox_fold, dim3(kFoldBlocks), dim3(kThreads), 0, fs, A.bbox_partials, (int)n_items, fold);
+        hipLaunchKernelGGL(k_bbox_fold, dim3(kFoldBlocks), dim3(kThreads), 0, fs, F[i].A.bbox_partials, (int)n_items,
+                           F[i].fold);
         AMT_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, fs, fold, kFoldBlocks, out->bbox);
+        hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, fs, F[i].fold, kFoldBlocks, F[i].out->bbox);
         AMT_LAUNCH_CHECK(ctx);
     }
     return AMT_OK;
 }
+
+int launch_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, const amt_georef_out* out,
+                  const amt_georef_tail* tail = nullptr) {
+    prepared_frame F;
+    if (int rc = prepare_georef(ctx, p, dirs, out, tail, &F)) return rc;
+    return launch_prepared(ctx, 1, &F);
+}
+
 
 }  // namespace
 
@@ -1024,6 +1094,16 @@ int amt_georef_launch(amt_ctx* ctx, const amt_frame_params* p, const double* dir
                       const amt_georef_tail* tail) {
     AMT_CHECK_CTX(ctx);
     return launch_georef(ctx, p, dirs, out, tail);
+}
+
+int amt_georef_launch_many(amt_ctx* ctx, int n, const amt_frame_params* const* p, const amt_georef_out* const* out,
+                           const amt_georef_tail* const* tail) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, n >= 1 && n <= kMaxBatch && p && out && tail, "bad batch");
+    prepared_frame F[kMaxBatch];
+    for (int i = 0; i < n; ++i)
+        if (int rc = prepare_georef(ctx, p[i], nullptr, out[i], tail[i], &F[i])) return rc;
+    return launch_prepared(ctx, n, F);
 }
 
 extern "C" {

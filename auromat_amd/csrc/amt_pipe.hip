@@ -24,6 +24,7 @@ struct amt_pipe {
     size_t partials_bytes;
     // state of the frame in flight
     bool coarse_pending, launched, fused, ready, tail_pending;
+    bool coarse_hinted;            // the pending coarse box came from the caller (amt_pipe_coarse_hint), no kernel ran
     int coarse_magnetic;           // coordinates of the pending coarse box (0 geodetic, 1 MLat / SM longitude)
     int lon_wrap;                  // the frame straddles the 180 deg discontinuity: longitudes are binned shifted by 180
     amt_grid super, exact;
@@ -222,14 +223,20 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
     if (rc != AMT_OK) return rc;
     AMT_HIP(ctx, hipEventRecord(pipe->coarse_done, pipe->pre_stream));
     pipe->coarse_pending = true;
+    pipe->coarse_hinted = false;
     pipe->coarse_magnetic = magnetic ? 1 : 0;
     return AMT_OK;
 }
 
-int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
-                    int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
-                    int pole_in_view, int magnetic) {
-    if (pipe == nullptr) return AMT_EINVAL;
+}  // extern "C"
+
+namespace {
+
+// Everything amt_pipe_launch does before the big kernel: wait for the coarse box, superset grid, accumulators,
+// kernel outputs (`o`) and the tail description for this frame.
+int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
+                 int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
+                 int pole_in_view, int magnetic, amt_georef_out* o_out, amt_georef_tail* tail_out) {
     amt_ctx* ctx = pipe->ctx;
     AMT_REQUIRE(ctx, p && out && img, "NULL argument");
     AMT_REQUIRE(ctx, img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
@@ -237,8 +244,9 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
     if (!pipe->coarse_pending || pipe->coarse_magnetic != magnetic) {
         if (int rc = amt_pipe_coarse(pipe, p, min_elevation, magnetic)) return rc;
     }
-    AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
+    if (!pipe->coarse_hinted) AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
     pipe->coarse_pending = false;
+    pipe->coarse_hinted = false;
     pipe->lat_ppd = lat_px_per_deg;
     pipe->lon_ppd = lon_px_per_deg;
     pipe->min_elev = min_elevation;
@@ -255,7 +263,8 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
     }
     if (int rc = ensure_partials(pipe, amt_georef_partials_bytes(p))) return rc;
 
-    amt_georef_out o = *out;
+    amt_georef_out& o = *o_out;
+    o = *out;
     o.bbox = pipe->host_small_dev + 8;          // the last fold writes straight into pinned host memory
     o.bbox_min_elevation = min_elevation;
     o.bin_acc = nullptr;
@@ -313,18 +322,77 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
         pipe->fused = true;
         pipe->acc_zero = false;
     }
-    amt_georef_tail tail;
-    tail.stream = pipe->tail_stream;
-    tail.kernel_done = pipe->kernel_done;
-    tail.partials = pipe->partials;
-    tail.partials_bytes = pipe->partials_bytes;
-    if (int rc = amt_georef_launch(ctx, p, nullptr, &o, &tail)) return rc;
+    tail_out->stream = pipe->tail_stream;
+    tail_out->kernel_done = pipe->kernel_done;
+    tail_out->partials = pipe->partials;
+    tail_out->partials_bytes = pipe->partials_bytes;
+    return AMT_OK;
+}
+
+int pipe_after_launch(amt_pipe* pipe) {
+    amt_ctx* ctx = pipe->ctx;
     AMT_HIP(ctx, hipEventRecord(pipe->bbox_done, pipe->tail_stream));
     AMT_HIP(ctx, hipEventRecord(pipe->tail_done, pipe->tail_stream));
     pipe->tail_pending = true;
     pipe->launched = true;
     return AMT_OK;
 }
+
+}  // namespace
+
+extern "C" {
+
+int amt_pipe_coarse_hint(amt_pipe* pipe, const double* bbox, int magnetic) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipe->ctx;
+    AMT_REQUIRE(ctx, bbox != nullptr, "NULL argument");
+    if (pipe->coarse_pending) {
+        // a pre-pass kernel may still be writing the same 8 doubles
+        AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
+    }
+    for (int i = 0; i < 7; ++i) pipe->host_small[i] = bbox[i];
+    pipe->host_small[7] = 0;                       // no hit statistics: item order from the camera model
+    pipe->coarse_pending = true;
+    pipe->coarse_magnetic = magnetic ? 1 : 0;
+    pipe->coarse_hinted = true;
+    return AMT_OK;
+}
+
+int amt_pipe_launch_many(amt_pipe* const* pipes, int32_t n, const amt_frame_params* const* p,
+                         const amt_georef_out* const* out, const void* const* img, int32_t img_dtype,
+                         double min_elevation, double lat_px_per_deg, double lon_px_per_deg, int pole_in_view,
+                         int magnetic) {
+    if (pipes == nullptr || n < 1 || pipes[0] == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipes[0]->ctx;
+    AMT_REQUIRE(ctx, n <= AMT_MAX_BATCH, "at most AMT_PIPE_MAX_BATCH frames per launch");
+    AMT_REQUIRE(ctx, p && out && img, "NULL argument");
+    amt_georef_out o[AMT_MAX_BATCH];
+    amt_georef_tail tails[AMT_MAX_BATCH];
+    const amt_georef_out* op[AMT_MAX_BATCH];
+    const amt_georef_tail* tp[AMT_MAX_BATCH];
+    for (int i = 0; i < n; ++i) {
+        AMT_REQUIRE(ctx, pipes[i] != nullptr && pipes[i]->ctx == ctx, "drivers of one launch must share the context");
+        for (int k = 0; k < i; ++k) AMT_REQUIRE(ctx, pipes[k] != pipes[i], "a driver can hold one frame of a launch");
+        if (int rc = pipe_prepare(pipes[i], p[i], out[i], img[i], img_dtype, min_elevation, lat_px_per_deg,
+                                  lon_px_per_deg, pole_in_view, magnetic, &o[i], &tails[i]))
+            return rc;
+        op[i] = &o[i];
+        tp[i] = &tails[i];
+    }
+    if (int rc = amt_georef_launch_many(ctx, n, p, op, tp)) return rc;
+    for (int i = 0; i < n; ++i)
+        if (int rc = pipe_after_launch(pipes[i])) return rc;
+    return AMT_OK;
+}
+
+int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
+                    int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
+                    int pole_in_view, int magnetic) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    return amt_pipe_launch_many(&pipe, 1, &p, &out, &img, img_dtype, min_elevation, lat_px_per_deg, lon_px_per_deg,
+                                pole_in_view, magnetic);
+}
+
 
 int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result) {
     if (pipe == nullptr) return AMT_EINVAL;

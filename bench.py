@@ -80,6 +80,10 @@ def main():
     ap.add_argument('--plan', default='fused', choices=('fused', 'two-pass'),
                     help='fused: binning inside the georeferencing kernel (superset grid + crop); '
                          'two-pass: separate binning kernel that re-reads the centre arrays')
+    ap.add_argument('--no-hints', action='store_true',
+                    help='run the coarse bounding-box pre-pass for every frame instead of re-using the previous exact box')
+    ap.add_argument('--batch', type=int, default=1, choices=(1, 2),
+                    help='frames per launch of the big kernel in the fused plan (amt_pipe_launch_many)')
     ap.add_argument('--streams', type=int, default=2, choices=(1, 2),
                     help='2: bin frame k beside the ray casting of frame k+1 on a second HIP stream')
     args = ap.parse_args()
@@ -108,7 +112,8 @@ def main():
     seq = SequencePipeline(WIDTH, HEIGHT, altitude=ALTITUDE, fast=fast, min_elevation=MIN_ELEV, pxPerDeg=PPD,
                            plan='single-pass' if fused else 'two-pass', bin_stream=args.streams == 2,
                            shared_image=frame_image(WIDTH, HEIGHT, seed=rank),     # resident before the timed region
-                           magnetic=args.magnetic)
+                           magnetic=args.magnetic, batch=args.batch)
+    seq.use_hints = not args.no_hints
     ctx = seq.ctx
     # the synthetic sequence (what a reader would hand over: WCS cards, camera position, time) exists before the
     # timed region, like the image; everything derived from it (matrices, grids) is computed inside
@@ -133,6 +138,7 @@ def main():
     t0 = time.perf_counter()
     results = seq.process(frames[args.warmup:])
     plans = list(seq.plans)
+    hinted = seq.hinted
     gathered = None
     if world > 1:
         # device-to-device over xGMI; rank 0 unpacks to the host after the timed region
@@ -198,7 +204,7 @@ def main():
                                     'maskedByElevation(10), mean-resample to 0.1 deg plate-carree, uint16 RGB'
                                     % ('fast' if fast else 'exact')),
                        'frame': [WIDTH, HEIGHT], 'px_per_deg': PPD, 'grid': list(res['mean'].shape),
-                       'plan': args.plan,
+                       'plan': args.plan, 'frames_per_launch': seq.batch, 'frames_without_prepass': hinted,
                        'single_pass_frames': sum(1 for q in plans if q == 'single-pass'),
                        'parallelism': 'frames sharded over %d GPU(s), RCCL gather of grids' % world,
                        'device': info['name']},

@@ -70,7 +70,8 @@ int amt_event_elapsed_ms(amt_ctx* ctx, void* start, void* stop, float* out_ms); 
  * launch (k_georef_rows / k_bin_frame, not the small fold / finalize kernels) with HIP events on the
  * context's stream.  enable = n > 0 brackets every n-th launch of each kind (the two event packets sit between
  * consecutive kernels on the stream, so a pipelined caller samples instead of timing every launch); 0 = off.
- * amt_timing_read sums the recorded launches and returns how many there were (synchronises); enabling resets. */
+ * amt_timing_read sums the recorded launches and returns how many frames they covered (synchronises; a launch of
+ * amt_pipe_launch_many covers several frames, so total / frames is the time per frame); enabling resets. */
 #define AMT_KERNEL_GEOREF 0
 #define AMT_KERNEL_BIN 1
 int amt_timing_enable(amt_ctx* ctx, int enable);
@@ -354,6 +355,11 @@ typedef struct amt_pipe_result {
 int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe);
 int amt_pipe_destroy(amt_pipe* pipe);
 int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation, int magnetic);
+/* Instead of the pre-pass: the caller supplies the estimate (bbox[0..6] as amt_georef_coarse_bbox reports them),
+ * e.g. the exact box amt_pipe_wait returned for a neighbouring frame of the same sequence.  Consecutive frames
+ * move by a fraction of the superset margin, and a frame whose exact box does not fit its superset grid takes
+ * the general path anyway (status 1), so a poor estimate costs time, never correctness. */
+int amt_pipe_coarse_hint(amt_pipe* pipe, const double* bbox, int magnetic);
 /* out: arrays to write (lat .. mlt_c as in amt_georef_frame; bbox / bin_* fields are managed by the driver).
  * img: (height, width, 3) uint8 (img_dtype 1) or uint16 (2).  min_elevation: -inf disables the mask.
  * pole_in_view: 0 / 1 = the caller's decision, < 0 = decide from the camera model (is a pole of the mapping
@@ -363,6 +369,15 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
 int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
                     int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
                     int pole_in_view, int magnetic);
+/* The same for n <= AMT_PIPE_MAX_BATCH frames, one per driver (all on one context), with ONE launch of the big
+ * kernel when the frames are equally sized and take the same kernel variant (their constants sit side by side in
+ * the kernel-argument segment; otherwise one launch each): the 14-17 us between two big kernels on a stream are
+ * then paid once per n frames.  amt_pipe_wait / amt_pipe_finalize stay per driver. */
+#define AMT_PIPE_MAX_BATCH 2
+int amt_pipe_launch_many(amt_pipe* const* pipes, int32_t n, const amt_frame_params* const* p,
+                         const amt_georef_out* const* out, const void* const* img, int32_t img_dtype,
+                         double min_elevation, double lat_px_per_deg, double lon_px_per_deg, int pole_in_view,
+                         int magnetic);
 int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result);
 /* mean (ny,nx,4) f64, out_img (ny,nx,3) of img_dtype, out_mask (ny,nx) u8, out_count (ny,nx) f64: device
  * buffers for result->grid of the preceding amt_pipe_wait (any may be NULL).  The kernel runs on the driver's

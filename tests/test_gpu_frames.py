@@ -472,3 +472,35 @@ def test_single_pass_plan_across_the_dateline(width, height):
     for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon', 'lat_c', 'lon_c'):
         assert np.array_equal(one[k], two[k], equal_nan=True), k
     assert one['lon_c'].min() < -170 and one['lon_c'].max() > 170
+
+
+def test_batched_launch_and_sequence_hints_change_nothing():
+    """Two frames per launch of the big kernel (amt_pipe_launch_many) and bounding-box hints from the previous
+    frame instead of the coarse pre-pass give the same bits as one frame at a time with pre-passes."""
+    from auromat_amd.pipeline import SequencePipeline
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    w, h = 250, 168
+    frames = []
+    for k in range(7):
+        hdr, cam, t, seed = sequence_frame(k, w, h)
+        frames.append((hdr, cam, t, frame_image(w, h, seed=seed)))
+    base = SequencePipeline(w, h, pxPerDeg=8, batch=1)
+    base.use_hints = False
+    ref = base.process(frames, keep_on_device=False)
+    assert base.hinted == 0 and base.plans == ['single-pass'] * 7
+    for batch, hints in ((2, False), (2, True), (1, True)):
+        seq = SequencePipeline(w, h, pxPerDeg=8, batch=batch)
+        seq.use_hints = hints
+        out = seq.process(frames, keep_on_device=False)
+        assert seq.plans == ['single-pass'] * 7
+        assert (seq.hinted > 0) == hints
+        for a, b in zip(out, ref):
+            for key in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
+                assert np.array_equal(a[key], b[key], equal_nan=True), (batch, hints, key)
+    # a jump in the sequence (other pointing) is not a neighbour: that frame gets a real pre-pass again
+    from auromat_amd.synthetic import frame_header
+    hdr2, cam2, t2 = frame_header(w, h, 'iss029')
+    seq = SequencePipeline(w, h, pxPerDeg=8)
+    out = seq.process(frames[:3] + [(hdr2, cam2, t2, frames[0][3])] + frames[3:5], keep_on_device=False)
+    assert seq.plans == ['single-pass'] * 6 and 0 < seq.hinted < 5
+    assert np.array_equal(out[4]['mean'], ref[3]['mean'], equal_nan=True)
