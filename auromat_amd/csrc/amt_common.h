@@ -21,6 +21,10 @@ struct amt_ctx {
     void* ws;               // grow-only device workspace (per-block partial reductions)
     size_t ws_bytes;
     std::string last_error;
+    // side streams shared by all frame drivers of this context (created by the first amt_pipe_create): every
+    // extra stream competes for the few hardware queues of the process, and streams that share a hardware queue
+    // are served in order, so a kernel can get stuck behind another stream's wait
+    hipStream_t aux_pre, aux_tail, aux_fin;     // coarse pre-pass | folds behind a big kernel | crop/finalise
     // optional per-kernel timing (amt_timing_*): event pairs recorded around the dominant kernels
     int timing;                       // 0 = off, n = bracket every n-th launch of each kind
     size_t tlaunch[2];                // launches seen per kind since timing was enabled
@@ -63,7 +67,7 @@ size_t amt_georef_partials_bytes(const amt_frame_params* p);
 int amt_georef_launch(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, const amt_georef_out* out,
                       const amt_georef_tail* tail);
 // n <= AMT_MAX_BATCH equally sized frames in ONE launch of the big kernel (falls back to n launches otherwise)
-#define AMT_MAX_BATCH 2
+#define AMT_MAX_BATCH 3
 int amt_georef_launch_many(amt_ctx* ctx, int n, const amt_frame_params* const* p, const amt_georef_out* const* out,
                            const amt_georef_tail* const* tail);
 // amt_bin_frame_finalize_window on `stream`; clear != 0 also zeroes every cell of the accumulator grid.

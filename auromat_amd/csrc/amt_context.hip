@@ -19,6 +19,7 @@ int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ct
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     ctx->timing = 0;
+    ctx->aux_pre = ctx->aux_tail = ctx->aux_fin = nullptr;
     ctx->tlaunch[0] = ctx->tlaunch[1] = 0;
     ctx->tframes[0] = ctx->tframes[1] = 0;
     ctx->tused[0] = ctx->tused[1] = 0;
@@ -51,6 +52,11 @@ int amt_ctx_destroy(amt_ctx* ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     for (int k = 0; k < 2; ++k)
         for (hipEvent_t e : ctx->tev[k]) (void)hipEventDestroy(e);
+    for (hipStream_t st : {ctx->aux_pre, ctx->aux_tail, ctx->aux_fin})
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
     if (ctx->owns_stream) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);

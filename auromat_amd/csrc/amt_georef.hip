@@ -119,7 +119,7 @@ struct georef_args {
 };
 
 // Frames of one launch of k_georef_rows (the kernel-argument segment holds their constants side by side)
-constexpr int kMaxBatch = 2;
+constexpr int kMaxBatch = 3;
 struct georef_batch {
     georef_args f[kMaxBatch];
 };

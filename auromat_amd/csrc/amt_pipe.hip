@@ -11,7 +11,10 @@ struct amt_pipe {
     amt_ctx* ctx;
     // The context's stream carries only the big kernel of each frame.  Everything small runs beside it:
     hipStream_t pre_stream;        // coarse pre-pass of a later frame (must not queue behind the running kernel)
-    hipStream_t tail_stream;       // bounding-box folds and the crop/finalise kernel of this frame
+    hipStream_t tail_stream;       // bounding-box folds of this frame, waiting for its big kernel
+    hipStream_t fin_stream;        // crop/finalise kernel: waits for nothing on the GPU (the host has seen the box),
+                                   // so it must not queue behind another frame's folds, which do wait
+                                   // (all three owned by the context and shared with its other drivers)
     hipEvent_t coarse_done, kernel_done, bbox_done, tail_done;
     double* host_small;            // pinned host memory: [0..7] coarse bbox, [8..15] exact bbox
     double* host_small_dev;        // the same 16 doubles as the kernels address them (the folds write them directly)
@@ -158,8 +161,13 @@ int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe) {
     pipe->ctx = ctx;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    bool ok = hipStreamCreateWithPriority(&pipe->pre_stream, hipStreamNonBlocking, hi) == hipSuccess &&
-              hipStreamCreateWithPriority(&pipe->tail_stream, hipStreamNonBlocking, hi) == hipSuccess &&
+    if (ctx->aux_pre == nullptr) (void)hipStreamCreateWithPriority(&ctx->aux_pre, hipStreamNonBlocking, hi);
+    if (ctx->aux_tail == nullptr) (void)hipStreamCreateWithPriority(&ctx->aux_tail, hipStreamNonBlocking, hi);
+    if (ctx->aux_fin == nullptr) (void)hipStreamCreateWithPriority(&ctx->aux_fin, hipStreamNonBlocking, hi);
+    pipe->pre_stream = ctx->aux_pre;
+    pipe->tail_stream = ctx->aux_tail;
+    pipe->fin_stream = ctx->aux_fin;
+    bool ok = pipe->pre_stream != nullptr && pipe->tail_stream != nullptr && pipe->fin_stream != nullptr &&
               hipEventCreateWithFlags(&pipe->coarse_done, hipEventDisableTiming) == hipSuccess &&
               hipEventCreate(&pipe->kernel_done) == hipSuccess &&
               hipEventCreateWithFlags(&pipe->bbox_done, hipEventDisableTiming) == hipSuccess &&
@@ -178,14 +186,9 @@ int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe) {
 
 int amt_pipe_destroy(amt_pipe* pipe) {
     if (pipe == nullptr) return AMT_EINVAL;
-    if (pipe->pre_stream) {
-        (void)hipStreamSynchronize(pipe->pre_stream);
-        (void)hipStreamDestroy(pipe->pre_stream);
-    }
-    if (pipe->tail_stream) {
-        (void)hipStreamSynchronize(pipe->tail_stream);
-        (void)hipStreamDestroy(pipe->tail_stream);
-    }
+    if (pipe->pre_stream) (void)hipStreamSynchronize(pipe->pre_stream);
+    if (pipe->tail_stream) (void)hipStreamSynchronize(pipe->tail_stream);
+    if (pipe->fin_stream) (void)hipStreamSynchronize(pipe->fin_stream);
     if (pipe->coarse_done) (void)hipEventDestroy(pipe->coarse_done);
     if (pipe->kernel_done) (void)hipEventDestroy(pipe->kernel_done);
     if (pipe->bbox_done) (void)hipEventDestroy(pipe->bbox_done);
@@ -447,12 +450,13 @@ int amt_pipe_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_
     pipe->ready = false;
     const amt_grid& s = pipe->super;
     const amt_grid& g = pipe->exact;
-    // on the tail stream (behind this frame's folds), zeroing the accumulators for the next frame on the way
-    if (int rc = amt_bin_finalize_on(ctx, pipe->tail_stream, pipe->acc, s.nx, s.ny, pipe->off_x, pipe->off_y, g.nx, g.ny,
+    // on the finalise stream (this frame's big kernel and folds are complete: the host has read the box), zeroing
+    // the accumulators for the next frame on the way
+    if (int rc = amt_bin_finalize_on(ctx, pipe->fin_stream, pipe->acc, s.nx, s.ny, pipe->off_x, pipe->off_y, g.nx, g.ny,
                                      3, pipe->img_dtype, mean, out_img, out_mask, out_count, 1))
         return rc;
     pipe->acc_zero = true;
-    AMT_HIP(ctx, hipEventRecord(pipe->tail_done, pipe->tail_stream));
+    AMT_HIP(ctx, hipEventRecord(pipe->tail_done, pipe->fin_stream));
     pipe->tail_pending = true;
     return AMT_OK;
 }

@@ -348,7 +348,7 @@ class SequencePipeline(object):
 
     def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, altitude=110, fast=True,
                  min_elevation=10.0, pxPerDeg=10, plan='single-pass', bin_stream=True, shared_image=None,
-                 magnetic=False, batch=1):
+                 magnetic=False, batch=2):
         import torch
         assert plan in ('single-pass', 'two-pass')
         try:
@@ -359,10 +359,11 @@ class SequencePipeline(object):
         self.altitude, self.fast, self.min_elevation = altitude, fast, min_elevation
         self.single_pass = plan == 'single-pass' and nchan == 3
         self.magnetic = bool(magnetic)          # grids in (MLat, SM longitude): resampleMLatMLT
-        # single-pass plan: `batch` frames can share one launch of the big kernel (amt_pipe_launch_many; batch frames
-        # in flight + batch being prepared = 2 * batch buffers).  Measured: the kernel is 6 % faster per frame at
-        # batch 2 (better filled end of the launch) but the time between launches grows by more, so 1 is the default.
-        self.batch = max(1, min(int(batch), 2)) if self.single_pass else 1
+        # single-pass plan: `batch` frames share one launch of the big kernel (amt_pipe_launch_many; batch frames in
+        # flight + batch being prepared = 2 * batch buffers).  The 14-17 us between two launches on a stream are
+        # paid once per batch and the end of a launch is better filled: 0.207 -> 0.200 -> 0.198 ms per frame for
+        # 1, 2, 3 frames per launch.
+        self.batch = max(1, min(int(batch), 3)) if self.single_pass else 1
         self.pipes = [FramePipeline(width, height, nchan, img_dtype, device, with_mag=self.magnetic)
                       for _ in range(2 * self.batch)]
         self.ctx = self.pipes[0].ctx

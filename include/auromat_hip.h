@@ -373,7 +373,7 @@ int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_
  * kernel when the frames are equally sized and take the same kernel variant (their constants sit side by side in
  * the kernel-argument segment; otherwise one launch each): the 14-17 us between two big kernels on a stream are
  * then paid once per n frames.  amt_pipe_wait / amt_pipe_finalize stay per driver. */
-#define AMT_PIPE_MAX_BATCH 2
+#define AMT_PIPE_MAX_BATCH 3
 int amt_pipe_launch_many(amt_pipe* const* pipes, int32_t n, const amt_frame_params* const* p,
                          const amt_georef_out* const* out, const void* const* img, int32_t img_dtype,
                          double min_elevation, double lat_px_per_deg, double lon_px_per_deg, int pole_in_view,

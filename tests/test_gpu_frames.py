@@ -488,19 +488,29 @@ def test_batched_launch_and_sequence_hints_change_nothing():
     base.use_hints = False
     ref = base.process(frames, keep_on_device=False)
     assert base.hinted == 0 and base.plans == ['single-pass'] * 7
-    for batch, hints in ((2, False), (2, True), (1, True)):
+    for batch, hints in ((2, False), (2, True), (1, True), (3, True)):
         seq = SequencePipeline(w, h, pxPerDeg=8, batch=batch)
         seq.use_hints = hints
         out = seq.process(frames, keep_on_device=False)
         assert seq.plans == ['single-pass'] * 7
-        assert (seq.hinted > 0) == hints
+        if batch < 3:                          # with 3 per launch all 7 frames are prepared before the first finishes
+            assert (seq.hinted > 0) == hints
         for a, b in zip(out, ref):
             for key in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
                 assert np.array_equal(a[key], b[key], equal_nan=True), (batch, hints, key)
     # a jump in the sequence (other pointing) is not a neighbour: that frame gets a real pre-pass again
     from auromat_amd.synthetic import frame_header
+    more = []
+    for k in range(7, 12):
+        hdr, cam, t, seed = sequence_frame(k, w, h)
+        more.append((hdr, cam, t, frame_image(w, h, seed=seed)))
     hdr2, cam2, t2 = frame_header(w, h, 'iss029')
+    mixed = frames + [(hdr2, cam2, t2, frames[0][3])] + more
     seq = SequencePipeline(w, h, pxPerDeg=8)
-    out = seq.process(frames[:3] + [(hdr2, cam2, t2, frames[0][3])] + frames[3:5], keep_on_device=False)
-    assert seq.plans == ['single-pass'] * 6 and 0 < seq.hinted < 5
-    assert np.array_equal(out[4]['mean'], ref[3]['mean'], equal_nan=True)
+    out = seq.process(mixed, keep_on_device=False)
+    assert seq.plans == ['single-pass'] * len(mixed) and 0 < seq.hinted < len(mixed) - 4
+    plain = SequencePipeline(w, h, pxPerDeg=8, batch=1)
+    plain.use_hints = False
+    want = plain.process(mixed, keep_on_device=False)
+    for a, b in zip(out, want):
+        assert np.array_equal(a['mean'], b['mean'], equal_nan=True) and np.array_equal(a['count'], b['count'])
