@@ -188,6 +188,7 @@ def main():
             kbytes += ab['mag']
             tkey += '_mag'               # no PMC pass of this variant under profiles/ yet: traffic = null
         achieved = kbytes / (georef_ms * 1e-3) / 1e9
+        fpl = seq.batch if fused else 1
         out = {
             'metric': 'Mpixels/s georef+resample, 4240x2832 frame',
             'value': world * args.steps * npx / 1e6 / elapsed,
@@ -212,9 +213,11 @@ def main():
             # DESIGN.md and profiles/), so the HBM fraction understates how busy the chip is.
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic.get(tkey, {}).get('hbm_bytes'),
-                         'algorithmic_bytes': kbytes, 'ms_per_launch': georef_ms,
-                         'launches_timed': g_n, 'valu_busy': traffic.get(tkey, {}).get('valu_busy')},
+                         # one launch covers `frames_per_launch` frames: bytes, traffic and duration are per launch
+                         'frames_per_launch': fpl,
+                         'traffic': (traffic.get(tkey, {}).get('hbm_bytes') or 0) * fpl or None,
+                         'algorithmic_bytes': kbytes * fpl, 'ms_per_launch': georef_ms * fpl,
+                         'frames_timed': g_n, 'valu_busy': traffic.get(tkey, {}).get('valu_busy')},
             'kernels': {
                 'k_georef_rows': {'ms': georef_ms, 'algorithmic_bytes': kbytes, 'frac_hbm_peak': frac(kbytes, georef_ms)},
                 'k_bin_frame': ({'ms': bin_ms, 'algorithmic_bytes': ab['resample'],
