@@ -22,6 +22,7 @@ from .coordinates.transform import rotation_matrix
 from .coordinates.geodesic import wgs84A, wgs84B
 from .mapping.mapping import (BaseMapping, BoundingBox, MappingCollection, bounding_box_from_reduction,
                               convertMappingToSM, convertSMMappingToGeo, wrap_at_180)
+from .coordinates.geodesic import angularDistanceOnParallel
 from .util.histogram import make_axis
 from ._native import Context, host9, ptr, to_host
 
@@ -29,24 +30,28 @@ from ._native import Context, host9, ptr, to_host
 def plateCarreeResolution(boundingBox, arcsecPerPx):
     """
     Approximates the latitude and longitude resolution of a plate carree projection from a
-    spherical resolution (reference resample.py:36-61).  The longitude part needs the geodesic
-    arc length between the box's mid-latitude end points, which the reference takes from
-    geographiclib; here it is the great-circle angle on the auxiliary sphere of the WGS84
-    ellipsoid (reduced latitude), which is what geographiclib's ``a12`` is for two points on one
-    parallel up to the ellipsoidal correction of the geodesic (< 0.3 %).
+    spherical resolution for the area given by the bounding box (reference resample.py:36-61).
+    The approximation is calculated for the bounding box center.  The longitude part needs
+    ``geodesic.angularDistance`` between the box's mid-latitude end points, geographiclib's ``a12`` in the
+    reference; :func:`auromat_amd.coordinates.geodesic.angularDistanceOnParallel` evaluates the same quantity
+    from Karney's integral formulation to ~1e-14 relative, so ``round(pxPerDeg * 360 + 1)`` and with it the
+    grid come out the same.
 
+    :type boundingBox: auromat_amd.mapping.mapping.BoundingBox
+    :param arcsecPerPx: spherical resolution
     :rtype: tuple (latPxPerDeg, lonPxPerDeg)
     """
     degPerPx = arcsecPerPx / 3600.0
     latPxPerDeg = 1 / degPerPx
     latMiddle = (boundingBox.latNorth + boundingBox.latSouth) / 2
     lonEast = boundingBox.lonEast
-    lons = lonEast + 360 - boundingBox.lonWest if boundingBox.lonWest > lonEast else lonEast - boundingBox.lonWest
-    f = 1 - wgs84B / wgs84A
-    beta = np.arctan((1 - f) * np.tan(np.deg2rad(latMiddle)))          # reduced latitude
-    dlon = np.deg2rad(min(lons, 360 - lons))
-    sigma = 2 * np.arcsin(np.cos(beta) * np.sin(dlon / 2))             # same-parallel great-circle angle
-    px = np.rad2deg(sigma) / degPerPx
+    if boundingBox.lonWest > lonEast:
+        lons = lonEast + 360 - boundingBox.lonWest
+    else:
+        lons = lonEast - boundingBox.lonWest
+    # the shortest geodesic between the two end points spans min(lons, 360 - lons) of longitude
+    lonMiddleDistance = angularDistanceOnParallel(latMiddle, min(lons, 360 - lons))
+    px = lonMiddleDistance / degPerPx
     return latPxPerDeg, px / lons
 
 

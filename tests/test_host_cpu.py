@@ -166,3 +166,59 @@ def test_header_helpers_and_synthetic_frames():
     h5, cam5, t5, seed = sequence_frame(5)
     assert abs(np.linalg.norm(cam5) - np.linalg.norm(cam0)) < 1e-9 and (t5 - t0).total_seconds() == 5
     assert abs(np.linalg.norm(cam5 - cam0) - 5 * 7.66) < 0.01 and h5['CRVAL1'] == h0['CRVAL1'] + 0.25
+
+
+def test_angular_distance_on_parallel_against_geodesic_integration():
+    """
+    plateCarreeResolution's geodesic arc (geographiclib's a12 in the reference, resample.py:36-61) against an
+    independent computation: the geodesic equations on the WGS84 ellipsoid integrated numerically and shot from
+    one end point to the other (Clairaut's relation then gives the arc on the auxiliary sphere).
+    """
+    import math
+    from scipy.integrate import solve_ivp
+    from scipy.optimize import brentq
+    from auromat_amd.coordinates.geodesic import WGS84_a_m, WGS84_f, angularDistanceOnParallel
+    from auromat_amd.mapping.mapping import BoundingBox
+    from auromat_amd.resample import plateCarreeResolution
+    f, a = WGS84_f, WGS84_a_m
+    e2 = f * (2 - f)
+
+    def shoot(lat, dlon):
+        phi1, target = math.radians(lat), math.radians(dlon)
+
+        def rhs(s, y):
+            phi, lam, al = y
+            w = math.sqrt(1 - e2 * math.sin(phi) ** 2)
+            return [math.cos(al) * w ** 3 / (a * (1 - e2)), math.sin(al) * w / (a * math.cos(phi)),
+                    math.sin(al) * math.tan(phi) * w / a]
+
+        def back_on_parallel(s, y):
+            return y[0] - phi1
+        back_on_parallel.terminal = True
+        back_on_parallel.direction = -1 if lat >= 0 else 1
+
+        def miss(alpha1):
+            sol = solve_ivp(rhs, [0, 3e7], [phi1, 0.0, alpha1], events=back_on_parallel, rtol=1e-12, atol=1e-12,
+                            max_step=2e5)
+            return sol.y_events[0][0][1] - target
+        a1 = brentq(miss, 1e-6, math.pi / 2 - 1e-9, xtol=1e-14) if lat >= 0 else \
+            brentq(miss, math.pi / 2 + 1e-9, math.pi - 1e-6, xtol=1e-14)
+        beta = math.atan((1 - f) * math.tan(phi1))
+        s1 = math.atan2(math.sin(beta), math.cos(a1) * math.cos(beta))
+        return math.degrees(abs((math.pi if lat >= 0 else -math.pi) - 2 * s1))      # symmetric: sigma2 = +-pi - sigma1
+
+    for lat, dlon in ((55.0, 25.0), (-57.5, 25.5), (80.0, 120.0), (30.0, 1.0), (10.0, 40.0)):
+        assert abs(angularDistanceOnParallel(lat, dlon) / shoot(lat, dlon) - 1) < 1e-9, (lat, dlon)
+    # equator, symmetry, the sphere limit as a sanity bound (< 0.3 % apart), zero
+    assert angularDistanceOnParallel(0.0, 10.0) == 10.0 / (1 - f)
+    assert angularDistanceOnParallel(-40.0, 33.0) == angularDistanceOnParallel(40.0, -33.0)
+    assert angularDistanceOnParallel(12.0, 0.0) == 0.0
+    beta = math.atan((1 - f) * math.tan(math.radians(51.0)))
+    sphere = math.degrees(2 * math.asin(math.cos(beta) * math.sin(math.radians(10.3) / 2)))
+    assert abs(angularDistanceOnParallel(51.0, 20.6) / sphere - 1) < 3e-3
+    # plateCarreeResolution: latitude part exact, longitude part from the arc; across the dateline the same
+    lat_ppd, lon_ppd = plateCarreeResolution(BoundingBox(47.9, -102.2, 54.2, -91.9), 100)
+    assert lat_ppd == 36.0
+    assert abs(lon_ppd - angularDistanceOnParallel(51.05, 10.3) / (100 / 3600.0) / (-91.9 + 102.2)) < 1e-9
+    assert plateCarreeResolution(BoundingBox(-5, 170, 5, -170), 200) == \
+        plateCarreeResolution(BoundingBox(-5, -10, 5, 10), 200)
