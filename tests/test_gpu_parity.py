@@ -387,3 +387,38 @@ def test_c_abi_error_behaviour(native):
     ctx.call('amt_georef_frame', C.byref(p), C.byref(good))
     ctx.synchronize()
     assert torch.isfinite(lat).any()
+
+
+@pytest.mark.parametrize('pointing', ['iss030', 'iss029'])
+def test_reference_mapping_test_call_sequence(native, pointing):
+    """
+    The reference's own mapping_test.py:24-42 / resample_test.py:105-108 call sequence on the north and south
+    fixtures' headers: checkGuarantees before and after maskedByElevation, resample(arcsecPerPx=100, method='mean'),
+    bounding boxes equal to one decimal.
+    """
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.resample import plateCarreeResolution, resample
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 530, 354
+    hdr, cam, t = frame_header(w, h, pointing)
+    m = ArraySpacecraftMapping(hdr, 110, frame_image(w, h, seed=9), cam, t, pointing, fastCenterCalculation=True)
+    m.checkGuarantees()
+    m2 = m.maskedByElevation(10)
+    m2.checkGuarantees()
+    assert np.any(~(ma.getmaskarray(m.latsCenter) == ma.getmaskarray(m2.latsCenter)))
+    assert np.any(~(ma.getmaskarray(m.lats) == ma.getmaskarray(m2.lats)))
+    m3 = resample(m2, arcsecPerPx=100, method='mean')
+    m3.checkGuarantees()
+    m3.checkPlateCarree()
+    lat_ppd, lon_ppd = plateCarreeResolution(m2.boundingBox, 100)
+    assert lat_ppd == 36.0 and 10 < lon_ppd < 36
+    # 100 arcsec per pixel: latitude spacing exactly 1/36 deg, longitude spacing 1/lon_ppd up to the global grid's rounding
+    dlat = np.abs(np.diff(m3.latsCenter.data[:, 0]))
+    dlon = np.abs(np.diff(m3.lonsCenter.data[0, :]))
+    np.testing.assert_allclose(dlat, 1 / 36.0, rtol=1e-9)
+    np.testing.assert_allclose(dlon, 360.0 / round(lon_ppd * 360), rtol=1e-9)
+    b1, b3 = m2.boundingBox, m3.boundingBox
+    np.testing.assert_allclose([b3.latSouth, b3.lonWest, b3.latNorth, b3.lonEast],
+                               [b1.latSouth, b1.lonWest, b1.latNorth, b1.lonEast], atol=0.15)   # 'approx_equal(.., 1)'
+    # the resampled image only holds values of the source image's range, and something was binned
+    assert m3.img.count() > 0 and m3.img.max() <= m2.img.max()
