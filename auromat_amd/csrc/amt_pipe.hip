@@ -215,8 +215,7 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
     ctx->ws_bytes = pipe->coarse_ws_bytes;
     const double thr = std::isinf(min_elevation) ? min_elevation : min_elevation - 0.5;
     const int shorter = p->width < p->height ? p->width : p->height;
-    static const int max_stride = std::getenv("AMT_COARSE_STRIDE") ? std::atoi(std::getenv("AMT_COARSE_STRIDE")) : kCoarseStride;
-    const int stride = std::max(1, std::min(max_stride, shorter / 128));
+    const int stride = std::max(1, std::min(kCoarseStride, shorter / 128));
     int rc = amt_georef_coarse_bbox(ctx, p, stride, thr, magnetic ? 1 : 0, pipe->host_small_dev);
     pipe->coarse_ws = ctx->ws;
     pipe->coarse_ws_bytes = ctx->ws_bytes;
