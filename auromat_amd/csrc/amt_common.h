@@ -514,18 +514,18 @@ inline axis_lin make_axis_lin(const axis_dev& a) {
     return l;
 }
 
-// Common path of bin_index for a uniform axis: 1-based bin, or 0 for an outlier / NaN.  `slow` is set when the
-// value needs the general routine (first guess off by one, or v >= last edge where the right-edge rule decides).
+// Common path of bin_index for a uniform axis.  t = (v - e0) / step locates v to ~1e-12 bins (two roundings of
+// the expression, and the edges np.linspace produces differ from e0 + i step by rounding only), so whenever the
+// fractional part of t keeps 1e-7 away from 0 and 1 the bin floor(t) is certain and no edge needs evaluating.
+// Everything else — within 1e-7 of an edge, outside the axis, NaN — sets `slow` and is decided exactly by
+// bin_index (a handful of pixels per frame).  Returns the 1-based bin, 0 when `slow` is set.
 __device__ __forceinline__ int bin_fast(const axis_lin& ax, double v, bool& slow) {
-#pragma clang fp contract(off)
-    int g = (int)((v - ax.e0) * ax.inv_step);
-    g = g < 0 ? 0 : (g > ax.nbin - 1 ? ax.nbin - 1 : g);
-    const double lo = (double)g * ax.step + ax.e0;
-    const double hi_lin = (double)(g + 1) * ax.step + ax.e0;
-    const double hi = g + 1 >= ax.nbin ? ax.e_last : hi_lin;
-    const bool in = (v >= lo) && (v < hi);
-    slow = !in && (v >= ax.e0);
-    return in ? g + 1 : 0;
+    const double t = (v - ax.e0) * ax.inv_step;
+    const double fl = floor(t);
+    const double fr = t - fl;
+    const bool sure = fr > 1e-7 && fr < 1.0 - 1e-7 && fl >= 0.0 && fl < (double)ax.nbin;     // false for NaN
+    slow = !sure;
+    return sure ? (int)fl + 1 : 0;
 }
 
 constexpr double kFix = 4294967296.0;   // 2^32: elevation sums are kept in signed 31.32 fixed point
