@@ -400,8 +400,13 @@ constexpr int kBinW = 8, kBinCells = kBinW * kBinW;
 #ifndef AMT_ROWS_MIN_WAVES
 #define AMT_ROWS_MIN_WAVES 5
 #endif
+// the fused variants sit right at the 96-VGPR edge of 5 waves and measured the same at 4 and 5 waves per SIMD:
+// give the allocator the room of 4 (128 VGPRs) rather than risk a spill
+#ifndef AMT_ROWS_MIN_WAVES_BIN
+#define AMT_ROWS_MIN_WAVES_BIN 4
+#endif
 template <bool FAST, bool DIRS_IN, bool MAG, int BIN>
-__global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
+__global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : (BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES)) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
                                                            int n_items, int n_frames) {
     constexpr int kBinWaves = BIN ? kRowsThreads / 64 : 1, kBinSlots = BIN ? kBinCells : 1;
     __shared__ unsigned int sCnt[kBinWaves][kBinSlots];
@@ -495,17 +500,46 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
 #pragma unroll
         for (int k = 0; k < 6; ++k) sBox[wave][k][lane] = (k & 1) ? -kInf : kInf;
     }
-    // Image pixel of the NEXT iteration's centre row, loaded one iteration ahead.  Loads and stores share one
-    // counter and the compiler waits for all of them when both kinds are in flight, so where the loaded words
-    // are first touched decides how long the wave waits for its own earlier stores (see below).
-    unsigned int raw0 = 0, raw1 = 0;                  // raw words as loaded; unpacked only after the wait
-    int img_shift = 0;
+    // Image pixels are loaded ahead, two rows per wait: loads and stores share one counter and the compiler waits
+    // for all of them when both kinds are in flight, so every wait for a pixel also waits for the wave's own
+    // earlier stores.  The even step of each pair of rows waits once (right before its first store, see below),
+    // takes its own pixel (A), sets the odd step's pixel (B) aside and issues the loads for the next pair.
+    unsigned int rawA0 = 0, rawA1 = 0, rawB0 = 0, rawB1 = 0;      // raw words as loaded; unpacked only after the wait
+    unsigned int curB0 = 0, curB1 = 0;
+    int shiftA = 0, shiftB = 0, curShiftB = 0;
+    // byte offsets into the image fit 32 bits (the host checks): half the address arithmetic of 64-bit indices
+    const unsigned int img_last = (unsigned int)((int64_t)A.width * A.height * (BIN == 1 ? 3 : 6) - 8);
+    auto load_pixel = [&](unsigned int byte_offset, unsigned int& w0, unsigned int& w1, int& shift) {
+        // one aligned 8-byte load covers the 3 (uint8) or 6 (uint16) bytes of the pixel wherever it starts; the
+        // address is clamped so that the load never reaches past the image
+        unsigned int a = byte_offset & ~3u;
+        a = a > img_last ? img_last : a;
+        shift = (int)(byte_offset - a) * 8;
+        uint2 w2;
+        __builtin_memcpy(&w2, static_cast<const unsigned char*>(A.bin_img) + a, 8);
+        w0 = w2.x;
+        w1 = w2.y;
+    };
+    auto unpack_pixel = [&](unsigned int w0, unsigned int w1, int shift, unsigned int& c0, unsigned int& c1, unsigned int& c2) {
+        if (BIN == 1) {
+            const unsigned int w = (unsigned int)((((unsigned long long)w1 << 32) | w0) >> shift);   // shift <= 40
+            c0 = w & 0xffu, c1 = (w >> 8) & 0xffu, c2 = (w >> 16) & 0xffu;
+        } else {
+            // shift is 0 or 16 (or 16 at the clamped end): two 32-bit funnel shifts
+            const unsigned int lo = __builtin_amdgcn_alignbit(w1, w0, (unsigned int)shift), hi = w1 >> shift;
+            c0 = lo & 0xffffu, c1 = lo >> 16, c2 = hi & 0xffffu;
+        }
+    };
 
     // element indices of this lane's corner (row gy) and pixel (row gy-1), advanced by one row per step: keeps
     // the quarter-rate 64-bit multiplies out of the loop
     int64_t gi_corner = (int64_t)y0 * W1 + gx;
     int64_t gi_pixel = (int64_t)(y0 - 1) * A.width + gx;
-    auto step = [&](const int r, const row_state& prev, row_state& cur) {
+    // byte offset of pixel (gy-1, gx) in the image and of one image row (unsigned wrap-around for row -1 is harmless:
+    // only offset + k rows with k >= 1 is ever used)
+    const unsigned int img_row = (unsigned int)A.width * (BIN == 1 ? 3u : 6u);
+    unsigned int img_off = (unsigned int)gi_pixel * (BIN == 1 ? 3u : 6u);
+    auto step = [&](const int r, const bool even, const row_state& prev, row_state& cur) {
         const int gy = y0 + r;
         unsigned int ch0 = 0, ch1 = 0, ch2 = 0;          // image pixel (gy-1, gx)
         // ---- corner (gy, gx) ------------------------------------------------------------------
@@ -529,32 +563,17 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
                 ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), p.x, p.y, p.z, la, lo);
             }
             if (BIN) {
-                // The wait for the prefetched pixel sits here, right before this iteration's first store: the
-                // counter also covers stores, and the youngest one (the centre row of the previous iteration)
-                // was issued a whole corner computation ago.
-                asm volatile("" : "+v"(raw0), "+v"(raw1));
-                {
-                    // the pixel's bytes sit `img_shift` bits into the 8 aligned bytes that were loaded
-                    const unsigned long long w = (((unsigned long long)raw1 << 32) | raw0) >> img_shift;
-                    if (BIN == 1) {
-                        ch0 = (unsigned int)w & 0xffu, ch1 = ((unsigned int)w >> 8) & 0xffu, ch2 = ((unsigned int)w >> 16) & 0xffu;
-                    } else {
-                        ch0 = (unsigned int)w & 0xffffu, ch1 = (unsigned int)w >> 16, ch2 = (unsigned int)(w >> 32) & 0xffffu;
-                    }
-                }
-                if (px_ok && r < rows) {
-                    // one aligned 8-byte load covers the 3 (uint8) or 6 (uint16) bytes of the pixel wherever it
-                    // starts; the address is clamped so that the load never reaches past the image
-                    const int64_t pix_bytes = BIN == 1 ? 3 : 6;
-                    const int64_t b = (gi_pixel + A.width) * pix_bytes;       // pixel (gy, gx): next step's centre row
-                    const int64_t last = (int64_t)A.width * A.height * pix_bytes - 8;
-                    int64_t a = b & ~(int64_t)3;
-                    a = a > last ? last : a;
-                    img_shift = (int)(b - a) * 8;
-                    uint2 w2;
-                    __builtin_memcpy(&w2, static_cast<const unsigned char*>(A.bin_img) + a, 8);
-                    raw0 = w2.x;
-                    raw1 = w2.y;
+                if (even) {
+                    // The one wait of this pair of rows sits here, right before the step's first store: the youngest
+                    // store in flight (the centre row of the previous step) was issued a whole corner computation ago.
+                    asm volatile("" : "+v"(rawA0), "+v"(rawA1), "+v"(rawB0), "+v"(rawB1));
+                    unpack_pixel(rawA0, rawA1, shiftA, ch0, ch1, ch2);      // pixel row gy-1: this step's centres
+                    curB0 = rawB0, curB1 = rawB1, curShiftB = shiftB;       // pixel row gy: the odd step's centres
+                    // next pair: pixel rows gy+1 (even step r+2) and gy+2 (odd step r+3)
+                    if (px_ok && r + 1 < rows) load_pixel(img_off + 2 * img_row, rawA0, rawA1, shiftA);
+                    if (px_ok && r + 2 < rows) load_pixel(img_off + 3 * img_row, rawB0, rawB1, shiftB);
+                } else {
+                    unpack_pixel(curB0, curB1, curShiftB, ch0, ch1, ch2);
                 }
             }
             // the last corner row of a chunk is the first of the next one (which owns it) unless it is
@@ -702,15 +721,17 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : AMT_ROWS_MIN_WAVES
         }
         gi_corner += W1;
         gi_pixel += A.width;
+        img_off += img_row;
         cur.p = p;
         cur.d = d;
         cur.la = la;
         cur.lo = lo;
         cur.flag = flag_cur;
     };
+    if (BIN && px_ok && rows > 0) load_pixel(img_off + img_row, rawB0, rawB1, shiftB);       // pixel row y0: step 1
     for (int r = 0; r <= rows; r += 2) {
-        step(r, S0, S1);
-        if (r + 1 <= rows) step(r + 1, S1, S0); else S0 = S1;      // the last row's state ends up in S0
+        step(r, true, S0, S1);
+        if (r + 1 <= rows) step(r + 1, false, S1, S0); else S0 = S1;      // the last row's state ends up in S0
     }
     if (BIN && bin_anchor) {
         if (run_key) bin_flush(run_key, run_cnt, run_c0, run_c1, run_c2, run_el);
@@ -965,6 +986,7 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
         AMT_REQUIRE(ctx, out->bin_img && (out->bin_img_dtype == 1 || out->bin_img_dtype == 2),
                     "fused binning needs a uint8 (1) or uint16 (2) RGB image");
         AMT_REQUIRE(ctx, (int64_t)p->width * p->height >= 3, "fused binning needs at least 3 pixels");
+        AMT_REQUIRE(ctx, (int64_t)p->width * p->height * 6 < (1ll << 32), "fused binning: image larger than 4 GiB");
         AMT_REQUIRE(ctx, axis_ok(out->bin_xaxis) && axis_ok(out->bin_yaxis) && out->bin_xaxis->uniform &&
                              out->bin_yaxis->uniform, "fused binning needs two uniform axes");
         AMT_REQUIRE(ctx, out->bin_xaxis->nbin < 65535 && out->bin_yaxis->nbin < 65535, "at most 65534 bins per axis");
