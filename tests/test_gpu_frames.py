@@ -514,3 +514,42 @@ def test_batched_launch_and_sequence_hints_change_nothing():
     want = plain.process(mixed, keep_on_device=False)
     for a, b in zip(out, want):
         assert np.array_equal(a['mean'], b['mean'], equal_nan=True) and np.array_equal(a['count'], b['count'])
+
+
+def test_sequence_with_a_pole_frame_uint8_and_magnetic():
+    """Batches whose frames take different plans (a pole frame between ordinary ones), uint8 images, MLat/MLT grids."""
+    from auromat_amd.coordinates import transform as T
+    from auromat_amd.pipeline import FramePipeline, SequencePipeline
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    w, h = 96, 96
+    frames = []
+    for k in range(6):
+        hdr, cam, t, seed = sequence_frame(k, w, h)
+        frames.append((hdr, cam, t, frame_image(w, h, seed=seed, dtype=np.uint8)))
+    t = datetime(2012, 1, 25, 9, 26, 55)
+    zen = T.mat_j2000_to_geo(T.date2es(t)).T.dot([0.0, 0.0, 1.0])
+    bore = -zen
+    pole_hdr = {'CTYPE1': 'RA---TAN', 'CTYPE2': 'DEC--TAN', 'LONPOLE': 180.0, 'LATPOLE': 0.0,
+                'CRVAL1': np.rad2deg(np.arctan2(bore[1], bore[0])) % 360, 'CRVAL2': np.rad2deg(np.arcsin(bore[2])),
+                'CRPIX1': w / 2 + 0.5, 'CRPIX2': h / 2 + 0.5, 'CD1_1': -0.5, 'CD1_2': 0.0, 'CD2_1': 0.0, 'CD2_2': 0.5,
+                'IMAGEW': w, 'IMAGEH': h}
+    mixed = frames[:3] + [(pole_hdr, zen * (6356.75 + 400.0), t, frames[0][3])] + frames[3:]
+    ref_pipe = FramePipeline(w, h, img_dtype=np.uint8)
+    ref = [ref_pipe.run(hd, 110, cam, tt, img=img, pxPerDeg=3) for hd, cam, tt, img in mixed]
+    for batch in (1, 2, 3):
+        seq = SequencePipeline(w, h, img_dtype=np.uint8, pxPerDeg=3, batch=batch)
+        out = seq.process(mixed, keep_on_device=False)
+        assert seq.plans == ['single-pass'] * 3 + ['two-pass'] + ['single-pass'] * 3
+        assert out[3]['contains_pole']
+        for a, b in zip(out, ref):
+            for key in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
+                assert np.array_equal(a[key], b[key], equal_nan=True), (batch, key)
+            assert a['img'].dtype == np.uint8
+    # MLat/MLT grids through the sequence loop, hints included
+    mag_ref_pipe = FramePipeline(w, h, img_dtype=np.uint8, with_mag=True)
+    mag_ref = [mag_ref_pipe.run(hd, 110, cam, tt, img=img, pxPerDeg=3, magnetic=True) for hd, cam, tt, img in frames]
+    seq = SequencePipeline(w, h, img_dtype=np.uint8, pxPerDeg=3, magnetic=True)
+    out = seq.process(frames * 2, keep_on_device=False)
+    assert seq.hinted > 0
+    for a, b in zip(out, mag_ref * 2):
+        assert np.array_equal(a['mean'], b['mean'], equal_nan=True) and np.array_equal(a['count'], b['count'])
