@@ -95,8 +95,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    # AMT_BENCH_FORCE_DIST=1 exercises the RCCL gather path with a single rank (boxes with one GPU)
+    use_dist = world > 1 or bool(os.environ.get('AMT_BENCH_FORCE_DIST'))
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29541')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     from auromat_amd.pipeline import SequencePipeline
     from auromat_amd.sequence import gather_device
@@ -125,12 +129,16 @@ def main():
         frames = [(frame_params(h, (100, 110, 120)[k % 3], c, t, fast, magnetic=True), c, t, None)
                   for k, (h, c, t, _) in enumerate(frames)]
 
-    seq.process(frames[:args.warmup])
+    warm = seq.process(frames[:args.warmup])
+    if use_dist and warm:
+        # first-call costs of the gather path (RCCL channels, torch.cat, allocations) belong to the warm-up as well
+        gather_device(warm, [rank * total + k for k in range(len(warm))], ctx.device)
+    del warm
     ctx.timing_enable(TIMING_EVERY)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -140,12 +148,12 @@ def main():
     plans = list(seq.plans)
     hinted = seq.hinted
     gathered = None
-    if world > 1:
+    if use_dist:
         # device-to-device over xGMI; rank 0 unpacks to the host after the timed region
         gathered = gather_device(results, [rank * total + args.warmup + k for k in range(args.steps)], ctx.device)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -234,7 +242,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -553,3 +553,28 @@ def test_sequence_with_a_pole_frame_uint8_and_magnetic():
     assert seq.hinted > 0
     for a, b in zip(out, mag_ref * 2):
         assert np.array_equal(a['mean'], b['mean'], equal_nan=True) and np.array_equal(a['count'], b['count'])
+
+
+def test_gather_over_rccl_single_rank():
+    """run_sequence() with an initialised "nccl" (= RCCL) process group of one rank: the collectives of the gather
+    (all_gather of sizes, padded gather of [descriptors | payload]) run on device tensors."""
+    import torch
+    import torch.distributed as dist
+    from auromat_amd.sequence import run_sequence
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    w, h = 200, 140
+    frames = []
+    for k in range(4):
+        hdr, cam, t, seed = sequence_frame(k, w, h)
+        frames.append((hdr, cam, t, frame_image(w, h, seed=seed)))
+    plain = run_sequence(frames, w, h, pxPerDeg=6)            # no process group: local packing only
+    store = dist.TCPStore('127.0.0.1', 29533, 1, True)
+    dist.init_process_group('nccl', store=store, rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        got = run_sequence(frames, w, h, pxPerDeg=6)
+    finally:
+        dist.destroy_process_group()
+    assert [f['index'] for f in got] == [0, 1, 2, 3]
+    for a, b in zip(got, plain):
+        assert np.array_equal(a['mean'], b['mean'], equal_nan=True) and np.array_equal(a['count'], b['count'])
+        assert (a['lat0'], a['lon0'], a['dlat'], a['dlon']) == (b['lat0'], b['lon0'], b['dlat'], b['dlon'])
