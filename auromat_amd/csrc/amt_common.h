@@ -364,21 +364,47 @@ __host__ inline bowring_fast make_bowring_fast(double a, double b) {
     return w;
 }
 
-// inv_r (optional out): 1 / |(x, y, z)|, a by-product the caller's elevation needs as well.
-__device__ __forceinline__ void ecef_to_geodetic_deg_fast(const bowring_fast& w, double x, double y, double z,
-                                                          double& lat_deg, double& lon_deg, double* inv_r = nullptr) {
+// Numerator and denominator of the Bowring latitude, lat = atan(n / d) with d > 0, and 1 / |(x, y, z)| as a
+// by-product (the caller's elevation needs it as well).
+__device__ __forceinline__ void bowring_fast_nd(const bowring_fast& w, double x, double y, double z, double& n, double& d,
+                                                double& inv_r) {
     const double p2 = x * x + y * y;
     double p, ip;
     fm::sqrt_rsqrt(p2, p, ip);
-    const double ir = fm::rsqrt(p2 + z * z);
-    if (inv_r) *inv_r = ir;
-    const double tu = w.b_over_a * z * fma(w.d, ir, 1.0) * ip;
+    inv_r = fm::rsqrt(p2 + z * z);
+    const double tu = w.b_over_a * z * fma(w.d, inv_r, 1.0) * ip;
     const double tu2 = tu * tu;
     const double c = fm::rsqrt(1.0 + tu2);
     const double cu3 = c * c * c;
     const double su3 = cu3 * tu2 * tu;
-    lat_deg = fm::atan_pos_deg(fma(w.d, su3, z), fma(-w.e2a, cu3, p));
+    n = fma(w.d, su3, z);
+    d = fma(-w.e2a, cu3, p);
+}
+
+// inv_r (optional out): 1 / |(x, y, z)|
+__device__ __forceinline__ void ecef_to_geodetic_deg_fast(const bowring_fast& w, double x, double y, double z,
+                                                          double& lat_deg, double& lon_deg, double* inv_r = nullptr) {
+    double n, d, ir;
+    bowring_fast_nd(w, x, y, z, n, d, ir);
+    if (inv_r) *inv_r = ir;
+    lat_deg = fm::atan_pos_deg(n, d);
     lon_deg = fm::atan2_deg(y, x);
+}
+
+// Angle in DEGREES from the plane vector (xr, yr) to (x, y), i.e. atan2(xr y - yr x, xr x + yr y), for the small
+// angles between neighbouring pixels: t (1 - t^2/3 + t^4/5 - t^6/7) with t = cross / dot.  `ok` is false (and the
+// value meaningless) when |t| > 0.03 (1.7 deg; the next term is then < 7e-14 relative), when dot <= 0 or for NaN:
+// the caller then evaluates the full arctangent.  One reciprocal + 11 multiply-adds instead of ~30 instructions.
+__device__ __forceinline__ double small_angle_deg(double xr, double yr, double x, double y, bool& ok) {
+    const double cross = xr * y - yr * x, dot = xr * x + yr * y;
+    const double t = cross * fm::rcp(dot);
+    const double s = t * t;
+    ok = s <= 9.0e-4 && dot > 0.0;
+    double q = -8.1851113590117602;              // -(180/pi)/7
+    q = fma(q, s, 11.459155902616464);           //  (180/pi)/5
+    q = fma(q, s, -19.098593171027442);          // -(180/pi)/3
+    q = fma(q, s, 57.295779513082323);           //   180/pi
+    return q * t;
 }
 
 // True when the closed longitude path o00 -> o01 -> o11 -> o10 -> o00 (corner quad of one pixel, degrees)

@@ -395,18 +395,16 @@ __device__ __forceinline__ T karg_load(karg_ptr base, size_t byte_offset) {
 constexpr int kBinW = 8, kBinCells = kBinW * kBinW;
 
 // BIN: 0 = no fused binning, 1 = uint8 RGB image, 2 = uint16 RGB image
-// Minimum waves per SIMD the register allocator must reach: with the bounding-box state in LDS the fused
-// variants fit 96 VGPRs (5 waves) without spilling; the magnetic + fused variant would spill and is exempt.
+// Minimum waves per SIMD the register allocator must reach: 5 for the georef-only variants (they need 66-96
+// VGPRs), 4 for the fused ones (119-128 VGPRs; 4 and 5 waves measured the same while they still fitted 96).
 #ifndef AMT_ROWS_MIN_WAVES
 #define AMT_ROWS_MIN_WAVES 5
 #endif
-// the fused variants sit right at the 96-VGPR edge of 5 waves and measured the same at 4 and 5 waves per SIMD:
-// give the allocator the room of 4 (128 VGPRs) rather than risk a spill
 #ifndef AMT_ROWS_MIN_WAVES_BIN
 #define AMT_ROWS_MIN_WAVES_BIN 4
 #endif
 template <bool FAST, bool DIRS_IN, bool MAG, int BIN>
-__global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : (BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES)) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
+__global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
                                                            int n_items, int n_frames) {
     constexpr int kBinWaves = BIN ? kRowsThreads / 64 : 1, kBinSlots = BIN ? kBinCells : 1;
     __shared__ unsigned int sCnt[kBinWaves][kBinSlots];
@@ -482,9 +480,18 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : (BIN ? AMT_ROWS_MI
     struct row_state {
         vec3 p, d;
         double la, lo;
+        double bn, bd;      // Bowring numerator / denominator of the corner: lat = atan(bn / bd)
+        double bla, blo;    // what the bounding box is reduced over when that is not (la, lo): MLat / SM longitude
         int flag;
     };
-    row_state S0 = {{NAN, NAN, NAN}, {NAN, NAN, NAN}, NAN, NAN, 0}, S1 = S0;
+    row_state S0 = {{NAN, NAN, NAN}, {NAN, NAN, NAN}, NAN, NAN, NAN, NAN, NAN, NAN, 0}, S1 = S0;
+    // Neighbouring pixels differ by a fraction of a degree, so latitude and longitude of a corner are taken as
+    // the previous row's plus a small angle (small_angle_deg: one reciprocal and a 4-term series instead of a
+    // range-reduced 9-term arctangent), and a centre's as its corner's plus a small angle.  The full arctangent
+    // runs where that does not apply: first row of a chunk, previous row missed the shell, steps above 1.7 deg at
+    // the limb, within 2 deg of the date line.
+    constexpr bool kDiff = true;
+    constexpr bool kMagBox = MAG && BIN != 0;      // the box may be asked for in (MLat, SM longitude): bla / blo
     int n_valid = 0;
     auto box_add = [&](double la_v, double lo_v) {
         __hip_atomic_fetch_min(&sBox[wave][0][lane], la_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : (BIN ? AMT_ROWS_MI
         unsigned int ch0 = 0, ch1 = 0, ch2 = 0;          // image pixel (gy-1, gx)
         // ---- corner (gy, gx) ------------------------------------------------------------------
         vec3 d = {NAN, NAN, NAN}, p = {NAN, NAN, NAN};
-        double la = NAN, lo = NAN;
+        double la = NAN, lo = NAN, bn = NAN, bd = NAN, bla = NAN, blo = NAN;
         if (col_ok) {
             const int64_t gi = gi_corner;
             karg_ptr K = karg_fresh(koff);
@@ -560,7 +567,16 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : (BIN ? AMT_ROWS_MI
             if (hit) {
                 p = quadric_point(ray, d, t);        // already in GEO
                 K = karg_fresh(koff);
-                ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), p.x, p.y, p.z, la, lo);
+                double ir;
+                bowring_fast_nd(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), p.x, p.y, p.z, bn, bd, ir);
+                bool ok_la = false, ok_lo = false;
+                if (kDiff) {
+                    la = prev.la + small_angle_deg(prev.bd, prev.bn, bd, bn, ok_la);
+                    lo = prev.lo + small_angle_deg(prev.p.x, prev.p.y, p.x, p.y, ok_lo);
+                    ok_lo = ok_lo && fabs(prev.lo) < 178.0;
+                }
+                if (!ok_la) la = fm::atan_pos_deg(bn, bd);
+                if (!ok_lo) lo = fm::atan2_deg(p.y, p.x);
             }
             if (BIN) {
                 if (even) {
@@ -594,9 +610,13 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : (BIN ? AMT_ROWS_MI
                         A.mlt[gi] = mt;
                     }
                     if (magbox) {
-                        la = ml;                                  // from here on only the bounding box reads them
-                        lo = (mt - 12.0) / (24.0 / 360.0);        // mltToSmLon, reference transform.py:388-401
+                        bla = ml;
+                        blo = (mt - 12.0) / (24.0 / 360.0);       // mltToSmLon, reference transform.py:388-401
                     }
+                }
+                if (kMagBox && !magbox) {
+                    bla = la;
+                    blo = lo;
                 }
             }
         }
@@ -635,9 +655,16 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : (BIN ? AMT_ROWS_MI
                 double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN;
                 if (pc.x == pc.x) {
                     karg_ptr K = karg_fresh(koff);
-                    double inv_r;
-                    ecef_to_geodetic_deg_fast(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), pc.x, pc.y, pc.z, lac, loc,
-                                              &inv_r);
+                    double inv_r, cn, cd;
+                    bowring_fast_nd(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), pc.x, pc.y, pc.z, cn, cd, inv_r);
+                    bool ok_la = false, ok_lo = false;
+                    if (kDiff) {                 // relative to this lane's corner of the current row
+                        lac = la + small_angle_deg(bd, bn, cd, cn, ok_la);
+                        loc = lo + small_angle_deg(p.x, p.y, pc.x, pc.y, ok_lo);
+                        ok_lo = ok_lo && fabs(lo) < 178.0;
+                    }
+                    if (!ok_la) lac = fm::atan_pos_deg(cn, cd);
+                    if (!ok_lo) loc = fm::atan2_deg(pc.y, pc.x);
                     // reference astrometry.py:200-212, utils.py:33-46: 90 - angle(-d, P/|P|) = asin(-d.P/|P|)
                     // (dot products do not depend on the frame; 1/|P| is a by-product of the Bowring step)
                     double c = -(dc.x * pc.x + dc.y * pc.y + dc.z * pc.z) * inv_r;
@@ -716,7 +743,11 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : (BIN ? AMT_ROWS_MI
                 const int vi = valid ? 1 : 0;
                 flag_cur = vi | from_prev_lane(vi);
                 n_valid += vi;
-                if ((prev.flag | flag_cur) && prev.la == prev.la) box_add(prev.la, prev.lo);
+                if (kMagBox) {
+                    if ((prev.flag | flag_cur) && prev.bla == prev.bla) box_add(prev.bla, prev.blo);
+                } else {
+                    if ((prev.flag | flag_cur) && prev.la == prev.la) box_add(prev.la, prev.lo);
+                }
             }
         }
         gi_corner += W1;
@@ -726,6 +757,12 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : (BIN ? AMT_ROWS_MI
         cur.d = d;
         cur.la = la;
         cur.lo = lo;
+        cur.bn = bn;
+        cur.bd = bd;
+        if (kMagBox) {
+            cur.bla = bla;
+            cur.blo = blo;
+        }
         cur.flag = flag_cur;
     };
     if (BIN && px_ok && rows > 0) load_pixel(img_off + img_row, rawB0, rawB1, shiftB);       // pixel row y0: step 1
@@ -756,7 +793,11 @@ __global__ __launch_bounds__(kRowsThreads, (MAG && BIN) ? 1 : (BIN ? AMT_ROWS_MI
     }
     if (want_bbox) {
         // the chunk's last corner row only has centres above it inside this chunk
-        if (S0.flag && S0.la == S0.la) box_add(S0.la, S0.lo);
+        if (kMagBox) {
+            if (S0.flag && S0.bla == S0.bla) box_add(S0.bla, S0.blo);
+        } else {
+            if (S0.flag && S0.la == S0.la) box_add(S0.la, S0.lo);
+        }
         double v[7];
 #pragma unroll
         for (int k = 0; k < 6; ++k)
