@@ -88,8 +88,9 @@ def pole_in_view(params, min_elevation=None, magnetic=False):
     return 0
 
 
-def georef_into(fd, params, geo=True, mag=False, bbox_min_elevation=None):
-    """Launch the fused kernel writing the requested output groups into `fd` (allocating them)."""
+def georef_into(fd, params, geo=True, mag=False, bbox_min_elevation=None, dirs=None):
+    """Launch the fused kernel writing the requested output groups into `fd` (allocating them).
+    `dirs`: device tensor (h+1, w+1, 3) of corner directions in J2000 instead of the TAN camera model."""
     h, w = fd.height, fd.width
     out = GeorefOut()
     ctx = fd.ctx
@@ -106,7 +107,10 @@ def georef_into(fd, params, geo=True, mag=False, bbox_min_elevation=None):
         fd.bbox = ctx.empty((8,))
         out.bbox = fd.bbox.data_ptr()
         out.bbox_min_elevation = float(bbox_min_elevation)
-    ctx.call('amt_georef_frame', C.byref(params), C.byref(out))
+    if dirs is not None:
+        ctx.call('amt_georef_frame_dirs', C.byref(params), ptr(dirs), C.byref(out))
+    else:
+        ctx.call('amt_georef_frame', C.byref(params), C.byref(out))
     return fd
 
 
@@ -221,6 +225,71 @@ class BaseAstrometryMapping(BaseMapping):
     def createResampled(self, lats, lons, latsCenter, lonsCenter, elevation, img):
         return GenericMapping(lats, lons, latsCenter, lonsCenter, elevation, self.altitude, img,
                               self.cameraPosGCRS, self.photoTime, self.identifier, metadata=self.metadata)
+
+
+class DirectionArrayMapping(BaseAstrometryMapping):
+    """
+    A mapping whose camera model is given as an array of line-of-sight unit vectors, one per pixel corner, in
+    J2000 / GCRS — the hook for camera models other than a TAN WCS: all-sky calibrations (reference
+    miracle.py:196-258 builds such vectors from azimuth / elevation tables), SIP-distorted or non-TAN WCS solutions
+    evaluated by another library, THEMIS-style reprojections.  Everything downstream of the direction generator
+    is the same kernel (``amt_georef_frame_dirs``: shell intersection, geodetic and geomagnetic coordinates,
+    elevation, masks); centres are the mean of their four corner hits (the reference's fast mode, which is also
+    what miracle.py:139-160 does).
+    """
+
+    def __init__(self, cornerDirections, alti, img, cameraPosGCRS, photoTime, identifier, metadata=None):
+        d = np.ascontiguousarray(cornerDirections, dtype=np.float64)
+        img = np.asarray(img)
+        assert d.ndim == 3 and d.shape[2] == 3 and img.ndim == 3
+        assert d.shape[:2] == (img.shape[0] + 1, img.shape[1] + 1), 'one direction per pixel corner'
+        hdr = {'IMAGEW': img.shape[1], 'IMAGEH': img.shape[0]}
+        BaseAstrometryMapping.__init__(self, hdr, alti, cameraPosGCRS, photoTime, identifier, metadata or {},
+                                       fastCenterCalculation=True)
+        self._dirs = d
+        self._dirs_dev = None
+        self._img_array = img
+
+    def _params(self):
+        p = FrameParams()
+        p.width, p.height, p.fast_center = self._wcsHeader['IMAGEW'], self._wcsHeader['IMAGEH'], 1
+        p.cd[:] = [1.0, 0.0, 0.0, 1.0]                     # the camera-model block is not used with directions
+        p.rot[:] = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]
+        p.cam[:] = [float(v) for v in self.cameraPosGCRS]
+        p.a, p.b = wgs84A + self.altitude, wgs84B + self.altitude
+        p.a0, p.b0 = wgs84A, wgs84B
+        et = date2es(self.photoTime)
+        p.m_geo[:] = list(mat_j2000_to_geo(et).ravel())
+        p.m_sm[:] = list(mat_j2000_to_sm(et).ravel())
+        return p
+
+    def _dirs_tensor(self, ctx):
+        if self._dirs_dev is None:
+            self._dirs_dev = ctx.to_device(self._dirs)
+        return self._dirs_dev
+
+    def frame(self):
+        if self._frame is None:
+            ctx = Context.current()
+            fd = FrameData(ctx, self._wcsHeader['IMAGEH'], self._wcsHeader['IMAGEW'])
+            georef_into(fd, self._params(), geo=True, dirs=self._dirs_tensor(ctx))
+            fd.set_image(self._img_array)
+            self._frame = fd
+        return self._frame
+
+    def _mlatmlt_tensors(self, center):
+        fd = self.frame()
+        if fd.mlat is None:
+            georef_into(fd, self._params(), geo=False, mag=True, dirs=self._dirs_tensor(fd.ctx))
+        return (fd.mlat_c, fd.mlt_c) if center else (fd.mlat, fd.mlt)
+
+    @property
+    def cameraToPixelCornerDirection(self):
+        return self._dirs
+
+    @property
+    def cameraToPixelCenterDirection(self):
+        return self._cached('dir_center', lambda: self._calcCenters(self._dirs.copy()))
 
 
 def pixelDirection(fitsWcsHeader, corner=True):

@@ -578,3 +578,36 @@ def test_gather_over_rccl_single_rank():
     for a, b in zip(got, plain):
         assert np.array_equal(a['mean'], b['mean'], equal_nan=True) and np.array_equal(a['count'], b['count'])
         assert (a['lat0'], a['lon0'], a['dlat'], a['dlon']) == (b['lat0'], b['lon0'], b['dlat'], b['dlon'])
+
+
+def test_direction_array_mapping_for_other_camera_models():
+    """A camera model supplied as corner direction vectors (all-sky calibrations, SIP / non-TAN WCS)
+    goes through the same kernel; with the TAN model's own directions it reproduces the WCS mapping."""
+    from auromat_amd.mapping.astrometry import DirectionArrayMapping, pixelDirection
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.resample import resample
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 257, 173
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    img = frame_image(w, h, seed=4)
+    dirs = pixelDirection(hdr, corner=True)
+    assert dirs.shape == (h + 1, w + 1, 3)
+    a = DirectionArrayMapping(dirs, 110, img, cam, t, 'dirs')
+    b = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'wcs', fastCenterCalculation=True)
+    a.checkGuarantees()
+    for name in ('lats', 'lons', 'latsCenter', 'lonsCenter', 'elevation'):
+        x, y = getattr(a, name), getattr(b, name)
+        assert np.array_equal(ma.getmaskarray(x), ma.getmaskarray(y)), name
+        assert np.max(np.abs(x.compressed() - y.compressed())) < 1e-9, name
+    (mla, mlt), (mlb, mltb) = a.mLatMlt, b.mLatMlt
+    assert np.max(np.abs(mla.compressed() - mlb.compressed())) < 1e-9
+    assert np.max(np.abs(mlt.compressed() - mltb.compressed())) < 1e-9
+    ra, rb = resample(a.maskedByElevation(10), pxPerDeg=10), resample(b.maskedByElevation(10), pxPerDeg=10)
+    assert ra.img.shape == rb.img.shape
+    assert (ma.getmaskarray(ra.img) != ma.getmaskarray(rb.img)).sum() <= 6
+    # a different camera: every direction tilted by a fixed rotation is still a valid model (no WCS involved)
+    th = np.deg2rad(0.3)
+    rot = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    c = DirectionArrayMapping(dirs.dot(rot.T), 110, img, cam, t, 'tilted')
+    c.checkGuarantees()
+    assert np.nanmax(np.abs(c.lons.filled(np.nan) - b.lons.filled(np.nan))) > 0.01
