@@ -546,6 +546,12 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
     // only offset + k rows with k >= 1 is ever used)
     const unsigned int img_row = (unsigned int)A.width * (BIN == 1 ? 3u : 6u);
     unsigned int img_off = (unsigned int)gi_pixel * (BIN == 1 ? 3u : 6u);
+    // directions-in variant: the corner direction of the row after the current one
+    double dj0 = NAN, dj1 = NAN, dj2 = NAN;
+    if (DIRS_IN && col_ok) {
+        const double* q = A.dirs_in + 3 * gi_corner;
+        dj0 = q[0], dj1 = q[1], dj2 = q[2];
+    }
     auto step = [&](const int r, const bool even, const row_state& prev, row_state& cur) {
         const int gy = y0 + r;
         unsigned int ch0 = 0, ch1 = 0, ch2 = 0;          // image pixel (gy-1, gx)
@@ -556,7 +562,14 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
             const int64_t gi = gi_corner;
             karg_ptr K = karg_fresh(koff);
             if (DIRS_IN) {
-                const vec3 dj = {A.dirs_in[3 * gi], A.dirs_in[3 * gi + 1], A.dirs_in[3 * gi + 2]};
+                // the direction of this corner was loaded one row ahead; fetch the next row's now, so that its
+                // latency is covered by this row's arithmetic
+                vec3 dj = {dj0, dj1, dj2};
+                asm volatile("" : "+v"(dj.x), "+v"(dj.y), "+v"(dj.z));
+                if (r < rows) {
+                    const double* q = A.dirs_in + 3 * (gi + W1);
+                    dj0 = q[0], dj1 = q[1], dj2 = q[2];
+                }
                 d = mul(karg_load<mat3>(K, offsetof(georef_args, m_geo)), dj);       // J2000 -> GEO
             } else {
                 d = tan_direction_fast(karg_load<tan_wcs>(K, offsetof(georef_args, wcs_geo)), gx - 0.5, gy - 0.5);
