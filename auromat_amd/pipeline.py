@@ -13,15 +13,16 @@ Two execution plans give identical results:
   The host reads the 8 bounding-box doubles between 1 and 2 and lays out the grid
   (reference resample.py:220-241,281-299).
 
-* single-pass (``fuse=True``; geodetic grids without pole / discontinuity): the binning happens inside the
-  georeferencing kernel, so nothing is read back.  Because the grid depends on the bounding box the kernel
-  itself produces, a cheap pre-pass (amt_georef_coarse_bbox, every 16th corner) estimates the box, the
-  kernel bins into a *superset* grid aligned to the same global nodes, and the exact window is cropped in
-  amt_bin_frame_finalize_window once the exact box is known.  If the exact box is not inside the superset
-  (never observed; the margin is > 3 lattice steps) the two-pass plan runs instead.
+* single-pass (``fuse=True``; geodetic or MLat/MLT grids, also across the 180 deg discontinuity; not with a pole
+  in view): the binning happens inside the georeferencing kernel, so nothing is read back.  Because the grid
+  depends on the bounding box the kernel itself produces, an estimate of the box comes first — a cheap pre-pass
+  (every 16th corner ray) or, in a sequence, the exact box of the previous frame — the kernel bins into a
+  *superset* grid aligned to the same global nodes, and the exact window is cropped by the finalise kernel once
+  the exact box is known.  If the exact box is not inside the superset the two-pass plan runs instead.  The
+  orchestration is native code (include/auromat_hip.h: amt_pipe_*); :class:`FramePipeline` binds it.
 
-This is the path bench.py times and that ``auromat_amd.sequence`` shards over GPUs; the mapping classes
-give the same results lazily.
+:class:`SequencePipeline` software-pipelines a sequence of frames over several frame buffers (what bench.py times
+and ``auromat_amd.sequence`` shards over GPUs); the mapping classes give the same results lazily.
 """
 import ctypes as C
 
