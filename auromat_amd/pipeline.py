@@ -349,7 +349,7 @@ class SequencePipeline(object):
 
     def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, altitude=110, fast=True,
                  min_elevation=10.0, pxPerDeg=10, plan='single-pass', bin_stream=True, shared_image=None,
-                 magnetic=False, batch=2):
+                 magnetic=False, batch=3):
         import torch
         assert plan in ('single-pass', 'two-pass')
         try:

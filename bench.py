@@ -82,7 +82,7 @@ def main():
                          'two-pass: separate binning kernel that re-reads the centre arrays')
     ap.add_argument('--no-hints', action='store_true',
                     help='run the coarse bounding-box pre-pass for every frame instead of re-using the previous exact box')
-    ap.add_argument('--batch', type=int, default=2, choices=(1, 2, 3),
+    ap.add_argument('--batch', type=int, default=3, choices=(1, 2, 3),
                     help='frames per launch of the big kernel in the fused plan (amt_pipe_launch_many)')
     ap.add_argument('--streams', type=int, default=2, choices=(1, 2),
                     help='2: bin frame k beside the ray casting of frame k+1 on a second HIP stream')
