@@ -109,7 +109,7 @@ typedef struct amt_frame_params {
  * (mapping.py:845-864).  Slot 7 (pole containment, what geodesic.py:183 containsOrCrossesPole decides
  * from the outline) is left 0 here: with a camera model the host projects the pole into the frame
  * instead; amt_bbox_corners fills it for arbitrary grids. */
-typedef struct amt_axis amt_axis;   /* defined in the binning section below */
+struct amt_axis;                    /* defined in the binning section below */
 
 typedef struct amt_georef_out {
     double* lat;      /* corners, deg   (BaseAstrometryMapping.lats,  astrometry.py:118-144) */
@@ -131,8 +131,8 @@ typedef struct amt_georef_out {
      * The grid must be known before the launch: callers use a superset of the final grid, aligned to the
      * same global nodes (amt_georef_coarse_bbox), and crop in amt_bin_frame_finalize_window.
      * Both axes must be uniform; bin_img is (height, width, 3) uint8 (dtype 1) or uint16 (dtype 2). */
-    const amt_axis* bin_xaxis;     /* host pointers */
-    const amt_axis* bin_yaxis;
+    const struct amt_axis* bin_xaxis;     /* host pointers */
+    const struct amt_axis* bin_yaxis;
     const void* bin_img;
     uint64_t* bin_acc;
     int32_t bin_img_dtype;

@@ -222,3 +222,19 @@ def test_angular_distance_on_parallel_against_geodesic_integration():
     assert abs(lon_ppd - angularDistanceOnParallel(51.05, 10.3) / (100 / 3600.0) / (-91.9 + 102.2)) < 1e-9
     assert plateCarreeResolution(BoundingBox(-5, 170, 5, -170), 200) == \
         plateCarreeResolution(BoundingBox(-5, -10, 5, 10), 200)
+
+
+def test_public_header_is_plain_c():
+    """include/auromat_hip.h is the C ABI: it must compile as C99 (and C++) without a HIP toolchain."""
+    import subprocess
+    import tempfile
+    inc = os.path.join(ROOT, 'include')
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, cc, std in (('t.c', 'gcc', '-std=c99'), ('t.cpp', 'g++', '-std=c++11')):
+            src = os.path.join(tmp, name)
+            with open(src, 'w') as fp:
+                fp.write('#include "auromat_hip.h"\nint main(void) { amt_pipe_result r; amt_georef_out o; '
+                         'return (int)(sizeof(r) + sizeof(o)) == 0; }\n')
+            res = subprocess.run([cc, std, '-pedantic', '-Wall', '-Wextra', '-Werror', '-I', inc, '-c', src, '-o',
+                                  src + '.o'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+            assert res.returncode == 0, res.stdout
