@@ -41,6 +41,22 @@ def algorithmic_bytes(width, height, nchan=3, pix_bytes=2):
                 resample=(24 + nchan * pix_bytes) * npx)
 
 
+def measured_copy_gbs(device):
+    """Device-to-device copy rate (read + write bytes per second) of this GPU, for reading the roofline fraction
+    against something achievable beside the 8 TB/s spec figure.  Outside the timed region."""
+    import torch
+    n = 1 << 27                                    # 1 GiB of float64 each way
+    a = torch.empty(n, dtype=torch.float64, device=device).fill_(1.0)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    return 10 * 2 * n * 8 / (time.perf_counter() - t0) / 1e9
+
+
 def cpu_baseline(sample_rows):
     """Oracle (NumPy restatement of the reference) on the same workload, 1 core, rows [0, sample_rows)."""
     from oracle import ref_numpy as O
@@ -171,6 +187,7 @@ def main():
 
     if rank == 0:
         npx = WIDTH * HEIGHT
+        copy_gbs = measured_copy_gbs(ctx.device)
         ab = algorithmic_bytes(WIDTH, HEIGHT)
         info = ctx.device_info()
         res = results[-1]
@@ -221,6 +238,7 @@ def main():
             # DESIGN.md and profiles/), so the HBM fraction understates how busy the chip is.
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'measured_copy_GBs': copy_gbs, 'fp64_vector_peak_TFLOPs': 78.6,
                          # one launch covers `frames_per_launch` frames: bytes, traffic and duration are per launch
                          'frames_per_launch': fpl,
                          'traffic': (traffic.get(tkey, {}).get('hbm_bytes') or 0) * fpl or None,
