@@ -29,7 +29,8 @@ class GeorefOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ('lat', 'lon', 'lat_c', 'lon_c', 'elev', 'mlat', 'mlt', 'mlat_c',
                                           'mlt_c', 'bbox')] + [('bbox_min_elevation', C.c_double)] + \
                [(k, C.c_void_p) for k in ('bin_xaxis', 'bin_yaxis', 'bin_img', 'bin_acc')] + \
-               [(k, C.c_int32) for k in ('bin_img_dtype', 'bin_lon_wrap', 'bin_magnetic', 'item_order')]
+               [(k, C.c_int32) for k in ('bin_img_dtype', 'bin_lon_wrap', 'bin_magnetic', 'item_order')] + \
+               [('bin_events', C.c_void_p), ('bin_event_count', C.c_void_p), ('bin_event_capacity', C.c_int64)]
 
 
 class Axis(C.Structure):
@@ -49,7 +50,7 @@ class Grid(C.Structure):
 
 class PipeResult(C.Structure):
     """amt_pipe_result"""
-    _fields_ = [('status', C.c_int32), ('fused', C.c_int32), ('lon_wrapped', C.c_int32), ('reserved', C.c_int32),
+    _fields_ = [('status', C.c_int32), ('fused', C.c_int32), ('lon_wrapped', C.c_int32), ('edge_pixels', C.c_int32),
                 ('bbox', C.c_double * 8), ('grid', Grid)]
 
 

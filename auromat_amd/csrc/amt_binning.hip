@@ -327,6 +327,33 @@ __global__ void k_bin_finalize(unsigned long long* __restrict__ acc, int acc_nx,
     }
 }
 
+// On-edge pixels recorded by the fused binning (bin_event): now that the final grid is known — the window
+// [off_x, off_x+nx) x [off_y, off_y+ny) of the accumulator grid — each goes into the bin the reference's
+// right-most-edge rule gives it: a pixel on the lower edge of the first cell beyond the window sits on the LAST
+// edge of the final grid and belongs to the last bin; everywhere else the edge is an interior one and the pixel
+// stays in the cell above it.  One block; resets the counter for the next frame.
+__global__ void k_apply_bin_events(const bin_event* __restrict__ events, unsigned int* __restrict__ count,
+                                   unsigned long long* __restrict__ acc, int acc_nx, int acc_ny, int off_x, int off_y,
+                                   int nx, int ny) {
+    const unsigned int n = *count;
+    const int64_t plane = (int64_t)acc_nx * acc_ny;
+    for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) {
+        const bin_event ev = events[i];
+        int cx = ev.bx - 1, cy = ev.by - 1;
+        if ((ev.flags & 1u) && cx == off_x + nx) cx -= 1;
+        if ((ev.flags & 2u) && cy == off_y + ny) cy -= 1;
+        if (cx < 0 || cx >= acc_nx || cy < 0 || cy >= acc_ny) continue;
+        const int64_t cell = (int64_t)cx * acc_ny + cy;
+        atomicAdd(&acc[cell], 1ull);
+        atomicAdd(&acc[plane + cell], (unsigned long long)ev.c0);
+        atomicAdd(&acc[2 * plane + cell], (unsigned long long)ev.c1);
+        atomicAdd(&acc[3 * plane + cell], (unsigned long long)ev.c2);
+        atomicAdd(&acc[4 * plane + cell], (unsigned long long)ev.el);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *count = 0;
+}
+
 inline dim3 grid_for(int64_t n) {
     int64_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -335,6 +362,15 @@ inline dim3 grid_for(int64_t n) {
 }
 
 }  // namespace
+
+int amt_bin_apply_events_on(amt_ctx* ctx, hipStream_t stream, const void* events, uint32_t* count, uint64_t* acc,
+                            int32_t acc_nx, int32_t acc_ny, int32_t off_x, int32_t off_y, int32_t nx, int32_t ny) {
+    AMT_REQUIRE(ctx, events && count && acc, "NULL argument");
+    hipLaunchKernelGGL(k_apply_bin_events, dim3(1), dim3(kBlock), 0, stream, static_cast<const bin_event*>(events), count,
+                       reinterpret_cast<unsigned long long*>(acc), acc_nx, acc_ny, off_x, off_y, nx, ny);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
 
 int amt_bin_finalize_on(amt_ctx* ctx, hipStream_t stream, uint64_t* acc, int32_t acc_nx, int32_t acc_ny, int32_t off_x,
                         int32_t off_y, int32_t nx, int32_t ny, int32_t nchan, int32_t img_dtype, double* mean,

@@ -70,6 +70,9 @@ int amt_georef_launch(amt_ctx* ctx, const amt_frame_params* p, const double* dir
 #define AMT_MAX_BATCH 3
 int amt_georef_launch_many(amt_ctx* ctx, int n, const amt_frame_params* const* p, const amt_georef_out* const* out,
                            const amt_georef_tail* const* tail);
+// k_apply_bin_events on `stream` (before the finalise kernel): see bin_event
+int amt_bin_apply_events_on(amt_ctx* ctx, hipStream_t stream, const void* events, uint32_t* count, uint64_t* acc,
+                            int32_t acc_nx, int32_t acc_ny, int32_t off_x, int32_t off_y, int32_t nx, int32_t ny);
 // amt_bin_frame_finalize_window on `stream`; clear != 0 also zeroes every cell of the accumulator grid.
 int amt_bin_finalize_on(amt_ctx* ctx, hipStream_t stream, uint64_t* acc, int32_t acc_nx, int32_t acc_ny, int32_t off_x,
                         int32_t off_y, int32_t nx, int32_t ny, int32_t nchan, int32_t img_dtype, double* mean,
@@ -526,8 +529,22 @@ __device__ __forceinline__ int bin_index(const axis_dev& ax, double v) {
 // The five scalars of a uniform axis that the common path of the fused binning needs.
 struct axis_lin {
     double e0, e_last, step, inv_step;
+    double margin;      // fractional positions below this (just above an edge) take the exact path, see bin_fast
     int nbin, pad;
 };
+
+// A pixel that sits on a bin edge in the sense of the reference's right-most-edge rule (histogram.py:215-224:
+// v >= edge and around(v, decimal) == around(edge, decimal)).  For an interior edge that changes nothing, but the
+// fused kernel bins into a superset of the final grid: if the edge turns out to be the LAST edge of the final
+// grid, the reference counts the pixel into the last bin.  Such pixels (a few dozen per frame) are therefore not
+// binned by the kernel but recorded, and resolved when the final grid is known (k_apply_bin_events).
+struct bin_event {
+    int bx, by;                 // 1-based superset bins by plain searchsorted(edges, v, 'right')
+    unsigned int flags;         // 1: on the lower x edge of bx, 2: on the lower y edge of by
+    unsigned int c0, c1, c2;    // image channels
+    long long el;               // elevation, 31.32 fixed point
+};
+static_assert(sizeof(bin_event) == 32, "bin_event layout");
 
 inline axis_lin make_axis_lin(const axis_dev& a) {
     axis_lin l;
@@ -537,21 +554,32 @@ inline axis_lin make_axis_lin(const axis_dev& a) {
     l.inv_step = a.inv_step;
     l.nbin = a.nbin;
     l.pad = 0;
+    // width of the on-edge zone of the rule above: one unit of the rounded decimal, in bins (<= 1e-5), with slack
+    const double zone = a.scale > 0 && a.step > 0 ? 1.5 / (a.scale * a.step) : 0.0;
+    l.margin = zone > 1e-7 ? zone : 1e-7;
     return l;
 }
 
 // Common path of bin_index for a uniform axis.  t = (v - e0) / step locates v to ~1e-12 bins (two roundings of
 // the expression, and the edges np.linspace produces differ from e0 + i step by rounding only), so whenever the
-// fractional part of t keeps 1e-7 away from 0 and 1 the bin floor(t) is certain and no edge needs evaluating.
-// Everything else — within 1e-7 of an edge, outside the axis, NaN — sets `slow` and is decided exactly by
-// bin_index (a handful of pixels per frame).  Returns the 1-based bin, 0 when `slow` is set.
+// fractional part of t keeps away from 0 (by ax.margin: the on-edge zone of the right-most-edge rule, <= 1e-5) and
+// from 1 (by 1e-7) the bin floor(t) is certain and no edge needs evaluating.  Everything else — close to an
+// edge, outside the axis, NaN — sets `slow` and is decided exactly by bin_index (a few dozen pixels per frame).
+// Returns the 1-based bin, 0 when `slow` is set.
 __device__ __forceinline__ int bin_fast(const axis_lin& ax, double v, bool& slow) {
     const double t = (v - ax.e0) * ax.inv_step;
     const double fl = floor(t);
     const double fr = t - fl;
-    const bool sure = fr > 1e-7 && fr < 1.0 - 1e-7 && fl >= 0.0 && fl < (double)ax.nbin;     // false for NaN
+    const bool sure = fr > ax.margin && fr < 1.0 - 1e-7 && fl >= 0.0 && fl < (double)ax.nbin;     // false for NaN
     slow = !sure;
     return sure ? (int)fl + 1 : 0;
+}
+
+// v lies in bin b (1-based, by plain searchsorted): does it sit on that bin's lower edge in the sense of the
+// right-most-edge rule?
+__device__ __forceinline__ bool on_lower_edge(const axis_dev& ax, int b, double v) {
+    const double e = linspace_edge(ax, b - 1);
+    return rint(v * ax.scale) / ax.scale == rint(e * ax.scale) / ax.scale;
 }
 
 constexpr double kFix = 4294967296.0;   // 2^32: elevation sums are kept in signed 31.32 fixed point

@@ -116,6 +116,9 @@ struct georef_args {
     unsigned long long* bin_acc;
     int bin_lon_wrap, bin_magnetic;
     int item_order, pad_;       // amt_georef_out.item_order
+    bin_event* bin_events;      // optional list for on-edge pixels (amt_georef_out.bin_events)
+    unsigned int* bin_event_count;
+    long long bin_event_cap;
 };
 
 // Frames of one launch of k_georef_rows (the kernel-argument segment holds their constants side by side)
@@ -704,23 +707,44 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
                     bool slow_x, slow_y;
                     int bx = bin_fast(karg_load<axis_lin>(K, offsetof(georef_args, bxl)), bxv, slow_x);
                     int by = bin_fast(karg_load<axis_lin>(K, offsetof(georef_args, byl)), byv, slow_y);
+                    unsigned int edge_flags = 0;
                     if (__ballot(slow_x || slow_y)) {          // wave-uniform and rare
                         K = karg_fresh(koff);
                         if (slow_x) {
                             const axis_dev ax = karg_load<axis_dev>(K, offsetof(georef_args, bax));
                             bx = bin_index<true>(ax, bxv);
                             bx = bx > ax.nbin ? 0 : bx;
+                            if (bx > 0 && on_lower_edge(ax, bx, bxv)) edge_flags |= 1u;
                         }
                         if (slow_y) {
                             const axis_dev ay = karg_load<axis_dev>(K, offsetof(georef_args, bay));
                             by = bin_index<true>(ay, byv);
                             by = by > ay.nbin ? 0 : by;
+                            if (by > 0 && on_lower_edge(ay, by, byv)) edge_flags |= 2u;
                         }
                     }
                     if (bx > 0 && by > 0) {
-                        bin_x = bx;
-                        bin_y = by;
                         el_fix = __double2ll_rn(el * kFix);
+                        bin_event* events = nullptr;
+                        if (edge_flags) events = karg_load<bin_event*>(karg_fresh(koff), offsetof(georef_args, bin_events));
+                        if (events != nullptr) {
+                            // on an edge in the sense of the right-most-edge rule: which bin it belongs to depends on
+                            // the final grid, so it is recorded instead of binned (see bin_event)
+                            karg_ptr KE = karg_fresh(koff);
+                            unsigned int* cnt = karg_load<unsigned int*>(KE, offsetof(georef_args, bin_event_count));
+                            const long long cap = karg_load<long long>(KE, offsetof(georef_args, bin_event_cap));
+                            const unsigned int slot = atomicAdd(cnt, 1u);
+                            if ((long long)slot < cap) {
+                                bin_event ev;
+                                ev.bx = bx, ev.by = by, ev.flags = edge_flags;
+                                ev.c0 = ch0, ev.c1 = ch1, ev.c2 = ch2;
+                                ev.el = el_fix;
+                                events[slot] = ev;
+                            }
+                        } else {
+                            bin_x = bx;
+                            bin_y = by;
+                        }
                     }
                 }
             }
@@ -832,8 +856,11 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
 }
 
 // Folds bbox partials ([n][8]) into gridDim.x rows of out ([gridDim.x][8]); launched twice (n -> 64 -> 1).
+// extra (optional, final stage only): a device counter whose value goes out in slot 7 (the number of on-edge
+// pixels recorded by the fused binning), so that the host gets it with the same 64 bytes as the box
 __global__ __launch_bounds__(kThreads) void k_bbox_fold(const double* __restrict__ partials, int n,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out,
+                                                         const unsigned int* __restrict__ extra) {
     __shared__ double sRed[8][kThreads / 64];
     double v[8] = {kInf, -kInf, kInf, -kInf, kInf, -kInf, 0, 0};
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
@@ -847,6 +874,7 @@ __global__ __launch_bounds__(kThreads) void k_bbox_fold(const double* __restrict
         v[6] += q[6];
         v[7] += q[7];
     }
+    if (extra != nullptr) v[7] = threadIdx.x == 0 ? (double)*extra : 0.0;     // slot 7 is summed over the block
     block_reduce8<kThreads>(v, out + (int64_t)blockIdx.x * 8, sRed);
 }
 
@@ -1030,6 +1058,9 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     A.bin_img = nullptr;
     A.bin_acc = nullptr;
     A.bin_lon_wrap = A.bin_magnetic = 0;
+    A.bin_events = nullptr;
+    A.bin_event_count = nullptr;
+    A.bin_event_cap = 0;
     A.item_order = out->item_order >= 1 && out->item_order <= 2 ? out->item_order : (dirs ? 1 : nadir_side(p));
     A.pad_ = 0;
     std::memset(&A.bax, 0, sizeof(A.bax));
@@ -1052,6 +1083,12 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
         A.bin_acc = reinterpret_cast<unsigned long long*>(out->bin_acc);
         A.bin_lon_wrap = out->bin_lon_wrap ? 1 : 0;
         A.bin_magnetic = out->bin_magnetic ? 1 : 0;
+        if (out->bin_events != nullptr) {
+            AMT_REQUIRE(ctx, out->bin_event_count != nullptr && out->bin_event_capacity > 0, "bin_events needs a counter and a capacity");
+            A.bin_events = static_cast<bin_event*>(out->bin_events);
+            A.bin_event_count = out->bin_event_count;
+            A.bin_event_cap = out->bin_event_capacity;
+        }
         bin = out->bin_img_dtype;
     }
     const launch_shape sh = shape_of(p);
@@ -1144,9 +1181,10 @@ int launch_prepared(amt_ctx* ctx, int n, prepared_frame* F) {
             fs = F[i].tail->stream;
         }
         hipLaunchKernelGGL(k_bbox_fold, dim3(kFoldBlocks), dim3(kThreads), 0, fs, F[i].A.bbox_partials, (int)n_items,
-                           F[i].fold);
+                           F[i].fold, (const unsigned int*)nullptr);
         AMT_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, fs, F[i].fold, kFoldBlocks, F[i].out->bbox);
+        hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, fs, F[i].fold, kFoldBlocks, F[i].out->bbox,
+                           (const unsigned int*)F[i].A.bin_event_count);
         AMT_LAUNCH_CHECK(ctx);
     }
     return AMT_OK;
@@ -1213,7 +1251,8 @@ int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stri
     hipLaunchKernelGGL(k_coarse_bbox, dim3(nblocks), dim3(kThreads), 0, ctx->stream, A, stride, magnetic ? 1 : 0,
                        min_elevation, partials);
     AMT_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, ctx->stream, partials, nblocks, bbox);
+    hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, ctx->stream, partials, nblocks, bbox,
+                       (const unsigned int*)nullptr);
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }

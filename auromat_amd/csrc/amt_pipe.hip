@@ -18,6 +18,9 @@ struct amt_pipe {
     hipEvent_t coarse_done, kernel_done, bbox_done, tail_done;
     double* host_small;            // pinned host memory: [0..7] coarse bbox, [8..15] exact bbox
     double* host_small_dev;        // the same 16 doubles as the kernels address them (the folds write them directly)
+    void* events;                  // on-edge pixels of the frame in flight (bin_event records, device)
+    uint32_t* event_count;         // device counter; zero between frames
+    long long n_events;            // what the frame reported (host copy)
     uint64_t* acc;                 // superset accumulators (device), 5 planes
     size_t acc_cells;              // capacity per plane
     bool acc_zero;                 // the accumulators are known to be all zero
@@ -40,6 +43,7 @@ struct amt_pipe {
 namespace {
 
 constexpr int kCoarseStride = 16;      // every 16th pixel corner at most; >= 128 lattice points on the short side
+constexpr long long kEventCapacity = 16384;   // on-edge pixels per frame (a few dozen in practice)
 constexpr double kMarginDeg = 1.0;     // safety margin around the coarse box (> 3 lattice steps on the ground)
 
 int ensure_acc(amt_pipe* pipe, size_t cells) {
@@ -172,6 +176,9 @@ int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe) {
               hipEventCreate(&pipe->kernel_done) == hipSuccess &&
               hipEventCreateWithFlags(&pipe->bbox_done, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&pipe->tail_done, hipEventDisableTiming) == hipSuccess &&
+              hipMalloc(&pipe->events, kEventCapacity * 32) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&pipe->event_count), sizeof(uint32_t)) == hipSuccess &&
+              hipMemset(pipe->event_count, 0, sizeof(uint32_t)) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&pipe->host_small), 16 * sizeof(double), hipHostMallocMapped) ==
                   hipSuccess &&
               hipHostGetDevicePointer(reinterpret_cast<void**>(&pipe->host_small_dev), pipe->host_small, 0) == hipSuccess;
@@ -194,6 +201,8 @@ int amt_pipe_destroy(amt_pipe* pipe) {
     if (pipe->bbox_done) (void)hipEventDestroy(pipe->bbox_done);
     if (pipe->tail_done) (void)hipEventDestroy(pipe->tail_done);
     if (pipe->partials) (void)hipFree(pipe->partials);
+    if (pipe->events) (void)hipFree(pipe->events);
+    if (pipe->event_count) (void)hipFree(pipe->event_count);
     if (pipe->host_small) (void)hipHostFree(pipe->host_small);
     if (pipe->acc) (void)hipFree(pipe->acc);
     if (pipe->coarse_ws) (void)hipFree(pipe->coarse_ws);
@@ -273,6 +282,9 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
     o.bin_xaxis = o.bin_yaxis = nullptr;
     o.bin_img = nullptr;
     o.bin_img_dtype = o.bin_lon_wrap = o.bin_magnetic = 0;
+    o.bin_events = nullptr;
+    o.bin_event_count = nullptr;
+    o.bin_event_capacity = 0;
     {
         // start with the side of the frame where the coarse pass found the hits (see amt_georef_out.item_order)
         const long long packed = (long long)pipe->host_small[7];
@@ -312,6 +324,7 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
         if (!pipe->acc_zero) {
             // first use / after a frame that was not finalised; otherwise the finalise kernel leaves zeros behind
             AMT_HIP(ctx, hipMemsetAsync(pipe->acc, 0, pipe->acc_cells * 5 * sizeof(uint64_t), ctx->stream));
+            AMT_HIP(ctx, hipMemsetAsync(pipe->event_count, 0, sizeof(uint32_t), ctx->stream));
             pipe->acc_zero = true;
         }
         o.bin_xaxis = &pipe->super.xaxis;
@@ -321,6 +334,9 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
         o.bin_acc = pipe->acc;
         o.bin_magnetic = magnetic;
         o.bin_lon_wrap = pipe->lon_wrap;
+        o.bin_events = pipe->events;
+        o.bin_event_count = pipe->event_count;
+        o.bin_event_capacity = kEventCapacity;
         pipe->fused = true;
         pipe->acc_zero = false;
     }
@@ -414,7 +430,10 @@ int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result) {
         return AMT_OK;
     }
     result->status = 1;
+    pipe->n_events = pipe->fused ? (long long)b[7] : 0;        // the last fold put the counter into slot 7
     if (!pipe->fused || pipe->pole) return AMT_OK;
+    result->edge_pixels = (int32_t)(pipe->n_events > 2000000000ll ? 2000000000ll : pipe->n_events);
+    if (pipe->n_events > kEventCapacity) return AMT_OK;         // more on-edge pixels than records: general path
     const bool straddles = b[3] - b[2] > 180;
     if (straddles != (pipe->lon_wrap != 0)) return AMT_OK;      // the coarse pass judged the discontinuity differently
     double lon_lo = b[2], lon_hi = b[3];
@@ -449,8 +468,14 @@ int amt_pipe_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_
     pipe->ready = false;
     const amt_grid& s = pipe->super;
     const amt_grid& g = pipe->exact;
-    // on the finalise stream (this frame's big kernel and folds are complete: the host has read the box), zeroing
-    // the accumulators for the next frame on the way
+    // on-edge pixels first (their bin depends on where the final grid ends), then the crop: on the finalise stream
+    // (this frame's big kernel and folds are complete: the host has read the box), zeroing the accumulators for
+    // the next frame on the way
+    if (pipe->n_events > 0) {
+        if (int rc = amt_bin_apply_events_on(ctx, pipe->fin_stream, pipe->events, pipe->event_count, pipe->acc, s.nx, s.ny,
+                                             pipe->off_x, pipe->off_y, g.nx, g.ny))
+            return rc;
+    }
     if (int rc = amt_bin_finalize_on(ctx, pipe->fin_stream, pipe->acc, s.nx, s.ny, pipe->off_x, pipe->off_y, g.nx, g.ny,
                                      3, pipe->img_dtype, mean, out_img, out_mask, out_count, 1))
         return rc;

@@ -145,6 +145,16 @@ typedef struct amt_georef_out {
      * cheap items fill the end of the launch (4-5 % shorter kernel; when the Earth is to the left or right every
      * row mixes both kinds anyway).  amt_georef_coarse_bbox reports the side from actual hits (bbox[7]). */
     int32_t item_order;
+    /* Optional, with bin_acc: pixels that sit ON a bin edge in the sense of the right-most-edge rule
+     * (histogram.py:215-224) are then not binned but appended to `bin_events` (32-byte records, see
+     * csrc/amt_common.h bin_event; device memory, room for bin_event_capacity records) and counted in
+     * *bin_event_count (device uint32, zero before the launch; it keeps counting beyond the capacity, which tells
+     * the caller that the frame must be redone).  Whether such a pixel belongs to the bin above or below its edge
+     * depends on whether the edge is the last one of the FINAL grid; the frame driver resolves them in
+     * amt_pipe_finalize.  NULL: they are binned above the edge, exact only when the grid given is the final one. */
+    void* bin_events;
+    uint32_t* bin_event_count;
+    int64_t bin_event_capacity;
 } amt_georef_out;
 
 /* ---- building blocks (auromat.coordinates) ------------------------------------------- */
@@ -348,7 +358,7 @@ typedef struct amt_pipe_result {
     int32_t lon_wrapped;    /* 1: the frame straddles the 180 deg discontinuity; `grid` is laid out for longitudes
                              * shifted by 180 deg (wrap_at_180(lon + 180)) and the caller shifts the output
                              * coordinates back (reference resample.py:203-218,274-277) */
-    int32_t reserved;
+    int32_t edge_pixels;    /* pixels on a bin edge (right-most-edge rule) that were resolved separately */
     double bbox[8];         /* exact reduction of amt_georef_frame; [7] = 1 when a pole is in view */
     amt_grid grid;          /* exact output grid (valid for status 0) */
 } amt_pipe_result;

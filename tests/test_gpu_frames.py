@@ -611,3 +611,39 @@ def test_direction_array_mapping_for_other_camera_models():
     c = DirectionArrayMapping(dirs.dot(rot.T), 110, img, cam, t, 'tilted')
     c.checkGuarantees()
     assert np.nanmax(np.abs(c.lons.filled(np.nan) - b.lons.filled(np.nan))) > 0.01
+
+
+def test_single_pass_right_most_edge_rule():
+    """
+    Pixels that sit on the last edge of the final grid (within the rounding of histogram.py:215-224) belong to the
+    last bin.  The fused kernel bins into a superset grid where that edge is an interior one, so it records such
+    pixels and the driver resolves them once the final grid is known.  Frame 0 of the synthetic sequence has one
+    on the eastern edge at 8 px/deg, frame 3 one on the northern MLat edge; before the fix the single-pass plan lost
+    them (count sums differed by one from the two-pass plan and the oracle's rule).
+    """
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    w, h = 4240, 2832
+    seen_edge_pixels = 0
+    for k, magnetic in ((0, False), (3, True)):
+        hdr, cam, t, seed = sequence_frame(k, w, h)
+        img = frame_image(w, h, seed=seed)
+        pipe = FramePipeline(w, h, with_mag=magnetic)
+        two = pipe.run(hdr, 110, cam, t, img=img, pxPerDeg=8, magnetic=magnetic, fuse=False)
+        one = pipe.run(hdr, 110, cam, t, pxPerDeg=8, magnetic=magnetic, fuse=True)
+        assert pipe.last_plan == 'single-pass'
+        seen_edge_pixels += pipe._fused['result'].edge_pixels
+        for key in ('mean', 'count', 'img', 'mask'):
+            assert np.array_equal(one[key], two[key], equal_nan=True), (k, key)
+        # the pixel in question is in the last column / first row of the output
+        a = pipe.host_arrays()
+        g = one['grid']
+        x = (a['mlt_c'] - 12) / (24 / 360) if magnetic else a['lon_c']
+        y = a['mlat_c'] if magnetic else a['lat_c']
+        keep = a['elev'] >= 10
+        beyond = keep & (((x >= g.xrange[1]) & (x < g.xrange[1] + 1e-6) & (y >= g.yrange[0]) & (y < g.yrange[1])) |
+                         ((y >= g.yrange[1]) & (y < g.yrange[1] + 1e-6) & (x >= g.xrange[0]) & (x < g.xrange[1])))
+        inside = keep & (x >= g.xrange[0]) & (x < g.xrange[1]) & (y >= g.yrange[0]) & (y < g.yrange[1])
+        assert beyond.sum() >= 1
+        assert int(one['count'].sum()) == int(inside.sum()) + int(beyond.sum())
+    assert seen_edge_pixels > 0
