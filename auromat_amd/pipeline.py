@@ -177,11 +177,13 @@ class FramePipeline(object):
             self._pcall('amt_pipe_launch', C.byref(p), C.byref(out), fd.img.data_ptr(),
                         fd.img_dtype_code, min_elev, float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1, mag)
             self._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
+            fd.corner_mask = fd.center_mask = None
             return fd
         self._fused = None
         self._pole = None                                # decided lazily in bounding_box()
         out.bbox_min_elevation = min_elev
         self.ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
+        fd.corner_mask = fd.center_mask = None
         # the 8 reduction doubles travel to pinned host memory right behind the kernel; the event lets
         # bounding_box() wait for exactly this point while later launches keep the GPU busy
         self._bbox_host.copy_(fd.bbox, non_blocking=True)
@@ -208,6 +210,7 @@ class FramePipeline(object):
         for q, p in zip(pipes, params):
             q.params, q.altitude, q.min_elevation = p, altitude, min_elevation
             q._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
+            q.fd.corner_mask = q.fd.center_mask = None
 
     def bounding_box(self):
         """Waits for the fused reduction of the last georef() -> BoundingBox; ValueError if nothing is valid."""
@@ -237,7 +240,10 @@ class FramePipeline(object):
         cmask = (~(fd.elev >= thr)).to(torch.uint8)
         corner = torch.isnan(fd.lat).to(torch.uint8)
         red = self.ctx.empty((8,))
-        self.ctx.call('amt_sanitize_masks', ptr(corner), ptr(cmask), None, fd.height, fd.width, 1)
+        # exact centres: a centre also needs its four corners (mapping.py:1093-1101); masking by elevation first
+        # and reconciling once gives the same masks as the reference's sanitize -> mask -> sanitize order
+        self.ctx.call('amt_sanitize_masks', ptr(corner), ptr(cmask), None, fd.height, fd.width,
+                      1 if self.params.fast_center else 0)
         self.ctx.call('amt_bbox_corners', ptr(lat), ptr(lon), ptr(corner), ptr(cmask), fd.height, fd.width, ptr(red))
         return to_host(red)
 
@@ -285,6 +291,13 @@ class FramePipeline(object):
             if res.status == 0 and not containsPole:       # status 0: neither pole nor discontinuity in the frame
                 self.last_plan = 'single-pass'
                 return self._finalize_fused(res, tuple(pxPerDeg), keep_on_device)
+        if not self.params.fast_center and fd.center_mask is None:
+            # exact centres carry their own misses: a centre also needs its four corners and a corner a centre
+            # (sanitize_data, reference mapping.py:1063-1125) — the separate binning pass takes the reconciled
+            # centre mask; fast centres are consistent by construction (astrometry.py:35-40).  The kernel's own
+            # bounding box and the single-pass plan apply the same rule per pixel.
+            self.ctx.call('amt_sanitize_masks', ptr(fd.corner_mask_tensor()), ptr(fd.center_mask_tensor()), None,
+                          fd.height, fd.width, 0)
         if magnetic:
             assert self.with_mag
             sm = fd.shallow_copy()

@@ -670,3 +670,43 @@ def test_single_pass_vs_oracle_full_size(k, ppd):
     assert np.array_equal(one['mean'][..., :3][filled], want['data'][..., :3][filled])
     assert np.max(np.abs(one['mean'][..., 3][filled] - want['data'][..., 3][filled])) < 1e-9
     assert np.array_equal(np.isnan(one['mean'][..., 0]), ~filled)
+
+
+@pytest.mark.parametrize('magnetic', [False, True])
+def test_exact_centres_without_elevation_threshold(magnetic):
+    """Exact centres (fast=False) and no elevation threshold: the limb pixels whose centre ray hits the shell while
+    one of their corner rays misses it are dropped by the reference's sanitisation (mapping.py:1093-1101); both plans
+    must apply that rule in the binning pass, not only in the bounding box."""
+    from oracle import ref_numpy as O
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 1060, 708
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    img = frame_image(w, h, seed=21, dtype=np.uint8)
+    pipe = FramePipeline(w, h, img_dtype=np.uint8, with_mag=magnetic)
+    two = pipe.run(hdr, 110, cam, t, img=img, fast=False, min_elevation=None, pxPerDeg=(4, 7), magnetic=magnetic)
+    assert pipe.last_plan == 'two-pass'
+    one = pipe.run(hdr, 110, cam, t, fast=False, min_elevation=None, pxPerDeg=(4, 7), magnetic=magnetic, fuse=True)
+    assert pipe.last_plan == 'single-pass'
+    for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
+        assert np.array_equal(one[k], two[k], equal_nan=True), k
+
+    g = oracle_frame(hdr, cam, t, False)
+    corner_mask, center_mask = O.sanitize_masks(np.isnan(g['lat']), np.isnan(g['lat_c']), after_masking=False)
+    limb = int((center_mask & ~np.isnan(g['lat_c'])).sum())
+    assert limb > 0, 'the frame must hold limb pixels that only the sanitisation removes'
+    # (pixels beyond the outermost bin edges are not binned — reference resample.py:301-351 —, hence <=)
+    assert (~center_mask).sum() - limb < one['count'].sum() <= (~center_mask).sum()
+    if magnetic:
+        return                                     # the oracle's resample_mean is the geodetic one
+    bbox, disc = O.bbox_of_corners(g['lat'], g['lon'], corner_mask)
+    data = np.dstack((img.astype(np.float64), g['elev']))
+    data[center_mask] = np.nan
+    want = O.resample_mean(np.where(center_mask, np.nan, g['lat_c']), np.where(center_mask, np.nan, g['lon_c']), 110,
+                           data, None, bbox, (4, 7), disc, False)
+    assert want['data'].shape == one['mean'].shape
+    assert want['count'].sum() == one['count'].sum()
+    assert int((want['count'] != one['count']).sum()) <= 2
+    same = (want['count'] == one['count']) & (want['count'] > 0)
+    assert np.array_equal(one['mean'][..., :3][same], want['data'][..., :3][same])
+    assert np.max(np.abs(one['mean'][..., 3][same] - want['data'][..., 3][same])) < 1e-9
