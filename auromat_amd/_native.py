@@ -24,6 +24,14 @@ class FrameParams(C.Structure):
                 ('a0', C.c_double), ('b0', C.c_double), ('m_geo', C.c_double * 9), ('m_sm', C.c_double * 9)]
 
 
+class AllSkyParams(C.Structure):
+    """amt_allsky_params"""
+    _fields_ = [('size', C.c_int32), ('reserved', C.c_int32), ('xc', C.c_double), ('yc', C.c_double),
+                ('k', C.c_double), ('rotation', C.c_double), ('center_offset', C.c_double),
+                ('to_geo', C.c_double * 9), ('station', C.c_double * 3), ('a', C.c_double), ('b', C.c_double),
+                ('a0', C.c_double), ('b0', C.c_double)]
+
+
 class GeorefOut(C.Structure):
     """amt_georef_out"""
     _fields_ = [(k, C.c_void_p) for k in ('lat', 'lon', 'lat_c', 'lon_c', 'elev', 'mlat', 'mlt', 'mlat_c',
@@ -90,6 +98,8 @@ _SIGNATURES = {
     'amt_rotate_pole': ([_P, c_double_p, _P, _P, _D, _L, _D, _D, _P, _P], _I),
     'amt_cartesian_to_spherical': ([_P, _P, _P, _P, _L, _P, _P, _P], _I),
     'amt_spherical_to_cartesian': ([_P, _P, _P, _P, _L, _P, _P, _P], _I),
+    'amt_georef_allsky': ([_P, C.POINTER(AllSkyParams), _I, _P, _P, _P, _P, _P], _I),
+    'amt_reproject_altitude': ([_P, _D, _D, _P, _P, _L, _D, _D, _D, _D, _P, _P], _I),
     'amt_georef_frame': ([_P, C.POINTER(FrameParams), C.POINTER(GeorefOut)], _I),
     'amt_georef_frame_dirs': ([_P, C.POINTER(FrameParams), _P, C.POINTER(GeorefOut)], _I),
     'amt_georef_coarse_bbox': ([_P, C.POINTER(FrameParams), C.c_int32, _D, _I, _P], _I),

@@ -226,6 +226,77 @@ __global__ void k_rotate_pole(mat3 m, bowring w, const double* __restrict__ lat,
     }
 }
 
+// All-sky equidistant camera -> az/el -> GEO direction -> shell -> geodetic, reference miracle.py:196-258,314-347.
+struct allsky_dev {
+    int n;                 // points per side
+    double off;            // index offset of this point family (0 for corners)
+    double xc, yc, inv_k, rotation;
+    mat3 to_geo;
+    ellipsoid_ray ray;
+    bowring bw;
+};
+
+__global__ void k_georef_allsky(allsky_dev A, double* __restrict__ az_out, double* __restrict__ el_out,
+                                double* __restrict__ dirs, double* __restrict__ lat, double* __restrict__ lon) {
+    constexpr double kDeg = 180.0 / M_PI, kRad = M_PI / 180.0;
+    const int64_t total = (int64_t)A.n * A.n;
+    AMT_GRID_STRIDE(i, total) {
+        const int row = (int)(i / A.n), col = (int)(i - (int64_t)row * A.n);
+        // miracle.py:328-343: vector from the zenith pixel, x vertical / y horizontal; north = (-1, 0) is the image top;
+        // signedAngleBetween(v, north) = atan2(v0*n1 - v1*n0, v0*n0 + v1*n1) (utils.py:48-56)
+        const double v0 = ((double)row + A.off) - A.xc, v1 = ((double)col + A.off) - A.yc;
+        double az = (atan2(v0 * 0.0 - v1 * -1.0, v0 * -1.0 + v1 * 0.0) - A.rotation) * kDeg;
+        az -= floor(az / 360.0) * 360.0;       // Angle.wrap_at(360 deg): into [0, 360)
+        if (az >= 360.0) az -= 360.0;
+        if (az < 0.0) az += 360.0;
+        const double el = 90.0 - sqrt(v0 * v0 + v1 * v1) * A.inv_k * kDeg;
+        if (az_out) az_out[i] = az;
+        if (el_out) el_out[i] = el;
+        if (!dirs && !lat && !lon) continue;
+        // miracle.py:239-258: local (el, -(az-180)) on the unit sphere, then latitude and longitude rotation
+        double se, ce, sa, ca;
+        sincos(el * kRad, &se, &ce);
+        sincos(-(az - 180.0) * kRad, &sa, &ca);
+        vec3 local;
+        local.x = ce * ca;
+        local.y = ce * sa;
+        local.z = se;
+        const vec3 d = mul(A.to_geo, local);
+        if (dirs) {
+            dirs[3 * i + 0] = d.x;
+            dirs[3 * i + 1] = d.y;
+            dirs[3 * i + 2] = d.z;
+        }
+        if (lat || lon) {
+            const vec3 hit = ray_point(A.ray, d, ray_param(A.ray, d));
+            double la, lo;
+            ecef_to_geodetic(A.bw, hit.x, hit.y, hit.z, la, lo);
+            if (lat) lat[i] = la * kDeg;
+            if (lon) lon[i] = lo * kDeg;
+        }
+    }
+}
+
+// reference themis.py:224-253 reproject, one thread per coordinate
+__global__ void k_reproject_altitude(bowring w, vec3 station, ellipsoid_ray ray, double h_ref,
+                                     const double* __restrict__ lat_ref, const double* __restrict__ lon_ref, int64_t n,
+                                     double* __restrict__ lat, double* __restrict__ lon) {
+    constexpr double kDeg = 180.0 / M_PI, kRad = M_PI / 180.0;
+    AMT_GRID_STRIDE(i, n) {
+        double x, y, z;
+        geodetic_to_ecef(w, lat_ref[i] * kRad, lon_ref[i] * kRad, h_ref, x, y, z);
+        vec3 d;
+        d.x = x - station.x;
+        d.y = y - station.y;
+        d.z = z - station.z;
+        const vec3 hit = ray_point(ray, d, ray_param(ray, d));
+        double la, lo;
+        ecef_to_geodetic(w, hit.x, hit.y, hit.z, la, lo);
+        lat[i] = la * kDeg;
+        lon[i] = lo * kDeg;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -413,6 +484,55 @@ int amt_rotate_pole(amt_ctx* ctx, const double* rot, const double* lat, const do
     if (n == 0) return AMT_OK;
     hipLaunchKernelGGL(k_rotate_pole, grid_for(n), dim3(kBlock), 0, ctx->stream, make_mat3(rot), make_bowring(a0, b0),
                        lat, lon, altitude, n, out_lat, out_lon);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_georef_allsky(amt_ctx* ctx, const amt_allsky_params* p, int corner, double* az_deg, double* el_deg,
+                      double* dirs, double* lat_deg, double* lon_deg) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, p != nullptr, "NULL argument");
+    AMT_REQUIRE(ctx, p->size > 0 && p->size < 32768, "bad image size");
+    AMT_REQUIRE(ctx, p->k > 0 && p->a > 0 && p->b > 0 && p->a0 > 0 && p->b0 > 0, "bad calibration or axes");
+    if (!az_deg && !el_deg && !dirs && !lat_deg && !lon_deg) return AMT_OK;
+    allsky_dev A;
+    A.n = p->size + (corner ? 1 : 0);
+    A.off = corner ? 0.0 : p->center_offset;
+    A.xc = p->xc;
+    A.yc = p->yc;
+    A.inv_k = 1.0 / p->k;
+    A.rotation = p->rotation;
+    A.to_geo = make_mat3(p->to_geo);
+    A.ray = make_ray(p->a, p->b, p->station, 1);
+    A.bw = make_bowring(p->a0, p->b0);
+    hipLaunchKernelGGL(k_georef_allsky, grid_for((int64_t)A.n * A.n), dim3(kBlock), 0, ctx->stream, A, az_deg, el_deg,
+                       dirs, lat_deg, lon_deg);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_reproject_altitude(amt_ctx* ctx, double station_lat_deg, double station_lon_deg, const double* lat_ref_deg,
+                           const double* lon_ref_deg, int64_t n, double height_ref, double height_new, double a0,
+                           double b0, double* out_lat_deg, double* out_lon_deg) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, n == 0 || (lat_ref_deg && lon_ref_deg && out_lat_deg && out_lon_deg), "NULL argument");
+    AMT_REQUIRE(ctx, n >= 0 && a0 > 0 && b0 > 0, "bad size or axes");
+    AMT_REQUIRE(ctx, a0 + height_new > 0 && b0 + height_new > 0, "bad height");
+    if (n == 0) return AMT_OK;
+    // geodetic2EcefZero of the station (transform.py:180-197)
+    const double kRad = M_PI / 180.0;
+    const double e2 = (a0 * a0 - b0 * b0) / (a0 * a0);
+    const double sl = sin(station_lat_deg * kRad), cl = cos(station_lat_deg * kRad);
+    const double nn = a0 / sqrt(1 - e2 * sl * sl);
+    const double o[3] = {nn * cl * cos(station_lon_deg * kRad), nn * cl * sin(station_lon_deg * kRad),
+                         nn * (1 - e2) * sl};
+    vec3 station;
+    station.x = o[0];
+    station.y = o[1];
+    station.z = o[2];
+    hipLaunchKernelGGL(k_reproject_altitude, grid_for(n), dim3(kBlock), 0, ctx->stream, make_bowring(a0, b0), station,
+                       make_ray(a0 + height_new, b0 + height_new, o, 1), height_ref, lat_ref_deg, lon_ref_deg, n,
+                       out_lat_deg, out_lon_deg);
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }

@@ -2,5 +2,6 @@
 Georeferenced-image ("mapping") classes backed by device-resident arrays.  Mirrors the parts of
 the reference's ``auromat.mapping`` package that sit on the georeferencing + resampling path:
 ``mapping`` (BaseMapping, GenericMapping, BoundingBox, ...), ``astrometry`` (WCS camera mappings)
-and ``spacecraft`` (ArraySpacecraftMapping, getMapping).
+``spacecraft`` (ArraySpacecraftMapping, getMapping), ``miracle`` (all-sky fisheye mappings) and ``themis``
+(altitude reprojection, ThemisMapping).
 """

@@ -215,6 +215,38 @@ int amt_cartesian_to_spherical(amt_ctx* ctx, const double* x, const double* y, c
 int amt_spherical_to_cartesian(amt_ctx* ctx, const double* r, const double* lat, const double* lon, int64_t n,
                                double* out_x, double* out_y, double* out_z);
 
+/* ---- other camera models feeding the same intersection + geodetic steps -------- */
+
+/* Equidistant all-sky (fisheye) calibration of one ground station, auromat/mapping/miracle.py:28-35,314-347
+ * (FMI MIRACLE cal.txt: zenith pixel (xc vertical, yc horizontal), d = k*z, CCW rotation in rad), already
+ * scaled to the image size (miracle.py:320-326), with the station's position and local-frame rotation. */
+typedef struct amt_allsky_params {
+    int32_t size;             /* image is size x size pixels */
+    int32_t reserved;
+    double xc, yc, k;         /* pixels, pixels, pixels per radian of zenith angle */
+    double rotation;          /* radians */
+    double center_offset;     /* added to the integer index of a pixel CENTRE (0.5; the reference run under its
+                                 pinned NumPy 1.6 adds 0: `ind += 0.5` on an integer array, miracle.py:333-334) */
+    double to_geo[9];         /* row-major R_z(-lon) . R_y(90deg - lat), miracle.py:249-252 */
+    double station[3];        /* geodetic2EcefZero(lat, lon) in km, miracle.py:139-140 */
+    double a, b;              /* shell semi-axes in km: wgs84A + altitude, wgs84B + altitude */
+    double a0, b0;            /* wgs84A, wgs84B */
+} amt_allsky_params;
+
+/* MIRACLEMapping.calculateAzEl -> _calculateCameraToPixelDirection -> intersectionInflated* -> _calculateLatsLons
+ * (auromat/mapping/miracle.py:196-258,314-347) for every pixel corner (corner=1: (size+1)^2 points) or centre
+ * (corner=0: size^2 points) in one launch.  Every output may be NULL: az_deg in [0,360), el_deg = 90 - deg(d/k),
+ * dirs (n,3) AoS unit vectors in GEO, lat_deg / lon_deg of the shell intersection. */
+int amt_georef_allsky(amt_ctx* ctx, const amt_allsky_params* p, int corner, double* az_deg, double* el_deg,
+                      double* dirs, double* lat_deg, double* lon_deg);
+
+/* auromat/mapping/themis.py:224-253 reproject: coordinates given on the shell at height_ref (km above the
+ * ellipsoid) as seen from the station at (station_lat_deg, station_lon_deg, height 0) -> the same lines of sight
+ * on the shell at height_new.  Degrees in and out; NaN in, NaN out. */
+int amt_reproject_altitude(amt_ctx* ctx, double station_lat_deg, double station_lon_deg, const double* lat_ref_deg,
+                           const double* lon_ref_deg, int64_t n, double height_ref, double height_new,
+                           double a0, double b0, double* out_lat_deg, double* out_lon_deg);
+
 /* ---- fused frame kernel ------------------------------------------------------------- */
 
 /* All lazy arrays of a BaseAstrometryMapping in one launch

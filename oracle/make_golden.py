@@ -14,6 +14,8 @@ Fixtures
   resample_*.npz        `_resample(method='mean')` cases: plain, discontinuity, pole, MLat/MLT
   histogram_edges.npz   bin-edge micro cases for util.histogram.histogram2d
   known_answers.json    literal known-answer vectors of the reference's own unit tests
+  miracle_*.npz         MIRACLEMapping (all-sky fisheye) arrays for calibrations of test/resources/cal.txt
+  themis_reproject.npz  themis.reproject of a coordinate table to two other heights
 """
 import json
 import os
@@ -371,9 +373,113 @@ def known_answers():
     print('wrote known_answers.json')
 
 
+class _NumpyFloatIndices(object):
+    """`np` as seen by the reference's miracle module, with ``indices`` returning floats so that its in-place
+    ``ind += 0.5`` (miracle.py:333-334) is legal under NumPy >= 1.10: `truncate=False` gives the documented intent
+    (+0.5), `truncate=True` what NumPy 1.6.1 (requirements.txt) did with the integer array (cast back: +0)."""
+
+    def __init__(self, truncate):
+        self._truncate = truncate
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    def indices(self, shape):
+        a = np.indices(shape).astype(np.float64)
+        if not self._truncate:
+            return a
+
+        class _Trunc(np.ndarray):
+            def __iadd__(self, other):          # int array += 0.5 under the "unsafe" casting of NumPy < 1.10
+                np.copyto(self, np.trunc(np.asarray(self) + other))
+                return self
+        return a.view(_Trunc)
+
+
+SOD = dict(station='SOD', lat=67.42, lon=26.39, xc=219.3, yc=244.2, k=155.81, rotation=0.14373,
+           lat_plus=3.3, lat_minus=-3.3, lon_minus=-16.3, lon_plus=16.3)      # test/resources/cal.txt, winter 2011-2012
+KEV = dict(station='KEV', lat=69.76, lon=27.01, xc=249.5, yc=273.8, k=154.59, rotation=0.07049,
+           lat_plus=2.7, lat_minus=-2.7, lon_minus=-7.9, lon_plus=7.9)
+
+
+def _miracle_mapping(cal, size, altitude, truncate, simple=False):
+    import auromat.mapping.miracle as M
+    M.np = _NumpyFloatIndices(truncate)
+    bb = BoundingBox(latSouth=cal['lat'] + cal['lat_minus'], lonWest=cal['lon'] + cal['lon_minus'],
+                     latNorth=cal['lat'] + cal['lat_plus'], lonEast=cal['lon'] + cal['lon_plus'])
+    cd = M.CalibrationData(station=cal['station'], validFrom=None, validTo=None, lat=cal['lat'], lon=cal['lon'],
+                           xc=cal['xc'], yc=cal['yc'], k=cal['k'], rotation=cal['rotation'], boundingBoxSimple=bb)
+    m = M.MIRACLEMapping(cd, None, datetime(2012, 3, 4, 17, 19, 0), altitude, simple=simple)
+    m._img_unmasked = np.zeros((size, size, 3), np.uint8)
+    return m
+
+
+def _miracle_arrays(m):
+    azc, elc = m.calculateAzEl(center=False)
+    az, el = m.calculateAzEl(center=True)
+    return dict(lat=m.lats.data, lon=m.lons.data, lat_c=m.latsCenter.data, lon_c=m.lonsCenter.data,
+                elev=np.asarray(m.elevation), az=np.asarray(azc), el_corner=np.asarray(elc), az_c=np.asarray(az),
+                dirs=np.asarray(m.cameraToPixelCornerDirection), dirs_c=np.asarray(m.cameraToPixelCenterDirection),
+                cam_geo=np.asarray(m.cameraPosGEO, dtype=np.float64), cam_gcrs=np.asarray(m.cameraPosGCRS))
+
+
+def miracle_cases():
+    """MIRACLEMapping of the reference (mapping/miracle.py) for the SOD / KEV calibrations of test/resources/cal.txt"""
+    def cal_arrays(cal):
+        return {'cal_' + k: (np.array(v) if isinstance(v, str) else np.float64(v)) for k, v in cal.items()}
+    for cal, size, alt, tag in [(SOD, 64, 110, 'sod64'), (KEV, 96, 95, 'kev96')]:
+        out = {}
+        for truncate, key in ((False, ''), (True, 'np16_')):
+            arrs = _miracle_arrays(_miracle_mapping(cal, size, alt, truncate))
+            out.update({key + k: v for k, v in arrs.items()})
+        m = _miracle_mapping(cal, size, alt, False)
+        mm = m.maskedByElevation(0.1)                    # getMapping, miracle.py:365
+        out.update(corner_mask=ma.getmaskarray(mm.lats), center_mask=ma.getmaskarray(mm.latsCenter))
+        # (simple=True cannot be run: miracle.py:200 reads self.img inside the coordinate calculation, which the
+        #  sanitize decorator answers by asking for the coordinates again, mapping.py:1216-1224 -> RecursionError)
+        out.update(cal_arrays(cal))
+        out.update(size=np.int64(size), altitude=np.float64(alt))
+        save('miracle_%s.npz' % tag, **out)
+    # native size: every 16th point + digests
+    step = 16
+    arrs = _miracle_arrays(_miracle_mapping(SOD, 512, 110, False))
+    out = {}
+    for k, v in arrs.items():
+        if v.ndim >= 2:
+            out[k] = np.ascontiguousarray(v[::step, ::step])
+            if v.ndim == 2:
+                out['digest_' + k] = digest(v)
+        else:
+            out[k] = v
+    out.update(cal_arrays(SOD))
+    out.update(size=np.int64(512), altitude=np.float64(110), step=np.int64(step))
+    save('miracle_sod512.npz', **out)
+
+
+def themis_reproject_cases():
+    """themis.reproject (mapping/themis.py:224-253) on coordinate tables shaped like the L2 calibration's: the
+    corners of an all-sky frame at 110 km (from the reference's own MIRACLE mapping), moved to 90 and 150 km;
+    NaN rows as in the L2 files ("coordinates are only defined for useful pixels")."""
+    # the module reads CDF files through spacepy (absent here, never reached by reproject): empty stand-in
+    refshim._mod('spacepy', pycdf=refshim._mod('spacepy.pycdf'))
+    import auromat.mapping.themis as TH
+    m = _miracle_mapping(KEV, 96, 110, False)
+    lat_ref, lon_ref = m.lats.data.copy(), m.lons.data.copy()
+    el = np.asarray(m.calculateAzEl(center=False)[1])
+    lat_ref[el < 5] = np.nan
+    lon_ref[el < 5] = np.nan
+    out = dict(station=np.array([KEV['lat'], KEV['lon']]), lat_ref=lat_ref, lon_ref=lon_ref, height_ref=np.float64(110))
+    for h in (90, 150):
+        la, lo = TH.reproject((KEV['lat'], KEV['lon']), lat_ref, lon_ref, 110, h)
+        out['lat_%d' % h] = la
+        out['lon_%d' % h] = lo
+    save('themis_reproject.npz', **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['host_scalars', 'georef_small', 'masks_small', 'resample_cases',
-                             'histogram_edges', 'known_answers', 'georef_full']
+                             'histogram_edges', 'known_answers', 'georef_full', 'miracle_cases',
+                             'themis_reproject_cases']
     for name in which:
         globals()[name]()

@@ -546,6 +546,82 @@ def georef_frame(hdr, altitude, cam, m_geo, m_sm=None, fast=True):
 
 
 # ---------------------------------------------------------------------------
+# other camera models on the same intersection + geodetic steps: all-sky fisheye (mapping/miracle.py),
+# THEMIS altitude reprojection (mapping/themis.py)
+# ---------------------------------------------------------------------------
+def allsky_az_el(size, xc, yc, k, rotation, center=True, center_offset=0.5):
+    """
+    mapping/miracle.py:314-347 calculateAzEl; xc, yc, k refer to a 512 px image (:320-326).
+    `center_offset`: the reference writes ``ind += 0.5`` on an integer index array (:333-334), which NumPy 1.6
+    (requirements.txt) silently truncates back to +0 and NumPy >= 1.10 rejects; 0.5 is the documented intent.
+    """
+    w = size
+    scale = w / 512
+    if w != 512:
+        xc, yc, k = xc * scale, yc * scale, k * scale
+    w_ = w if center else w + 1
+    ind = np.indices((w_, w_)).astype(np.float64)
+    if center:
+        ind += center_offset
+    ind = np.dstack((ind[0], ind[1])).reshape(w_ * w_, 2)
+    vecs = ind - np.array([xc, yc])
+    north = np.repeat([[-1, 0]], len(vecs), axis=0)
+    # utils.py:48-56 signedAngleBetween
+    az = np.arctan2(vecs[:, 0] * north[:, 1] - vecs[:, 1] * north[:, 0],
+                    vecs[:, 0] * north[:, 0] + vecs[:, 1] * north[:, 1]).reshape(w_, w_)
+    az -= rotation
+    az = wrap_at(az * (180.0 / np.pi), 360.0)
+    z = np.sqrt((vecs * vecs).sum(axis=1)).reshape(w_, w_) / k
+    np.rad2deg(z, z)
+    return az, 90 - z
+
+
+def allsky_directions(el, az, station_lat, station_lon):
+    """mapping/miracle.py:239-258 _calculateCameraToPixelDirection (degrees in, GEO unit vectors out)"""
+    el = np.deg2rad(el)
+    az = np.deg2rad(-(az - 180))
+    x, y, z = spherical_to_cartesian(1, el, az)
+    vecs = np.dstack((x, y, z))
+    mat_lat = rotation_matrix3(np.deg2rad(90 - station_lat), [0, 1, 0])       # Y, transform.py:493
+    mat_lon = rotation_matrix3(np.deg2rad(-station_lon), [0, 0, -1])          # Z, transform.py:494
+    mat = np.dot(mat_lon, mat_lat)
+    return np.matmul(mat, vecs.reshape(-1, 3)[..., None]).reshape(el.shape[0], el.shape[1], 3)
+
+
+def allsky_georef(size, cal, altitude=110, center_offset=0.5):
+    """
+    mapping/miracle.py:139-140,196-237,260-272: dict(lat, lon, lat_c, lon_c [deg], elev, az, az_c, el_corner) of an
+    all-sky frame; `cal` = dict(lat, lon, xc, yc, k, rotation).
+    """
+    cam = np.array(geodetic_to_ecef_zero(np.deg2rad(cal['lat']), np.deg2rad(cal['lon'])))
+    out = {}
+    for center in (False, True):
+        az, el = allsky_az_el(size, cal['xc'], cal['yc'], cal['k'], cal['rotation'], center, center_offset)
+        dirs = allsky_directions(el, az, cal['lat'], cal['lon'])
+        hit = inflated_earth_intersection(dirs.reshape(-1, 3), cam, altitude)
+        lat, lon = ecef_to_geodetic(hit[:, 0], hit[:, 1], hit[:, 2])
+        lat, lon = np.rad2deg(lat).reshape(el.shape), np.rad2deg(lon).reshape(el.shape)
+        if center:
+            out.update(lat_c=lat, lon_c=lon, elev=el, az_c=az, dirs_c=dirs)
+        else:
+            out.update(lat=lat, lon=lon, el_corner=el, az=az, dirs=dirs)
+    return out
+
+
+def themis_reproject(lat_lon_asi, lats_ref, lons_ref, height_ref, height_new):
+    """mapping/themis.py:224-253 reproject (degrees in and out)"""
+    lat_asi, lon_asi = lat_lon_asi
+    cam = np.array(geodetic_to_ecef_zero(np.deg2rad(lat_asi), np.deg2rad(lon_asi)))
+    x, y, z = geodetic_to_ecef(np.deg2rad(lats_ref), np.deg2rad(lons_ref), height_ref)
+    direction = np.transpose([x - cam[0], y - cam[1], z - cam[2]])
+    hit = ellipsoid_line_intersection(WGS84_A + height_new, WGS84_B + height_new, cam, direction.reshape(-1, 3))
+    hit = hit.reshape(direction.shape)
+    x, y, z = hit.transpose()
+    lat, lon = ecef_to_geodetic(x, y, z)
+    return np.rad2deg(lat), np.rad2deg(lon)
+
+
+# ---------------------------------------------------------------------------
 # mask rules (mapping.py:299-316, 845-864, 1063-1125)
 # ---------------------------------------------------------------------------
 def _all_neighbours_missing(center_mask):

@@ -197,3 +197,54 @@ def test_reference_known_answers():
     la, lo = O.ecef_to_geodetic(x.ravel(), y.ravel(), z.ravel())
     aae(np.rad2deg(la).reshape(lat.shape), lat, g['decimals'])
     aae(np.rad2deg(lo).reshape(lon.shape), lon, g['decimals'])
+
+
+# ---- other camera models: all-sky fisheye, THEMIS altitude reprojection ----------------
+def _cal(z):
+    return {k: float(z['cal_' + k]) for k in ('lat', 'lon', 'xc', 'yc', 'k', 'rotation')}
+
+
+@pytest.mark.parametrize('name', ['miracle_sod64.npz', 'miracle_kev96.npz'])
+def test_allsky_oracle_vs_reference(name):
+    """MIRACLEMapping of the real reference, with the centre offset as intended (+0.5) and as its pinned NumPy 1.6
+    evaluates it (+0): az/el tables, GEO directions, geodetic coordinates."""
+    z = load_golden(name)
+    for prefix, off in (('', 0.5), ('np16_', 0.0)):
+        g = O.allsky_georef(int(z['size']), _cal(z), float(z['altitude']), center_offset=off)
+        for k in ('az', 'el_corner', 'az_c', 'elev'):
+            same(g[k], z[prefix + k], 1e-12)
+        for k in ('dirs', 'dirs_c'):
+            same(g[k], z[prefix + k], 1e-15)
+        for k in ('lat', 'lon', 'lat_c', 'lon_c'):
+            same(g[k], z[prefix + k], 1e-12)
+    # the rays of a ground camera always leave the shell: nothing is missing before the elevation mask
+    assert not np.isnan(z['lat']).any()
+    corner_mask, center_mask = O.mask_by_elevation(z['elev'], np.isnan(z['lat']), 0.1)
+    assert np.array_equal(corner_mask, z['corner_mask'])
+    assert np.array_equal(center_mask, z['center_mask'])
+
+
+def test_allsky_oracle_native_size_samples():
+    z = load_golden('miracle_sod512.npz')
+    g = O.allsky_georef(512, _cal(z), 110.0)
+    step = int(z['step'])
+    for k in ('az', 'el_corner', 'az_c', 'elev', 'lat', 'lon', 'lat_c', 'lon_c'):
+        same(g[k][::step, ::step], z[k], 1e-12)
+        d = z['digest_' + k]
+        a = g[k]
+        assert a.size == d[0]
+        assert abs(a.sum() - d[1]) <= 1e-9 * max(1.0, abs(d[1]))
+        assert abs(a.min() - d[2]) <= 1e-12 and abs(a.max() - d[3]) <= 1e-12
+
+
+def test_themis_reproject_oracle_vs_reference():
+    z = load_golden('themis_reproject.npz')
+    for h in (90, 150):
+        la, lo = O.themis_reproject(tuple(z['station']), z['lat_ref'], z['lon_ref'], float(z['height_ref']), h)
+        same(la, z['lat_%d' % h], 1e-12)
+        same(lo, z['lon_%d' % h], 1e-12)
+    # the reference height itself is nearly a fixed point (the shell a+h, b+h is not exactly the surface of
+    # constant geodetic height h, hence micro-degrees and not rounding errors)
+    la, lo = O.themis_reproject(tuple(z['station']), z['lat_ref'], z['lon_ref'], 110.0, 110.0)
+    same(la, z['lat_ref'], 1e-5)
+    same(lo, z['lon_ref'], 1e-5)
