@@ -157,6 +157,43 @@ __global__ __launch_bounds__(kBlock) void k_bbox_fold_small(const double* __rest
     block_reduce8(v, bbox);
 }
 
+// Contour links of a mask (reference utils.py:97-151: skimage find_contours at level 0.99 on the padded mask, rounded
+// to pixel indices).  A "crossing" is a valid pixel p together with a direction d (0 up, 1 right, 2 down, 3 left) whose
+// 4-neighbour is masked or outside; the contour visits every crossing exactly once, with the valid region on its
+// right-hand side (clockwise in image coordinates, valid pixels joined through edges only, as marching squares joins the
+// values above the level).  One thread per pixel writes (key, next key) for each of its crossings, key = 4*index + d.
+__global__ void k_mask_outline_links(const uint8_t* __restrict__ mask, int height, int width,
+                                     long long* __restrict__ links, long long capacity,
+                                     unsigned long long* __restrict__ count) {
+    const int64_t n = (int64_t)height * width;
+    auto valid = [&](int r, int c) -> bool {
+        return r >= 0 && c >= 0 && r < height && c < width && mask[(int64_t)r * width + c] == 0;
+    };
+    AMT_GRID_STRIDE(i, n) {
+        if (mask[i] != 0) continue;
+        const int r = (int)(i / width), c = (int)(i - (int64_t)r * width);
+        const int dr[4] = {-1, 0, 1, 0}, dc[4] = {0, 1, 0, -1};
+        for (int d = 0; d < 4; ++d) {
+            if (valid(r + dr[d], c + dc[d])) continue;
+            const int f = (d + 1) & 3;
+            const int fr = r + dr[f], fc = c + dc[f];          // the pixel ahead along the contour
+            long long next;
+            if (!valid(fr, fc)) {
+                next = 4 * i + f;                                // around this pixel's corner
+            } else if (!valid(fr + dr[d], fc + dc[d])) {
+                next = 4 * ((int64_t)fr * width + fc) + d;       // straight on
+            } else {
+                next = 4 * ((int64_t)(fr + dr[d]) * width + (fc + dc[d])) + ((d + 3) & 3);   // inner corner
+            }
+            const unsigned long long slot = atomicAdd(count, 1ull);
+            if ((long long)slot < capacity) {
+                links[2 * slot] = 4 * i + d;
+                links[2 * slot + 1] = next;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -221,6 +258,22 @@ int amt_bbox_corners(amt_ctx* ctx, const double* lat, const double* lon, const u
                        width, partials);
     AMT_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_bbox_fold_small, dim3(1), dim3(kBlock), 0, ctx->stream, partials, (int)grid.x, bbox);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_mask_outline_links(amt_ctx* ctx, const uint8_t* mask, int32_t height, int32_t width, int64_t* links,
+                           int64_t capacity, uint64_t* count) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, mask && count && (capacity == 0 || links), "NULL argument");
+    AMT_REQUIRE(ctx, height > 0 && width > 0 && capacity >= 0, "bad size");
+    if (hipMemsetAsync(count, 0, sizeof(uint64_t), ctx->stream) != hipSuccess) {
+        ctx->last_error = "amt_mask_outline_links: memset failed";
+        return AMT_EHIP;
+    }
+    hipLaunchKernelGGL(k_mask_outline_links, grid_for((int64_t)height * width), dim3(kBlock), 0, ctx->stream, mask,
+                       height, width, reinterpret_cast<long long*>(links), (long long)capacity,
+                       reinterpret_cast<unsigned long long*>(count));
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }

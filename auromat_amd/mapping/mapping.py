@@ -349,22 +349,50 @@ class BaseMapping(object):
     @property
     def outline(self):
         """
-        Coordinates of all unmasked corners as an (n,2) [lat,lon] array.  The reference returns the
-        traced contour (mapping.py:655-680); every consumer on the resampling path only takes
-        min/max of it, for which the full corner set is equivalent.
+        The complete outline of this mapping as an (n,2) [lat,lon] array: the traced contour of the unmasked
+        corners (reference mapping.py:655-691, utils.py:97-151), clockwise in image coordinates.
+        Note that the outline can be concave.
         """
-        lats, lons = self.lats, self.lons
-        return np.transpose([lats.compressed(), lons.compressed()])
+        full, _ = self._fullAndConvexOutlines
+        return full
+
+    @property
+    def outlineConvexHull(self):
+        """The convex hull (in pixel space) of the regular outline, as [lat,lon] (reference mapping.py:664-690)."""
+        _, convex = self._fullAndConvexOutlines
+        return convex
+
+    @property
+    def _fullAndConvexOutlines(self):
+        def make():
+            import torch
+            from ..utils import convexHull, outline_of_mask_tensor
+            fd = self.frame()
+            outl = outline_of_mask_tensor(fd.ctx, fd.corner_mask_tensor(), fd.height + 1, fd.width + 1)
+
+            def latlon(xy):
+                idx = torch.from_numpy(np.ascontiguousarray(xy[:, 1] * (fd.width + 1) + xy[:, 0])).to(fd.lat.device)
+                return np.transpose([to_host(fd.lat.reshape(-1)[idx]), to_host(fd.lon.reshape(-1)[idx])])
+            return latlon(outl), latlon(convexHull(outl))
+        return self._cached('outlines', make)
 
     @property
     def centroid(self):
-        """Mean position of the unmasked corners (the reference uses the outline polygon's centroid)."""
+        """The centroid of the mapping based on the plate-carree projection (reference mapping.py:758-784).
+
+        :rtype: auromat.coordinates.geodesic.Location
+        """
+        from ..utils import polygonCentroid
         if self.containsPole:
+            # TODO rotate away from pole, see resample module
             raise NotImplementedError
-        lats, lons = self.lats.compressed(), self.lons.compressed()
+        outline = self.outline
         if self.containsDiscontinuity:
-            return Location(lats.mean(), wrap_at_180(wrap_at_180(lons + 180).mean() + 180))
-        return Location(lats.mean(), lons.mean())
+            shifted = np.transpose([outline[:, 0], wrap_at_180(outline[:, 1] + 180)])
+            lat, lon = polygonCentroid(shifted)
+            return Location(lat, float(wrap_at_180(lon + 180)))
+        lat, lon = polygonCentroid(outline)
+        return Location(lat, lon)
 
     # -- masking -----------------------------------------------------------------------------------
     def maskedByElevation(self, minElevation=10):

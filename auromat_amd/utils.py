@@ -1,0 +1,147 @@
+"""
+Polygon / outline helpers of the reference's ``auromat.utils`` that sit between georeferencing and resampling
+(reference utils.py:97-275): the traced outline of a validity mask, polygon area and centroid, convex hull.
+
+The outline is traced on the device: ``amt_mask_outline_links`` emits, for the whole mask in one pass, the links
+of the contour that scikit-image's ``find_contours(mask, 0.99)`` walks (the reference's ``_outline_skimage``,
+utils.py:97-140); the host only follows a few thousand links.
+"""
+import numpy as np
+
+from ._native import Context, ptr, to_host
+
+
+def contours_from_links(links):
+    """
+    Closed contours from (key, next key) records (see ``amt_mask_outline_links``): list of int64 arrays of pixel
+    indices (key // 4), each without consecutive duplicates (also across the closing point).
+    """
+    links = np.asarray(links, dtype=np.int64).reshape(-1, 2)
+    if len(links) == 0:
+        return []
+    order = np.argsort(links[:, 0], kind='stable')
+    keys = links[order, 0]
+    nxt = np.searchsorted(keys, links[order, 1])
+    assert np.all(nxt < len(keys)) and np.array_equal(keys[nxt], links[order, 1]), 'dangling contour link'
+    nxt = nxt.tolist()
+    seen = np.zeros(len(keys), bool)
+    contours = []
+    for start in range(len(keys)):
+        if seen[start]:
+            continue
+        chain = []
+        k = start
+        while not seen[k]:
+            seen[k] = True
+            chain.append(k)
+            k = nxt[k]
+        assert k == start, 'contour does not close'
+        px = keys[np.asarray(chain)] // 4
+        keep = np.ones(len(px), bool)
+        keep[1:] = px[1:] != px[:-1]
+        px = px[keep]
+        if len(px) > 1 and px[0] == px[-1]:
+            px = px[:-1]
+        contours.append(px)
+    return contours
+
+
+def outline_of_mask_tensor(ctx, mask, height, width):
+    """Outline of a device uint8 mask (1 = masked): (n,2) int array in x,y order, see :func:`outline`."""
+    import torch
+    count = ctx.zeros((1,), torch.int64)
+    capacity = 16 * (height + width) + 64
+    while True:
+        links = ctx.empty((capacity, 2), torch.int64)
+        ctx.call('amt_mask_outline_links', ptr(mask), height, width, ptr(links), capacity, ptr(count))
+        n = int(to_host(count, dtype=np.int64)[0])
+        if n <= capacity:
+            break
+        capacity = n
+    if n == 0:
+        raise ValueError('the mask has no unmasked element')
+    contours = contours_from_links(to_host(links[:n], dtype=np.int64))
+    polys = [np.transpose([c % width, c // width]) for c in contours]
+    if len(polys) > 1:
+        # several contours (holes, islands): the biggest one (utils.py:127-137); degenerate ones are dropped
+        polys = [p for p in polys if len(p) > 2]
+        if not polys:
+            raise ValueError('the mask only has degenerate contours')
+        polys = [polys[int(np.argmax([polygonArea(p) for p in polys]))]]
+    return polys[0]
+
+
+def outline(im):
+    """
+    Finds the outline of a binary image, assuming that the inner structure is filled with True's.  The returned
+    points are in clockwise order (image coordinates, y down) and can be used as a polygon.  This works for
+    concave forms as well (reference utils.py:142-151).
+
+    :param im: shape (h,w), True = inside
+    :rtype: ndarray of shape (n,2) in x,y order
+    """
+    im = np.asarray(im, dtype=bool)
+    assert im.ndim == 2
+    ctx = Context.current()
+    mask = ctx.to_device(np.ascontiguousarray(~im).astype(np.uint8), np.uint8)
+    return outline_of_mask_tensor(ctx, mask, im.shape[0], im.shape[1])
+
+
+def polygonArea(poly, signed=False):
+    """Area of an unclosed polygon, (n,2)-array (shoelace formula; reference utils.py:153-171)."""
+    p = np.asarray(poly, dtype=np.float64)
+    q = np.roll(p, -1, axis=0)
+    area = 0.5 * float(np.sum(p[:, 0] * q[:, 1] - q[:, 0] * p[:, 1]))
+    return area if signed else abs(area)
+
+
+def polygonCentroid(poly):
+    """
+    Centroid (x,y) of an unclosed polygon, (n,2)-array (reference utils.py:173-225).  As in the reference the
+    moments are divided by the *unsigned* area: a polygon running against the mathematical orientation gives the
+    negated centroid.
+    """
+    p = np.asarray(poly, dtype=np.float64)
+    q = np.roll(p, -1, axis=0)
+    cross = p[:, 0] * q[:, 1] - q[:, 0] * p[:, 1]
+    area = abs(0.5 * float(np.sum(cross)))
+    cx = float(np.sum((p[:, 0] + q[:, 0]) * cross)) / (area * 6.0)
+    cy = float(np.sum((p[:, 1] + q[:, 1]) * cross)) / (area * 6.0)
+    return (cx, cy)
+
+
+def withoutConsecutiveDuplicates(arr):
+    """Copy of the input where consecutive duplicates on the first dimension are removed (utils.py:235-245)."""
+    a = np.asarray(arr)
+    if len(a) == 0:
+        return a
+    keep = np.ones(len(a), bool)
+    keep[1:] = np.any(a[1:].reshape(len(a) - 1, -1) != a[:-1].reshape(len(a) - 1, -1), axis=1)
+    return a[keep]
+
+
+def convexHull(points):
+    """
+    Convex hull spanning the given points, (n,2) -> (m,2), ordered by ``arctan2(dx, dy)`` about the mean of the hull
+    vertices as the reference orders them (utils.py:247-276).  Monotone chain instead of the reference's Delaunay
+    triangulation; points lying on a hull edge between two vertices are not part of the result.
+    """
+    pts = np.unique(np.asarray(points).reshape(-1, 2), axis=0)
+    assert pts.ndim == 2 and pts.shape[1] == 2
+    if len(pts) > 2:
+        def half(seq):
+            h = []
+            for p in seq:
+                while len(h) >= 2 and ((h[-1][0] - h[-2][0]) * (p[1] - h[-2][1]) -
+                                       (h[-1][1] - h[-2][1]) * (p[0] - h[-2][0])) <= 0:
+                    h.pop()
+                h.append(p)
+            return h
+        seq = pts.tolist()
+        lower, upper = half(seq), half(seq[::-1])
+        pts = np.asarray(lower[:-1] + upper[:-1], dtype=pts.dtype)
+    centered = pts - pts.mean(axis=0)
+    return pts[np.argsort(np.arctan2(centered[:, 0], centered[:, 1]))]
+
+
+__all__ = ['outline', 'polygonArea', 'polygonCentroid', 'withoutConsecutiveDuplicates', 'convexHull']

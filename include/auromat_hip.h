@@ -283,6 +283,16 @@ int amt_mask_by_elevation(amt_ctx* ctx, const double* elev, const double* corner
  * img_mask may be NULL; after_masking as in the reference. */
 int amt_sanitize_masks(amt_ctx* ctx, uint8_t* corner_mask, uint8_t* center_mask, const uint8_t* img_mask,
                        int32_t height, int32_t width, int after_masking);
+/* auromat/utils.py:97-151 outline (skimage.measure.find_contours(padded mask, 0.99), rounded): the contour links of
+ * a (height, width) uint8 mask (1 = masked).  For every unmasked pixel p (flat index i) and every direction d
+ * (0 up, 1 right, 2 down, 3 left) whose 4-neighbour is masked or outside, one record links[2k] = 4*i + d,
+ * links[2k+1] = the key of the crossing that follows it on the contour (unmasked region on the right-hand side, i.e.
+ * clockwise in image coordinates; unmasked pixels are joined through edges only).  Records come in no particular order;
+ * *count (device uint64, zeroed by the call) receives their number, which may exceed `capacity` (then only the first
+ * `capacity` were written: call again with a larger buffer).  Following the links from any key yields one closed
+ * contour; the pixel of each key (key / 4), with consecutive duplicates dropped, is the polygon the reference traces. */
+int amt_mask_outline_links(amt_ctx* ctx, const uint8_t* mask, int32_t height, int32_t width, int64_t* links,
+                           int64_t capacity, uint64_t* count);
 /* Inputs of BaseMapping.boundingBox (mapping.py:693-743) for arbitrary corner grids:
  * bbox[0..5] = min/max over unmasked corners as in amt_georef_out.bbox, bbox[6] = number of unmasked
  * corners, bbox[7] = number of unmasked centres whose corner quad winds around a pole.

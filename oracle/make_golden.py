@@ -368,6 +368,19 @@ def known_answers():
     # transform_test.py:70-83: geodetic round trip to 11 decimals (degrees)
     ka['geodetic_roundtrip'] = dict(decimals=11, lat_linspace=[-89.9, 89.9, 50], lon_linspace=[-179.9, 179.9, 50],
                                     mgrid=[[-89, 89, 5], [-179, 179, 5]])
+    # outline_test.py:22-36,109-158: literal vectors of the polygon helpers and of the traced outline; the polygon of
+    # testPolygonArea is the outline of `_testIm(10)` (a disc of radius 4 in a 10x10 image minus one pixel)
+    from auromat.utils import polygonArea, polygonCentroid
+    poly_area = [[4, 8], [3, 7], [2, 7], [1, 6], [1, 5], [1, 4], [1, 3], [1, 2], [2, 1], [3, 1], [4, 0], [5, 1], [6, 1],
+                 [7, 2], [7, 3], [8, 4], [7, 5], [7, 6], [6, 7], [5, 7]]
+    poly_centroid = [[30, 50], [200, 10], [250, 50], [350, 100], [200, 180], [100, 140], [10, 200]]
+    assert polygonArea(poly_area) == 37.0
+    ka['outline'] = dict(test_image=dict(n=10, radius=4.0, removed=[4, 0]), polygon=poly_area, area=37.0,
+                         centroid_polygon=poly_centroid, centroid=[159.2903828197946, 98.88888888888],
+                         centroid_ref=list(polygonCentroid(poly_centroid)), centroid_decimals=7,
+                         mapping_centroid=dict(header='ISS030-E-102170_dc.wcs (tests/golden/georef_full_iss030_fast.npz)',
+                                               fast=True, altitude=110, expect=[55.00295889563608, -99.21825084682715],
+                                               decimals=6))
     with open(os.path.join(OUT, 'known_answers.json'), 'w') as fp:
         json.dump(ka, fp, indent=1)
     print('wrote known_answers.json')

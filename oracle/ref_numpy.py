@@ -622,6 +622,97 @@ def themis_reproject(lat_lon_asi, lats_ref, lons_ref, height_ref, height_new):
 
 
 # ---------------------------------------------------------------------------
+# outline of a validity mask, polygon area / centroid (utils.py:97-225, mapping.py:655-691,758-784)
+# ---------------------------------------------------------------------------
+def find_contours_binary(image, level=0.99):
+    """
+    Third-party step of utils.py:97-103: ``skimage.measure.find_contours(image, level)`` of scikit-image 0.10.1
+    (requirements.txt; absent from this image).  Restated from its published algorithm (marching squares with linear
+    interpolation, `fully_connected='low'`, `positive_orientation='low'`; Lorensen & Cline 1987 as implemented in
+    skimage/measure/_find_contours*.py): every 2x2 square contributes 0, 1 or 2 directed segments between points
+    interpolated on its edges, high values on the right-hand side of the direction of travel (image coordinates);
+    segments are joined into contours, closed ones repeat their first point at the end.  Returns a list of (n,2)
+    arrays in (row, col) order.  Parity of this restatement is anchored on the reference's own vectors: the literal
+    polygon of outline_test.py:110-131 (the outline of its `_testIm(10)`), polygon area / centroid known answers and
+    the mapping centroid of outline_test.py:151-158.
+    """
+    a = np.asarray(image, dtype=np.float64)
+
+    def frac(v_from, v_to):
+        return (level - v_from) / (v_to - v_from)
+    segments = {}
+    hi = a > level
+    cases = hi[:-1, :-1] * 1 + hi[:-1, 1:] * 2 + hi[1:, :-1] * 4 + hi[1:, 1:] * 8
+    for r0, c0 in zip(*np.nonzero((cases != 0) & (cases != 15))):       # squares in raster order, as the scan visits them
+        r0, c0 = int(r0), int(c0)
+        if True:
+            ul, ur, ll, lr = a[r0, c0], a[r0, c0 + 1], a[r0 + 1, c0], a[r0 + 1, c0 + 1]
+            case = int(cases[r0, c0])
+            top = (r0, c0 + frac(ul, ur)) if (ul > level) != (ur > level) else None
+            bottom = (r0 + 1, c0 + frac(ll, lr)) if (ll > level) != (lr > level) else None
+            left = (r0 + frac(ul, ll), c0) if (ul > level) != (ll > level) else None
+            right = (r0 + frac(ur, lr), c0 + 1) if (ur > level) != (lr > level) else None
+            table = {1: [(top, left)], 2: [(right, top)], 3: [(right, left)], 4: [(left, bottom)],
+                     5: [(top, bottom)], 6: [(right, top), (left, bottom)], 7: [(right, bottom)],
+                     8: [(bottom, right)], 9: [(top, left), (bottom, right)], 10: [(bottom, top)],
+                     11: [(bottom, left)], 12: [(left, right)], 13: [(top, right)], 14: [(left, top)]}
+            for p, q in table[case]:
+                segments[p] = q
+    contours = []
+    while segments:
+        start, nxt = segments.popitem()
+        pts = [start, nxt]
+        while nxt in segments:
+            nxt = segments.pop(nxt)
+            pts.append(nxt)
+        # an open contour (touching the image border) may continue backwards; masks padded with False never do
+        contours.append(np.array(pts, dtype=np.float64))
+    return contours
+
+
+def polygon_area(poly, signed=False):
+    """utils.py:153-171"""
+    poly = [list(p) for p in np.asarray(poly).tolist()]
+    segments = zip(poly, poly[1:] + [poly[0]])
+    area = 0.5 * sum(x0 * y1 - x1 * y0 for ((x0, y0), (x1, y1)) in segments)
+    return area if signed else abs(area)
+
+
+def polygon_centroid(poly):
+    """utils.py:173-225 (moments over the unsigned area)"""
+    poly = np.asarray(poly).tolist()
+    area = polygon_area(poly)
+    rx = ry = 0
+    n = len(poly)
+    for i in range(n):
+        x0, y0 = poly[i]
+        x1, y1 = poly[(i + 1) % n]
+        cross = (x0 * y1) - (x1 * y0)
+        rx += (x0 + x1) * cross
+        ry += (y0 + y1) * cross
+    return rx / (area * 6.0), ry / (area * 6.0)
+
+
+def outline(im):
+    """utils.py:97-151 _outline_skimage: (n,2) int array in x,y order, clockwise in image coordinates"""
+    im = np.asarray(im, dtype=bool)
+    border = np.zeros((im.shape[0] + 2, im.shape[1] + 2), dtype=bool)
+    border[1:-1, 1:-1] = im
+    contours = find_contours_binary(border, 0.99)
+
+    def fix(contour):
+        contour = np.fliplr(contour)                        # (row, col) -> (x, y)
+        contour = np.round(contour - 1).astype(int)         # padding off, nearest pixel
+        keep = np.ones(len(contour), bool)
+        keep[1:] = np.any(contour[1:] != contour[:-1], axis=1)
+        return contour[keep][:-1]                           # consecutive duplicates off, un-close
+    if len(contours) > 1:
+        contours = [c for c in map(fix, contours) if len(c) > 2]
+        return contours[int(np.argmax([polygon_area(c) for c in contours]))]
+    return fix(contours[0])
+
+
+# ---------------------------------------------------------------------------
 # mask rules (mapping.py:299-316, 845-864, 1063-1125)
 # ---------------------------------------------------------------------------
 def _all_neighbours_missing(center_mask):

@@ -27,3 +27,25 @@ def test_oracle_full_size_bit_exact():
     # the survey's anchors for this fixture
     assert abs(np.nanmin(g['lat']) - (-68.3209)) < 1e-4 and abs(np.nanmax(g['lon']) - 179.9564) < 1e-4
     assert np.isnan(g['lat'][0, 2000]) and not np.isnan(g['lat'][-1, 2000])      # intersection_test.py:155-169
+
+
+def test_mapping_centroid_known_answer():
+    """outline_test.py:151-158 testMappingCentroid on the real ISS030-E-102170 header: centroid of the traced outline
+    of the valid corners = [55.00295889563608, -99.21825084682715] to 6 decimals (the literal is an OpenCV float32
+    moment; "the two solutions differ slightly after the 7th decimal").  Pins the restated find_contours including
+    its orientation (the centroid formula flips sign with it)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, 'known_answers.json')) as fp:
+        ka = json.load(fp)['outline']['mapping_centroid']
+    z = load_golden('georef_full_iss030_fast.npz')
+    hdr = header_from(z)
+    dirs = O.pixel_directions(hdr, corner=True)
+    hit = O.inflated_earth_intersection(dirs.reshape(-1, 3), z['cam'], float(z['altitude']))
+    lat, lon = O.j2000_to_latlon(hit, z['m_geo'])
+    lat, lon = lat.reshape(dirs.shape[:2]), lon.reshape(dirs.shape[:2])
+    outl = O.outline(~np.isnan(lat))
+    assert len(outl) > 10000
+    centroid = O.polygon_centroid(np.transpose([lat[outl[:, 1], outl[:, 0]], lon[outl[:, 1], outl[:, 0]]]))
+    np.testing.assert_almost_equal(centroid, ka['expect'], decimal=ka['decimals'])

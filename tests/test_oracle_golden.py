@@ -248,3 +248,34 @@ def test_themis_reproject_oracle_vs_reference():
     la, lo = O.themis_reproject(tuple(z['station']), z['lat_ref'], z['lon_ref'], 110.0, 110.0)
     same(la, z['lat_ref'], 1e-5)
     same(lo, z['lon_ref'], 1e-5)
+
+
+# ---- traced outline, polygon area / centroid (utils.py:97-225; outline_test.py as data) ------------------------
+def outline_test_image(spec):
+    n, r = int(spec['n']), float(spec['radius'])
+    y, x = np.ogrid[-r: r + 1, -r: r + 1]
+    im = np.zeros((n, n), bool)
+    disc = x ** 2 + y ** 2 <= r ** 2
+    im[:disc.shape[0], :disc.shape[1]] = disc
+    im[tuple(spec['removed'])] = False
+    return im
+
+
+def test_outline_oracle_vs_reference_known_answers():
+    """outline_test.py:109-149: the literal outline polygon of `_testIm(10)` (order and starting point included), its
+    area, and the polygon centroid vector."""
+    with open(os.path.join(GOLDEN, 'known_answers.json')) as fp:
+        ka = json.load(fp)['outline']
+    assert O.outline(outline_test_image(ka['test_image'])).tolist() == ka['polygon']
+    assert O.polygon_area(ka['polygon']) == ka['area']
+    assert O.polygon_area(ka['polygon'], signed=True) == ka['area']        # clockwise in image coordinates
+    got = O.polygon_centroid(ka['centroid_polygon'])
+    np.testing.assert_almost_equal(got, ka['centroid'], decimal=ka['centroid_decimals'])
+    assert list(got) == ka['centroid_ref']                                  # the real function, bit for bit
+    # two blobs: the bigger one is returned; a hole does not change the outer outline
+    im = outline_test_image(ka['test_image'])
+    two = np.hstack((im, np.zeros((10, 3), bool), im[:, :6]))
+    assert O.outline(two).tolist() == ka['polygon']
+    holed = im.copy()
+    holed[4, 4] = False
+    assert O.outline(holed).tolist() == ka['polygon']
