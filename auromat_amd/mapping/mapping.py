@@ -48,7 +48,7 @@ def wrap_at_180(deg):
 class BoundingBox(object):
     """
     Describes a geographical bounding box that can span across the discontinuity
-    (reference mapping.py:44-287; the geodesic-based ``center``/``size`` are not part of the hot path).
+    (reference mapping.py:44-287).
     """
 
     def __init__(self, latSouth, lonWest, latNorth, lonEast):
@@ -66,6 +66,51 @@ class BoundingBox(object):
     bottomLeft = property(lambda self: Location(self.latSouth, self.lonWest))
     topRight = property(lambda self: Location(self.latNorth, self.lonEast))
     bottomRight = property(lambda self: Location(self.latSouth, self.lonEast))
+
+    @property
+    def _minSphericalRectangle(self):
+        """
+        (center, Size(width, height) in km) of the minimum spherical rectangle that fits the box (reference
+        mapping.py:118-170; sizes are only meaningful for boxes spanning less than 180 degrees of longitude).
+        """
+        from ..coordinates import geodesic
+        if self.containsPole:
+            if self.latNorth == 90:                      # north pole
+                center = Location(90, 0)
+                width = geodesic.distance(center, Location(self.latSouth, 0)) * 2
+            else:                                        # south pole
+                center = Location(-90, 0)
+                width = geodesic.distance(center, Location(self.latNorth, 0)) * 2
+            height = width
+        else:
+            lonWest, lonEast = self.lonWest, self.lonEast
+            if lonWest > lonEast:
+                lonEast += 360
+            lonc = wrap_at_180((lonWest + lonEast) / 2)
+            width = geodesic.distance(self.bottomLeft, self.bottomRight)
+            width2 = geodesic.distance(self.topLeft, self.topRight)
+            if width2 > width:                           # southern hemisphere
+                width = width2
+                bottomCenter = geodesic.intermediate(self.bottomLeft, self.bottomRight, 0.5)
+                topDataCenter = Location(self.latNorth, lonc)
+                height = geodesic.distance(topDataCenter, bottomCenter)
+                center = geodesic.intermediate(topDataCenter, bottomCenter, 0.5)
+            else:                                        # northern hemisphere
+                topCenter = geodesic.intermediate(self.topLeft, self.topRight, 0.5)
+                bottomDataCenter = Location(self.latSouth, lonc)
+                height = geodesic.distance(bottomDataCenter, topCenter)
+                center = geodesic.intermediate(bottomDataCenter, topCenter, 0.5)
+        return center, Size(width / 1000, height / 1000)
+
+    @property
+    def center(self):
+        """Center of the minimum spherical rectangle that fits the bounding box (:class:`Location`)."""
+        return self._minSphericalRectangle[0]
+
+    @property
+    def size(self):
+        """Width and height in km of the minimum spherical rectangle that fits the bounding box."""
+        return self._minSphericalRectangle[1]
 
     @property
     def containsDiscontinuity(self):

@@ -489,10 +489,51 @@ def themis_reproject_cases():
     save('themis_reproject.npz', **out)
 
 
+def geodesic_cases():
+    """Known answers of the reference's geodesic_test.py / boundingbox_test.py as data: the literal polygons of
+    testContainsPole / testPoleBug / testPoleBug2 (read from the test file's syntax tree; the functions themselves
+    need geographiclib and cannot run here) with the outcomes the tests assert, and the bounding-box vectors."""
+    import ast
+    src = open('/root/reference/auromat/test/geodesic_test.py').read()
+    tree = ast.parse(src)
+    out = {}
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name in ('testPoleBug', 'testPoleBug2')]:
+        for node in fn.body:
+            if not isinstance(node, ast.Assign):
+                continue
+            value = node.value
+            if isinstance(value, ast.Call) and getattr(value.func, 'attr', '') == 'array':
+                value = value.args[0]
+            if isinstance(value, ast.List):
+                out['%s_%s' % (fn.name, node.targets[0].id)] = np.array(ast.literal_eval(value), dtype=np.float64)
+    assert sorted(out) == ['testPoleBug2_outlineFull', 'testPoleBug2_outlineHull', 'testPoleBug2_outlineHullReduced',
+                           'testPoleBug_outlineFull', 'testPoleBug_outlineReduced100'], sorted(out)
+    save('geodesic_polygons.npz', **out)
+    with open(os.path.join(OUT, 'known_answers.json')) as fp:
+        ka = json.load(fp)
+    ka['contains_pole'] = [            # geodesic_test.py:14-29
+        dict(poly=[[1, 0], [1, 4], [5, 6], [5, 2]], expect=False),
+        dict(poly=[[1, 179], [1, -177], [5, -175], [5, -179]], expect=False),
+        dict(poly=[[85, -135], [85, -45], [85, 45], [85, 135]], expect=True),
+        dict(poly=[[85, -90], [85, 0], [85, 90]], expect=True)]
+    ka['bounding_box'] = [             # boundingbox_test.py:12-50 (assert_array_almost_equal: 6 decimals)
+        dict(box=[-60, 80, -30, 85], center=[-45.03119418083877, 82.5], size=[482.39311013217343, 3336.5953086140203]),
+        dict(box=[-60.646114098, 82.7852215499, -38.7515567117, -178.546517062],
+             center=[-54.33647117488648, 132.11935224395], size=[8084.704893634039, 3464.8889697347718]),
+        dict(box=[60, -180, 90, 180], center=[90, 0], size=[6695.78581964, 6695.78581964]),
+        dict(box=[-90, -180, -60, 180], center=[-90, 0], size=[6695.78581964, 6695.78581964]),
+        dict(box=[50, 80, 50, 80], center=[50, 80], size=[0, 0])]
+    ka['bounding_box_merge'] = dict(boxes=[[-55, 95, -45, 109], [44, -164, 74, -35]], merged=[-55, 95, 74, -35],
+                                    center=[21.136113246, -150])
+    with open(os.path.join(OUT, 'known_answers.json'), 'w') as fp:
+        json.dump(ka, fp, indent=1)
+    print('updated known_answers.json')
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['host_scalars', 'georef_small', 'masks_small', 'resample_cases',
                              'histogram_edges', 'known_answers', 'georef_full', 'miracle_cases',
-                             'themis_reproject_cases']
+                             'themis_reproject_cases', 'geodesic_cases']
     for name in which:
         globals()[name]()

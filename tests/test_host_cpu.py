@@ -10,7 +10,7 @@ from datetime import datetime
 import numpy as np
 import pytest
 
-from conftest import ROOT, load_golden
+from conftest import GOLDEN, ROOT, load_golden
 
 
 def parse(s):
@@ -238,3 +238,70 @@ def test_public_header_is_plain_c():
             res = subprocess.run([cc, std, '-pedantic', '-Wall', '-Wextra', '-Werror', '-I', inc, '-c', src, '-o',
                                   src + '.o'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
             assert res.returncode == 0, res.stdout
+
+
+# ---- geodesic helpers and BoundingBox centre / size against the reference's own known answers --------------------
+def _known():
+    import json
+    with open(os.path.join(GOLDEN, 'known_answers.json')) as fp:
+        return json.load(fp)
+
+
+def test_contains_or_crosses_pole_reference_vectors():
+    """geodesic_test.py:14-29 literal polygons, and the large outline polygons of testPoleBug / testPoleBug2
+    (geodesic_test.py:41-2644, data in tests/golden/geodesic_polygons.npz): none of those contains a pole."""
+    from auromat_amd.coordinates.geodesic import containsOrCrossesPole
+    from auromat_amd.utils import convexHull
+    for case in _known()['contains_pole']:
+        assert containsOrCrossesPole(case['poly']) == case['expect'], case
+    z = load_golden('geodesic_polygons.npz')
+    r100 = z['testPoleBug_outlineReduced100']
+    assert not containsOrCrossesPole(convexHull(r100[::2]))
+    assert not containsOrCrossesPole(convexHull(r100))
+    assert not containsOrCrossesPole(z['testPoleBug_outlineFull'])
+    assert not containsOrCrossesPole(z['testPoleBug2_outlineFull'])
+    assert not containsOrCrossesPole(z['testPoleBug2_outlineHull'])
+    assert not containsOrCrossesPole(z['testPoleBug2_outlineHullReduced'])
+    # the same polygons rotated onto a pole do contain it
+    assert containsOrCrossesPole([[80, lon] for lon in range(-180, 180, 30)])
+    assert containsOrCrossesPole([[-80, lon] for lon in range(170, -190, -30)])
+
+
+def test_bounding_box_center_and_size_reference_vectors():
+    """boundingbox_test.py:12-50 to the 6 decimals its assert_array_almost_equal asks for (km and degrees)."""
+    from auromat_amd.mapping.mapping import BoundingBox
+    ka = _known()
+    for case in ka['bounding_box']:
+        s, w, n, e = case['box']
+        bb = BoundingBox(latSouth=s, lonWest=w, latNorth=n, lonEast=e)
+        np.testing.assert_array_almost_equal(bb.center, case['center'])
+        np.testing.assert_array_almost_equal(bb.size, case['size'])
+    m = ka['bounding_box_merge']
+    boxes = [BoundingBox(latSouth=b[0], lonWest=b[1], latNorth=b[2], lonEast=b[3]) for b in m['boxes']]
+    bb = BoundingBox.mergedBoundingBoxes(boxes)
+    assert [bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast] == m['merged']
+    np.testing.assert_array_almost_equal(bb.center, m['center'])
+
+
+def test_geodesic_direct_inverse_consistency():
+    """destination / intermediate / line invert distance / course; the parallel arc of plateCarreeResolution equals
+    the general inverse solution."""
+    from auromat_amd.coordinates import geodesic as G
+    rng = np.random.RandomState(3)
+    for _ in range(200):
+        p = G.Location(rng.uniform(-89, 89), rng.uniform(-180, 180))
+        azi, dist = rng.uniform(-180, 180), rng.uniform(1.0, 9.0e6)
+        q = G.destination(p, azi, dist)
+        assert abs(G.distance(p, q) - dist) < 1e-3                          # < 1 mm over up to 9000 km
+        assert abs((G.course(p, q) - azi + 180) % 360 - 180) < 1e-7
+        mid = G.intermediate(p, q, 0.5)
+        assert abs(G.distance(p, mid) - dist / 2) < 1e-3 and abs(G.distance(mid, q) - dist / 2) < 1e-3
+    for lat, dlon in [(0.0, 10.0), (35.0, 60.0), (-62.0, 25.0), (80.0, 120.0)]:
+        a = G.angularDistance(G.Location(lat, -20.0), G.Location(lat, -20.0 + dlon))
+        assert abs(a - G.angularDistanceOnParallel(lat, dlon)) < 1e-9
+    pts = G.line(G.Location(10, 20), G.Location(12, 25), resolution=10000)
+    assert len(pts) == int(G.distance(G.Location(10, 20), G.Location(12, 25)) // 10000)
+    np.testing.assert_allclose(pts[0], [10, 20], atol=1e-12)
+    np.testing.assert_allclose(pts[-1], [12, 25], atol=1e-8)
+    assert G.line(G.Location(10, 20), G.Location(10.001, 20), resolution=1000).shape == (2, 2)
+    assert G.distance(G.Location(5, 5), G.Location(5, 5)) == 0
