@@ -79,12 +79,13 @@ def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=No
     :param None|number|tuple pxPerDeg: tuple (latPxPerDeg, lonPxPerDeg) or a number if both are the same
     :param None|number arcsecPerPx: spherical resolution, used to approximate pxPerDeg; has precedence
     :param None|bool containsPole: specify True|False to skip the pole check
-    :param method: binning: 'mean'.  The reference's interpolating methods ('nearest', 'linear',
-                   'cubic', scipy griddata) are not implemented.
+    :param method: binning: 'mean'; interpolation: 'nearest' (value of the closest pixel centre in the lat/lon
+                   plane, masked outside the mapping's outline).  The reference's triangulating methods ('linear',
+                   'cubic': scipy griddata on a Delaunay triangulation, "considerably longer ... no benefit over
+                   'nearest' if the goal is downsampling") are not implemented.
     :rtype: a subclass of BaseMapping or MappingCollection
     """
-    if method != 'mean':
-        raise NotImplementedError("only method='mean' is implemented")
+    _check_method(method)
 
     def doResample(mapping, pxPerDeg, arcsecPerPx, containsPole):
         if containsPole is None:
@@ -98,7 +99,8 @@ def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=No
                 assert pxPerDeg is not None
                 pxPerDeg = (pxPerDeg, pxPerDeg)
         res = resample_frame(mapping.frame(), mapping.altitude, mapping.boundingBox, pxPerDeg,
-                             mapping.containsDiscontinuity, containsPole)
+                             mapping.containsDiscontinuity, containsPole, method=method,
+                             outline=None if method == 'mean' else mapping.outline)
         img = ma.masked_array(res['img'], mask=np.repeat(res['mask'][:, :, None], res['img'].shape[2], 2))
         elevation = ma.masked_invalid(res['mean'][:, :, -1], copy=False) if res['has_elev'] else None
         return mapping.createResampled(res['lat'], res['lon'], res['lat_c'], res['lon_c'], elevation, img)
@@ -249,8 +251,46 @@ def _rotate_pole_host(lat_deg, lon_deg, altitude, angle):
     return to_host(la), to_host(lo)
 
 
+def _check_method(method):
+    if method in ('linear', 'cubic', 'median'):
+        raise NotImplementedError("method='%s' is not implemented (use 'mean' or 'nearest')" % method)
+    if method not in ('mean', 'nearest'):
+        raise ValueError('unknown resampling method: ' + str(method))
+
+
+def outside_outline_mask(ctx, grid, outline):
+    """
+    (ny, nx) uint8 device mask of the grid cells with a corner outside the outline polygon (reference
+    resample.py:246-259: pointsInsidePolygon of the corner grid, a cell is masked if any of its 4 corners is outside).
+
+    :param outline: (n,2) [lat,lon] polygon in the coordinates of the grid (rotated / shifted like the data)
+    """
+    import torch
+    poly = ctx.to_device(np.ascontiguousarray(outline, dtype=np.float64))
+    lat = ctx.to_device(np.ascontiguousarray(grid.lat, dtype=np.float64))
+    lon = ctx.to_device(np.ascontiguousarray(grid.lon, dtype=np.float64))
+    inside = ctx.empty(tuple(lat.shape), torch.uint8)
+    ctx.call('amt_points_in_polygon', ptr(lat), ptr(lon), lat.numel(), ptr(poly), int(poly.shape[0]), ptr(inside))
+    out = inside == 0
+    return (out[:-1, :-1] | out[1:, :-1] | out[:-1, 1:] | out[1:, 1:]).to(torch.uint8).contiguous()
+
+
+def nearest_indices(ctx, lat_c, lon_c, elev, center_mask, height, width, min_elevation, grid, lon_wrap, target_mask):
+    """(ny, nx) int64 device tensor: flat index of the pixel centre nearest to every grid centre, -1 = none / masked
+    (``amt_nearest_frame``; reference resample.py:323-327, griddata(method='nearest'))."""
+    import torch
+    xaxis, yaxis = grid.axes(ctx)
+    tlat = ctx.to_device(np.ascontiguousarray(grid.latCenters))
+    tlon = ctx.to_device(np.ascontiguousarray(grid.lonCenters))
+    index = ctx.empty((grid.ny, grid.nx), torch.int64)
+    min_el = float('-inf') if min_elevation is None else float(min_elevation)
+    ctx.call('amt_nearest_frame', ptr(lat_c), ptr(lon_c), ptr(elev), ptr(center_mask), height, width, min_el,
+             C.byref(xaxis), C.byref(yaxis), lon_wrap, ptr(tlat), ptr(tlon), ptr(target_mask), ptr(index))
+    return index
+
+
 def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=False, containsPole=False,
-                   min_elevation=None, keep_on_device=False):
+                   min_elevation=None, keep_on_device=False, method='mean', outline=None):
     """
     ``_resample`` + ``_resampleCenterData(method='mean')`` + the image finalisation of ``resample``
     (reference resample.py:119-136,159-279,301-351) on a device-resident frame.
@@ -258,10 +298,14 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
     :param FrameData fd: centre lat/lon, elevation (optional), image and masks in HBM
     :param min_elevation: fuse ``maskedByElevation(min_elevation)`` into the binning pass (the frame's
                           own centre mask is applied in addition)
+    :param method: 'mean' (binning) or 'nearest' (closest pixel centre; needs `outline`)
+    :param outline: (n,2) [lat,lon] polygon of the mapping (``BaseMapping.outline``) for the interpolating methods:
+                    grid cells with a corner outside it are masked (reference resample.py:246-259)
     :return: dict(lat, lon, lat_c, lon_c [grid coordinates, host], mean (ny,nx,C+1), img (ny,nx,C),
-                  mask (ny,nx), count (ny,nx), has_elev)
+                  mask (ny,nx), count (ny,nx) ['mean' only], has_elev)
     """
     import torch
+    _check_method(method)
     ctx = fd.ctx
     latMin, latMax = boundingBox.latSouth, boundingBox.latNorth
     lonMin, lonMax = boundingBox.lonWest, boundingBox.lonEast
@@ -285,6 +329,30 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
     grid = cached_grid(pxPerDeg, latMin, latMax, lonMin, lonMax)
     xaxis, yaxis = grid.axes(ctx)
     nch = fd.nchan
+    if method == 'nearest':
+        assert outline is not None, "method='nearest' needs the outline of the mapping"
+        outline = np.array(outline, dtype=np.float64)
+        if containsPole:
+            outline[:, 0], outline[:, 1] = _rotate_pole_host(outline[:, 0], outline[:, 1], altitude, 90)
+        elif containsDiscontinuity:
+            outline[:, 1] = wrap_at_180(outline[:, 1] + 180)
+        target_mask = outside_outline_mask(ctx, grid, outline)
+        index = nearest_indices(ctx, lat_c, lon_c, fd.elev, fd.center_mask, fd.height, fd.width, min_elevation, grid,
+                                lon_wrap, target_mask)
+        mean = ctx.empty((grid.ny, grid.nx, nch + 1))
+        img = ctx.empty((grid.ny, grid.nx, max(nch, 1)), torch.uint8 if fd.img_dtype_code != 2 else torch.int16)
+        mask = ctx.empty((grid.ny, grid.nx), torch.uint8)
+        ctx.call('amt_nearest_gather', ptr(index), grid.nx * grid.ny, ptr(fd.img), fd.img_dtype_code or 1, nch,
+                 ptr(fd.elev), ptr(mean), ptr(img) if nch else None, ptr(mask))
+        out = dict(has_elev=fd.elev is not None, grid=grid, contains_pole=bool(containsPole),
+                   contains_discontinuity=bool(containsDiscontinuity), altitude=altitude)
+        if keep_on_device:
+            out.update(mean=mean, img=img, mask=mask, index=index)
+            return out
+        out.update(grid_coordinates(out))
+        out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype if nch else np.uint8),
+                   mask=to_host(mask).astype(bool), index=to_host(index, dtype=np.int64))
+        return out
     acc = ctx.zeros((nch + 2, grid.nx * grid.ny), torch.int64)
     min_el = float('-inf') if min_elevation is None else float(min_elevation)
     ctx.call('amt_bin_frame', ptr(lat_c), ptr(lon_c), ptr(fd.elev), ptr(fd.img), fd.img_dtype_code, nch,
@@ -334,29 +402,46 @@ def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingB
     :param pxPerDeg: tuple (latPxPerDeg, lonPxPerDeg)
     :rtype: tuple (lat, lon, latCenter, lonCenter, data)
     """
-    if method != 'mean':
-        raise NotImplementedError("only method='mean' is implemented")
+    _check_method(method)
     ctx = Context.current()
     latMin, latMax = boundingBox.latSouth, boundingBox.latNorth
     lonMin, lonMax = boundingBox.lonWest, boundingBox.lonEast
     lat_c = ctx.to_device(np.asarray(latsCenter, dtype=np.float64))
     lon_c = ctx.to_device(np.asarray(lonsCenter, dtype=np.float64))
     lon_wrap = 0
+    outline = None
     if containsPole:
-        outline = np.asarray(outlineLatLonFn(), dtype=np.float64)
-        ola, olo = _rotate_pole_host(outline[:, 0], outline[:, 1], altitude, 90)
-        latMin, latMax, lonMin, lonMax = np.min(ola), np.max(ola), np.min(olo), np.max(olo)
+        outline = np.array(outlineLatLonFn(), dtype=np.float64)
+        outline[:, 0], outline[:, 1] = _rotate_pole_host(outline[:, 0], outline[:, 1], altitude, 90)
+        latMin, latMax, lonMin, lonMax = np.min(outline[:, 0]), np.max(outline[:, 0]), np.min(outline[:, 1]), \
+            np.max(outline[:, 1])
         lat_c, lon_c = _rotate_pole_dev(ctx, lat_c, lon_c, altitude, 90)
     elif containsDiscontinuity:
-        outlineLons = wrap_at_180(np.asarray(outlineLatLonFn(), dtype=np.float64)[:, 1] + 180)
-        lonMin, lonMax = np.min(outlineLons), np.max(outlineLons)
+        outline = np.array(outlineLatLonFn(), dtype=np.float64)
+        outline[:, 1] = wrap_at_180(outline[:, 1] + 180)
+        lonMin, lonMax = np.min(outline[:, 1]), np.max(outline[:, 1])
         lon_wrap = 1
     grid = _Grid(pxPerDeg, latMin, latMax, lonMin, lonMax)
     scalar = np.ndim(data) == 2
     d = np.asarray(data, dtype=np.float64)
     if scalar:
         d = d[..., None]
-    mean = _resampleCenterData(lat_c, lon_c, d, grid, lon_wrap)
+    if method == 'mean':
+        mean = _resampleCenterData(lat_c, lon_c, d, grid, lon_wrap)
+    else:
+        # nearest pixel centre for every grid centre, then everything outside the outline is masked
+        # (reference resample.py:246-259,323-327; the reference rotates / shifts the outline in place, :176-218)
+        import torch
+        if outline is None:
+            outline = np.array(outlineLatLonFn(), dtype=np.float64)
+        target_mask = outside_outline_mask(ctx, grid, outline)
+        h, w = d.shape[:2]
+        index = nearest_indices(ctx, lat_c.reshape(-1), lon_c.reshape(-1), None, None, h, w, None, grid, lon_wrap,
+                                target_mask)
+        flat = ctx.to_device(np.ascontiguousarray(d.reshape(h * w, d.shape[2])))
+        picked = flat[index.clamp(min=0).reshape(-1)]
+        picked[index.reshape(-1) < 0] = float('nan')
+        mean = to_host(picked.reshape(grid.ny, grid.nx, d.shape[2]))
     lat, lon, lat_gc, lon_gc = grid.lat, grid.lon, grid.lat_c, grid.lon_c
     if containsPole:
         lat, lon = _rotate_pole_host(lat, lon, altitude, -90)

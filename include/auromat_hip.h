@@ -363,6 +363,32 @@ int amt_bin_frame_finalize_window(amt_ctx* ctx, const uint64_t* acc, int32_t acc
 int amt_hist2d_finalize_mean(amt_ctx* ctx, const double* count, const double* const* sums, int32_t nweights,
                              int32_t nx, int32_t ny, double* mean);
 
+/* ---- resample(method='nearest') and the outside-outline masking -------------------- */
+
+/* auromat/resample.py:301-327: scipy.interpolate.griddata((lat_c, lon_c)[valid], values, (latSpaceCenter[:,None],
+ * lonSpaceCenter[None,:]), method='nearest'), i.e. for every grid centre the valid pixel centre at the smallest
+ * Euclidean distance in the (lat, lon) plane in degrees.  Valid pixels as in amt_bin_frame (finite coordinates,
+ * center_mask == 0, elev >= min_elevation unless that is -inf); lon_wrap != 0 searches with wrap_at(lon + 180, 180).
+ * xaxis / yaxis: the uniform histogram axes of the output grid (amt_grid.xaxis / .yaxis: one bin per grid centre);
+ * target_lat (ny, north -> south) / target_lon (nx): the grid centres themselves (device arrays);
+ * target_mask: (ny, nx) uint8, 1 = do not search (e.g. outside the outline), may be NULL.
+ * out_index: (ny, nx) int64, the flat index of the nearest pixel, -1 where masked or when there is no valid pixel.
+ * Of several pixels at exactly the same distance the one with the lowest index wins (the k-d tree of the reference
+ * returns an unspecified one).  Uses the context's workspace (about 8 bytes per pixel + 12 per grid cell). */
+int amt_nearest_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, const double* elev,
+                      const uint8_t* center_mask, int32_t height, int32_t width, double min_elevation,
+                      const amt_axis* xaxis, const amt_axis* yaxis, int lon_wrap, const double* target_lat,
+                      const double* target_lon, const uint8_t* target_mask, int64_t* out_index);
+/* Values of the pixels chosen by amt_nearest_frame, laid out like the outputs of amt_bin_frame_finalize:
+ * mean (optional): (n_targets, nchan+1) float64 image channels + elevation, NaN where index < 0;
+ * out_img (optional): (n_targets, nchan) of img_dtype (0 where index < 0); out_mask (optional): 1 where index < 0. */
+int amt_nearest_gather(amt_ctx* ctx, const int64_t* index, int64_t n_targets, const void* img, int32_t img_dtype,
+                       int32_t nchan, const double* elev, double* mean, void* out_img, uint8_t* out_mask);
+/* auromat/utils.py:58-74 pointsInsidePolygon = matplotlib.path.Path(polygon).contains_points(points): crossing test
+ * with Agg's half-open edge rule; polygon: (n_vertices, 2) device doubles (x, y), closed implicitly. */
+int amt_points_in_polygon(amt_ctx* ctx, const double* px, const double* py, int64_t n, const double* polygon,
+                          int32_t n_vertices, uint8_t* out_inside);
+
 /* ---- grid layout and the single-pass frame driver ------------------------------------------ */
 
 /* Output grid of resample(method='mean') for a bounding box: auromat/resample.py:281-299 fixedGrid (global

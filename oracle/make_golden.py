@@ -530,10 +530,61 @@ def geodesic_cases():
     print('updated known_answers.json')
 
 
+def _traced_outline(lats, lons):
+    """mapping.outline (mapping.py:655-680) with the oracle's restated find_contours (skimage is absent)"""
+    from oracle import ref_numpy as O
+    outl = O.outline(~ma.getmaskarray(lats))
+    return np.transpose([lats.data[outl[:, 1], outl[:, 0]], lons.data[outl[:, 1], outl[:, 0]]])
+
+
+def _run_resample_nearest(lats, lons, lats_c, lons_c, altitude, merged, ppd, pole=False):
+    bb = _bbox_from(lats, lons)
+    outline = _traced_outline(lats, lons)
+    outline_in = outline.copy()
+    disc = bool(bb.lonWest > bb.lonEast)
+    if pole:
+        bb = BoundingBox(bb.latSouth, -180, 90, 180) if bb.latNorth > 0 else BoundingBox(-90, -180, bb.latNorth, 180)
+    # like `lambda: mapping.outline` (resample.py:124): the SAME array on every call — the reference rotates / shifts
+    # it in place (:192-193,214) and reads it again for the masking (:254)
+    res = R._resample(lats_c, lons_c, altitude, merged, lambda: outline, bb, ppd,
+                      containsDiscontinuity=disc or pole, containsPole=pole, method='nearest')
+    la, lo, lac, loc, data = res
+    return dict(bbox=np.array([bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast]),
+                contains_discontinuity=np.bool_(disc), contains_pole=np.bool_(pole),
+                outline=outline_in, out_lat=la, out_lon=lo, out_lat_c=lac, out_lon_c=loc, out_data=data)
+
+
+def resample_nearest_cases():
+    """`_resample(method='nearest')` of the real reference (scipy griddata + matplotlib point-in-polygon)"""
+    for pointing, ppd in (('iss030', (10, 10)), ('iss029', (4, 7))):
+        w, h = 256, 170
+        hdr, cam, t = frame_header(w, h, pointing)
+        img = frame_image(w, h, seed=3)
+        m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'r', fastCenterCalculation=True)
+        mm = m.maskedByElevation(10)
+        merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+        lats_c, lons_c = mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan)
+        case = _run_resample_nearest(mm.lats, mm.lons, lats_c, lons_c, 110, merged, ppd)
+        case.update(hdr_arrays(hdr))
+        case.update(time_arrays(t))
+        case.update(cam=cam, altitude=np.float64(110), img=img, min_elev=np.float64(10), lats_c=lats_c, lons_c=lons_c,
+                    elev=mm.elevation.filled(np.nan), corner_lat=mm.lats.filled(np.nan),
+                    corner_lon=mm.lons.filled(np.nan), ppd=np.array(ppd, dtype=np.float64))
+        save('resample_nearest_%s.npz' % pointing, **case)
+    for tag in ('plain', 'disc', 'pole'):
+        z = np.load(os.path.join(OUT, 'resample_synth_%s.npz' % tag))
+        case = _run_resample_nearest(ma.masked_invalid(z['corner_lat']), ma.masked_invalid(z['corner_lon']),
+                                     z['lats_c'], z['lons_c'], 110, z['data'], (4, 4), pole=(tag == 'pole'))
+        case.update(lats_c=z['lats_c'], lons_c=z['lons_c'], data=z['data'], corner_lat=z['corner_lat'],
+                    corner_lon=z['corner_lon'], altitude=np.float64(110), ppd=np.array((4, 4), dtype=np.float64))
+        save('resample_nearest_synth_%s.npz' % tag, **case)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['host_scalars', 'georef_small', 'masks_small', 'resample_cases',
                              'histogram_edges', 'known_answers', 'georef_full', 'miracle_cases',
-                             'themis_reproject_cases', 'geodesic_cases']
+                             'themis_reproject_cases', 'geodesic_cases',
+                             'resample_nearest_cases']
     for name in which:
         globals()[name]()

@@ -847,19 +847,37 @@ def bin_mean(lats_c, lons_c, data, lat_centers, lon_centers, lat_step, lon_step)
     return np.dstack(planes), np.flipud(count)
 
 
+def points_inside_polygon(points, polygon):
+    """utils.py:58-74 pointsInsidePolygon: matplotlib's Path.contains_points, the library call the reference makes
+    (matplotlib is part of this image); points, polygon: (n,2)"""
+    import matplotlib.path
+    return matplotlib.path.Path(polygon).contains_points(points)
+
+
+def resample_nearest(lats_c, lons_c, altitude, data, outline_latlon, bbox, px_per_deg,
+                     contains_discontinuity=False, contains_pole=False):
+    """resample.py:159-279 for method='nearest': scipy.interpolate.griddata (the reference's own call, :323-327) and
+    the outside-outline masking (:246-259).  Returns dict(lat, lon, lat_c, lon_c, data)."""
+    return resample_mean(lats_c, lons_c, altitude, data, outline_latlon, bbox, px_per_deg, contains_discontinuity,
+                         contains_pole, method='nearest')
+
+
 def resample_mean(lats_c, lons_c, altitude, data, outline_latlon, bbox, px_per_deg,
-                  contains_discontinuity=False, contains_pole=False):
+                  contains_discontinuity=False, contains_pole=False, method='mean'):
     """
-    resample.py:159-279 for method='mean'.
+    resample.py:159-279 for method='mean' (and, through resample_nearest, 'nearest').
     bbox = (latSouth, lonWest, latNorth, lonEast); outline_latlon (n,2) is only
-    used (min/max) in the pole / discontinuity branches.
+    used (min/max) in the pole / discontinuity branches of 'mean'.
     Returns dict(lat, lon, lat_c, lon_c, data, count).
     """
     lat_min, lon_min, lat_max, lon_max = bbox
+    if outline_latlon is not None:
+        outline_latlon = np.array(outline_latlon, dtype=np.float64, copy=True)
     if contains_pole:
-        ol = np.array(outline_latlon, dtype=np.float64, copy=True)
+        ol = outline_latlon
         ola, olo = rotate_pole(np.deg2rad(ol[:, 0]), np.deg2rad(ol[:, 1]), altitude, angle=90, axis=(1, 0, 0))
         ola, olo = np.rad2deg(ola), np.rad2deg(olo)
+        outline_latlon[:, 0], outline_latlon[:, 1] = ola, olo        # in place, as resample.py:192-193
         lat_min, lat_max = np.min(ola), np.max(ola)
         lon_min, lon_max = np.min(olo), np.max(olo)
         la, lo = rotate_pole(np.deg2rad(np.ravel(lats_c)), np.deg2rad(np.ravel(lons_c)), altitude,
@@ -868,6 +886,7 @@ def resample_mean(lats_c, lons_c, altitude, data, outline_latlon, bbox, px_per_d
         lons_c = np.rad2deg(lo.reshape(lons_c.shape))
     elif contains_discontinuity:
         olo = wrap_at(np.asarray(outline_latlon)[:, 1] + 180, 180)
+        outline_latlon[:, 1] = olo                                   # in place, as resample.py:214
         lon_min, lon_max = np.min(olo), np.max(olo)
         lons_c = wrap_at(lons_c + 180, 180)
 
@@ -886,7 +905,19 @@ def resample_mean(lats_c, lons_c, altitude, data, outline_latlon, bbox, px_per_d
 
     if data.ndim == 2:
         data = data[..., None]
-    mean, count = bin_mean(lats_c, lons_c, data, lat_centers, lon_centers, lat_step, lon_step)
+    if method == 'mean':
+        mean, count = bin_mean(lats_c, lons_c, data, lat_centers, lon_centers, lat_step, lon_step)
+    else:
+        import scipy.interpolate
+        ok = ~np.isnan(np.ravel(lats_c))                               # resample.py:315-321
+        flat = data.reshape(-1, data.shape[2])[ok]
+        mean = scipy.interpolate.griddata((np.ravel(lats_c)[ok], np.ravel(lons_c)[ok]), flat,
+                                          (lat_centers[:, None], lon_centers[None, :]), method=method)
+        count = None
+        pts = np.asarray([np.ravel(lat_grid), np.ravel(lon_grid)]).T    # resample.py:253-259
+        outside = ~points_inside_polygon(pts, outline_latlon).reshape(lat_grid.shape)
+        mask = np.logical_or.reduce((outside[:-1, :-1], outside[1:, :-1], outside[:-1, 1:], outside[1:, 1:]))
+        mean[mask] = np.nan
 
     if contains_pole:
         def back(la, lo):

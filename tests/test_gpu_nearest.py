@@ -1,0 +1,212 @@
+"""
+GPU parity tests of resample(method='nearest') and the outside-outline masking (reference
+resample.py:246-259,301-327, utils.py:58-74): against outputs of the real reference's `_resample(method='nearest')`
+(tests/golden/resample_nearest_*.npz: scipy griddata + matplotlib point-in-polygon) and against the oracle.
+"""
+import ctypes as C
+
+import numpy as np
+import numpy.ma as ma
+import pytest
+
+from conftest import header_from, load_golden
+
+pytestmark = pytest.mark.gpu
+
+NEAREST = ['resample_nearest_iss030.npz', 'resample_nearest_iss029.npz', 'resample_nearest_synth_plain.npz',
+           'resample_nearest_synth_disc.npz', 'resample_nearest_synth_pole.npz']
+
+
+def same(a, b, tol=0.0):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    assert np.array_equal(np.isnan(a), np.isnan(b)), int((np.isnan(a) != np.isnan(b)).sum())
+    ok = ~np.isnan(a)
+    assert np.max(np.abs(a[ok] - b[ok]), initial=0.0) <= tol
+
+
+@pytest.mark.parametrize('name', NEAREST)
+def test_array_level_resample_nearest_vs_reference(name):
+    """`_resample(..., method='nearest')` with the reference's signature: identical values and masks, cell by cell."""
+    from auromat_amd.mapping.mapping import BoundingBox
+    from auromat_amd.resample import _resample
+    z = load_golden(name)
+    if 'img' in z.files:
+        data = np.dstack((z['img'].astype(np.float64), z['elev']))
+        data[np.isnan(z['lats_c'])] = np.nan
+    else:
+        data = z['data']
+    s, w, n, e = z['bbox']
+    outline = z['outline'].copy()
+    lat, lon, lat_c, lon_c, out = _resample(z['lats_c'], z['lons_c'], float(z['altitude']), data, lambda: outline,
+                                            BoundingBox(s, w, n, e), tuple(z['ppd']),
+                                            bool(z['contains_discontinuity']), bool(z['contains_pole']),
+                                            method='nearest')
+    pole = bool(z['contains_pole'])
+    for got, k in ((lat, 'lat'), (lon, 'lon'), (lat_c, 'lat_c'), (lon_c, 'lon_c')):
+        same(got, z['out_' + k], 1e-9 if pole else 0.0)
+    same(out, z['out_data'])
+
+
+@pytest.mark.parametrize('pointing,ppd', [('iss030', 10), ('iss029', (4, 7))])
+def test_mapping_resample_nearest_vs_oracle(pointing, ppd):
+    """resample(mapping.maskedByElevation(10), method='nearest') end to end: device outline, point-in-polygon mask,
+    grid search, gather — against the oracle run on the oracle's own arrays of the same frame."""
+    from oracle import ref_numpy as O
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.resample import resample
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 256, 170
+    hdr, cam, t = frame_header(w, h, pointing)
+    img = frame_image(w, h, seed=3)
+    m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'n', fastCenterCalculation=True).maskedByElevation(10)
+    r = resample(m, pxPerDeg=ppd, method='nearest')
+    r.checkGuarantees()
+    r.checkPlateCarree()
+
+    et = O.date2es(t)
+    g = O.georef_frame(hdr, 110, cam, O.mat_j2000_to_geo(et), None, fast=True)
+    corner_mask, center_mask = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), 10)
+    bbox, disc = O.bbox_of_corners(g['lat'], g['lon'], corner_mask)
+    outl = O.outline(~corner_mask)
+    outline = np.transpose([g['lat'][outl[:, 1], outl[:, 0]], g['lon'][outl[:, 1], outl[:, 0]]])
+    data = np.dstack((img.astype(np.float64), g['elev']))
+    data[center_mask] = np.nan
+    p = (ppd, ppd) if np.ndim(ppd) == 0 else ppd
+    want = O.resample_nearest(np.where(center_mask, np.nan, g['lat_c']), np.where(center_mask, np.nan, g['lon_c']), 110,
+                              data, outline, bbox, p, disc, False)
+    assert want['data'].shape[:2] == r.latsCenter.shape
+    got_mask = ma.getmaskarray(r.latsCenter)
+    want_mask = np.isnan(want['data'][..., 0])
+    # coordinates agree to 1e-11 deg: a grid corner within that of the outline or two pixels within that of being
+    # equidistant may flip; nothing else may differ
+    assert int((got_mask != want_mask).sum()) <= 2
+    both = ~got_mask & ~want_mask
+    assert both.sum() > 1000
+    diff = np.any(r.img.data[both] != want['data'][..., :3][both], axis=-1)
+    assert int(diff.sum()) <= 2
+    ok = both.copy()
+    ok[both] = ~diff
+    assert np.array_equal(r.elevation.data[ok], want['data'][..., 3][ok]) or \
+        np.max(np.abs(r.elevation.data[ok] - want['data'][..., 3][ok])) < 1e-9
+
+
+def test_points_in_polygon_vs_matplotlib():
+    """amt_points_in_polygon == matplotlib.path.Path.contains_points (the reference's pointsInsidePolygon), random
+    points and a lattice whose points fall exactly on vertices and edges of an integer polygon."""
+    import matplotlib.path
+    from auromat_amd._native import Context, ptr, to_host
+    import torch
+    ctx = Context.current()
+    rng = np.random.RandomState(11)
+    ang = np.sort(rng.uniform(0, 2 * np.pi, 700))
+    rad = 5 + 2 * np.sin(5 * ang) + rng.uniform(-0.3, 0.3, ang.size)
+    poly = np.transpose([3 + rad * np.cos(ang), -2 + rad * np.sin(ang)])
+    pts = rng.uniform(-6, 12, (20000, 2))
+    cases = [(poly, pts), (poly[::-1].copy(), pts)]
+    ipoly = np.array([[0, 0], [6, 0], [6, 3], [3, 3], [3, 6], [0, 6]], dtype=np.float64)
+    gy, gx = np.mgrid[-1:8, -1:8]
+    lattice = np.transpose([gx.ravel(), gy.ravel()]).astype(np.float64)
+    half = lattice + 0.5
+    cases += [(ipoly, lattice), (ipoly, half), (ipoly[::-1].copy(), lattice)]
+    for polygon, points in cases:
+        want = matplotlib.path.Path(polygon).contains_points(points)
+        px = ctx.to_device(np.ascontiguousarray(points[:, 0]))
+        py = ctx.to_device(np.ascontiguousarray(points[:, 1]))
+        out = ctx.empty((len(points),), torch.uint8)
+        ctx.call('amt_points_in_polygon', ptr(px), ptr(py), len(points), ptr(ctx.to_device(polygon)), len(polygon),
+                 ptr(out))
+        got = to_host(out).astype(bool)
+        assert np.array_equal(got, want), (int((got != want).sum()), points[got != want][:5])
+
+
+def test_nearest_frame_brute_force_and_ties():
+    """amt_nearest_frame against a brute-force search (NumPy) on scattered points with empty regions (rings > 1),
+    points beyond the grid, masked targets, an elevation threshold, and exact ties (lowest index wins)."""
+    from auromat_amd._native import Context, ptr, to_host
+    from auromat_amd.resample import _Grid, nearest_indices
+    import torch
+    ctx = Context.current()
+    rng = np.random.RandomState(5)
+    h, w = 60, 70
+    lat = rng.uniform(40.2, 47.9, (h, w))
+    lon = rng.uniform(9.7, 21.3, (h, w))
+    far = (lat > 43) & (lat < 45.5) & (lon > 13) & (lon < 17)          # an empty region several cells wide
+    lat[far] = np.nan
+    lon[far] = np.nan
+    lat[0, :5], lon[0, :5] = 39.0, 8.0                                   # beyond the grid: border candidates
+    lat[1, 0], lon[1, 0] = 42.05, 12.05                                  # two pixels on top of each other: a tie
+    lat[1, 1], lon[1, 1] = 42.05, 12.05
+    elev = rng.uniform(0, 40, (h, w))
+    grid = _Grid((10, 10), 41.0, 47.0, 10.5, 20.5)
+    tmask = np.zeros((grid.ny, grid.nx), np.uint8)
+    tmask[:3, :] = 1
+    for thr, use_mask in ((None, False), (12.0, True)):
+        idx = nearest_indices(ctx, ctx.to_device(lat), ctx.to_device(lon), ctx.to_device(elev), None, h, w, thr, grid,
+                              0, ctx.to_device(tmask, np.uint8) if use_mask else None)
+        got = to_host(idx, dtype=np.int64)
+        ok = ~np.isnan(lat.ravel())
+        if thr is not None:
+            ok &= elev.ravel() >= thr
+        src = np.nonzero(ok)[0]
+        d = (lat.ravel()[src][None, None, :] - grid.latCenters[:, None, None]) ** 2 + \
+            (lon.ravel()[src][None, None, :] - grid.lonCenters[None, :, None]) ** 2
+        want = src[np.argmin(d, axis=2)]                                  # argmin: first = lowest index on ties
+        if use_mask:
+            want = np.where(tmask == 1, -1, want)
+        assert np.array_equal(got, want), int((got != want).sum())
+    # no valid pixel at all
+    idx = nearest_indices(ctx, ctx.to_device(np.full((4, 4), np.nan)), ctx.to_device(np.full((4, 4), np.nan)), None,
+                          None, 4, 4, None, grid, 0, None)
+    assert (to_host(idx, dtype=np.int64) == -1).all()
+
+
+def test_resample_methods_error_behaviour():
+    from auromat_amd.resample import resample
+    with pytest.raises(NotImplementedError):
+        resample(None, method='linear')
+    with pytest.raises(NotImplementedError):
+        resample(None, method='cubic')
+    with pytest.raises(ValueError):
+        resample(None, method='bogus')
+
+
+def test_nearest_full_size_properties():
+    """BASELINE full-size frame: every unmasked cell carries the value of a real pixel that is at least as close as
+    any other pixel of a random sample; cells of the 'mean' grid that hold pixels are unmasked here too."""
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.resample import resample_frame
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 4240, 2832
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    img = frame_image(w, h, seed=1)
+    m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'f', fastCenterCalculation=True).maskedByElevation(10)
+    fd = m.frame()
+    res = resample_frame(fd, 110, m.boundingBox, (10, 10), m.containsDiscontinuity, False, method='nearest',
+                         outline=m.outline)
+    mean = resample_frame(fd, 110, m.boundingBox, (10, 10), m.containsDiscontinuity, False)
+    assert res['img'].shape == mean['img'].shape
+    idx = res['index']
+    valid = idx >= 0
+    assert valid.sum() > 0.5 * valid.size
+    lat_c, lon_c = m.latsCenter, m.lonsCenter
+    flat_img = img.reshape(-1, 3)
+    assert np.array_equal(res['img'][valid], flat_img[idx[valid]])
+    assert not ma.getmaskarray(lat_c).ravel()[idx[valid]].any()            # only unmasked pixels are chosen
+    # the chosen pixel is no farther than any pixel of a random sample
+    rng = np.random.RandomState(0)
+    sample = rng.choice(np.nonzero(~ma.getmaskarray(lat_c).ravel())[0], 4000, replace=False)
+    rows, cols = np.nonzero(valid)
+    pick = rng.choice(len(rows), 300, replace=False)
+    glat, glon = res['lat_c'], res['lon_c']
+    la, lo = lat_c.data.ravel(), lon_c.data.ravel()
+    for k in pick:
+        r, c = rows[k], cols[k]
+        d_best = (la[idx[r, c]] - glat[r, c]) ** 2 + (lo[idx[r, c]] - glon[r, c]) ** 2
+        d_s = (la[sample] - glat[r, c]) ** 2 + (lo[sample] - glon[r, c]) ** 2
+        assert d_best <= d_s.min()
+    # interior cells of the binned grid are unmasked in the nearest grid as well
+    filled = ~mean['mask']
+    interior = filled[1:-1, 1:-1] & filled[:-2, 1:-1] & filled[2:, 1:-1] & filled[1:-1, :-2] & filled[1:-1, 2:]
+    assert (res['mask'][1:-1, 1:-1][interior]).mean() < 0.02

@@ -279,3 +279,24 @@ def test_outline_oracle_vs_reference_known_answers():
     holed = im.copy()
     holed[4, 4] = False
     assert O.outline(holed).tolist() == ka['polygon']
+
+
+# ---- resample(method='nearest') (resample.py:246-259,323-327) --------------------------------------------------
+NEAREST = ['resample_nearest_iss030.npz', 'resample_nearest_iss029.npz', 'resample_nearest_synth_plain.npz',
+           'resample_nearest_synth_disc.npz', 'resample_nearest_synth_pole.npz']
+
+
+@pytest.mark.parametrize('name', NEAREST)
+def test_resample_nearest_oracle_vs_reference(name):
+    z = load_golden(name)
+    if 'img' in z.files:
+        data = np.dstack((z['img'].astype(np.float64), z['elev']))
+        data[np.isnan(z['lats_c'])] = np.nan
+    else:
+        data = z['data']
+    res = O.resample_nearest(z['lats_c'], z['lons_c'], float(z['altitude']), data, z['outline'], tuple(z['bbox']),
+                             tuple(z['ppd']), bool(z['contains_discontinuity']), bool(z['contains_pole']))
+    for k in ('lat', 'lon', 'lat_c', 'lon_c'):
+        same(res[k], z['out_' + k], 0.0 if not bool(z['contains_pole']) else 1e-12)
+    same(res['data'], z['out_data'])
+    assert not np.isnan(res['data'][..., 0]).all()
