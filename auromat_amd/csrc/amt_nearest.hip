@@ -4,7 +4,7 @@
 // Nearest neighbour of every grid centre among the valid pixel centres, Euclidean in the (lat, lon) plane in
 // degrees, as scipy.interpolate.griddata(method='nearest') (a cKDTree query) defines it.  On the device the
 // search structure is the output grid itself: a counting sort of the source pixels by the grid cell they fall
-// into (count -> exclusive scan -> fill), then one thread per grid centre visits the cells ring by ring and
+// into (count -> exclusive scan -> fill), then one wavefront per grid centre visits the cells ring by ring and
 // stops as soon as the best candidate is closer than anything an unvisited cell can hold.  HBM-bound: two passes
 // over the centre coordinates plus ~9 cells x (pixels per cell) gathered coordinate pairs per grid centre.
 #include "amt_common.h"
@@ -60,15 +60,38 @@ __device__ __forceinline__ int source_cell(const nn_args& A, double x, double y)
     return iy * A.nx + ix;
 }
 
-__global__ void k_nn_count(nn_args A, int* __restrict__ cell_of, unsigned* __restrict__ count) {
-    AMT_GRID_STRIDE(i, A.n) {
+// Neighbouring pixels mostly fall into the same grid cell: lanes of a wave that hold a run of equal cells let the
+// first lane of the run issue ONE atomic for all of them (6-10 atomics per wave instead of 64).
+struct lane_run {
+    int head;       // lane that starts this lane's run
+    int length;     // pixels in the run (meaningful on the head lane)
+};
+
+__device__ __forceinline__ lane_run run_of(int c, int lane) {
+    const int prev = __shfl_up(c, 1);
+    const bool is_head = lane == 0 || prev != c;
+    const unsigned long long heads = __ballot(is_head);
+    const unsigned long long upto = heads & (~0ull >> (63 - lane));      // heads at or below this lane
+    lane_run r;
+    r.head = 63 - __clzll(upto);
+    const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+    r.length = above ? __ffsll((long long)above) : 64 - lane;
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_nn_count(nn_args A, int* __restrict__ cell_of,
+                                                    unsigned* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // whole waves stay in the loop together (the shuffles need every lane)
+    for (int64_t base = blockIdx.x * (int64_t)blockDim.x + (threadIdx.x & ~63); base < A.n; base += stride) {
+        const int64_t i = base + lane;
         double x, y;
         int c = -1;
-        if (source_xy(A, i, x, y)) {
-            c = source_cell(A, x, y);
-            atomicAdd(&count[c], 1u);
-        }
-        cell_of[i] = c;
+        if (i < A.n && source_xy(A, i, x, y)) c = source_cell(A, x, y);
+        if (i < A.n) cell_of[i] = c;
+        const lane_run r = run_of(c, lane);
+        if (r.head == lane && c >= 0) atomicAdd(&count[c], (unsigned)r.length);
     }
 }
 
@@ -100,36 +123,52 @@ __global__ __launch_bounds__(kScanThreads) void k_nn_scan(const unsigned* __rest
     if (threadIdx.x == 0) offset[n] = sCarry;
 }
 
-__global__ void k_nn_fill(const int* __restrict__ cell_of, int64_t n, const unsigned* __restrict__ offset,
-                          unsigned* __restrict__ cursor, int* __restrict__ order) {
-    AMT_GRID_STRIDE(i, n) {
-        const int c = cell_of[i];
-        if (c < 0) continue;
-        const unsigned slot = offset[c] + atomicAdd(&cursor[c], 1u);
-        order[slot] = (int)i;
+__global__ __launch_bounds__(kBlock) void k_nn_fill(const int* __restrict__ cell_of, int64_t n,
+                                                   const unsigned* __restrict__ offset,
+                                                   unsigned* __restrict__ cursor, int* __restrict__ order) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = blockIdx.x * (int64_t)blockDim.x + (threadIdx.x & ~63); base < n; base += stride) {
+        const int64_t i = base + lane;
+        const int c = i < n ? cell_of[i] : -1;
+        const lane_run r = run_of(c, lane);
+        unsigned first = 0;
+        if (r.head == lane && c >= 0) first = offset[c] + atomicAdd(&cursor[c], (unsigned)r.length);
+        first = __shfl(first, r.head);
+        if (c >= 0) order[first + (unsigned)(lane - r.head)] = (int)i;
     }
 }
 
-__global__ void k_nn_search(nn_args A, const unsigned* __restrict__ offset, const int* __restrict__ order,
-                            const double* __restrict__ target_lat, const double* __restrict__ target_lon,
-                            const uint8_t* __restrict__ target_mask, double safe_step,
-                            long long* __restrict__ out_index) {
+// One wavefront per grid centre: the lanes share the pixels of the cells of one ring, then reduce (distance, index).
+__global__ __launch_bounds__(kBlock) void k_nn_search(nn_args A, const unsigned* __restrict__ offset,
+                                                     const int* __restrict__ order,
+                                                     const double* __restrict__ target_lat,
+                                                     const double* __restrict__ target_lon,
+                                                     const uint8_t* __restrict__ target_mask, double safe_step,
+                                                     long long* __restrict__ out_index) {
     const int64_t total = (int64_t)A.nx * A.ny;
     const unsigned n_sources = offset[total];
-    AMT_GRID_STRIDE(t, total) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t t = wave; t < total; t += n_waves) {
         const int row = (int)(t / A.nx), col = (int)(t - (int64_t)row * A.nx);
         if ((target_mask && target_mask[t]) || n_sources == 0) {
-            out_index[t] = -1;
+            if (lane == 0) out_index[t] = -1;
             continue;
         }
         const double ty = target_lat[row], tx = target_lon[col];
         const int cy = A.ny - 1 - row;                 // histogram rows ascend in latitude, output rows descend
         double best = __builtin_huge_val();
-        int best_i = -1;
-        auto visit = [&](int iy, int ix) {
-            if (iy < 0 || iy >= A.ny || ix < 0 || ix >= A.nx) return;
-            const int c = iy * A.nx + ix;
-            for (unsigned k = offset[c], e = offset[c + 1]; k < e; ++k) {
+        int best_i = 0x7fffffff;
+        // pixels of the cells (iy, ix0..ix1), which are contiguous in `order`
+        auto visit = [&](int iy, int ix0, int ix1) {
+            if (iy < 0 || iy >= A.ny) return;
+            ix0 = ix0 < 0 ? 0 : ix0;
+            ix1 = ix1 >= A.nx ? A.nx - 1 : ix1;
+            if (ix0 > ix1) return;
+            const int c = iy * A.nx;
+            for (unsigned k = offset[c + ix0] + lane, e = offset[c + ix1 + 1]; k < e; k += 64) {
                 const int i = order[k];
                 double y = A.lat_c[i], x = A.lon_c[i];
                 if (A.lon_wrap) x = wrap180_shifted(x);
@@ -144,22 +183,29 @@ __global__ void k_nn_search(nn_args A, const unsigned* __restrict__ offset, cons
         const int r_max = max(max(col, A.nx - 1 - col), max(cy, A.ny - 1 - cy));
         for (int r = 0; r <= r_max; ++r) {
             if (r == 0) {
-                visit(cy, col);
+                visit(cy, col, col);
             } else {
-                for (int ix = col - r; ix <= col + r; ++ix) {
-                    visit(cy - r, ix);
-                    visit(cy + r, ix);
-                }
+                visit(cy - r, col - r, col + r);
+                visit(cy + r, col - r, col + r);
                 for (int iy = cy - r + 1; iy <= cy + r - 1; ++iy) {
-                    visit(iy, col - r);
-                    visit(iy, col + r);
+                    visit(iy, col - r, col - r);
+                    visit(iy, col + r, col + r);
+                }
+            }
+            // wave minimum of (distance, index); every lane ends up with it
+            for (int o = 32; o > 0; o >>= 1) {
+                const double d2 = __shfl_xor(best, o);
+                const int i2 = __shfl_xor(best_i, o);
+                if (d2 < best || (d2 == best && i2 < best_i)) {
+                    best = d2;
+                    best_i = i2;
                 }
             }
             // every source closer than (r + 1/2) cells in both axes lies in the rings visited so far
             const double reach = ((double)r + 0.5) * safe_step;
-            if (best_i >= 0 && best <= reach * reach) break;
+            if (best_i != 0x7fffffff && best <= reach * reach) break;
         }
-        out_index[t] = best_i;
+        if (lane == 0) out_index[t] = best_i == 0x7fffffff ? -1 : best_i;
     }
 }
 
@@ -182,28 +228,56 @@ __global__ void k_nn_gather(const long long* __restrict__ index, int64_t total, 
 
 // matplotlib.path.Path(polygon).contains_points(points) (reference utils.py:58-74): crossing test of a ray towards
 // +x with the half-open edge rule (vertex y >= point y) of Agg's point_in_path; the path is closed implicitly.
-__global__ void k_points_in_polygon(const double* __restrict__ px, const double* __restrict__ py, int64_t n,
-                                    const double* __restrict__ poly, int m, uint8_t* __restrict__ inside) {
-    __shared__ double sx[kBlock + 1], sy[kBlock + 1];
+// Edges are staged through LDS in chunks; an edge whose y-range misses the y-range of the block's points cannot
+// change any of them and is dropped while staging (callers order the points so that a block is narrow in y).
+__global__ __launch_bounds__(kBlock) void k_points_in_polygon(const double* __restrict__ px,
+                                                             const double* __restrict__ py, int64_t n,
+                                                             const double* __restrict__ poly, int m,
+                                                             uint8_t* __restrict__ inside) {
+    __shared__ double sx0[kBlock], sy0[kBlock], sx1[kBlock], sy1[kBlock];
+    __shared__ double sLo[kBlock / 64], sHi[kBlock / 64];
+    __shared__ int sCount;
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const bool live = i < n;
     const double tx = live ? px[i] : 0.0, ty = live ? py[i] : 0.0;
+    // y-range of this block's points (NaN coordinates never compare, they stay outside)
+    double lo = live && ty == ty ? ty : __builtin_huge_val(), hi = live && ty == ty ? ty : -__builtin_huge_val();
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, o));
+        hi = fmax(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sLo[threadIdx.x >> 6] = lo;
+        sHi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    for (int w = 0; w < kBlock / 64; ++w) {
+        lo = fmin(lo, sLo[w]);
+        hi = fmax(hi, sHi[w]);
+    }
     bool in = false;
     for (int base = 0; base < m; base += kBlock) {
-        const int cnt = min(kBlock, m - base);
         __syncthreads();
-        if ((int)threadIdx.x < cnt) {
-            sx[threadIdx.x] = poly[2 * (int64_t)(base + threadIdx.x)];
-            sy[threadIdx.x] = poly[2 * (int64_t)(base + threadIdx.x) + 1];
-        }
-        if (threadIdx.x == 0) {                       // the vertex that closes this chunk's last edge
-            const int nxt = (base + cnt) % m;
-            sx[cnt] = poly[2 * (int64_t)nxt];
-            sy[cnt] = poly[2 * (int64_t)nxt + 1];
+        if (threadIdx.x == 0) sCount = 0;
+        __syncthreads();
+        const int k = base + (int)threadIdx.x;
+        if (k < m) {
+            const int k1 = k + 1 == m ? 0 : k + 1;
+            const double x0 = poly[2 * (int64_t)k], y0 = poly[2 * (int64_t)k + 1];
+            const double x1 = poly[2 * (int64_t)k1], y1 = poly[2 * (int64_t)k1 + 1];
+            // the edge flips a point only if (y0 >= ty) != (y1 >= ty) for some ty in [lo, hi]
+            if (fmax(y0, y1) >= lo && fmin(y0, y1) <= hi) {
+                const int slot = atomicAdd(&sCount, 1);
+                sx0[slot] = x0;
+                sy0[slot] = y0;
+                sx1[slot] = x1;
+                sy1[slot] = y1;
+            }
         }
         __syncthreads();
-        for (int k = 0; k < cnt; ++k) {
-            const double x0 = sx[k], y0 = sy[k], x1 = sx[k + 1], y1 = sy[k + 1];
+        const int cnt = sCount;
+        for (int e = 0; e < cnt; ++e) {
+            const double x0 = sx0[e], y0 = sy0[e], x1 = sx1[e], y1 = sy1[e];
             const bool f0 = y0 >= ty, f1 = y1 >= ty;
             if (f0 != f1 && (((y1 - ty) * (x0 - x1) >= (x1 - tx) * (y0 - y1)) == f1)) in = !in;
         }
@@ -264,7 +338,7 @@ int amt_nearest_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, co
     hipLaunchKernelGGL(k_nn_fill, grid_for(A.n), dim3(kBlock), 0, ctx->stream, cell_of, A.n, offset, cursor, order);
     // cell sizes as the centres see them, with a margin for the rounding of edges and centres
     const double safe_step = std::fmin(xaxis->step, yaxis->step) * (1.0 - 1e-9);
-    hipLaunchKernelGGL(k_nn_search, grid_for(cells), dim3(kBlock), 0, ctx->stream, A, offset, order, target_lat,
+    hipLaunchKernelGGL(k_nn_search, grid_for(cells * 64), dim3(kBlock), 0, ctx->stream, A, offset, order, target_lat,
                        target_lon, target_mask, safe_step, reinterpret_cast<long long*>(out_index));
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;

@@ -398,28 +398,29 @@ class BaseMapping(object):
         corners (reference mapping.py:655-691, utils.py:97-151), clockwise in image coordinates.
         Note that the outline can be concave.
         """
-        full, _ = self._fullAndConvexOutlines
-        return full
+        return self._latlon_at(self._outline_pixels)
 
     @property
     def outlineConvexHull(self):
         """The convex hull (in pixel space) of the regular outline, as [lat,lon] (reference mapping.py:664-690)."""
-        _, convex = self._fullAndConvexOutlines
-        return convex
+        from ..utils import convexHull
+        return self._cached('outline_hull', lambda: self._latlon_at(convexHull(self._outline_pixels), cache=None))
 
     @property
-    def _fullAndConvexOutlines(self):
+    def _outline_pixels(self):
+        def make():
+            from ..utils import outline_of_mask_tensor
+            fd = self.frame()
+            return outline_of_mask_tensor(fd.ctx, fd.corner_mask_tensor(), fd.height + 1, fd.width + 1)
+        return self._cached('outline_px', make)
+
+    def _latlon_at(self, xy, cache='outline'):
         def make():
             import torch
-            from ..utils import convexHull, outline_of_mask_tensor
             fd = self.frame()
-            outl = outline_of_mask_tensor(fd.ctx, fd.corner_mask_tensor(), fd.height + 1, fd.width + 1)
-
-            def latlon(xy):
-                idx = torch.from_numpy(np.ascontiguousarray(xy[:, 1] * (fd.width + 1) + xy[:, 0])).to(fd.lat.device)
-                return np.transpose([to_host(fd.lat.reshape(-1)[idx]), to_host(fd.lon.reshape(-1)[idx])])
-            return latlon(outl), latlon(convexHull(outl))
-        return self._cached('outlines', make)
+            idx = torch.from_numpy(np.ascontiguousarray(xy[:, 1] * (fd.width + 1) + xy[:, 0])).to(fd.lat.device)
+            return np.transpose([to_host(fd.lat.reshape(-1)[idx]), to_host(fd.lon.reshape(-1)[idx])])
+        return self._cached(cache, make) if cache else make()
 
     @property
     def centroid(self):

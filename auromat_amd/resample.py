@@ -267,11 +267,13 @@ def outside_outline_mask(ctx, grid, outline):
     """
     import torch
     poly = ctx.to_device(np.ascontiguousarray(outline, dtype=np.float64))
-    lat = ctx.to_device(np.ascontiguousarray(grid.lat, dtype=np.float64))
-    lon = ctx.to_device(np.ascontiguousarray(grid.lon, dtype=np.float64))
+    # points in longitude-major order: consecutive points share their y (= longitude), which lets the kernel drop
+    # almost every polygon edge per block of points (it skips edges whose y-range misses the block's)
+    lat = ctx.to_device(np.ascontiguousarray(grid.lat.T, dtype=np.float64))
+    lon = ctx.to_device(np.ascontiguousarray(grid.lon.T, dtype=np.float64))
     inside = ctx.empty(tuple(lat.shape), torch.uint8)
     ctx.call('amt_points_in_polygon', ptr(lat), ptr(lon), lat.numel(), ptr(poly), int(poly.shape[0]), ptr(inside))
-    out = inside == 0
+    out = inside.T == 0
     return (out[:-1, :-1] | out[1:, :-1] | out[:-1, 1:] | out[1:, 1:]).to(torch.uint8).contiguous()
 
 

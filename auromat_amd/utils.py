@@ -14,35 +14,47 @@ from ._native import Context, ptr, to_host
 def contours_from_links(links):
     """
     Closed contours from (key, next key) records (see ``amt_mask_outline_links``): list of int64 arrays of pixel
-    indices (key // 4), each without consecutive duplicates (also across the closing point).
+    indices (key // 4), each without consecutive duplicates (also across the closing point).  The links form
+    disjoint cycles; they are ranked with pointer doubling (log2(n) vectorised rounds) instead of being walked.
     """
     links = np.asarray(links, dtype=np.int64).reshape(-1, 2)
-    if len(links) == 0:
+    n = len(links)
+    if n == 0:
         return []
     order = np.argsort(links[:, 0], kind='stable')
     keys = links[order, 0]
     nxt = np.searchsorted(keys, links[order, 1])
-    assert np.all(nxt < len(keys)) and np.array_equal(keys[nxt], links[order, 1]), 'dangling contour link'
-    nxt = nxt.tolist()
-    seen = np.zeros(len(keys), bool)
+    assert np.all(nxt < n) and np.array_equal(keys[nxt], links[order, 1]), 'dangling contour link'
+    rounds = max(1, int(np.ceil(np.log2(n))) + 1)
+    # leader of every cycle: its smallest node
+    leader = np.arange(n)
+    hop = nxt.copy()
+    for _ in range(rounds):
+        leader = np.minimum(leader, leader[hop])
+        hop = hop[hop]
+    # steps from every node forward to its leader (the leader absorbs)
+    is_leader = leader == np.arange(n)
+    dist = np.where(is_leader, 0, 1)
+    hop = np.where(is_leader, np.arange(n), nxt)
+    for _ in range(rounds):
+        dist = dist + dist[hop]
+        hop = hop[hop]
+    assert np.all(hop == leader), 'contour does not close'
+    length = np.zeros(n, dtype=np.int64)
+    np.maximum.at(length, leader, dist + 1)                       # the leader's predecessor is length - 1 steps away
+    pos = np.where(is_leader, 0, length[leader] - dist)
+    walk = np.lexsort((pos, leader))                              # cycle by cycle, in contour order from the leader
+    px = keys[walk] // 4
+    starts = np.nonzero(is_leader[walk])[0]
     contours = []
-    for start in range(len(keys)):
-        if seen[start]:
-            continue
-        chain = []
-        k = start
-        while not seen[k]:
-            seen[k] = True
-            chain.append(k)
-            k = nxt[k]
-        assert k == start, 'contour does not close'
-        px = keys[np.asarray(chain)] // 4
-        keep = np.ones(len(px), bool)
-        keep[1:] = px[1:] != px[:-1]
-        px = px[keep]
-        if len(px) > 1 and px[0] == px[-1]:
-            px = px[:-1]
-        contours.append(px)
+    for a, b in zip(starts, list(starts[1:]) + [n]):
+        c = px[a:b]
+        keep = np.ones(len(c), bool)
+        keep[1:] = c[1:] != c[:-1]
+        c = c[keep]
+        if len(c) > 1 and c[0] == c[-1]:
+            c = c[:-1]
+        contours.append(c)
     return contours
 
 

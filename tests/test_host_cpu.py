@@ -305,3 +305,36 @@ def test_geodesic_direct_inverse_consistency():
     np.testing.assert_allclose(pts[-1], [12, 25], atol=1e-8)
     assert G.line(G.Location(10, 20), G.Location(10.001, 20), resolution=1000).shape == (2, 2)
     assert G.distance(G.Location(5, 5), G.Location(5, 5)) == 0
+
+
+def test_contour_links_are_ranked_like_a_walk():
+    """utils.contours_from_links (pointer doubling over the device's contour links) against a plain walk of random
+    link sets made of several cycles, shuffled records, with pixels that repeat along a contour."""
+    from auromat_amd.utils import contours_from_links
+    rng = np.random.RandomState(0)
+    for trial in range(40):
+        n = rng.randint(1, 400)
+        perm = rng.permutation(n)
+        cuts = sorted(set(rng.randint(1, n + 1, size=rng.randint(1, 6)).tolist() + [n]))
+        keys = np.sort(rng.choice(4 * n + 8, n, replace=False))         # dense keys: neighbouring keys share pixels
+        nxt = np.empty(n, dtype=np.int64)
+        cycles, a = [], 0
+        for b in cuts:
+            cyc = perm[a:b]
+            a = b
+            if len(cyc):
+                cycles.append(cyc)
+                nxt[cyc] = np.roll(cyc, -1)
+        links = np.transpose([keys, keys[nxt]])[rng.permutation(n)]
+        got = contours_from_links(links)
+        want = []
+        for cyc in cycles:
+            c = np.roll(cyc, -int(np.argmin(keys[cyc])))                 # contours start at their smallest key
+            px = keys[c] // 4
+            keep = np.ones(len(px), bool)
+            keep[1:] = px[1:] != px[:-1]
+            px = px[keep]
+            want.append(px[:-1] if len(px) > 1 and px[0] == px[-1] else px)
+        key = lambda c: (len(c), c.tolist())
+        assert [c.tolist() for c in sorted(got, key=key)] == [c.tolist() for c in sorted(want, key=key)], trial
+    assert contours_from_links(np.zeros((0, 2), np.int64)) == []
