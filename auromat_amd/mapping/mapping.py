@@ -28,6 +28,8 @@ from ..frame import FrameData
 from .._native import Context, host9, ptr, to_host
 
 Size = namedtuple('Size', ['width', 'height'])
+PixelScales = namedtuple('PixelScales', ['width', 'height', 'diagonal'])
+PixelScale = namedtuple('PixelScale', ['mean', 'median', 'min', 'max'])
 MappingProperties = namedtuple('MappingProperties',
                                'altitude cameraPosGCRS boundingBox photoTime '
                                'centroid cameraFootpoint identifier')
@@ -472,6 +474,76 @@ class BaseMapping(object):
         if count == 0:
             raise ValueError('minElevation=' + str(minElevation) + ' would mask all pixels!')
         return self.createMasked(center, _corner_mask=corner)
+
+    def maskedByPolygon(self, polygon):
+        """
+        Returns a copy of this mapping where the image is masked using the given polygon.  Only those pixels are
+        retained where all of its corners are inside the polygon (reference mapping.py:866-917; the point-in-polygon
+        test of all corners runs on the device, ``amt_points_in_polygon``).
+
+        .. warning:: If the mapping or the polygon contains the discontinuity and/or poles then this method tries to
+                 handle it in a best-effort approach, as the reference does.
+
+        :param array-like polygon: ordered points of an unclosed polygon in [lat,lon] order
+        :rtype: BaseMapping
+        """
+        import torch
+        from ..coordinates.geodesic import containsOrCrossesPole
+        from ..resample import _rotate_pole_dev, _rotate_pole_host
+        polygon = np.array(polygon, dtype=np.float64)
+        fd = self.frame()
+        ctx = fd.ctx
+        lat, lon = fd.lat, fd.lon
+        polyBoundingBox = BoundingBox.minimumBoundingBox(polygon)
+        if self.containsDiscontinuity or polyBoundingBox.containsDiscontinuity:
+            polygon[:, 1] = wrap_at_180(polygon[:, 1] + 180)
+            lon = torch.remainder(lon + 360.0, 360.0) - 180.0           # wrap_at(lon + 180, 180)
+        elif self.containsPole or containsOrCrossesPole(polygon):
+            polygon[:, 0], polygon[:, 1] = _rotate_pole_host(polygon[:, 0], polygon[:, 1], self.altitude, 90)
+            lat, lon = _rotate_pole_dev(ctx, lat, lon, self.altitude, 90)
+        inside = ctx.empty(tuple(lat.shape), torch.uint8)
+        ctx.call('amt_points_in_polygon', ptr(lat.contiguous()), ptr(lon.contiguous()), lat.numel(),
+                 ptr(ctx.to_device(polygon)), len(polygon), ptr(inside))
+        mask = (inside == 0) | (fd.corner_mask_tensor() != 0)
+        if bool(mask.all().item()):
+            raise ValueError('The given mask would mask all pixels!')
+        # we mask every pixel which misses at least one of its four corner coordinates
+        centerMask = mask[:-1, :-1] | mask[1:, :-1] | mask[:-1, 1:] | mask[1:, 1:]
+        return self.createMasked(centerMask.to(torch.uint8).contiguous())
+
+    @property
+    def arcSecPerPx(self):
+        """
+        Min, max, median, and mean angular sizes of pixels/polygons determined for the width, height, and
+        diagonal of 1000 polygons (reference mapping.py:786-843; the geodesic arcs of the sampled polygons are host
+        arithmetic, only their 3 x 1000 corner coordinates leave the device).
+
+        :rtype: PixelScales
+        """
+        def make():
+            import torch
+            from ..coordinates import geodesic
+            fd = self.frame()
+            bad = fd.corner_mask_tensor() != 0
+            has_nans = bad[:-1, :-1] | bad[:-1, 1:] | bad[1:, 1:] | bad[1:, :-1]
+            polys = torch.nonzero(~has_nans.reshape(-1)).reshape(-1)
+            polyCount = int(polys.numel())
+            sampleCount = min(polyCount, 1000)
+            pick = polys[torch.from_numpy(np.round(np.linspace(0, polyCount - 1, sampleCount)).astype(np.int64))
+                         .to(polys.device)]
+            i, j = pick // fd.width, pick % fd.width
+            W1 = fd.width + 1
+            corners = torch.stack((i * W1 + j, i * W1 + j + 1, (i + 1) * W1 + j + 1))        # verts 0, 1, 2
+            la = to_host(fd.lat.reshape(-1)[corners.reshape(-1)]).reshape(3, -1)
+            lo = to_host(fd.lon.reshape(-1)[corners.reshape(-1)]).reshape(3, -1)
+            scales = []
+            for a, b in ((0, 1), (1, 2), (0, 2)):               # width, height, diagonal
+                deg = [geodesic.angularDistance(Location(la[a, k], lo[a, k]), Location(la[b, k], lo[b, k]))
+                       for k in range(sampleCount)]
+                scales.append(PixelScale(np.mean(deg) * 3600, np.median(deg) * 3600, min(deg) * 3600,
+                                         max(deg) * 3600))
+            return PixelScales(width=scales[0], height=scales[1], diagonal=scales[2])
+        return self._cached('pixel_scales', make)
 
     def createMasked(self, centerMask, _corner_mask=None):
         """

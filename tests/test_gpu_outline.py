@@ -157,3 +157,72 @@ def test_outline_links_error_behaviour():
         ctx.call('amt_mask_outline_links', ptr(mask), 0, 4, None, 0, ptr(count))
     ctx.call('amt_mask_outline_links', ptr(mask), 4, 4, None, 0, ptr(count))       # counting only
     assert int(count.cpu()[0]) == 16                                                  # 4 sides x 4 pixels
+
+
+def test_masked_by_polygon_vs_matplotlib():
+    """BaseMapping.maskedByPolygon (mapping.py:866-917): corners inside the polygon (matplotlib's rule), a pixel needs
+    all four; checked against the same steps in NumPy on the oracle's arrays, plain and across the date line."""
+    import matplotlib.path
+    from datetime import timedelta
+    from oracle import ref_numpy as O
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 256, 170
+    for pointing, shift in (('iss030', 0), ('iss029', 80)):
+        hdr, cam, t = frame_header(w, h, pointing)
+        t = t - timedelta(minutes=shift)
+        m = ArraySpacecraftMapping(hdr, 110, frame_image(w, h, seed=4), cam, t, 'p', fastCenterCalculation=True)
+        et = O.date2es(t)
+        g = O.georef_frame(hdr, 110, cam, O.mat_j2000_to_geo(et), None, fast=True)
+        ok = ~np.isnan(g['lat'])
+        lat0, lat1 = np.percentile(g['lat'][ok], [30, 70])
+        lon = g['lon'][ok]
+        disc = m.containsDiscontinuity
+        lons = O.wrap_at(lon + 180, 180) if disc else lon
+        lon0, lon1 = np.percentile(lons, [25, 75])
+        poly = np.array([[lat0, lon0], [lat1 + 1, lon0 + 0.5], [lat1, lon1], [(lat0 + lat1) / 2, (lon0 + lon1) / 2],
+                         [lat0 - 0.5, lon1]])
+        if disc:
+            poly[:, 1] = O.wrap_at(poly[:, 1] - 180, 180)              # back to true longitudes, straddling +-180
+        mm = m.maskedByPolygon(poly)
+        mm.checkGuarantees()
+        pts = np.transpose([g['lat'].ravel(), (O.wrap_at(g['lon'] + 180, 180) if disc else g['lon']).ravel()])
+        p2 = poly.copy()
+        if disc:
+            p2[:, 1] = O.wrap_at(p2[:, 1] + 180, 180)
+        inside = matplotlib.path.Path(p2).contains_points(np.nan_to_num(pts, nan=1e9)).reshape(g['lat'].shape)
+        mask = ~inside | ~ok
+        center = np.logical_or.reduce((mask[:-1, :-1], mask[1:, :-1], mask[:-1, 1:], mask[1:, 1:]))
+        assert 0 < (~center).sum() < center.size
+        got = ma.getmaskarray(mm.latsCenter)
+        assert int((got != center).sum()) <= 2, int((got != center).sum())      # corners within 1e-11 deg of an edge
+    with pytest.raises(ValueError):
+        m.maskedByPolygon([[0, 0], [1, 0], [1, 1]])
+
+
+def test_arc_sec_per_px():
+    """BaseMapping.arcSecPerPx (mapping.py:786-843): geodesic arcs of the sides and the diagonal of 1000 sampled
+    pixel polygons, the same sample as the reference takes."""
+    from oracle import ref_numpy as O
+    from auromat_amd.coordinates.geodesic import Location, angularDistance
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 253, 171
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    m = ArraySpacecraftMapping(hdr, 110, frame_image(w, h, seed=4), cam, t, 'p', fastCenterCalculation=True)
+    s = m.arcSecPerPx
+    for side in (s.width, s.height, s.diagonal):
+        assert 0 < side.min <= side.median <= side.max and side.min <= side.mean <= side.max
+    assert s.diagonal.median > s.width.median and s.diagonal.median > s.height.median
+    # the sampling rule itself, on the oracle's arrays
+    et = O.date2es(t)
+    g = O.georef_frame(hdr, 110, cam, O.mat_j2000_to_geo(et), None, fast=True)
+    bad = np.isnan(g['lat'])
+    has_nans = bad[:-1, :-1] | bad[:-1, 1:] | bad[1:, 1:] | bad[1:, :-1]
+    polys = np.nonzero(~has_nans.ravel())[0]
+    pick = polys[np.round(np.linspace(0, len(polys) - 1, 1000)).astype(int)]
+    i, j = pick // w, pick % w
+    widths = [angularDistance(Location(g['lat'][a, b], g['lon'][a, b]), Location(g['lat'][a, b + 1], g['lon'][a, b + 1]))
+              for a, b in zip(i, j)]
+    assert abs(np.median(widths) * 3600 - s.width.median) < 1e-6
+    assert abs(max(widths) * 3600 - s.width.max) < 1e-6
