@@ -211,7 +211,7 @@ def main():
             kbytes = ab['georef']
         if args.magnetic:
             kbytes += ab['mag']
-            tkey += '_mag'               # no PMC pass of this variant under profiles/ yet: traffic = null
+            tkey += '_mag'               # profiles/r1/k_pmc_summary_magnetic.txt
         achieved = kbytes / (georef_ms * 1e-3) / 1e9
         fpl = seq.batch if fused else 1
         out = {
