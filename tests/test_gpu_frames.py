@@ -710,3 +710,40 @@ def test_exact_centres_without_elevation_threshold(magnetic):
     same = (want['count'] == one['count']) & (want['count'] > 0)
     assert np.array_equal(one['mean'][..., :3][same], want['data'][..., :3][same])
     assert np.max(np.abs(one['mean'][..., 3][same] - want['data'][..., 3][same])) < 1e-9
+
+
+@pytest.mark.parametrize('width,height', [(1, 1), (2, 1), (1, 3), (5, 3), (64, 1), (65, 2), (129, 5), (3, 70)])
+def test_degenerate_frame_sizes(width, height):
+    """Frames smaller than a wavefront / a row chunk, single rows and columns: coordinates equal the oracle's and the
+    single-pass plan (when a grid exists at all) equals the two-pass plan."""
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_header, frame_image
+    # a width x height window in the Earth-looking lower part of a 256 x 170 frame
+    hdr, cam, t = frame_header(256, 170, 'iss030')
+    ox, oy = 60, 170 - height - 4
+    hdr.update(IMAGEW=width, IMAGEH=height, CRPIX1=hdr['CRPIX1'] - ox, CRPIX2=hdr['CRPIX2'] - oy)
+    img = frame_image(width, height, seed=6)
+    for fast in (True, False):
+        pipe = FramePipeline(width, height, with_mag=True)
+        pipe.set_image(img)
+        pipe.georef(hdr, 110, cam, t, fast=fast, min_elevation=None)
+        got = pipe.host_arrays()
+        ref = oracle_frame(hdr, cam, t, fast)
+        for k in ('lat', 'lon', 'lat_c', 'lon_c', 'elev', 'mlat', 'mlt', 'mlat_c', 'mlt_c'):
+            assert got[k].shape == ref[k].shape, k
+            nan_close(got[k], ref[k], TOL_DEG)
+    if width * height < 3:
+        return
+    # a resolution fine enough that the few pixels still span more than one grid node
+    span = max(np.ptp(ref['lat'][~np.isnan(ref['lat'])]), 1e-3)
+    ppd = float(min(2000.0, max(10.0, 8.0 / span)))
+    assert not np.isnan(ref['lat_c']).any(), 'the window must look at the Earth'
+    pipe = FramePipeline(width, height)
+    try:
+        two = pipe.run(hdr, 110, cam, t, img=img, fast=True, min_elevation=None, pxPerDeg=ppd, fuse=False)
+    except AssertionError:
+        return                                   # the reference asserts nLat, nLon > 1 as well (resample.py:226-227)
+    one = pipe.run(hdr, 110, cam, t, fast=True, min_elevation=None, pxPerDeg=ppd, fuse=True)
+    for k in ('mean', 'count', 'img', 'mask'):
+        assert np.array_equal(one[k], two[k], equal_nan=True), (k, pipe.last_plan)
+    assert two['count'].sum() <= width * height
