@@ -107,6 +107,7 @@ _SIGNATURES = {
     'amt_sanitize_masks': ([_P, _P, _P, _P, C.c_int32, C.c_int32, _I], _I),
     'amt_bbox_corners': ([_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P], _I),
     'amt_mask_outline_links': ([_P, _P, C.c_int32, C.c_int32, _P, _L, _P], _I),
+    'amt_pixel_polygons': ([_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _L, _P, _P, _P], _I),
     'amt_hist2d_accumulate': ([_P, _P, _P, _L, c_void_pp, C.c_int32, C.POINTER(Axis), C.POINTER(Axis), _I, _P,
                                c_void_pp], _I),
     'amt_hist2d_finalize_mean': ([_P, _P, c_void_pp, C.c_int32, C.c_int32, C.c_int32, _P], _I),

@@ -194,6 +194,36 @@ __global__ void k_mask_outline_links(const uint8_t* __restrict__ mask, int heigh
     }
 }
 
+// Pixel polygons for drawing (reference draw_helpers.py:34-94): the four corners (lat, lon) of every listed pixel in the
+// order (r,c), (r,c+1), (r+1,c+1), (r+1,c) and its colour (DefaultRGBMixin: uint16 * (255/65535) truncated to uint8).
+template <typename T>
+__global__ void k_pixel_polygons(const double* __restrict__ lat, const double* __restrict__ lon, const T* __restrict__ img,
+                                 int nchan, int width, const long long* __restrict__ index, int64_t n,
+                                 double* __restrict__ verts, uint8_t* __restrict__ colors_u8,
+                                 double* __restrict__ colors_f64) {
+    const int W1 = width + 1;
+    AMT_GRID_STRIDE(k, n) {
+        const long long i = index[k];
+        const int r = (int)(i / width), c = (int)(i - (long long)r * width);
+        const int64_t q = (int64_t)r * W1 + c;
+        double* v = verts + 8 * k;
+        v[0] = lat[q];
+        v[1] = lon[q];
+        v[2] = lat[q + 1];
+        v[3] = lon[q + 1];
+        v[4] = lat[q + W1 + 1];
+        v[5] = lon[q + W1 + 1];
+        v[6] = lat[q + W1];
+        v[7] = lon[q + W1];
+        for (int ch = 0; ch < 3; ++ch) {
+            const T raw = img[i * nchan + (nchan == 1 ? 0 : ch)];
+            const uint8_t u = sizeof(T) == 1 ? (uint8_t)raw : (uint8_t)((double)raw * (255.0 / 65535.0));
+            if (colors_u8) colors_u8[3 * k + ch] = u;
+            if (colors_f64) colors_f64[3 * k + ch] = (double)u / 255.0;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -274,6 +304,26 @@ int amt_mask_outline_links(amt_ctx* ctx, const uint8_t* mask, int32_t height, in
     hipLaunchKernelGGL(k_mask_outline_links, grid_for((int64_t)height * width), dim3(kBlock), 0, ctx->stream, mask,
                        height, width, reinterpret_cast<long long*>(links), (long long)capacity,
                        reinterpret_cast<unsigned long long*>(count));
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_pixel_polygons(amt_ctx* ctx, const double* lat, const double* lon, const void* img, int32_t img_dtype,
+                       int32_t nchan, int32_t height, int32_t width, const int64_t* index, int64_t n, double* verts,
+                       uint8_t* colors_u8, double* colors_f64) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, lat && lon && img && (n == 0 || (index && verts)), "NULL argument");
+    AMT_REQUIRE(ctx, height > 0 && width > 0 && n >= 0, "bad size");
+    AMT_REQUIRE(ctx, (nchan == 1 || nchan == 3) && (img_dtype == 1 || img_dtype == 2), "image must be 1 or 3 channels of uint8 (1) / uint16 (2)");
+    if (n == 0) return AMT_OK;
+    const long long* idx = reinterpret_cast<const long long*>(index);
+    if (img_dtype == 2) {
+        hipLaunchKernelGGL(k_pixel_polygons<uint16_t>, grid_for(n), dim3(kBlock), 0, ctx->stream, lat, lon,
+                           static_cast<const uint16_t*>(img), nchan, width, idx, n, verts, colors_u8, colors_f64);
+    } else {
+        hipLaunchKernelGGL(k_pixel_polygons<uint8_t>, grid_for(n), dim3(kBlock), 0, ctx->stream, lat, lon,
+                           static_cast<const uint8_t*>(img), nchan, width, idx, n, verts, colors_u8, colors_f64);
+    }
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }

@@ -293,6 +293,14 @@ int amt_sanitize_masks(amt_ctx* ctx, uint8_t* corner_mask, uint8_t* center_mask,
  * contour; the pixel of each key (key / 4), with consecutive duplicates dropped, is the polygon the reference traces. */
 int amt_mask_outline_links(amt_ctx* ctx, const uint8_t* mask, int32_t height, int32_t width, int64_t* links,
                            int64_t capacity, uint64_t* count);
+/* auromat/draw_helpers.py:34-94 createPolygonsAndColors + filterNanPolygons for the pixels listed in `index` (n flat
+ * pixel indices, normally the unmasked ones in row-major order): verts (n,4,2) float64 = (lat, lon) of the corners
+ * (r,c), (r,c+1), (r+1,c+1), (r+1,c); colours per pixel as the mapping's `rgb` gives them (mapping.py:980-1007: uint8 as
+ * is, uint16 * (255/65535) truncated; one channel is repeated): colors_u8 (n,3) and / or colors_f64 (n,3) = rgb / 255
+ * (ColorMode.matplotlib); either may be NULL.  lat/lon: (height+1, width+1); img: (height, width, nchan), nchan 1 or 3. */
+int amt_pixel_polygons(amt_ctx* ctx, const double* lat, const double* lon, const void* img, int32_t img_dtype,
+                       int32_t nchan, int32_t height, int32_t width, const int64_t* index, int64_t n, double* verts,
+                       uint8_t* colors_u8, double* colors_f64);
 /* Inputs of BaseMapping.boundingBox (mapping.py:693-743) for arbitrary corner grids:
  * bbox[0..5] = min/max over unmasked corners as in amt_georef_out.bbox, bbox[6] = number of unmasked
  * corners, bbox[7] = number of unmasked centres whose corner quad winds around a pole.

@@ -226,3 +226,26 @@ def test_arc_sec_per_px():
               for a, b in zip(i, j)]
     assert abs(np.median(widths) * 3600 - s.width.median) < 1e-6
     assert abs(max(widths) * 3600 - s.width.max) < 1e-6
+
+
+@pytest.mark.parametrize('dtype', [np.uint8, np.uint16])
+def test_pixel_polygons_for_drawing(dtype):
+    """draw_helpers.generatePolygonsFromMapping (draw_helpers.py:34-94, the call of mapping_test.py:16-23): the device
+    gather equals the reference's array expressions evaluated on the mapping's host arrays."""
+    from auromat_amd.draw_helpers import (ColorMode, createPolygonsAndColors, filterNanPolygons,
+                                          generatePolygonsFromMapping)
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 253, 171
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    m = ArraySpacecraftMapping(hdr, 110, frame_image(w, h, seed=8, dtype=dtype), cam, t, 'd',
+                               fastCenterCalculation=True).maskedByElevation(10)
+    for mode in (None, ColorMode.matplotlib):
+        verts, colors = generatePolygonsFromMapping(m, mode)
+        wv, wc = filterNanPolygons(*createPolygonsAndColors(m.lats, m.lons, m.rgb, mode))
+        assert verts.shape == wv.shape == (int((~ma.getmaskarray(m.latsCenter)).sum()), 4, 2)
+        assert np.array_equal(verts, wv) and not np.isnan(verts).any()
+        assert colors.dtype == wc.dtype and np.array_equal(colors, wc)
+    # other coordinates (MLat / MLT corners): the host path
+    v2, c2 = generatePolygonsFromMapping(m, None, coordsFn=lambda mp: mp.mLatMlt)
+    assert v2.shape == verts.shape and np.array_equal(c2, generatePolygonsFromMapping(m)[1])
