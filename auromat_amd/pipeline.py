@@ -104,8 +104,13 @@ class FramePipeline(object):
 
     # -- inputs ---------------------------------------------------------------------------------
     def set_image(self, img):
-        """Copy an (h, w, c) host image (or device tensor of the same bytes) into the frame buffer."""
+        """Copy an (h, w, c) host image (or device tensor of the same bytes) into the frame buffer.  A pinned host
+        tensor of the buffer's dtype (uint16 images as their int16 bits) is copied asynchronously on the current
+        stream."""
         import torch
+        if isinstance(img, torch.Tensor) and not img.is_cuda and img.is_pinned() and img.dtype == self.fd.img.dtype:
+            self.fd.img.copy_(img.reshape(self.fd.img.shape), non_blocking=True)
+            return
         if isinstance(img, torch.Tensor):
             t = self.ctx.to_device(img, self.fd.img_dtype)
         else:
@@ -394,6 +399,10 @@ class SequencePipeline(object):
         self.s_bin = torch.cuda.Stream(device=self.ctx.device) if (bin_stream and not self.single_pass) else self.s_main
         self._geo_done = [torch.cuda.Event() for _ in self.pipes]
         self._bin_done = [None for _ in self.pipes]
+        # per-frame images: uploaded on a copy stream of their own (created on first use: every extra stream competes
+        # for the few hardware queues), so that frame k+1's 72 MB cross PCIe while frame k is being computed
+        self.s_copy = None
+        self._img_read = [None for _ in self.pipes]      # the last kernel reading this buffer's image has finished
         self.plans = []                     # plan taken by each frame of the last process() call
         self.use_hints = True               # sequence coherence instead of the coarse pre-pass where possible
         self._hint = None                   # (exact bbox reduction, amt_frame_params) of the latest finished frame
@@ -424,10 +433,24 @@ class SequencePipeline(object):
                 if two_streams and self._bin_done[slot] is not None:
                     self.s_main.wait_event(self._bin_done[slot])     # the buffer's previous frame is still being binned
                 if img is not None:
-                    q.set_image(img)
+                    if self.s_copy is None:
+                        self.s_copy = torch.cuda.Stream(device=self.ctx.device)
+                    with torch.cuda.stream(self.s_copy):
+                        busy = self._bin_done[slot] if two_streams else self._img_read[slot]
+                        if busy is not None:
+                            self.s_copy.wait_event(busy)             # the buffer's previous image is still being read
+                        q.set_image(img)
+                        uploaded = torch.cuda.Event()
+                        uploaded.record(self.s_copy)
+                    self.s_main.wait_event(uploaded)
             if self.single_pass:
                 FramePipeline.georef_many(qs, [pr[0] for pr in prepared], self.altitude, self.min_elevation,
                                           self.pxPerDeg, self.magnetic)
+                if self.s_copy is not None:
+                    done = torch.cuda.Event()
+                    done.record(self.s_main)
+                    for i in range(len(prepared)):
+                        self._img_read[(k0 + i) % nb] = done
             else:
                 for i, (q, (p, cam, t, img)) in enumerate(zip(qs, prepared)):
                     q.georef(None, self.altitude, cam, t, self.fast, self.min_elevation, params=p)

@@ -100,6 +100,9 @@ def main():
                     help='run the coarse bounding-box pre-pass for every frame instead of re-using the previous exact box')
     ap.add_argument('--batch', type=int, default=3, choices=(1, 2, 3),
                     help='frames per launch of the big kernel in the fused plan (amt_pipe_launch_many)')
+    ap.add_argument('--upload', action='store_true',
+                    help='PCIe-inclusive variant (never the headline value): every frame brings its own image from '
+                         'pinned host memory, uploaded on a copy stream beside the previous frames\' kernels')
     ap.add_argument('--streams', type=int, default=2, choices=(1, 2),
                     help='2: bin frame k beside the ray casting of frame k+1 on a second HIP stream')
     args = ap.parse_args()
@@ -131,19 +134,25 @@ def main():
     fused = args.plan == 'fused'
     seq = SequencePipeline(WIDTH, HEIGHT, altitude=ALTITUDE, fast=fast, min_elevation=MIN_ELEV, pxPerDeg=PPD,
                            plan='single-pass' if fused else 'two-pass', bin_stream=args.streams == 2,
-                           shared_image=frame_image(WIDTH, HEIGHT, seed=rank),     # resident before the timed region
+                           # resident before the timed region (unless --upload brings one per frame)
+                           shared_image=None if args.upload else frame_image(WIDTH, HEIGHT, seed=rank),
                            magnetic=args.magnetic, batch=args.batch)
     seq.use_hints = not args.no_hints
     ctx = seq.ctx
     # the synthetic sequence (what a reader would hand over: WCS cards, camera position, time) exists before the
     # timed region, like the image; everything derived from it (matrices, grids) is computed inside
     frames = [sequence_frame(rank * total + k, WIDTH, HEIGHT)[:3] + (None,) for k in range(total)]
+    if args.upload:
+        # four distinct images in pinned host memory (uint16 bits as int16, the frame buffer's layout), cycled
+        host_imgs = [torch.from_numpy(frame_image(WIDTH, HEIGHT, seed=100 + i).view(np.int16)).pin_memory()
+                     for i in range(4)]
+        frames = [f[:3] + (host_imgs[k % 4],) for k, f in enumerate(frames)]
     if args.magnetic:
         # per-frame shells: the matrices are made here (outside the timed region only in this variant, because the
         # sequence loop takes one altitude); 100 / 110 / 120 km alternate
         from auromat_amd.mapping.astrometry import frame_params
-        frames = [(frame_params(h, (100, 110, 120)[k % 3], c, t, fast, magnetic=True), c, t, None)
-                  for k, (h, c, t, _) in enumerate(frames)]
+        frames = [(frame_params(h, (100, 110, 120)[k % 3], c, t, fast, magnetic=True), c, t, im)
+                  for k, (h, c, t, im) in enumerate(frames)]
 
     warm = seq.process(frames[:args.warmup])
     if use_dist and warm:
@@ -221,7 +230,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
+            'dtype': 'f64', 'data': 'synthetic' + (', image of every frame uploaded from pinned host memory' if args.upload else ''),
             'config': {'workload': ('configs[3]: as configs[2] on shells 100/110/120 km + MLat/MLT of corners and centres, '
                                     'mean-resample on the 0.1 deg (MLat, SM longitude) grid (resampleMLatMLT)'
                                     if args.magnetic else
