@@ -211,15 +211,18 @@ def main():
             return nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
         if fused:
-            # one kernel does both stages: it writes the five coordinate arrays (480.4 MB) and reads the image
-            # (6 B/pixel, 72.0 MB); the centre arrays are never read back
+            # One kernel does both stages.  Algorithmic bytes = SURVEY.md 8d: "georef, WCS-fused variant" (16 B per
+            # corner + 24 B per pixel written) + "resample-mean" (30 B per pixel read) = 840.6 MB per frame (MLat/MLT
+            # config: the same 16 Nc + 54 Np).  The fused kernel never re-reads the centre arrays, so it MOVES less:
+            # 480.4 MB written + the 72.0 MB image read = 552.5 MB (`bytes_moved_min`; `traffic` is what PMC counted).
             kname, tkey = 'k_georef_rows<BIN> (amt_georef_frame with fused binning, via amt_pipe_launch)', 'k_georef_rows_fused'
-            kbytes = ab['georef'] + ab['image']
+            kbytes = ab['georef'] + ab['resample']
+            moved = ab['georef'] + ab['image']
         else:
             kname, tkey = 'k_georef_rows (amt_georef_frame)', 'k_georef_rows'
-            kbytes = ab['georef']
+            kbytes = moved = ab['georef']
         if args.magnetic:
-            kbytes += ab['mag']
+            moved += ab['mag']           # this variant writes MLat/MLT beside lat/lon (more than the contract counts)
             tkey += '_mag'               # profiles/r1/k_pmc_summary_magnetic.txt
         achieved = kbytes / (georef_ms * 1e-3) / 1e9
         fpl = seq.batch if fused else 1
@@ -252,9 +255,12 @@ def main():
                          'frames_per_launch': fpl,
                          'traffic': (traffic.get(tkey, {}).get('hbm_bytes') or 0) * fpl or None,
                          'algorithmic_bytes': kbytes * fpl, 'ms_per_launch': georef_ms * fpl,
+                         # the bytes this kernel has to move at the very least, and the same fraction on that basis
+                         'bytes_moved_min': moved * fpl, 'frac_bytes_moved_min': frac(moved, georef_ms),
                          'frames_timed': g_n, 'valu_busy': traffic.get(tkey, {}).get('valu_busy')},
             'kernels': {
-                'k_georef_rows': {'ms': georef_ms, 'algorithmic_bytes': kbytes, 'frac_hbm_peak': frac(kbytes, georef_ms)},
+                'k_georef_rows': {'ms': georef_ms, 'algorithmic_bytes': kbytes, 'frac_hbm_peak': frac(kbytes, georef_ms),
+                                  'bytes_moved_min': moved},
                 'k_bin_frame': ({'ms': bin_ms, 'algorithmic_bytes': ab['resample'],
                                  'frac_hbm_peak': frac(ab['resample'], bin_ms),
                                  'traffic': traffic.get('k_bin_frame', {}).get('hbm_bytes')} if bin_ms else
