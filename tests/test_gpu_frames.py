@@ -4,6 +4,7 @@ end, uint8 images, full-size frames against the reference's strided samples + di
 size-independent properties at BASELINE.json's full size (pixel conservation, determinism, linearity
 of the sums in the image, agreement of the fused pipeline with the mapping classes).
 """
+import os
 from datetime import datetime
 
 import numpy as np
@@ -771,3 +772,53 @@ def test_sequence_with_uploaded_images_from_pinned_memory():
         for k in range(n):
             for key in ('mean', 'count', 'img', 'mask'):
                 assert np.array_equal(got[k][key], want[k][key], equal_nan=True), (plan, k, key)
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """examples/c_abi_demo.c — C99, no Python / torch / HIP headers — built with gcc against the in-tree library and
+    run as its own process: same bits as the Python host for the coordinate arrays, the bounding-box reduction and
+    the binned grid of the same frame."""
+    import ctypes as C
+    import subprocess
+    from conftest import ROOT
+    from auromat_amd._build import LIB_DIR
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_header, frame_image
+    exe = str(tmp_path / 'c_abi_demo')
+    build = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-I' + os.path.join(ROOT, 'include'),
+                            os.path.join(ROOT, 'examples', 'c_abi_demo.c'), '-L' + LIB_DIR, '-lauromat_hip',
+                            '-Wl,-rpath,' + LIB_DIR, '-Wl,-rpath,/opt/rocm/lib', '-lm', '-o', exe],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert build.returncode == 0 and build.stdout.strip() == '', build.stdout
+    w, h = 253, 171
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    img = frame_image(w, h, seed=13)
+    params = frame_params(hdr, 110, cam, t, True)
+    (tmp_path / 'params.bin').write_bytes(bytes(C.string_at(C.byref(params), C.sizeof(params))))
+    (tmp_path / 'img.bin').write_bytes(img.tobytes())
+    run = subprocess.run([exe, str(tmp_path / 'params.bin'), str(tmp_path / 'img.bin'), '10', str(tmp_path / 'out.bin')],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
+    assert run.returncode == 0, run.stdout
+    assert run.stdout.startswith('ok %d x %d frame' % (w, h)), run.stdout
+    raw = np.fromfile(str(tmp_path / 'out.bin'), dtype=np.float64)
+    nc, npx = (w + 1) * (h + 1), w * h
+    pipe = FramePipeline(w, h)
+    res = pipe.run(hdr, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10)
+    got = pipe.host_arrays()
+    o = 0
+    for k, n, shape in (('lat', nc, (h + 1, w + 1)), ('lon', nc, (h + 1, w + 1)), ('lat_c', npx, (h, w)),
+                        ('lon_c', npx, (h, w)), ('elev', npx, (h, w))):
+        assert np.array_equal(raw[o:o + n].reshape(shape), got[k], equal_nan=True), k
+        o += n
+    bbox = raw[o:o + 8]
+    o += 8
+    ny, nx = int(raw[o]), int(raw[o + 1])
+    o += 2
+    assert (ny, nx) == res['count'].shape
+    assert np.array_equal(raw[o:o + ny * nx].reshape(ny, nx), res['count'])
+    o += ny * nx
+    assert np.array_equal(raw[o:o + ny * nx * 4].reshape(ny, nx, 4), res['mean'], equal_nan=True)
+    assert o + ny * nx * 4 == raw.size
+    bb = pipe.bounding_box()
+    assert (bbox[0], bbox[1], bbox[2], bbox[3]) == (bb.latSouth, bb.latNorth, bb.lonWest, bb.lonEast)
