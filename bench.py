@@ -113,6 +113,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if rank != 0:
+        # only rank 0 reports; libraries that write to stdout (RCCL prints a version banner with C stdio) must not
+        # interleave with its JSON line in the launcher's merged output
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     torch.cuda.set_device(local_rank)
     # AMT_BENCH_FORCE_DIST=1 exercises the RCCL gather path with a single rank (boxes with one GPU)
     use_dist = world > 1 or bool(os.environ.get('AMT_BENCH_FORCE_DIST'))
@@ -274,7 +278,13 @@ def main():
             out['cpu_baseline'] = cpu_baseline(min(args.cpu_rows, HEIGHT))
         else:
             out['cpu_baseline'] = None
+        # the JSON line is the LAST thing on stdout: flush what C libraries have buffered there (RCCL's banner),
+        # print, and close the descriptor for whatever they print while shutting down
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if use_dist:
         dist.destroy_process_group()
 
