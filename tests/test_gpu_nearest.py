@@ -210,3 +210,61 @@ def test_nearest_full_size_properties():
     filled = ~mean['mask']
     interior = filled[1:-1, 1:-1] & filled[:-2, 1:-1] & filled[2:, 1:-1] & filled[1:-1, :-2] & filled[1:-1, 2:]
     assert (res['mask'][1:-1, 1:-1][interior]).mean() < 0.02
+
+
+def _reference_test_coords(offset):
+    """resample_test.py:21-36 `_testCoords`: a disc of valid values on a 10 x 10 grid (float32 like the original)"""
+    n = 10
+    sp, step = np.linspace(offset, offset + 10, num=n, retstep=True)
+    coord = np.tile(sp, n).reshape(n, n).astype(np.float32)
+    r = n * 0.4
+    y, x = np.ogrid[-r: r + 1, -r: r + 1]
+    disc = np.zeros((n, n), bool)
+    disc[:9, :9] = x ** 2 + y ** 2 <= r ** 2
+    coord[~disc] = np.nan
+    return coord, coord[:-1, :-1] + step / 2
+
+
+def test_reference_resample_test_call_sequence():
+    """The reference's own resample_test.py:70-88 on its synthetic grid across the date line
+    (`testCoordsDiscontinuity`): resample(pxPerDeg=1, 'mean') is plate carree; resampleMLatMLT(arcsecPerPx=100,
+    method='nearest') is not, but its (MLat, SM longitude) corners are.  And the sequence of `_testReal` (:90-99) on a
+    camera frame: mean at 15 px/deg, then nearest at 100 arcsec, bounding boxes equal to one decimal."""
+    from datetime import datetime
+    from auromat_amd.coordinates.transform import mltToSmLon
+    from auromat_amd.mapping.mapping import GenericMapping, checkPlateCarree, wrap_at_180
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.resample import resample, resampleMLatMLT
+    from auromat_amd.synthetic import frame_header, frame_image
+    lats, latsCenter = _reference_test_coords(70)
+    lats, latsCenter = lats.T, latsCenter.T
+    lons, lonsCenter = _reference_test_coords(160)
+    lons, lonsCenter = wrap_at_180(lons + 15), wrap_at_180(lonsCenter + 15)
+    rgb = ma.masked_array((np.random.RandomState(1).rand(lats.shape[0] - 1, lats.shape[1] - 1, 3) * 255).astype(np.uint8))
+    elevation = np.zeros((rgb.shape[0], rgb.shape[1]))
+    mapping = GenericMapping(lats, lons, latsCenter, lonsCenter, elevation, 110, rgb, cameraPosGCRS=np.array([0, 0, 0]),
+                             photoTime=datetime(2012, 1, 25, 9, 26, 55), identifier=None)
+    assert mapping.containsDiscontinuity
+    m = resample(mapping, pxPerDeg=1, method='mean')
+    m.checkPlateCarree()
+    mm = resampleMLatMLT(mapping, arcsecPerPx=100, method='nearest')
+    assert not mm.isPlateCarree
+    mlat, mlt = mm.mLatMlt
+    checkPlateCarree(mlat.data, mltToSmLon(mlt.data))
+
+    w, h = 530, 354
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    # (the reference keeps `_testReal` disabled: without an elevation mask the sparse limb pixels leave the outer grid
+    #  rows empty and the boxes differ by more than a decimal; with maskedByElevation(10) the assertion holds)
+    m1 = ArraySpacecraftMapping(hdr, 110, frame_image(w, h, seed=2), cam, t, 'r',
+                                fastCenterCalculation=True).maskedByElevation(10)
+    m2 = resample(m1, pxPerDeg=15, method='mean')
+    m2.checkPlateCarree()
+    m3 = resample(m2, arcsecPerPx=100, method='nearest')
+    m3.checkPlateCarree()
+
+    def bb(mp):
+        b = mp.boundingBox
+        return [b.latNorth, b.latSouth, b.lonWest, b.lonEast]
+    np.testing.assert_allclose(bb(m2), bb(m1), atol=0.15)
+    np.testing.assert_allclose(bb(m3), bb(m1), atol=0.15)
