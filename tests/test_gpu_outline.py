@@ -104,6 +104,8 @@ def test_mapping_outline_centroid_known_answer_full_size():
     m = ArraySpacecraftMapping(hdr, float(z['altitude']), img, z['cam'], t, 'iss030', fastCenterCalculation=True)
     c = m.centroid
     np.testing.assert_almost_equal([c.lat, c.lon], ka['expect'], decimal=ka['decimals'])
+    el = m.elevation                                         # elevation_test.py:15-22 on the same fixture
+    assert 0 <= el.min() <= el.max() <= 90
     outl = m.outline
     assert outl.shape[1] == 2 and len(outl) > 10000
     mask = ~ma.getmaskarray(m.lats)
