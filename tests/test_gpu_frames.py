@@ -822,3 +822,23 @@ def test_plain_c_client_of_the_abi(tmp_path):
     assert o + ny * nx * 4 == raw.size
     bb = pipe.bounding_box()
     assert (bbox[0], bbox[1], bbox[2], bbox[3]) == (bb.latSouth, bb.latNorth, bb.lonWest, bb.lonEast)
+
+
+def test_readme_quick_start():
+    """The snippet of README.md, as written there."""
+    from auromat_amd.mapping.spacecraft import getMapping
+    from auromat_amd.resample import resample, resampleMLatMLT
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 253, 171
+    wcsHeader, cam, t = frame_header(w, h, 'iss030')
+    wcsHeader.update({'DATE-OBS': t.strftime('%Y-%m-%dT%H:%M:%S.%f'), 'POSX': cam[0], 'POSY': cam[1], 'POSZ': cam[2]})
+    img = frame_image(w, h, seed=1)
+    m = getMapping(img, wcsHeader, altitude=110, fastCenterCalculation=True).maskedByElevation(10)
+    geo = resample(m, pxPerDeg=10)
+    mag = resampleMLatMLT(m, pxPerDeg=10)
+    near = resample(m, arcsecPerPx=100, method='nearest')
+    for r in (geo, mag, near):
+        r.checkGuarantees()
+    assert geo.lats.shape == geo.lons.shape and geo.img.shape[:2] == geo.elevation.shape
+    assert geo.boundingBox.latSouth < geo.centroid.lat < geo.boundingBox.latNorth
+    assert geo.outline.shape[1] == 2 and geo.isPlateCarree and not mag.isPlateCarree
