@@ -213,6 +213,22 @@ class _Grid(object):
         (xaxis, _), (yaxis, _) = self._axes[key]
         return xaxis, yaxis
 
+    def device_corners(self, ctx):
+        """(lat, lon) of the corner grid on the device, longitude-major ((nx+1, ny+1)), kept with the grid."""
+        key = ('corners', ctx.device.index)
+        if key not in self._axes:
+            self._axes[key] = (ctx.to_device(np.ascontiguousarray(self.lat.T, dtype=np.float64)),
+                               ctx.to_device(np.ascontiguousarray(self.lon.T, dtype=np.float64)))
+        return self._axes[key]
+
+    def device_centers(self, ctx):
+        """(latCenters (ny), lonCenters (nx)) on the device, kept with the grid."""
+        key = ('centers', ctx.device.index)
+        if key not in self._axes:
+            self._axes[key] = (ctx.to_device(np.ascontiguousarray(self.latCenters)),
+                               ctx.to_device(np.ascontiguousarray(self.lonCenters)))
+        return self._axes[key]
+
     # 2-D coordinate arrays of the output mapping (reference resample.py:239-241), built on first use
     def _corners(self):
         if self._corner_grid is None:
@@ -269,8 +285,7 @@ def outside_outline_mask(ctx, grid, outline):
     poly = ctx.to_device(np.ascontiguousarray(outline, dtype=np.float64))
     # points in longitude-major order: consecutive points share their y (= longitude), which lets the kernel drop
     # almost every polygon edge per block of points (it skips edges whose y-range misses the block's)
-    lat = ctx.to_device(np.ascontiguousarray(grid.lat.T, dtype=np.float64))
-    lon = ctx.to_device(np.ascontiguousarray(grid.lon.T, dtype=np.float64))
+    lat, lon = grid.device_corners(ctx)
     inside = ctx.empty(tuple(lat.shape), torch.uint8)
     ctx.call('amt_points_in_polygon', ptr(lat), ptr(lon), lat.numel(), ptr(poly), int(poly.shape[0]), ptr(inside))
     out = inside.T == 0
@@ -282,8 +297,7 @@ def nearest_indices(ctx, lat_c, lon_c, elev, center_mask, height, width, min_ele
     (``amt_nearest_frame``; reference resample.py:323-327, griddata(method='nearest'))."""
     import torch
     xaxis, yaxis = grid.axes(ctx)
-    tlat = ctx.to_device(np.ascontiguousarray(grid.latCenters))
-    tlon = ctx.to_device(np.ascontiguousarray(grid.lonCenters))
+    tlat, tlon = grid.device_centers(ctx)
     index = ctx.empty((grid.ny, grid.nx), torch.int64)
     min_el = float('-inf') if min_elevation is None else float(min_elevation)
     ctx.call('amt_nearest_frame', ptr(lat_c), ptr(lon_c), ptr(elev), ptr(center_mask), height, width, min_el,
