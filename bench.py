@@ -57,30 +57,36 @@ def measured_copy_gbs(device):
     return 10 * 2 * n * 8 / (time.perf_counter() - t0) / 1e9
 
 
-def cpu_baseline(sample_rows):
-    """Oracle (NumPy restatement of the reference) on the same workload, 1 core, rows [0, sample_rows)."""
+def cpu_baseline(sample_rows, frames=4):
+    """Oracle (NumPy restatement of the reference) on the same workload, 1 core: `frames` frames of the synthetic
+    sequence (rows [0, sample_rows) of each), about 12 s of CPU work at the full frame height."""
     from oracle import ref_numpy as O
-    from auromat_amd.synthetic import frame_header, frame_image
+    from auromat_amd.synthetic import sequence_frame, frame_image
     from auromat_amd.coordinates import transform as T
-    hdr, cam, t = frame_header(WIDTH, HEIGHT, 'iss030')
-    # crop: same pixels as the top `sample_rows` rows of the full frame
-    hdr = dict(hdr, IMAGEH=sample_rows)
-    img = frame_image(WIDTH, HEIGHT, seed=0)[:sample_rows]
-    t0 = time.time()
-    et = T.date2es(t)
-    g = O.georef_frame(hdr, ALTITUDE, cam, O.mat_j2000_to_geo(et), None, fast=True)
-    t1 = time.time()
-    corner_mask, center_mask = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), MIN_ELEV)
-    bbox, disc = O.bbox_of_corners(g['lat'], g['lon'], corner_mask)
-    data = np.dstack((img.astype(np.float64), g['elev']))
-    data[center_mask] = np.nan
-    O.resample_mean(np.where(center_mask, np.nan, g['lat_c']), np.where(center_mask, np.nan, g['lon_c']), ALTITUDE,
-                    data, None, bbox, (PPD, PPD), disc, False)
-    t2 = time.time()
-    npx = WIDTH * sample_rows
-    return dict(value=npx / 1e6 / (t2 - t0), unit='Mpixels/s', cores=1, kind='port',
-                sample='rows 0..%d of the %dx%d frame (%.1f Mpx): georef %.1f s + mask/resample %.1f s, NumPy, 1 thread'
-                       % (sample_rows, WIDTH, HEIGHT, npx / 1e6, t1 - t0, t2 - t1))
+    t_geo = t_res = 0.0
+    for k in range(frames):
+        hdr, cam, t, seed = sequence_frame(k, WIDTH, HEIGHT)
+        # crop: same pixels as the top `sample_rows` rows of the full frame
+        hdr = dict(hdr, IMAGEH=sample_rows)
+        img = frame_image(WIDTH, HEIGHT, seed=seed)[:sample_rows]
+        t0 = time.time()
+        et = T.date2es(t)
+        g = O.georef_frame(hdr, ALTITUDE, cam, O.mat_j2000_to_geo(et), None, fast=True)
+        t1 = time.time()
+        corner_mask, center_mask = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), MIN_ELEV)
+        bbox, disc = O.bbox_of_corners(g['lat'], g['lon'], corner_mask)
+        data = np.dstack((img.astype(np.float64), g['elev']))
+        data[center_mask] = np.nan
+        O.resample_mean(np.where(center_mask, np.nan, g['lat_c']), np.where(center_mask, np.nan, g['lon_c']), ALTITUDE,
+                        data, None, bbox, (PPD, PPD), disc, False)
+        t2 = time.time()
+        t_geo += t1 - t0
+        t_res += t2 - t1
+        del g, data
+    npx = WIDTH * sample_rows * frames
+    return dict(value=npx / 1e6 / (t_geo + t_res), unit='Mpixels/s', cores=1, kind='port',
+                sample='%d frames of the sequence, rows 0..%d of %dx%d each (%.1f Mpx): georef %.1f s + mask/resample '
+                       '%.1f s, NumPy, 1 thread' % (frames, sample_rows, WIDTH, HEIGHT, npx / 1e6, t_geo, t_res))
 
 
 def main():
