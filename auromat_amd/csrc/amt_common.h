@@ -18,8 +18,14 @@ struct amt_ctx {
     hipStream_t stream;
     bool owns_stream;
     double* scratch;        // small device scratch (counters)
-    void* ws;               // grow-only device workspace (per-block partial reductions)
-    size_t ws_bytes;
+    // grow-only device workspaces (per-block partial reductions, sort buffers), ONE PER STREAM the context has been
+    // used on: kernels of different streams run concurrently and must not share scratch memory
+    struct workspace {
+        hipStream_t stream;
+        void* ptr;
+        size_t bytes;
+    };
+    std::vector<workspace> workspaces;
     std::string last_error;
     // side streams shared by all frame drivers of this context (created by the first amt_pipe_create): every
     // extra stream competes for the few hardware queues of the process, and streams that share a hardware queue
@@ -78,22 +84,31 @@ int amt_bin_finalize_on(amt_ctx* ctx, hipStream_t stream, uint64_t* acc, int32_t
                         int32_t off_y, int32_t nx, int32_t ny, int32_t nchan, int32_t img_dtype, double* mean,
                         void* out_img, uint8_t* out_mask, double* out_count, int clear);
 
-// Returns a device workspace of at least `bytes` (grow-only; reallocation synchronises the stream).
+// Returns the device workspace of the context's CURRENT stream, at least `bytes` large (grow-only; reallocation
+// synchronises that stream).  The Python host switches the context between torch streams (frame k is binned on one
+// while frame k+1 is georeferenced on another), so scratch memory is kept per stream.
 static inline void* amt_workspace(amt_ctx* ctx, size_t bytes) {
-    if (bytes <= ctx->ws_bytes) return ctx->ws;
-    if (ctx->ws) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(ctx->ws);
-        ctx->ws = nullptr;
-        ctx->ws_bytes = 0;
+    amt_ctx::workspace* w = nullptr;
+    for (auto& e : ctx->workspaces)
+        if (e.stream == ctx->stream) w = &e;
+    if (w == nullptr) {
+        ctx->workspaces.push_back({ctx->stream, nullptr, 0});
+        w = &ctx->workspaces.back();
     }
-    size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
-    if (hipMalloc(&ctx->ws, cap) != hipSuccess) {
-        ctx->ws = nullptr;
+    if (bytes <= w->bytes) return w->ptr;
+    if (w->ptr) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(w->ptr);
+        w->ptr = nullptr;
+        w->bytes = 0;
+    }
+    const size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
+    if (hipMalloc(&w->ptr, cap) != hipSuccess) {
+        w->ptr = nullptr;
         return nullptr;
     }
-    ctx->ws_bytes = cap;
-    return ctx->ws;
+    w->bytes = cap;
+    return w->ptr;
 }
 
 #define AMT_CHECK_CTX(ctx) \

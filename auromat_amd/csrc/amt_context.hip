@@ -16,8 +16,6 @@ int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ct
     ctx->stream = nullptr;
     ctx->owns_stream = false;
     ctx->scratch = nullptr;
-    ctx->ws = nullptr;
-    ctx->ws_bytes = 0;
     ctx->timing = 0;
     ctx->aux_pre = ctx->aux_tail = ctx->aux_fin = nullptr;
     ctx->tlaunch[0] = ctx->tlaunch[1] = 0;
@@ -49,7 +47,8 @@ int amt_ctx_destroy(amt_ctx* ctx) {
     AMT_CHECK_CTX(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->ws) (void)hipFree(ctx->ws);
+    for (auto& w : ctx->workspaces)
+        if (w.ptr) (void)hipFree(w.ptr);
     for (int k = 0; k < 2; ++k)
         for (hipEvent_t e : ctx->tev[k]) (void)hipEventDestroy(e);
     for (hipStream_t st : {ctx->aux_pre, ctx->aux_tail, ctx->aux_fin})

@@ -24,8 +24,6 @@ struct amt_pipe {
     uint64_t* acc;                 // superset accumulators (device), 5 planes
     size_t acc_cells;              // capacity per plane
     bool acc_zero;                 // the accumulators are known to be all zero
-    void* coarse_ws;               // workspace of the pre-pass (the context's belongs to the main stream)
-    size_t coarse_ws_bytes;
     double* partials;              // per-wave partial boxes of the big kernel (read by the folds on tail_stream)
     size_t partials_bytes;
     // state of the frame in flight
@@ -205,7 +203,6 @@ int amt_pipe_destroy(amt_pipe* pipe) {
     if (pipe->event_count) (void)hipFree(pipe->event_count);
     if (pipe->host_small) (void)hipHostFree(pipe->host_small);
     if (pipe->acc) (void)hipFree(pipe->acc);
-    if (pipe->coarse_ws) (void)hipFree(pipe->coarse_ws);
     delete pipe;
     return AMT_OK;
 }
@@ -214,23 +211,15 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
     if (pipe == nullptr) return AMT_EINVAL;
     amt_ctx* ctx = pipe->ctx;
     AMT_REQUIRE(ctx, p != nullptr, "NULL argument");
-    // the pre-pass runs on the driver's own stream with its own workspace: the context's stream and workspace
-    // are in use by the previous frame's kernels
+    // the pre-pass runs on the driver's own stream (and with that stream's workspace, see amt_workspace): the
+    // context's stream is busy with the previous frames' kernels
     hipStream_t saved = ctx->stream;
-    void* saved_ws = ctx->ws;
-    size_t saved_ws_bytes = ctx->ws_bytes;
     ctx->stream = pipe->pre_stream;
-    ctx->ws = pipe->coarse_ws;
-    ctx->ws_bytes = pipe->coarse_ws_bytes;
     const double thr = std::isinf(min_elevation) ? min_elevation : min_elevation - 0.5;
     const int shorter = p->width < p->height ? p->width : p->height;
     const int stride = std::max(1, std::min(kCoarseStride, shorter / 128));
     int rc = amt_georef_coarse_bbox(ctx, p, stride, thr, magnetic ? 1 : 0, pipe->host_small_dev);
-    pipe->coarse_ws = ctx->ws;
-    pipe->coarse_ws_bytes = ctx->ws_bytes;
     ctx->stream = saved;
-    ctx->ws = saved_ws;
-    ctx->ws_bytes = saved_ws_bytes;
     if (rc != AMT_OK) return rc;
     AMT_HIP(ctx, hipEventRecord(pipe->coarse_done, pipe->pre_stream));
     pipe->coarse_pending = true;

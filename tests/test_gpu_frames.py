@@ -842,3 +842,27 @@ def test_readme_quick_start():
     assert geo.lats.shape == geo.lons.shape and geo.img.shape[:2] == geo.elevation.shape
     assert geo.boundingBox.latSouth < geo.centroid.lat < geo.boundingBox.latNorth
     assert geo.outline.shape[1] == 2 and geo.isPlateCarree and not mag.isPlateCarree
+
+
+def test_scratch_memory_is_per_stream_in_two_pass_magnetic_sequences():
+    """Regression: in the two-pass MLat/MLT plan frame k's bounding-box reduction (amt_bbox_corners, on the binning
+    stream) and frame k+1's georeferencing (on the main stream) both used the context's one scratch buffer; with
+    asynchronous uploads the overlap was long enough to corrupt a frame now and then.  Workspaces are per stream."""
+    import torch
+    from auromat_amd.pipeline import FramePipeline, SequencePipeline
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    w, h, n = 1060, 708, 60
+    frames, imgs = [], []
+    for k in range(n):
+        hdr, cam, t, seed = sequence_frame(k, w, h)
+        imgs.append(frame_image(w, h, seed=seed))
+        frames.append((hdr, cam, t, torch.from_numpy(imgs[-1].view(np.int16)).pin_memory()))
+    single = FramePipeline(w, h, with_mag=True)
+    want = [single.run(hdr, 110, cam, t, img=imgs[k], pxPerDeg=8, magnetic=True)
+            for k, (hdr, cam, t, _) in enumerate(frames)]
+    seq = SequencePipeline(w, h, pxPerDeg=8, plan='two-pass', magnetic=True)
+    for rep in range(3):
+        got = seq.process(frames, keep_on_device=False)
+        for k in range(n):
+            for key in ('mean', 'count', 'img', 'mask'):
+                assert np.array_equal(got[k][key], want[k][key], equal_nan=True), (rep, k, key)

@@ -1,5 +1,5 @@
 """Race hunt: long sequences with per-frame images through SequencePipeline (all batch sizes, both plans, MLat/MLT)
-against one-frame-at-a-time results; every mismatch is reported."""
+against one-frame-at-a-time results; every mismatch is reported.  PIN=1: per-frame images from pinned host memory."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +11,11 @@ frames = []
 for k in range(n):
     hdr, cam, t, seed = sequence_frame(k, w, h)
     frames.append((hdr, cam, t, frame_image(w, h, seed=seed)))
+seq_frames = frames
+if os.environ.get('PIN'):
+    # images in pinned host memory: asynchronous uploads on the copy stream (buffers re-used while frames are in flight)
+    import torch
+    seq_frames = [(hd, cam, t, torch.from_numpy(img.view(np.int16)).pin_memory()) for hd, cam, t, img in frames]
 bad = 0
 for magnetic in (False, True):
     ref_pipe = FramePipeline(w, h, with_mag=magnetic)
@@ -18,7 +23,7 @@ for magnetic in (False, True):
     for plan, batch in (('single-pass', 1), ('single-pass', 2), ('single-pass', 3), ('two-pass', 1)):
         seq = SequencePipeline(w, h, pxPerDeg=8, plan=plan, batch=batch, magnetic=magnetic)
         for rep in range(2):
-            out = seq.process(frames, keep_on_device=False)
+            out = seq.process(seq_frames, keep_on_device=False)
             for k, (a, b) in enumerate(zip(out, ref)):
                 for key in ('mean', 'count', 'img', 'mask'):
                     if not np.array_equal(a[key], b[key], equal_nan=True):
