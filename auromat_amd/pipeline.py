@@ -525,4 +525,11 @@ class SequencePipeline(object):
         cur.wait_stream(self.s_main)
         if self.s_bin is not self.s_main:
             cur.wait_stream(self.s_bin)
+        if keep_on_device:
+            # the result tensors were allocated on the pipeline's streams: tell the caching allocator that the caller's
+            # stream uses them too, so that their memory is not handed out again while the caller still reads it
+            for res in out:
+                for v in res.values():
+                    if isinstance(v, torch.Tensor) and v.is_cuda:
+                        v.record_stream(cur)
         return out
