@@ -866,3 +866,15 @@ def test_scratch_memory_is_per_stream_in_two_pass_magnetic_sequences():
         for k in range(n):
             for key in ('mean', 'count', 'img', 'mask'):
                 assert np.array_equal(got[k][key], want[k][key], equal_nan=True), (rep, k, key)
+
+
+def test_differential_fuzz_of_both_plans_against_the_oracle():
+    """tools/fuzz_frames.py with a fixed seed: 150 random frames (sizes, pointings, times incl. date-line crossings,
+    shells, anisotropic resolutions, fast / exact centres, thresholds incl. none, uint8 / uint16): single-pass ==
+    two-pass bit for bit, two-pass vs oracle within 2 cells with exact integer means."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    run = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_frames.py'), '150', '11'],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=500)
+    assert run.returncode == 0 and 'failures 0' in run.stdout, run.stdout[-2000:]
