@@ -21,24 +21,27 @@ for case in range(cases):
     fast = bool(rng.randint(2))
     thr = [None, 5.0, 10.0, 20.0][rng.randint(4)]
     dtype = (np.uint8, np.uint16)[rng.randint(2)]
+    magnetic = rng.randint(4) == 0                     # MLat/MLT grid: the two plans against each other only
     hdr, cam, t = frame_header(w, h, pointing)
     t = t - timedelta(minutes=shift)
     img = frame_image(w, h, seed=case, dtype=dtype)
-    tag = '%d: %dx%d %s -%gmin alt %g ppd %s %s thr %s %s' % (case, w, h, pointing, shift, alt, ppd,
-                                                               'fast' if fast else 'exact', thr, dtype.__name__)
-    pipe = FramePipeline(w, h, img_dtype=dtype)
+    tag = '%d: %dx%d %s -%gmin alt %g ppd %s %s thr %s %s%s' % (case, w, h, pointing, shift, alt, ppd,
+                                                                 'fast' if fast else 'exact', thr, dtype.__name__,
+                                                                 ' magnetic' if magnetic else '')
+    pipe = FramePipeline(w, h, img_dtype=dtype, with_mag=magnetic)
     try:
-        two = pipe.run(hdr, alt, cam, t, img=img, fast=fast, min_elevation=thr, pxPerDeg=ppd, fuse=False)
+        two = pipe.run(hdr, alt, cam, t, img=img, fast=fast, min_elevation=thr, pxPerDeg=ppd, fuse=False,
+                       magnetic=magnetic)
     except (ValueError, AssertionError) as e:
         skipped += 1                                   # nothing above the threshold / degenerate grid: as the reference
         continue
-    one = pipe.run(hdr, alt, cam, t, fast=fast, min_elevation=thr, pxPerDeg=ppd, fuse=True)
+    one = pipe.run(hdr, alt, cam, t, fast=fast, min_elevation=thr, pxPerDeg=ppd, fuse=True, magnetic=magnetic)
     for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
         if not np.array_equal(one[k], two[k], equal_nan=True):
             bad += 1
             print('PLANS DIFFER', tag, k, pipe.last_plan)
             break
-    if two['contains_pole']:
+    if two['contains_pole'] or magnetic:
         continue
     et = O.date2es(t)
     g = O.georef_frame(hdr, alt, cam, O.mat_j2000_to_geo(et), None, fast=fast)
