@@ -502,8 +502,8 @@ class BaseMapping(object):
             polygon[:, 0], polygon[:, 1] = _rotate_pole_host(polygon[:, 0], polygon[:, 1], self.altitude, 90)
             lat, lon = _rotate_pole_dev(ctx, lat, lon, self.altitude, 90)
         inside = ctx.empty(tuple(lat.shape), torch.uint8)
-        ctx.call('amt_points_in_polygon', ptr(lat.contiguous()), ptr(lon.contiguous()), lat.numel(),
-                 ptr(ctx.to_device(polygon)), len(polygon), ptr(inside))
+        lat, lon, poly = lat.contiguous(), lon.contiguous(), ctx.to_device(polygon)     # named: they outlive the call
+        ctx.call('amt_points_in_polygon', ptr(lat), ptr(lon), lat.numel(), ptr(poly), len(polygon), ptr(inside))
         mask = (inside == 0) | (fd.corner_mask_tensor() != 0)
         if bool(mask.all().item()):
             raise ValueError('The given mask would mask all pixels!')
