@@ -87,5 +87,29 @@ for it in range(rounds):
     if not ok:
         bad += 1
         print('NEAREST', it, hh, ww, ppd)
+    # --- all-sky camera model and altitude reprojection vs the oracle ---
+    if it % 10 == 0:
+        from datetime import datetime
+        from auromat_amd.mapping.miracle import CalibrationData, MIRACLEMapping
+        from auromat_amd.mapping.mapping import BoundingBox
+        from auromat_amd.mapping.themis import reproject
+        n = int(rng.randint(4, 90))
+        cal = dict(lat=float(rng.uniform(-80, 80)), lon=float(rng.uniform(-179, 179)), xc=float(rng.uniform(200, 300)),
+                   yc=float(rng.uniform(200, 300)), k=float(rng.uniform(120, 200)), rotation=float(rng.uniform(-3, 3)))
+        alt = float(rng.uniform(80, 300))
+        cd = CalibrationData(station='XXX', validFrom=None, validTo=None, boundingBoxSimple=BoundingBox(0, 0, 1, 1), **cal)
+        mp = MIRACLEMapping(cd, np.zeros((n, n, 3), np.uint8), datetime(2012, 3, 4, 17, 19), alt)
+        g = O.allsky_georef(n, cal, alt)
+        err = max(np.nanmax(np.abs(mp.lats.data - g['lat'])), np.nanmax(np.abs(mp.latsCenter.data - g['lat_c'])),
+                  np.nanmax(np.abs(mp.elevation.data - g['elev'])),
+                  np.nanmax(np.abs((mp.lons.data - g['lon'] + 180) % 360 - 180)))
+        la, lo = reproject((cal['lat'], cal['lon']), g['lat'], g['lon'], alt, alt * 1.4)
+        wla, wlo = O.themis_reproject((cal['lat'], cal['lon']), g['lat'], g['lon'], alt, alt * 1.4)
+        ok = np.array_equal(np.isnan(la), np.isnan(wla))
+        fin = ~np.isnan(la)
+        err2 = max(np.max(np.abs(la[fin] - wla[fin]), initial=0), np.max(np.abs((lo[fin] - wlo[fin] + 180) % 360 - 180), initial=0))
+        if not ok or err > 1e-9 or err2 > 1e-9:
+            bad += 1
+            print('ALLSKY', it, n, cal, alt, err, err2, ok)
 print('rounds', rounds, 'failures', bad)
 sys.exit(1 if bad else 0)
