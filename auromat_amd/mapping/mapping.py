@@ -379,11 +379,40 @@ class BaseMapping(object):
         Smallest lat/lon box around the unmasked corners (reference mapping.py:693-743).  The
         reference traces the mask outline on the host and asks geographiclib whether it encloses a
         pole; here one device pass reduces the corner extremes and counts pixels whose corner quad
-        winds around a pole.  In case containsPole is True the box spans the full longitude range.
+        winds around a pole; mappings whose longitudes go all around but where no unmasked pixel sees a pole are
+        decided by the reference's own rule on the traced outline (see _pole_possible).  In case containsPole is
+        True the box spans the full longitude range.
         """
         if self._boundingBox is None:
-            self._boundingBox = bounding_box_from_reduction(self._bbox_reduction())
+            red = np.array(self._bbox_reduction(), dtype=np.float64)
+            if red[6] > 0 and red[7] == 0 and self._pole_possible(red) and self._hull_contains_pole():
+                red[7] = 1
+            self._boundingBox = bounding_box_from_reduction(red)
         return self._boundingBox
+
+    @staticmethod
+    def _pole_possible(red):
+        """
+        The device counts pixels whose corner quad winds around a pole.  A pole can also lie in a hole or in a masked
+        part of the footprint, where no unmasked pixel sees it, while the reference's rule — does the (sampled) convex
+        hull of the outline contain or cross a pole, mapping.py:705-721 — still says yes.  That needs longitudes all
+        around: this is the cheap test for it (corner longitudes spanning more than 180 deg and no gap of more than
+        180 deg around longitude 0, which is what a mapping across the date line has).
+        """
+        lon_min, lon_max, lon_pos, lon_neg = red[2], red[3], red[4], red[5]
+        if lon_max - lon_min <= 180:
+            return False
+        return not (lon_pos - lon_neg > 180)
+
+    def _hull_contains_pole(self):
+        # reference mapping.py:705-715: at most 50 points of the convex hull of the outline
+        from ..coordinates.geodesic import containsOrCrossesPole
+        hull = self.outlineConvexHull
+        pointCount = len(hull)
+        if pointCount < 3:
+            return False
+        indices = np.round(np.linspace(0, pointCount - 1, min(pointCount, 50))).astype(int)
+        return bool(containsOrCrossesPole(hull[indices]))
 
     @property
     def containsDiscontinuity(self):

@@ -251,3 +251,39 @@ def test_pixel_polygons_for_drawing(dtype):
     # other coordinates (MLat / MLT corners): the host path
     v2, c2 = generatePolygonsFromMapping(m, None, coordsFn=lambda mp: mp.mLatMlt)
     assert v2.shape == verts.shape and np.array_equal(c2, generatePolygonsFromMapping(m)[1])
+
+
+def test_pole_inside_a_hole_of_the_mapping():
+    """The device pole test counts unmasked pixels whose corner quad winds around a pole; when the pole sits in a hole
+    (or in a part masked by elevation) no pixel sees it, but the reference's rule — the sampled convex hull of the
+    outline contains or crosses a pole (mapping.py:705-721) — still applies: the box is degenerate and resampling
+    rotates the pole away.  Found by tools/fuzz_mapping.py."""
+    from datetime import datetime
+    from oracle import ref_numpy as O
+    from auromat_amd.mapping.mapping import GenericMapping
+    from auromat_amd.resample import resample
+    h, w = 16, 18
+    lat_g, lon_g = np.meshgrid(np.linspace(4, -4, h + 1), np.linspace(-4.5, 4.5, w + 1), indexing='ij')
+
+    def move(la, lo):        # the patch centred on (0, 0) is tipped over the north pole
+        a, o = O.rotate_pole(np.deg2rad(la.ravel()), np.deg2rad(lo.ravel()), 110, angle=-90.3, axis=(0, 1, 0))
+        return np.rad2deg(a).reshape(la.shape), np.rad2deg(o).reshape(la.shape)
+    lats, lons = move(lat_g, lon_g)
+    lats_c, lons_c = move((lat_g[:-1, :-1] + lat_g[1:, 1:]) / 2, (lon_g[:-1, :-1] + lon_g[1:, 1:]) / 2)
+    assert lats.max() > 89
+    img = np.random.RandomState(2).randint(0, 256, (h, w, 3)).astype(np.uint8)
+    elev = np.full((h, w), 45.0)
+    whole = GenericMapping(lats, lons, lats_c, lons_c, elev, 110, img, np.array([7000.0, 0, 0]), datetime(2012, 1, 25), 'p')
+    assert whole.containsPole
+    # mask the 3 x 3 pixels around the pole
+    r, c = np.unravel_index(np.argmax(lats_c), lats_c.shape)
+    holed_c, holed_o = lats_c.copy(), lons_c.copy()
+    holed_c[r - 1:r + 2, c - 1:c + 2] = np.nan
+    holed_o[r - 1:r + 2, c - 1:c + 2] = np.nan
+    m = GenericMapping(lats, lons, holed_c, holed_o, elev, 110, img, np.array([7000.0, 0, 0]), datetime(2012, 1, 25), 'p')
+    assert m.containsPole and m.containsDiscontinuity
+    bb = m.boundingBox
+    assert (bb.lonWest, bb.lonEast, bb.latNorth) == (-180, 180, 90)
+    res = resample(m, pxPerDeg=2)
+    res.checkGuarantees()
+    assert (~ma.getmaskarray(res.latsCenter)).sum() > 20

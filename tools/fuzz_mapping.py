@@ -1,0 +1,107 @@
+"""Class-level fuzz: GenericMapping over random coordinate patches (anywhere on the globe, also over the poles and the
+date line, with holes and image masks) — masks after sanitisation and maskedByElevation vs the oracle, bounding box vs
+the oracle, pole containment (device: pixel quads winding around a pole) vs the reference's rule (course deltas
+along the sampled convex hull of the outline, geodesic.py:139-202), resample(method='mean') vs the oracle.
+usage: fuzz_mapping.py [rounds] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from datetime import datetime
+import numpy as np
+import numpy.ma as ma
+from auromat_amd.coordinates.geodesic import containsOrCrossesPole
+from auromat_amd.mapping.mapping import GenericMapping
+from auromat_amd.resample import resample
+from oracle import ref_numpy as O
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = pole_cases = disc_cases = 0
+for it in range(rounds):
+    h, w = int(rng.randint(6, 40)), int(rng.randint(6, 40))
+    size_lat, size_lon = rng.uniform(2, 12), rng.uniform(2, 12)
+    # a patch around (0, 0), moved to a random place by a rotation about y (latitude) and z (longitude)
+    lat1 = np.linspace(size_lat / 2, -size_lat / 2, h + 1)
+    lon1 = np.linspace(-size_lon / 2, size_lon / 2, w + 1)
+    lat_g, lon_g = np.meshgrid(lat1, lon1, indexing='ij')
+    lat_c = (lat_g[:-1, :-1] + lat_g[1:, 1:]) / 2
+    lon_c = (lon_g[:-1, :-1] + lon_g[1:, 1:]) / 2
+    tilt = float(rng.choice([rng.uniform(-80, 80), rng.uniform(84, 96), rng.uniform(-96, -84)]))
+    spin = float(rng.choice([rng.uniform(-180, 180), rng.uniform(170, 190)]))
+
+    def move(la, lo):
+        a, o = O.rotate_pole(np.deg2rad(la.ravel()), np.deg2rad(lo.ravel()), 110, angle=tilt, axis=(0, 1, 0))
+        o = O.wrap_at(np.rad2deg(o) + spin, 180)
+        return np.rad2deg(a).reshape(la.shape), o.reshape(la.shape)
+    lats, lons = move(lat_g, lon_g)
+    lats_c, lons_c = move(lat_c, lon_c)
+    hole = rng.rand(h, w) < rng.uniform(0, 0.15)
+    lats_c[hole] = np.nan
+    lons_c[hole] = np.nan
+    img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    img_mask = rng.rand(h, w) < rng.uniform(0, 0.1)
+    elev = rng.uniform(0, 60, (h, w))
+    thr = float(rng.uniform(0, 25))
+    m = GenericMapping(lats, lons, lats_c, lons_c, elev, 110, ma.masked_array(img, np.repeat(img_mask[:, :, None], 3, 2)),
+                       np.array([7000.0, 0, 0]), datetime(2012, 1, 25, 9, 26, 55), 'f')
+    corner0, center0 = O.sanitize_masks(np.isnan(lats), np.isnan(lats_c), img_mask, after_masking=False)
+    with np.errstate(invalid='ignore'):
+        ce = center0 | ~(elev >= thr)
+    if ce.all():
+        continue
+    corner1, center1 = O.sanitize_masks(corner0, ce, after_masking=True)
+    mm = m.maskedByElevation(thr)
+    if not (np.array_equal(ma.getmaskarray(m.lats), corner0) and np.array_equal(ma.getmaskarray(m.latsCenter), center0)
+            and np.array_equal(ma.getmaskarray(mm.lats), corner1) and np.array_equal(ma.getmaskarray(mm.latsCenter), center1)):
+        bad += 1
+        print('MASKS', it, h, w)
+        continue
+    # pole: the reference's rule on its own sample of the convex hull of the outline
+    hull = mm.outlineConvexHull
+    idx = np.round(np.linspace(0, len(hull) - 1, min(len(hull), 50))).astype(int)
+    want_pole = bool(containsOrCrossesPole(hull[idx]))
+    got_pole = bool(mm.containsPole)
+    pole_cases += want_pole
+    if want_pole != got_pole:
+        bad += 1
+        print('POLE', it, 'tilt', tilt, 'spin', spin, 'reference rule', want_pole, 'device', got_pole)
+        continue
+    if want_pole:
+        # the box is degenerate (mapping.py:716-724); resampling rotates the pole away (resample.py:176-201)
+        la_v = lats[~corner1]
+        bb = mm.boundingBox
+        bbox = (-90.0, -180.0, float(la_v.max()), 180.0) if la_v.max() < 0 else (float(la_v.min()), -180.0, 90.0, 180.0)
+        if (bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast) != bbox:
+            bad += 1
+            print('POLE BBOX', it, bbox, bb)
+            continue
+        disc = False
+    else:
+        bbox, disc = O.bbox_of_corners(lats, lons, corner1)
+        bb = mm.boundingBox
+        disc_cases += bool(disc)
+        if not np.allclose([bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast], bbox, rtol=0, atol=1e-12) or \
+                bool(disc) != bool(mm.containsDiscontinuity):
+            bad += 1
+            print('BBOX', it, bbox, bb)
+            continue
+    ppd = (float(rng.choice([1, 2, 4])), float(rng.choice([1, 2, 4])))
+    try:
+        r = resample(mm, pxPerDeg=ppd)
+    except AssertionError:
+        continue                                      # nLat / nLon <= 1: the reference asserts as well
+    data = np.dstack((img.astype(np.float64), elev))
+    data[center1] = np.nan
+    outline = np.transpose([lats[~corner1], lons[~corner1]])
+    want = O.resample_mean(np.where(center1, np.nan, lats_c), np.where(center1, np.nan, lons_c), 110, data, outline, bbox,
+                           ppd, disc or want_pole, want_pole)
+    wimg, wmask = O.finalize_image(want['data'][..., :3], np.uint8)
+    if r.img.shape != wimg.shape or int((ma.getmaskarray(r.img)[..., 0] != wmask[..., 0]).sum()) > 2:
+        bad += 1
+        print('RESAMPLE', it, r.img.shape, wimg.shape)
+        continue
+    both = ~ma.getmaskarray(r.img)[..., 0] & ~wmask[..., 0]
+    if int((np.asarray(r.img.data)[both] != wimg[both]).sum()) > 6:
+        bad += 1
+        print('RESAMPLE VALUES', it)
+print('rounds', rounds, 'pole cases', pole_cases, 'date-line cases', disc_cases, 'failures', bad)
+sys.exit(1 if bad else 0)
