@@ -103,5 +103,24 @@ for it in range(rounds):
     if int((np.asarray(r.img.data)[both] != wimg[both]).sum()) > 6:
         bad += 1
         print('RESAMPLE VALUES', it)
+    # every third round also method='nearest' (traced outline, point-in-polygon mask, grid search)
+    if it % 3 == 0:
+        outl = O.outline(~corner1)
+        poly = np.transpose([lats[outl[:, 1], outl[:, 0]], lons[outl[:, 1], outl[:, 0]]])
+        try:
+            rn = resample(mm, pxPerDeg=ppd, method='nearest')
+        except AssertionError:
+            continue
+        wn = O.resample_nearest(np.where(center1, np.nan, lats_c), np.where(center1, np.nan, lons_c), 110, data, poly, bbox,
+                                ppd, disc or want_pole, want_pole)
+        gm, wm = ma.getmaskarray(rn.img)[..., 0], np.isnan(wn['data'][..., 0])
+        if gm.shape != wm.shape or int((gm != wm).sum()) > 2:
+            bad += 1
+            print('NEAREST MASK', it, gm.shape, wm.shape, int((gm != wm).sum()) if gm.shape == wm.shape else -1, want_pole, disc)
+            continue
+        both = ~gm & ~wm
+        if int(np.any(np.asarray(rn.img.data)[both] != wn['data'][..., :3][both], axis=-1).sum()) > 2:
+            bad += 1
+            print('NEAREST VALUES', it, want_pole, disc)
 print('rounds', rounds, 'pole cases', pole_cases, 'date-line cases', disc_cases, 'failures', bad)
 sys.exit(1 if bad else 0)
