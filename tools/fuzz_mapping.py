@@ -103,6 +103,38 @@ for it in range(rounds):
     if int((np.asarray(r.img.data)[both] != wimg[both]).sum()) > 6:
         bad += 1
         print('RESAMPLE VALUES', it)
+    # maskedByPolygon (mapping.py:866-917) with a random polygon around the patch, same steps in NumPy + matplotlib
+    if it % 2 == 0:
+        import matplotlib.path
+        from auromat_amd.mapping.mapping import BoundingBox
+        k = int(rng.randint(3, 9))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+        pl, po = move((rng.uniform(0.4, 1.0, k) * size_lat / 2 * np.sin(ang)).reshape(1, -1),
+                      (rng.uniform(0.4, 1.0, k) * size_lon / 2 * np.cos(ang)).reshape(1, -1))
+        poly = np.transpose([pl.ravel(), po.ravel()])
+        pbb = BoundingBox.minimumBoundingBox(poly)
+        g_la, g_lo, q = lats.copy(), lons.copy(), poly.copy()
+        try:
+            poly_pole = containsOrCrossesPole(poly)
+        except AssertionError:
+            continue            # course deltas do not add up (a vertex next to the pole): the reference asserts as well
+        if mm.containsDiscontinuity or pbb.containsDiscontinuity:
+            g_lo, q[:, 1] = O.wrap_at(g_lo + 180, 180), O.wrap_at(q[:, 1] + 180, 180)
+        elif mm.containsPole or poly_pole:
+            a, o = O.rotate_pole(np.deg2rad(g_la.ravel()), np.deg2rad(g_lo.ravel()), 110, angle=90, axis=(1, 0, 0))
+            g_la, g_lo = np.rad2deg(a).reshape(lats.shape), np.rad2deg(o).reshape(lats.shape)
+            a, o = O.rotate_pole(np.deg2rad(q[:, 0]), np.deg2rad(q[:, 1]), 110, angle=90, axis=(1, 0, 0))
+            q = np.transpose([np.rad2deg(a), np.rad2deg(o)])
+        inside = matplotlib.path.Path(q).contains_points(np.transpose([g_la.ravel(), g_lo.ravel()])).reshape(lats.shape)
+        pm = ~inside | corner1
+        want_center = np.logical_or.reduce((pm[:-1, :-1], pm[1:, :-1], pm[:-1, 1:], pm[1:, 1:]))
+        try:
+            got_center = ma.getmaskarray(mm.maskedByPolygon(poly).latsCenter)
+        except ValueError:
+            got_center = np.ones_like(want_center)
+        if int((got_center != want_center).sum()) > 2:
+            bad += 1
+            print('POLYGON', it, int((got_center != want_center).sum()), want_pole, disc, bool(pbb.containsDiscontinuity))
     # every third round also method='nearest' (traced outline, point-in-polygon mask, grid search)
     if it % 3 == 0:
         outl = O.outline(~corner1)
