@@ -412,7 +412,13 @@ class BaseMapping(object):
         if pointCount < 3:
             return False
         indices = np.round(np.linspace(0, pointCount - 1, min(pointCount, 50))).astype(int)
-        return bool(containsOrCrossesPole(hull[indices]))
+        try:
+            return bool(containsOrCrossesPole(hull[indices]))
+        except AssertionError:
+            # the course deltas do not add up to a multiple of 180 deg: a hull vertex sits (numerically) on a pole,
+            # where an azimuth is not defined (the reference's own test notes this case as broken,
+            # geodesic_test.py:31-38) — the outline crosses the pole
+            return True
 
     @property
     def containsDiscontinuity(self):
