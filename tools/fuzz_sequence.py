@@ -1,0 +1,50 @@
+"""Sequence fuzz: frames that do NOT follow each other smoothly (random pointings, times up to 95 min apart — date-line
+and pole frames included —, jumps back and forth, repeated frames) through SequencePipeline with every plan / batch
+size and hints on, against one frame at a time.  usage: fuzz_sequence.py [sequences] [seed]"""
+import os, sys
+from datetime import timedelta
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from auromat_amd.pipeline import FramePipeline, SequencePipeline
+from auromat_amd.synthetic import frame_header, frame_image, sequence_frame
+
+nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+w, h = 250, 168
+bad = 0
+for s in range(nseq):
+    n = int(rng.randint(1, 40))
+    frames = []
+    k = 0
+    while len(frames) < n:
+        mode = rng.randint(4)
+        if mode == 0:                                     # a smooth stretch of the synthetic sequence
+            for _ in range(int(rng.randint(1, 8))):
+                hdr, cam, t, seed = sequence_frame(k, w, h)
+                frames.append((hdr, cam, t, frame_image(w, h, seed=seed)))
+                k += 1
+        elif mode == 1:                                   # a jump somewhere else in time / pointing
+            hdr, cam, t = frame_header(w, h, ('iss030', 'iss029')[rng.randint(2)])
+            t = t - timedelta(minutes=float(rng.choice([0, 20, 45, 80, 95])))
+            frames.append((hdr, cam, t, frame_image(w, h, seed=1000 + len(frames))))
+        elif mode == 2 and frames:                        # the same frame again
+            frames.append(frames[-1])
+        else:
+            k = int(rng.randint(0, 300))
+    frames = frames[:n]
+    magnetic = bool(rng.randint(2))
+    ppd = float(rng.choice([4, 8, 10]))
+    ref_pipe = FramePipeline(w, h, with_mag=magnetic)
+    ref = [ref_pipe.run(hd, 110, cam, t, img=img, pxPerDeg=ppd, magnetic=magnetic) for hd, cam, t, img in frames]
+    for plan, batch in (('single-pass', 1), ('single-pass', 2), ('single-pass', 3), ('two-pass', 1)):
+        seq = SequencePipeline(w, h, pxPerDeg=ppd, plan=plan, batch=batch, magnetic=magnetic)
+        out = seq.process(frames, keep_on_device=False)
+        for i, (a, b) in enumerate(zip(out, ref)):
+            for key in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
+                if not np.array_equal(a[key], b[key], equal_nan=True):
+                    bad += 1
+                    print('MISMATCH seq %d n %d magnetic %s %s batch %d frame %d %s plan %s' % (s, n, magnetic, plan, batch, i,
+                                                                                              key, seq.plans[i]))
+                    break
+print('sequences', nseq, 'failures', bad)
+sys.exit(1 if bad else 0)
