@@ -385,6 +385,15 @@ class BaseMapping(object):
         """
         if self._boundingBox is None:
             red = np.array(self._bbox_reduction(), dtype=np.float64)
+            if red[6] > 0:
+                # the extremes come from the outline, as in the reference (mapping.py:699-705): identical to the
+                # device's reduction over all unmasked corners unless the mask has islands besides its biggest
+                # component, which the reference's outline (the biggest contour) leaves out
+                outl = self.outline
+                lo = outl[:, 1]
+                red[0], red[1], red[2], red[3] = outl[:, 0].min(), outl[:, 0].max(), lo.min(), lo.max()
+                red[4] = lo[lo > 0].min() if np.any(lo > 0) else np.inf
+                red[5] = lo[lo <= 0].max() if np.any(lo <= 0) else -np.inf
             if red[6] > 0 and red[7] == 0 and self._pole_possible(red) and self._hull_contains_pole():
                 red[7] = 1
             self._boundingBox = bounding_box_from_reduction(red)

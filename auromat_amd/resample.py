@@ -100,7 +100,7 @@ def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=No
                 pxPerDeg = (pxPerDeg, pxPerDeg)
         res = resample_frame(mapping.frame(), mapping.altitude, mapping.boundingBox, pxPerDeg,
                              mapping.containsDiscontinuity, containsPole, method=method,
-                             outline=None if method == 'mean' else mapping.outline)
+                             outline=mapping.outline if (method != 'mean' or containsPole) else None)
         img = ma.masked_array(res['img'], mask=np.repeat(res['mask'][:, :, None], res['img'].shape[2], 2))
         elevation = ma.masked_invalid(res['mean'][:, :, -1], copy=False) if res['has_elev'] else None
         return mapping.createResampled(res['lat'], res['lon'], res['lat_c'], res['lon_c'], elevation, img)
@@ -329,12 +329,19 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
     lon_wrap = 0
     if containsPole:
         # rotate the pole out of the data by +90 deg about x (reference resample.py:176-201)
-        rla, rlo = _rotate_pole_dev(ctx, fd.lat, fd.lon, altitude, 90)
-        red = ctx.empty((8,))
-        ctx.call('amt_bbox_corners', ptr(rla), ptr(rlo), ptr(fd.corner_mask_tensor()), ptr(fd.center_mask_tensor()),
-                 fd.height, fd.width, ptr(red))
-        r = to_host(red)
-        latMin, latMax, lonMin, lonMax = r[0], r[1], r[2], r[3]
+        if outline is not None:
+            # as the reference: the extent of the rotated outline
+            ola, olo = _rotate_pole_host(np.asarray(outline, dtype=np.float64)[:, 0],
+                                         np.asarray(outline, dtype=np.float64)[:, 1], altitude, 90)
+            latMin, latMax, lonMin, lonMax = ola.min(), ola.max(), olo.min(), olo.max()
+        else:
+            # (no outline at hand — the frame pipeline: all unmasked corners, the same unless the mask has islands)
+            rla, rlo = _rotate_pole_dev(ctx, fd.lat, fd.lon, altitude, 90)
+            red = ctx.empty((8,))
+            ctx.call('amt_bbox_corners', ptr(rla), ptr(rlo), ptr(fd.corner_mask_tensor()),
+                     ptr(fd.center_mask_tensor()), fd.height, fd.width, ptr(red))
+            r = to_host(red)
+            latMin, latMax, lonMin, lonMax = r[0], r[1], r[2], r[3]
         lat_c, lon_c = _rotate_pole_dev(ctx, fd.lat_c, fd.lon_c, altitude, 90)
     elif containsDiscontinuity:
         # rotate longitudes out of the 180 deg discontinuity (reference resample.py:203-218); the outline's

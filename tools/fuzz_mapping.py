@@ -65,9 +65,11 @@ for it in range(rounds):
         bad += 1
         print('POLE', it, 'tilt', tilt, 'spin', spin, 'reference rule', want_pole, 'device', got_pole)
         continue
+    outl1 = O.outline(~corner1)                     # the reference's outline: the biggest contour of the corner mask
+    poly1 = np.transpose([lats[outl1[:, 1], outl1[:, 0]], lons[outl1[:, 1], outl1[:, 0]]])
     if want_pole:
         # the box is degenerate (mapping.py:716-724); resampling rotates the pole away (resample.py:176-201)
-        la_v = lats[~corner1]
+        la_v = poly1[:, 0]
         bb = mm.boundingBox
         bbox = (-90.0, -180.0, float(la_v.max()), 180.0) if la_v.max() < 0 else (float(la_v.min()), -180.0, 90.0, 180.0)
         if (bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast) != bbox:
@@ -76,7 +78,10 @@ for it in range(rounds):
             continue
         disc = False
     else:
-        bbox, disc = O.bbox_of_corners(lats, lons, corner1)
+        plo = poly1[:, 1]
+        disc = bool(plo.max() - plo.min() > 180)
+        bbox = (poly1[:, 0].min(), plo[plo > 0].min() if disc else plo.min(), poly1[:, 0].max(),
+                plo[plo <= 0].max() if disc else plo.max())
         bb = mm.boundingBox
         disc_cases += bool(disc)
         if not np.allclose([bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast], bbox, rtol=0, atol=1e-12) or \
@@ -91,7 +96,7 @@ for it in range(rounds):
         continue                                      # nLat / nLon <= 1: the reference asserts as well
     data = np.dstack((img.astype(np.float64), elev))
     data[center1] = np.nan
-    outline = np.transpose([lats[~corner1], lons[~corner1]])
+    outline = poly1
     want = O.resample_mean(np.where(center1, np.nan, lats_c), np.where(center1, np.nan, lons_c), 110, data, outline, bbox,
                            ppd, disc or want_pole, want_pole)
     wimg, wmask = O.finalize_image(want['data'][..., :3], np.uint8)
@@ -137,8 +142,7 @@ for it in range(rounds):
             print('POLYGON', it, int((got_center != want_center).sum()), want_pole, disc, bool(pbb.containsDiscontinuity))
     # every third round also method='nearest' (traced outline, point-in-polygon mask, grid search)
     if it % 3 == 0:
-        outl = O.outline(~corner1)
-        poly = np.transpose([lats[outl[:, 1], outl[:, 0]], lons[outl[:, 1], outl[:, 0]]])
+        poly = poly1
         try:
             rn = resample(mm, pxPerDeg=ppd, method='nearest')
         except AssertionError:
@@ -154,5 +158,44 @@ for it in range(rounds):
         if int(np.any(np.asarray(rn.img.data)[both] != wn['data'][..., :3][both], axis=-1).sum()) > 2:
             bad += 1
             print('NEAREST VALUES', it, want_pole, disc)
+    # every fourth round: resampleMLatMLT (mapping.py:540-550,1519-1559, resample.py:63-71) against the oracle's steps
+    if it % 4 == 1:
+        from auromat_amd.resample import resampleMLatMLT
+        et = O.date2es(datetime(2012, 1, 25, 9, 26, 55))
+        m_geo_sm = O.mat_geo_to_sm(et)
+
+        def to_sm(la, lo):
+            ok = ~np.isnan(la)
+            x, y, z = O.geodetic_to_ecef(np.deg2rad(np.where(ok, la, 0.0)), np.deg2rad(np.where(ok, lo, 0.0)), 110)
+            ml, mt = O.geo_to_mlat_mlt(np.transpose([x.ravel(), y.ravel(), z.ravel()]), m_geo_sm)
+            sl = O.mlt_to_sm_lon(mt)
+            return np.where(ok, ml.reshape(la.shape), np.nan), np.where(ok, sl.reshape(la.shape), np.nan)
+        sm_la, sm_lo = to_sm(lats, lons)
+        sm_lac, sm_loc = to_sm(lats_c, lons_c)
+        hull_sm = None
+        try:
+            smm = resampleMLatMLT(mm, pxPerDeg=ppd)
+        except AssertionError:
+            continue
+        v_la, v_lo = sm_la[outl1[:, 1], outl1[:, 0]], sm_lo[outl1[:, 1], outl1[:, 0]]      # the outline in SM coordinates
+        span = v_lo.max() - v_lo.min()
+        gap = (v_lo[v_lo > 0].min() - v_lo[v_lo <= 0].max()) if (np.any(v_lo > 0) and np.any(v_lo <= 0)) else 0
+        if span > 180 and not gap > 180:
+            continue                                   # around the SM pole: covered by the geodetic pole cases
+        sdisc = bool(span > 180)
+        sbbox = (v_la.min(), v_lo[v_lo > 0].min() if sdisc else v_lo.min(), v_la.max(),
+                 v_lo[v_lo <= 0].max() if sdisc else v_lo.max())
+        wsm = O.resample_mean(np.where(center1, np.nan, sm_lac), np.where(center1, np.nan, sm_loc), 110, data,
+                              np.transpose([v_la, v_lo]), sbbox, ppd, sdisc, False)
+        simg, smask = O.finalize_image(wsm['data'][..., :3], np.uint8)
+        gmask = ma.getmaskarray(smm.img)[..., 0]
+        if gmask.shape != smask[..., 0].shape or int((gmask != smask[..., 0]).sum()) > 2:
+            bad += 1
+            print('MLATMLT', it, gmask.shape, smask.shape)
+            continue
+        both = ~gmask & ~smask[..., 0]
+        if int((np.asarray(smm.img.data)[both] != simg[both]).sum()) > 6:
+            bad += 1
+            print('MLATMLT VALUES', it)
 print('rounds', rounds, 'pole cases', pole_cases, 'date-line cases', disc_cases, 'failures', bad)
 sys.exit(1 if bad else 0)
