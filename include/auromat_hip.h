@@ -47,6 +47,10 @@ int amt_abi_version(void);
    is active.  own_stream != 0: ignore `stream`, create and own a non-blocking stream instead. */
 int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ctx);
 int amt_ctx_destroy(amt_ctx* ctx);
+/* A context may be moved between streams (the Python host follows torch's current stream): every call enqueues on
+   the stream set at that moment, and the library's internal scratch memory is kept per stream, so work enqueued
+   on different streams through one context may overlap on the GPU.  The context itself is not thread-safe: one
+   host thread at a time. */
 int amt_ctx_set_stream(amt_ctx* ctx, void* stream);
 void* amt_ctx_get_stream(amt_ctx* ctx);
 int amt_ctx_synchronize(amt_ctx* ctx);                 /* synchronises */
