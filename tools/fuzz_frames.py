@@ -1,6 +1,6 @@
 """Differential fuzz: random frame sizes, pointings, times, shells, resolutions, centre modes, thresholds and image
 types — single-pass plan == two-pass plan bit for bit, and the two-pass plan against the oracle (identical masks,
-counts differing in at most 2 cells, exact integer means elsewhere).  usage: fuzz_frames.py [cases] [seed]"""
+counts differing in at most 2 cells, exact integer means elsewhere).  usage: [BIG=5] fuzz_frames.py [cases] [seed]"""
 import os, sys
 from datetime import timedelta
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,8 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = skipped = 0
 for case in range(cases):
-    w, h = int(rng.randint(40, 420)), int(rng.randint(30, 300))
+    big = int(os.environ.get('BIG', '1'))                # BIG=5: frames up to 2100 x 1500
+    w, h = int(rng.randint(40, 420 * big)), int(rng.randint(30, 300 * big))
     pointing = ('iss030', 'iss029')[rng.randint(2)]
     shift = float(rng.choice([0, 0, 20, 45, 80, 95]))
     alt = float(rng.choice([90, 100, 110, 120, 135]))
