@@ -6,8 +6,6 @@ auromat/coordinates/intersection.py; its `_np` / `_ne` twins (intersection.py:58
 are replaced by the kernels behind ``amt_intersect_ellipsoid`` / ``amt_intersects_ellipsoid`` /
 ``amt_intersect_sphere``.
 """
-import ctypes as C
-
 import numpy as np
 
 from .._native import host3

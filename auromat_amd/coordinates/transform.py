@@ -13,7 +13,6 @@ Note that some functions depend on the IGRF model whose parameters are defined i
 """
 from __future__ import division
 
-import ctypes as C
 import math
 from datetime import datetime
 

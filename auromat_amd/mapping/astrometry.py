@@ -13,13 +13,12 @@ from __future__ import division
 import ctypes as C
 
 import numpy as np
-import numpy.ma as ma
 
 from ..coordinates.geodesic import wgs84A, wgs84B
 from ..coordinates.transform import date2es, mat_j2000_to_geo, mat_j2000_to_sm
 from ..coordinates.wcs import fill_wcs_params, pix2world
 from ..frame import FrameData
-from .._native import Context, FrameParams, GeorefOut, ptr, to_host
+from .._native import Context, FrameParams, GeorefOut, ptr
 from .mapping import BaseMapping, GenericMapping, inflatedEarthIntersection
 
 

@@ -12,7 +12,6 @@ work on the device tensors directly and never round-trip through the host.
 from __future__ import division
 
 import copy
-import ctypes as C
 from abc import ABCMeta, abstractmethod
 from collections import namedtuple
 
@@ -25,7 +24,7 @@ from ..coordinates.intersection import ellipsoidLineIntersection, sphereLineInte
 from ..coordinates.transform import (date2es, j2000ToLatLon, j2000ToMLatMLT, mat_geo_to_sm, mltToSmLon,
                                      smToLatLon)
 from ..frame import FrameData
-from .._native import Context, host9, ptr, to_host
+from .._native import host9, ptr, to_host
 
 Size = namedtuple('Size', ['width', 'height'])
 PixelScales = namedtuple('PixelScales', ['width', 'height', 'diagonal'])

@@ -20,8 +20,8 @@ import numpy.ma as ma
 
 from .coordinates.transform import rotation_matrix
 from .coordinates.geodesic import wgs84A, wgs84B
-from .mapping.mapping import (BaseMapping, BoundingBox, MappingCollection, bounding_box_from_reduction,
-                              convertMappingToSM, convertSMMappingToGeo, wrap_at_180)
+from .mapping.mapping import (BaseMapping, MappingCollection, convertMappingToSM, convertSMMappingToGeo,
+                              wrap_at_180)
 from .coordinates.geodesic import angularDistanceOnParallel
 from .util.histogram import make_axis
 from ._native import Context, host9, ptr, to_host
