@@ -39,3 +39,16 @@ timed('centroid (cached outline)', lambda: m.centroid)
 timed("resample_frame method='mean' (two-pass)", lambda: resample_frame(fd, 110, bb, (10, 10), False, False, keep_on_device=True))
 timed("resample_frame method='nearest' 0.1 deg", lambda: resample_frame(fd, 110, bb, (10, 10), False, False, keep_on_device=True, method='nearest', outline=o))
 timed("resample_frame method='nearest' 0.04 deg", lambda: resample_frame(fd, 110, bb, (25, 25), False, False, keep_on_device=True, method='nearest', outline=o))
+
+# class API end to end (device arrays -> masked host arrays of the resampled mapping)
+from auromat_amd.resample import resample
+timed("resample(mapping, pxPerDeg=10) class API, host arrays out", lambda: resample(m, pxPerDeg=10).img, n=3)
+timed("resample(mapping, 10, method='nearest') class API", lambda: resample(m, pxPerDeg=10, method='nearest').img, n=3)
+
+
+def fresh_bbox():
+    m.setDirty()
+    return m.boundingBox
+
+
+timed('boundingBox from scratch (reduction + traced outline)', fresh_bbox)
