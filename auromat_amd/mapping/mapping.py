@@ -393,8 +393,12 @@ class BaseMapping(object):
                 red[0], red[1], red[2], red[3] = outl[:, 0].min(), outl[:, 0].max(), lo.min(), lo.max()
                 red[4] = lo[lo > 0].min() if np.any(lo > 0) else np.inf
                 red[5] = lo[lo <= 0].max() if np.any(lo <= 0) else -np.inf
-            if red[6] > 0 and red[7] == 0 and self._pole_possible(red) and self._hull_contains_pole():
-                red[7] = 1
+            # pole: the reference's rule (does the sampled convex hull of the outline contain or cross a pole,
+            # mapping.py:705-721), asked only when the outline's longitudes go all around.  The device's count of
+            # pixel quads winding around a pole agrees with it except when the pole sits in a hole / masked part
+            # (no pixel sees it) or in an island that is not part of the outline (a pixel sees it, the outline
+            # does not) — tools/fuzz_mapping.py found both.
+            red[7] = 1 if (red[6] > 0 and self._pole_possible(red) and self._hull_contains_pole()) else 0
             self._boundingBox = bounding_box_from_reduction(red)
         return self._boundingBox
 

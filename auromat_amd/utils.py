@@ -136,7 +136,9 @@ def convexHull(points):
     """
     Convex hull spanning the given points, (n,2) -> (m,2), ordered by ``arctan2(dx, dy)`` about the mean of the hull
     vertices as the reference orders them (utils.py:247-276).  Monotone chain instead of the reference's Delaunay
-    triangulation; points lying on a hull edge between two vertices are not part of the result.
+    triangulation; like the boundary of that triangulation it keeps the points that lie ON a hull edge — the pole
+    test samples this hull (mapping.py:705-715), and along the straight sides of a frame those points are what makes
+    the sampled polygon follow the footprint instead of cutting across it with a few long geodesics.
     """
     pts = np.unique(np.asarray(points).reshape(-1, 2), axis=0)
     assert pts.ndim == 2 and pts.shape[1] == 2
@@ -145,7 +147,7 @@ def convexHull(points):
             h = []
             for p in seq:
                 while len(h) >= 2 and ((h[-1][0] - h[-2][0]) * (p[1] - h[-2][1]) -
-                                       (h[-1][1] - h[-2][1]) * (p[0] - h[-2][0])) <= 0:
+                                       (h[-1][1] - h[-2][1]) * (p[0] - h[-2][0])) < 0:
                     h.pop()
                 h.append(p)
             return h
