@@ -37,6 +37,10 @@ from ._native import Context, GeorefOut, PipeResult, ptr, to_host
 NEG_INF = float('-inf')
 
 
+class EmptyFrame(ValueError):
+    """No pixel of the frame is valid (the reference's ValueError of maskedByElevation, mapping.py:858-859)."""
+
+
 class _GridView(object):
     """
     Output grid as laid out by the native driver (amt_grid): sizes, steps and first centres are available
@@ -59,7 +63,7 @@ class _GridView(object):
 
 
 class FramePipeline(object):
-    def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, with_mag=False):
+    def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, with_mag=False, alloc_image=True):
         import torch
         self.ctx = ctx = Context.current(device)
         self.width, self.height = int(width), int(height)
@@ -72,7 +76,11 @@ class FramePipeline(object):
             fd.mlat_c, fd.mlt_c = ctx.empty((h, w)), ctx.empty((h, w))
         fd.bbox = ctx.empty((8,))
         fd.img_dtype = np.dtype(img_dtype)
-        fd.img = ctx.empty((h, w, nchan), torch.uint8 if fd.img_dtype == np.uint8 else torch.int16)
+        self._img_torch_dtype = torch.uint8 if fd.img_dtype == np.uint8 else torch.int16
+        self._img_shape = (h, w, nchan)
+        # alloc_image=False: the caller aliases a device-resident image before the first frame (use_image)
+        fd.img = ctx.empty(self._img_shape, self._img_torch_dtype) if alloc_image else None
+        self._img_own = fd.img
         self.with_mag = with_mag
         self._bbox_host = torch.empty(8, dtype=torch.float64, pin_memory=True)
         self._bbox_event = torch.cuda.Event()
@@ -108,6 +116,11 @@ class FramePipeline(object):
         tensor of the buffer's dtype (uint16 images as their int16 bits) is copied asynchronously on the current
         stream."""
         import torch
+        if self.fd.img is not self._img_own or self._img_own is None:
+            # the buffer aliased a caller's device image (use_image): copy into a buffer of our own
+            if self._img_own is None:
+                self._img_own = self.ctx.empty(self._img_shape, self._img_torch_dtype)
+            self.fd.img = self._img_own
         if isinstance(img, torch.Tensor) and not img.is_cuda and img.is_pinned() and img.dtype == self.fd.img.dtype:
             self.fd.img.copy_(img.reshape(self.fd.img.shape), non_blocking=True)
             return
@@ -119,6 +132,18 @@ class FramePipeline(object):
                 a = a.copy()
             t = torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)     # one H2D copy, no staging
         self.fd.img.copy_(t.reshape(self.fd.img.shape))
+
+    def use_image(self, img):
+        """Use a device-resident image of the buffer's layout ((h, w, c) uint8, or uint16 bits as int16) in place:
+        nothing is copied; the caller keeps the tensor alive and unchanged until the frame's results exist."""
+        assert img.is_cuda and img.dtype == self._img_torch_dtype and img.is_contiguous() and \
+            img.numel() == int(np.prod(self._img_shape)), 'device image of the wrong layout'
+        self.fd.img = img.view(self._img_shape)
+
+    def is_resident_image(self, img):
+        import torch
+        return isinstance(img, torch.Tensor) and img.is_cuda and img.dtype == self._img_torch_dtype and \
+            img.is_contiguous() and img.numel() == int(np.prod(self._img_shape))
 
     # -- single-pass plan (native driver, include/auromat_hip.h amt_pipe_*) ----------------------
     def _pipe(self):
@@ -196,7 +221,7 @@ class FramePipeline(object):
         return fd
 
     @staticmethod
-    def georef_many(pipes, params, altitude, min_elevation, fuse_pxPerDeg, fuse_magnetic=False):
+    def georef_many(pipes, params, altitudes, min_elevation, fuse_pxPerDeg, fuse_magnetic=False):
         """
         The single-pass launch of :meth:`georef` for up to AMT_PIPE_MAX_BATCH pipelines at once (one frame each, coarse
         pre-pass already started): ONE launch of the big kernel covers all frames (amt_pipe_launch_many).
@@ -212,7 +237,9 @@ class FramePipeline(object):
         ii = (C.c_void_p * n)(*[q.fd.img.data_ptr() for q in pipes])
         ctx.check(ctx._lib.amt_pipe_launch_many(handles, n, pp, oo, ii, pipes[0].fd.img_dtype_code, min_elev,
                                                 float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1, mag))
-        for q, p in zip(pipes, params):
+        if not isinstance(altitudes, (list, tuple)):
+            altitudes = [altitudes] * n
+        for q, p, altitude in zip(pipes, params, altitudes):
             q.params, q.altitude, q.min_elevation = p, altitude, min_elevation
             q._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
             q.fd.corner_mask = q.fd.center_mask = None
@@ -233,7 +260,8 @@ class FramePipeline(object):
                 self._pole = pole_in_view(self.params, self.min_elevation)
             red[7] = 1.0 if self._pole else 0.0
         if red[6] == 0:
-            raise ValueError('minElevation=' + str(self.min_elevation) + ' would mask all pixels!')
+            self.last_plan = 'empty'
+            raise EmptyFrame('minElevation=' + str(self.min_elevation) + ' would mask all pixels!')
         return bounding_box_from_reduction(red)
 
     def _reduce_bbox(self, lat, lon):
@@ -310,6 +338,9 @@ class FramePipeline(object):
             sm.lon, sm.lon_c = (fd.mlt - 12) / (24 / 360), (fd.mlt_c - 12) / (24 / 360)
             # corners of centres that pass the elevation threshold, in SM coordinates
             red = self._reduce_bbox(sm.lat, sm.lon)
+            if red[6] == 0:
+                self.last_plan = 'empty'
+                raise EmptyFrame('minElevation=' + str(self.min_elevation) + ' would mask all pixels!')
             bb = bounding_box_from_reduction(red)
             fd = sm
         else:
@@ -367,7 +398,7 @@ class SequencePipeline(object):
 
     def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, altitude=110, fast=True,
                  min_elevation=10.0, pxPerDeg=10, plan='single-pass', bin_stream=True, shared_image=None,
-                 magnetic=False, batch=3):
+                 magnetic=False, batch=3, own_image_buffers=True):
         import torch
         assert plan in ('single-pass', 'two-pass')
         try:
@@ -383,8 +414,11 @@ class SequencePipeline(object):
         # paid once per batch and the end of a launch is better filled: 0.207 -> 0.200 -> 0.198 ms per frame for
         # 1, 2, 3 frames per launch.
         self.batch = max(1, min(int(batch), 3)) if self.single_pass else 1
-        self.pipes = [FramePipeline(width, height, nchan, img_dtype, device, with_mag=self.magnetic)
-                      for _ in range(2 * self.batch)]
+        # own_image_buffers=False: every frame of process() brings a device-resident image that is used in place
+        # (no per-slot image buffer is allocated)
+        self.pipes = [FramePipeline(width, height, nchan, img_dtype, device, with_mag=self.magnetic,
+                                    alloc_image=own_image_buffers and (shared_image is None or i == 0))
+                      for i in range(2 * self.batch)]
         self.ctx = self.pipes[0].ctx
         if shared_image is not None:
             # every frame shows the same image (synthetic benchmarks): upload it once, both buffers alias it
@@ -402,16 +436,20 @@ class SequencePipeline(object):
         # per-frame images: uploaded on a copy stream of their own (created on first use: every extra stream competes
         # for the few hardware queues), so that frame k+1's 72 MB cross PCIe while frame k is being computed
         self.s_copy = None
-        self._img_read = [None for _ in self.pipes]      # the last kernel reading this buffer's image has finished
+        # events after which nothing enqueued so far reads this buffer's image any more: the single-pass launch on
+        # s_main, and the separate binning kernel of a two-pass frame (plan='two-pass', or the per-frame fall-back of
+        # the single-pass plan: pole in view, box misjudged, ...) wherever that runs.  An upload into the buffer waits
+        # for all of them.
+        self._img_busy = [[] for _ in self.pipes]
         self.plans = []                     # plan taken by each frame of the last process() call
         self.use_hints = True               # sequence coherence instead of the coarse pre-pass where possible
         self._hint = None                   # (exact bbox reduction, amt_frame_params) of the latest finished frame
         self.hinted = 0                     # frames of the last process() call that needed no pre-pass
 
     def _prepare(self, k, frame):
-        hdr, cam, t, img = frame
-        p = hdr if not isinstance(hdr, dict) else frame_params(hdr, self.altitude, cam, t, self.fast,
-                                                               magnetic=self.magnetic)
+        hdr, cam, t, img = frame[:4]
+        alt = frame[4] if len(frame) > 4 and frame[4] is not None else self.altitude     # per-frame shell
+        p = hdr if not isinstance(hdr, dict) else frame_params(hdr, alt, cam, t, self.fast, magnetic=self.magnetic)
         if self.single_pass:
             # the superset grid needs an estimate of the frame's bounding box: the exact box of the latest finished
             # frame when this one is its neighbour in the sequence (no kernel at all), else a coarse pre-pass (a
@@ -419,7 +457,7 @@ class SequencePipeline(object):
             hint = self._hint[0] if (self.use_hints and self._hint is not None and _close(self._hint[1], p)) else None
             self.pipes[k % len(self.pipes)].start_coarse(p, self.min_elevation, self.magnetic, hint)
             self.hinted += hint is not None
-        return p, cam, t, img
+        return p, cam, t, img, alt
 
     def _launch(self, k0, prepared):
         """Launch the frames k0, k0+1, ... (one batch; prepared = their _prepare results)."""
@@ -428,32 +466,36 @@ class SequencePipeline(object):
         qs = [self.pipes[(k0 + i) % nb] for i in range(len(prepared))]
         two_streams = self.s_bin is not self.s_main
         with torch.cuda.stream(self.s_main):
-            for i, (q, (p, cam, t, img)) in enumerate(zip(qs, prepared)):
+            for i, (q, (p, cam, t, img, alt)) in enumerate(zip(qs, prepared)):
                 slot = (k0 + i) % nb
                 if two_streams and self._bin_done[slot] is not None:
                     self.s_main.wait_event(self._bin_done[slot])     # the buffer's previous frame is still being binned
-                if img is not None:
-                    if self.s_copy is None:
-                        self.s_copy = torch.cuda.Stream(device=self.ctx.device)
-                    with torch.cuda.stream(self.s_copy):
-                        busy = self._bin_done[slot] if two_streams else self._img_read[slot]
-                        if busy is not None:
-                            self.s_copy.wait_event(busy)             # the buffer's previous image is still being read
-                        q.set_image(img)
-                        uploaded = torch.cuda.Event()
-                        uploaded.record(self.s_copy)
-                    self.s_main.wait_event(uploaded)
+                if img is None:
+                    continue
+                if q.is_resident_image(img):
+                    q.use_image(img)                                 # in place: nothing is overwritten
+                    self._img_busy[slot] = []
+                    continue
+                if self.s_copy is None:
+                    self.s_copy = torch.cuda.Stream(device=self.ctx.device)
+                with torch.cuda.stream(self.s_copy):
+                    for busy in self._img_busy[slot]:
+                        self.s_copy.wait_event(busy)                 # the buffer's previous image is still being read
+                    self._img_busy[slot] = []
+                    q.set_image(img)
+                    uploaded = torch.cuda.Event()
+                    uploaded.record(self.s_copy)
+                self.s_main.wait_event(uploaded)
             if self.single_pass:
-                FramePipeline.georef_many(qs, [pr[0] for pr in prepared], self.altitude, self.min_elevation,
-                                          self.pxPerDeg, self.magnetic)
-                if self.s_copy is not None:
-                    done = torch.cuda.Event()
-                    done.record(self.s_main)
-                    for i in range(len(prepared)):
-                        self._img_read[(k0 + i) % nb] = done
+                FramePipeline.georef_many(qs, [pr[0] for pr in prepared], [pr[4] for pr in prepared],
+                                          self.min_elevation, self.pxPerDeg, self.magnetic)
+                done = torch.cuda.Event()
+                done.record(self.s_main)
+                for i in range(len(prepared)):
+                    self._img_busy[(k0 + i) % nb].append(done)
             else:
-                for i, (q, (p, cam, t, img)) in enumerate(zip(qs, prepared)):
-                    q.georef(None, self.altitude, cam, t, self.fast, self.min_elevation, params=p)
+                for i, (q, (p, cam, t, img, alt)) in enumerate(zip(qs, prepared)):
+                    q.georef(None, alt, cam, t, self.fast, self.min_elevation, params=p)
                     if two_streams:
                         self._geo_done[(k0 + i) % nb].record(self.s_main)
 
@@ -465,10 +507,22 @@ class SequencePipeline(object):
         with torch.cuda.stream(self.s_bin):
             if two_streams:
                 self.s_bin.wait_event(self._geo_done[slot])
-            res = q.resample(self.pxPerDeg, magnetic=self.magnetic, keep_on_device=keep_on_device)
-            if two_streams:
-                self._bin_done[slot] = torch.cuda.Event()
-                self._bin_done[slot].record(self.s_bin)
+            try:
+                res = q.resample(self.pxPerDeg, magnetic=self.magnetic, keep_on_device=keep_on_device)
+            except EmptyFrame:
+                # no pixel of this frame is valid (looking off the limb, or min_elevation masks everything; the
+                # reference raises ValueError there, mapping.py:858-859): the sequence goes on, the frame's place in
+                # the results holds None
+                res = None
+            if res is not None:
+                res['magnetic'] = self.magnetic
+            if q.last_plan == 'two-pass':
+                # the separate binning kernel reads the buffer's image (and coordinate arrays) on this stream
+                ev = torch.cuda.Event()
+                ev.record(self.s_bin)
+                self._img_busy[slot].append(ev)
+                if two_streams:
+                    self._bin_done[slot] = ev
         self.plans.append(q.last_plan)
         if q.last_plan == 'single-pass':
             self._hint = (list(q._fused['result'].bbox), q.params)
@@ -478,9 +532,13 @@ class SequencePipeline(object):
 
     def process(self, frames, keep_on_device=True):
         """
-        frames: iterable of (wcsHeader | amt_frame_params, cameraPosGCRS, photoTime, image | None).
+        frames: iterable of (wcsHeader | amt_frame_params, cameraPosGCRS, photoTime, image | None[, altitude]);
+        a fifth element overrides the pipeline's altitude for that frame (several shells in one sequence).
+        An image can be a host array, a pinned host tensor of the buffer's dtype (uploaded asynchronously on a copy
+        stream) or a device tensor of the buffer's layout, which is used in place.
         Returns the list of per-frame result dicts (see :func:`auromat_amd.resample.resample_frame`) in order;
-        with keep_on_device the arrays are device tensors that are valid for work on the current stream.
+        with keep_on_device the arrays are device tensors that are valid for work on the current stream.  A frame
+        without any valid pixel yields None (the reference raises ValueError for it, mapping.py:858-859).
         """
         import torch
         del self.plans[:]
@@ -529,7 +587,7 @@ class SequencePipeline(object):
             # the result tensors were allocated on the pipeline's streams: tell the caching allocator that the caller's
             # stream uses them too, so that their memory is not handed out again while the caller still reads it
             for res in out:
-                for v in res.values():
+                for v in (res or {}).values():
                     if isinstance(v, torch.Tensor) and v.is_cuda:
                         v.record_stream(cur)
         return out

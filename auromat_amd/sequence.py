@@ -19,7 +19,12 @@ def shard(n_frames, rank, world_size):
     return list(range(start, start + base + (1 if rank < extra else 0)))
 
 
-DESC_LEN = 8   # ny, nx, nchan+1, lat of first row centre, lon of first column centre, dlat, dlon, frame index
+# ny, nx, nchan+1, lat of first row centre, lon of first column centre, dlat, dlon, frame index,
+# contains_pole, contains_discontinuity, altitude [km], magnetic.  The grid of a frame that straddles the 180 deg
+# discontinuity is laid out for longitudes shifted by 180 deg and that of a pole frame for coordinates rotated by
+# +90 deg about x at `altitude` (reference resample.py:176-218, 262-277): with the two flags (and the altitude) the
+# receiver can undo either, see :func:`frame_coordinates`.  ny == 0 marks a frame without any valid pixel.
+DESC_LEN = 12
 
 
 def pack_results(results, indices, device):
@@ -32,32 +37,63 @@ def pack_results(results, indices, device):
     descs = np.zeros((len(results), DESC_LEN), dtype=np.float64)
     parts = []
     for i, (res, idx) in enumerate(zip(results, indices)):
+        if res is None:
+            # no valid pixel in this frame (maskedByElevation would raise ValueError, reference mapping.py:858-859)
+            descs[i, 7] = idx
+            continue
         mean, count = res['mean'], res['count']
         if not isinstance(mean, torch.Tensor):
             mean, count = torch.from_numpy(np.ascontiguousarray(mean)), torch.from_numpy(np.ascontiguousarray(count))
         ny, nx, nc = mean.shape
         g = res['grid']
-        descs[i] = [ny, nx, nc, g.lat0, g.lon0, g.latStep, g.lonStep, idx]
+        descs[i] = [ny, nx, nc, g.lat0, g.lon0, g.latStep, g.lonStep, idx,
+                    1.0 if res.get('contains_pole') else 0.0, 1.0 if res.get('contains_discontinuity') else 0.0,
+                    float(res.get('altitude') or 0.0), 1.0 if res.get('magnetic') else 0.0]
         parts += [mean.reshape(-1).to(device), count.reshape(-1).to(device)]
     payload = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.float64, device=device)
     return torch.from_numpy(descs).to(device), payload
 
 
-def unpack_results(descs, payload):
-    """Inverse of :func:`pack_results` on host tensors -> list of dict(index, mean, count, lat0, lon0, dlat, dlon)."""
+def unpack_results(descs, payload, failed=None):
+    """Inverse of :func:`pack_results` on host tensors -> list of dict(index, mean, count, lat0, lon0, dlat, dlon,
+    contains_pole, contains_discontinuity, altitude, magnetic).  Frames without a valid pixel are left out; their
+    indices are appended to `failed` when a list is given."""
     out, off = [], 0
     descs = descs.cpu().numpy()
     payload = payload.cpu().numpy()
     for d in descs:
         ny, nx, nc = int(d[0]), int(d[1]), int(d[2])
         if ny == 0:
+            if failed is not None:
+                failed.append(int(d[7]))
             continue
         n_mean, n_cnt = ny * nx * nc, ny * nx
         mean = payload[off:off + n_mean].reshape(ny, nx, nc)
         count = payload[off + n_mean:off + n_mean + n_cnt].reshape(ny, nx)
         off += n_mean + n_cnt
-        out.append(dict(index=int(d[7]), mean=mean, count=count, lat0=d[3], lon0=d[4], dlat=d[5], dlon=d[6]))
+        out.append(dict(index=int(d[7]), mean=mean, count=count, lat0=d[3], lon0=d[4], dlat=d[5], dlon=d[6],
+                        contains_pole=bool(d[8]), contains_discontinuity=bool(d[9]), altitude=float(d[10]),
+                        magnetic=bool(d[11])))
     return out
+
+
+def frame_coordinates(frame):
+    """
+    True cell-centre coordinates (lat_c, lon_c), each (ny, nx), of one unpacked frame: geodetic degrees, or (MLat,
+    SM longitude) for a `magnetic` frame.  Undoes the 180 deg shift of a date-line frame and the pole rotation of a
+    pole frame exactly as the reference does after binning (resample.py:262-277).
+    """
+    from .resample import _rotate_pole_host
+    from .mapping.mapping import wrap_at_180
+    ny, nx = frame['count'].shape
+    lat = frame['lat0'] + frame['dlat'] * np.arange(ny)
+    lon = frame['lon0'] + frame['dlon'] * np.arange(nx)
+    lon_c, lat_c = np.meshgrid(lon, lat)
+    if frame['contains_pole']:
+        lat_c, lon_c = _rotate_pole_host(lat_c, lon_c, frame['altitude'], -90)
+    elif frame['contains_discontinuity']:
+        lon_c = wrap_at_180(lon_c - 180)
+    return lat_c, lon_c
 
 
 class Gathered(object):
@@ -68,6 +104,7 @@ class Gathered(object):
 
     def __init__(self, bufs, sizes, max_frames):
         self.bufs, self.sizes, self.max_frames = bufs, sizes, max_frames
+        self.failed = []            # indices of the frames without any valid pixel (filled by unpack)
 
     @property
     def n_frames(self):
@@ -79,7 +116,8 @@ class Gathered(object):
             nf, npay = int(self.sizes[r, 0]), int(self.sizes[r, 1])
             d = buf[:nf * DESC_LEN].reshape(nf, DESC_LEN)
             p = buf[self.max_frames * DESC_LEN:self.max_frames * DESC_LEN + npay]
-            out += unpack_results(d, p)
+            out += unpack_results(d, p, self.failed)
+        self.failed.sort()
         return sorted(out, key=lambda f: f['index'])
 
 
@@ -118,11 +156,12 @@ def gather_results(results, indices, device, dst=0, group=None):
 
 
 def run_sequence(frames, width, height, altitude=110, fast=True, min_elevation=10.0, pxPerDeg=10,
-                 magnetic=False, gather=True, device=None):
+                 magnetic=False, gather=True, device=None, return_failed=False):
     """
     Process this rank's share of `frames` — a list of (wcsHeader, cameraPosGCRS, photoTime, image)
     tuples, identical on every rank — and gather the grids on rank 0.  Works without an initialised
-    process group (single GPU).
+    process group (single GPU).  Frames without any valid pixel (the reference raises ValueError for them,
+    mapping.py:858-859) are left out of the list; with `return_failed` the result is (list, their indices).
     """
     import torch.distributed as dist
     from .pipeline import SequencePipeline
@@ -137,7 +176,16 @@ def run_sequence(frames, width, height, altitude=110, fast=True, min_elevation=1
                            magnetic=magnetic)
     results = seq.process([frames[k] for k in mine])
     dev = seq.ctx.device
+    # every rank takes part in the collectives whatever its frames did: a frame without a valid pixel travels as
+    # an empty descriptor and is reported in `failed`, it does not raise on one rank while the others wait
+    failed = []
     if not distributed or not gather:
         descs, payload = pack_results(results, mine, dev)
-        return unpack_results(descs, payload)
-    return gather_results(results, mine, dev)
+        out = unpack_results(descs, payload, failed)
+    else:
+        g = gather_device(results, mine, dev)
+        out = g.unpack() if g is not None else None
+        failed = g.failed if g is not None else failed
+    if return_failed:
+        return out, failed
+    return out

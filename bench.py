@@ -2,20 +2,27 @@
 """
 bench.py — georef + resample throughput on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+With N > 1 and no WORLD_SIZE in the environment this process touches no GPU: it starts
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py`` as a child,
+passes rank 0's JSON line through and exits with the child's code.  Under torch.distributed.run (the driver's own
+launch form) every rank runs :func:`main` directly.
 
 One step = one synthetic 4240x2832 ISS-like frame through the whole hot path on one GPU:
 fused georeferencing (WCS -> ray -> inflated-WGS84 hit -> geodetic lat/lon of corners and centres,
 elevation), maskedByElevation(10), bounding box, 0.1 deg plate-carree grid, binned mean of the
-uint16 RGB image + elevation (BASELINE.json configs[2]; configs[1] is its first kernel).  The image
-is resident in HBM before the timed region; per-frame host set-up (matrices, grid) is inside it.
-With N > 1 every rank processes its own frames (weak scaling) and the per-frame grids are gathered
-on rank 0 over RCCL inside the timed region.  Prints ONE JSON line on rank 0.
+uint16 RGB image + elevation (BASELINE.json configs[2]; configs[1] is its first kernel).  Every frame has its OWN
+image, resident in HBM before the timed region (pointing, time, camera and image differ frame by
+frame); per-frame host set-up (matrices, grid) is inside the timed region.  With N > 1 every rank processes K frames
+of its own (weak scaling; K defaults to 32 so that N = 8 is the 256 frames of configs[4]) and the per-frame grids are
+gathered on rank 0 over RCCL inside the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,8 +34,10 @@ if ROOT not in sys.path:
 
 WIDTH, HEIGHT = 4240, 2832
 ALTITUDE, MIN_ELEV, PPD = 110, 10.0, 10
+SHELLS = (100, 110, 120)  # configs[3]
 TIMING_EVERY = 1        # events ride on the dispatch packets (hipExtLaunchKernelGGL): every launch is timed
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+MAX_RESIDENT_IMAGES = 96   # distinct images kept in HBM (72 MB each); longer runs cycle through them
 
 
 def algorithmic_bytes(width, height, nchan=3, pix_bytes=2):
@@ -38,9 +47,113 @@ def algorithmic_bytes(width, height, nchan=3, pix_bytes=2):
                 mag=16 * nc + 16 * npx,                  # mlat, mlt corners + mlat_c, mlt_c centres written
                 georef=16 * nc + 24 * npx,              # WCS-fused: lat, lon corners + latC, lonC, elev written
                 georef_dirs_in=40 * nc + 24 * npx,      # + 24 B/corner direction read (contract row "directions-in")
-                resample=(24 + nchan * pix_bytes) * npx)
+                resample=(24 + nchan * pix_bytes) * npx,
+                # SURVEY 8d "MLat/MLT + resample per shell": 40 Nc + 54 Np
+                mag_shell=40 * nc + 54 * npx)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None, help='frames per rank in the timed region (default 50; 32 with --gpus > 1)')
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--cpu-rows', type=int, default=2832, help='rows of the frame the CPU baseline processes (0 = skip)')
+    ap.add_argument('--exact', action='store_true', help='exact centre rays instead of fast centres')
+    ap.add_argument('--magnetic', action='store_true',
+                    help='configs[3] instead of configs[2]: MLat/MLT outputs and the (MLat, SM longitude) grid of '
+                         'resampleMLatMLT; the three altitude shells 100/110/120 km alternate frame by frame')
+    ap.add_argument('--plan', default='fused', choices=('fused', 'two-pass'),
+                    help='fused: binning inside the georeferencing kernel (superset grid + crop); '
+                         'two-pass: separate binning kernel that re-reads the centre arrays')
+    ap.add_argument('--no-hints', action='store_true',
+                    help='run the coarse bounding-box pre-pass for every frame instead of re-using the previous exact box')
+    ap.add_argument('--batch', type=int, default=3, choices=(1, 2, 3),
+                    help='frames per launch of the big kernel in the fused plan (amt_pipe_launch_many)')
+    ap.add_argument('--upload', action='store_true',
+                    help='PCIe-inclusive variant (never the headline value): every frame brings its own image from '
+                         'pinned host memory, uploaded on a copy stream beside the previous frames\' kernels')
+    ap.add_argument('--shared-image', action='store_true',
+                    help='round-1 conditions: one resident image shared by all frames (A/B only)')
+    ap.add_argument('--streams', type=int, default=2, choices=(1, 2),
+                    help='2: bin frame k beside the ray casting of frame k+1 on a second HIP stream (two-pass plan)')
+    ap.add_argument('--no-variants', action='store_true',
+                    help='skip the short extra runs (exact centres, configs[3]) whose figures the JSON line carries as '
+                         '"variants" (they run on rank 0 at N = 1 only, after the timed region)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / reporting path only: gloo on the CPU, no GPU, a step is a sleep (tests)')
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 32 if args.gpus > 1 else 50
+    return args
+
+
+# ------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher
+# ------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_children(argv):
+    """
+    Start the N ranks as a child `python -m torch.distributed.run` (this process has made no GPU call and makes none),
+    hand rank 0's JSON line on and return the child's exit code (non-zero when any rank failed: the launcher tears the
+    others down).
+    """
+    args = parse_args(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, universal_newlines=True)
+    line = None
+    for out in child.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)       # banners of libraries and the launcher: not on our stdout
+    rc = child.wait()
+    if rc != 0:
+        sys.stderr.write('bench.py: the %d-rank child run failed with exit code %d\n' % (args.gpus, rc))
+        return rc
+    if line is None:
+        sys.stderr.write('bench.py: the child run printed no result line\n')
+        return 1
+    print(line)
+    sys.stdout.flush()
+    return 0
+
+
+def dry_run(args, world, rank):
+    """The reporting path without a GPU (gloo): barrier, K sleeps as steps, max over ranks, one JSON line."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    if os.environ.get('AMT_BENCH_DRYRUN_FAIL_RANK') == str(rank):
+        raise SystemExit(3)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'metric': 'dry run (no GPU work)', 'value': world * args.steps / elapsed, 'unit': 'steps/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'dry_run': True}))
+        sys.stdout.flush()
+
+
+# ------------------------------------------------------------------------------------------------------------
 def measured_copy_gbs(device):
     """Device-to-device copy rate (read + write bytes per second) of this GPU, for reading the roofline fraction
     against something achievable beside the 8 TB/s spec figure.  Outside the timed region."""
@@ -55,6 +168,17 @@ def measured_copy_gbs(device):
         b.copy_(a)
     torch.cuda.synchronize()
     return 10 * 2 * n * 8 / (time.perf_counter() - t0) / 1e9
+
+
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as fp:
+            for ln in fp:
+                if ln.startswith('model name'):
+                    return ln.split(':', 1)[1].strip()
+    except IOError:
+        pass
+    return 'unknown'
 
 
 def cpu_baseline(sample_rows, frames=4):
@@ -84,45 +208,77 @@ def cpu_baseline(sample_rows, frames=4):
         t_res += t2 - t1
         del g, data
     npx = WIDTH * sample_rows * frames
-    return dict(value=npx / 1e6 / (t_geo + t_res), unit='Mpixels/s', cores=1, kind='port',
+    return dict(value=npx / 1e6 / (t_geo + t_res), unit='Mpixels/s', cores=1, kind='port', cpu=cpu_model(),
+                host_cores=os.cpu_count(),
                 sample='%d frames of the sequence, rows 0..%d of %dx%d each (%.1f Mpx): georef %.1f s + mask/resample '
-                       '%.1f s, NumPy, 1 thread' % (frames, sample_rows, WIDTH, HEIGHT, npx / 1e6, t_geo, t_res))
+                       '%.1f s, NumPy, 1 thread (the reference is single-threaded NumPy; one process per frame would '
+                       'scale it by the core count at best)' % (frames, sample_rows, WIDTH, HEIGHT, npx / 1e6, t_geo, t_res))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--cpu-rows', type=int, default=2832, help='rows of the frame the CPU baseline processes (0 = skip)')
-    ap.add_argument('--exact', action='store_true', help='exact centre rays instead of fast centres')
-    ap.add_argument('--magnetic', action='store_true',
-                    help='configs[3] instead of configs[2]: MLat/MLT outputs and the (MLat, SM longitude) grid of '
-                         'resampleMLatMLT; the three altitude shells 100/110/120 km alternate frame by frame')
-    ap.add_argument('--plan', default='fused', choices=('fused', 'two-pass'),
-                    help='fused: binning inside the georeferencing kernel (superset grid + crop); '
-                         'two-pass: separate binning kernel that re-reads the centre arrays')
-    ap.add_argument('--no-hints', action='store_true',
-                    help='run the coarse bounding-box pre-pass for every frame instead of re-using the previous exact box')
-    ap.add_argument('--batch', type=int, default=3, choices=(1, 2, 3),
-                    help='frames per launch of the big kernel in the fused plan (amt_pipe_launch_many)')
-    ap.add_argument('--upload', action='store_true',
-                    help='PCIe-inclusive variant (never the headline value): every frame brings its own image from '
-                         'pinned host memory, uploaded on a copy stream beside the previous frames\' kernels')
-    ap.add_argument('--streams', type=int, default=2, choices=(1, 2),
-                    help='2: bin frame k beside the ray casting of frame k+1 on a second HIP stream')
-    args = ap.parse_args()
-
+def resident_images(device, n, first_seed):
+    """n distinct uint16 RGB images (bits as int16, the frame buffers' layout) generated in HBM, seeded per frame."""
     import torch
-    import torch.distributed as dist
+    out = []
+    for k in range(n):
+        g = torch.Generator(device=device)
+        g.manual_seed(1000003 * (first_seed + k) + 17)
+        out.append(torch.randint(0, 65535, (HEIGHT, WIDTH, 3), generator=g, device=device, dtype=torch.int32)
+                   .to(torch.int16))
+    return out
+
+
+def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_hints, shared_image, own_buffers,
+              fence, after=None):
+    """
+    W untimed + K timed frames through a fresh SequencePipeline.  Returns dict(elapsed, georef_ms, bin_ms, plans,
+    hinted, seq, results, extra) — georef_ms / bin_ms are per FRAME, from HIP events on the dispatch packets.
+    `after(results)` runs inside the timed region (the gather of the N > 1 runs).
+    """
+    from auromat_amd.pipeline import SequencePipeline
+    seq = SequencePipeline(WIDTH, HEIGHT, altitude=ALTITUDE, fast=fast, min_elevation=MIN_ELEV, pxPerDeg=PPD,
+                           plan='single-pass' if plan == 'fused' else 'two-pass', bin_stream=streams == 2,
+                           shared_image=shared_image, magnetic=magnetic, batch=batch, own_image_buffers=own_buffers)
+    seq.use_hints = use_hints
+    ctx = seq.ctx
+    warm = seq.process(frames[:warmup])
+    if after is not None and warm:
+        after(warm, True)
+    del warm
+    ctx.timing_enable(TIMING_EVERY)
+    fence()
+    t0 = time.perf_counter()
+    results = seq.process(frames[warmup:warmup + steps])
+    plans, hinted = list(seq.plans), seq.hinted
+    extra = after(results, False) if after is not None else None
+    fence()
+    elapsed = time.perf_counter() - t0
+    g_total, g_n = ctx.timing_read(0)
+    b_total, b_n = ctx.timing_read(1)
+    ctx.timing_enable(False)
+    n_timed = (steps + TIMING_EVERY - 1) // TIMING_EVERY
+    assert g_n == n_timed and b_n in (0, n_timed), (g_n, b_n)
+    return dict(elapsed=elapsed, georef_ms=g_total / g_n, bin_ms=(b_total / b_n if b_n else 0.0), plans=plans,
+                hinted=hinted, seq=seq, results=results, extra=extra)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_children(argv))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
     if rank != 0:
         # only rank 0 reports; libraries that write to stdout (RCCL prints a version banner with C stdio) must not
         # interleave with its JSON line in the launcher's merged output
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    if args.dry_run:
+        return dry_run(args, world, rank)
+
+    import torch
+    import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     # AMT_BENCH_FORCE_DIST=1 exercises the RCCL gather path with a single rank (boxes with one GPU)
     use_dist = world > 1 or bool(os.environ.get('AMT_BENCH_FORCE_DIST'))
@@ -131,45 +287,32 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29541')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
-    from auromat_amd.pipeline import SequencePipeline
+    from auromat_amd._native import Context
     from auromat_amd.sequence import gather_device
     from auromat_amd.synthetic import sequence_frame, frame_image
 
-    # The product's own sequence loop (auromat_amd/pipeline.py): two frame buffers, frame k+1 is georeferenced
-    # while the host finishes frame k and prepares frame k+2.  plan=fused: binning inside the georeferencing
-    # kernel via the native frame driver; plan=two-pass: separate binning kernel, on a second HIP stream beside
-    # the next frame's ray casting when --streams 2.
+    ctx = Context.current()
+    device = ctx.device
     fast = not args.exact
     total = args.warmup + args.steps
-    fused = args.plan == 'fused'
-    seq = SequencePipeline(WIDTH, HEIGHT, altitude=ALTITUDE, fast=fast, min_elevation=MIN_ELEV, pxPerDeg=PPD,
-                           plan='single-pass' if fused else 'two-pass', bin_stream=args.streams == 2,
-                           # resident before the timed region (unless --upload brings one per frame)
-                           shared_image=None if args.upload else frame_image(WIDTH, HEIGHT, seed=rank),
-                           magnetic=args.magnetic, batch=args.batch)
-    seq.use_hints = not args.no_hints
-    ctx = seq.ctx
-    # the synthetic sequence (what a reader would hand over: WCS cards, camera position, time) exists before the
-    # timed region, like the image; everything derived from it (matrices, grids) is computed inside
-    frames = [sequence_frame(rank * total + k, WIDTH, HEIGHT)[:3] + (None,) for k in range(total)]
+    first = rank * total                    # this rank's block of the synthetic sequence
+    # the synthetic sequence (what a reader would hand over: WCS cards, camera position, time, image) exists before
+    # the timed region; everything derived from it (matrices, grids) is computed inside
+    shared = frame_image(WIDTH, HEIGHT, seed=rank) if args.shared_image else None
     if args.upload:
         # four distinct images in pinned host memory (uint16 bits as int16, the frame buffer's layout), cycled
-        host_imgs = [torch.from_numpy(frame_image(WIDTH, HEIGHT, seed=100 + i).view(np.int16)).pin_memory()
-                     for i in range(4)]
-        frames = [f[:3] + (host_imgs[k % 4],) for k, f in enumerate(frames)]
-    if args.magnetic:
-        # per-frame shells: the matrices are made here (outside the timed region only in this variant, because the
-        # sequence loop takes one altitude); 100 / 110 / 120 km alternate
-        from auromat_amd.mapping.astrometry import frame_params
-        frames = [(frame_params(h, (100, 110, 120)[k % 3], c, t, fast, magnetic=True), c, t, im)
-                  for k, (h, c, t, im) in enumerate(frames)]
+        imgs = [torch.from_numpy(frame_image(WIDTH, HEIGHT, seed=100 + i).view(np.int16)).pin_memory() for i in range(4)]
+    elif shared is None:
+        imgs = resident_images(device, min(total, MAX_RESIDENT_IMAGES), first)
+    else:
+        imgs = [None]
 
-    warm = seq.process(frames[:args.warmup])
-    if use_dist and warm:
-        # first-call costs of the gather path (RCCL channels, torch.cat, allocations) belong to the warm-up as well
-        gather_device(warm, [rank * total + k for k in range(len(warm))], ctx.device)
-    del warm
-    ctx.timing_enable(TIMING_EVERY)
+    def make_frames(n, magnetic):
+        fr = []
+        for k in range(n):
+            hdr, cam, t, _ = sequence_frame(first + k, WIDTH, HEIGHT)
+            fr.append((hdr, cam, t, imgs[k % len(imgs)], SHELLS[k % 3] if magnetic else None))
+        return fr
 
     def fence():
         torch.cuda.synchronize()
@@ -177,36 +320,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    results = seq.process(frames[args.warmup:])
-    plans = list(seq.plans)
-    hinted = seq.hinted
-    gathered = None
+    def gather(results, warm):
+        # device-to-device over xGMI; rank 0 unpacks to the host after the timed region.  The first call's costs
+        # (RCCL channels, allocations) belong to the warm-up.
+        if not use_dist:
+            return None
+        base = first + (0 if warm else args.warmup)
+        return gather_device(results, [base + k for k in range(len(results))], device)
+
+    run = timed_run(make_frames(total, args.magnetic), args.warmup, args.steps, fast, args.plan, args.magnetic,
+                    args.batch, args.streams, not args.no_hints, shared, own_buffers=args.upload, fence=fence,
+                    after=gather)
+    elapsed = run['elapsed']
     if use_dist:
-        # device-to-device over xGMI; rank 0 unpacks to the host after the timed region
-        gathered = gather_device(results, [rank * total + args.warmup + k for k in range(args.steps)], ctx.device)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         if rank == 0:
+            gathered = run['extra']
             assert gathered.n_frames == world * args.steps and len(gathered.unpack()) == world * args.steps
 
-    # kernel durations measured live over the timed region: HIP events recorded by the library directly
-    # around each k_georef_rows / k_bin_frame launch, on the stream they run on
-    g_total, g_n = ctx.timing_read(0)
-    b_total, b_n = ctx.timing_read(1)
-    n_timed = (args.steps + TIMING_EVERY - 1) // TIMING_EVERY
-    assert g_n == n_timed and b_n in (0, n_timed), (g_n, b_n)
-    georef_ms, bin_ms = g_total / g_n, (b_total / b_n if b_n else 0.0)
-    ctx.timing_enable(False)
-
     if rank == 0:
+        fused = args.plan == 'fused'
+        seq, results, plans = run['seq'], run['results'], run['plans']
+        georef_ms, bin_ms = run['georef_ms'], run['bin_ms']
         npx = WIDTH * HEIGHT
-        copy_gbs = measured_copy_gbs(ctx.device)
+        copy_gbs = measured_copy_gbs(device)
         ab = algorithmic_bytes(WIDTH, HEIGHT)
         info = ctx.device_info()
         res = results[-1]
@@ -233,9 +372,10 @@ def main():
             kbytes = moved = ab['georef']
         if args.magnetic:
             moved += ab['mag']           # this variant writes MLat/MLT beside lat/lon (more than the contract counts)
-            tkey += '_mag'               # profiles/r1/k_pmc_summary_magnetic.txt
+            tkey += '_mag'
         achieved = kbytes / (georef_ms * 1e-3) / 1e9
         fpl = seq.batch if fused else 1
+        tr = traffic.get(tkey, {})
         out = {
             'metric': 'Mpixels/s georef+resample, 4240x2832 frame',
             'value': world * args.steps * npx / 1e6 / elapsed,
@@ -243,31 +383,41 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic' + (', image of every frame uploaded from pinned host memory' if args.upload else ''),
+            'dtype': 'f64',
+            'data': 'synthetic; ' + ('image of every frame uploaded from pinned host memory' if args.upload else
+                                     'one image shared by all frames, resident in HBM' if shared is not None else
+                                     'a distinct image per frame (%d resident in HBM before the timed region)' % len(imgs)),
             'config': {'workload': ('configs[3]: as configs[2] on shells 100/110/120 km + MLat/MLT of corners and centres, '
                                     'mean-resample on the 0.1 deg (MLat, SM longitude) grid (resampleMLatMLT)'
                                     if args.magnetic else
                                     'configs[2]: 4240x2832 ISS-like frame, WCS ray cast + WGS84(+110 km) '
                                     'intersection + geodetic transform + elevation (%s centres), '
                                     'maskedByElevation(10), mean-resample to 0.1 deg plate-carree, uint16 RGB'
-                                    % ('fast' if fast else 'exact')),
+                                    % ('fast' if fast else 'exact')) +
+                                   ('; configs[4] when n_gpus = 8 and steps = 32: 256 frames sharded over 8 GPUs, grids '
+                                    'gathered on rank 0' if world > 1 else ''),
                        'frame': [WIDTH, HEIGHT], 'px_per_deg': PPD, 'grid': list(res['mean'].shape),
-                       'plan': args.plan, 'frames_per_launch': seq.batch, 'frames_without_prepass': hinted,
+                       'plan': args.plan, 'frames_per_launch': seq.batch, 'frames_without_prepass': run['hinted'],
                        'single_pass_frames': sum(1 for q in plans if q == 'single-pass'),
+                       'frames_total': world * args.steps,
                        'parallelism': 'frames sharded over %d GPU(s), RCCL gather of grids' % world,
                        'device': info['name']},
-            # dominant kernel.  It is FP64-VALU bound (about 400 VALU instructions per pixel row and lane, see
-            # DESIGN.md and profiles/), so the HBM fraction understates how busy the chip is.
+            # dominant kernel.  It is FP64-VALU bound (see DESIGN.md and profiles/), so the HBM fraction understates
+            # how busy the chip is.
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'measured_copy_GBs': copy_gbs, 'fp64_vector_peak_TFLOPs': 78.6,
                          # one launch covers `frames_per_launch` frames: bytes, traffic and duration are per launch
                          'frames_per_launch': fpl,
-                         'traffic': (traffic.get(tkey, {}).get('hbm_bytes') or 0) * fpl or None,
+                         # NOT measured in this run: PMC counters of an earlier rocprofv3 pass of the same kernel
+                         'traffic': (tr.get('hbm_bytes') or 0) * fpl or None,
+                         'traffic_source': 'profiles/traffic.json (%s), per frame x frames_per_launch'
+                                           % tr.get('source', 'rocprofv3 --pmc pass, see its _comment'),
                          'algorithmic_bytes': kbytes * fpl, 'ms_per_launch': georef_ms * fpl,
                          # the bytes this kernel has to move at the very least, and the same fraction on that basis
                          'bytes_moved_min': moved * fpl, 'frac_bytes_moved_min': frac(moved, georef_ms),
-                         'frames_timed': g_n, 'valu_busy': traffic.get(tkey, {}).get('valu_busy')},
+                         'frames_timed': args.steps, 'valu_busy': tr.get('valu_busy'),
+                         'valu_busy_source': 'profiles/traffic.json'},
             'kernels': {
                 'k_georef_rows': {'ms': georef_ms, 'algorithmic_bytes': kbytes, 'frac_hbm_peak': frac(kbytes, georef_ms),
                                   'bytes_moved_min': moved},
@@ -280,6 +430,29 @@ def main():
                 'pipeline_frac_directions_in_1129.0MB': frac(ab['georef_dirs_in'] + ab['resample'], georef_ms + bin_ms),
             },
         }
+        del run, seq, results
+        if world == 1 and not args.no_variants and shared is None and not (args.exact or args.magnetic or args.upload or not fused):
+            # the other configurations of SURVEY 8d on the record of the same run: short runs of the same loop
+            torch.cuda.empty_cache()
+            variants = {}
+            nv_w, nv_k = 3, 12
+            for name, kw in (('exact_centres', dict(fast=False, magnetic=False)),
+                             ('configs3_magnetic_3_shells', dict(fast=True, magnetic=True))):
+                v = timed_run(make_frames(nv_w + nv_k, kw['magnetic']), nv_w, nv_k, kw['fast'], 'fused', kw['magnetic'],
+                              args.batch, args.streams, True, None, own_buffers=False, fence=fence)
+                vb = ab['mag_shell'] - 24 * (WIDTH + 1) * (HEIGHT + 1) if kw['magnetic'] else ab['georef'] + ab['resample']
+                variants[name] = {
+                    'ms_per_frame': v['elapsed'] / nv_k * 1e3, 'Mpixels_per_s': nv_k * npx / 1e6 / v['elapsed'],
+                    'frames': nv_k, 'kernel_ms_per_frame': v['georef_ms'],
+                    'single_pass_frames': sum(1 for q in v['plans'] if q == 'single-pass'),
+                    'algorithmic_bytes_per_frame': vb, 'frac': frac(vb, v['georef_ms']),
+                }
+                if kw['magnetic']:
+                    # SURVEY 8d config 4 counts 40 Nc + 54 Np per shell (directions read); the kernel generates them
+                    variants[name]['frac_contract_3387MB_for_3_shells'] = frac(ab['mag_shell'], v['georef_ms'])
+                del v
+                torch.cuda.empty_cache()
+            out['variants'] = variants
         if world == 1 and args.cpu_rows > 0:
             out['cpu_baseline'] = cpu_baseline(min(args.cpu_rows, HEIGHT))
         else:

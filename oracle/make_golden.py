@@ -16,6 +16,9 @@ Fixtures
   known_answers.json    literal known-answer vectors of the reference's own unit tests
   miracle_*.npz         MIRACLEMapping (all-sky fisheye) arrays for calibrations of test/resources/cal.txt
   themis_reproject.npz  themis.reproject of a coordinate table to two other heights
+  config1_*.npz         BASELINE.json configs[0] / SURVEY 8d config 1: the 512x512 synthetic frame (fast + exact
+                        centres): every 4th sample + digests of all arrays, masks, and the full
+                        maskedByElevation(10) -> resample(pxPerDeg=10, 'mean') output
 """
 import json
 import os
@@ -578,6 +581,56 @@ def resample_nearest_cases():
         case.update(lats_c=z['lats_c'], lons_c=z['lons_c'], data=z['data'], corner_lat=z['corner_lat'],
                     corner_lon=z['corner_lon'], altitude=np.float64(110), ppd=np.array((4, 4), dtype=np.float64))
         save('resample_nearest_synth_%s.npz' % tag, **case)
+
+
+def config1_header():
+    """SURVEY.md 8d config 1 (BASELINE.json configs[0]): 512x512 synthetic frame, known camera pose, 110 km."""
+    s = 4256 / 512
+    hdr = {'CTYPE1': 'RA---TAN', 'CTYPE2': 'DEC--TAN', 'LONPOLE': 180.0, 'LATPOLE': 0.0,
+           'CRVAL1': 16.0531567459, 'CRVAL2': 23.1148929108, 'IMAGEW': 512, 'IMAGEH': 512,
+           'CRPIX1': 256.5, 'CRPIX2': 2832 / s / 2 + 0.5,
+           'CD1_1': s * -0.00912247310646, 'CD1_2': s * -0.00250608809647,
+           'CD2_1': s * 0.00250608809647, 'CD2_2': s * -0.00912247310646}
+    cam = np.array([-4809.524217485676, 524.8117887762777, 4729.265809729493])
+    t = datetime(2012, 1, 25, 9, 26, 55, 60000)
+    img = np.random.RandomState(1).randint(0, 65535, (512, 512, 3)).astype(np.uint16)
+    return hdr, cam, t, img
+
+
+def config1():
+    hdr, cam, t, img = config1_header()
+    step = 4
+    for fast in (True, False):
+        m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'c1', fastCenterCalculation=fast)
+        arrs = raw(m, fast)
+        out = {}
+        for k, v in arrs.items():
+            if v.ndim != 2:
+                continue
+            out[k] = np.ascontiguousarray(v[::step, ::step])
+            out['digest_' + k] = digest(v)
+        out['corner_mask'] = np.packbits(ma.getmaskarray(m.lats))
+        out['center_mask'] = np.packbits(ma.getmaskarray(m.latsCenter))
+        out['img_mask'] = np.packbits(ma.getmaskarray(m.img)[:, :, 0])
+        mm = m.maskedByElevation(10)
+        mm.checkGuarantees()
+        out['e10_corner_mask'] = np.packbits(ma.getmaskarray(mm.lats))
+        out['e10_center_mask'] = np.packbits(ma.getmaskarray(mm.latsCenter))
+        merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+        case = _run_resample(mm.lats, mm.lons, mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan), 110, merged,
+                             (10, 10))
+        rimg, relev = np.dsplit(case['out_data'], [-1])
+        with np.errstate(invalid='ignore'):
+            rimg = np.round(rimg)
+        rimg = np.require(ma.masked_invalid(rimg, copy=False), np.uint16)
+        del case['outline']
+        out.update(case)
+        out.update(out_img=rimg.data, out_img_mask=ma.getmaskarray(rimg))
+        out.update(hdr_arrays(hdr))
+        out.update(time_arrays(t))
+        out.update(cam=cam, altitude=np.float64(110), step=np.int64(step), min_elev=np.float64(10),
+                   ppd=np.array((10, 10), dtype=np.float64), image_seed=np.int64(1))
+        save('config1_%s.npz' % ('fast' if fast else 'exact'), **out)
 
 
 if __name__ == '__main__':

@@ -32,7 +32,8 @@ def _fake_result(k):
     mean = rs.uniform(0, 65535, (grid.ny, grid.nx, 4))
     mean[rs.rand(grid.ny, grid.nx) < 0.2] = np.nan
     count = rs.randint(0, 50, (grid.ny, grid.nx)).astype(np.float64)
-    return dict(mean=torch.from_numpy(mean), count=torch.from_numpy(count), grid=grid)
+    return dict(mean=torch.from_numpy(mean), count=torch.from_numpy(count), grid=grid, contains_pole=k % 4 == 3,
+                contains_discontinuity=k % 4 == 1, altitude=100.0 + k, magnetic=k % 2 == 0)
 
 
 def _worker(rank, world, port, n_frames, out_dir):
@@ -42,16 +43,29 @@ def _worker(rank, world, port, n_frames, out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from auromat_amd.sequence import gather_results, shard
     mine = shard(n_frames, rank, world)
-    results = [_fake_result(k) for k in mine]
-    got = gather_results(results, mine, torch.device('cpu'))
+    # frame 1 (when there is one) has no valid pixel: it travels as an empty descriptor
+    results = [None if k == 1 and n_frames > 2 else _fake_result(k) for k in mine]
+    from auromat_amd.sequence import gather_device
+    g = gather_device(results, mine, torch.device('cpu'))
+    got = g.unpack() if g is not None else None
     if rank == 0:
-        assert [f['index'] for f in got] == list(range(n_frames))
+        ok = [k for k in range(n_frames) if not (k == 1 and n_frames > 2)]
+        assert [f['index'] for f in got] == ok and g.failed == ([1] if n_frames > 2 else [])
         for f in got:
             ref = _fake_result(f['index'])
             np.testing.assert_array_equal(f['mean'], ref['mean'].numpy())
             np.testing.assert_array_equal(f['count'], ref['count'].numpy())
             assert f['lat0'] == ref['grid'].latCenters[0] and f['lon0'] == ref['grid'].lonCenters[0]
             assert f['dlat'] == ref['grid'].latStep and f['dlon'] == ref['grid'].lonStep
+            for key in ('contains_pole', 'contains_discontinuity', 'altitude', 'magnetic'):
+                assert f[key] == ref[key], key
+            if f['contains_discontinuity']:
+                # the grid was laid out in longitudes shifted by 180 deg: frame_coordinates() undoes it
+                from auromat_amd.sequence import frame_coordinates
+                from auromat_amd.mapping.mapping import wrap_at_180
+                lat_c, lon_c = frame_coordinates(f)
+                assert np.allclose(lat_c[:, 0], ref['grid'].latCenters, atol=1e-12, rtol=0)
+                assert np.allclose(lon_c[0], wrap_at_180(np.asarray(ref['grid'].lonCenters) - 180))
         open(os.path.join(out_dir, 'ok'), 'w').write('ok')
     else:
         assert got is None

@@ -1,0 +1,150 @@
+"""
+GPU tests of the sequence loop in its PRODUCTION mode — ``SequencePipeline.process(..., keep_on_device=True)``, what
+bench.py and ``run_sequence`` use: nothing synchronises between frames, results are copied to the host only after
+process() has returned.  Distinct per-frame images (pageable, pinned, device resident), every plan and batch size,
+with pole frames (per-frame fall-back to the two-pass plan inside the single-pass plan) and frames without any valid
+pixel in between (image-buffer races, empty frames, gather descriptors).
+"""
+from datetime import datetime
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def pole_frame(w, h):
+    """A camera 400 km above the geographic north pole looking straight down (48 deg field of view)."""
+    from auromat_amd.coordinates import transform as T
+    t = datetime(2012, 1, 25, 9, 26, 55)
+    zen = T.mat_j2000_to_geo(T.date2es(t)).T.dot([0.0, 0.0, 1.0])
+    bore = -zen
+    s = 48.0 / w
+    hdr = {'CTYPE1': 'RA---TAN', 'CTYPE2': 'DEC--TAN', 'LONPOLE': 180.0, 'LATPOLE': 0.0,
+           'CRVAL1': np.rad2deg(np.arctan2(bore[1], bore[0])) % 360, 'CRVAL2': np.rad2deg(np.arcsin(bore[2])),
+           'CRPIX1': w / 2 + 0.5, 'CRPIX2': h / 2 + 0.5, 'CD1_1': -s, 'CD1_2': 0.0, 'CD2_1': 0.0, 'CD2_2': s,
+           'IMAGEW': w, 'IMAGEH': h}
+    return hdr, zen * (6356.75 + 400.0), t
+
+
+def sky_frame(w, h):
+    """The same camera looking away from the Earth: no ray hits the shell."""
+    hdr, cam, t = pole_frame(w, h)
+    hdr = dict(hdr, CRVAL1=(hdr['CRVAL1'] + 180.0) % 360, CRVAL2=-hdr['CRVAL2'])
+    return hdr, cam, t
+
+
+def build_sequence(w, h, n, every_pole=5, empty_at=()):
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    frames = []
+    for k in range(n):
+        img = frame_image(w, h, seed=100 + k)
+        if k in empty_at:
+            hdr, cam, t = sky_frame(w, h)
+        elif every_pole and k % every_pole == every_pole - 1:
+            hdr, cam, t = pole_frame(w, h)
+        else:
+            hdr, cam, t, _ = sequence_frame(k, w, h)
+        frames.append((hdr, cam, t, img))
+    return frames
+
+
+def host(res):
+    import torch
+    return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in res.items()}
+
+
+KEYS = ('mean', 'count', 'img', 'mask')
+
+
+@pytest.mark.parametrize('how', ['pageable', 'pinned', 'resident'])
+def test_keep_on_device_sequences_equal_frame_by_frame(how):
+    import torch
+    from auromat_amd.pipeline import FramePipeline, SequencePipeline
+    w, h, n = 1060, 708, 23
+    frames = build_sequence(w, h, n)
+    single = FramePipeline(w, h)
+    want = [single.run(hdr, 110, cam, t, img=img, pxPerDeg=6) for hdr, cam, t, img in frames]
+    n_pole = sum(1 for r in want if r['contains_pole'])
+    assert n_pole == 4
+    if how == 'pinned':
+        feed = [(hd, c, t, torch.from_numpy(im.view(np.int16)).pin_memory()) for hd, c, t, im in frames]
+    elif how == 'resident':
+        feed = [(hd, c, t, torch.from_numpy(im.view(np.int16)).cuda()) for hd, c, t, im in frames]
+    else:
+        feed = frames
+    for plan, batch, bin_stream in (('single-pass', 3, True), ('single-pass', 1, True), ('single-pass', 2, True),
+                                    ('two-pass', 1, True), ('two-pass', 1, False)):
+        seq = SequencePipeline(w, h, pxPerDeg=6, plan=plan, batch=batch, bin_stream=bin_stream,
+                               own_image_buffers=how != 'resident')
+        for rep in range(2):                # the second call re-uses buffers that still have readers in flight
+            got = seq.process(feed, keep_on_device=True)
+            assert all(isinstance(r['mean'], torch.Tensor) and r['mean'].is_cuda for r in got)
+            if plan == 'single-pass':
+                assert seq.plans.count('two-pass') == n_pole
+            got = [host(r) for r in got]    # only now
+            for k in range(n):
+                for key in KEYS:
+                    a, b = got[k][key], want[k][key]
+                    if key == 'img':
+                        a = a.view(b.dtype)
+                    assert np.array_equal(a.astype(b.dtype) if key == 'mask' else a, b, equal_nan=True), \
+                        (how, plan, batch, bin_stream, rep, k, key)
+                assert got[k]['contains_pole'] == want[k]['contains_pole']
+
+
+def test_a_frame_without_valid_pixels_does_not_stop_the_sequence():
+    from auromat_amd.pipeline import FramePipeline, SequencePipeline
+    from auromat_amd.sequence import frame_coordinates, run_sequence
+    w, h, n = 300, 200, 9
+    frames = build_sequence(w, h, n, every_pole=4, empty_at=(2, 8))
+    single = FramePipeline(w, h)
+    want = []
+    for k, (hdr, cam, t, img) in enumerate(frames):
+        if k in (2, 8):
+            with pytest.raises(ValueError):
+                single.run(hdr, 110, cam, t, img=img, pxPerDeg=5)
+            want.append(None)
+        else:
+            want.append(single.run(hdr, 110, cam, t, img=img, pxPerDeg=5))
+    for plan, batch in (('single-pass', 3), ('single-pass', 1), ('two-pass', 1)):
+        seq = SequencePipeline(w, h, pxPerDeg=5, plan=plan, batch=batch)
+        got = seq.process(frames, keep_on_device=True)
+        assert [r is None for r in got] == [k in (2, 8) for k in range(n)]
+        assert seq.plans[2] == seq.plans[8] == 'empty'
+        for k in range(n):
+            if want[k] is not None:
+                g = host(got[k])
+                assert np.array_equal(g['mean'], want[k]['mean'], equal_nan=True), (plan, batch, k)
+                assert np.array_equal(g['count'], want[k]['count']), (plan, batch, k)
+    # the gather path: empty frames are reported, pole and date-line flags travel, coordinates can be recovered
+    out, failed = run_sequence(frames, w, h, pxPerDeg=5, return_failed=True)
+    assert failed == [2, 8] and [f['index'] for f in out] == [0, 1, 3, 4, 5, 6, 7]
+    for f in out:
+        ref = want[f['index']]
+        assert f['contains_pole'] == ref['contains_pole'] and f['altitude'] == 110 and not f['magnetic']
+        assert f['contains_discontinuity'] == ref['contains_discontinuity']
+        lat_c, lon_c = frame_coordinates(f)
+        assert np.allclose(lat_c, ref['lat_c'], atol=1e-9, rtol=0), f['index']
+        dl = np.abs(lon_c - ref['lon_c'])
+        assert np.all(np.minimum(dl, 360 - dl) * np.cos(np.deg2rad(ref['lat_c'])) < 1e-9), f['index']
+
+
+def test_gathered_dateline_frame_keeps_its_true_coordinates():
+    """iss029 moved so that its footprint straddles the date line: the grid is laid out in longitudes shifted by
+    180 deg (resample.py:203-218); the descriptor says so and frame_coordinates() undoes it."""
+    from datetime import timedelta
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.sequence import frame_coordinates, run_sequence
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 253, 171
+    hdr, cam, t = frame_header(w, h, 'iss029')
+    t = t - timedelta(minutes=20)           # the Earth turns 5 deg under the fixed footprint
+    img = frame_image(w, h, seed=5)
+    want = FramePipeline(w, h).run(hdr, 110, cam, t, img=img, pxPerDeg=5)
+    assert want['contains_discontinuity']
+    out = run_sequence([(hdr, cam, t, img)], w, h, pxPerDeg=5)
+    assert out[0]['contains_discontinuity'] and not out[0]['contains_pole']
+    lat_c, lon_c = frame_coordinates(out[0])
+    assert np.allclose(lat_c, want['lat_c'], atol=1e-12, rtol=0) and np.allclose(lon_c, want['lon_c'], atol=1e-12, rtol=0)
+    assert lon_c.min() < -170 and lon_c.max() > 170
