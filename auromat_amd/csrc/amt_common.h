@@ -425,6 +425,185 @@ __device__ __forceinline__ double small_angle_deg(double xr, double yr, double x
     return q * t;
 }
 
+// ------------------------------------------------------------------------------------------
+// fx:: the arithmetic of the row-marching frame kernel, written operation by operation.
+//
+// k_georef_rows evaluates a row either on a speculative straight-line path (every lane hits the shell, every
+// small angle applies, ...) or on the general, divergent path.  Both must give the same BITS (the two execution
+// plans of the pipeline are tested for bit-identical grids, and a row may take either path depending on the
+// kernel variant), so the arithmetic lives here once: explicit fma / mul / add in a fixed order with contraction
+// off — the compiler can schedule these but not re-associate or fuse them differently in different contexts.
+// Issue costs on gfx950 (tools/valu_rates.hip): f64 fma/mul/add 3.0 cycles per wave and SIMD, v_rcp/rsq_f64 11,
+// 32-bit moves and integer ops 2, v_cndmask 3.1, DPP move 3.2, LDS f64 atomic 15.
+// ------------------------------------------------------------------------------------------
+namespace fx {
+__device__ __forceinline__ double rcp_n(double x) {              // 1 / x, 2e-15 relative
+#pragma clang fp contract(off)
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+__device__ __forceinline__ double rsqrt_n(double x) {            // 1 / sqrt(x), x > 0, 4e-15 relative
+#pragma clang fp contract(off)
+    const double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * y, g = x * y;
+    const double e = __builtin_fma(-h, g, 0.5);
+    return __builtin_fma(y, e, y);
+}
+
+__device__ __forceinline__ double sqrt_n(double x) {             // sqrt(x); NaN for x < 0 (a missed ray)
+#pragma clang fp contract(off)
+    const double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * y, g = x * y;
+    const double e = __builtin_fma(-h, g, 0.5);
+    return __builtin_fma(g, e, g);
+}
+
+__device__ __forceinline__ void sqrt_rsqrt_n(double x, double& s, double& rs) {
+#pragma clang fp contract(off)
+    const double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * y, g = x * y;
+    const double e = __builtin_fma(-h, g, 0.5);
+    s = __builtin_fma(g, e, g);
+    rs = __builtin_fma(y, e, y);
+}
+
+__device__ __forceinline__ double dot3(double ax, double ay, double az, double bx, double by, double bz) {
+#pragma clang fp contract(off)
+    return __builtin_fma(az, bz, __builtin_fma(ay, by, ax * bx));
+}
+
+// Bowring numerator / denominator (lat = atan(n / d), d > 0) and 1 / |(x, y, z)|: 27 operations + 3 v_rsq_f64
+__device__ __forceinline__ void bowring_nd(const bowring_fast& w, double x, double y, double z, double& n, double& d,
+                                           double& inv_r) {
+#pragma clang fp contract(off)
+    const double p2 = __builtin_fma(x, x, y * y);
+    double p, ip;
+    sqrt_rsqrt_n(p2, p, ip);
+    inv_r = rsqrt_n(__builtin_fma(z, z, p2));
+    const double k = __builtin_fma(w.d, inv_r, 1.0);
+    const double tu = ((w.b_over_a * z) * k) * ip;
+    const double tu2 = tu * tu;
+    const double c = rsqrt_n(__builtin_fma(tu, tu, 1.0));
+    const double cu3 = (c * c) * c;
+    const double su3 = (cu3 * tu2) * tu;
+    n = __builtin_fma(w.d, su3, z);
+    d = __builtin_fma(-w.e2a, cu3, p);
+}
+
+// Polynomial coefficients of the row kernel.  They travel in the kernel-argument segment and are read through the
+// scalar cache where they are used: as literals the compiler keeps all of them in VGPRs across the row loop (64-bit
+// literals cannot be encoded in VOP3), which cost ~40 of the 128 registers.
+struct math_table {
+    double small4[4];       // (180/pi) {-1/7, 1/5, -1/3, 1}: atan(t) / t in degrees for t^2 <= 9e-4
+    double atan9[9];        // atan(t) / t in degrees for |t| <= tan(pi/8), highest power first (fm::atan_core_deg)
+    double pad_[3];
+};
+
+__host__ inline math_table make_math_table() {
+    math_table t = {{-8.1851113590117602, 11.459155902616464, -19.098593171027442, 57.295779513082323},
+                    {1.8906869702149334, -3.454838730079989, 4.3575716232982611, -5.2048471660339564, 6.3660331903476619,
+                     -8.1851078904860763, 11.45915587463822, -19.098593170990291, 57.295779513082323},
+                    {0, 0, 0}};
+    return t;
+}
+
+// t (1 - s/3 + s^2/5 - s^3/7) in degrees, s = t^2 <= 9e-4 (next term < 7e-14 relative)
+__device__ __forceinline__ double small_atan_deg(double t, double s, const double (&c)[4]) {
+#pragma clang fp contract(off)
+    double q = __builtin_fma(c[0], s, c[1]);
+    q = __builtin_fma(q, s, c[2]);
+    q = __builtin_fma(q, s, c[3]);
+    return q * t;
+}
+
+// The two small angles (degrees) a corner or centre needs, with ONE reciprocal: from the plane vector (ar, br) to
+// (a, b) — Bowring (d, n) pairs: the step in latitude — and from (xr, yr) to (x, y) — GEO (x, y): the step in
+// longitude.  `ok` is false (values meaningless) when either angle is above 1.7 deg, a dot product is not positive,
+// or anything is NaN: the caller then evaluates the full arctangents.
+__device__ __forceinline__ void small_angles(double ar, double br, double a, double b, double xr, double yr, double x,
+                                             double y, const double (&c)[4], double& dlat, double& dlon, bool& ok) {
+#pragma clang fp contract(off)
+    const double cross_a = __builtin_fma(ar, b, -(br * a)), dot_a = __builtin_fma(ar, a, br * b);
+    const double cross_o = __builtin_fma(xr, y, -(yr * x)), dot_o = __builtin_fma(xr, x, yr * y);
+    const double r = rcp_n(dot_a * dot_o);
+    const double ta = (cross_a * dot_o) * r, to = (cross_o * dot_a) * r;
+    const double sa = ta * ta, so = to * to;
+    ok = sa <= 9.0e-4 && so <= 9.0e-4 && dot_a > 0.0 && dot_o > 0.0;
+    dlat = small_atan_deg(ta, sa, c);
+    dlon = small_atan_deg(to, so, c);
+}
+
+// atan(t) in DEGREES for |t| <= tan(pi/8): t * P(t^2), 1.1e-13 relative
+__device__ __forceinline__ double atan_core_deg(double t, const double (&c)[9]) {
+#pragma clang fp contract(off)
+    const double s = t * t;
+    double p = __builtin_fma(c[0], s, c[1]);
+    p = __builtin_fma(p, s, c[2]);
+    p = __builtin_fma(p, s, c[3]);
+    p = __builtin_fma(p, s, c[4]);
+    p = __builtin_fma(p, s, c[5]);
+    p = __builtin_fma(p, s, c[6]);
+    p = __builtin_fma(p, s, c[7]);
+    p = __builtin_fma(p, s, c[8]);
+    return p * t;
+}
+
+// atan2(n, d) in degrees for d > 0 (result in (-90, 90))
+__device__ __forceinline__ double atan_pos_deg(double n, double d, const double (&c)[9]) {
+#pragma clang fp contract(off)
+    const double an = fabs(n);
+    const bool flip = an > d;
+    const double mx = flip ? an : d, mn = flip ? d : an;
+    const bool big = mn > fm::kTanPi8 * mx;
+    const double num = big ? mn - mx : mn;
+    const double den = big ? mn + mx : mx;
+    double r = atan_core_deg(num * rcp_n(den), c) + (big ? 45.0 : 0.0);
+    r = flip ? 90.0 - r : r;
+    return copysign(r, n);
+}
+
+// atan2(y, x) in degrees, all quadrants; (0, 0) gives NaN instead of 0
+__device__ __forceinline__ double atan2_deg(double y, double x, const double (&c)[9]) {
+#pragma clang fp contract(off)
+    const double ax = fabs(x), ay = fabs(y);
+    const bool flip = ay > ax;
+    const double mx = flip ? ay : ax, mn = flip ? ax : ay;
+    const bool big = mn > fm::kTanPi8 * mx;
+    const double num = big ? mn - mx : mn;
+    const double den = big ? mn + mx : mx;
+    double r = atan_core_deg(num * rcp_n(den), c) + (big ? 45.0 : 0.0);
+    r = flip ? 90.0 - r : r;
+    r = x < 0 ? 180.0 - r : r;
+    return copysign(r, y);
+}
+
+constexpr double kSin45 = 0.7071;       // below sin(45 deg): c / (1 + sqrt(1 - c^2)) stays within tan(pi/8)
+
+// asin(c) in degrees for |c| <= kSin45 as 2 atan(c / (1 + sqrt(1 - c^2))): no range reduction, no selects
+// (21 operations + v_rsq + v_rcp; the general form below costs three times that)
+__device__ __forceinline__ double asin_deg_low(double c, const double (&k)[9]) {
+#pragma clang fp contract(off)
+    const double sq = sqrt_n(__builtin_fma(-c, c, 1.0));
+    const double t = c * rcp_n(1.0 + sq);
+    return 2.0 * atan_core_deg(t, k);
+}
+
+// asin(c) in degrees, |c| <= 1, any elevation
+__device__ __forceinline__ double asin_deg_any(double c, const double (&k)[9]) {
+#pragma clang fp contract(off)
+    const double q = (1.0 - c) * (1.0 + c);
+    const double d = q > 0 ? sqrt_n(q) : 0.0;
+    return atan_pos_deg(c, d, k);
+}
+
+__device__ __forceinline__ double asin_deg(double c, const double (&k)[9]) {
+    return fabs(c) <= kSin45 ? asin_deg_low(c, k) : asin_deg_any(c, k);
+}
+
+}  // namespace fx
+
 // True when the closed longitude path o00 -> o01 -> o11 -> o10 -> o00 (corner quad of one pixel, degrees)
 // winds once around a geographic pole: the wrapped longitude steps then sum to +-360 instead of 0.
 __device__ __forceinline__ bool quad_winds_pole(double o00, double o01, double o11, double o10) {
@@ -581,13 +760,16 @@ inline axis_lin make_axis_lin(const axis_dev& a) {
 // from 1 (by 1e-7) the bin floor(t) is certain and no edge needs evaluating.  Everything else — close to an
 // edge, outside the axis, NaN — sets `slow` and is decided exactly by bin_index (a few dozen pixels per frame).
 // Returns the 1-based bin, 0 when `slow` is set.
-__device__ __forceinline__ int bin_fast(const axis_lin& ax, double v, bool& slow) {
-    const double t = (v - ax.e0) * ax.inv_step;
+__device__ __forceinline__ int bin_fast(double e0, double inv_step, double margin, int nbin, double v, bool& slow) {
+    const double t = (v - e0) * inv_step;
     const double fl = floor(t);
     const double fr = t - fl;
-    const bool sure = fr > ax.margin && fr < 1.0 - 1e-7 && fl >= 0.0 && fl < (double)ax.nbin;     // false for NaN
+    const bool sure = fr > margin && fr < 1.0 - 1e-7 && fl >= 0.0 && fl < (double)nbin;     // false for NaN
     slow = !sure;
     return sure ? (int)fl + 1 : 0;
+}
+__device__ __forceinline__ int bin_fast(const axis_lin& ax, double v, bool& slow) {
+    return bin_fast(ax.e0, ax.inv_step, ax.margin, ax.nbin, v, slow);
 }
 
 // v lies in bin b (1-based, by plain searchsorted): does it sit on that bin's lower edge in the sense of the

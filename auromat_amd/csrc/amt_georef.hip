@@ -21,18 +21,23 @@ namespace {
 
 using namespace amt;
 
-// The same ray / shell intersection with everything expressed in the GEO frame (k_georef_rows).  The shell is
-// aligned with the J2000 axes (reference intersection.py:63-74 scales J2000 components by 1/a, 1/a, 1/b), so in
-// GEO coordinates it is the general quadric x^T Q x = 1 with Q = M diag(1/a^2, 1/a^2, 1/b^2) M^T.  Intersecting
-// there costs 6 multiply-adds more per ray than the axis-aligned form but the hit comes out in GEO coordinates:
-// the 3x3 rotation of every corner point and of every centre point (18 multiply-adds per pixel) disappears, and
-// the centre of the fast mode, a mean of corner hits, needs none either because rotations are linear.
-struct quadric_ray {
-    double qxx, qyy, qzz, qxy, qxz, qyz;   // Q
-    double qox, qoy, qoz;                  // Q o
-    double c0;                             // o^T Q o - 1
-    double ox, oy, oz;                     // camera in GEO
-    long long inside;                      // camera inside the shell (intersection.py:239-241)
+// The ray / shell intersection with everything expressed in the GEO frame (k_georef_rows).  The shell is aligned
+// with the J2000 axes (reference intersection.py:63-74 scales J2000 components by 1/a, 1/a, 1/b), so in GEO
+// coordinates it is the quadric x^T Q x = 1 with Q = M diag(1/a^2, 1/a^2, 1/b^2) M^T = q_a I + q_d k k^T, where
+// q_a = 1/a^2, q_d = 1/b^2 - 1/a^2 and k = M e_z is the J2000 pole in GEO coordinates.  Intersecting there gives
+// the hit in GEO coordinates: the 3x3 rotation of every corner point and of every centre point (18 multiply-adds
+// per pixel) disappears, and the centre of the fast mode, a mean of corner hits, needs none either because
+// rotations are linear.  With the rank-one form the quadratic's coefficients of a ray o + t u are
+//   a2 = q_a (u.u) + q_d (k.u)^2,   -b/2 = -(q_a (u.o) + q_d (k.u)(k.o)),   c = o^T Q o - 1
+// (11 constants, 14 multiply-adds; u need not be normalised).
+struct shell_ray {
+    double qa, qd;                          // 1/a^2, 1/b^2 - 1/a^2
+    double kx, ky, kz;                      // J2000 z axis in GEO
+    double qd_ko;                           // q_d (k.o)
+    double c0;                              // o^T Q o - 1
+    double ox, oy, oz;                      // camera in GEO
+    double root_sign;                       // +1: camera inside the shell (far root), -1: outside (intersection.py:84-91,239-241)
+    double pad_;
 };
 
 __host__ inline void mat_mul3(const double* a, const double* b, double* out) {     // out = a b (row major 3x3)
@@ -40,50 +45,46 @@ __host__ inline void mat_mul3(const double* a, const double* b, double* out) {  
         for (int j = 0; j < 3; ++j) out[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
 }
 
-__host__ inline quadric_ray make_quadric_ray(double a, double b, const double* cam, const double* m) {
-    const double w[3] = {1 / (a * a), 1 / (a * a), 1 / (b * b)};
-    double q[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            q[3 * i + j] = 0;
-            for (int k = 0; k < 3; ++k) q[3 * i + j] += m[3 * i + k] * w[k] * m[3 * j + k];
-        }
-    quadric_ray r;
-    r.qxx = q[0], r.qyy = q[4], r.qzz = q[8];
-    r.qxy = 0.5 * (q[1] + q[3]), r.qxz = 0.5 * (q[2] + q[6]), r.qyz = 0.5 * (q[5] + q[7]);
+__host__ inline shell_ray make_shell_ray(double a, double b, const double* cam, const double* m) {
+    shell_ray r;
+    r.qa = 1 / (a * a);
+    r.qd = 1 / (b * b) - 1 / (a * a);
+    r.kx = m[2], r.ky = m[5], r.kz = m[8];
     r.ox = m[0] * cam[0] + m[1] * cam[1] + m[2] * cam[2];
     r.oy = m[3] * cam[0] + m[4] * cam[1] + m[5] * cam[2];
     r.oz = m[6] * cam[0] + m[7] * cam[1] + m[8] * cam[2];
-    r.qox = r.qxx * r.ox + r.qxy * r.oy + r.qxz * r.oz;
-    r.qoy = r.qxy * r.ox + r.qyy * r.oy + r.qyz * r.oz;
-    r.qoz = r.qxz * r.ox + r.qyz * r.oy + r.qzz * r.oz;
+    r.qd_ko = r.qd * cam[2];                // k.o = (M e_z).(M cam) = cam_z
     const double qx = cam[0] / a, qy = cam[1] / a, qz = cam[2] / b;
     const double oo = qx * qx + qy * qy + qz * qz;       // axis-aligned form: exact decision, and a better c0
     r.c0 = oo - 1;
-    r.inside = oo < 1;
+    r.root_sign = oo < 1 ? 1.0 : -1.0;
+    r.pad_ = 0;
     return r;
 }
 
-// t of the first hit of x = o + t d (d in GEO), NaN for a miss or a hit behind the camera.
-__device__ __forceinline__ double quadric_param(const quadric_ray& e, const vec3& d) {
-    const double ux = e.qxx * d.x + e.qxy * d.y + e.qxz * d.z;
-    const double uy = e.qxy * d.x + e.qyy * d.y + e.qyz * d.z;
-    const double uz = e.qxz * d.x + e.qyz * d.y + e.qzz * d.z;
-    const double a2 = d.x * ux + d.y * uy + d.z * uz;
-    const double nb = -(d.x * e.qox + d.y * e.qoy + d.z * e.qoz);       // = d_o of the axis-aligned form
-    const double disc = nb * nb - a2 * e.c0;
-    const double root = fm::sqrt_pos(disc);          // NaN when the line misses
-    double t = e.inside ? nb + root : nb - root;
-    if (t < 0) t = NAN;
-    return t * fm::rcp(a2);
-}
+// Affine form of the TAN camera model in the GEO frame.  reference wcs.py:93-142 evaluates atan2 / atan and then
+// cos / sin of those angles; algebraically the un-normalised native vector is (-Y, X, 180/pi) with (X, Y) = CD (p -
+// CRPIX + 1), i.e. after the rotation w = u0 + px ux + py uy: the direction of a pixel is three multiply-adds and
+// one normalisation.  px = column + cx, py = row + cy for CORNER (column - 1/2, row - 1/2); centres add 1/2.
+struct affine_cam {
+    double u0[3], ux[3], uy[3];
+    double cx, cy;
+    double pad_;
+};
 
-__device__ __forceinline__ vec3 quadric_point(const quadric_ray& e, const vec3& d, double t) {
-    vec3 p;
-    p.x = d.x * t + e.ox;
-    p.y = d.y * t + e.oy;
-    p.z = d.z * t + e.oz;
-    return p;
+__host__ inline affine_cam make_affine_cam(const tan_wcs& w) {
+    affine_cam c;
+    const double* r = w.rot.m;
+    for (int i = 0; i < 3; ++i) {
+        const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
+        c.u0[i] = kRad2Deg * r2;
+        c.ux[i] = w.cd[0] * r1 - w.cd[2] * r0;
+        c.uy[i] = w.cd[1] * r1 - w.cd[3] * r0;
+    }
+    c.cx = 0.5 - w.crpix[0];
+    c.cy = 0.5 - w.crpix[1];
+    c.pad_ = 0;
+    return c;
 }
 
 struct georef_args {
@@ -93,8 +94,8 @@ struct georef_args {
     mat3 m_sm;
     bowring_fast bw;
     // k_georef_rows works in the GEO frame: camera model rotated into GEO, shell as a general quadric, GEO -> SM
-    tan_wcs wcs_geo;
-    quadric_ray qray;
+    affine_cam cam;
+    shell_ray sray;
     mat3 m_geo_sm;
     int width, height;
     const double* dirs_in;   // optional (H+1, W+1, 3)
@@ -115,7 +116,7 @@ struct georef_args {
     const void* bin_img;
     unsigned long long* bin_acc;
     int bin_lon_wrap, bin_magnetic;
-    int item_order, pad_;       // amt_georef_out.item_order
+    int item_order, chunk_stride;       // amt_georef_out.item_order; stride of the interleaved chunk order
     bin_event* bin_events;      // optional list for on-edge pixels (amt_georef_out.bin_events)
     unsigned int* bin_event_count;
     long long bin_event_cap;
@@ -125,6 +126,7 @@ struct georef_args {
 constexpr int kMaxBatch = 3;
 struct georef_batch {
     georef_args f[kMaxBatch];
+    fx::math_table math;
 };
 static_assert(sizeof(georef_args) % 8 == 0 && sizeof(georef_batch) <= 4096, "kernel-argument segment");
 
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(kThreads) void k_georef(georef_args A) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Row-marching variant: no LDS, no workgroup barriers.
+// Row-marching variant: no workgroup barriers.
 //
 // One WAVE owns a strip of 63 pixel columns (64 corner columns, one per lane) and marches down
 // `rows` pixel rows.  Each lane casts the ray of its corner column once per corner row and keeps the
@@ -347,6 +349,12 @@ __global__ __launch_bounds__(kThreads) void k_georef(georef_args A) {
 // the same two of lane+1, fetched with DPP wave shifts.  Redundancy: 64/63 horizontally, (rows+1)/rows
 // vertically.  The bounding box is accumulated from the corner side with a one-row delay (a corner
 // row is final once the centre row below it has been classified).
+//
+// All arithmetic is in fx:: (amt_common.h): explicit fma / mul / add in a fixed order, so that every variant of the
+// kernel gives the same bits (the two execution plans of the pipeline are tested for bit-identical grids).
+// What round 2 measured about this kernel: it is not FP64-issue bound any more; straight-line
+// "speculative" and per-phase wave-uniform variants of the row step (no NaN presets, no exec-mask regions) were
+// built and were SLOWER than this plain divergent form (register pressure, code size), so they were dropped.
 // ------------------------------------------------------------------------------------------
 constexpr int kDppWaveShl1 = 0x130;   // lane i <- lane i+1
 constexpr int kDppWaveShr1 = 0x138;   // lane i <- lane i-1
@@ -391,6 +399,42 @@ __device__ __forceinline__ T karg_load(karg_ptr base, size_t byte_offset) {
     return u.value;
 }
 
+// Un-normalised direction (GEO frame) of the corner / centre ray from the affine camera model: u = ub + py * uy
+// (ub = u0 + px * ux is per lane and fixed for a work item).
+__device__ __forceinline__ vec3 affine_ray(double ubx, double uby, double ubz, double uyx, double uyy, double uyz, double py) {
+#pragma clang fp contract(off)
+    vec3 u = {__builtin_fma(py, uyx, ubx), __builtin_fma(py, uyy, uby), __builtin_fma(py, uyz, ubz)};
+    return u;
+}
+
+// Ray parameter t >= 0 (in units of |u|) of the first hit of x = o + t u with the shell, NaN or negative for no hit.
+// uu = u.u.  14 + 2 + 5 + 1 + 4 operations, v_rsq_f64 + v_rcp_f64.
+__device__ __forceinline__ double shell_t(const shell_ray& e, const vec3& u, double uu) {
+#pragma clang fp contract(off)
+    const double ku = fx::dot3(u.x, u.y, u.z, e.kx, e.ky, e.kz);
+    const double uo = fx::dot3(u.x, u.y, u.z, e.ox, e.oy, e.oz);
+    const double a2 = __builtin_fma(e.qd * ku, ku, e.qa * uu);
+    const double nb = -__builtin_fma(e.qa, uo, e.qd_ko * ku);              // = d_o of the axis-aligned form
+    const double disc = __builtin_fma(nb, nb, -(a2 * e.c0));
+    const double root = fx::sqrt_n(disc);                                   // NaN when the line misses
+    const double t = __builtin_fma(e.root_sign, root, nb);                  // nearer root from outside the shell
+    return t * fx::rcp_n(a2);
+}
+
+__device__ __forceinline__ vec3 shell_point(const shell_ray& e, const vec3& u, double t) {
+#pragma clang fp contract(off)
+    vec3 p = {__builtin_fma(u.x, t, e.ox), __builtin_fma(u.y, t, e.oy), __builtin_fma(u.z, t, e.oz)};
+    return p;
+}
+
+__device__ __forceinline__ vec3 rotate3(const mat3& a, const vec3& v) {
+#pragma clang fp contract(off)
+    vec3 r = {__builtin_fma(a.m[2], v.z, __builtin_fma(a.m[1], v.y, a.m[0] * v.x)),
+              __builtin_fma(a.m[5], v.z, __builtin_fma(a.m[4], v.y, a.m[3] * v.x)),
+              __builtin_fma(a.m[8], v.z, __builtin_fma(a.m[7], v.y, a.m[6] * v.x))};
+    return r;
+}
+
 // Fused binning: every wave keeps a private kBinW x kBinW-cell window of the output grid in LDS, anchored
 // at the cell of its first kept pixel (a 63 x 16-pixel strip spans a few cells only).  Pixels add to it with
 // LDS atomics as soon as their coordinates exist; pixels outside the window go straight to global atomics;
@@ -398,10 +442,9 @@ __device__ __forceinline__ T karg_load(karg_ptr base, size_t byte_offset) {
 constexpr int kBinW = 8, kBinCells = kBinW * kBinW;
 
 // BIN: 0 = no fused binning, 1 = uint8 RGB image, 2 = uint16 RGB image
-// Minimum waves per SIMD the register allocator must reach: 5 for the georef-only variants (they need 66-96
-// VGPRs), 4 for the fused ones (119-128 VGPRs; 4 and 5 waves measured the same while they still fitted 96).
+// Minimum waves per SIMD the register allocator must reach: 5 for the georef-only variants, 4 for the fused ones.
 #ifndef AMT_ROWS_MIN_WAVES
-#define AMT_ROWS_MIN_WAVES 5
+#define AMT_ROWS_MIN_WAVES 4
 #endif
 #ifndef AMT_ROWS_MIN_WAVES_BIN
 #define AMT_ROWS_MIN_WAVES_BIN 4
@@ -470,6 +513,7 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
     chunk = item / strips_x;
     strip = item - chunk * strips_x;
     if (A.item_order == 2) chunk = chunks_y - 1 - chunk;
+    if (A.item_order == 3) chunk = (int)(((long long)chunk * A.chunk_stride) % chunks_y);
     const int x0 = strip * 63, y0 = chunk * rows_per_chunk;
     const int rows = min(rows_per_chunk, A.height - y0);
     const int gx = x0 + lane;
@@ -478,22 +522,64 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
     const bool px_ok = lane < 63 && gx < A.width;      // this lane's pixel column exists (and is owned)
     const bool want_bbox = A.bbox_partials != nullptr;
 
+    // The constants of the common path are read ONCE, before the row loop, and stay in SGPRs (the compiler parks what
+    // does not fit in VGPR lanes, a v_readlane per use).  Re-reading them from the kernel-argument segment in every
+    // phase of every row, as the first version did to save registers, made the scalar data cache the bottleneck of
+    // the whole kernel: an s_load that hits costs ~320 cycles of latency with 4 waves per SIMD and the cache serves
+    // a CU about one request per 20 cycles (tools/sload_latency.hip), and a row made 23 of them.
+    // (Each value is passed through an empty asm: the compiler must then keep that very value alive; otherwise it
+    // prefers to re-load "invariant" kernel arguments inside the loop whenever SGPRs run short.)
+    // AMT_ROWS_PIN (A/B builds): 0 = nothing is pinned, 1 = what a row that misses the shell needs (camera model, ray),
+    // 2 = everything
+#ifndef AMT_ROWS_PIN
+#define AMT_ROWS_PIN 1
+#endif
+    auto pin = [](auto v) {
+        if (AMT_ROWS_PIN >= 1) asm volatile("" : "+s"(v));
+        return v;
+    };
+    auto pin2 = [](auto v) {
+        if (AMT_ROWS_PIN >= 2) asm volatile("" : "+s"(v));
+        return v;
+    };
+    affine_cam cm = A.cam;
+    cm.uy[0] = pin(cm.uy[0]), cm.uy[1] = pin(cm.uy[1]), cm.uy[2] = pin(cm.uy[2]), cm.cy = pin(cm.cy);
+    shell_ray ray = A.sray;
+    ray.qa = pin(ray.qa), ray.qd = pin(ray.qd), ray.kx = pin(ray.kx), ray.ky = pin(ray.ky), ray.kz = pin(ray.kz);
+    ray.qd_ko = pin(ray.qd_ko), ray.c0 = pin(ray.c0), ray.ox = pin(ray.ox), ray.oy = pin(ray.oy), ray.oz = pin(ray.oz);
+    ray.root_sign = pin(ray.root_sign);
+    bowring_fast bw = A.bw;
+    bw.b_over_a = pin2(bw.b_over_a), bw.d = pin2(bw.d), bw.e2a = pin2(bw.e2a);
+    const double min_elev = pin2(A.bbox_min_elev);
+    double* const out_lat = pin2(A.lat);
+    double* const out_lon = pin2(A.lon);
+    double* const out_lat_c = pin2(A.lat_c);
+    double* const out_lon_c = pin2(A.lon_c);
+    double* const out_elev = pin2(A.elev);
+    const unsigned char* const img_base = pin2(static_cast<const unsigned char*>(A.bin_img));
+    const double bx_e0 = pin2(A.bxl.e0), bx_inv = pin2(A.bxl.inv_step), bx_margin = pin2(A.bxl.margin), by_e0 = pin2(A.byl.e0),
+                 by_inv = pin2(A.byl.inv_step), by_margin = pin2(A.byl.margin);
+    const int bx_n = pin2(A.bxl.nbin), by_n = pin2(A.byl.nbin);
+    const bool lon_wrap = pin2(A.bin_lon_wrap) != 0;
+    const double sm0 = pin2(B.math.small4[0]), sm1 = pin2(B.math.small4[1]), sm2 = pin2(B.math.small4[2]), sm3 = pin2(B.math.small4[3]);
+    const int frame_w = pin2(A.width), frame_h = pin2(A.height);
     // State of the previous corner row.  The row loop is unrolled by two with the roles of S0 / S1 swapped, so
-    // that no prev <- cur register moves are needed (they were ~30 of ~400 VALU instructions per row).
+    // that no prev <- cur register moves are needed.
     struct row_state {
         vec3 p, d;
         double la, lo;
         double bn, bd;      // Bowring numerator / denominator of the corner: lat = atan(bn / bd)
         double bla, blo;    // what the bounding box is reduced over when that is not (la, lo): MLat / SM longitude
+        vec3 s;             // MAG: the corner in SM coordinates, |(s.x, s.y)|, MLat and SM longitude (degrees)
+        double sxy, ml, sl;
         int flag;
     };
-    row_state S0 = {{NAN, NAN, NAN}, {NAN, NAN, NAN}, NAN, NAN, NAN, NAN, NAN, NAN, 0}, S1 = S0;
+    row_state S0 = {{NAN, NAN, NAN}, {NAN, NAN, NAN}, NAN, NAN, NAN, NAN, NAN, NAN, {NAN, NAN, NAN}, NAN, NAN, NAN, 0}, S1 = S0;
     // Neighbouring pixels differ by a fraction of a degree, so latitude and longitude of a corner are taken as
-    // the previous row's plus a small angle (small_angle_deg: one reciprocal and a 4-term series instead of a
-    // range-reduced 9-term arctangent), and a centre's as its corner's plus a small angle.  The full arctangent
+    // the previous row's plus a small angle (fx::small_angles: one reciprocal and two 4-term series instead of two
+    // range-reduced 9-term arctangents), and a centre's as its corner's plus a small angle.  The full arctangent
     // runs where that does not apply: first row of a chunk, previous row missed the shell, steps above 1.7 deg at
     // the limb, within 2 deg of the date line.
-    constexpr bool kDiff = true;
     constexpr bool kMagBox = MAG && BIN != 0;      // the box may be asked for in (MLat, SM longitude): bla / blo
     int n_valid = 0;
     auto box_add = [&](double la_v, double lo_v) {
@@ -526,7 +612,7 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
         a = a > img_last ? img_last : a;
         shift = (int)(byte_offset - a) * 8;
         uint2 w2;
-        __builtin_memcpy(&w2, static_cast<const unsigned char*>(A.bin_img) + a, 8);
+        __builtin_memcpy(&w2, img_base + a, 8);
         w0 = w2.x;
         w1 = w2.y;
     };
@@ -541,94 +627,199 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
         }
     };
 
-    // element indices of this lane's corner (row gy) and pixel (row gy-1), advanced by one row per step: keeps
-    // the quarter-rate 64-bit multiplies out of the loop
-    int64_t gi_corner = (int64_t)y0 * W1 + gx;
-    int64_t gi_pixel = (int64_t)(y0 - 1) * A.width + gx;
+    // byte offsets of this lane's corner (row gy) and pixel (row gy-1) inside their arrays, advanced by one row per
+    // step.  They fit 32 bits (the host checks), so every store is `base in SGPRs + 32-bit lane offset`.
+    unsigned int off_corner = (unsigned int)(y0 * W1 + gx) * 8u;
+    unsigned int off_pixel = (unsigned int)((y0 - 1) * A.width + gx) * 8u;      // row -1 wraps; used from row 0 on only
+    const unsigned int pitch_corner = (unsigned int)W1 * 8u, pitch_pixel = (unsigned int)A.width * 8u;
+    auto at = [](double* base, unsigned int byte_offset) -> double& {
+        return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_offset);
+    };
     // byte offset of pixel (gy-1, gx) in the image and of one image row (unsigned wrap-around for row -1 is harmless:
     // only offset + k rows with k >= 1 is ever used)
     const unsigned int img_row = (unsigned int)A.width * (BIN == 1 ? 3u : 6u);
-    unsigned int img_off = (unsigned int)gi_pixel * (BIN == 1 ? 3u : 6u);
+    unsigned int img_off = (unsigned int)((y0 - 1) * A.width + gx) * (BIN == 1 ? 3u : 6u);
+    // this lane's share of the affine camera model (see affine_ray): corner column gx - 1/2; the centre of pixel
+    // (row - 1, gx) is the corner (row, gx) plus half a column minus half a row
+    double ubx = 0, uby = 0, ubz = 0;
+    if (!DIRS_IN || !FAST) {
+#pragma clang fp contract(off)
+        const double px = (double)gx + cm.cx;
+        ubx = __builtin_fma(px, cm.ux[0], cm.u0[0]), uby = __builtin_fma(px, cm.ux[1], cm.u0[1]);
+        ubz = __builtin_fma(px, cm.ux[2], cm.u0[2]);
+    }
+    const double hcx = 0.5 * (cm.ux[0] - cm.uy[0]), hcy = 0.5 * (cm.ux[1] - cm.uy[1]), hcz = 0.5 * (cm.ux[2] - cm.uy[2]);
     // directions-in variant: the corner direction of the row after the current one
     double dj0 = NAN, dj1 = NAN, dj2 = NAN;
     if (DIRS_IN && col_ok) {
-        const double* q = A.dirs_in + 3 * gi_corner;
+        const double* q = A.dirs_in + 3 * ((int64_t)y0 * W1 + gx);
         dj0 = q[0], dj1 = q[1], dj2 = q[2];
     }
-    auto step = [&](const int r, const bool even, const row_state& prev, row_state& cur) {
+
+    // ---- pieces shared by the two paths ---------------------------------------------------------------------
+    typedef double coef4[4];
+    typedef double coef9[9];
+    struct c4 { coef4 c; };
+    struct c9 { coef9 c; };
+    auto small_table = [&]() {
+        c4 k = {{sm0, sm1, sm2, sm3}};
+        return k;
+    };
+    auto atan_table = [&]() { return karg_load<c9>(karg_fresh(), offsetof(georef_batch, math) + offsetof(fx::math_table, atan9)); };
+    auto full_angles = [&](double n, double d, double x, double y, double& la_v, double& lo_v) {
+        const c9 k = atan_table();
+        la_v = fx::atan_pos_deg(n, d, k.c);
+        lo_v = fx::atan2_deg(y, x, k.c);
+    };
+    // GEO point -> SM cartesian, |(x, y)|; then (MLat deg, SM longitude deg) as the reference point's plus two small
+    // angles (like latitude / longitude), the full arctangents where that does not apply.  MLT = SM longitude *
+    // 24/360 + 12 (reference transform.py:104-127,373-386,421-427).
+    auto sm_point = [&](const vec3& pt, vec3& sv, double& sxy) {
+#pragma clang fp contract(off)
+        sv = rotate3(karg_load<mat3>(karg_fresh(koff), offsetof(georef_args, m_geo_sm)), pt);
+        const double q = __builtin_fma(sv.x, sv.x, sv.y * sv.y);
+        sxy = q > 0 ? fx::sqrt_n(q) : 0.0;
+    };
+    auto sm_angles = [&](const vec3& ref, double ref_sxy, double ref_ml, double ref_sl, const vec3& sv, double sxy, double& ml,
+                         double& sl) {
+        double dml, dsl;
+        bool ok;
+        fx::small_angles(ref_sxy, ref.z, sxy, sv.z, ref.x, ref.y, sv.x, sv.y, small_table().c, dml, dsl, ok);
+        ok = ok && fabs(ref_sl) < 178.0;
+        ml = ref_ml + dml;
+        sl = ref_sl + dsl;
+        if (!ok) {
+            const c9 k = atan_table();
+            ml = fx::atan_pos_deg(sv.z, sxy, k.c);
+            sl = fx::atan2_deg(sv.y, sv.x, k.c);
+        }
+    };
+    // un-normalised direction of this lane's corner of row gy (GEO frame)
+    auto corner_ray = [&](int gy, const vec3& dj) -> vec3 {
+        if (DIRS_IN) return rotate3(karg_load<mat3>(karg_fresh(koff), offsetof(georef_args, m_geo)), dj);       // J2000 -> GEO
+        return affine_ray(ubx, uby, ubz, cm.uy[0], cm.uy[1], cm.uy[2], (double)gy + cm.cy);
+    };
+    // the image pixel of this step's centre row (see the comment at rawA0)
+    auto take_pixel = [&](int r, bool even, unsigned int& ch0, unsigned int& ch1, unsigned int& ch2) {
+        if (even) {
+            asm volatile("" : "+v"(rawA0), "+v"(rawA1), "+v"(rawB0), "+v"(rawB1));
+            unpack_pixel(rawA0, rawA1, shiftA, ch0, ch1, ch2);      // pixel row gy-1: this step's centres
+            curB0 = rawB0, curB1 = rawB1, curShiftB = shiftB;       // pixel row gy: the odd step's centres
+            // next pair: pixel rows gy+1 (even step r+2) and gy+2 (odd step r+3)
+            if (px_ok && r + 1 < rows) load_pixel(img_off + 2 * img_row, rawA0, rawA1, shiftA);
+            if (px_ok && r + 2 < rows) load_pixel(img_off + 3 * img_row, rawB0, rawB1, shiftB);
+        } else {
+            unpack_pixel(curB0, curB1, curShiftB, ch0, ch1, ch2);
+        }
+    };
+    // a pixel with its 1-based bins (0 = not binned) joins the lane's run; the run goes to the wave's LDS window
+    // when the cell changes
+    auto bin_account = [&](int bin_x, int bin_y, unsigned int ch0, unsigned int ch1, unsigned int ch2, long long el_fix) {
+        const unsigned long long m = __ballot(bin_x > 0);
+        if (m && !bin_anchor) {          // first kept pixel of this wave: centre the window on its cell
+            const int src = __builtin_ctzll(m);
+            bin_ax0 = __shfl(bin_x, src) - kBinW / 2;
+            bin_ay0 = __shfl(bin_y, src) - kBinW / 2;
+            bin_anchor = true;
+        }
+        // A lane walks down one pixel column: consecutive rows mostly stay in one cell, so the lane sums
+        // that run in registers and only touches the (conflict-prone) LDS window when the cell changes.
+        if (bin_x > 0) {
+            const int key = (bin_x << 16) | bin_y;
+            if (key != run_key) {
+                if (run_key) bin_flush(run_key, run_cnt, run_c0, run_c1, run_c2, run_el);
+                run_key = key;
+                run_cnt = 0;
+                run_c0 = run_c1 = run_c2 = 0;
+                run_el = 0;
+            }
+            run_cnt += 1;
+            run_c0 += ch0;
+            run_c1 += ch1;
+            run_c2 += ch2;
+            run_el += el_fix;
+        }
+    };
+    // bins of a valid pixel at (bxv, byv): common path without edges; anything near an edge or outside the axes
+    // sets `slow` (decided exactly by bin_slow)
+    auto bin_common = [&](double bxv, double byv, int& bx, int& by, bool& slow) {
+        bool slow_x, slow_y;
+        bx = bin_fast(bx_e0, bx_inv, bx_margin, bx_n, bxv, slow_x);
+        by = bin_fast(by_e0, by_inv, by_margin, by_n, byv, slow_y);
+        slow = slow_x || slow_y;
+    };
+    auto bin_slow = [&](double bxv, double byv, int& bx, int& by, unsigned int& edge_flags) {
+        karg_ptr K = karg_fresh(koff);
+        const axis_dev ax = karg_load<axis_dev>(K, offsetof(georef_args, bax));
+        bx = bin_index<true>(ax, bxv);
+        bx = bx > ax.nbin ? 0 : bx;
+        if (bx > 0 && on_lower_edge(ax, bx, bxv)) edge_flags |= 1u;
+        const axis_dev ay = karg_load<axis_dev>(K, offsetof(georef_args, bay));
+        by = bin_index<true>(ay, byv);
+        by = by > ay.nbin ? 0 : by;
+        if (by > 0 && on_lower_edge(ay, by, byv)) edge_flags |= 2u;
+    };
+
+    // ---- one corner row + the centre row above it --------------------------------------------------------------
+    auto step = [&](const int r, const bool even, const vec3& dj, const row_state& prev, row_state& cur) {
         const int gy = y0 + r;
         unsigned int ch0 = 0, ch1 = 0, ch2 = 0;          // image pixel (gy-1, gx)
         // ---- corner (gy, gx) ------------------------------------------------------------------
-        vec3 d = {NAN, NAN, NAN}, p = {NAN, NAN, NAN};
+        vec3 d = {NAN, NAN, NAN}, p = {NAN, NAN, NAN}, u = {NAN, NAN, NAN};
         double la = NAN, lo = NAN, bn = NAN, bd = NAN, bla = NAN, blo = NAN;
+        vec3 sv = {NAN, NAN, NAN};       // MAG: the corner in SM coordinates
+        double sxy = NAN, sml = NAN, ssl = NAN;
+        bool hit = false;
         if (col_ok) {
-            const int64_t gi = gi_corner;
-            karg_ptr K = karg_fresh(koff);
+            const shell_ray& ry = ray;
+            u = corner_ray(gy, dj);
+            const double uu = fx::dot3(u.x, u.y, u.z, u.x, u.y, u.z);
+            const double t = shell_t(ry, u, uu);
+            hit = t >= 0.0;
+            // unit direction (what the centre's elevation averages, reference astrometry.py:154-160); caller-supplied
+            // directions are used as they are, like the reference does
             if (DIRS_IN) {
-                // the direction of this corner was loaded one row ahead; fetch the next row's now, so that its
-                // latency is covered by this row's arithmetic
-                vec3 dj = {dj0, dj1, dj2};
-                asm volatile("" : "+v"(dj.x), "+v"(dj.y), "+v"(dj.z));
-                if (r < rows) {
-                    const double* q = A.dirs_in + 3 * (gi + W1);
-                    dj0 = q[0], dj1 = q[1], dj2 = q[2];
-                }
-                d = mul(karg_load<mat3>(K, offsetof(georef_args, m_geo)), dj);       // J2000 -> GEO
+                d = u;
             } else {
-                d = tan_direction_fast(karg_load<tan_wcs>(K, offsetof(georef_args, wcs_geo)), gx - 0.5, gy - 0.5);
+#pragma clang fp contract(off)
+                const double rs = fx::rsqrt_n(uu);
+                d.x = u.x * rs, d.y = u.y * rs, d.z = u.z * rs;
             }
-            const quadric_ray ray = karg_load<quadric_ray>(K, offsetof(georef_args, qray));
-            const double t = quadric_param(ray, d);
-            const bool hit = t == t;
             if (hit) {
-                p = quadric_point(ray, d, t);        // already in GEO
-                K = karg_fresh(koff);
+                p = shell_point(ry, u, t);           // already in GEO
                 double ir;
-                bowring_fast_nd(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), p.x, p.y, p.z, bn, bd, ir);
-                bool ok_la = false, ok_lo = false;
-                if (kDiff) {
-                    la = prev.la + small_angle_deg(prev.bd, prev.bn, bd, bn, ok_la);
-                    lo = prev.lo + small_angle_deg(prev.p.x, prev.p.y, p.x, p.y, ok_lo);
-                    ok_lo = ok_lo && fabs(prev.lo) < 178.0;
-                }
-                if (!ok_la) la = fm::atan_pos_deg(bn, bd);
-                if (!ok_lo) lo = fm::atan2_deg(p.y, p.x);
+                fx::bowring_nd(bw, p.x, p.y, p.z, bn, bd, ir);
+                double dla, dlo;
+                bool ok;
+                fx::small_angles(prev.bd, prev.bn, bd, bn, prev.p.x, prev.p.y, p.x, p.y, small_table().c, dla, dlo, ok);
+                ok = ok && fabs(prev.lo) < 178.0;
+                la = prev.la + dla;
+                lo = prev.lo + dlo;
+                if (!ok) full_angles(bn, bd, p.x, p.y, la, lo);
             }
-            if (BIN) {
-                if (even) {
-                    // The one wait of this pair of rows sits here, right before the step's first store: the youngest
-                    // store in flight (the centre row of the previous step) was issued a whole corner computation ago.
-                    asm volatile("" : "+v"(rawA0), "+v"(rawA1), "+v"(rawB0), "+v"(rawB1));
-                    unpack_pixel(rawA0, rawA1, shiftA, ch0, ch1, ch2);      // pixel row gy-1: this step's centres
-                    curB0 = rawB0, curB1 = rawB1, curShiftB = shiftB;       // pixel row gy: the odd step's centres
-                    // next pair: pixel rows gy+1 (even step r+2) and gy+2 (odd step r+3)
-                    if (px_ok && r + 1 < rows) load_pixel(img_off + 2 * img_row, rawA0, rawA1, shiftA);
-                    if (px_ok && r + 2 < rows) load_pixel(img_off + 3 * img_row, rawB0, rawB1, shiftB);
-                } else {
-                    unpack_pixel(curB0, curB1, curShiftB, ch0, ch1, ch2);
-                }
-            }
+            if (BIN) take_pixel(r, even, ch0, ch1, ch2);
             // the last corner row of a chunk is the first of the next one (which owns it) unless it is
             // the image's last; lane 63's column likewise belongs to the next strip unless it is the last
-            const bool owner = (lane < 63 || gx == A.width) && (r < rows || gy == A.height);
+            const bool owner = (lane < 63 || gx == frame_w) && (r < rows || gy == frame_h);
             if (owner) {
-                if (A.lat) A.lat[gi] = la;
-                if (A.lon) A.lon[gi] = lo;
+                if (out_lat) at(out_lat, off_corner) = la;
+                if (out_lon) at(out_lon, off_corner) = lo;
             }
             if (MAG) {
                 // with bin_magnetic the bounding box is reduced over (MLat, SM longitude) as well
                 const bool magbox = BIN && A.bin_magnetic;
-                if ((owner && A.mlat) || magbox) {
-                    double ml = NAN, mt = NAN;
-                    if (hit) sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(koff), offsetof(georef_args, m_geo_sm)), p), ml, mt);
-                    if (owner && A.mlat) {
-                        A.mlat[gi] = ml;
-                        A.mlt[gi] = mt;
-                    }
-                    if (magbox) {
-                        bla = ml;
-                        blo = (mt - 12.0) / (24.0 / 360.0);       // mltToSmLon, reference transform.py:388-401
-                    }
+                if (hit) {
+                    sm_point(p, sv, sxy);
+                    sm_angles(prev.s, prev.sxy, prev.ml, prev.sl, sv, sxy, sml, ssl);
+                }
+                const double mt = ssl * (24.0 / 360.0) + 12.0;
+                if (owner && A.mlat) {
+                    at(A.mlat, off_corner) = sml;
+                    at(A.mlt, off_corner) = mt;
+                }
+                if (magbox) {
+                    bla = sml;
+                    blo = (mt - 12.0) / (24.0 / 360.0);       // mltToSmLon, reference transform.py:388-401
                 }
                 if (kMagBox && !magbox) {
                     bla = la;
@@ -639,7 +830,8 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
         int flag_cur = 0;
         if (r > 0) {
             // ---- centre (gy-1, gx): corners own/next lane x previous/current row -----------------
-            vec3 pc, dc;
+            vec3 pc, dsum;
+            double dscale;               // centre direction = dsum * dscale
             bool corners_ok = true;
             if (FAST) {
                 // mean of the 4 corner hits / directions (reference astrometry.py:154-160); the summation
@@ -649,14 +841,25 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
                 pc.x = (sx + from_next_lane(sx)) * 0.25;
                 pc.y = (sy + from_next_lane(sy)) * 0.25;
                 pc.z = (sz + from_next_lane(sz)) * 0.25;
-                dc.x = (tx + from_next_lane(tx)) * 0.25;
-                dc.y = (ty + from_next_lane(ty)) * 0.25;
-                dc.z = (tz + from_next_lane(tz)) * 0.25;
+                dsum.x = tx + from_next_lane(tx);
+                dsum.y = ty + from_next_lane(ty);
+                dsum.z = tz + from_next_lane(tz);
+                dscale = 0.25;
             } else {
-                karg_ptr K = karg_fresh(koff);
-                dc = tan_direction_fast(karg_load<tan_wcs>(K, offsetof(georef_args, wcs_geo)), (double)gx, (double)(gy - 1));
-                const quadric_ray ray = karg_load<quadric_ray>(K, offsetof(georef_args, qray));
-                pc = quadric_point(ray, dc, quadric_param(ray, dc));
+                // the pixel's own ray (exact centres): the corner's plus half a column minus half a row
+                const shell_ray& ry = ray;
+                vec3 uc;
+                double uuc;
+                {
+#pragma clang fp contract(off)
+                    uc.x = u.x + hcx, uc.y = u.y + hcy, uc.z = u.z + hcz;
+                    uuc = fx::dot3(uc.x, uc.y, uc.z, uc.x, uc.y, uc.z);
+                    const double rs = fx::rsqrt_n(uuc);
+                    dsum.x = uc.x * rs, dsum.y = uc.y * rs, dsum.z = uc.z * rs;
+                }
+                dscale = 1.0;
+                const double tc = shell_t(ry, uc, uuc);
+                pc = shell_point(ry, uc, tc >= 0.0 ? tc : NAN);
                 if (want_bbox) {
                     // after sanitisation a centre also needs its 4 corners (reference mapping.py:1093-1101)
                     const int h = (prev.p.x == prev.p.x) && (p.x == p.x);
@@ -667,61 +870,52 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
             int bin_x = 0, bin_y = 0;            // 1-based bin indices of this pixel, 0 = not binned
             long long el_fix = 0;
             if (px_ok) {
-                const int64_t gi = gi_pixel;
                 double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN;
                 if (pc.x == pc.x) {
-                    karg_ptr K = karg_fresh(koff);
                     double inv_r, cn, cd;
-                    bowring_fast_nd(karg_load<bowring_fast>(K, offsetof(georef_args, bw)), pc.x, pc.y, pc.z, cn, cd, inv_r);
-                    bool ok_la = false, ok_lo = false;
-                    if (kDiff) {                 // relative to this lane's corner of the current row
-                        lac = la + small_angle_deg(bd, bn, cd, cn, ok_la);
-                        loc = lo + small_angle_deg(p.x, p.y, pc.x, pc.y, ok_lo);
-                        ok_lo = ok_lo && fabs(lo) < 178.0;
-                    }
-                    if (!ok_la) lac = fm::atan_pos_deg(cn, cd);
-                    if (!ok_lo) loc = fm::atan2_deg(pc.y, pc.x);
+                    fx::bowring_nd(bw, pc.x, pc.y, pc.z, cn, cd, inv_r);
+                    // relative to this lane's corner of the current row
+                    double dla, dlo;
+                    bool ok;
+                    fx::small_angles(bd, bn, cd, cn, p.x, p.y, pc.x, pc.y, small_table().c, dla, dlo, ok);
+                    ok = ok && fabs(lo) < 178.0;
+                    lac = la + dla;
+                    loc = lo + dlo;
+                    if (!ok) full_angles(cn, cd, pc.x, pc.y, lac, loc);
                     // reference astrometry.py:200-212, utils.py:33-46: 90 - angle(-d, P/|P|) = asin(-d.P/|P|)
                     // (dot products do not depend on the frame; 1/|P| is a by-product of the Bowring step)
-                    double c = -(dc.x * pc.x + dc.y * pc.y + dc.z * pc.z) * inv_r;
+                    double c = -(fx::dot3(dsum.x, dsum.y, dsum.z, pc.x, pc.y, pc.z) * dscale) * inv_r;
                     c = fmin(1.0, fmax(-1.0, c));
-                    el = fm::asin_deg(c);
-                    if (MAG && (A.mlat_c || (BIN && A.bin_magnetic)))
-                        sm_to_mlat_mlt_fast(mul(karg_load<mat3>(karg_fresh(koff), offsetof(georef_args, m_geo_sm)), pc), ml, mt);
+                    el = fx::asin_deg(c, atan_table().c);
+                    if (MAG) {
+                        // relative to this lane's corner of the current row, like latitude and longitude
+                        vec3 sc;
+                        double sxyc, slc;
+                        sm_point(pc, sc, sxyc);
+                        sm_angles(sv, sxy, sml, ssl, sc, sxyc, ml, slc);
+                        mt = slc * (24.0 / 360.0) + 12.0;
+                    }
                 }
-                if (A.lat_c) A.lat_c[gi] = lac;
-                if (A.lon_c) A.lon_c[gi] = loc;
-                if (A.elev) A.elev[gi] = el;
+                if (out_lat_c) at(out_lat_c, off_pixel) = lac;
+                if (out_lon_c) at(out_lon_c, off_pixel) = loc;
+                if (out_elev) at(out_elev, off_pixel) = el;
                 if (MAG && A.mlat_c) {
-                    A.mlat_c[gi] = ml;
-                    A.mlt_c[gi] = mt;
+                    at(A.mlat_c, off_pixel) = ml;
+                    at(A.mlt_c, off_pixel) = mt;
                 }
-                valid = (el >= A.bbox_min_elev) && corners_ok;
+                valid = (el >= min_elev) && corners_ok;
                 if (BIN && valid) {
                     // reference resample.py:301-351 on (lon, lat) or, for resampleMLatMLT, on
                     // (SM longitude = mltToSmLon(mlt), MLat) (mapping.py:1519-1547, transform.py:388-401)
                     double bxv = (MAG && A.bin_magnetic) ? (mt - 12.0) / (24.0 / 360.0) : loc;
                     const double byv = (MAG && A.bin_magnetic) ? ml : lac;
-                    karg_ptr K = karg_fresh(koff);
-                    if (karg_load<long long>(K, offsetof(georef_args, bin_lon_wrap)) & 0xffffffffll) bxv = wrap180_shifted(bxv);
-                    bool slow_x, slow_y;
-                    int bx = bin_fast(karg_load<axis_lin>(K, offsetof(georef_args, bxl)), bxv, slow_x);
-                    int by = bin_fast(karg_load<axis_lin>(K, offsetof(georef_args, byl)), byv, slow_y);
+                    if (lon_wrap) bxv = wrap180_shifted(bxv);
+                    int bx, by;
+                    bool slow;
+                    bin_common(bxv, byv, bx, by, slow);
                     unsigned int edge_flags = 0;
-                    if (__ballot(slow_x || slow_y)) {          // wave-uniform and rare
-                        K = karg_fresh(koff);
-                        if (slow_x) {
-                            const axis_dev ax = karg_load<axis_dev>(K, offsetof(georef_args, bax));
-                            bx = bin_index<true>(ax, bxv);
-                            bx = bx > ax.nbin ? 0 : bx;
-                            if (bx > 0 && on_lower_edge(ax, bx, bxv)) edge_flags |= 1u;
-                        }
-                        if (slow_y) {
-                            const axis_dev ay = karg_load<axis_dev>(K, offsetof(georef_args, bay));
-                            by = bin_index<true>(ay, byv);
-                            by = by > ay.nbin ? 0 : by;
-                            if (by > 0 && on_lower_edge(ay, by, byv)) edge_flags |= 2u;
-                        }
+                    if (__ballot(slow)) {          // wave-uniform and rare
+                        if (slow) bin_slow(bxv, byv, bx, by, edge_flags);
                     }
                     if (bx > 0 && by > 0) {
                         el_fix = __double2ll_rn(el * kFix);
@@ -748,32 +942,7 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
                     }
                 }
             }
-            if (BIN) {
-                const unsigned long long m = __ballot(bin_x > 0);
-                if (m && !bin_anchor) {          // first kept pixel of this wave: centre the window on its cell
-                    const int src = __builtin_ctzll(m);
-                    bin_ax0 = __shfl(bin_x, src) - kBinW / 2;
-                    bin_ay0 = __shfl(bin_y, src) - kBinW / 2;
-                    bin_anchor = true;
-                }
-                // A lane walks down one pixel column: consecutive rows mostly stay in one cell, so the lane sums
-                // that run in registers and only touches the (conflict-prone) LDS window when the cell changes.
-                if (bin_x > 0) {
-                    const int key = (bin_x << 16) | bin_y;
-                    if (key != run_key) {
-                        if (run_key) bin_flush(run_key, run_cnt, run_c0, run_c1, run_c2, run_el);
-                        run_key = key;
-                        run_cnt = 0;
-                        run_c0 = run_c1 = run_c2 = 0;
-                        run_el = 0;
-                    }
-                    run_cnt += 1;
-                    run_c0 += ch0;
-                    run_c1 += ch1;
-                    run_c2 += ch2;
-                    run_el += el_fix;
-                }
-            }
+            if (BIN) bin_account(bin_x, bin_y, ch0, ch1, ch2, el_fix);
             if (want_bbox) {
                 // corner row gy-1 is final now: it keeps a corner when a centre above (prev.flag) or below
                 // (this row: own pixel or the left neighbour's) is valid
@@ -787,9 +956,6 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
                 }
             }
         }
-        gi_corner += W1;
-        gi_pixel += A.width;
-        img_off += img_row;
         cur.p = p;
         cur.d = d;
         cur.la = la;
@@ -800,12 +966,35 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
             cur.bla = bla;
             cur.blo = blo;
         }
+        if (MAG) {
+            cur.s = sv;
+            cur.sxy = sxy;
+            cur.ml = sml;
+            cur.sl = ssl;
+        }
         cur.flag = flag_cur;
+    };
+
+    auto advance = [&](const int r, const bool even, const row_state& prev, row_state& cur) {
+        vec3 dj = {dj0, dj1, dj2};
+        if (DIRS_IN) {
+            // the direction of this corner was loaded one row ahead; fetch the next row's now, so that its
+            // latency is covered by this row's arithmetic
+            asm volatile("" : "+v"(dj.x), "+v"(dj.y), "+v"(dj.z));
+            if (col_ok && r < rows) {
+                const double* q = A.dirs_in + 3 * ((int64_t)(y0 + r + 1) * W1 + gx);
+                dj0 = q[0], dj1 = q[1], dj2 = q[2];
+            }
+        }
+        step(r, even, dj, prev, cur);
+        off_corner += pitch_corner;
+        off_pixel += pitch_pixel;
+        img_off += img_row;
     };
     if (BIN && px_ok && rows > 0) load_pixel(img_off + img_row, rawB0, rawB1, shiftB);       // pixel row y0: step 1
     for (int r = 0; r <= rows; r += 2) {
-        step(r, true, S0, S1);
-        if (r + 1 <= rows) step(r + 1, false, S1, S0); else S0 = S1;      // the last row's state ends up in S0
+        advance(r, true, S0, S1);
+        if (r + 1 <= rows) advance(r + 1, false, S1, S0); else S0 = S1;      // the last row's state ends up in S0
     }
     if (BIN && bin_anchor) {
         if (run_key) bin_flush(run_key, run_cnt, run_c0, run_c1, run_c2, run_el);
@@ -1002,6 +1191,24 @@ launch_shape shape_of(const amt_frame_params* p) {
     return s;
 }
 
+// Stride s of the interleaved chunk order (item_order 3): rows of work items are visited in the order (k * s) mod n,
+// s coprime to n and close to n / golden ratio, so that any stretch of the launch samples the whole frame evenly.
+int interleave_stride(int n) {
+    if (n < 3) return 1;
+    auto gcd = [](int a, int b) {
+        while (b) {
+            const int t = a % b;
+            a = b;
+            b = t;
+        }
+        return a;
+    };
+    int s = (int)(n * 0.6180339887498949);
+    if (s < 1) s = 1;
+    while (gcd(s, n) != 1) ++s;
+    return s % n ? s % n : 1;
+}
+
 // One frame of a launch, validated and with its kernel arguments assembled
 struct prepared_frame {
     georef_args A;
@@ -1032,9 +1239,10 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
         // GEO-frame constants of k_georef_rows: camera model and SM rotation composed with M = J2000 -> GEO
         double rot_geo[9], mt[9], geo_sm[9];
         mat_mul3(p->m_geo, p->rot, rot_geo);
-        A.wcs_geo = A.wcs;
-        A.wcs_geo.rot = make_mat3(rot_geo);
-        A.qray = make_quadric_ray(p->a, p->b, p->cam, p->m_geo);
+        tan_wcs wcs_geo = A.wcs;
+        wcs_geo.rot = make_mat3(rot_geo);
+        A.cam = make_affine_cam(wcs_geo);
+        A.sray = make_shell_ray(p->a, p->b, p->cam, p->m_geo);
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) mt[3 * i + j] = p->m_geo[3 * j + i];
         mat_mul3(p->m_sm, mt, geo_sm);               // M_sm M^T: GEO -> SM
@@ -1061,8 +1269,14 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     A.bin_events = nullptr;
     A.bin_event_count = nullptr;
     A.bin_event_cap = 0;
-    A.item_order = out->item_order >= 1 && out->item_order <= 2 ? out->item_order : (dirs ? 1 : nadir_side(p));
-    A.pad_ = 0;
+    // AMT_ITEM_ORDER = 1, 2, 3 overrides the order for A/B runs
+    static const int forced_order = [] {
+        const char* e = std::getenv("AMT_ITEM_ORDER");
+        return e ? std::atoi(e) : 0;
+    }();
+    A.item_order = out->item_order >= 1 && out->item_order <= 3 ? out->item_order : (dirs ? 1 : nadir_side(p));
+    if (forced_order >= 1 && forced_order <= 3) A.item_order = forced_order;
+    A.chunk_stride = 1;
     std::memset(&A.bax, 0, sizeof(A.bax));
     std::memset(&A.bay, 0, sizeof(A.bay));
     std::memset(&A.bxl, 0, sizeof(A.bxl));
@@ -1092,9 +1306,13 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
         bin = out->bin_img_dtype;
     }
     const launch_shape sh = shape_of(p);
+    A.chunk_stride = interleave_stride(sh.chunks_y);
     const bool use_tiles = sh.use_tiles;
     const int64_t n_items = sh.n_items;
     AMT_REQUIRE(ctx, n_items < (1ll << 31), "frame too large");
+    // the row-marching kernel addresses its arrays with 32-bit byte offsets
+    AMT_REQUIRE(ctx, use_tiles || ((int64_t)p->width + 1) * ((int64_t)p->height + 1) * 8 < (1ll << 32),
+                "frame too large (more than 2^29 pixel corners)");
     A.bbox_partials = nullptr;
     double* fold = nullptr;
     if (out->bbox) {
@@ -1164,6 +1382,7 @@ int launch_prepared(amt_ctx* ctx, int n, prepared_frame* F) {
     } else {
         georef_batch B;
         for (int i = 0; i < kMaxBatch; ++i) B.f[i] = F[i < n ? i : 0].A;
+        B.math = fx::make_math_table();
         if (dirs) {
             launch_rows<true, true>(ctx, B, n, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
         } else if (p->fast_center) {

@@ -139,7 +139,7 @@ def test_gathered_dateline_frame_keeps_its_true_coordinates():
     from auromat_amd.synthetic import frame_header, frame_image
     w, h = 253, 171
     hdr, cam, t = frame_header(w, h, 'iss029')
-    t = t - timedelta(minutes=20)           # the Earth turns 5 deg under the fixed footprint
+    t = t - timedelta(minutes=80)           # same inertial geometry, the Earth 20 deg further west (142..168 E before)
     img = frame_image(w, h, seed=5)
     want = FramePipeline(w, h).run(hdr, 110, cam, t, img=img, pxPerDeg=5)
     assert want['contains_discontinuity']
