@@ -56,6 +56,14 @@ class Grid(C.Structure):
                                           'lon_center_last')] + [('xaxis', Axis), ('yaxis', Axis)]
 
 
+class SeqFrame(C.Structure):
+    """amt_seq_frame"""
+    _fields_ = [('ny', C.c_int32), ('nx', C.c_int32), ('nc', C.c_int32), ('index', C.c_int32),
+                ('lat0', C.c_double), ('lon0', C.c_double), ('dlat', C.c_double), ('dlon', C.c_double),
+                ('contains_pole', C.c_int32), ('contains_discontinuity', C.c_int32), ('magnetic', C.c_int32),
+                ('reserved', C.c_int32), ('altitude', C.c_double), ('mean', C.c_void_p), ('count', C.c_void_p)]
+
+
 class PipeResult(C.Structure):
     """amt_pipe_result"""
     _fields_ = [('status', C.c_int32), ('fused', C.c_int32), ('lon_wrapped', C.c_int32), ('edge_pixels', C.c_int32),
@@ -129,6 +137,9 @@ _SIGNATURES = {
     'amt_pipe_wait': ([_P, C.POINTER(PipeResult)], _I),
     'amt_pipe_finalize': ([_P, _P, _P, _P, _P], _I),
     'amt_pipe_join': ([_P], _I),
+    'amt_seq_payload_size': ([C.POINTER(SeqFrame), C.c_int32, C.POINTER(_L)], _I),
+    'amt_seq_pack': ([_P, C.POINTER(SeqFrame), C.c_int32, C.c_int32, _P, _L], _I),
+    'amt_seq_unpack': ([_P, _L, C.c_int32, C.c_int32, C.POINTER(SeqFrame), C.c_int32, C.POINTER(C.c_int32)], _I),
 }
 
 _lib = None

@@ -1,0 +1,301 @@
+"""
+``auromat-convert`` on the MI355X path: georeference (and optionally resample) a sequence of frames and write one
+netCDF file per frame — the flag set and the flow of the reference's console script (auromat/cli/convert.py:58-219).
+
+What differs, and why:
+
+* ``--data`` is a directory of frames as ``<id>.wcs`` (an astrometry.net FITS header as 80-column cards, or a ``.json``
+  dict of the same cards: ``CRVAL*``, ``CD*``, ``CRPIX*``, ``IMAGEW/H``, ``DATE-OBS`` [+ ``DATESHIF``], ``POS?``
+  [+ ``POS?SHIF``]) next to ``<id>.npy`` (uint8 / uint16 array (h, w, 3)).  The reference reads provider archives
+  there (ESA ISS ``api.json``, THEMIS ``thg_l1_*`` CDFs): downloads, RAW development and the CDF library are its I/O
+  layer, not part of this package — ``--bps``, ``--correctgamma`` and ``--autobright`` belong to that layer and are
+  accepted but have nothing to act on.
+* ``--format netcdf`` only (``cdf`` needs NASA's CDF library through spacepy); the files are netCDF classic
+  (:mod:`auromat_amd.export._nc3`).
+* ``--resample`` with ``--resolution`` (arcsec / px, the reference's flag) goes frame by frame through the mapping
+  classes, because the reference derives the grid's px/deg from each frame's own bounding box
+  (``plateCarreeResolution``).  ``--px-per-deg N`` (an addition) fixes the grid instead and runs the sequence through
+  the single-pass frame pipeline (:class:`auromat_amd.pipeline.SequencePipeline`, grids only: no per-pixel array is
+  ever written or copied to the host); with several GPUs (``torchrun --nproc-per-node N -m auromat_amd.cli.convert``)
+  the frames are sharded over the ranks and every rank writes the files of its own frames.
+"""
+from __future__ import print_function
+
+import argparse
+import json
+import os
+import sys
+from datetime import datetime, timedelta
+
+import numpy as np
+import numpy.ma as ma
+
+description = 'Georeference frames on the GPU, optionally resample them, and store them as netCDF files.'
+
+epilog = '''
+Resample on the geomagnetic grid with the reference's resolution rule:
+auromat-convert --data frames/ --format netcdf --resample --resolution 80
+
+Resample a long sequence on a fixed 0.1 degree geographic grid, as fast as the GPU goes:
+auromat-convert --data frames/ --format netcdf --resample --grid geo --px-per-deg 10
+
+Don't store pixel corner coordinates:
+auromat-convert --data frames/ --format netcdf --without-bounds
+'''
+
+
+class Grid(object):
+    geo = 'geo'
+    mag = 'mag'
+
+
+class Format(object):
+    cdf = 'cdf'
+    netcdf = 'netcdf'
+
+
+def date(s):
+    return datetime.strptime(s, '%Y-%m-%dT%H:%M:%S')
+
+
+def getParser():
+    parser = argparse.ArgumentParser(prog='auromat-convert', epilog=epilog, description=description,
+                                     formatter_class=argparse.RawDescriptionHelpFormatter)
+    parser.add_argument('--data', help='Data directory, by default the current directory: <id>.wcs (or <id>.json) '
+                                       'header files next to <id>.npy images.', default=os.getcwd())
+    period = parser.add_argument_group('period', 'These arguments optionally specify which data to convert.')
+    period.add_argument('--start', help='UTC start date, format 2000-01-01T12:00:00', type=date)
+    period.add_argument('--end', help='UTC end date (inclusive)', type=date)
+    mappingArgs = parser.add_argument_group('mapping')
+    mappingArgs.add_argument('--altitude', help='Altitude in km onto which to map the images, default is 110km',
+                             default=110, type=int)
+    mappingArgs.add_argument('--exact-centers', dest='exactCenters', action='store_true',
+                             help='Cast a ray through every pixel centre (the reference\'s getMapping default) instead of '
+                                  'averaging the four corner hits.')
+    mappingArgs.add_argument('--min-elevation', dest='minElevation', type=float, default=10.0,
+                             help='Mask pixels seen under a smaller elevation angle before resampling (the user guide\'s '
+                                  'recommendation, docs/userguide: 10 degrees); negative to disable.')
+    esaIssArgs = parser.add_argument_group('ESA ISS data (accepted for compatibility; RAW development is not part of this package)')
+    esaIssArgs.add_argument('--bps', help='bits per sample, default is 16', choices=[8, 16], default=16, type=int)
+    esaIssArgs.add_argument('--correctgamma', action='store_true')
+    esaIssArgs.add_argument('--autobright', action='store_true')
+    resampleArgs = parser.add_argument_group('resampling')
+    resampleArgs.add_argument('--resample', help='Whether to resample or not', action='store_true')
+    resampleArgs.add_argument('--resolution', metavar='RES', help='in arcsec/px, default 100', default=100, type=float)
+    resampleArgs.add_argument('--px-per-deg', dest='pxPerDeg', metavar='N', type=float,
+                              help='fixed grid resolution in pixels per degree instead of --resolution: the sequence then '
+                                   'runs through the single-pass frame pipeline')
+    resampleArgs.add_argument('--grid', help='The grid which will be regular after resampling. Default is MLat/MLT grid. '
+                                             'Use geo for geographical grid.', default=Grid.mag, choices=[Grid.geo, Grid.mag])
+    outputArgs = parser.add_argument_group('output')
+    outputArgs.add_argument('--out', help='Output directory, by default the "converted" subdirectory of --data')
+    outputArgs.add_argument('--overwrite', help='Overwrites existing files.', action='store_true')
+    outputArgs.add_argument('--skip', help='Skips already converted files.', action='store_true')
+    outputArgs.add_argument('--format', help='Data format of converted files', choices=[Format.cdf, Format.netcdf],
+                            required=True)
+    outputArgs.add_argument('--without-bounds', dest='withoutBounds', action='store_true',
+                            help='Do not include coordinates of pixel corners. If set, then only the pixel center '
+                                 'coordinates are written, otherwise both.')
+    outputArgs.add_argument('--without-mag', dest='withoutMag', help='Do not include MLat/MLT coordinates.',
+                            action='store_true')
+    outputArgs.add_argument('--without-geo', dest='withoutGeo', action='store_true',
+                            help='Do not include geodetic coordinates. Only usable with CDF output.')
+    parser.add_argument('--version', action='version', version='auromat_amd (MI355X)')
+    return parser
+
+
+def parseargs(argv=None):
+    parser = getParser()
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) == 0:
+        parser.print_help()
+        sys.exit(1)
+    args = parser.parse_args(argv)
+    if not args.out:
+        args.out = os.path.join(args.data, 'converted')
+    if args.overwrite and args.skip:
+        parser.error('only one of --overwrite and --skip is allowed')
+    if args.withoutGeo and args.format == Format.netcdf:
+        parser.error('--without-geo is only usable with --format cdf')
+    if args.format == Format.cdf:
+        parser.error('--format cdf needs NASA\'s CDF library (spacepy.pycdf), which this package does not wrap; use netcdf')
+    return args
+
+
+# ---- input: a directory of headers + arrays ---------------------------------------------------------------------
+def read_header(path):
+    """A FITS header stored as 80-column ASCII cards (what astrometry.net's .wcs files are) or as JSON -> dict."""
+    if path.endswith('.json'):
+        with open(path) as fp:
+            return json.load(fp)
+    with open(path, 'rb') as fp:
+        raw = fp.read().decode('ascii', 'replace')
+    hdr = {}
+    for i in range(0, len(raw) - 79, 80):
+        card = raw[i:i + 80]
+        key = card[:8].strip()
+        if key == 'END':
+            break
+        if card[8:10] != '= ':
+            continue
+        val = card[10:]
+        if val.lstrip().startswith("'"):
+            hdr[key] = val.lstrip()[1:].split("'")[0].rstrip()
+        else:
+            val = val.split('/')[0].strip()
+            if val in ('T', 'F'):
+                hdr[key] = val == 'T'
+            else:
+                try:
+                    hdr[key] = int(val)
+                except ValueError:
+                    try:
+                        hdr[key] = float(val.replace('D', 'E'))
+                    except ValueError:
+                        hdr[key] = val
+    return hdr
+
+
+def list_frames(data_dir, start=None, end=None):
+    """-> sorted list of (identifier, header dict, image path) within [start, end] by (shifted) photo time."""
+    from ..mapping.spacecraft import getPhotoTime
+    frames = []
+    for name in sorted(os.listdir(data_dir)):
+        base, ext = os.path.splitext(name)
+        if ext not in ('.wcs', '.json'):
+            continue
+        img = os.path.join(data_dir, base + '.npy')
+        if not os.path.exists(img):
+            continue
+        hdr = read_header(os.path.join(data_dir, name))
+        t = getPhotoTime(hdr)
+        if t is None:
+            continue
+        if 'DATESHIF' in hdr:
+            t = t + timedelta(seconds=float(hdr['DATESHIF']))
+        if (start and t < start) or (end and t > end):
+            continue
+        frames.append((t, base, hdr, img))
+    frames.sort(key=lambda f: f[0])
+    return [(b, h, i) for _, b, h, i in frames]
+
+
+def target_path(args, identifier):
+    """-> path to write, or None when the frame is to be skipped; exits like the reference when the file exists."""
+    path = os.path.join(args.out, identifier + '.nc')
+    if os.path.exists(path):
+        if args.skip:
+            print('skipping', path)
+            return None
+        elif args.overwrite:
+            os.remove(path)
+        else:
+            print('The file', path, 'already exists.\nPlease use --skip or --overwrite, or a different output folder.',
+                  file=sys.stderr)
+            sys.exit(1)
+    return path
+
+
+# ---- the two ways through the GPU ----------------------------------------------------------------------------
+def convert_with_classes(args, frames, export):
+    """Frame by frame through the mapping classes: the reference's flow, its resolution rule included."""
+    from ..mapping.spacecraft import getMapping
+    from ..resample import resample, resampleMLatMLT
+    for identifier, hdr, img_path in frames:
+        path = target_path(args, identifier)
+        if path is None:
+            continue
+        mapping = getMapping(np.load(img_path), hdr, altitude=args.altitude,
+                             fastCenterCalculation=not args.exactCenters, identifier=identifier)
+        if args.resample:
+            if args.minElevation >= 0:
+                mapping = mapping.maskedByElevation(args.minElevation)
+            fn = resample if args.grid == Grid.geo else resampleMLatMLT
+            mapping = fn(mapping, arcsecPerPx=args.resolution)
+        print('storing', path)
+        export(path, mapping)
+
+
+def grid_mapping(res, cam, t, altitude, identifier, magnetic):
+    """The resampled grid of one frame (host arrays of the few hundred KB the pipeline returns) as the mapping that
+    ``resample`` / ``resampleMLatMLT`` would have returned: a GenericMapping in geodetic coordinates; a grid that is
+    regular in (MLat, SM longitude) goes through SM -> GEO like ``convertSMMappingToGeo`` (reference
+    mapping.py:1549-1559)."""
+    from ..coordinates.transform import smToLatLon
+    from ..mapping.mapping import GenericMapping
+    lat, lon, lat_c, lon_c = res['lat'], res['lon'], res['lat_c'], res['lon_c']
+    if magnetic:
+        lat, lon = smToLatLon(lat, lon, t)
+        lat_c, lon_c = smToLatLon(lat_c, lon_c, t)
+    img = ma.masked_array(res['img'], mask=np.repeat(res['mask'][:, :, None], res['img'].shape[2], 2))
+    return GenericMapping(lat, lon, lat_c, lon_c, ma.masked_invalid(res['mean'][:, :, -1]), altitude, img, cam, t, identifier)
+
+
+def convert_with_pipeline(args, frames, export):
+    """The whole sequence through the single-pass frame pipeline at a fixed px/deg; this rank's share of the frames."""
+    import torch
+    import torch.distributed as dist
+    from ..mapping.spacecraft import frame_inputs
+    from ..pipeline import SequencePipeline
+    from ..resample import grid_coordinates
+    from ..sequence import shard
+    from .._native import to_host
+    distributed = 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) > 1
+    rank, world = 0, 1
+    if distributed:
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group('nccl')
+        rank, world = dist.get_rank(), dist.get_world_size()
+    todo = []
+    for identifier, hdr, img_path in [frames[k] for k in shard(len(frames), rank, world)]:
+        path = target_path(args, identifier)
+        if path is not None:
+            todo.append((identifier, hdr, img_path, path))
+    if todo:
+        first = np.load(todo[0][2], mmap_mode='r')
+        magnetic = args.grid == Grid.mag
+        seq = SequencePipeline(first.shape[1], first.shape[0], nchan=first.shape[2], img_dtype=first.dtype,
+                               altitude=args.altitude, fast=not args.exactCenters,
+                               min_elevation=args.minElevation if args.minElevation >= 0 else None,
+                               pxPerDeg=args.pxPerDeg, magnetic=magnetic, keep_coordinates=False)
+
+        def feed():
+            for identifier, hdr, img_path, path in todo:
+                cam, t = frame_inputs(hdr)
+                yield hdr, cam, t, np.load(img_path)
+
+        metas = [frame_inputs(hdr) for _, hdr, _, _ in todo]
+        results = seq.process(feed(), keep_on_device=True)
+        for (identifier, hdr, img_path, path), (cam, t), res in zip(todo, metas, results):
+            if res is None:
+                print('no valid pixel in', identifier, file=sys.stderr)
+                continue
+            host = dict(res)
+            host.update(grid_coordinates(res))
+            host.update(mean=to_host(res['mean']), img=to_host(res['img'], dtype=first.dtype), mask=to_host(res['mask']).astype(bool))
+            print('storing', path)
+            export(path, grid_mapping(host, cam, t, args.altitude, identifier, magnetic))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = parseargs(argv)
+    from functools import partial
+    from ..export.netcdf import write
+    frames = list_frames(args.data, args.start, args.end)
+    if not frames:
+        raise NotImplementedError('No <id>.wcs / <id>.json + <id>.npy frames found in ' + args.data)
+    export = partial(write, includeBounds=not args.withoutBounds, includeMagCoords=not args.withoutMag,
+                     includeGeoCoords=not args.withoutGeo)
+    os.makedirs(args.out, exist_ok=True)
+    if args.resample and args.pxPerDeg:
+        convert_with_pipeline(args, frames, export)
+    else:
+        convert_with_classes(args, frames, export)
+    print('Done.')
+
+
+if __name__ == '__main__':
+    main()

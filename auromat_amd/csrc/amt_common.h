@@ -24,8 +24,10 @@ struct amt_ctx {
         hipStream_t stream;
         void* ptr;
         size_t bytes;
+        unsigned long long last_use;
     };
     std::vector<workspace> workspaces;
+    unsigned long long workspace_clock;
     std::string last_error;
     // side streams shared by all frame drivers of this context (created by the first amt_pipe_create): every
     // extra stream competes for the few hardware queues of the process, and streams that share a hardware queue
@@ -87,14 +89,31 @@ int amt_bin_finalize_on(amt_ctx* ctx, hipStream_t stream, uint64_t* acc, int32_t
 // Returns the device workspace of the context's CURRENT stream, at least `bytes` large (grow-only; reallocation
 // synchronises that stream).  The Python host switches the context between torch streams (frame k is binned on one
 // while frame k+1 is georeferenced on another), so scratch memory is kept per stream.
+// At most kMaxWorkspaces streams keep one: a host that keeps creating streams (torch does, per thread) would otherwise
+// leak a megabyte per stream ever seen; the least recently used one is synchronised and freed.
+constexpr size_t kMaxWorkspaces = 16;
 static inline void* amt_workspace(amt_ctx* ctx, size_t bytes) {
     amt_ctx::workspace* w = nullptr;
     for (auto& e : ctx->workspaces)
         if (e.stream == ctx->stream) w = &e;
     if (w == nullptr) {
-        ctx->workspaces.push_back({ctx->stream, nullptr, 0});
+        if (ctx->workspaces.size() >= kMaxWorkspaces) {
+            size_t lru = 0;
+            for (size_t i = 1; i < ctx->workspaces.size(); ++i)
+                if (ctx->workspaces[i].last_use < ctx->workspaces[lru].last_use) lru = i;
+            amt_ctx::workspace& old = ctx->workspaces[lru];
+            if (old.ptr) {
+                // (the stream may have been destroyed by its owner: then everything on it has completed)
+                (void)hipStreamSynchronize(old.stream);
+                (void)hipGetLastError();
+                (void)hipFree(old.ptr);
+            }
+            ctx->workspaces.erase(ctx->workspaces.begin() + (long)lru);
+        }
+        ctx->workspaces.push_back({ctx->stream, nullptr, 0, 0});
         w = &ctx->workspaces.back();
     }
+    w->last_use = ++ctx->workspace_clock;
     if (bytes <= w->bytes) return w->ptr;
     if (w->ptr) {
         (void)hipStreamSynchronize(ctx->stream);

@@ -12,7 +12,7 @@ work on the device tensors directly and never round-trip through the host.
 from __future__ import division
 
 import copy
-from abc import ABCMeta, abstractmethod
+from abc import ABCMeta, abstractmethod, abstractproperty
 from collections import namedtuple
 
 import numpy as np
@@ -784,6 +784,39 @@ class MappingCollection(object):
 
     def __len__(self):
         return len(self._mappings)
+
+
+@add_metaclass(ABCMeta)
+class BaseMappingProvider(object):
+    """Base class for all mapping providers (reference mapping.py:1376-1445)."""
+
+    def __init__(self, maxTimeOffset):
+        """:param maxTimeOffset: in seconds"""
+        self.maxTimeOffset = maxTimeOffset
+
+    @abstractproperty
+    def range(self):
+        """The dates of the first and last available mappings: datetime tuple (from, to)."""
+
+    @abstractmethod
+    def contains(self, date):
+        """True if there is a mapping for the given date within +-maxTimeOffset."""
+
+    def containsAny(self, dates):
+        """True if there is a mapping for at least one of the given dates within +-maxTimeOffset."""
+        return any(self.contains(date) for date in dates)
+
+    @abstractmethod
+    def get(self, date):
+        """The mapping closest to the given date within +-maxTimeOffset; ValueError when there is none."""
+
+    @abstractmethod
+    def getById(self, identifier):
+        """The mapping with the given identifier; ValueError when there is none."""
+
+    @abstractmethod
+    def getSequence(self, dateBegin=None, dateEnd=None):
+        """Generator of mappings ordered by date for the given (inclusive) date range; all of them by default."""
 
 
 def MaskByElevationProvider(provider, *args, **kw):

@@ -45,6 +45,17 @@ def getShiftedSpacecraftPosition(header):
     return xyz, date + delta, delta
 
 
+def frame_inputs(header):
+    """(cameraPosGCRS, photoTime) of a frame from its header cards: the shifted ones (POS?SHIF, DATE-OBS + DATESHIF)
+    when present, else POS? and DATE-OBS — the choice ``getMapping`` makes (reference spacecraft.py:437-452)."""
+    cam, t, _ = getShiftedSpacecraftPosition(header)
+    if cam is None:
+        cam, t = getSpacecraftPosition(header)
+    if cam is None:
+        raise ValueError('Spacecraft position is missing in the header (POSX/POSY/POSZ cards)')
+    return cam, t
+
+
 class BaseSpacecraftMapping(BaseAstrometryMapping):
     """
     A camera in/on a spacecraft looking both on earth and the stars; the stars gave the WCS
@@ -105,15 +116,27 @@ class ArraySpacecraftMapping(BaseSpacecraftMapping):
 ArrayMapping = ArraySpacecraftMapping
 
 
-def getMapping(imageArray, wcsHeader, timeshift=None, altitude=110, fastCenterCalculation=False, metadata=None,
-               identifier=None, cameraPosGCRS=None):
+def getMapping(imagePathOrArray, wcsPathOrHeader, timeshift=None, noradId=None, tleFolder=None, spacetrack=None,
+               altitude=110, fastCenterCalculation=False, metadata=None, nosanitize=False, identifier=None,
+               cameraPosGCRS=None):
     """
-    Build a mapping from an image array and a WCS header dict (reference spacecraft.py:380-426,
-    428-485 for array/dict inputs).  Photo time and camera position are taken from the header:
-    the shifted cards (DATESHIF, POS?SHIF) if present, else DATE-OBS and POS?.  With `timeshift`
-    (a timedelta) or a header lacking POS? cards, `cameraPosGCRS` must be supplied — the reference
-    recomputes it from two-line elements, which is outside this package.
+    Build a mapping from an image array and a WCS header dict — the reference's signature and positional order
+    (spacecraft.py:380-426, 428-485), for array / dict inputs.  Photo time and camera position are taken from the
+    header: the shifted cards (DATESHIF, POS?SHIF) if present, else DATE-OBS and POS?.
+
+    Not supported here (they are the reference's file and network plumbing, out of this package's scope) and
+    rejected with a clear error instead of being ignored: image or header given as a file PATH; ``noradId`` /
+    ``tleFolder`` / ``spacetrack`` (camera position from two-line elements: pass ``cameraPosGCRS`` instead, which is
+    also needed with ``timeshift`` or for a header without POS? cards).  ``nosanitize`` only affects the reference's
+    file-based mappings and is accepted.
     """
+    imageArray, wcsHeader = imagePathOrArray, wcsPathOrHeader
+    if isinstance(imageArray, str) or isinstance(wcsHeader, str):
+        raise NotImplementedError('auromat_amd.getMapping takes an image ARRAY and a WCS header DICT; reading image / '
+                                  '.wcs files (astropy.io.fits, PIL) is the reference\'s I/O layer')
+    if noradId is not None or tleFolder is not None or spacetrack is not None:
+        raise NotImplementedError('noradId / tleFolder / spacetrack (camera position from two-line elements via '
+                                  'pyephem) are not part of auromat_amd: pass cameraPosGCRS=[x, y, z] (km, GCRS)')
     originalPhotoTime = getPhotoTime(wcsHeader)
     if originalPhotoTime is None:
         raise ValueError('DATE-OBS missing in FITS header')

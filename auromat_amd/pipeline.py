@@ -63,17 +63,22 @@ class _GridView(object):
 
 
 class FramePipeline(object):
-    def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, with_mag=False, alloc_image=True):
+    def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, with_mag=False, alloc_image=True,
+                 alloc_coords=True):
         import torch
         self.ctx = ctx = Context.current(device)
         self.width, self.height = int(width), int(height)
         h, w = self.height, self.width
         fd = self.fd = FrameData(ctx, h, w)
-        fd.lat, fd.lon = ctx.empty((h + 1, w + 1)), ctx.empty((h + 1, w + 1))
-        fd.lat_c, fd.lon_c, fd.elev = ctx.empty((h, w)), ctx.empty((h, w)), ctx.empty((h, w))
-        if with_mag:
-            fd.mlat, fd.mlt = ctx.empty((h + 1, w + 1)), ctx.empty((h + 1, w + 1))
-            fd.mlat_c, fd.mlt_c = ctx.empty((h, w)), ctx.empty((h, w))
+        self.with_mag = with_mag
+        self._out = GeorefOut()
+        # alloc_coords=False ("grids only"): the single-pass plan then writes no per-pixel coordinate arrays at all (its
+        # kernel bins every pixel as soon as its coordinates exist; 480 MB per frame of stores fall away) and the
+        # arrays are only allocated, and the frame georeferenced again into them, when a frame has to take the
+        # two-pass plan (pole in view, ...) or somebody asks for them
+        self._coords_valid = False
+        if alloc_coords:
+            self._alloc_coords()
         fd.bbox = ctx.empty((8,))
         fd.img_dtype = np.dtype(img_dtype)
         self._img_torch_dtype = torch.uint8 if fd.img_dtype == np.uint8 else torch.int16
@@ -81,7 +86,6 @@ class FramePipeline(object):
         # alloc_image=False: the caller aliases a device-resident image before the first frame (use_image)
         fd.img = ctx.empty(self._img_shape, self._img_torch_dtype) if alloc_image else None
         self._img_own = fd.img
-        self.with_mag = with_mag
         self._bbox_host = torch.empty(8, dtype=torch.float64, pin_memory=True)
         self._bbox_event = torch.cuda.Event()
         self._driver = None         # amt_pipe handle of the single-pass plan (created on first use)
@@ -95,12 +99,32 @@ class FramePipeline(object):
         self.params = None
         self.altitude = None
         self.min_elevation = None
-        out = self._out = GeorefOut()
-        out.lat, out.lon, out.lat_c, out.lon_c, out.elev = (t.data_ptr() for t in
-                                                            (fd.lat, fd.lon, fd.lat_c, fd.lon_c, fd.elev))
-        if with_mag:
+        self._out.bbox = fd.bbox.data_ptr()
+
+    def _alloc_coords(self):
+        fd, ctx, out = self.fd, self.ctx, self._out
+        if fd.lat is not None:
+            return
+        h, w = self.height, self.width
+        fd.lat, fd.lon = ctx.empty((h + 1, w + 1)), ctx.empty((h + 1, w + 1))
+        fd.lat_c, fd.lon_c, fd.elev = ctx.empty((h, w)), ctx.empty((h, w)), ctx.empty((h, w))
+        out.lat, out.lon, out.lat_c, out.lon_c, out.elev = (t.data_ptr() for t in (fd.lat, fd.lon, fd.lat_c, fd.lon_c, fd.elev))
+        if self.with_mag:
+            fd.mlat, fd.mlt = ctx.empty((h + 1, w + 1)), ctx.empty((h + 1, w + 1))
+            fd.mlat_c, fd.mlt_c = ctx.empty((h, w)), ctx.empty((h, w))
             out.mlat, out.mlt, out.mlat_c, out.mlt_c = (t.data_ptr() for t in (fd.mlat, fd.mlt, fd.mlat_c, fd.mlt_c))
-        out.bbox = fd.bbox.data_ptr()
+
+    def coordinates(self):
+        """Make sure the per-pixel coordinate arrays of the last frame exist (grids-only pipelines compute them on
+        demand: one more run of the georeferencing kernel) -> the FrameData."""
+        if not self._coords_valid:
+            self._alloc_coords()
+            Context.current(self.ctx.device)
+            self._out.bbox_min_elevation = NEG_INF if self.min_elevation is None else float(self.min_elevation)
+            self.ctx.call('amt_georef_frame', C.byref(self.params), C.byref(self._out))
+            self.fd.corner_mask = self.fd.center_mask = None
+            self._coords_valid = True
+        return self.fd
 
     def __del__(self):
         if getattr(self, '_driver', None):
@@ -208,7 +232,10 @@ class FramePipeline(object):
                         fd.img_dtype_code, min_elev, float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1, mag)
             self._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
             fd.corner_mask = fd.center_mask = None
+            self._coords_valid = fd.lat is not None
             return fd
+        self._alloc_coords()
+        self._coords_valid = True
         self._fused = None
         self._pole = None                                # decided lazily in bounding_box()
         out.bbox_min_elevation = min_elev
@@ -243,6 +270,7 @@ class FramePipeline(object):
             q.params, q.altitude, q.min_elevation = p, altitude, min_elevation
             q._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
             q.fd.corner_mask = q.fd.center_mask = None
+            q._coords_valid = q.fd.lat is not None
 
     def bounding_box(self):
         """Waits for the fused reduction of the last georef() -> BoundingBox; ValueError if nothing is valid."""
@@ -250,6 +278,7 @@ class FramePipeline(object):
             red = np.array(self._wait_fused().bbox[:])
         elif self._fused is not None:
             # the driver reduced the box over (MLat, SM longitude); the geodetic one comes from the corner arrays
+            self.coordinates()
             red = self._reduce_bbox(self.fd.lat, self.fd.lon)
             red[7] = 1.0 if pole_in_view(self.params, self.min_elevation) else 0.0
         else:
@@ -324,6 +353,7 @@ class FramePipeline(object):
             if res.status == 0 and not containsPole:       # status 0: neither pole nor discontinuity in the frame
                 self.last_plan = 'single-pass'
                 return self._finalize_fused(res, tuple(pxPerDeg), keep_on_device)
+        self.coordinates()          # (grids-only pipelines: the arrays the two-pass plan reads are computed now)
         if not self.params.fast_center and fd.center_mask is None:
             # exact centres carry their own misses: a centre also needs its four corners and a corner a centre
             # (sanitize_data, reference mapping.py:1063-1125) — the separate binning pass takes the reconciled
@@ -366,6 +396,7 @@ class FramePipeline(object):
     def host_arrays(self):
         """Raw (NaN = missing) coordinate arrays of the last frame as NumPy arrays."""
         names = ['lat', 'lon', 'lat_c', 'lon_c', 'elev'] + (['mlat', 'mlt', 'mlat_c', 'mlt_c'] if self.with_mag else [])
+        self.coordinates()
         return {k: self.fd.host(k) for k in names}
 
 
@@ -398,7 +429,7 @@ class SequencePipeline(object):
 
     def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, altitude=110, fast=True,
                  min_elevation=10.0, pxPerDeg=10, plan='single-pass', bin_stream=True, shared_image=None,
-                 magnetic=False, batch=3, own_image_buffers=True):
+                 magnetic=False, batch=3, own_image_buffers=True, keep_coordinates=True):
         import torch
         assert plan in ('single-pass', 'two-pass')
         try:
@@ -415,9 +446,11 @@ class SequencePipeline(object):
         # 1, 2, 3 frames per launch.
         self.batch = max(1, min(int(batch), 3)) if self.single_pass else 1
         # own_image_buffers=False: every frame of process() brings a device-resident image that is used in place
-        # (no per-slot image buffer is allocated)
+        # (no per-slot image buffer is allocated).  keep_coordinates=False ("grids only", what a convert run needs):
+        # the single-pass plan writes no per-pixel latitude / longitude / elevation arrays, see FramePipeline.
         self.pipes = [FramePipeline(width, height, nchan, img_dtype, device, with_mag=self.magnetic,
-                                    alloc_image=own_image_buffers and (shared_image is None or i == 0))
+                                    alloc_image=own_image_buffers and (shared_image is None or i == 0),
+                                    alloc_coords=keep_coordinates or not self.single_pass)
                       for i in range(2 * self.batch)]
         self.ctx = self.pipes[0].ctx
         if shared_image is not None:

@@ -228,7 +228,7 @@ def resident_images(device, n, first_seed):
 
 
 def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_hints, shared_image, own_buffers,
-              fence, after=None):
+              fence, after=None, keep_coordinates=True):
     """
     W untimed + K timed frames through a fresh SequencePipeline.  Returns dict(elapsed, georef_ms, bin_ms, plans,
     hinted, seq, results, extra) — georef_ms / bin_ms are per FRAME, from HIP events on the dispatch packets.
@@ -237,7 +237,8 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
     from auromat_amd.pipeline import SequencePipeline
     seq = SequencePipeline(WIDTH, HEIGHT, altitude=ALTITUDE, fast=fast, min_elevation=MIN_ELEV, pxPerDeg=PPD,
                            plan='single-pass' if plan == 'fused' else 'two-pass', bin_stream=streams == 2,
-                           shared_image=shared_image, magnetic=magnetic, batch=batch, own_image_buffers=own_buffers)
+                           shared_image=shared_image, magnetic=magnetic, batch=batch, own_image_buffers=own_buffers,
+                           keep_coordinates=keep_coordinates)
     seq.use_hints = use_hints
     ctx = seq.ctx
     warm = seq.process(frames[:warmup])
@@ -435,12 +436,18 @@ def main(argv=None):
             # the other configurations of SURVEY 8d on the record of the same run: short runs of the same loop
             torch.cuda.empty_cache()
             variants = {}
-            nv_w, nv_k = 3, 12
+            nv_w, nv_k = 6, 24
             for name, kw in (('exact_centres', dict(fast=False, magnetic=False)),
-                             ('configs3_magnetic_3_shells', dict(fast=True, magnetic=True))):
+                             ('configs3_magnetic_3_shells', dict(fast=True, magnetic=True)),
+                             # NOT the headline workload: the resampled grids only, no per-pixel coordinate arrays
+                             # written (what a convert run needs; SequencePipeline(keep_coordinates=False))
+                             ('grids_only_no_coordinate_arrays', dict(fast=True, magnetic=False, keep=False))):
                 v = timed_run(make_frames(nv_w + nv_k, kw['magnetic']), nv_w, nv_k, kw['fast'], 'fused', kw['magnetic'],
-                              args.batch, args.streams, True, None, own_buffers=False, fence=fence)
+                              args.batch, args.streams, True, None, own_buffers=False, fence=fence,
+                              keep_coordinates=kw.get('keep', True))
                 vb = ab['mag_shell'] - 24 * (WIDTH + 1) * (HEIGHT + 1) if kw['magnetic'] else ab['georef'] + ab['resample']
+                if not kw.get('keep', True):
+                    vb = ab['image']            # all it has to move: the image
                 variants[name] = {
                     'ms_per_frame': v['elapsed'] / nv_k * 1e3, 'Mpixels_per_s': nv_k * npx / 1e6 / v['elapsed'],
                     'frames': nv_k, 'kernel_ms_per_frame': v['georef_ms'],

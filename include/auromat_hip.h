@@ -479,6 +479,43 @@ int amt_pipe_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_
  * before work on the context's stream — or, after amt_ctx_synchronize, the host — reads the outputs. */
 int amt_pipe_join(amt_pipe* pipe);
 
+/* ---- sequences over several GPUs: packing of per-frame grids for the gather ------------------------------------
+ * Whole frames are independent (reference mapping/spacecraft.py:326-332 iterates them with a plain `map`,
+ * cli/convert.py:178-185), so a sequence shards by frame, one process per GPU, and only the per-frame output grids
+ * travel: each rank packs its grids into ONE device buffer, the ranks exchange (frames, payload length) and the
+ * root gathers the buffers padded to the longest (ncclAllGather of 2 int64 + ncclGather / grouped send-recv over
+ * xGMI; python: auromat_amd/sequence.py on torch.distributed).  These three entry points give a non-Python host
+ * the same wire format:
+ *   buffer = [ max_frames x AMT_SEQ_DESC_LEN doubles | payload ],  payload per frame = mean (ny, nx, nc) then
+ *   count (ny, nx), float64;  descriptor = ny, nx, nc, lat of the first row's centres, lon of the first column's
+ *   centres, dlat, dlon, frame index, contains_pole, contains_discontinuity, altitude [km], magnetic.
+ * A frame that straddles the 180 deg discontinuity has its grid laid out in longitudes shifted by 180 deg, a pole
+ * frame in coordinates rotated by +90 deg about x at `altitude` (reference resample.py:176-218,262-277); the two
+ * flags tell the receiver.  ny = 0 marks a frame without any valid pixel (the reference raises ValueError there,
+ * mapping.py:858-859). */
+#define AMT_SEQ_DESC_LEN 12
+typedef struct amt_seq_frame {
+    int32_t ny, nx, nc;            /* grid rows, columns, planes of `mean` (image channels + elevation) */
+    int32_t index;                 /* position of the frame in the whole sequence */
+    double lat0, lon0, dlat, dlon;
+    int32_t contains_pole, contains_discontinuity, magnetic, reserved;
+    double altitude;
+    const double* mean;            /* pack: device pointers; unpack: pointers INTO the host buffer */
+    const double* count;
+} amt_seq_frame;
+/* Payload length in doubles of n frames (host arithmetic only). */
+int amt_seq_payload_size(const amt_seq_frame* frames, int32_t n, int64_t* n_doubles);
+/* Writes the descriptors of the n frames and copies their grids (device to device, on the context's stream) into
+ * `buffer` (device, capacity_doubles >= max_frames * AMT_SEQ_DESC_LEN + payload size; max_frames >= n is the
+ * largest frame count of any rank, so that all ranks' payloads start at the same offset).  The unused tail of
+ * the descriptor table is zeroed. */
+int amt_seq_pack(amt_ctx* ctx, const amt_seq_frame* frames, int32_t n, int32_t max_frames, double* buffer,
+                 int64_t capacity_doubles);
+/* Splits one rank's gathered buffer, already in HOST memory, into frames: n_frames descriptors are read,
+ * frames with ny = 0 are skipped; returns the number of entries written to `out` (at most capacity) in *n_out. */
+int amt_seq_unpack(const double* host_buffer, int64_t n_doubles, int32_t n_frames, int32_t max_frames,
+                   amt_seq_frame* out, int32_t capacity, int32_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,10 @@ Fixtures
   known_answers.json    literal known-answer vectors of the reference's own unit tests
   miracle_*.npz         MIRACLEMapping (all-sky fisheye) arrays for calibrations of test/resources/cal.txt
   themis_reproject.npz  themis.reproject of a coordinate table to two other heights
+  netcdf_layout_*.json  what the reference's export.netcdf.write() creates (dimensions, variables, dtypes, fill
+  + netcdf_case_*.npz   values, attributes, in order) for an unresampled camera mapping and for a resampled plate carree
+                        one, recorded from the reference's own code through a netCDF4.Dataset stand-in that writes
+                        nothing (netCDF4 is absent here), plus the mapping arrays that went in and the data that came out
   config1_*.npz         BASELINE.json configs[0] / SURVEY 8d config 1: the 512x512 synthetic frame (fast + exact
                         centres): every 4th sample + digests of all arrays, masks, and the full
                         maskedByElevation(10) -> resample(pxPerDeg=10, 'mean') output
@@ -581,6 +585,127 @@ def resample_nearest_cases():
         case.update(lats_c=z['lats_c'], lons_c=z['lons_c'], data=z['data'], corner_lat=z['corner_lat'],
                     corner_lon=z['corner_lon'], altitude=np.float64(110), ppd=np.array((4, 4), dtype=np.float64))
         save('resample_nearest_synth_%s.npz' % tag, **case)
+
+
+class _RecVar(object):
+    """Variable of the recording netCDF4.Dataset stand-in."""
+
+    def __init__(self, name, dtype, dims, fill_value, kw):
+        object.__setattr__(self, '_rec', dict(name=name, dtype=np.dtype(dtype).name, dims=list(dims),
+                                              fill_value=None if fill_value is None else np.asarray(fill_value).item(),
+                                              options={k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
+                                              attrs=[]))
+        object.__setattr__(self, '_data', None)
+
+    def __setattr__(self, k, v):
+        self._rec['attrs'].append((k, v))
+
+    def __setitem__(self, key, value):
+        object.__setattr__(self, '_data', np.ma.filled(np.asarray(value)) if np.ma.isMaskedArray(value) else np.asarray(value))
+
+
+class _RecDataset(object):
+    """netCDF4.Dataset stand-in: records what export.netcdf.write() does, in order; writes no file."""
+    last = None
+
+    def __init__(self, path, mode, format=None):
+        object.__setattr__(self, '_rec', dict(format=format, dims=[], vars=[], attrs=[]))
+        object.__setattr__(self, '_vars', [])
+        _RecDataset.last = self
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def __setattr__(self, k, v):
+        self._rec['attrs'].append((k, v))
+
+    def createDimension(self, name, size):
+        self._rec['dims'].append((name, int(size)))
+
+    def createVariable(self, name, dtype, dims=(), fill_value=None, **kw):
+        if isinstance(dims, str):
+            dims = (dims,)
+        v = _RecVar(name, dtype, dims, fill_value, kw)
+        self._vars.append(v)
+        self._rec['vars'].append(v._rec)
+        return v
+
+
+def _jsonable(v):
+    if isinstance(v, (np.ndarray, list, tuple)):
+        a = np.asarray(v)
+        return {'dtype': a.dtype.name, 'value': a.tolist()}
+    if isinstance(v, np.generic):
+        return {'dtype': v.dtype.name, 'value': v.item()}
+    if isinstance(v, (bool, int, float, str)):
+        return {'dtype': type(v).__name__, 'value': v}
+    raise TypeError(type(v))
+
+
+def netcdf_layout():
+    """Layout of the reference's netCDF export, recorded from its own code (export/netcdf.py:24-386)."""
+    import types
+    sys.modules['netCDF4'] = types.ModuleType('netCDF4')
+    sys.modules['netCDF4'].Dataset = _RecDataset
+    import auromat.export.netcdf as X
+
+    def with_box(m):
+        # boundingBox needs scikit-image + geographiclib (absent): the extremes of the unmasked corners instead,
+        # which is what the reference's outline-based box equals for these one-piece masks
+        bb = _bbox_from(m.lats, m.lons)
+        cls = type(m)
+        sub = type(cls.__name__ + 'Boxed', (cls,), {'boundingBox': property(lambda self: bb)})
+        m.__class__ = sub
+        return m
+
+    hdr, cam, t = frame_header(64, 48, 'iss030')
+    img = frame_image(64, 48, seed=2)
+    cases = {}
+    m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'frame_a', metadata={'Project': 'auromat', 'Calibrated': True},
+                               fastCenterCalculation=True).maskedByElevation(10)
+    cases['unresampled'] = with_box(m)
+    # a resampled (plate carree) mapping, as resample() would return it
+    merged = np.dstack((m.img.astype(np.float64).filled(np.nan), m.elevation.filled(np.nan)))
+    case = _run_resample(m.lats, m.lons, m.latsCenter.filled(np.nan), m.lonsCenter.filled(np.nan), 110, merged, (4, 4))
+    rimg, relev = np.dsplit(case['out_data'], [-1])
+    with np.errstate(invalid='ignore'):
+        rimg = np.round(rimg)
+    rimg = np.require(ma.masked_invalid(rimg, copy=False), np.uint16)
+    relev = ma.masked_invalid(relev[:, :, 0])
+    g = GenericMapping(case['out_lat'], case['out_lon'], case['out_lat_c'], case['out_lon_c'], relev, 110, rimg, cam, t,
+                       'frame_a_resampled', metadata={'Project': 'auromat'})
+    cases['resampled'] = with_box(g)
+    for tag, mp in cases.items():
+        for opts in (dict(), dict(includeBounds=False), dict(includeMagCoords=False)):
+            otag = tag + ''.join('_' + k for k in opts)
+            X.write('/nonexistent/%s.nc' % otag, mp, metadata={'Source_name': 'test'}, **opts)
+            rec = _RecDataset.last
+            listing = dict(format=rec._rec['format'], dims=rec._rec['dims'],
+                           attrs=[(k, _jsonable(v)) for k, v in rec._rec['attrs']], vars=[])
+            data = {}
+            for v in rec._vars:
+                r = dict(v._rec)
+                r['attrs'] = [(k, _jsonable(a)) for k, a in r['attrs']]
+                listing['vars'].append(r)
+                if v._data is not None:
+                    data['var_' + r['name']] = v._data
+            with open(os.path.join(OUT, 'netcdf_layout_%s.json' % otag), 'w') as fp:
+                json.dump(listing, fp, indent=1)
+            mlat, mlt = mp.mLatMlt
+            mlatc, mltc = mp.mLatMltCenter
+            bb = mp.boundingBox
+            save('netcdf_case_%s.npz' % otag, lats=mp.lats.filled(np.nan), lons=mp.lons.filled(np.nan),
+                 lats_c=mp.latsCenter.filled(np.nan), lons_c=mp.lonsCenter.filled(np.nan),
+                 lats_c_data=mp.latsCenter.data, lons_c_data=mp.lonsCenter.data, lats_data=mp.lats.data,
+                 lons_data=mp.lons.data, elev=mp.elevation.filled(np.nan), img=mp.img.data,
+                 img_mask=ma.getmaskarray(mp.img), mlat=mlat.filled(np.nan), mlt=mlt.filled(np.nan),
+                 mlat_c=mlatc.filled(np.nan), mlt_c=mltc.filled(np.nan), mlat_data=mlat.data, mlt_data=mlt.data,
+                 mlat_c_data=mlatc.data, mlt_c_data=mltc.data, cam=cam,
+                 time_iso=np.array(t.strftime('%Y-%m-%dT%H:%M:%S.%f')), altitude=np.float64(110),
+                 bbox=np.array([bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast]), **data)
 
 
 def config1_header():

@@ -1,0 +1,117 @@
+"""
+The convert driver (auromat_amd/cli/convert.py): the reference's flag set (cli/convert.py:58-130) and its checks on
+the CPU; on the GPU a directory of frames through both routes — mapping classes with the reference's arcsec/px rule,
+and the single-pass sequence pipeline at a fixed px/deg — into netCDF files that read back as the same grids.
+"""
+import json
+import os
+
+import numpy as np
+import numpy.ma as ma
+import pytest
+
+
+def write_frames(tmp_path, n=3, w=256, h=170):
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    d = tmp_path / 'frames'
+    d.mkdir()
+    for k in range(n):
+        hdr, cam, t, seed = sequence_frame(k, w, h)
+        hdr = dict(hdr)
+        hdr.update({'DATE-OBS': t.strftime('%Y-%m-%dT%H:%M:%S.%f'), 'POSX': float(cam[0]), 'POSY': float(cam[1]),
+                    'POSZ': float(cam[2])})
+        if k == 0:
+            # a real .wcs-style file: 80-column cards
+            cards = []
+            for key, v in hdr.items():
+                val = ("'%s'" % v).ljust(20) if isinstance(v, str) else ('%20s' % repr(v))
+                cards.append(('%-8s= %s' % (key, val)).ljust(80))
+            cards.append('END'.ljust(80))
+            (d / ('frame%02d.wcs' % k)).write_text(''.join(cards))
+        else:
+            (d / ('frame%02d.json' % k)).write_text(json.dumps(hdr))
+        np.save(str(d / ('frame%02d.npy' % k)), frame_image(w, h, seed=seed))
+    return str(d)
+
+
+def test_flags_are_the_references():
+    from auromat_amd.cli.convert import getParser, parseargs
+    opts = {a.option_strings[0] for a in getParser()._actions if a.option_strings}
+    for flag in ('--data', '--start', '--end', '--altitude', '--bps', '--correctgamma', '--autobright', '--resample',
+                 '--resolution', '--grid', '--out', '--overwrite', '--skip', '--format', '--without-bounds', '--without-mag',
+                 '--without-geo', '--version'):
+        assert flag in opts, flag
+    a = parseargs(['--data', '/x', '--format', 'netcdf'])
+    assert a.out == '/x/converted' and a.altitude == 110 and a.resolution == 100 and a.grid == 'mag' and not a.resample
+    for bad in (['--format', 'netcdf', '--overwrite', '--skip'], ['--format', 'netcdf', '--without-geo'], ['--format', 'cdf'],
+                ['--data', '/x']):
+        with pytest.raises(SystemExit):
+            parseargs(bad)
+    with pytest.raises(SystemExit):
+        parseargs([])
+
+
+def test_header_cards_and_frame_listing(tmp_path):
+    from datetime import datetime
+    from auromat_amd.cli.convert import list_frames, read_header
+    d = write_frames(tmp_path)
+    hdr = read_header(os.path.join(d, 'frame00.wcs'))
+    ref = json.load(open(os.path.join(d, 'frame01.json')))
+    assert set(hdr) == set(ref) and hdr['CTYPE1'] == 'RA---TAN' and hdr['IMAGEW'] == 256
+    assert hdr['CD1_1'] == ref['CD1_1'] and isinstance(hdr['CRPIX1'], float)
+    frames = list_frames(d)
+    assert [f[0] for f in frames] == ['frame00', 'frame01', 'frame02']
+    assert [f[0] for f in list_frames(d, start=datetime(2012, 1, 25, 9, 26, 56))] == ['frame01', 'frame02']
+
+
+@pytest.mark.gpu
+def test_convert_both_routes(tmp_path, capsys):
+    from auromat_amd.cli.convert import main
+    from auromat_amd.export import _nc3
+    from auromat_amd.mapping.netcdf import NetCDFMapping, read_arrays
+    from auromat_amd.mapping.spacecraft import getMapping
+    from auromat_amd.resample import resample, resampleMLatMLT
+    d = write_frames(tmp_path)
+    # 1. the reference's route: arcsec / px from each frame's box, MLat/MLT grid by default
+    out1 = str(tmp_path / 'o1')
+    main(['--data', d, '--format', 'netcdf', '--resample', '--resolution', '900', '--out', out1])
+    assert sorted(os.listdir(out1)) == ['frame00.nc', 'frame01.nc', 'frame02.nc']
+    hdr = json.load(open(os.path.join(d, 'frame01.json')))
+    m = getMapping(np.load(os.path.join(d, 'frame01.npy')), hdr, fastCenterCalculation=True,
+                   identifier='frame01').maskedByElevation(10)
+    want = resampleMLatMLT(m, arcsecPerPx=900)
+    got = read_arrays(os.path.join(out1, 'frame01.nc'))
+    assert np.array_equal(got['lats'].filled(np.nan), want.lats.filled(np.nan), equal_nan=True)
+    assert np.array_equal(got['img'].filled(0), want.img.filled(0)) and np.array_equal(ma.getmaskarray(got['img']), ma.getmaskarray(want.img))
+    assert np.allclose(got['elevation'].filled(-1), want.elevation.filled(-1), atol=1e-4)       # stored as float32 zenith angle
+    f = _nc3.File(os.path.join(out1, 'frame01.nc'))
+    # (the geodetic coordinates of an MLat/MLT grid are curvilinear; and the MLat/MLT the exporter recomputes from them at the
+    # mapping altitude are not exactly regular either, in the reference as here: smToLatLon goes through a point 1 km
+    # from the Earth's centre, transform.py:472-480 — so both systems are stored as 2-D arrays with cell bounds)
+    assert f.vars['mlat'].dims == ('y', 'x') and f.vars['lat'].dims == ('y', 'x') and f.vars['mlat_bounds'].dims == ('y', 'x', 'vertex4')
+    # the file reads back as a mapping that satisfies the class guarantees
+    back = NetCDFMapping(os.path.join(out1, 'frame01.nc'))
+    back.checkGuarantees()
+    assert back.identifier == 'frame01' and back.altitude == 110 and back.photoTime == m.photoTime
+    # re-running refuses, --skip skips, --overwrite overwrites
+    with pytest.raises(SystemExit):
+        main(['--data', d, '--format', 'netcdf', '--resample', '--resolution', '900', '--out', out1])
+    main(['--data', d, '--format', 'netcdf', '--resample', '--resolution', '900', '--out', out1, '--skip'])
+    assert 'skipping' in capsys.readouterr().out
+    # 2. the fast route: fixed px/deg through the single-pass sequence pipeline, geographic grid, no bounds
+    out2 = str(tmp_path / 'o2')
+    main(['--data', d, '--format', 'netcdf', '--resample', '--grid', 'geo', '--px-per-deg', '5', '--out', out2, '--without-bounds',
+          '--without-mag'])
+    want = resample(m, pxPerDeg=5)
+    f = _nc3.File(os.path.join(out2, 'frame01.nc'))
+    assert f.vars['lat'].dims == ('lats',) and 'lat_bounds' not in f.vars and 'mlat' not in f.vars
+    assert np.array_equal(f.vars['lat'].data, want.latsCenter.data[:, 0]) and np.array_equal(f.vars['lon'].data, want.lonsCenter.data[0, :])
+    red = ma.masked_equal(f.vars['img_red'].data, f.vars['img_red'].attrs['_FillValue'])
+    assert np.array_equal(ma.getmaskarray(red), ma.getmaskarray(want.img)[:, :, 0])
+    assert np.array_equal(red.filled(0), want.img[:, :, 0].filled(0).astype(np.int32))
+    # 3. without --resample the unresampled mapping goes out (2D coordinates with cell bounds)
+    out3 = str(tmp_path / 'o3')
+    main(['--data', d, '--format', 'netcdf', '--out', out3, '--end', '2012-01-25T09:26:55'])
+    assert os.listdir(out3) == ['frame00.nc']
+    f = _nc3.File(os.path.join(out3, 'frame00.nc'))
+    assert f.vars['lat'].dims == ('y', 'x') and f.vars['lat_bounds'].data.shape == (170, 256, 4)

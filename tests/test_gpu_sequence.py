@@ -148,3 +148,69 @@ def test_gathered_dateline_frame_keeps_its_true_coordinates():
     lat_c, lon_c = frame_coordinates(out[0])
     assert np.allclose(lat_c, want['lat_c'], atol=1e-12, rtol=0) and np.allclose(lon_c, want['lon_c'], atol=1e-12, rtol=0)
     assert lon_c.min() < -170 and lon_c.max() > 170
+
+
+def test_grids_only_pipeline_equals_the_full_one():
+    """keep_coordinates=False: the single-pass plan writes no per-pixel coordinate arrays; frames that need the two-pass
+    plan (a pole in view) compute them on demand.  Same grids, bit for bit; the arrays appear when asked for."""
+    import torch
+    from auromat_amd.pipeline import FramePipeline, SequencePipeline
+    w, h, n = 530, 354, 11
+    frames = build_sequence(w, h, n, every_pole=4)
+    full = SequencePipeline(w, h, pxPerDeg=6)
+    want = [host(r) for r in full.process(frames)]
+    lean = SequencePipeline(w, h, pxPerDeg=6, keep_coordinates=False)
+    got = [host(r) for r in lean.process(frames)]
+    assert lean.plans == full.plans and lean.plans.count('two-pass') == 2
+    for a, b in zip(got, want):
+        for key in KEYS:
+            assert np.array_equal(a[key], b[key], equal_nan=True), key
+    # no coordinate arrays were allocated for the slots that never saw a pole frame ...
+    assert sum(q.fd.lat is None for q in lean.pipes) >= 1
+    # ... and a single frame's arrays come on demand, equal to the full pipeline's
+    one = FramePipeline(w, h, alloc_coords=False)
+    hdr, cam, t, img = frames[0]
+    res = one.run(hdr, 110, cam, t, img=img, pxPerDeg=6, fuse=True)
+    assert one.last_plan == 'single-pass' and one.fd.lat is None
+    ref = FramePipeline(w, h)
+    ref.run(hdr, 110, cam, t, img=img, pxPerDeg=6, fuse=True)
+    a, b = one.host_arrays(), ref.host_arrays()
+    for k in b:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert np.array_equal(res['mean'], host(want[0])['mean'], equal_nan=True)
+
+
+def test_c_abi_pack_writes_the_python_wire_format():
+    """amt_seq_pack (what a C host feeds to RCCL) == auromat_amd.sequence.pack_results on the same device grids."""
+    import ctypes as C
+    import torch
+    from auromat_amd._native import SeqFrame, ptr
+    from auromat_amd.pipeline import SequencePipeline
+    from auromat_amd.sequence import DESC_LEN, pack_results
+    w, h, n = 300, 200, 5
+    frames = build_sequence(w, h, n, every_pole=3, empty_at=(3,))
+    seq = SequencePipeline(w, h, pxPerDeg=5)
+    results = seq.process(frames)
+    idx = [10, 11, 12, 13, 14]
+    descs, payload = pack_results(results, idx, seq.ctx.device)
+    max_frames = 7
+    fr = (SeqFrame * n)()
+    for f, r, i in zip(fr, results, idx):
+        f.index = i
+        if r is None:
+            continue
+        g = r['grid']
+        f.ny, f.nx, f.nc = r['mean'].shape
+        f.lat0, f.lon0, f.dlat, f.dlon = g.lat0, g.lon0, g.latStep, g.lonStep
+        f.contains_pole, f.contains_discontinuity, f.magnetic = int(r['contains_pole']), int(r['contains_discontinuity']), 0
+        f.altitude = r['altitude']
+        f.mean, f.count = r['mean'].data_ptr(), r['count'].data_ptr()
+    size = C.c_int64()
+    assert seq.ctx._lib.amt_seq_payload_size(fr, n, C.byref(size)) == 0 and size.value == payload.numel()
+    buf = torch.full((max_frames * DESC_LEN + size.value,), -1.0, dtype=torch.float64, device=seq.ctx.device)
+    seq.ctx.call('amt_seq_pack', fr, n, max_frames, ptr(buf), buf.numel())
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy()
+    assert np.array_equal(got[:n * DESC_LEN].reshape(n, DESC_LEN), descs.cpu().numpy())
+    assert not got[n * DESC_LEN:max_frames * DESC_LEN].any()
+    assert np.array_equal(got[max_frames * DESC_LEN:], payload.cpu().numpy(), equal_nan=True)

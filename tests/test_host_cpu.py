@@ -338,3 +338,68 @@ def test_contour_links_are_ranked_like_a_walk():
         key = lambda c: (len(c), c.tolist())
         assert [c.tolist() for c in sorted(got, key=key)] == [c.tolist() for c in sorted(want, key=key)], trial
     assert contours_from_links(np.zeros((0, 2), np.int64)) == []
+
+
+def test_getMapping_has_the_references_positional_order():
+    """reference spacecraft.py:380-382: a 4th positional argument is noradId, not the altitude."""
+    import inspect
+    from auromat_amd.mapping.spacecraft import getMapping, getMappingSequence
+    names = list(inspect.signature(getMapping).parameters)
+    assert names[:11] == ['imagePathOrArray', 'wcsPathOrHeader', 'timeshift', 'noradId', 'tleFolder', 'spacetrack',
+                          'altitude', 'fastCenterCalculation', 'metadata', 'nosanitize', 'identifier']
+    sig = inspect.signature(getMapping)
+    assert sig.parameters['altitude'].default == 110 and sig.parameters['fastCenterCalculation'].default is False
+    hdr = {'DATE-OBS': '2012-01-25T09:26:55.060', 'POSX': 1.0, 'POSY': 2.0, 'POSZ': 3.0}
+    img = np.zeros((2, 2, 3), np.uint8)
+    for bad in (dict(noradId=25544), dict(tleFolder='/tmp'), dict(spacetrack=object())):
+        with pytest.raises(NotImplementedError):
+            getMapping(img, hdr, **bad)
+    with pytest.raises(NotImplementedError):
+        getMapping(img, hdr, None, 25544)          # positionally, as a caller of the reference would
+    with pytest.raises(NotImplementedError):
+        getMapping('frame.jpg', hdr)
+    assert list(inspect.signature(getMappingSequence).parameters)[:2] == ['imageArrays', 'wcsHeaders']
+
+
+def test_seq_unpack_and_payload_size_are_host_functions():
+    """amt_seq_payload_size / amt_seq_unpack (the C side of the gather's wire format) run without a GPU and read what
+    auromat_amd.sequence.pack_results writes."""
+    import ctypes as C
+    import torch
+    from auromat_amd._native import SeqFrame, lib
+    from auromat_amd.sequence import DESC_LEN, pack_results
+    from auromat_amd.resample import _Grid
+    assert C.sizeof(SeqFrame) == 16 + 32 + 16 + 8 + 16
+    L = lib()
+    res = []
+    for k in (2, 5, 7):
+        grid = _Grid((4, 5), 40.0 + 0.3 * k, 43.0 + 0.37 * k, -100.0 + k, -96.5 + 1.2 * k)
+        rs = np.random.RandomState(k)
+        res.append(dict(mean=torch.from_numpy(rs.uniform(0, 9, (grid.ny, grid.nx, 4))), count=torch.from_numpy(
+            rs.randint(0, 50, (grid.ny, grid.nx)).astype(np.float64)), grid=grid, contains_pole=k == 5,
+            contains_discontinuity=k == 7, altitude=100.0 + k, magnetic=k == 2))
+    res.insert(1, None)                                  # a frame without valid pixels
+    descs, payload = pack_results(res, [2, 3, 5, 7], torch.device('cpu'))
+    max_frames = 6
+    buf = np.zeros(max_frames * DESC_LEN + payload.numel())
+    buf[:descs.numel()] = descs.numpy().ravel()
+    buf[max_frames * DESC_LEN:] = payload.numpy()
+    out = (SeqFrame * 8)()
+    n = C.c_int32()
+    rc = L.amt_seq_unpack(buf.ctypes.data_as(C.c_void_p), buf.size, 4, max_frames, out, 8, C.byref(n))
+    assert rc == 0 and n.value == 3
+    for f, r in zip(out[:3], [res[0], res[2], res[3]]):
+        ny, nx, nc = f.ny, f.nx, f.nc
+        assert (ny, nx, nc) == tuple(r['mean'].shape)
+        mean = np.ctypeslib.as_array(C.cast(f.mean, C.POINTER(C.c_double)), (ny, nx, nc))
+        cnt = np.ctypeslib.as_array(C.cast(f.count, C.POINTER(C.c_double)), (ny, nx))
+        assert np.array_equal(mean, r['mean'].numpy()) and np.array_equal(cnt, r['count'].numpy())
+        assert (f.lat0, f.lon0, f.dlat, f.dlon) == (r['grid'].lat0, r['grid'].lon0, r['grid'].latStep, r['grid'].lonStep)
+        assert (bool(f.contains_pole), bool(f.contains_discontinuity), bool(f.magnetic), f.altitude) == \
+            (r['contains_pole'], r['contains_discontinuity'], r['magnetic'], r['altitude'])
+    assert [f.index for f in out[:3]] == [2, 5, 7]
+    size = C.c_int64()
+    assert L.amt_seq_payload_size(out, 3, C.byref(size)) == 0 and size.value == payload.numel()
+    # truncated buffers and impossible descriptors are refused, not read past
+    assert L.amt_seq_unpack(buf.ctypes.data_as(C.c_void_p), buf.size - 1, 4, max_frames, out, 8, C.byref(n)) != 0
+    assert L.amt_seq_unpack(buf.ctypes.data_as(C.c_void_p), buf.size, 4, 3, out, 8, C.byref(n)) != 0
