@@ -111,7 +111,7 @@ def test_convert_both_routes(tmp_path, capsys):
     assert np.array_equal(red.filled(0), want.img[:, :, 0].filled(0).astype(np.int32))
     # 3. without --resample the unresampled mapping goes out (2D coordinates with cell bounds)
     out3 = str(tmp_path / 'o3')
-    main(['--data', d, '--format', 'netcdf', '--out', out3, '--end', '2012-01-25T09:26:55'])
+    main(['--data', d, '--format', 'netcdf', '--out', out3, '--end', '2012-01-25T09:26:56'])
     assert os.listdir(out3) == ['frame00.nc']
     f = _nc3.File(os.path.join(out3, 'frame00.nc'))
     assert f.vars['lat'].dims == ('y', 'x') and f.vars['lat_bounds'].data.shape == (170, 256, 4)
