@@ -79,6 +79,11 @@ def parse_args(argv=None):
     ap.add_argument('--no-variants', action='store_true',
                     help='skip the short extra runs (exact centres, configs[3]) whose figures the JSON line carries as '
                          '"variants" (they run on rank 0 at N = 1 only, after the timed region)')
+    ap.add_argument('--spinup-ms', type=float, default=400.0,
+                    help='untimed: before the W warm-up steps the same loop runs for about this long, so that the clocks '
+                         'and the memory system are in their sustained state when the timed region starts (a cold chip '
+                         'runs its first few dozen launches 3-5 %% slower; MI355X_MICROARCH.md asks for 2 s of back-to-back '
+                         'launches before trusting an in-kernel clock); 0 disables')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / reporting path only: gloo on the CPU, no GPU, a step is a sleep (tests)')
     args = ap.parse_args(argv)
@@ -228,7 +233,7 @@ def resident_images(device, n, first_seed):
 
 
 def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_hints, shared_image, own_buffers,
-              fence, after=None, keep_coordinates=True):
+              fence, after=None, keep_coordinates=True, spinup_ms=0.0):
     """
     W untimed + K timed frames through a fresh SequencePipeline.  Returns dict(elapsed, georef_ms, bin_ms, plans,
     hinted, seq, results, extra) — georef_ms / bin_ms are per FRAME, from HIP events on the dispatch packets.
@@ -241,6 +246,14 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
                            keep_coordinates=keep_coordinates)
     seq.use_hints = use_hints
     ctx = seq.ctx
+    spun = 0
+    if spinup_ms > 0 and warmup + steps > 0:
+        import torch
+        t_end = time.perf_counter() + spinup_ms * 1e-3
+        while time.perf_counter() < t_end:
+            seq.process(frames[:max(warmup, 2 * batch)])
+            torch.cuda.synchronize()
+            spun += max(warmup, 2 * batch)
     warm = seq.process(frames[:warmup])
     if after is not None and warm:
         after(warm, True)
@@ -259,7 +272,7 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
     n_timed = (steps + TIMING_EVERY - 1) // TIMING_EVERY
     assert g_n == n_timed and b_n in (0, n_timed), (g_n, b_n)
     return dict(elapsed=elapsed, georef_ms=g_total / g_n, bin_ms=(b_total / b_n if b_n else 0.0), plans=plans,
-                hinted=hinted, seq=seq, results=results, extra=extra)
+                hinted=hinted, seq=seq, results=results, extra=extra, spinup_frames=spun)
 
 
 def main(argv=None):
@@ -331,7 +344,7 @@ def main(argv=None):
 
     run = timed_run(make_frames(total, args.magnetic), args.warmup, args.steps, fast, args.plan, args.magnetic,
                     args.batch, args.streams, not args.no_hints, shared, own_buffers=args.upload, fence=fence,
-                    after=gather)
+                    after=gather, spinup_ms=args.spinup_ms)
     elapsed = run['elapsed']
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -401,6 +414,8 @@ def main(argv=None):
                        'plan': args.plan, 'frames_per_launch': seq.batch, 'frames_without_prepass': run['hinted'],
                        'single_pass_frames': sum(1 for q in plans if q == 'single-pass'),
                        'frames_total': world * args.steps,
+                       # untimed frames run before the W warm-up steps to bring the chip to its sustained state
+                       'spinup_frames_untimed': run['spinup_frames'], 'spinup_ms': args.spinup_ms,
                        'parallelism': 'frames sharded over %d GPU(s), RCCL gather of grids' % world,
                        'device': info['name']},
             # dominant kernel.  It is FP64-VALU bound (see DESIGN.md and profiles/), so the HBM fraction understates
@@ -444,7 +459,7 @@ def main(argv=None):
                              ('grids_only_no_coordinate_arrays', dict(fast=True, magnetic=False, keep=False))):
                 v = timed_run(make_frames(nv_w + nv_k, kw['magnetic']), nv_w, nv_k, kw['fast'], 'fused', kw['magnetic'],
                               args.batch, args.streams, True, None, own_buffers=False, fence=fence,
-                              keep_coordinates=kw.get('keep', True))
+                              keep_coordinates=kw.get('keep', True), spinup_ms=min(args.spinup_ms, 150.0))
                 vb = ab['mag_shell'] - 24 * (WIDTH + 1) * (HEIGHT + 1) if kw['magnetic'] else ab['georef'] + ab['resample']
                 if not kw.get('keep', True):
                     vb = ab['image']            # all it has to move: the image
