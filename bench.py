@@ -459,7 +459,7 @@ def main(argv=None):
                              ('grids_only_no_coordinate_arrays', dict(fast=True, magnetic=False, keep=False))):
                 v = timed_run(make_frames(nv_w + nv_k, kw['magnetic']), nv_w, nv_k, kw['fast'], 'fused', kw['magnetic'],
                               args.batch, args.streams, True, None, own_buffers=False, fence=fence,
-                              keep_coordinates=kw.get('keep', True), spinup_ms=min(args.spinup_ms, 150.0))
+                              keep_coordinates=kw.get('keep', True), spinup_ms=args.spinup_ms)
                 vb = ab['mag_shell'] - 24 * (WIDTH + 1) * (HEIGHT + 1) if kw['magnetic'] else ab['georef'] + ab['resample']
                 if not kw.get('keep', True):
                     vb = ab['image']            # all it has to move: the image

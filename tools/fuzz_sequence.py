@@ -38,10 +38,16 @@ for s in range(nseq):
     ref = [ref_pipe.run(hd, 110, cam, t, img=img, pxPerDeg=ppd, magnetic=magnetic) for hd, cam, t, img in frames]
     for plan, batch in (('single-pass', 1), ('single-pass', 2), ('single-pass', 3), ('two-pass', 1)):
         seq = SequencePipeline(w, h, pxPerDeg=ppd, plan=plan, batch=batch, magnetic=magnetic)
-        out = seq.process(frames, keep_on_device=False)
+        # the production mode: nothing synchronises between frames, results come to the host after process() returns
+        import torch
+        from auromat_amd.resample import grid_coordinates
+        out = seq.process(frames, keep_on_device=True)
+        out = [dict({key: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for key, v in r.items()}, **grid_coordinates(r))
+               for r in out]
         for i, (a, b) in enumerate(zip(out, ref)):
             for key in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
-                if not np.array_equal(a[key], b[key], equal_nan=True):
+                x = a[key].view(b[key].dtype) if key == 'img' else (a[key].astype(b[key].dtype) if key == 'mask' else a[key])
+                if not np.array_equal(x, b[key], equal_nan=True):
                     bad += 1
                     print('MISMATCH seq %d n %d magnetic %s %s batch %d frame %d %s plan %s' % (s, n, magnetic, plan, batch, i,
                                                                                               key, seq.plans[i]))
