@@ -38,7 +38,8 @@ class GeorefOut(C.Structure):
                                           'mlt_c', 'bbox')] + [('bbox_min_elevation', C.c_double)] + \
                [(k, C.c_void_p) for k in ('bin_xaxis', 'bin_yaxis', 'bin_img', 'bin_acc')] + \
                [(k, C.c_int32) for k in ('bin_img_dtype', 'bin_lon_wrap', 'bin_magnetic', 'item_order')] + \
-               [('bin_events', C.c_void_p), ('bin_event_count', C.c_void_p), ('bin_event_capacity', C.c_int64)]
+               [('bin_events', C.c_void_p), ('bin_event_count', C.c_void_p), ('bin_event_capacity', C.c_int64),
+                ('bin_pole', C.c_int32), ('reserved_pole', C.c_int32), ('altitude', C.c_double)]
 
 
 class Axis(C.Structure):
@@ -104,6 +105,7 @@ _SIGNATURES = {
     'amt_latlon_to_mlat_mlt': ([_P, c_double_p, _P, _P, _D, _L, _D, _D, _P, _P], _I),
     'amt_sm_to_latlon': ([_P, c_double_p, _P, _P, _L, _D, _D, _P, _P], _I),
     'amt_rotate_pole': ([_P, c_double_p, _P, _P, _D, _L, _D, _D, _P, _P], _I),
+    'amt_rotate_pole_deg': ([_P, c_double_p, _P, _P, _D, _L, _D, _D, _P, _P], _I),
     'amt_cartesian_to_spherical': ([_P, _P, _P, _P, _L, _P, _P, _P], _I),
     'amt_spherical_to_cartesian': ([_P, _P, _P, _P, _L, _P, _P, _P], _I),
     'amt_georef_allsky': ([_P, C.POINTER(AllSkyParams), _I, _P, _P, _P, _P, _P], _I),

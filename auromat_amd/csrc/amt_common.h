@@ -301,6 +301,75 @@ __device__ __forceinline__ void geodetic_to_ecef(const bowring& w, double lat, d
     z = (n * (1 - e2) + h) * sl;
 }
 
+// rotatePole (reference transform.py:301-322) of one point: geodetic (rad) at altitude h -> ECEF -> rotation m -> geodetic
+// (rad).  Same arithmetic as geodetic_to_ecef / ecef_to_geodetic above, but with every operation spelled out (no
+// contraction): the single-pass kernel re-evaluates the pixels next to a bin edge with it and must then agree with
+// k_rotate_pole, which the two-pass plan runs over whole arrays, bit for bit — whatever code surrounds the call.
+__device__ __forceinline__ void rotate_pole_rad(const bowring& w, const mat3& m, double e2, double lat, double lon, double h,
+                                                double& out_lat, double& out_lon) {
+#pragma clang fp contract(off)
+    double sl, cl, so, co;
+    sincos(lat, &sl, &cl);
+    sincos(lon, &so, &co);
+    const double q = __builtin_fma(-(e2 * sl), sl, 1.0);
+    const double yq = __builtin_amdgcn_rsq(q);
+    const double n = w.a * __builtin_fma(yq, __builtin_fma(-0.5 * yq, q * yq, 0.5), yq);
+    const double nh = n + h;
+    const double gx = (nh * cl) * co, gy = (nh * cl) * so, gz = __builtin_fma(n, 1.0 - e2, h) * sl;
+    const double x = __builtin_fma(m.m[2], gz, __builtin_fma(m.m[1], gy, m.m[0] * gx));
+    const double y = __builtin_fma(m.m[5], gz, __builtin_fma(m.m[4], gy, m.m[3] * gx));
+    const double z = __builtin_fma(m.m[8], gz, __builtin_fma(m.m[7], gy, m.m[6] * gx));
+    const double p2 = __builtin_fma(x, x, y * y);
+    const double yp = __builtin_amdgcn_rsq(p2);
+    const double hp = 0.5 * yp, gp = p2 * yp;
+    const double ep = __builtin_fma(-hp, gp, 0.5);
+    const double p = __builtin_fma(gp, ep, gp), ip = __builtin_fma(yp, ep, yp);
+    const double r2 = __builtin_fma(z, z, p2);
+    const double yr = __builtin_amdgcn_rsq(r2);
+    const double ir = __builtin_fma(yr, __builtin_fma(-0.5 * yr, r2 * yr, 0.5), yr);
+    const double tu = (((w.b / w.a) * z) * __builtin_fma(w.d, ir, 1.0)) * ip;
+    const double tu2 = tu * tu;
+    const double qq = 1.0 + tu2;
+    const double yc = __builtin_amdgcn_rsq(qq);
+    const double c = __builtin_fma(yc, __builtin_fma(-0.5 * yc, qq * yc, 0.5), yc);
+    const double cu3 = (c * c) * c;
+    const double su3 = (cu3 * tu2) * tu;
+    out_lat = atan2(__builtin_fma(w.d, su3, z), __builtin_fma(-w.e2a, cu3, p));
+    out_lon = atan2(y, x);
+}
+
+// ... in degrees (what the resampling code works in; torch.deg2rad / rad2deg are these two products)
+__device__ __forceinline__ void rotate_pole_deg(const bowring& w, const mat3& m, double e2, double lat_deg, double lon_deg, double h,
+                                                double& out_lat_deg, double& out_lon_deg) {
+#pragma clang fp contract(off)
+    double la, lo;
+    rotate_pole_rad(w, m, e2, lat_deg * kDeg2Rad, lon_deg * kDeg2Rad, h, la, lo);
+    out_lat_deg = la * kRad2Deg;
+    out_lon_deg = lo * kRad2Deg;
+}
+
+// Constants of the pole plan of the fused binning (amt_georef_out.bin_pole): the rotation by +90 deg about x that the
+// reference applies to frames with a pole in view (resample.py:176-201), as rotation_matrix() builds it (cos(pi/2) is
+// 6.1e-17, not 0), the reference ellipsoid and the mapping altitude.
+struct pole_consts {
+    bowring w;
+    mat3 rot;
+    double e2, one_minus_e2, alt, pad_;
+};
+
+__host__ inline pole_consts make_pole_consts(double a0, double b0, double altitude) {
+    pole_consts c;
+    c.w = make_bowring(a0, b0);
+    const double cs = std::cos(M_PI / 2), sn = std::sin(M_PI / 2);
+    const double r[9] = {1, 0, 0, 0, cs, -sn, 0, sn, cs};
+    c.rot = make_mat3(r);
+    c.e2 = c.w.e2a / c.w.a;
+    c.one_minus_e2 = 1.0 - c.e2;
+    c.alt = altitude;
+    c.pad_ = 0;
+    return c;
+}
+
 // SM cartesian -> (mlat deg, mlt h), reference transform.py:104-127,373-386,421-427
 __device__ __forceinline__ void sm_to_mlat_mlt(const vec3& s, double& mlat, double& mlt) {
     const double sxy = sqrt(s.x * s.x + s.y * s.y);

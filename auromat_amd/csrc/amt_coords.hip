@@ -213,14 +213,15 @@ __global__ void k_spherical_to_cartesian(const double* __restrict__ r, const dou
     }
 }
 
-__global__ void k_rotate_pole(mat3 m, bowring w, const double* __restrict__ lat, const double* __restrict__ lon,
+template <bool DEG>
+__global__ void k_rotate_pole(mat3 m, bowring w, double e2, const double* __restrict__ lat, const double* __restrict__ lon,
                               double altitude, int64_t n, double* __restrict__ olat, double* __restrict__ olon) {
     AMT_GRID_STRIDE(i, n) {
-        vec3 g;
-        geodetic_to_ecef(w, lat[i], lon[i], altitude, g.x, g.y, g.z);
-        const vec3 r = mul(m, g);
         double la, lo;
-        ecef_to_geodetic(w, r.x, r.y, r.z, la, lo);
+        if (DEG)
+            rotate_pole_deg(w, m, e2, lat[i], lon[i], altitude, la, lo);
+        else
+            rotate_pole_rad(w, m, e2, lat[i], lon[i], altitude, la, lo);
         olat[i] = la;
         olon[i] = lo;
     }
@@ -482,8 +483,22 @@ int amt_rotate_pole(amt_ctx* ctx, const double* rot, const double* lat, const do
     AMT_REQUIRE(ctx, rot && (n == 0 || (lat && lon && out_lat && out_lon)), "NULL argument");
     AMT_REQUIRE(ctx, n >= 0 && a0 > 0 && b0 > 0, "bad size or axes");
     if (n == 0) return AMT_OK;
-    hipLaunchKernelGGL(k_rotate_pole, grid_for(n), dim3(kBlock), 0, ctx->stream, make_mat3(rot), make_bowring(a0, b0),
-                       lat, lon, altitude, n, out_lat, out_lon);
+    const bowring w = make_bowring(a0, b0);
+    hipLaunchKernelGGL(k_rotate_pole<false>, grid_for(n), dim3(kBlock), 0, ctx->stream, make_mat3(rot), w, w.e2a / w.a, lat, lon,
+                       altitude, n, out_lat, out_lon);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_rotate_pole_deg(amt_ctx* ctx, const double* rot, const double* lat_deg, const double* lon_deg, double altitude,
+                        int64_t n, double a0, double b0, double* out_lat_deg, double* out_lon_deg) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, rot && (n == 0 || (lat_deg && lon_deg && out_lat_deg && out_lon_deg)), "NULL argument");
+    AMT_REQUIRE(ctx, n >= 0 && a0 > 0 && b0 > 0, "bad size or axes");
+    if (n == 0) return AMT_OK;
+    const bowring w = make_bowring(a0, b0);
+    hipLaunchKernelGGL(k_rotate_pole<true>, grid_for(n), dim3(kBlock), 0, ctx->stream, make_mat3(rot), w, w.e2a / w.a, lat_deg,
+                       lon_deg, altitude, n, out_lat_deg, out_lon_deg);
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }

@@ -117,6 +117,8 @@ struct georef_args {
     unsigned long long* bin_acc;
     int bin_lon_wrap, bin_magnetic;
     int item_order, chunk_stride;       // amt_georef_out.item_order; stride of the interleaved chunk order
+    int bin_pole, pad_pole_;            // amt_georef_out.bin_pole: bin (and box) in the coordinates rotated by 90 deg about x
+    pole_consts pole;
     bin_event* bin_events;      // optional list for on-edge pixels (amt_georef_out.bin_events)
     unsigned int* bin_event_count;
     long long bin_event_cap;
@@ -581,6 +583,14 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
     // runs where that does not apply: first row of a chunk, previous row missed the shell, steps above 1.7 deg at
     // the limb, within 2 deg of the date line.
     constexpr bool kMagBox = MAG && BIN != 0;      // the box may be asked for in (MLat, SM longitude): bla / blo
+    // Pole plan (bin_pole; runs on the MAG variants, whose second pair of angles it takes over): the reference rotates a
+    // frame with a pole in view by +90 deg about x before binning (resample.py:176-201: geodetic -> ECEF at the mapping
+    // altitude -> rotation -> geodetic).  Here: the point is rebuilt from the Bowring numerator / denominator of its
+    // latitude and its (x, y) — no trigonometry —, turned (x, y, z) -> (x, -z, y), and its rotated latitude /
+    // longitude follow as the previous point's plus two small angles, exactly like MLat / SM longitude.  That locates a
+    // pixel to ~1e-11 deg; the few pixels within 1e-7 bins of an edge are re-evaluated with rotate_pole_deg, the very
+    // function the two-pass plan uses.
+    const bool pole_bin = kMagBox && A.bin_pole != 0;
     int n_valid = 0;
     auto box_add = [&](double la_v, double lo_v) {
         __hip_atomic_fetch_min(&sBox[wave][0][lane], la_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -679,6 +689,23 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
         sv = rotate3(karg_load<mat3>(karg_fresh(koff), offsetof(georef_args, m_geo_sm)), pt);
         const double q = __builtin_fma(sv.x, sv.x, sv.y * sv.y);
         sxy = q > 0 ? fx::sqrt_n(q) : 0.0;
+    };
+    // pole plan: geodetic latitude atan(n / d) and planar position (x, y) at the mapping altitude -> the rotated point's
+    // (x, y, Bowring numerator) in `sv` and its Bowring denominator in `sxy`, which is what sm_angles works on
+    auto pole_point = [&](double n, double d, double x, double y, vec3& sv, double& sxy) {
+#pragma clang fp contract(off)
+        const pole_consts pc = karg_load<pole_consts>(karg_fresh(koff), offsetof(georef_args, pole));
+        const double rs = fx::rsqrt_n(__builtin_fma(n, n, d * d));
+        const double sphi = n * rs, cphi = d * rs;
+        const double q = __builtin_fma(x, x, y * y);
+        const double ip = q > 0 ? fx::rsqrt_n(q) : 0.0;
+        const double big_n = pc.w.a * fx::rsqrt_n(__builtin_fma(-(pc.e2 * sphi), sphi, 1.0));
+        const double rc = ((big_n + pc.alt) * cphi) * ip;
+        const double gx = rc * x, gy = rc * y, gz = __builtin_fma(big_n, pc.one_minus_e2, pc.alt) * sphi;
+        double rn, rd, ir;
+        fx::bowring_nd(bw, gx, -gz, gy, rn, rd, ir);
+        sv.x = gx, sv.y = -gz, sv.z = rn;
+        sxy = rd;
     };
     auto sm_angles = [&](const vec3& ref, double ref_sxy, double ref_ml, double ref_sl, const vec3& sv, double sxy, double& ml,
                          double& sl) {
@@ -809,7 +836,7 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
                 // with bin_magnetic the bounding box is reduced over (MLat, SM longitude) as well
                 const bool magbox = BIN && A.bin_magnetic;
                 if (hit) {
-                    sm_point(p, sv, sxy);
+                    if (pole_bin) pole_point(bn, bd, p.x, p.y, sv, sxy); else sm_point(p, sv, sxy);
                     sm_angles(prev.s, prev.sxy, prev.ml, prev.sl, sv, sxy, sml, ssl);
                 }
                 const double mt = ssl * (24.0 / 360.0) + 12.0;
@@ -821,7 +848,11 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
                     bla = sml;
                     blo = (mt - 12.0) / (24.0 / 360.0);       // mltToSmLon, reference transform.py:388-401
                 }
-                if (kMagBox && !magbox) {
+                if (pole_bin) {
+                    bla = sml;
+                    blo = ssl;
+                }
+                if (kMagBox && !magbox && !pole_bin) {
                     bla = la;
                     blo = lo;
                 }
@@ -870,7 +901,7 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
             int bin_x = 0, bin_y = 0;            // 1-based bin indices of this pixel, 0 = not binned
             long long el_fix = 0;
             if (px_ok) {
-                double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN;
+                double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN, slc = NAN;
                 if (pc.x == pc.x) {
                     double inv_r, cn, cd;
                     fx::bowring_nd(bw, pc.x, pc.y, pc.z, cn, cd, inv_r);
@@ -890,8 +921,8 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
                     if (MAG) {
                         // relative to this lane's corner of the current row, like latitude and longitude
                         vec3 sc;
-                        double sxyc, slc;
-                        sm_point(pc, sc, sxyc);
+                        double sxyc;
+                        if (pole_bin) pole_point(cn, cd, pc.x, pc.y, sc, sxyc); else sm_point(pc, sc, sxyc);
                         sm_angles(sv, sxy, sml, ssl, sc, sxyc, ml, slc);
                         mt = slc * (24.0 / 360.0) + 12.0;
                     }
@@ -908,14 +939,22 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
                     // reference resample.py:301-351 on (lon, lat) or, for resampleMLatMLT, on
                     // (SM longitude = mltToSmLon(mlt), MLat) (mapping.py:1519-1547, transform.py:388-401)
                     double bxv = (MAG && A.bin_magnetic) ? (mt - 12.0) / (24.0 / 360.0) : loc;
-                    const double byv = (MAG && A.bin_magnetic) ? ml : lac;
+                    double byv = (MAG && A.bin_magnetic) ? ml : lac;
+                    if (pole_bin) bxv = slc, byv = ml;
                     if (lon_wrap) bxv = wrap180_shifted(bxv);
                     int bx, by;
                     bool slow;
                     bin_common(bxv, byv, bx, by, slow);
                     unsigned int edge_flags = 0;
                     if (__ballot(slow)) {          // wave-uniform and rare
-                        if (slow) bin_slow(bxv, byv, bx, by, edge_flags);
+                        if (slow) {
+                            if (pole_bin) {
+                                // next to an edge: the rotated coordinates as the two-pass plan computes them
+                                const pole_consts pk = karg_load<pole_consts>(karg_fresh(koff), offsetof(georef_args, pole));
+                                rotate_pole_deg(pk.w, pk.rot, pk.e2, lac, loc, pk.alt, byv, bxv);
+                            }
+                            bin_slow(bxv, byv, bx, by, edge_flags);
+                        }
                     }
                     if (bx > 0 && by > 0) {
                         el_fix = __double2ll_rn(el * kFix);
@@ -1108,7 +1147,8 @@ void launch_rows(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 grid, b
 }
 
 // One thread per lattice corner (every `stride`-th pixel corner): bounding box of the corners whose own ray
-// has an elevation >= min_elev, in (lat, lon) or (MLat, SM longitude).  Partials per workgroup.
+// has an elevation >= min_elev, in (lat, lon), (MLat, SM longitude) [magnetic = 1] or (lat, lon) rotated by 90 deg
+// about x [magnetic = 2, the pole plan].  Partials per workgroup.
 __global__ __launch_bounds__(kThreads) void k_coarse_bbox(georef_args A, int stride, int magnetic, double min_elev,
                                                            double* __restrict__ partials) {
     __shared__ double sRed[8][kThreads / 64];
@@ -1128,13 +1168,14 @@ __global__ __launch_bounds__(kThreads) void k_coarse_bbox(georef_args A, int str
             c = fmin(1.0, fmax(-1.0, c));
             if (fm::asin_deg(c) >= min_elev) {
                 double la, lo;
-                if (magnetic) {
+                if (magnetic == 1) {
                     double mt;
                     sm_to_mlat_mlt_fast(mul(A.m_sm, p), la, mt);
                     lo = (mt - 12.0) / (24.0 / 360.0);
                 } else {
                     const vec3 g = mul(A.m_geo, p);
                     ecef_to_geodetic_deg_fast(A.bw, g.x, g.y, g.z, la, lo);
+                    if (magnetic == 2) rotate_pole_deg(A.pole.w, A.pole.rot, A.pole.e2, la, lo, A.pole.alt, la, lo);
                 }
                 v[0] = v[1] = la;
                 v[2] = v[3] = lo;
@@ -1265,7 +1306,8 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     int bin = 0;
     A.bin_img = nullptr;
     A.bin_acc = nullptr;
-    A.bin_lon_wrap = A.bin_magnetic = 0;
+    A.bin_lon_wrap = A.bin_magnetic = A.bin_pole = A.pad_pole_ = 0;
+    A.pole = make_pole_consts(p->a0, p->b0, 0.0);
     A.bin_events = nullptr;
     A.bin_event_count = nullptr;
     A.bin_event_cap = 0;
@@ -1297,6 +1339,14 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
         A.bin_acc = reinterpret_cast<unsigned long long*>(out->bin_acc);
         A.bin_lon_wrap = out->bin_lon_wrap ? 1 : 0;
         A.bin_magnetic = out->bin_magnetic ? 1 : 0;
+        if (out->bin_pole) {
+            AMT_REQUIRE(ctx, !A.bin_magnetic && !A.bin_lon_wrap, "bin_pole excludes bin_magnetic and bin_lon_wrap");
+            AMT_REQUIRE(ctx, dirs == nullptr, "bin_pole needs the camera model");
+            AMT_REQUIRE(ctx, std::fabs((p->a - p->a0) - out->altitude) < 1e-6 && std::fabs((p->b - p->b0) - out->altitude) < 1e-6,
+                        "bin_pole: amt_georef_out.altitude does not match the shell of the frame");
+            A.bin_pole = 1;
+            A.pole = make_pole_consts(p->a0, p->b0, out->altitude);
+        }
         if (out->bin_events != nullptr) {
             AMT_REQUIRE(ctx, out->bin_event_count != nullptr && out->bin_event_capacity > 0, "bin_events needs a counter and a capacity");
             A.bin_events = static_cast<bin_event*>(out->bin_events);
@@ -1336,7 +1386,7 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     F->out = out;
     F->tail = tail;
     F->fold = fold;
-    F->mag = out->mlat != nullptr || out->mlat_c != nullptr || A.bin_magnetic;
+    F->mag = out->mlat != nullptr || out->mlat_c != nullptr || A.bin_magnetic || A.bin_pole;
     F->bin = bin;
     return AMT_OK;
 }
@@ -1458,6 +1508,7 @@ int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stri
     A.m_geo = make_mat3(p->m_geo);
     A.m_sm = make_mat3(p->m_sm);
     A.bw = make_bowring_fast(p->a0, p->b0);
+    A.pole = make_pole_consts(p->a0, p->b0, p->a - p->a0);      // (coarse: the altitude need not be exact to the bit)
     A.width = p->width;
     A.height = p->height;
     const int nxl = (p->width + stride - 1) / stride + 1, nyl = (p->height + stride - 1) / stride + 1;
@@ -1467,8 +1518,8 @@ int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stri
         ctx->last_error = "amt_georef_coarse_bbox: workspace allocation failed";
         return AMT_ENOMEM;
     }
-    hipLaunchKernelGGL(k_coarse_bbox, dim3(nblocks), dim3(kThreads), 0, ctx->stream, A, stride, magnetic ? 1 : 0,
-                       min_elevation, partials);
+    hipLaunchKernelGGL(k_coarse_bbox, dim3(nblocks), dim3(kThreads), 0, ctx->stream, A, stride,
+                       magnetic == 2 ? 2 : (magnetic ? 1 : 0), min_elevation, partials);
     AMT_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, ctx->stream, partials, nblocks, bbox,
                        (const unsigned int*)nullptr);

@@ -29,12 +29,14 @@ struct amt_pipe {
     // state of the frame in flight
     bool coarse_pending, launched, fused, ready, tail_pending;
     bool coarse_hinted;            // the pending coarse box came from the caller (amt_pipe_coarse_hint), no kernel ran
-    int coarse_magnetic;           // coordinates of the pending coarse box (0 geodetic, 1 MLat / SM longitude)
+    int coarse_magnetic;           // coordinates of the pending coarse box (0 geodetic, 1 MLat / SM longitude,
+                                   // 2 geodetic rotated by 90 deg about x: the pole plan)
     int lon_wrap;                  // the frame straddles the 180 deg discontinuity: longitudes are binned shifted by 180
     amt_grid super, exact;
     int32_t off_x, off_y;          // window of the exact grid inside the superset
     double lat_ppd, lon_ppd, min_elev;
     int pole;
+    bool pole_plan;                // this frame is binned in the coordinates rotated by 90 deg about x (bin_pole)
     int img_dtype;
 };
 
@@ -207,10 +209,13 @@ int amt_pipe_destroy(amt_pipe* pipe) {
     return AMT_OK;
 }
 
-int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation, int magnetic) {
-    if (pipe == nullptr) return AMT_EINVAL;
+}  // extern "C"
+
+namespace {
+
+// coarse box in the coordinates of `mode` (see amt_pipe.coarse_magnetic)
+int pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation, int mode) {
     amt_ctx* ctx = pipe->ctx;
-    AMT_REQUIRE(ctx, p != nullptr, "NULL argument");
     // the pre-pass runs on the driver's own stream (and with that stream's workspace, see amt_workspace): the
     // context's stream is busy with the previous frames' kernels
     hipStream_t saved = ctx->stream;
@@ -218,14 +223,27 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
     const double thr = std::isinf(min_elevation) ? min_elevation : min_elevation - 0.5;
     const int shorter = p->width < p->height ? p->width : p->height;
     const int stride = std::max(1, std::min(kCoarseStride, shorter / 128));
-    int rc = amt_georef_coarse_bbox(ctx, p, stride, thr, magnetic ? 1 : 0, pipe->host_small_dev);
+    int rc = amt_georef_coarse_bbox(ctx, p, stride, thr, mode, pipe->host_small_dev);
     ctx->stream = saved;
     if (rc != AMT_OK) return rc;
     AMT_HIP(ctx, hipEventRecord(pipe->coarse_done, pipe->pre_stream));
     pipe->coarse_pending = true;
     pipe->coarse_hinted = false;
-    pipe->coarse_magnetic = magnetic ? 1 : 0;
+    pipe->coarse_magnetic = mode;
     return AMT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation, int magnetic) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipe->ctx;
+    AMT_REQUIRE(ctx, p != nullptr, "NULL argument");
+    // a geodetic frame with a pole in view is binned in rotated coordinates (the pole plan): its box is needed in those
+    const int mode = magnetic ? 1 : (pole_visible(p, min_elevation, 0) ? 2 : 0);
+    return pipe_coarse(pipe, p, min_elevation, mode);
 }
 
 }  // extern "C"
@@ -241,8 +259,14 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
     AMT_REQUIRE(ctx, p && out && img, "NULL argument");
     AMT_REQUIRE(ctx, img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
     magnetic = magnetic ? 1 : 0;
-    if (!pipe->coarse_pending || pipe->coarse_magnetic != magnetic) {
-        if (int rc = amt_pipe_coarse(pipe, p, min_elevation, magnetic)) return rc;
+    pipe->pole = pole_in_view < 0 ? (pole_visible(p, min_elevation, magnetic) ? 1 : 0) : (pole_in_view ? 1 : 0);
+    // geodetic frames with a pole in view take the pole plan (binned in rotated coordinates); a magnetic pole in view
+    // of an MLat / MLT frame still means the general path
+    const int mode = magnetic ? 1 : (pipe->pole ? 2 : 0);
+    pipe->pole_plan = mode == 2;
+    if (!pipe->coarse_pending || pipe->coarse_magnetic != mode) {
+        if (pipe->coarse_pending && !pipe->coarse_hinted) AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
+        if (int rc = pipe_coarse(pipe, p, min_elevation, mode)) return rc;
     }
     if (!pipe->coarse_hinted) AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
     pipe->coarse_pending = false;
@@ -250,7 +274,6 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
     pipe->lat_ppd = lat_px_per_deg;
     pipe->lon_ppd = lon_px_per_deg;
     pipe->min_elev = min_elevation;
-    pipe->pole = pole_in_view < 0 ? (pole_visible(p, min_elevation, magnetic) ? 1 : 0) : (pole_in_view ? 1 : 0);
     pipe->img_dtype = img_dtype;
     pipe->fused = false;
 
@@ -270,7 +293,7 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
     o.bin_acc = nullptr;
     o.bin_xaxis = o.bin_yaxis = nullptr;
     o.bin_img = nullptr;
-    o.bin_img_dtype = o.bin_lon_wrap = o.bin_magnetic = 0;
+    o.bin_img_dtype = o.bin_lon_wrap = o.bin_magnetic = o.bin_pole = 0;
     o.bin_events = nullptr;
     o.bin_event_count = nullptr;
     o.bin_event_capacity = 0;
@@ -286,9 +309,10 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
 
     // coarse [lat_min, lat_max, lon_min, lon_max, lon_min_positive, lon_max_nonpositive, n, hint]
     const double* c = pipe->host_small;
-    bool fuse = c[6] > 0 && !pipe->pole;
+    bool fuse = c[6] > 0 && (!pipe->pole || pipe->pole_plan);
     pipe->lon_wrap = 0;
     double box_lo = c[2], box_hi = c[3];
+    if (fuse && pipe->pole_plan && c[3] - c[2] > 180) fuse = false;      // (cannot happen: the rotated frame sits at the equator)
     if (fuse && c[3] - c[2] > 180) {
         // the box straddles the 180 deg discontinuity (mappings are narrower than 180 deg, mapping.py:722-737):
         // west = smallest positive, east = largest non-positive longitude; bin longitudes shifted by 180 deg
@@ -322,6 +346,7 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
         o.bin_img_dtype = img_dtype;
         o.bin_acc = pipe->acc;
         o.bin_magnetic = magnetic;
+        o.bin_pole = pipe->pole_plan ? 1 : 0;
         o.bin_lon_wrap = pipe->lon_wrap;
         o.bin_events = pipe->events;
         o.bin_event_count = pipe->event_count;
@@ -360,7 +385,8 @@ int amt_pipe_coarse_hint(amt_pipe* pipe, const double* bbox, int magnetic) {
     for (int i = 0; i < 7; ++i) pipe->host_small[i] = bbox[i];
     pipe->host_small[7] = 0;                       // no hit statistics: item order from the camera model
     pipe->coarse_pending = true;
-    pipe->coarse_magnetic = magnetic ? 1 : 0;
+    // the exact box of a pole-plan frame (bbox[7] = 1 in amt_pipe_result of a fused frame) is in rotated coordinates
+    pipe->coarse_magnetic = magnetic ? 1 : (bbox[7] != 0 ? 2 : 0);
     pipe->coarse_hinted = true;
     return AMT_OK;
 }
@@ -420,11 +446,19 @@ int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result) {
     }
     result->status = 1;
     pipe->n_events = pipe->fused ? (long long)b[7] : 0;        // the last fold put the counter into slot 7
-    if (!pipe->fused || pipe->pole) return AMT_OK;
+    if (!pipe->fused || (pipe->pole && !pipe->pole_plan)) return AMT_OK;
     result->edge_pixels = (int32_t)(pipe->n_events > 2000000000ll ? 2000000000ll : pipe->n_events);
     if (pipe->n_events > kEventCapacity) return AMT_OK;         // more on-edge pixels than records: general path
     const bool straddles = b[3] - b[2] > 180;
     if (straddles != (pipe->lon_wrap != 0)) return AMT_OK;      // the coarse pass judged the discontinuity differently
+    if (pipe->pole_plan) {
+        // the kernel knows the rotated corners to ~1e-11 deg, the two-pass plan to the bit: the grids are the same
+        // unless an extreme of the box sits that close to a grid node (k / px-per-deg); then the general path decides
+        if (straddles) return AMT_OK;
+        const double v[4] = {b[0] * pipe->lat_ppd, b[1] * pipe->lat_ppd, b[2] * pipe->lon_ppd, b[3] * pipe->lon_ppd};
+        for (int i = 0; i < 4; ++i)
+            if (!(std::fabs(v[i] - std::nearbyint(v[i])) > 1e-6)) return AMT_OK;
+    }
     double lon_lo = b[2], lon_hi = b[3];
     if (straddles) {
         if (!(std::isfinite(b[4]) && std::isfinite(b[5]))) return AMT_OK;

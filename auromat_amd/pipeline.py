@@ -228,6 +228,7 @@ class FramePipeline(object):
             mag = 1 if fuse_magnetic else 0
             if not coarse_started:
                 self.start_coarse(p, min_elevation, mag)
+            out.altitude = float(altitude)
             self._pcall('amt_pipe_launch', C.byref(p), C.byref(out), fd.img.data_ptr(),
                         fd.img_dtype_code, min_elev, float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1, mag)
             self._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
@@ -258,14 +259,16 @@ class FramePipeline(object):
         Context.current(ctx.device)
         min_elev = NEG_INF if min_elevation is None else float(min_elevation)
         mag = 1 if fuse_magnetic else 0
+        if not isinstance(altitudes, (list, tuple)):
+            altitudes = [altitudes] * n
+        for q, altitude in zip(pipes, altitudes):
+            q._out.altitude = float(altitude)
         handles = (C.c_void_p * n)(*[q._pipe() for q in pipes])
         pp = (C.c_void_p * n)(*[C.addressof(p) for p in params])
         oo = (C.c_void_p * n)(*[C.addressof(q._out) for q in pipes])
         ii = (C.c_void_p * n)(*[q.fd.img.data_ptr() for q in pipes])
         ctx.check(ctx._lib.amt_pipe_launch_many(handles, n, pp, oo, ii, pipes[0].fd.img_dtype_code, min_elev,
                                                 float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1, mag))
-        if not isinstance(altitudes, (list, tuple)):
-            altitudes = [altitudes] * n
         for q, p, altitude in zip(pipes, params, altitudes):
             q.params, q.altitude, q.min_elevation = p, altitude, min_elevation
             q._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
@@ -274,10 +277,12 @@ class FramePipeline(object):
 
     def bounding_box(self):
         """Waits for the fused reduction of the last georef() -> BoundingBox; ValueError if nothing is valid."""
-        if self._fused is not None and not self._fused['magnetic']:
+        if self._fused is not None and not self._fused['magnetic'] and not \
+                (self._wait_fused().fused and self._wait_fused().bbox[7]):
             red = np.array(self._wait_fused().bbox[:])
         elif self._fused is not None:
-            # the driver reduced the box over (MLat, SM longitude); the geodetic one comes from the corner arrays
+            # the driver reduced the box over (MLat, SM longitude) or, pole in view, over the rotated corners; the
+            # geodetic one comes from the corner arrays
             self.coordinates()
             red = self._reduce_bbox(self.fd.lat, self.fd.lon)
             red[7] = 1.0 if pole_in_view(self.params, self.min_elevation) else 0.0
@@ -316,6 +321,7 @@ class FramePipeline(object):
         g = res.grid
         b = res.bbox
         wrapped = bool(res.lon_wrapped)
+        pole = bool(b[7]) and not self._fused['magnetic']       # the pole plan: grid in rotated coordinates
         if wrapped:
             # straddles the 180 deg discontinuity: the grid is laid out for longitudes shifted by 180 deg
             box = (b[0], b[1], wrap_at_180(b[4] + 180), wrap_at_180(b[5] + 180))
@@ -329,7 +335,8 @@ class FramePipeline(object):
         self._pcall('amt_pipe_finalize', ptr(mean), ptr(img), ptr(mask), ptr(count))
         if not (keep_on_device and self.defer_join):
             self.join()
-        out = dict(has_elev=True, grid=grid, contains_pole=False, contains_discontinuity=wrapped,
+        # (BoundingBox.containsDiscontinuity is true for every box with a pole in it, reference mapping.py:200-206)
+        out = dict(has_elev=True, grid=grid, contains_pole=pole, contains_discontinuity=wrapped or pole,
                    altitude=self.altitude)
         if keep_on_device:
             out.update(mean=mean, img=img, mask=mask, count=count)
@@ -350,7 +357,8 @@ class FramePipeline(object):
         if self._fused is not None and self._fused['pxPerDeg'] == tuple(pxPerDeg) and \
                 self._fused['magnetic'] == bool(magnetic):
             res = self._wait_fused()
-            if res.status == 0 and not containsPole:       # status 0: neither pole nor discontinuity in the frame
+            # status 0: the driver could finalise the frame; a caller's containsPole must agree with its decision
+            if res.status == 0 and (containsPole is None or bool(containsPole) == bool(res.bbox[7])):
                 self.last_plan = 'single-pass'
                 return self._finalize_fused(res, tuple(pxPerDeg), keep_on_device)
         self.coordinates()          # (grids-only pipelines: the arrays the two-pass plan reads are computed now)

@@ -252,12 +252,15 @@ def _rot_x(angle):
 
 def _rotate_pole_dev(ctx, lat_deg, lon_deg, altitude, angle):
     """rotatePole (reference transform.py:301-322) on device tensors in degrees."""
-    import torch
-    la, lo = torch.deg2rad(lat_deg).reshape(-1), torch.deg2rad(lon_deg).reshape(-1)
+    la, lo = lat_deg.reshape(-1), lon_deg.reshape(-1)
+    if not la.is_contiguous():
+        la = la.contiguous()
+    if not lo.is_contiguous():
+        lo = lo.contiguous()
     ola, olo = ctx.empty(la.shape), ctx.empty(lo.shape)
-    ctx.call('amt_rotate_pole', host9(_rot_x(angle)), ptr(la), ptr(lo), float(altitude), la.numel(), wgs84A, wgs84B,
+    ctx.call('amt_rotate_pole_deg', host9(_rot_x(angle)), ptr(la), ptr(lo), float(altitude), la.numel(), wgs84A, wgs84B,
              ptr(ola), ptr(olo))
-    return torch.rad2deg(ola).reshape(lat_deg.shape), torch.rad2deg(olo).reshape(lon_deg.shape)
+    return ola.reshape(lat_deg.shape), olo.reshape(lon_deg.shape)
 
 
 def _rotate_pole_host(lat_deg, lon_deg, altitude, angle):
@@ -337,9 +340,15 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
         else:
             # (no outline at hand — the frame pipeline: all unmasked corners, the same unless the mask has islands)
             rla, rlo = _rotate_pole_dev(ctx, fd.lat, fd.lon, altitude, 90)
+            corner, cmask = fd.corner_mask_tensor(), fd.center_mask_tensor()
+            if min_elevation is not None and fd.elev is not None:
+                # maskedByElevation(min_elevation) is fused into the binning pass below; the box is that of the corners
+                # which survive it (mapping.py:845-864 + the lazy sanitisation, 1161-1213)
+                cmask = (cmask.bool() | ~(fd.elev >= float(min_elevation))).to(torch.uint8)
+                corner = corner.clone()
+                ctx.call('amt_sanitize_masks', ptr(corner), ptr(cmask), None, fd.height, fd.width, 1)
             red = ctx.empty((8,))
-            ctx.call('amt_bbox_corners', ptr(rla), ptr(rlo), ptr(fd.corner_mask_tensor()),
-                     ptr(fd.center_mask_tensor()), fd.height, fd.width, ptr(red))
+            ctx.call('amt_bbox_corners', ptr(rla), ptr(rlo), ptr(corner), ptr(cmask), fd.height, fd.width, ptr(red))
             r = to_host(red)
             latMin, latMax, lonMin, lonMax = r[0], r[1], r[2], r[3]
         lat_c, lon_c = _rotate_pole_dev(ctx, fd.lat_c, fd.lon_c, altitude, 90)

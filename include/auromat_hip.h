@@ -129,7 +129,8 @@ typedef struct amt_georef_out {
     double bbox_min_elevation;
     /* Optional fused binning (single-pass resample(method='mean'), auromat/resample.py:301-351): when
      * bin_acc != NULL every pixel with elevation >= bbox_min_elevation is binned right where it is
-     * computed — x = lon_c, y = lat_c, or (SM longitude, MLat) with bin_magnetic — into the uint64
+     * computed — x = lon_c, y = lat_c, or (SM longitude, MLat) with bin_magnetic, or the pole-rotated
+     * (lon, lat) with bin_pole — into the uint64
      * accumulator planes of amt_bin_frame (count, 3 channel sums, fixed-point elevation), so the centre
      * arrays need not be read back (and need not be written at all: lat_c/lon_c/elev may be NULL).
      * The grid must be known before the launch: callers use a superset of the final grid, aligned to the
@@ -161,6 +162,14 @@ typedef struct amt_georef_out {
     void* bin_events;
     uint32_t* bin_event_count;
     int64_t bin_event_capacity;
+    /* Pole plan of the fused binning (a pole of the mapping is in view; not with bin_magnetic / bin_lon_wrap): pixels are
+     * binned at (lat, lon) rotated by +90 deg about x at `altitude` — amt_rotate_pole_deg of (lat_c, lon_c), reference
+     * resample.py:176-201 — and bbox[0..5] are reduced over the rotated corners (to ~1e-11 deg: good for laying out the
+     * grid unless an extreme sits within that of a grid node, see amt_pipe_wait).  `altitude` [km] is the mapping
+     * altitude the shell (a, b) = (a0, b0) + altitude was built from, as rotatePole takes it. */
+    int32_t bin_pole;
+    int32_t reserved_pole;
+    double altitude;
 } amt_georef_out;
 
 /* ---- building blocks (auromat.coordinates) ------------------------------------------- */
@@ -214,6 +223,11 @@ int amt_sm_to_latlon(amt_ctx* ctx, const double* m_sm_to_geo, const double* smla
  * 3x3 `rot` (host) about the origin, back to geodetic (rad). */
 int amt_rotate_pole(amt_ctx* ctx, const double* rot, const double* lat, const double* lon, double altitude,
                     int64_t n, double a0, double b0, double* out_lat, double* out_lon);
+/* The same with degrees in and out (lat_deg * pi/180 -> amt_rotate_pole -> * 180/pi, rounding for rounding what
+ * np.deg2rad / np.rad2deg around the call give): what the pole branch of the resampling works in
+ * (auromat/resample.py:176-201,262-273). */
+int amt_rotate_pole_deg(amt_ctx* ctx, const double* rot, const double* lat_deg, const double* lon_deg, double altitude,
+                        int64_t n, double a0, double b0, double* out_lat_deg, double* out_lon_deg);
 /* auromat/coordinates/transform.py:142-154 cartesian_to_spherical -> (r, lat, lon) radians; out_r may be NULL. */
 int amt_cartesian_to_spherical(amt_ctx* ctx, const double* x, const double* y, const double* z, int64_t n,
                                double* out_r, double* out_lat, double* out_lon);
@@ -267,7 +281,8 @@ int amt_georef_frame_dirs(amt_ctx* ctx, const amt_frame_params* p, const double*
                           const amt_georef_out* out);
 /* Cheap estimate of the same bbox[0..6] from every `stride`-th pixel corner in both directions (a
  * 1/stride^2 sample of the rays): a corner counts when the elevation of its own ray is >= min_elevation.
- * With magnetic != 0 the box is in (MLat, SM longitude) instead of (lat, lon).  Used to lay out a superset
+ * With magnetic == 1 the box is in (MLat, SM longitude) instead of (lat, lon), with magnetic == 2 in (lat, lon)
+ * rotated by +90 deg about x at the altitude a - a0 (the pole plan, amt_georef_out.bin_pole).  Used to lay out a superset
  * grid for the fused binning before the full kernel runs; the caller adds a safety margin and checks the
  * exact box afterwards.  bbox[7] = sx * 2^20 + sy, where sx (sy) is the number of sampled rays that hit the
  * shell right of (below) the frame centre minus those left of (above) it: the input of amt_georef_out.item_order. */
@@ -422,16 +437,18 @@ int amt_grid_layout(double lat_px_per_deg, double lon_px_per_deg, double lat_min
                     double lon_min, double lon_max, amt_grid* out);
 
 /* Single-pass driver: georeference + mask by elevation + bounding box + grid + binned mean of one frame with
- * the binning fused into the georeferencing kernel (see amt_georef_out.bin_*), for geodetic or MLat/MLT grids that
- * do not contain a pole (frames that straddle the 180 deg discontinuity are binned with shifted longitudes).  Separate calls per stage so that frames can be software
- * pipelined by one host thread:
+ * the binning fused into the georeferencing kernel (see amt_georef_out.bin_*), for geodetic grids (frames that straddle
+ * the 180 deg discontinuity are binned with shifted longitudes, frames with a pole in view in coordinates rotated by
+ * 90 deg about x: reference resample.py:176-218) and for MLat/MLT grids without a magnetic pole in view.  Separate calls
+ * per stage so that frames can be software pipelined by one host thread:
  *   amt_pipe_coarse   enqueue the coarse bounding-box pre-pass (own high-priority stream), any time earlier
  *   amt_pipe_launch   wait for it, lay out the superset grid, zero the accumulators, launch the fused kernel
  *                     on the context's stream, start the copy of the exact bounding box
  *   amt_pipe_wait     wait for the exact box (the only host synchronisation), lay out the exact grid
  *   amt_pipe_finalize crop + finalise into arrays the caller sized from the grid amt_pipe_wait returned
- * status in amt_pipe_result: 0 = ready to finalise; 1 = this frame needs the general path (pole in view,
- * exact box outside the superset) — the coordinate arrays and bbox are valid, nothing else;
+ * status in amt_pipe_result: 0 = ready to finalise; 1 = this frame needs the general path (magnetic pole in view,
+ * exact box outside the superset, an extreme of a pole frame's box within 1e-6 cells of a grid node) — the coordinate
+ * arrays and bbox are valid, nothing else;
  * 2 = no pixel above the elevation threshold (mapping.py:858-859 -> ValueError). */
 typedef struct amt_pipe amt_pipe;
 typedef struct amt_pipe_result {
@@ -441,7 +458,9 @@ typedef struct amt_pipe_result {
                              * shifted by 180 deg (wrap_at_180(lon + 180)) and the caller shifts the output
                              * coordinates back (reference resample.py:203-218,274-277) */
     int32_t edge_pixels;    /* pixels on a bin edge (right-most-edge rule) that were resolved separately */
-    double bbox[8];         /* exact reduction of amt_georef_frame; [7] = 1 when a pole is in view */
+    double bbox[8];         /* exact reduction of amt_georef_frame; [7] = 1 when a pole is in view: for a geodetic frame
+                             * [0..5] are then in the rotated coordinates the grid is laid out in (amt_georef_out.
+                             * bin_pole), and the caller rotates the output coordinates back (resample.py:262-273) */
     amt_grid grid;          /* exact output grid (valid for status 0) */
 } amt_pipe_result;
 int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe);
@@ -452,7 +471,8 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
  * move by a fraction of the superset margin, and a frame whose exact box does not fit its superset grid takes
  * the general path anyway (status 1), so a poor estimate costs time, never correctness. */
 int amt_pipe_coarse_hint(amt_pipe* pipe, const double* bbox, int magnetic);
-/* out: arrays to write (lat .. mlt_c as in amt_georef_frame; bbox / bin_* fields are managed by the driver).
+/* out: arrays to write (lat .. mlt_c as in amt_georef_frame; bbox / bin_* fields are managed by the driver) and
+ * out->altitude, the mapping altitude [km] (read when a pole is in view).
  * img: (height, width, 3) uint8 (img_dtype 1) or uint16 (2).  min_elevation: -inf disables the mask.
  * pole_in_view: 0 / 1 = the caller's decision, < 0 = decide from the camera model (is a pole of the mapping
  * shell imaged by a valid pixel; replaces geodesic.py:183 / mapping.py:705-721 for camera mappings).

@@ -23,6 +23,8 @@ Fixtures
   config1_*.npz         BASELINE.json configs[0] / SURVEY 8d config 1: the 512x512 synthetic frame (fast + exact
                         centres): every 4th sample + digests of all arrays, masks, and the full
                         maskedByElevation(10) -> resample(pxPerDeg=10, 'mean') output
+  pole_frame_*.npz      a 200x160 camera frame with the north (south) pole in view (fast + exact centres):
+                        maskedByElevation(10) -> _resample(containsPole=True, pxPerDeg=8) output, inputs included
 """
 import json
 import os
@@ -756,6 +758,58 @@ def config1():
         out.update(cam=cam, altitude=np.float64(110), step=np.int64(step), min_elev=np.float64(10),
                    ppd=np.array((10, 10), dtype=np.float64), image_seed=np.int64(1))
         save('config1_%s.npz' % ('fast' if fast else 'exact'), **out)
+
+
+def pole_frame_header(south=False):
+    """A 200x160 frame of a camera 400 km above 83 deg latitude that looks across the pole (which is imaged well inside
+    the frame): the pole branch of the resampling on a camera mapping."""
+    w, h = 200, 160
+    t = datetime(2012, 1, 25, 9, 26, 55, 60000)
+    m_geo = np.asarray(T.mat_j2000_to_geo(T.date2es(t)))
+    sgn = -1.0 if south else 1.0
+
+    def geo(lat, lon, r):
+        la, lo = np.deg2rad(lat), np.deg2rad(lon)
+        return r * np.array([np.cos(la) * np.cos(lo), np.cos(la) * np.sin(lo), np.sin(la)])
+
+    cam_geo = geo(sgn * 83.0, 30.0, 6360.0 + 400.0)
+    target = geo(sgn * 87.5, -140.0, 6360.0 + 110.0)
+    bore = m_geo.T.dot(target - cam_geo)
+    bore /= np.linalg.norm(bore)
+    cam = m_geo.T.dot(cam_geo)
+    hdr = {'CTYPE1': 'RA---TAN', 'CTYPE2': 'DEC--TAN', 'LONPOLE': 180.0, 'LATPOLE': 0.0,
+           'CRVAL1': float(np.rad2deg(np.arctan2(bore[1], bore[0])) % 360), 'CRVAL2': float(np.rad2deg(np.arcsin(bore[2]))),
+           'CRPIX1': w / 2 + 0.5, 'CRPIX2': h / 2 + 0.5, 'CD1_1': -0.33, 'CD1_2': 0.05, 'CD2_1': 0.05, 'CD2_2': 0.33,
+           'IMAGEW': w, 'IMAGEH': h}
+    img = np.random.RandomState(7 + int(south)).randint(0, 65535, (h, w, 3)).astype(np.uint16)
+    return hdr, cam, t, img
+
+
+def pole_frames():
+    """pole_frame_{north,south}_{fast,exact}.npz: camera mapping -> maskedByElevation(10) -> _resample(containsPole=True)"""
+    for south in (False, True):
+        hdr, cam, t, img = pole_frame_header(south)
+        for fast in (True, False):
+            m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'pole', fastCenterCalculation=fast)
+            # (boundingBox.containsPole needs skimage's contour tracing, absent here: the pole is inside when |lat| gets to 90)
+            assert np.nanmax(np.abs(m.lats.filled(np.nan))) > 89.8, 'the frame does not contain the pole'
+            mm = m.maskedByElevation(10)
+            mm.checkGuarantees()
+            merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+            case = _run_resample(mm.lats, mm.lons, mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan), 110, merged,
+                                 (8, 8), pole=True)
+            rimg, relev = np.dsplit(case['out_data'], [-1])
+            with np.errstate(invalid='ignore'):
+                rimg = np.round(rimg)
+            rimg = np.require(ma.masked_invalid(rimg, copy=False), np.uint16)
+            del case['outline']
+            out = dict(case)
+            out.update(out_img=rimg.data, out_img_mask=ma.getmaskarray(rimg))
+            out.update(lat_c=mm.latsCenter.filled(np.nan), lon_c=mm.lonsCenter.filled(np.nan), img=img)
+            out.update(hdr_arrays(hdr))
+            out.update(time_arrays(t))
+            out.update(cam=cam, altitude=np.float64(110), min_elev=np.float64(10), ppd=np.array((8, 8), dtype=np.float64))
+            save('pole_frame_%s_%s.npz' % ('south' if south else 'north', 'fast' if fast else 'exact'), **out)
 
 
 if __name__ == '__main__':

@@ -314,8 +314,9 @@ def test_single_pass_plan_equals_two_pass(width, height, pointing):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
 
 
-def test_single_pass_plan_falls_back_on_pole():
-    """Frames with a pole (or the discontinuity) take the two-pass plan even when fusing is requested."""
+def test_single_pass_plan_with_camera_over_the_pole():
+    """A camera straight above the pole: the single-pass plan takes the frame (pole plan, tests/test_pole_frames.py) and
+    agrees with the two-pass plan."""
     from auromat_amd.pipeline import FramePipeline
     from auromat_amd.coordinates import transform as T
     t = datetime(2012, 1, 25, 9, 26, 55)
@@ -331,8 +332,11 @@ def test_single_pass_plan_falls_back_on_pole():
     pipe = FramePipeline(w, h)
     img = np.full((h, w, 3), 777, np.uint16)
     res = pipe.run(hdr, 110, cam, t, img=img, min_elevation=10, pxPerDeg=2, fuse=True)
-    assert pipe.last_plan == 'two-pass' and res['contains_pole']
+    assert pipe.last_plan == 'single-pass' and res['contains_pole']
     assert np.all(res['img'][~res['mask']] == 777)
+    two = FramePipeline(w, h).run(hdr, 110, cam, t, img=img, min_elevation=10, pxPerDeg=2, fuse=False)
+    for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
+        assert np.array_equal(res[k], two[k], equal_nan=True), k
 
 
 def test_sequence_pipeline_plans_agree_with_frame_by_frame():
@@ -540,7 +544,7 @@ def test_sequence_with_a_pole_frame_uint8_and_magnetic():
     for batch in (1, 2, 3):
         seq = SequencePipeline(w, h, img_dtype=np.uint8, pxPerDeg=3, batch=batch)
         out = seq.process(mixed, keep_on_device=False)
-        assert seq.plans == ['single-pass'] * 3 + ['two-pass'] + ['single-pass'] * 3
+        assert seq.plans == ['single-pass'] * 7         # the pole frame too (pole plan of the fused kernel)
         assert out[3]['contains_pole']
         for a, b in zip(out, ref):
             for key in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):

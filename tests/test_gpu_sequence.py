@@ -81,7 +81,7 @@ def test_keep_on_device_sequences_equal_frame_by_frame(how):
             got = seq.process(feed, keep_on_device=True)
             assert all(isinstance(r['mean'], torch.Tensor) and r['mean'].is_cuda for r in got)
             if plan == 'single-pass':
-                assert seq.plans.count('two-pass') == n_pole
+                assert seq.plans == ['single-pass'] * n      # pole frames included (pole plan of the fused kernel)
             got = [host(r) for r in got]    # only now
             for k in range(n):
                 for key in KEYS:
@@ -151,8 +151,8 @@ def test_gathered_dateline_frame_keeps_its_true_coordinates():
 
 
 def test_grids_only_pipeline_equals_the_full_one():
-    """keep_coordinates=False: the single-pass plan writes no per-pixel coordinate arrays; frames that need the two-pass
-    plan (a pole in view) compute them on demand.  Same grids, bit for bit; the arrays appear when asked for."""
+    """keep_coordinates=False: the single-pass plan writes no per-pixel coordinate arrays (pole frames included).  Same
+    grids, bit for bit; the arrays appear when asked for."""
     import torch
     from auromat_amd.pipeline import FramePipeline, SequencePipeline
     w, h, n = 530, 354, 11
@@ -161,12 +161,12 @@ def test_grids_only_pipeline_equals_the_full_one():
     want = [host(r) for r in full.process(frames)]
     lean = SequencePipeline(w, h, pxPerDeg=6, keep_coordinates=False)
     got = [host(r) for r in lean.process(frames)]
-    assert lean.plans == full.plans and lean.plans.count('two-pass') == 2
+    assert lean.plans == full.plans == ['single-pass'] * n
     for a, b in zip(got, want):
         for key in KEYS:
             assert np.array_equal(a[key], b[key], equal_nan=True), key
-    # no coordinate arrays were allocated for the slots that never saw a pole frame ...
-    assert sum(q.fd.lat is None for q in lean.pipes) >= 1
+    # no coordinate arrays were allocated ...
+    assert all(q.fd.lat is None for q in lean.pipes)
     # ... and a single frame's arrays come on demand, equal to the full pipeline's
     one = FramePipeline(w, h, alloc_coords=False)
     hdr, cam, t, img = frames[0]

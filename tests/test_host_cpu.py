@@ -42,7 +42,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     from auromat_amd._native import Axis, FrameParams, GeorefOut, Grid, PipeResult
     assert C.sizeof(FrameParams) == 16 + 8 * (4 + 2 + 9 + 3 + 4 + 9 + 9)
-    assert C.sizeof(GeorefOut) == 8 * 11 + 8 * 4 + 4 * 4 + 8 * 3
+    assert C.sizeof(GeorefOut) == 8 * 11 + 8 * 4 + 4 * 4 + 8 * 3 + 4 * 2 + 8
     assert C.sizeof(Axis) == 8 + 8 + 8 * 5
     assert C.sizeof(Grid) == 16 + 8 * 10 + 2 * C.sizeof(Axis)
     assert C.sizeof(PipeResult) == 16 + 8 * 8 + C.sizeof(Grid)

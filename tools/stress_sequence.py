@@ -3,7 +3,7 @@ against one-frame-at-a-time results; every mismatch is reported.  PIN=1: per-fra
 Both result modes: keep_on_device=False (a synchronisation after every frame) and the production default
 keep_on_device=True, where nothing synchronises between frames and the results are copied to the host only after
 process() has returned — the mode in which a frame buffer can be re-used while a kernel still reads it (ADVICE r1);
-every fifth frame looks at the pole, i.e. takes the two-pass plan in the middle of single-pass batches."""
+every fifth frame looks at the pole (pole plan of the fused kernel: another kernel variant in the middle of a batch)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
