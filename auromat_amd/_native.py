@@ -138,6 +138,7 @@ _SIGNATURES = {
     'amt_pipe_launch_many': ([c_void_pp, C.c_int32, c_void_pp, c_void_pp, c_void_pp, C.c_int32, _D, _D, _D, _I, _I], _I),
     'amt_pipe_wait': ([_P, C.POINTER(PipeResult)], _I),
     'amt_pipe_finalize': ([_P, _P, _P, _P, _P], _I),
+    'amt_pipe_finalize_stream': ([_P, _P], _I),
     'amt_pipe_join': ([_P], _I),
     'amt_seq_payload_size': ([C.POINTER(SeqFrame), C.c_int32, C.POINTER(_L)], _I),
     'amt_seq_pack': ([_P, C.POINTER(SeqFrame), C.c_int32, C.c_int32, _P, _L], _I),

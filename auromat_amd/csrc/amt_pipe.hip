@@ -508,6 +508,12 @@ int amt_pipe_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_
     return AMT_OK;
 }
 
+int amt_pipe_finalize_stream(amt_pipe* pipe, void** stream) {
+    if (pipe == nullptr || stream == nullptr) return AMT_EINVAL;
+    *stream = reinterpret_cast<void*>(pipe->fin_stream);
+    return AMT_OK;
+}
+
 int amt_pipe_join(amt_pipe* pipe) {
     if (pipe == nullptr) return AMT_EINVAL;
     amt_ctx* ctx = pipe->ctx;

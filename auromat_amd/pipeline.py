@@ -89,6 +89,7 @@ class FramePipeline(object):
         self._bbox_host = torch.empty(8, dtype=torch.float64, pin_memory=True)
         self._bbox_event = torch.cuda.Event()
         self._driver = None         # amt_pipe handle of the single-pass plan (created on first use)
+        self._fin_stream = None     # the driver's finalise stream as torch sees it (see _finalize_fused)
         self._fused = None          # single-pass launch in flight: its px/deg, later its amt_pipe_result
         self._pole = 0
         self.last_plan = None       # 'single-pass' or 'two-pass': what the last resample() did
@@ -180,6 +181,16 @@ class FramePipeline(object):
     def _pcall(self, name, *args):
         # amt_pipe_* take the driver handle (not the context) as their first argument
         self.ctx.check(getattr(self.ctx._lib, name)(self._pipe(), *args))
+
+    def _finalize_stream(self):
+        """The driver's finalise stream, wrapped for torch: tensors that the finalise kernel writes are allocated for
+        it (amt_pipe_finalize_stream)."""
+        import torch
+        if self._fin_stream is None:
+            handle = C.c_void_p()
+            self._pcall('amt_pipe_finalize_stream', C.byref(handle))
+            self._fin_stream = torch.cuda.ExternalStream(handle.value, device=self.ctx.device)
+        return self._fin_stream
 
     def join(self):
         """Order the current stream behind the single-pass driver's finalise kernels (see amt_pipe_join)."""
@@ -328,13 +339,24 @@ class FramePipeline(object):
         else:
             box = (b[0], b[1], b[2], b[3])
         grid = _GridView(g, pxPerDeg, box)
-        mean = ctx.empty((g.ny, g.nx, 4))
-        img = ctx.empty((g.ny, g.nx, 3), torch.uint8 if fd.img_dtype_code != 2 else torch.int16)
-        mask = ctx.empty((g.ny, g.nx), torch.uint8)
-        count = ctx.empty((g.ny, g.nx))
+        # The finalise kernel runs on the driver's own stream and does not wait for the current one.  The caching
+        # allocator hands out memory per stream: a block freed on the current stream (say the accumulators of a
+        # two-pass frame before this one) may go out again at once while kernels queued there still use it — fine
+        # for consumers on that stream, fatal for a kernel on another one that writes right away (found by
+        # tools/fuzz_sequence.py: frames that fell back to the two-pass plan inside a single-pass sequence came out
+        # wrong now and then).  So the outputs are allocated FOR the finalise stream, and the streams that read them
+        # are recorded on them.
+        cur = torch.cuda.current_stream(ctx.device)
+        with torch.cuda.stream(self._finalize_stream()):
+            mean = ctx.empty((g.ny, g.nx, 4))
+            img = ctx.empty((g.ny, g.nx, 3), torch.uint8 if fd.img_dtype_code != 2 else torch.int16)
+            mask = ctx.empty((g.ny, g.nx), torch.uint8)
+            count = ctx.empty((g.ny, g.nx))
         self._pcall('amt_pipe_finalize', ptr(mean), ptr(img), ptr(mask), ptr(count))
         if not (keep_on_device and self.defer_join):
             self.join()
+        for t_ in (mean, img, mask, count):
+            t_.record_stream(cur)
         # (BoundingBox.containsDiscontinuity is true for every box with a pole in it, reference mapping.py:200-206)
         out = dict(has_elev=True, grid=grid, contains_pole=pole, contains_discontinuity=wrapped or pole,
                    altitude=self.altitude)

@@ -68,3 +68,33 @@ def sequence_frame(k, width=4240, height=2832, pointing='iss030'):
     ang = 7.66 * k / r
     cam_k = r * (np.cos(ang) * u + np.sin(ang) * v)
     return hdr, cam_k, t + timedelta(seconds=k), k
+
+
+def random_sequence(rng, width, height, max_frames=40):
+    """
+    A sequence whose frames do NOT follow each other smoothly (what tools/fuzz_sequence.py feeds to SequencePipeline):
+    stretches of sequence_frame(), jumps to other pointings at times up to 95 min apart (date-line and pole frames
+    included), repeated frames, jumps back and forth inside the smooth sequence.
+
+    :param rng: np.random.RandomState (consumed in a fixed order: a seed names its sequences)
+    :return: list of (header, cameraPosGCRS, time, image)
+    """
+    n = int(rng.randint(1, max_frames))
+    frames = []
+    k = 0
+    while len(frames) < n:
+        mode = rng.randint(4)
+        if mode == 0:                                     # a smooth stretch of the synthetic sequence
+            for _ in range(int(rng.randint(1, 8))):
+                hdr, cam, t, seed = sequence_frame(k, width, height)
+                frames.append((hdr, cam, t, frame_image(width, height, seed=seed)))
+                k += 1
+        elif mode == 1:                                   # a jump somewhere else in time / pointing
+            hdr, cam, t = frame_header(width, height, ('iss030', 'iss029')[rng.randint(2)])
+            t = t - timedelta(minutes=float(rng.choice([0, 20, 45, 80, 95])))
+            frames.append((hdr, cam, t, frame_image(width, height, seed=1000 + len(frames))))
+        elif mode == 2 and frames:                        # the same frame again
+            frames.append(frames[-1])
+        else:
+            k = int(rng.randint(0, 300))
+    return frames[:n]

@@ -495,6 +495,11 @@ int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result);
  * buffers for result->grid of the preceding amt_pipe_wait (any may be NULL).  The kernel runs on the driver's
  * own stream so that it does not sit between two frames' big kernels on the context's stream. */
 int amt_pipe_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_mask, double* out_count);
+/* The stream (hipStream_t) amt_pipe_finalize enqueues on.  A host whose allocator is stream ordered (PyTorch's caching
+ * allocator, hipMallocAsync pools) must allocate the four output buffers FOR THIS STREAM: memory handed out for another
+ * stream may still be in use by work queued there (the driver's finalise kernel does not wait for the context's
+ * stream, that is its point), and the kernel would write into it too early. */
+int amt_pipe_finalize_stream(amt_pipe* pipe, void** stream);
 /* Orders the context's stream behind the last amt_pipe_finalize (no-op when it already completed): call it
  * before work on the context's stream — or, after amt_ctx_synchronize, the host — reads the outputs. */
 int amt_pipe_join(amt_pipe* pipe);

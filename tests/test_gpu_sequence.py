@@ -214,3 +214,31 @@ def test_c_abi_pack_writes_the_python_wire_format():
     assert np.array_equal(got[:n * DESC_LEN].reshape(n, DESC_LEN), descs.cpu().numpy())
     assert not got[n * DESC_LEN:max_frames * DESC_LEN].any()
     assert np.array_equal(got[max_frames * DESC_LEN:], payload.cpu().numpy(), equal_nan=True)
+
+
+def test_fallback_frames_inside_a_single_pass_sequence_do_not_race_with_the_finalise_stream():
+    """Sequence 35 of `tools/fuzz_sequence.py 80 1`: two frames whose box hint is too poor take the two-pass plan in the
+    middle of single-pass batches.  Their accumulators are torch temporaries of the main stream; the next frames'
+    outputs used to be carved from the same memory while the driver's finalise kernel — on its own stream — wrote them
+    at once (amt_pipe_finalize_stream: outputs are now allocated for that stream).  Timing dependent: 4 of 5 fuzz runs
+    hit it before the fix."""
+    import torch
+    from auromat_amd.pipeline import FramePipeline, SequencePipeline
+    from auromat_amd.synthetic import random_sequence
+    w, h = 250, 168
+    rng = np.random.RandomState(1)
+    for s in range(36):
+        frames = random_sequence(rng, w, h)
+        rng.randint(2), rng.choice([4, 8, 10])              # what the fuzzer draws per sequence
+    assert len(frames) == 24
+    one = FramePipeline(w, h)
+    want = [one.run(hd, 110, cam, t, img=img, pxPerDeg=4) for hd, cam, t, img in frames]
+    for rep in range(8):
+        seq = SequencePipeline(w, h, pxPerDeg=4, plan='single-pass', batch=3)
+        got = seq.process(frames, keep_on_device=True)
+        assert seq.plans.count('two-pass') >= 1 and seq.plans.count('single-pass') >= 20
+        got = [host(r) for r in got]
+        for k, (a, b) in enumerate(zip(got, want)):
+            for key in KEYS:
+                x = a[key].view(b[key].dtype) if key == 'img' else a[key].astype(b[key].dtype)
+                assert np.array_equal(x, b[key], equal_nan=True), (rep, k, key, seq.plans[k])

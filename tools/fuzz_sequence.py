@@ -2,36 +2,18 @@
 and pole frames included —, jumps back and forth, repeated frames) through SequencePipeline with every plan / batch
 size and hints on, against one frame at a time.  usage: fuzz_sequence.py [sequences] [seed]"""
 import os, sys
-from datetime import timedelta
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from auromat_amd.pipeline import FramePipeline, SequencePipeline
-from auromat_amd.synthetic import frame_header, frame_image, sequence_frame
+from auromat_amd.synthetic import random_sequence
 
 nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 w, h = 250, 168
 bad = 0
 for s in range(nseq):
-    n = int(rng.randint(1, 40))
-    frames = []
-    k = 0
-    while len(frames) < n:
-        mode = rng.randint(4)
-        if mode == 0:                                     # a smooth stretch of the synthetic sequence
-            for _ in range(int(rng.randint(1, 8))):
-                hdr, cam, t, seed = sequence_frame(k, w, h)
-                frames.append((hdr, cam, t, frame_image(w, h, seed=seed)))
-                k += 1
-        elif mode == 1:                                   # a jump somewhere else in time / pointing
-            hdr, cam, t = frame_header(w, h, ('iss030', 'iss029')[rng.randint(2)])
-            t = t - timedelta(minutes=float(rng.choice([0, 20, 45, 80, 95])))
-            frames.append((hdr, cam, t, frame_image(w, h, seed=1000 + len(frames))))
-        elif mode == 2 and frames:                        # the same frame again
-            frames.append(frames[-1])
-        else:
-            k = int(rng.randint(0, 300))
-    frames = frames[:n]
+    frames = random_sequence(rng, w, h)
+    n = len(frames)
     magnetic = bool(rng.randint(2))
     ppd = float(rng.choice([4, 8, 10]))
     ref_pipe = FramePipeline(w, h, with_mag=magnetic)
@@ -50,7 +32,10 @@ for s in range(nseq):
                 if not np.array_equal(x, b[key], equal_nan=True):
                     bad += 1
                     print('MISMATCH seq %d n %d magnetic %s %s batch %d frame %d %s plan %s' % (s, n, magnetic, plan, batch, i,
-                                                                                              key, seq.plans[i]))
+                                                                                              key, seq.plans[i]),
+                          'pole', b['contains_pole'], 'date line', b['contains_discontinuity'], 'shapes', x.shape, b[key].shape,
+                          'cells differing', int((~np.isclose(x, b[key], equal_nan=True)).sum()) if x.shape == b[key].shape else -1,
+                          'plans', seq.plans)
                     break
 print('sequences', nseq, 'failures', bad)
 sys.exit(1 if bad else 0)
