@@ -451,9 +451,17 @@ constexpr int kBinW = 8, kBinCells = kBinW * kBinW;
 #ifndef AMT_ROWS_MIN_WAVES_BIN
 #define AMT_ROWS_MIN_WAVES_BIN 4
 #endif
-template <bool FAST, bool DIRS_IN, bool MAG, int BIN>
-__global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
+// SECOND: the second pair of angles a point gets besides (lat, lon): 0 none, 1 (MLat, SM longitude) — outputs mlat / mlt
+// and, with bin_magnetic, binning and box —, 2 the pole plan (bin_pole): (lat, lon) rotated by 90 deg about x, for binning
+// and box only
+#ifndef AMT_ROWS_MIN_WAVES_POLE
+#define AMT_ROWS_MIN_WAVES_POLE 3       // the pole variants need ~150 VGPRs; at 4 waves (128) they spill 40
+#endif
+template <bool FAST, bool DIRS_IN, int SECOND, int BIN>
+__global__ __launch_bounds__(kRowsThreads, SECOND == 2 ? AMT_ROWS_MIN_WAVES_POLE : (BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES)) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
                                                            int n_items, int n_frames) {
+    constexpr bool MAG = SECOND != 0, kPole = SECOND == 2;
+    static_assert(!kPole || (BIN != 0 && !DIRS_IN), "the pole plan exists for fused binning with the camera model only");
     constexpr int kBinWaves = BIN ? kRowsThreads / 64 : 1, kBinSlots = BIN ? kBinCells : 1;
     __shared__ unsigned int sCnt[kBinWaves][kBinSlots];
     __shared__ unsigned int sCh[kBinWaves][3][kBinSlots];
@@ -583,14 +591,14 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
     // runs where that does not apply: first row of a chunk, previous row missed the shell, steps above 1.7 deg at
     // the limb, within 2 deg of the date line.
     constexpr bool kMagBox = MAG && BIN != 0;      // the box may be asked for in (MLat, SM longitude): bla / blo
-    // Pole plan (bin_pole; runs on the MAG variants, whose second pair of angles it takes over): the reference rotates a
+    // Pole plan (bin_pole; SECOND = 2, the machinery of the MLat / MLT variants on another second pair of angles): the reference rotates a
     // frame with a pole in view by +90 deg about x before binning (resample.py:176-201: geodetic -> ECEF at the mapping
     // altitude -> rotation -> geodetic).  Here: the point is rebuilt from the Bowring numerator / denominator of its
     // latitude and its (x, y) — no trigonometry —, turned (x, y, z) -> (x, -z, y), and its rotated latitude /
     // longitude follow as the previous point's plus two small angles, exactly like MLat / SM longitude.  That locates a
     // pixel to ~1e-11 deg; the few pixels within 1e-7 bins of an edge are re-evaluated with rotate_pole_deg, the very
     // function the two-pass plan uses.
-    const bool pole_bin = kMagBox && A.bin_pole != 0;
+    constexpr bool pole_bin = kPole;
     int n_valid = 0;
     auto box_add = [&](double la_v, double lo_v) {
         __hip_atomic_fetch_min(&sBox[wave][0][lane], la_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -834,13 +842,13 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
             }
             if (MAG) {
                 // with bin_magnetic the bounding box is reduced over (MLat, SM longitude) as well
-                const bool magbox = BIN && A.bin_magnetic;
+                const bool magbox = BIN && !kPole && A.bin_magnetic;
                 if (hit) {
                     if (pole_bin) pole_point(bn, bd, p.x, p.y, sv, sxy); else sm_point(p, sv, sxy);
                     sm_angles(prev.s, prev.sxy, prev.ml, prev.sl, sv, sxy, sml, ssl);
                 }
                 const double mt = ssl * (24.0 / 360.0) + 12.0;
-                if (owner && A.mlat) {
+                if (!kPole && owner && A.mlat) {
                     at(A.mlat, off_corner) = sml;
                     at(A.mlt, off_corner) = mt;
                 }
@@ -930,7 +938,7 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
                 if (out_lat_c) at(out_lat_c, off_pixel) = lac;
                 if (out_lon_c) at(out_lon_c, off_pixel) = loc;
                 if (out_elev) at(out_elev, off_pixel) = el;
-                if (MAG && A.mlat_c) {
+                if (MAG && !kPole && A.mlat_c) {
                     at(A.mlat_c, off_pixel) = ml;
                     at(A.mlt_c, off_pixel) = mt;
                 }
@@ -938,8 +946,8 @@ __global__ __launch_bounds__(kRowsThreads, BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_RO
                 if (BIN && valid) {
                     // reference resample.py:301-351 on (lon, lat) or, for resampleMLatMLT, on
                     // (SM longitude = mltToSmLon(mlt), MLat) (mapping.py:1519-1547, transform.py:388-401)
-                    double bxv = (MAG && A.bin_magnetic) ? (mt - 12.0) / (24.0 / 360.0) : loc;
-                    double byv = (MAG && A.bin_magnetic) ? ml : lac;
+                    double bxv = (MAG && !kPole && A.bin_magnetic) ? (mt - 12.0) / (24.0 / 360.0) : loc;
+                    double byv = (MAG && !kPole && A.bin_magnetic) ? ml : lac;
                     if (pole_bin) bxv = slc, byv = ml;
                     if (lon_wrap) bxv = wrap180_shifted(bxv);
                     int bx, by;
@@ -1123,27 +1131,33 @@ void launch_variant(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, lau
         hipExtLaunchKernelGGL((k_georef<kTW, kTH, FAST, DIRS_IN, false>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, A);
 }
 
+// second: 0 / 1 / 2 as the kernel's SECOND
 template <bool FAST, bool DIRS_IN, int BIN>
-void launch_rows_bin(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 grid, bool mag, int rows, int strips_x,
+void launch_rows_bin(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 grid, int second, int rows, int strips_x,
                      int n_items, launch_events ev) {
     const dim3 block(kRowsThreads);
-    if (mag)
-        hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, true, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
+    if (second == 2) {
+        if constexpr (BIN != 0 && !DIRS_IN)
+            hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, 2, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
+                                  rows, strips_x, n_items, n_frames);
+    } else if (second == 1) {
+        hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, 1, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
                               rows, strips_x, n_items, n_frames);
-    else
-        hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, false, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
+    } else {
+        hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, 0, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
                               rows, strips_x, n_items, n_frames);
+    }
 }
 
 template <bool FAST, bool DIRS_IN>
-void launch_rows(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 grid, bool mag, int bin, int rows, int strips_x,
+void launch_rows(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 grid, int second, int bin, int rows, int strips_x,
                  int n_items, launch_events ev) {
     if (bin == 1)
-        launch_rows_bin<FAST, DIRS_IN, 1>(ctx, B, n_frames, grid, mag, rows, strips_x, n_items, ev);
+        launch_rows_bin<FAST, DIRS_IN, 1>(ctx, B, n_frames, grid, second, rows, strips_x, n_items, ev);
     else if (bin == 2)
-        launch_rows_bin<FAST, DIRS_IN, 2>(ctx, B, n_frames, grid, mag, rows, strips_x, n_items, ev);
+        launch_rows_bin<FAST, DIRS_IN, 2>(ctx, B, n_frames, grid, second, rows, strips_x, n_items, ev);
     else
-        launch_rows_bin<FAST, DIRS_IN, 0>(ctx, B, n_frames, grid, mag, rows, strips_x, n_items, ev);
+        launch_rows_bin<FAST, DIRS_IN, 0>(ctx, B, n_frames, grid, second, rows, strips_x, n_items, ev);
 }
 
 // One thread per lattice corner (every `stride`-th pixel corner): bounding box of the corners whose own ray
@@ -1260,6 +1274,7 @@ struct prepared_frame {
     const amt_georef_tail* tail;
     double* fold;       // scratch of the first fold stage (behind the partials)
     bool mag;
+    int second;         // k_georef_rows' SECOND
     int bin;
 };
 
@@ -1386,7 +1401,10 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     F->out = out;
     F->tail = tail;
     F->fold = fold;
-    F->mag = out->mlat != nullptr || out->mlat_c != nullptr || A.bin_magnetic || A.bin_pole;
+    F->mag = out->mlat != nullptr || out->mlat_c != nullptr || A.bin_magnetic;
+    AMT_REQUIRE(ctx, !(A.bin_pole && F->mag), "bin_pole cannot be combined with MLat / MLT outputs");
+    AMT_REQUIRE(ctx, !(A.bin_pole && use_tiles), "bin_pole is implemented by the row-marching kernel only");
+    F->second = A.bin_pole ? 2 : (F->mag ? 1 : 0);
     F->bin = bin;
     return AMT_OK;
 }
@@ -1398,7 +1416,7 @@ int launch_prepared(amt_ctx* ctx, int n, prepared_frame* F) {
     bool together = n > 1;
     for (int i = 1; i < n && together; ++i)
         together = !F[0].sh.use_tiles && F[i].p->width == F[0].p->width && F[i].p->height == F[0].p->height &&
-                   F[i].p->fast_center == F[0].p->fast_center && F[i].mag == F[0].mag && F[i].bin == F[0].bin &&
+                   F[i].p->fast_center == F[0].p->fast_center && F[i].second == F[0].second && F[i].bin == F[0].bin &&
                    F[i].dirs == nullptr && F[0].dirs == nullptr;
     if (n > 1 && !together) {
         for (int i = 0; i < n; ++i)
@@ -1434,11 +1452,11 @@ int launch_prepared(amt_ctx* ctx, int n, prepared_frame* F) {
         for (int i = 0; i < kMaxBatch; ++i) B.f[i] = F[i < n ? i : 0].A;
         B.math = fx::make_math_table();
         if (dirs) {
-            launch_rows<true, true>(ctx, B, n, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
+            launch_rows<true, true>(ctx, B, n, grid, F[0].second, bin, rows_per_chunk, strips_x, (int)n_items, ev);
         } else if (p->fast_center) {
-            launch_rows<true, false>(ctx, B, n, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
+            launch_rows<true, false>(ctx, B, n, grid, F[0].second, bin, rows_per_chunk, strips_x, (int)n_items, ev);
         } else {
-            launch_rows<false, false>(ctx, B, n, grid, mag, bin, rows_per_chunk, strips_x, (int)n_items, ev);
+            launch_rows<false, false>(ctx, B, n, grid, F[0].second, bin, rows_per_chunk, strips_x, (int)n_items, ev);
         }
     }
     AMT_LAUNCH_CHECK(ctx);

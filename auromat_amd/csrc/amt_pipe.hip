@@ -262,7 +262,10 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
     pipe->pole = pole_in_view < 0 ? (pole_visible(p, min_elevation, magnetic) ? 1 : 0) : (pole_in_view ? 1 : 0);
     // geodetic frames with a pole in view take the pole plan (binned in rotated coordinates); a magnetic pole in view
     // of an MLat / MLT frame still means the general path
-    const int mode = magnetic ? 1 : (pipe->pole ? 2 : 0);
+    // (the pole plan is a kernel variant of its own, without MLat / MLT outputs: a geodetic pole frame of a caller that
+    // wants those arrays as well takes the general path)
+    const bool mag_arrays = out->mlat != nullptr || out->mlat_c != nullptr;
+    const int mode = magnetic ? 1 : (pipe->pole && !mag_arrays ? 2 : 0);
     pipe->pole_plan = mode == 2;
     if (!pipe->coarse_pending || pipe->coarse_magnetic != mode) {
         if (pipe->coarse_pending && !pipe->coarse_hinted) AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
