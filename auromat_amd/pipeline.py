@@ -459,7 +459,7 @@ class SequencePipeline(object):
 
     def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, altitude=110, fast=True,
                  min_elevation=10.0, pxPerDeg=10, plan='single-pass', bin_stream=True, shared_image=None,
-                 magnetic=False, batch=3, own_image_buffers=True, keep_coordinates=True):
+                 magnetic=False, batch=3, own_image_buffers=True, keep_coordinates=True, launch_streams=1):
         import torch
         assert plan in ('single-pass', 'two-pass')
         try:
@@ -491,6 +491,11 @@ class SequencePipeline(object):
         for q in self.pipes:
             q.defer_join = True             # joined once per process() call
         self.s_main = torch.cuda.Stream(device=self.ctx.device)
+        # launch_streams=2 (single-pass plan): the batches alternate between two streams.  A buffer set is used by every
+        # second batch, i.e. always on the same stream, so every ordering between its users stays stream order; what
+        # falls away is the order between CONSECUTIVE big kernels, which do not depend on each other: the next one
+        # starts while the last waves of the previous one drain.
+        self.s_alt = torch.cuda.Stream(device=self.ctx.device) if (launch_streams == 2 and self.single_pass) else None
         # two-pass plan: the binning kernel is memory bound and the ray casting FP64 bound, so frame k's binning
         # runs beside frame k+1's ray casting on a second stream
         self.s_bin = torch.cuda.Stream(device=self.ctx.device) if (bin_stream and not self.single_pass) else self.s_main
@@ -508,6 +513,12 @@ class SequencePipeline(object):
         self.use_hints = True               # sequence coherence instead of the coarse pre-pass where possible
         self._hint = None                   # (exact bbox reduction, amt_frame_params) of the latest finished frame
         self.hinted = 0                     # frames of the last process() call that needed no pre-pass
+
+    def _stream_of(self, k):
+        """The stream the batch of frame k is launched on (and its buffers are used on)."""
+        if self.s_alt is None:
+            return self.s_main
+        return self.s_alt if (k // self.batch) % 2 else self.s_main
 
     def _prepare(self, k, frame):
         hdr, cam, t, img = frame[:4]
@@ -528,11 +539,12 @@ class SequencePipeline(object):
         nb = len(self.pipes)
         qs = [self.pipes[(k0 + i) % nb] for i in range(len(prepared))]
         two_streams = self.s_bin is not self.s_main
-        with torch.cuda.stream(self.s_main):
+        s_main = self._stream_of(k0)
+        with torch.cuda.stream(s_main):
             for i, (q, (p, cam, t, img, alt)) in enumerate(zip(qs, prepared)):
                 slot = (k0 + i) % nb
                 if two_streams and self._bin_done[slot] is not None:
-                    self.s_main.wait_event(self._bin_done[slot])     # the buffer's previous frame is still being binned
+                    s_main.wait_event(self._bin_done[slot])     # the buffer's previous frame is still being binned
                 if img is None:
                     continue
                 if q.is_resident_image(img):
@@ -548,28 +560,29 @@ class SequencePipeline(object):
                     q.set_image(img)
                     uploaded = torch.cuda.Event()
                     uploaded.record(self.s_copy)
-                self.s_main.wait_event(uploaded)
+                s_main.wait_event(uploaded)
             if self.single_pass:
                 FramePipeline.georef_many(qs, [pr[0] for pr in prepared], [pr[4] for pr in prepared],
                                           self.min_elevation, self.pxPerDeg, self.magnetic)
                 done = torch.cuda.Event()
-                done.record(self.s_main)
+                done.record(s_main)
                 for i in range(len(prepared)):
                     self._img_busy[(k0 + i) % nb].append(done)
             else:
                 for i, (q, (p, cam, t, img, alt)) in enumerate(zip(qs, prepared)):
                     q.georef(None, alt, cam, t, self.fast, self.min_elevation, params=p)
                     if two_streams:
-                        self._geo_done[(k0 + i) % nb].record(self.s_main)
+                        self._geo_done[(k0 + i) % nb].record(s_main)
 
     def _finish(self, k, keep_on_device):
         import torch
         slot = k % len(self.pipes)
         q = self.pipes[slot]
         two_streams = self.s_bin is not self.s_main
-        with torch.cuda.stream(self.s_bin):
+        s_bin = self.s_bin if two_streams else self._stream_of(k)
+        with torch.cuda.stream(s_bin):
             if two_streams:
-                self.s_bin.wait_event(self._geo_done[slot])
+                s_bin.wait_event(self._geo_done[slot])
             try:
                 res = q.resample(self.pxPerDeg, magnetic=self.magnetic, keep_on_device=keep_on_device)
             except EmptyFrame:
@@ -582,7 +595,7 @@ class SequencePipeline(object):
             if q.last_plan == 'two-pass':
                 # the separate binning kernel reads the buffer's image (and coordinate arrays) on this stream
                 ev = torch.cuda.Event()
-                ev.record(self.s_bin)
+                ev.record(s_bin)
                 self._img_busy[slot].append(ev)
                 if two_streams:
                     self._bin_done[slot] = ev
@@ -644,6 +657,8 @@ class SequencePipeline(object):
                 q.join()
         cur = torch.cuda.current_stream(self.ctx.device)
         cur.wait_stream(self.s_main)
+        if self.s_alt is not None:
+            cur.wait_stream(self.s_alt)
         if self.s_bin is not self.s_main:
             cur.wait_stream(self.s_bin)
         if keep_on_device:

@@ -37,7 +37,8 @@ ALTITUDE, MIN_ELEV, PPD = 110, 10.0, 10
 SHELLS = (100, 110, 120)  # configs[3]
 TIMING_EVERY = 1        # events ride on the dispatch packets (hipExtLaunchKernelGGL): every launch is timed
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
-MAX_RESIDENT_IMAGES = 96   # distinct images kept in HBM (72 MB each); longer runs cycle through them
+LAUNCH_STREAMS = 1      # --launch-streams
+MAX_RESIDENT_IMAGES = 128  # distinct images kept in HBM (72 MB each); longer runs cycle through them
 
 
 def algorithmic_bytes(width, height, nchan=3, pix_bytes=2):
@@ -55,7 +56,8 @@ def algorithmic_bytes(width, height, nchan=3, pix_bytes=2):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=None, help='frames per rank in the timed region (default 50; 32 with --gpus > 1)')
+    ap.add_argument('--steps', type=int, default=None, help='frames per rank in the timed region (default 96 for every N: weak scaling; BASELINE.json configs[4], the '
+                         '256-frame job on 8 GPUs, is --gpus 8 --steps 32)')
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--cpu-rows', type=int, default=2832, help='rows of the frame the CPU baseline processes (0 = skip)')
     ap.add_argument('--exact', action='store_true', help='exact centre rays instead of fast centres')
@@ -76,6 +78,8 @@ def parse_args(argv=None):
                     help='round-1 conditions: one resident image shared by all frames (A/B only)')
     ap.add_argument('--streams', type=int, default=2, choices=(1, 2),
                     help='2: bin frame k beside the ray casting of frame k+1 on a second HIP stream (two-pass plan)')
+    ap.add_argument('--launch-streams', type=int, default=1, choices=(1, 2),
+                    help='fused plan: 2 = consecutive launches of the big kernel alternate between two HIP streams')
     ap.add_argument('--no-variants', action='store_true',
                     help='skip the short extra runs (exact centres, configs[3]) whose figures the JSON line carries as '
                          '"variants" (they run on rank 0 at N = 1 only, after the timed region)')
@@ -88,7 +92,7 @@ def parse_args(argv=None):
                     help='launcher / reporting path only: gloo on the CPU, no GPU, a step is a sleep (tests)')
     args = ap.parse_args(argv)
     if args.steps is None:
-        args.steps = 32 if args.gpus > 1 else 50
+        args.steps = 96
     return args
 
 
@@ -243,7 +247,7 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
     seq = SequencePipeline(WIDTH, HEIGHT, altitude=ALTITUDE, fast=fast, min_elevation=MIN_ELEV, pxPerDeg=PPD,
                            plan='single-pass' if plan == 'fused' else 'two-pass', bin_stream=streams == 2,
                            shared_image=shared_image, magnetic=magnetic, batch=batch, own_image_buffers=own_buffers,
-                           keep_coordinates=keep_coordinates)
+                           keep_coordinates=keep_coordinates, launch_streams=LAUNCH_STREAMS)
     seq.use_hints = use_hints
     ctx = seq.ctx
     spun = 0
@@ -278,6 +282,8 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    global LAUNCH_STREAMS
+    LAUNCH_STREAMS = args.launch_streams
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_children(argv))
     world = int(os.environ.get('WORLD_SIZE', '1'))
