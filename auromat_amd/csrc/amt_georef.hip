@@ -453,15 +453,17 @@ constexpr int kBinW = 8, kBinCells = kBinW * kBinW;
 #endif
 // SECOND: the second pair of angles a point gets besides (lat, lon): 0 none, 1 (MLat, SM longitude) — outputs mlat / mlt
 // and, with bin_magnetic, binning and box —, 2 the pole plan (bin_pole): (lat, lon) rotated by 90 deg about x, for binning
-// and box only
+// and box only, 3 the pole plan of an MLat / MLT frame (bin_magnetic + bin_pole): (MLat, SM longitude) as in 1 and, for
+// binning and box, a third pair: those two rotated by 90 deg about x as if they were geodetic (what resampleMLatMLT does
+// with a magnetic pole in view, mapping.py:1519-1547 -> resample.py:176-201)
 #ifndef AMT_ROWS_MIN_WAVES_POLE
 #define AMT_ROWS_MIN_WAVES_POLE 3       // the pole variants need ~150 VGPRs; at 4 waves (128) they spill 40
 #endif
 template <bool FAST, bool DIRS_IN, int SECOND, int BIN>
-__global__ __launch_bounds__(kRowsThreads, SECOND == 2 ? AMT_ROWS_MIN_WAVES_POLE : (BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES)) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
+__global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE : (BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES)) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
                                                            int n_items, int n_frames) {
-    constexpr bool MAG = SECOND != 0, kPole = SECOND == 2;
-    static_assert(!kPole || (BIN != 0 && !DIRS_IN), "the pole plan exists for fused binning with the camera model only");
+    constexpr bool MAG = SECOND != 0, kPole = SECOND == 2, kMagPole = SECOND == 3;
+    static_assert(!(kPole || kMagPole) || (BIN != 0 && !DIRS_IN), "the pole plans exist for fused binning with the camera model only");
     constexpr int kBinWaves = BIN ? kRowsThreads / 64 : 1, kBinSlots = BIN ? kBinCells : 1;
     __shared__ unsigned int sCnt[kBinWaves][kBinSlots];
     __shared__ unsigned int sCh[kBinWaves][3][kBinSlots];
@@ -582,9 +584,12 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 2 ? AMT_ROWS_MIN_WAVES_POLE
         double bla, blo;    // what the bounding box is reduced over when that is not (la, lo): MLat / SM longitude
         vec3 s;             // MAG: the corner in SM coordinates, |(s.x, s.y)|, MLat and SM longitude (degrees)
         double sxy, ml, sl;
+        vec3 r;             // kMagPole: the rotated point of (MLat, SM longitude) as pole_point gives it, its angles
+        double rxy, rla, rlo;
         int flag;
     };
-    row_state S0 = {{NAN, NAN, NAN}, {NAN, NAN, NAN}, NAN, NAN, NAN, NAN, NAN, NAN, {NAN, NAN, NAN}, NAN, NAN, NAN, 0}, S1 = S0;
+    row_state S0 = {{NAN, NAN, NAN}, {NAN, NAN, NAN}, NAN, NAN, NAN, NAN, NAN, NAN, {NAN, NAN, NAN}, NAN, NAN, NAN,
+                    {NAN, NAN, NAN}, NAN, NAN, NAN, 0}, S1 = S0;
     // Neighbouring pixels differ by a fraction of a degree, so latitude and longitude of a corner are taken as
     // the previous row's plus a small angle (fx::small_angles: one reciprocal and two 4-term series instead of two
     // range-reduced 9-term arctangents), and a centre's as its corner's plus a small angle.  The full arctangent
@@ -804,6 +809,8 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 2 ? AMT_ROWS_MIN_WAVES_POLE
         double la = NAN, lo = NAN, bn = NAN, bd = NAN, bla = NAN, blo = NAN;
         vec3 sv = {NAN, NAN, NAN};       // MAG: the corner in SM coordinates
         double sxy = NAN, sml = NAN, ssl = NAN;
+        vec3 rv = {NAN, NAN, NAN};       // kMagPole: the rotated point and its angles
+        double rxy = NAN, rla = NAN, rlo = NAN;
         bool hit = false;
         if (col_ok) {
             const shell_ray& ry = ray;
@@ -846,6 +853,11 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 2 ? AMT_ROWS_MIN_WAVES_POLE
                 if (hit) {
                     if (pole_bin) pole_point(bn, bd, p.x, p.y, sv, sxy); else sm_point(p, sv, sxy);
                     sm_angles(prev.s, prev.sxy, prev.ml, prev.sl, sv, sxy, sml, ssl);
+                    if (kMagPole) {
+                        // MLat = atan(s.z / |s.xy|), SM longitude = atan2(s.y, s.x): the same construction on the SM vector
+                        pole_point(sv.z, sxy, sv.x, sv.y, rv, rxy);
+                        sm_angles(prev.r, prev.rxy, prev.rla, prev.rlo, rv, rxy, rla, rlo);
+                    }
                 }
                 const double mt = ssl * (24.0 / 360.0) + 12.0;
                 if (!kPole && owner && A.mlat) {
@@ -855,6 +867,10 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 2 ? AMT_ROWS_MIN_WAVES_POLE
                 if (magbox) {
                     bla = sml;
                     blo = (mt - 12.0) / (24.0 / 360.0);       // mltToSmLon, reference transform.py:388-401
+                }
+                if (kMagPole) {
+                    bla = rla;
+                    blo = rlo;
                 }
                 if (pole_bin) {
                     bla = sml;
@@ -909,7 +925,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 2 ? AMT_ROWS_MIN_WAVES_POLE
             int bin_x = 0, bin_y = 0;            // 1-based bin indices of this pixel, 0 = not binned
             long long el_fix = 0;
             if (px_ok) {
-                double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN, slc = NAN;
+                double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN, slc = NAN, rlac = NAN, rloc = NAN;
                 if (pc.x == pc.x) {
                     double inv_r, cn, cd;
                     fx::bowring_nd(bw, pc.x, pc.y, pc.z, cn, cd, inv_r);
@@ -933,6 +949,12 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 2 ? AMT_ROWS_MIN_WAVES_POLE
                         if (pole_bin) pole_point(cn, cd, pc.x, pc.y, sc, sxyc); else sm_point(pc, sc, sxyc);
                         sm_angles(sv, sxy, sml, ssl, sc, sxyc, ml, slc);
                         mt = slc * (24.0 / 360.0) + 12.0;
+                        if (kMagPole) {
+                            vec3 rc;
+                            double rxyc;
+                            pole_point(sc.z, sxyc, sc.x, sc.y, rc, rxyc);
+                            sm_angles(rv, rxy, rla, rlo, rc, rxyc, rlac, rloc);
+                        }
                     }
                 }
                 if (out_lat_c) at(out_lat_c, off_pixel) = lac;
@@ -949,6 +971,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 2 ? AMT_ROWS_MIN_WAVES_POLE
                     double bxv = (MAG && !kPole && A.bin_magnetic) ? (mt - 12.0) / (24.0 / 360.0) : loc;
                     double byv = (MAG && !kPole && A.bin_magnetic) ? ml : lac;
                     if (pole_bin) bxv = slc, byv = ml;
+                    if (kMagPole) bxv = rloc, byv = rlac;
                     if (lon_wrap) bxv = wrap180_shifted(bxv);
                     int bx, by;
                     bool slow;
@@ -956,10 +979,13 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 2 ? AMT_ROWS_MIN_WAVES_POLE
                     unsigned int edge_flags = 0;
                     if (__ballot(slow)) {          // wave-uniform and rare
                         if (slow) {
-                            if (pole_bin) {
+                            if (pole_bin || kMagPole) {
                                 // next to an edge: the rotated coordinates as the two-pass plan computes them
                                 const pole_consts pk = karg_load<pole_consts>(karg_fresh(koff), offsetof(georef_args, pole));
-                                rotate_pole_deg(pk.w, pk.rot, pk.e2, lac, loc, pk.alt, byv, bxv);
+                                if (kMagPole)
+                                    rotate_pole_deg(pk.w, pk.rot, pk.e2, ml, (mt - 12.0) / (24.0 / 360.0), pk.alt, byv, bxv);
+                                else
+                                    rotate_pole_deg(pk.w, pk.rot, pk.e2, lac, loc, pk.alt, byv, bxv);
                             }
                             bin_slow(bxv, byv, bx, by, edge_flags);
                         }
@@ -1018,6 +1044,12 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 2 ? AMT_ROWS_MIN_WAVES_POLE
             cur.sxy = sxy;
             cur.ml = sml;
             cur.sl = ssl;
+        }
+        if (kMagPole) {
+            cur.r = rv;
+            cur.rxy = rxy;
+            cur.rla = rla;
+            cur.rlo = rlo;
         }
         cur.flag = flag_cur;
     };
@@ -1136,7 +1168,11 @@ template <bool FAST, bool DIRS_IN, int BIN>
 void launch_rows_bin(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 grid, int second, int rows, int strips_x,
                      int n_items, launch_events ev) {
     const dim3 block(kRowsThreads);
-    if (second == 2) {
+    if (second == 3) {
+        if constexpr (BIN != 0 && !DIRS_IN)
+            hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, 3, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
+                                  rows, strips_x, n_items, n_frames);
+    } else if (second == 2) {
         if constexpr (BIN != 0 && !DIRS_IN)
             hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, 2, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
                                   rows, strips_x, n_items, n_frames);
@@ -1162,7 +1198,7 @@ void launch_rows(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 grid, i
 
 // One thread per lattice corner (every `stride`-th pixel corner): bounding box of the corners whose own ray
 // has an elevation >= min_elev, in (lat, lon), (MLat, SM longitude) [magnetic = 1] or (lat, lon) rotated by 90 deg
-// about x [magnetic = 2, the pole plan].  Partials per workgroup.
+// about x [magnetic = 2, the pole plan; 3: (MLat, SM longitude) rotated likewise].  Partials per workgroup.
 __global__ __launch_bounds__(kThreads) void k_coarse_bbox(georef_args A, int stride, int magnetic, double min_elev,
                                                            double* __restrict__ partials) {
     __shared__ double sRed[8][kThreads / 64];
@@ -1182,10 +1218,11 @@ __global__ __launch_bounds__(kThreads) void k_coarse_bbox(georef_args A, int str
             c = fmin(1.0, fmax(-1.0, c));
             if (fm::asin_deg(c) >= min_elev) {
                 double la, lo;
-                if (magnetic == 1) {
+                if (magnetic == 1 || magnetic == 3) {
                     double mt;
                     sm_to_mlat_mlt_fast(mul(A.m_sm, p), la, mt);
                     lo = (mt - 12.0) / (24.0 / 360.0);
+                    if (magnetic == 3) rotate_pole_deg(A.pole.w, A.pole.rot, A.pole.e2, la, lo, A.pole.alt, la, lo);
                 } else {
                     const vec3 g = mul(A.m_geo, p);
                     ecef_to_geodetic_deg_fast(A.bw, g.x, g.y, g.z, la, lo);
@@ -1355,7 +1392,7 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
         A.bin_lon_wrap = out->bin_lon_wrap ? 1 : 0;
         A.bin_magnetic = out->bin_magnetic ? 1 : 0;
         if (out->bin_pole) {
-            AMT_REQUIRE(ctx, !A.bin_magnetic && !A.bin_lon_wrap, "bin_pole excludes bin_magnetic and bin_lon_wrap");
+            AMT_REQUIRE(ctx, !A.bin_lon_wrap, "bin_pole excludes bin_lon_wrap");
             AMT_REQUIRE(ctx, dirs == nullptr, "bin_pole needs the camera model");
             AMT_REQUIRE(ctx, std::fabs((p->a - p->a0) - out->altitude) < 1e-6 && std::fabs((p->b - p->b0) - out->altitude) < 1e-6,
                         "bin_pole: amt_georef_out.altitude does not match the shell of the frame");
@@ -1402,9 +1439,10 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     F->tail = tail;
     F->fold = fold;
     F->mag = out->mlat != nullptr || out->mlat_c != nullptr || A.bin_magnetic;
-    AMT_REQUIRE(ctx, !(A.bin_pole && F->mag), "bin_pole cannot be combined with MLat / MLT outputs");
+    AMT_REQUIRE(ctx, !(A.bin_pole && !A.bin_magnetic && F->mag),
+                "bin_pole on a geodetic grid cannot be combined with MLat / MLT outputs");
     AMT_REQUIRE(ctx, !(A.bin_pole && use_tiles), "bin_pole is implemented by the row-marching kernel only");
-    F->second = A.bin_pole ? 2 : (F->mag ? 1 : 0);
+    F->second = A.bin_pole ? (A.bin_magnetic ? 3 : 2) : (F->mag ? 1 : 0);
     F->bin = bin;
     return AMT_OK;
 }
@@ -1537,7 +1575,7 @@ int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stri
         return AMT_ENOMEM;
     }
     hipLaunchKernelGGL(k_coarse_bbox, dim3(nblocks), dim3(kThreads), 0, ctx->stream, A, stride,
-                       magnetic == 2 ? 2 : (magnetic ? 1 : 0), min_elevation, partials);
+                       (magnetic == 2 || magnetic == 3) ? magnetic : (magnetic ? 1 : 0), min_elevation, partials);
     AMT_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, ctx->stream, partials, nblocks, bbox,
                        (const unsigned int*)nullptr);

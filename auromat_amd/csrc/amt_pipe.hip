@@ -30,7 +30,7 @@ struct amt_pipe {
     bool coarse_pending, launched, fused, ready, tail_pending;
     bool coarse_hinted;            // the pending coarse box came from the caller (amt_pipe_coarse_hint), no kernel ran
     int coarse_magnetic;           // coordinates of the pending coarse box (0 geodetic, 1 MLat / SM longitude,
-                                   // 2 geodetic rotated by 90 deg about x: the pole plan)
+                                   // 2 / 3 the same rotated by 90 deg about x: the pole plans)
     int lon_wrap;                  // the frame straddles the 180 deg discontinuity: longitudes are binned shifted by 180
     amt_grid super, exact;
     int32_t off_x, off_y;          // window of the exact grid inside the superset
@@ -241,8 +241,8 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
     if (pipe == nullptr) return AMT_EINVAL;
     amt_ctx* ctx = pipe->ctx;
     AMT_REQUIRE(ctx, p != nullptr, "NULL argument");
-    // a geodetic frame with a pole in view is binned in rotated coordinates (the pole plan): its box is needed in those
-    const int mode = magnetic ? 1 : (pole_visible(p, min_elevation, 0) ? 2 : 0);
+    // a frame with a pole of its grid in view is binned in rotated coordinates (the pole plans): its box is needed in those
+    const int mode = (magnetic ? 1 : 0) + (pole_visible(p, min_elevation, magnetic ? 1 : 0) ? 2 : 0);
     return pipe_coarse(pipe, p, min_elevation, mode);
 }
 
@@ -260,13 +260,12 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
     AMT_REQUIRE(ctx, img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
     magnetic = magnetic ? 1 : 0;
     pipe->pole = pole_in_view < 0 ? (pole_visible(p, min_elevation, magnetic) ? 1 : 0) : (pole_in_view ? 1 : 0);
-    // geodetic frames with a pole in view take the pole plan (binned in rotated coordinates); a magnetic pole in view
-    // of an MLat / MLT frame still means the general path
-    // (the pole plan is a kernel variant of its own, without MLat / MLT outputs: a geodetic pole frame of a caller that
-    // wants those arrays as well takes the general path)
+    // frames with a pole of their grid in view take a pole plan (binned in rotated coordinates).  (The geodetic one is a
+    // kernel variant without MLat / MLT outputs: a geodetic pole frame of a caller that wants those arrays as well takes
+    // the general path.)
     const bool mag_arrays = out->mlat != nullptr || out->mlat_c != nullptr;
-    const int mode = magnetic ? 1 : (pipe->pole && !mag_arrays ? 2 : 0);
-    pipe->pole_plan = mode == 2;
+    const int mode = magnetic ? (pipe->pole ? 3 : 1) : (pipe->pole && !mag_arrays ? 2 : 0);
+    pipe->pole_plan = mode >= 2;
     if (!pipe->coarse_pending || pipe->coarse_magnetic != mode) {
         if (pipe->coarse_pending && !pipe->coarse_hinted) AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
         if (int rc = pipe_coarse(pipe, p, min_elevation, mode)) return rc;
@@ -389,7 +388,7 @@ int amt_pipe_coarse_hint(amt_pipe* pipe, const double* bbox, int magnetic) {
     pipe->host_small[7] = 0;                       // no hit statistics: item order from the camera model
     pipe->coarse_pending = true;
     // the exact box of a pole-plan frame (bbox[7] = 1 in amt_pipe_result of a fused frame) is in rotated coordinates
-    pipe->coarse_magnetic = magnetic ? 1 : (bbox[7] != 0 ? 2 : 0);
+    pipe->coarse_magnetic = (magnetic ? 1 : 0) + (bbox[7] != 0 ? 2 : 0);
     pipe->coarse_hinted = true;
     return AMT_OK;
 }

@@ -332,7 +332,7 @@ class FramePipeline(object):
         g = res.grid
         b = res.bbox
         wrapped = bool(res.lon_wrapped)
-        pole = bool(b[7]) and not self._fused['magnetic']       # the pole plan: grid in rotated coordinates
+        pole = bool(b[7])                                       # a pole plan: grid in rotated coordinates
         if wrapped:
             # straddles the 180 deg discontinuity: the grid is laid out for longitudes shifted by 180 deg
             box = (b[0], b[1], wrap_at_180(b[4] + 180), wrap_at_180(b[5] + 180))

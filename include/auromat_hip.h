@@ -162,9 +162,10 @@ typedef struct amt_georef_out {
     void* bin_events;
     uint32_t* bin_event_count;
     int64_t bin_event_capacity;
-    /* Pole plan of the fused binning (a pole of the mapping is in view; not with bin_magnetic / bin_lon_wrap): pixels are
-     * binned at (lat, lon) rotated by +90 deg about x at `altitude` — amt_rotate_pole_deg of (lat_c, lon_c), reference
-     * resample.py:176-201 — and bbox[0..5] are reduced over the rotated corners (to ~1e-11 deg: good for laying out the
+    /* Pole plan of the fused binning (a pole of the grid's coordinates is in view; not with bin_lon_wrap): pixels are
+     * binned at (lat, lon) — with bin_magnetic at (MLat, SM longitude) taken as if they were geodetic, as
+     * resampleMLatMLT does — rotated by +90 deg about x at `altitude`: amt_rotate_pole_deg of the centre coordinates,
+     * reference resample.py:176-201 — and bbox[0..5] are reduced over the rotated corners (to ~1e-11 deg: good for laying out the
      * grid unless an extreme sits within that of a grid node, see amt_pipe_wait).  `altitude` [km] is the mapping
      * altitude the shell (a, b) = (a0, b0) + altitude was built from, as rotatePole takes it. */
     int32_t bin_pole;
@@ -282,7 +283,8 @@ int amt_georef_frame_dirs(amt_ctx* ctx, const amt_frame_params* p, const double*
 /* Cheap estimate of the same bbox[0..6] from every `stride`-th pixel corner in both directions (a
  * 1/stride^2 sample of the rays): a corner counts when the elevation of its own ray is >= min_elevation.
  * With magnetic == 1 the box is in (MLat, SM longitude) instead of (lat, lon), with magnetic == 2 in (lat, lon)
- * rotated by +90 deg about x at the altitude a - a0 (the pole plan, amt_georef_out.bin_pole).  Used to lay out a superset
+ * rotated by +90 deg about x at the altitude a - a0 (the pole plan, amt_georef_out.bin_pole), with magnetic == 3 in
+ * (MLat, SM longitude) rotated likewise.  Used to lay out a superset
  * grid for the fused binning before the full kernel runs; the caller adds a safety margin and checks the
  * exact box afterwards.  bbox[7] = sx * 2^20 + sy, where sx (sy) is the number of sampled rays that hit the
  * shell right of (below) the frame centre minus those left of (above) it: the input of amt_georef_out.item_order. */
@@ -439,15 +441,16 @@ int amt_grid_layout(double lat_px_per_deg, double lon_px_per_deg, double lat_min
 /* Single-pass driver: georeference + mask by elevation + bounding box + grid + binned mean of one frame with
  * the binning fused into the georeferencing kernel (see amt_georef_out.bin_*), for geodetic grids (frames that straddle
  * the 180 deg discontinuity are binned with shifted longitudes, frames with a pole in view in coordinates rotated by
- * 90 deg about x: reference resample.py:176-218) and for MLat/MLT grids without a magnetic pole in view.  Separate calls
- * per stage so that frames can be software pipelined by one host thread:
+ * 90 deg about x: reference resample.py:176-218) and for MLat/MLT grids (resampleMLatMLT) likewise.  Separate calls per
+ * stage so that frames can be software pipelined by one host thread:
  *   amt_pipe_coarse   enqueue the coarse bounding-box pre-pass (own high-priority stream), any time earlier
  *   amt_pipe_launch   wait for it, lay out the superset grid, zero the accumulators, launch the fused kernel
  *                     on the context's stream, start the copy of the exact bounding box
  *   amt_pipe_wait     wait for the exact box (the only host synchronisation), lay out the exact grid
  *   amt_pipe_finalize crop + finalise into arrays the caller sized from the grid amt_pipe_wait returned
- * status in amt_pipe_result: 0 = ready to finalise; 1 = this frame needs the general path (magnetic pole in view,
- * exact box outside the superset, an extreme of a pole frame's box within 1e-6 cells of a grid node) — the coordinate
+ * status in amt_pipe_result: 0 = ready to finalise; 1 = this frame needs the general path (exact box outside the
+ * superset, an extreme of a pole frame's box within 1e-6 cells of a grid node, a geodetic pole frame whose caller also
+ * wants MLat / MLT arrays) — the coordinate
  * arrays and bbox are valid, nothing else;
  * 2 = no pixel above the elevation threshold (mapping.py:858-859 -> ValueError). */
 typedef struct amt_pipe amt_pipe;
@@ -458,8 +461,8 @@ typedef struct amt_pipe_result {
                              * shifted by 180 deg (wrap_at_180(lon + 180)) and the caller shifts the output
                              * coordinates back (reference resample.py:203-218,274-277) */
     int32_t edge_pixels;    /* pixels on a bin edge (right-most-edge rule) that were resolved separately */
-    double bbox[8];         /* exact reduction of amt_georef_frame; [7] = 1 when a pole is in view: for a geodetic frame
-                             * [0..5] are then in the rotated coordinates the grid is laid out in (amt_georef_out.
+    double bbox[8];         /* exact reduction of amt_georef_frame; [7] = 1 when a pole (of the grid's coordinates) is in
+                             * view: [0..5] are then in the rotated coordinates the grid is laid out in (amt_georef_out.
                              * bin_pole), and the caller rotates the output coordinates back (resample.py:262-273) */
     amt_grid grid;          /* exact output grid (valid for status 0) */
 } amt_pipe_result;

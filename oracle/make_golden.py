@@ -24,7 +24,8 @@ Fixtures
                         centres): every 4th sample + digests of all arrays, masks, and the full
                         maskedByElevation(10) -> resample(pxPerDeg=10, 'mean') output
   pole_frame_*.npz      a 200x160 camera frame with the north (south) pole in view (fast + exact centres):
-                        maskedByElevation(10) -> _resample(containsPole=True, pxPerDeg=8) output, inputs included
+                        maskedByElevation(10) -> _resample(containsPole=True, pxPerDeg=8) output, inputs included;
+                        pole_frame_magnetic_*: across the geomagnetic pole, the _resample call of resampleMLatMLT
 """
 import json
 import os
@@ -810,6 +811,61 @@ def pole_frames():
             out.update(time_arrays(t))
             out.update(cam=cam, altitude=np.float64(110), min_elev=np.float64(10), ppd=np.array((8, 8), dtype=np.float64))
             save('pole_frame_%s_%s.npz' % ('south' if south else 'north', 'fast' if fast else 'exact'), **out)
+
+
+def magnetic_pole_frame_header():
+    """Like pole_frame_header, across the north geomagnetic (SM) pole: resampleMLatMLT of this frame takes the pole branch."""
+    w, h = 200, 160
+    t = datetime(2012, 1, 25, 9, 26, 55, 60000)
+    et = T.date2es(t)
+    m_geo = np.asarray(T.mat_j2000_to_geo(et))
+    axis = np.asarray(T.mat_geo_to_sm(et)).T.dot([0.0, 0.0, 1.0])           # SM z axis in GEO
+    e1 = np.cross(axis, [0.0, 0.0, 1.0])
+    e1 /= np.linalg.norm(e1)
+    cam_geo = (6360.0 + 400.0) * (np.cos(np.deg2rad(7.0)) * axis + np.sin(np.deg2rad(7.0)) * e1)
+    target = (6360.0 + 110.0) * (np.cos(np.deg2rad(2.5)) * axis - np.sin(np.deg2rad(2.5)) * e1)
+    bore = m_geo.T.dot(target - cam_geo)
+    bore /= np.linalg.norm(bore)
+    cam = m_geo.T.dot(cam_geo)
+    hdr = {'CTYPE1': 'RA---TAN', 'CTYPE2': 'DEC--TAN', 'LONPOLE': 180.0, 'LATPOLE': 0.0,
+           'CRVAL1': float(np.rad2deg(np.arctan2(bore[1], bore[0])) % 360), 'CRVAL2': float(np.rad2deg(np.arcsin(bore[2]))),
+           'CRPIX1': w / 2 + 0.5, 'CRPIX2': h / 2 + 0.5, 'CD1_1': -0.33, 'CD1_2': 0.05, 'CD2_1': 0.05, 'CD2_2': 0.33,
+           'IMAGEW': w, 'IMAGEH': h}
+    img = np.random.RandomState(9).randint(0, 65535, (h, w, 3)).astype(np.uint16)
+    return hdr, cam, t, img
+
+
+def magnetic_pole_frames():
+    """pole_frame_magnetic_{fast,exact}.npz: camera mapping -> maskedByElevation(10) -> the _resample call of
+    resampleMLatMLT (mapping.py:1519-1547) with containsPole=True"""
+    hdr, cam, t, img = magnetic_pole_frame_header()
+    for fast in (True, False):
+        m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'mpole', fastCenterCalculation=fast)
+        mm = m.maskedByElevation(10)
+        mm.checkGuarantees()
+        merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+        mlat, mlt = mm.mLatMlt
+        mlat_c, mlt_c = mm.mLatMltCenter
+        assert np.nanmax(mlat.filled(np.nan)) > 89.8, 'the frame does not contain the magnetic pole'
+        mask = ma.getmaskarray(mm.lats)
+        sm_lats = ma.masked_array(mlat.data, mask)
+        sm_lons = ma.masked_array(T.mltToSmLon(mlt.data), mask)
+        cmask = ma.getmaskarray(mm.latsCenter)
+        sm_lats_c = np.where(cmask, np.nan, mlat_c.data)
+        sm_lons_c = np.where(cmask, np.nan, T.mltToSmLon(mlt_c.data))
+        case = _run_resample(sm_lats, sm_lons, sm_lats_c, sm_lons_c, 110, merged, (8, 8), pole=True)
+        rimg, relev = np.dsplit(case['out_data'], [-1])
+        with np.errstate(invalid='ignore'):
+            rimg = np.round(rimg)
+        rimg = np.require(ma.masked_invalid(rimg, copy=False), np.uint16)
+        del case['outline']
+        out = dict(case)
+        out.update(out_img=rimg.data, out_img_mask=ma.getmaskarray(rimg))
+        out.update(lat_c=sm_lats_c, lon_c=sm_lons_c, img=img)
+        out.update(hdr_arrays(hdr))
+        out.update(time_arrays(t))
+        out.update(cam=cam, altitude=np.float64(110), min_elev=np.float64(10), ppd=np.array((8, 8), dtype=np.float64))
+        save('pole_frame_magnetic_%s.npz' % ('fast' if fast else 'exact'), **out)
 
 
 if __name__ == '__main__':
