@@ -6,7 +6,8 @@ from auromat_amd.pipeline import SequencePipeline, FramePipeline
 from auromat_amd.synthetic import sequence_frame, frame_image
 W, H = 4240, 2832
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-seq = SequencePipeline(W, H, pxPerDeg=10, shared_image=frame_image(W, H), batch=batch)
+keep = not (len(sys.argv) > 2 and sys.argv[2] == 'grids')        # 'grids': no per-pixel coordinate arrays
+seq = SequencePipeline(W, H, pxPerDeg=10, shared_image=frame_image(W, H), batch=batch, keep_coordinates=keep)
 frames = [sequence_frame(k, W, H)[:3] + (None,) for k in range(70)]
 acc = {}
 def timed(obj, name, label=None):
@@ -23,6 +24,6 @@ for v in acc.values(): del v[:]
 torch.cuda.synchronize(); t0 = time.perf_counter()
 seq.process(frames[10:])
 torch.cuda.synchronize(); el = time.perf_counter() - t0
-print('batch', batch, 'us/frame', round(el / 60 * 1e6, 1))
+print('batch', batch, 'with arrays' if keep else 'grids only', 'us/frame', round(el / 60 * 1e6, 1))
 for k, v in acc.items():
     print('  %-10s n=%3d mean %.1f us  total/frame %.1f us' % (k, len(v), sum(v) / len(v) * 1e6, sum(v) / 60 * 1e6))
