@@ -266,10 +266,15 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
     fence()
     t0 = time.perf_counter()
     results = seq.process(frames[warmup:warmup + steps])
+    t_proc = time.perf_counter()
     plans, hinted = list(seq.plans), seq.hinted
     extra = after(results, False) if after is not None else None
+    t_after = time.perf_counter()
     fence()
     elapsed = time.perf_counter() - t0
+    if os.environ.get('AMT_BENCH_DEBUG'):
+        sys.stderr.write('timed region: process %.3f ms, after %.3f ms, fence %.3f ms\n' % (
+            (t_proc - t0) * 1e3, (t_after - t_proc) * 1e3, (t0 + elapsed - t_after) * 1e3))
     g_total, g_n = ctx.timing_read(0)
     b_total, b_n = ctx.timing_read(1)
     ctx.timing_enable(False)
@@ -302,10 +307,13 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     # AMT_BENCH_FORCE_DIST=1 exercises the RCCL gather path with a single rank (boxes with one GPU)
     use_dist = world > 1 or bool(os.environ.get('AMT_BENCH_FORCE_DIST'))
-    if use_dist:
+    def init_dist():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29541')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    if use_dist:
+        init_dist()
 
     from auromat_amd._native import Context
     from auromat_amd.sequence import gather_device
@@ -336,7 +344,7 @@ def main(argv=None):
 
     def fence():
         torch.cuda.synchronize()
-        if use_dist:
+        if use_dist and dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -345,6 +353,10 @@ def main(argv=None):
         # (RCCL channels, allocations) belong to the warm-up.
         if not use_dist:
             return None
+        if warm:
+            # as many frames as the timed gather will carry, so that its buffers (payload, padded send and receive
+            # buffers) come out of the caching allocator instead of hipMalloc inside the timed region
+            results = (results * (args.steps // max(len(results), 1) + 1))[:args.steps]
         base = first + (0 if warm else args.warmup)
         return gather_device(results, [base + k for k in range(len(results))], device)
 
