@@ -56,7 +56,7 @@ def algorithmic_bytes(width, height, nchan=3, pix_bytes=2):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=None, help='frames per rank in the timed region (default 96 for every N: weak scaling; BASELINE.json configs[4], the '
+    ap.add_argument('--steps', type=int, default=None, help='frames per rank in the timed region (default 192 for every N: weak scaling; BASELINE.json configs[4], the '
                          '256-frame job on 8 GPUs, is --gpus 8 --steps 32)')
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--cpu-rows', type=int, default=2832, help='rows of the frame the CPU baseline processes (0 = skip)')
@@ -92,7 +92,7 @@ def parse_args(argv=None):
                     help='launcher / reporting path only: gloo on the CPU, no GPU, a step is a sleep (tests)')
     args = ap.parse_args(argv)
     if args.steps is None:
-        args.steps = 96
+        args.steps = 192
     return args
 
 
