@@ -456,11 +456,14 @@ constexpr int kBinW = 8, kBinCells = kBinW * kBinW;
 // and box only, 3 the pole plan of an MLat / MLT frame (bin_magnetic + bin_pole): (MLat, SM longitude) as in 1 and, for
 // binning and box, a third pair: those two rotated by 90 deg about x as if they were geodetic (what resampleMLatMLT does
 // with a magnetic pole in view, mapping.py:1519-1547 -> resample.py:176-201)
+#ifndef AMT_ROWS_MIN_WAVES_MAG
+#define AMT_ROWS_MIN_WAVES_MAG 3        // fused MLat / MLT variants: 271 us per frame at 3 waves (no spills), 278 at 4 (128 VGPRs, 2-3 spills)
+#endif
 #ifndef AMT_ROWS_MIN_WAVES_POLE
 #define AMT_ROWS_MIN_WAVES_POLE 3       // the pole variants need ~150 VGPRs; at 4 waves (128) they spill 40
 #endif
 template <bool FAST, bool DIRS_IN, int SECOND, int BIN>
-__global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE : (BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES)) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
+__global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE : (SECOND == 1 && BIN ? AMT_ROWS_MIN_WAVES_MAG : (BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES))) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
                                                            int n_items, int n_frames) {
     constexpr bool MAG = SECOND != 0, kPole = SECOND == 2, kMagPole = SECOND == 3;
     static_assert(!(kPole || kMagPole) || (BIN != 0 && !DIRS_IN), "the pole plans exist for fused binning with the camera model only");
