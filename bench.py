@@ -469,7 +469,7 @@ def main(argv=None):
             # the other configurations of SURVEY 8d on the record of the same run: short runs of the same loop
             torch.cuda.empty_cache()
             variants = {}
-            nv_w, nv_k = 9, 36
+            nv_w, nv_k = 9, 96
             for name, kw in (('exact_centres', dict(fast=False, magnetic=False)),
                              ('configs3_magnetic_3_shells', dict(fast=True, magnetic=True)),
                              # NOT the headline workload: the resampled grids only, no per-pixel coordinate arrays

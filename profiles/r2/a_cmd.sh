@@ -24,3 +24,8 @@ for v in exact magnetic; do
   timeout -s INT 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/d_stats_$v -- python3 $R/bench.py --cpu-rows 0 --no-variants --$v > $O/d_bench_${v}_under_rocprof.json 2> $O/d_rocprof_$v.err
 done
 find $O -name "*kernel_stats.csv" | head
+# p  frames with a pole in view (single-pass pole plan vs two-pass), g  one rank with a process group (RCCL gather inside the timed region)
+timeout 300 python3 $R/tools/pole_probe.py 2>&1 | grep "frame" > $O/p_pole_frames.txt
+AMT_BENCH_DEBUG=1 AMT_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout -s INT 300 python3 $R/bench.py --gpus 1 --cpu-rows 0 --no-variants > $O/g_bench_one_rank_rccl.json 2> $O/g_bench_one_rank_rccl.err
+grep "timed region" $O/g_bench_one_rank_rccl.err
+cat $O/p_pole_frames.txt
