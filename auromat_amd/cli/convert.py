@@ -6,7 +6,8 @@ What differs, and why:
 
 * ``--data`` is a directory of frames as ``<id>.wcs`` (an astrometry.net FITS header as 80-column cards, or a ``.json``
   dict of the same cards: ``CRVAL*``, ``CD*``, ``CRPIX*``, ``IMAGEW/H``, ``DATE-OBS`` [+ ``DATESHIF``], ``POS?``
-  [+ ``POS?SHIF``]) next to ``<id>.npy`` (uint8 / uint16 array (h, w, 3)).  The reference reads provider archives
+  [+ ``POS?SHIF``]) next to ``<id>.npy`` (uint8 / uint16 array (h, w, 3)) or a developed image file (``<id>.jpg`` /
+  ``.png`` / ``.tif`` through Pillow, as the reference's ISS provider caches them).  The reference reads provider archives
   there (ESA ISS ``api.json``, THEMIS ``thg_l1_*`` CDFs): downloads, RAW development and the CDF library are its I/O
   layer, not part of this package — ``--bps``, ``--correctgamma`` and ``--autobright`` belong to that layer and are
   accepted but have nothing to act on.
@@ -62,7 +63,7 @@ def getParser():
     parser = argparse.ArgumentParser(prog='auromat-convert', epilog=epilog, description=description,
                                      formatter_class=argparse.RawDescriptionHelpFormatter)
     parser.add_argument('--data', help='Data directory, by default the current directory: <id>.wcs (or <id>.json) '
-                                       'header files next to <id>.npy images.', default=os.getcwd())
+                                       'header files next to <id>.npy (or .jpg / .png / .tif) images.', default=os.getcwd())
     period = parser.add_argument_group('period', 'These arguments optionally specify which data to convert.')
     period.add_argument('--start', help='UTC start date, format 2000-01-01T12:00:00', type=date)
     period.add_argument('--end', help='UTC end date (inclusive)', type=date)
@@ -156,6 +157,44 @@ def read_header(path):
     return hdr
 
 
+IMAGE_EXTENSIONS = ('.npy', '.jpg', '.jpeg', '.png', '.tif', '.tiff')
+
+
+def find_image(data_dir, base):
+    """-> path of the image that belongs to header `base` (<base>.npy, or a developed image file as the reference's ISS
+    provider keeps next to its .wcs files: <base>.jpg / .png / .tif), None when there is none."""
+    for ext in IMAGE_EXTENSIONS:
+        for e in (ext, ext.upper()):
+            path = os.path.join(data_dir, base + e)
+            if os.path.exists(path):
+                return path
+    return None
+
+
+def read_image(path, mmap=False):
+    """(h, w, 3) uint8 / uint16 array of an image file: .npy as stored, anything else through Pillow (8-bit JPEG / PNG,
+    8- or 16-bit TIFF / PNG; grey images are repeated over three channels, an alpha channel is dropped)."""
+    if path.lower().endswith('.npy'):
+        return np.load(path, mmap_mode='r' if mmap else None)
+    try:
+        from PIL import Image
+    except ImportError:
+        raise NotImplementedError('Reading ' + path + ' needs Pillow; store the frame as .npy instead')
+    with Image.open(path) as im:
+        if im.mode in ('I;16', 'I;16B', 'I;16L', 'I'):
+            a = np.asarray(im).astype(np.uint16)
+        else:
+            if im.mode not in ('RGB', 'L'):
+                im = im.convert('RGB')
+            a = np.asarray(im)
+    if a.ndim == 2:
+        a = np.repeat(a[:, :, None], 3, axis=2)
+    a = np.ascontiguousarray(a[:, :, :3])
+    if a.dtype not in (np.uint8, np.uint16):
+        raise NotImplementedError('unsupported sample type %s in %s' % (a.dtype, path))
+    return a
+
+
 def list_frames(data_dir, start=None, end=None):
     """-> sorted list of (identifier, header dict, image path) within [start, end] by (shifted) photo time."""
     from ..mapping.spacecraft import getPhotoTime
@@ -164,8 +203,8 @@ def list_frames(data_dir, start=None, end=None):
         base, ext = os.path.splitext(name)
         if ext not in ('.wcs', '.json'):
             continue
-        img = os.path.join(data_dir, base + '.npy')
-        if not os.path.exists(img):
+        img = find_image(data_dir, base)
+        if img is None:
             continue
         hdr = read_header(os.path.join(data_dir, name))
         t = getPhotoTime(hdr)
@@ -205,7 +244,7 @@ def convert_with_classes(args, frames, export):
         path = target_path(args, identifier)
         if path is None:
             continue
-        mapping = getMapping(np.load(img_path), hdr, altitude=args.altitude,
+        mapping = getMapping(read_image(img_path), hdr, altitude=args.altitude,
                              fastCenterCalculation=not args.exactCenters, identifier=identifier)
         if args.resample:
             if args.minElevation >= 0:
@@ -252,7 +291,7 @@ def convert_with_pipeline(args, frames, export):
         if path is not None:
             todo.append((identifier, hdr, img_path, path))
     if todo:
-        first = np.load(todo[0][2], mmap_mode='r')
+        first = read_image(todo[0][2], mmap=True)
         magnetic = args.grid == Grid.mag
         seq = SequencePipeline(first.shape[1], first.shape[0], nchan=first.shape[2], img_dtype=first.dtype,
                                altitude=args.altitude, fast=not args.exactCenters,
@@ -262,7 +301,7 @@ def convert_with_pipeline(args, frames, export):
         def feed():
             for identifier, hdr, img_path, path in todo:
                 cam, t = frame_inputs(hdr)
-                yield hdr, cam, t, np.load(img_path)
+                yield hdr, cam, t, read_image(img_path)
 
         metas = [frame_inputs(hdr) for _, hdr, _, _ in todo]
         results = seq.process(feed(), keep_on_device=True)
@@ -286,7 +325,7 @@ def main(argv=None):
     from ..export.netcdf import write
     frames = list_frames(args.data, args.start, args.end)
     if not frames:
-        raise NotImplementedError('No <id>.wcs / <id>.json + <id>.npy frames found in ' + args.data)
+        raise NotImplementedError('No <id>.wcs / <id>.json + <id>.npy (or .jpg / .png / .tif) frames found in ' + args.data)
     export = partial(write, includeBounds=not args.withoutBounds, includeMagCoords=not args.withoutMag,
                      includeGeoCoords=not args.withoutGeo)
     os.makedirs(args.out, exist_ok=True)

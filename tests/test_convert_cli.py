@@ -115,3 +115,38 @@ def test_convert_both_routes(tmp_path, capsys):
     assert os.listdir(out3) == ['frame00.nc']
     f = _nc3.File(os.path.join(out3, 'frame00.nc'))
     assert f.vars['lat'].dims == ('y', 'x') and f.vars['lat_bounds'].data.shape == (170, 256, 4)
+
+
+def test_image_files_next_to_the_header(tmp_path):
+    """<id>.png / .tif / .jpg beside <id>.wcs (what the reference's ISS provider caches) are read through Pillow."""
+    PIL = pytest.importorskip('PIL')
+    from PIL import Image
+    from auromat_amd.cli.convert import find_image, list_frames, read_image
+    rs = np.random.RandomState(3)
+    rgb8 = rs.randint(0, 255, (20, 30, 3)).astype(np.uint8)
+    grey16 = rs.randint(0, 65535, (20, 30)).astype(np.uint16)
+    d = str(tmp_path)
+    Image.fromarray(rgb8).save(os.path.join(d, 'a.png'))
+    Image.fromarray(rgb8).save(os.path.join(d, 'b.tif'))
+    Image.fromarray(grey16).save(os.path.join(d, 'c.tif'))
+    smooth = np.dstack([np.add.outer(np.arange(20) * 5, np.arange(30) * 4 + 20 * c) for c in range(3)]).astype(np.uint8)
+    Image.fromarray(smooth).save(os.path.join(d, 'e.JPG'), quality=95)
+    np.save(os.path.join(d, 'f.npy'), rgb8)
+    for base, want in (('a', rgb8), ('b', rgb8), ('f', rgb8)):
+        got = read_image(find_image(d, base))
+        assert got.dtype == np.uint8 and np.array_equal(got, want), base
+    got = read_image(find_image(d, 'c'))
+    assert got.dtype == np.uint16 and got.shape == (20, 30, 3) and np.array_equal(got[..., 1], grey16)
+    got = read_image(find_image(d, 'e'))
+    assert got.shape == (20, 30, 3) and got.dtype == np.uint8 and np.abs(got.astype(int) - smooth).mean() < 3     # lossy
+    assert find_image(d, 'nothing') is None
+    # a header next to a .png is a frame
+    from auromat_amd.synthetic import sequence_frame
+    hdr, cam, t, _ = sequence_frame(0, 30, 20)
+    hdr = dict(hdr)
+    hdr.update({'DATE-OBS': t.strftime('%Y-%m-%dT%H:%M:%S.%f'), 'POSX': float(cam[0]), 'POSY': float(cam[1]),
+                'POSZ': float(cam[2])})
+    with open(os.path.join(d, 'a.json'), 'w') as fp:
+        json.dump(hdr, fp)
+    frames = list_frames(d)
+    assert [f[0] for f in frames] == ['a'] and frames[0][2].endswith('a.png')
