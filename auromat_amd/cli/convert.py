@@ -126,35 +126,8 @@ def parseargs(argv=None):
 # ---- input: a directory of headers + arrays ---------------------------------------------------------------------
 def read_header(path):
     """A FITS header stored as 80-column ASCII cards (what astrometry.net's .wcs files are) or as JSON -> dict."""
-    if path.endswith('.json'):
-        with open(path) as fp:
-            return json.load(fp)
-    with open(path, 'rb') as fp:
-        raw = fp.read().decode('ascii', 'replace')
-    hdr = {}
-    for i in range(0, len(raw) - 79, 80):
-        card = raw[i:i + 80]
-        key = card[:8].strip()
-        if key == 'END':
-            break
-        if card[8:10] != '= ':
-            continue
-        val = card[10:]
-        if val.lstrip().startswith("'"):
-            hdr[key] = val.lstrip()[1:].split("'")[0].rstrip()
-        else:
-            val = val.split('/')[0].strip()
-            if val in ('T', 'F'):
-                hdr[key] = val == 'T'
-            else:
-                try:
-                    hdr[key] = int(val)
-                except ValueError:
-                    try:
-                        hdr[key] = float(val.replace('D', 'E'))
-                    except ValueError:
-                        hdr[key] = val
-    return hdr
+    from ..fits import readHeader
+    return readHeader(path)
 
 
 IMAGE_EXTENSIONS = ('.npy', '.jpg', '.jpeg', '.png', '.tif', '.tiff')
@@ -174,22 +147,10 @@ def find_image(data_dir, base):
 def read_image(path, mmap=False):
     """(h, w, 3) uint8 / uint16 array of an image file: .npy as stored, anything else through Pillow (8-bit JPEG / PNG,
     8- or 16-bit TIFF / PNG; grey images are repeated over three channels, an alpha channel is dropped)."""
-    if path.lower().endswith('.npy'):
-        return np.load(path, mmap_mode='r' if mmap else None)
-    try:
-        from PIL import Image
-    except ImportError:
-        raise NotImplementedError('Reading ' + path + ' needs Pillow; store the frame as .npy instead')
-    with Image.open(path) as im:
-        if im.mode in ('I;16', 'I;16B', 'I;16L', 'I'):
-            a = np.asarray(im).astype(np.uint16)
-        else:
-            if im.mode not in ('RGB', 'L'):
-                im = im.convert('RGB')
-            a = np.asarray(im)
-    if a.ndim == 2:
-        a = np.repeat(a[:, :, None], 3, axis=2)
-    a = np.ascontiguousarray(a[:, :, :3])
+    if mmap and path.lower().endswith('.npy'):
+        return np.load(path, mmap_mode='r')
+    from ..util.image import loadImage
+    a = loadImage(path)
     if a.dtype not in (np.uint8, np.uint16):
         raise NotImplementedError('unsupported sample type %s in %s' % (a.dtype, path))
     return a

@@ -120,20 +120,27 @@ def getMapping(imagePathOrArray, wcsPathOrHeader, timeshift=None, noradId=None, 
                altitude=110, fastCenterCalculation=False, metadata=None, nosanitize=False, identifier=None,
                cameraPosGCRS=None):
     """
-    Build a mapping from an image array and a WCS header dict — the reference's signature and positional order
-    (spacecraft.py:380-426, 428-485), for array / dict inputs.  Photo time and camera position are taken from the
-    header: the shifted cards (DATESHIF, POS?SHIF) if present, else DATE-OBS and POS?.
+    Build a mapping from an image (array, or path of an image file) and a WCS header (dict, or path of a ``.wcs``
+    header-only FITS file) — the reference's signature and positional order (spacecraft.py:380-426, 428-485).  Photo
+    time and camera position are taken from the header: the shifted cards (DATESHIF, POS?SHIF) if present, else
+    DATE-OBS and POS?.  Files are read with :func:`auromat_amd.util.image.loadImage` (Pillow; not for RAW files) and
+    :func:`auromat_amd.fits.readHeader`.
 
-    Not supported here (they are the reference's file and network plumbing, out of this package's scope) and
-    rejected with a clear error instead of being ignored: image or header given as a file PATH; ``noradId`` /
-    ``tleFolder`` / ``spacetrack`` (camera position from two-line elements: pass ``cameraPosGCRS`` instead, which is
-    also needed with ``timeshift`` or for a header without POS? cards).  ``nosanitize`` only affects the reference's
-    file-based mappings and is accepted.
+    Not supported (the reference's network plumbing, out of this package's scope) and rejected with a clear error
+    instead of being ignored: ``noradId`` / ``tleFolder`` / ``spacetrack`` (camera position from two-line elements:
+    pass ``cameraPosGCRS`` instead, which is also needed with ``timeshift`` or for a header without POS? cards).
+    ``nosanitize`` only affects the reference's file-based mappings and is accepted.
     """
     imageArray, wcsHeader = imagePathOrArray, wcsPathOrHeader
-    if isinstance(imageArray, str) or isinstance(wcsHeader, str):
-        raise NotImplementedError('auromat_amd.getMapping takes an image ARRAY and a WCS header DICT; reading image / '
-                                  '.wcs files (astropy.io.fits, PIL) is the reference\'s I/O layer')
+    if isinstance(wcsHeader, str):
+        from ..fits import readHeader
+        wcsHeader = readHeader(wcsHeader)
+    if isinstance(imageArray, str):
+        from ..util.image import loadImage
+        if identifier is None:
+            import os
+            identifier = os.path.splitext(os.path.basename(imageArray))[0]
+        imageArray = loadImage(imageArray)
     if noradId is not None or tleFolder is not None or spacetrack is not None:
         raise NotImplementedError('noradId / tleFolder / spacetrack (camera position from two-line elements via '
                                   'pyephem) are not part of auromat_amd: pass cameraPosGCRS=[x, y, z] (km, GCRS)')

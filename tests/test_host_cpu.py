@@ -356,8 +356,8 @@ def test_getMapping_has_the_references_positional_order():
             getMapping(img, hdr, **bad)
     with pytest.raises(NotImplementedError):
         getMapping(img, hdr, None, 25544)          # positionally, as a caller of the reference would
-    with pytest.raises(NotImplementedError):
-        getMapping('frame.jpg', hdr)
+    with pytest.raises((IOError, OSError)):
+        getMapping('no-such-frame.jpg', hdr)       # paths are read (auromat_amd.util.image.loadImage)
     assert list(inspect.signature(getMappingSequence).parameters)[:2] == ['imageArrays', 'wcsHeaders']
 
 
@@ -403,3 +403,45 @@ def test_seq_unpack_and_payload_size_are_host_functions():
     # truncated buffers and impossible descriptors are refused, not read past
     assert L.amt_seq_unpack(buf.ctypes.data_as(C.c_void_p), buf.size - 1, 4, max_frames, out, 8, C.byref(n)) != 0
     assert L.amt_seq_unpack(buf.ctypes.data_as(C.c_void_p), buf.size, 4, 3, out, 8, C.byref(n)) != 0
+
+
+def test_fits_header_files_and_image_paths(tmp_path):
+    """auromat_amd.fits.readHeader on a real astrometry.net .wcs file of the reference's test resources (header-only FITS:
+    80-column cards in 2880-byte blocks), writeHeader round trip, and getMapping(imagePath, wcsPath)."""
+    from conftest import GOLDEN, header_from, load_golden
+    from auromat_amd import fits
+    from auromat_amd.mapping.spacecraft import getMapping
+    path = os.path.join(GOLDEN, 'resources', 'ISS030-E-102170_dc.wcs')
+    hdr = fits.readHeader(path)
+    z = load_golden('georef_full_iss030_fast.npz')          # made from the same file by the reference's own reader
+    want = header_from(z)
+    for k, v in want.items():
+        if k.startswith('CTYPE'):
+            continue
+        assert float(hdr[k]) == float(v), k
+    assert hdr['CTYPE1'] == 'RA---TAN' and hdr['CTYPE2'] == 'DEC--TAN' and hdr['SIMPLE'] is True
+    assert fits.getPhotoTime(hdr).isoformat() == '2012-01-25T09:27:08.060000'
+    # the frame was shifted by -13 s (DATESHIF, POS?SHIF): the mapping uses the shifted cards, the fixture holds them
+    cam, t, shift = fits.getShiftedSpacecraftPosition(hdr)
+    assert np.array_equal(cam, z['cam']) and t.isoformat() == str(z['time_iso']) and shift.total_seconds() == -13.0
+    assert np.array_equal(fits.getSpacecraftPosition(hdr)[0], [hdr['POSX'], hdr['POSY'], hdr['POSZ']])
+    out = str(tmp_path / 'copy.wcs')
+    fits.writeHeader(out, hdr)
+    assert os.path.getsize(out) % 2880 == 0
+    again = fits.readHeader(out)
+    assert again == {k: v for k, v in hdr.items() if v is not None}
+    with pytest.raises(IOError):
+        fits.writeHeader(out, hdr)
+    # strings with quotes, exponents, comments
+    fits.writeHeader(out, {'OBJECT': "it's", 'SMALL': 1.5e-12, 'FLAG': False, 'N': -3}, overwrite=True)
+    assert fits.readHeader(out) == {'SIMPLE': True, 'BITPIX': 8, 'NAXIS': 0, 'OBJECT': "it's", 'SMALL': 1.5e-12, 'FLAG': False,
+                                    'N': -3}
+    # image + header given as paths
+    img = np.random.RandomState(0).randint(0, 255, (int(hdr['IMAGEH']) // 16, int(hdr['IMAGEW']) // 16, 3)).astype(np.uint8)
+    np.save(str(tmp_path / 'ISS030-E-102170.npy'), img)
+    small = dict(hdr, IMAGEW=img.shape[1], IMAGEH=img.shape[0], CRPIX1=hdr['CRPIX1'] / 16, CRPIX2=hdr['CRPIX2'] / 16,
+                 **{k: hdr[k] * 16 for k in ('CD1_1', 'CD1_2', 'CD2_1', 'CD2_2')})
+    fits.writeHeader(str(tmp_path / 'small.wcs'), small)
+    m = getMapping(str(tmp_path / 'ISS030-E-102170.npy'), str(tmp_path / 'small.wcs'))
+    assert m.identifier == 'ISS030-E-102170' and m.altitude == 110
+    assert m.photoTime == t and np.array_equal(m.cameraPosGCRS, cam)
