@@ -26,6 +26,8 @@ Fixtures
   pole_frame_*.npz      a 200x160 camera frame with the north (south) pole in view (fast + exact centres):
                         maskedByElevation(10) -> _resample(containsPole=True, pxPerDeg=8) output, inputs included;
                         pole_frame_magnetic_*: across the geomagnetic pole, the _resample call of resampleMLatMLT
+  real_frame_iss030.npz the reference's own ISS030-E-102170_dc.jpg + .wcs at full size -> maskedByElevation(10) ->
+                        _resample(pxPerDeg=10): complete output (the two data files: tests/golden/resources/)
 """
 import json
 import os
@@ -866,6 +868,34 @@ def magnetic_pole_frames():
         out.update(time_arrays(t))
         out.update(cam=cam, altitude=np.float64(110), min_elev=np.float64(10), ppd=np.array((8, 8), dtype=np.float64))
         save('pole_frame_magnetic_%s.npz' % ('fast' if fast else 'exact'), **out)
+
+
+def real_frame():
+    """real_frame_iss030.npz: the reference's own test resources ISS030-E-102170_dc.jpg + .wcs (4256 x 2832, the frame
+    its draw tests map) -> mapping with fast centres -> maskedByElevation(10) -> _resample(pxPerDeg=10, 'mean'): the
+    complete output grid.  Copies of the two data files live in tests/golden/resources/ (the image is decoded with
+    Pillow here and in the test)."""
+    from PIL import Image
+    from auromat_amd.fits import readHeader
+    from auromat_amd.mapping.spacecraft import getShiftedSpacecraftPosition
+    hdr = readHeader(RES + 'ISS030-E-102170_dc.wcs')
+    img = np.asarray(Image.open(RES + 'ISS030-E-102170_dc.jpg'))
+    cam, t, _ = getShiftedSpacecraftPosition(hdr)
+    m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'ISS030-E-102170_dc', fastCenterCalculation=True)
+    mm = m.maskedByElevation(10)
+    merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+    case = _run_resample(mm.lats, mm.lons, mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan), 110, merged, (10, 10))
+    rimg, relev = np.dsplit(case['out_data'], [-1])
+    with np.errstate(invalid='ignore'):
+        rimg = np.round(rimg)
+    rimg = np.require(ma.masked_invalid(rimg, copy=False), np.uint8)
+    del case['outline']
+    out = dict(case)
+    out.update(out_img=rimg.data, out_img_mask=ma.getmaskarray(rimg))
+    out.update(time_arrays(t))
+    out.update(cam=cam, altitude=np.float64(110), min_elev=np.float64(10), ppd=np.array((10, 10), dtype=np.float64),
+               n_valid=np.int64((~ma.getmaskarray(mm.latsCenter)).sum()))
+    save('real_frame_iss030.npz', **out)
 
 
 if __name__ == '__main__':

@@ -1,0 +1,86 @@
+"""
+The reference's own test frame at full size: ISS030-E-102170_dc.jpg + .wcs (4256 x 2832; `draw_test.py` maps it), copies
+of the two data files under tests/golden/resources/.  Expected values from the REAL reference (oracle/make_golden.py:
+real_frame): fast centres -> maskedByElevation(10) -> _resample(pxPerDeg=10, 'mean'), the complete output grid.
+
+CPU: the oracle equals the reference cell for cell.  GPU: what a user of the reference would write —
+`resample(getMapping(imagePath, wcsPath, ...).maskedByElevation(10), pxPerDeg=10)` — and the frame pipeline with both plans.
+"""
+import os
+
+import numpy as np
+import numpy.ma as ma
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+JPG = os.path.join(GOLDEN, 'resources', 'ISS030-E-102170_dc.jpg')
+WCS = os.path.join(GOLDEN, 'resources', 'ISS030-E-102170_dc.wcs')
+
+
+def check(res_img, res_mask, mean, z):
+    want = z['out_data']
+    assert np.array_equal(res_mask, np.isnan(want[..., 0]))
+    ok = ~res_mask
+    assert ok.sum() > 4000
+    if mean is not None:
+        assert np.array_equal(mean[..., :3][ok], want[..., :3][ok])                 # exact integer sums / counts
+        assert np.max(np.abs(mean[..., 3][ok] - want[..., 3][ok])) < 1e-9           # elevation, fixed point
+    assert np.array_equal(res_img[ok], z['out_img'][ok])
+
+
+def test_oracle_equals_the_reference_on_its_own_test_frame():
+    from oracle import ref_numpy as O
+    from auromat_amd.fits import readHeader
+    from auromat_amd.util.image import loadImage
+    z = load_golden('real_frame_iss030.npz')
+    hdr = readHeader(WCS)
+    img = loadImage(JPG)
+    assert img.shape == (2832, 4256, 3) and img.dtype == np.uint8
+    g = O.georef_frame(hdr, 110.0, z['cam'], z['m_geo'], z['m_sm'], fast=True)
+    corner_mask, center_mask = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), 10)
+    assert int((~center_mask).sum()) == int(z['n_valid'])
+    bbox, disc = O.bbox_of_corners(g['lat'], g['lon'], corner_mask)
+    assert np.array_equal(bbox, z['bbox']) and not disc
+    data = np.dstack((img.astype(np.float64), g['elev']))
+    data[center_mask] = np.nan
+    res = O.resample_mean(np.where(center_mask, np.nan, g['lat_c']), np.where(center_mask, np.nan, g['lon_c']), 110.0,
+                          data, None, bbox, (10, 10), False, False)
+    for a, b in (('lat', 'out_lat'), ('lon', 'out_lon'), ('lat_c', 'out_lat_c'), ('lon_c', 'out_lon_c'),
+                 ('data', 'out_data')):
+        assert np.array_equal(res[a], z[b], equal_nan=True), a
+
+
+@pytest.mark.gpu
+def test_the_references_call_sequence_on_its_own_test_frame():
+    from auromat_amd.mapping.spacecraft import getMapping
+    from auromat_amd.resample import resample
+    z = load_golden('real_frame_iss030.npz')
+    m = getMapping(JPG, WCS, altitude=110, fastCenterCalculation=True)
+    assert m.identifier == 'ISS030-E-102170_dc' and m.img.shape == (2832, 4256, 3)
+    mm = m.maskedByElevation(10)
+    assert int((~ma.getmaskarray(mm.latsCenter)).sum()) == int(z['n_valid'])
+    bb = mm.boundingBox
+    np.testing.assert_allclose([bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast], z['bbox'], rtol=0, atol=1e-9)
+    r = resample(mm, pxPerDeg=10)
+    r.checkGuarantees()
+    assert np.array_equal(r.lats.data, z['out_lat']) and np.array_equal(r.lonsCenter.data, z['out_lon_c'])
+    check(r.img.data, ma.getmaskarray(r.img)[..., 0], None, z)
+    assert r.img.dtype == np.uint8
+
+
+@pytest.mark.gpu
+def test_both_plans_on_the_references_test_frame():
+    from auromat_amd.fits import getShiftedSpacecraftPosition, readHeader
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.util.image import loadImage
+    z = load_golden('real_frame_iss030.npz')
+    hdr = readHeader(WCS)
+    img = loadImage(JPG)
+    cam, t, _ = getShiftedSpacecraftPosition(hdr)
+    for fuse in (True, False):
+        pipe = FramePipeline(4256, 2832, img_dtype=np.uint8)
+        res = pipe.run(hdr, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, fuse=fuse)
+        assert pipe.last_plan == ('single-pass' if fuse else 'two-pass')
+        assert np.array_equal(res['lat'], z['out_lat']) and np.array_equal(res['lon_c'], z['out_lon_c'])
+        check(res['img'], res['mask'], res['mean'], z)
