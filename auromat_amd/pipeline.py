@@ -431,14 +431,17 @@ class FramePipeline(object):
 
 
 def _close(a, b):
-    """Are two amt_frame_params neighbours in a sequence: same frame size and camera model, camera within 100 km,
-    boresight and Earth rotation within about half a degree, shell within 30 km?"""
+    """Are two amt_frame_params neighbours in a sequence: same frame size, camera model within 1 % in scale, camera
+    within 100 km, boresight and Earth rotation within about half a degree, shell within 30 km?"""
     if (a.width, a.height, a.fast_center) != (b.width, b.height, b.fast_center):
         return False
     if abs(a.a - b.a) > 30.0 or abs(a.b - b.b) > 30.0:
         return False
+    # (separately solved frames of one sequence differ in the sixth digit of their CD matrix: the plate scale within 1 %
+    # and the reference pixel within 5 px move the box by far less than the superset's margin)
+    cd_tol = 0.01 * max(abs(v) for v in a.cd)
     for x, y, tol in ((a.cam, b.cam, 100.0), (a.rot, b.rot, 0.01), (a.m_geo, b.m_geo, 0.01), (a.m_sm, b.m_sm, 0.01),
-                      (a.cd, b.cd, 1e-9)):
+                      (a.cd, b.cd, cd_tol), (a.crpix, b.crpix, 5.0)):
         for u, v in zip(x, y):
             if abs(u - v) > tol:
                 return False

@@ -26,6 +26,8 @@ Fixtures
   pole_frame_*.npz      a 200x160 camera frame with the north (south) pole in view (fast + exact centres):
                         maskedByElevation(10) -> _resample(containsPole=True, pxPerDeg=8) output, inputs included;
                         pole_frame_magnetic_*: across the geomagnetic pole, the _resample call of resampleMLatMLT
+  real_sequence_iss029.npz  the ten consecutive real headers seq/ISS029-E-8493..8502.wcs with synthetic images at full
+                        size -> the same flow, per-frame output grids (headers: tests/golden/resources/seq/)
   real_frame_iss030.npz the reference's own ISS030-E-102170_dc.jpg + .wcs at full size -> maskedByElevation(10) ->
                         _resample(pxPerDeg=10): complete output (the two data files: tests/golden/resources/)
 """
@@ -896,6 +898,34 @@ def real_frame():
     out.update(cam=cam, altitude=np.float64(110), min_elev=np.float64(10), ppd=np.array((10, 10), dtype=np.float64),
                n_valid=np.int64((~ma.getmaskarray(mm.latsCenter)).sum()))
     save('real_frame_iss030.npz', **out)
+
+
+def real_sequence():
+    """real_sequence_iss029.npz: the ten consecutive headers of the reference's test resources seq/ISS029-E-8493 ... 8502.wcs
+    (4256 x 2832, one frame every 3 s), each with the synthetic image frame_image(4256, 2832, seed=k): fast centres ->
+    maskedByElevation(10) -> _resample(pxPerDeg=10, 'mean').  Per frame k: bbox_k, out_data_k (the grid coordinates follow
+    from the box).  Copies of the headers: tests/golden/resources/seq/."""
+    import glob
+    from auromat_amd.fits import readHeader
+    from auromat_amd.mapping.spacecraft import getSpacecraftPosition
+    out = {}
+    names = []
+    for k, path in enumerate(sorted(glob.glob(RES + 'seq/*.wcs'))):
+        hdr = readHeader(path)
+        cam, t = getSpacecraftPosition(hdr)
+        img = frame_image(4256, 2832, seed=k)
+        m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 's', fastCenterCalculation=True)
+        mm = m.maskedByElevation(10)
+        merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+        case = _run_resample(mm.lats, mm.lons, mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan), 110, merged, (10, 10))
+        out['bbox_%d' % k] = case['bbox']
+        out['out_data_%d' % k] = case['out_data']
+        out['out_lat_%d' % k] = case['out_lat']
+        out['out_lon_%d' % k] = case['out_lon']
+        names.append(os.path.basename(path))
+        print(k, names[-1], case['out_data'].shape, flush=True)
+    out['names'] = np.array(names)
+    save('real_sequence_iss029.npz', **out)
 
 
 if __name__ == '__main__':

@@ -84,3 +84,60 @@ def test_both_plans_on_the_references_test_frame():
         assert pipe.last_plan == ('single-pass' if fuse else 'two-pass')
         assert np.array_equal(res['lat'], z['out_lat']) and np.array_equal(res['lon_c'], z['out_lon_c'])
         check(res['img'], res['mask'], res['mean'], z)
+
+
+# ---- ten consecutive real headers (seq/ISS029-E-8493 ... 8502.wcs, one frame every 3 s) with synthetic images ---------
+
+def real_sequence():
+    import glob
+    from auromat_amd.fits import getSpacecraftPosition, readHeader
+    from auromat_amd.synthetic import frame_image
+    frames = []
+    for k, path in enumerate(sorted(glob.glob(os.path.join(GOLDEN, 'resources', 'seq', '*.wcs')))):
+        hdr = readHeader(path)
+        cam, t = getSpacecraftPosition(hdr)
+        frames.append((hdr, cam, t, frame_image(4256, 2832, seed=k)))
+    return frames
+
+
+def test_real_sequence_headers_are_the_references():
+    z = load_golden('real_sequence_iss029.npz')
+    frames = real_sequence()
+    assert len(frames) == 10 == len(z['names'])
+    assert [str(n) for n in z['names']] == ['ISS029-E-%d.wcs' % i for i in range(8493, 8503)]
+    times = [f[2] for f in frames]
+    assert all(2.9 < (b - a).total_seconds() < 3.1 for a, b in zip(times, times[1:]))
+    assert all(f[0]['IMAGEW'] == 4256 and f[0]['IMAGEH'] == 2832 for f in frames)
+    # neighbouring real frames are neighbours for the box hints too (their separately solved CD matrices differ in the
+    # sixth digit), frames 20 s apart are not
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.pipeline import _close
+    ps = [frame_params(h, 110, cam, t, True) for h, cam, t, _ in frames]
+    assert all(_close(a, b) for a, b in zip(ps, ps[1:])) and _close(ps[0], ps[3]) and not _close(ps[0], ps[7])
+
+
+@pytest.mark.gpu
+def test_sequence_pipeline_on_real_consecutive_frames():
+    """The sequence loop (batches of three, box hints between neighbouring frames, results left on the device) on ten real
+    consecutive headers at full size: every frame's grid equals the reference's, cell for cell."""
+    import torch
+    from auromat_amd.pipeline import SequencePipeline
+    from auromat_amd.resample import grid_coordinates
+    z = load_golden('real_sequence_iss029.npz')
+    frames = real_sequence()
+    for keep_coordinates in (True, False):
+        seq = SequencePipeline(4256, 2832, pxPerDeg=10, keep_coordinates=keep_coordinates)
+        got = seq.process(frames, keep_on_device=True)
+        # (no box hints here: a frame is prepared two batches = 6-8 frames = 20 s = 150 km of orbit ahead of the latest
+        # finished one, more than the superset's margin; sequences at 1 s cadence do use them)
+        assert seq.plans == ['single-pass'] * 10
+        for k, r in enumerate(got):
+            want = z['out_data_%d' % k]
+            mean, mask = r['mean'].cpu().numpy(), r['mask'].cpu().numpy().astype(bool)
+            assert mean.shape == want.shape, k
+            assert np.array_equal(mask, np.isnan(want[..., 0])), k
+            ok = ~mask
+            assert np.array_equal(mean[..., :3][ok], want[..., :3][ok]), k
+            assert np.max(np.abs(mean[..., 3][ok] - want[..., 3][ok])) < 1e-9, k
+            c = grid_coordinates(r)
+            assert np.array_equal(c['lat'], z['out_lat_%d' % k]) and np.array_equal(c['lon'], z['out_lon_%d' % k]), k
