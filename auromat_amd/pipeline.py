@@ -448,6 +448,41 @@ def _close(a, b):
     return True
 
 
+def _steady(a, b, c, n_ab, n_bc):
+    """Frames a, b (n_ab frames apart) and c (n_bc frames after b): same frame size, shell and camera model as `_close`
+    asks, c within 400 km of b, and the camera has moved from b to c as it did from a to b (20 % + 5 km)?"""
+    if n_ab <= 0 or n_bc <= 0 or n_bc > 16:
+        return False
+    if (b.width, b.height, b.fast_center) != (c.width, c.height, c.fast_center):
+        return False
+    if abs(b.a - c.a) > 30.0 or abs(b.b - c.b) > 30.0:
+        return False
+    for x, y, tol in ((b.cam, c.cam, 400.0), (b.rot, c.rot, 0.05), (b.m_geo, c.m_geo, 0.05), (b.m_sm, c.m_sm, 0.05),
+                      (b.crpix, c.crpix, 5.0)):
+        for u, v in zip(x, y):
+            if abs(u - v) > tol:
+                return False
+    # the CD matrix turns with the camera's roll (5e-4 per element over 20 s of the real ISS029 sequence): same plate scale
+    # within 1 %, and the elements where the pace of a -> b puts them
+    scale_b = abs(b.cd[0] * b.cd[3] - b.cd[1] * b.cd[2]) ** 0.5
+    scale_c = abs(c.cd[0] * c.cd[3] - c.cd[1] * c.cd[2]) ** 0.5
+    if not (scale_b > 0 and abs(scale_c - scale_b) <= 0.01 * scale_b):
+        return False
+    for i in range(4):
+        step = (b.cd[i] - a.cd[i]) / n_ab
+        if abs((c.cd[i] - b.cd[i]) - step * n_bc) > 0.3 * abs(step * n_bc) + 0.01 * scale_b:
+            return False
+    for i in range(3):
+        step = (b.cam[i] - a.cam[i]) / n_ab
+        if abs((c.cam[i] - b.cam[i]) - step * n_bc) > 0.2 * abs(step * n_bc) + 5.0:
+            return False
+    for i in range(9):
+        step = (b.rot[i] - a.rot[i]) / n_ab
+        if abs((c.rot[i] - b.rot[i]) - step * n_bc) > 0.3 * abs(step * n_bc) + 2e-3:
+            return False
+    return True
+
+
 class SequencePipeline(object):
     """
     Software-pipelined processing of a sequence of equally sized frames on one GPU — what the reference does
@@ -514,7 +549,8 @@ class SequencePipeline(object):
         self._img_busy = [[] for _ in self.pipes]
         self.plans = []                     # plan taken by each frame of the last process() call
         self.use_hints = True               # sequence coherence instead of the coarse pre-pass where possible
-        self._hint = None                   # (exact bbox reduction, amt_frame_params) of the latest finished frame
+        self._hint = None                   # (exact bbox reduction, amt_frame_params, index) of the latest finished frame
+        self._hint_prev = None              # ... and of the one finished before it (for the extrapolation, see _box_hint)
         self.hinted = 0                     # frames of the last process() call that needed no pre-pass
 
     def _stream_of(self, k):
@@ -522,6 +558,32 @@ class SequencePipeline(object):
         if self.s_alt is None:
             return self.s_main
         return self.s_alt if (k // self.batch) % 2 else self.s_main
+
+    def _box_hint(self, k, p):
+        """
+        Estimate of frame k's bounding-box reduction from frames that are already finished, or None (then the coarse
+        pre-pass runs).  The latest finished frame's exact box as it is when that frame is a neighbour of this one
+        (`_close`: camera within 100 km); else, in a steady sequence — the two latest finished frames are neighbours
+        of each other and the camera has kept its pace — their boxes extrapolated linearly to this frame: a frame is
+        prepared two batches ahead of the latest finished one, 20 s of orbit at the ISS's 3 s cadence, which moves
+        the box by more than the superset's margin, but smoothly.  A poor estimate costs time (the frame falls back
+        to the two-pass plan), never correctness.
+        """
+        last, prev = self._hint, self._hint_prev
+        if last is None:
+            return None
+        if _close(last[1], p):
+            return last[0]
+        if prev is None or not _close(prev[1], last[1]) or not _steady(prev[1], last[1], p, last[2] - prev[2], k - last[2]):
+            return None
+        if bool(prev[0][7]) != bool(last[0][7]) or (last[0][3] - last[0][2] > 180) != (prev[0][3] - prev[0][2] > 180):
+            return None                     # a pole or the date line came into view between the two
+        f = (k - last[2]) / float(last[2] - prev[2])
+        est = [b + f * (b - a) for a, b in zip(prev[0][:6], last[0][:6])] + list(last[0][6:])
+        est[0], est[1] = max(est[0], -90.0), min(est[1], 90.0)
+        for i in (2, 3, 4, 5):
+            est[i] = min(max(est[i], -180.0), 180.0)
+        return est
 
     def _prepare(self, k, frame):
         hdr, cam, t, img = frame[:4]
@@ -531,7 +593,7 @@ class SequencePipeline(object):
             # the superset grid needs an estimate of the frame's bounding box: the exact box of the latest finished
             # frame when this one is its neighbour in the sequence (no kernel at all), else a coarse pre-pass (a
             # tiny kernel on the driver's own stream, which has to find room on a busy GPU)
-            hint = self._hint[0] if (self.use_hints and self._hint is not None and _close(self._hint[1], p)) else None
+            hint = self._box_hint(k, p) if self.use_hints else None
             self.pipes[k % len(self.pipes)].start_coarse(p, self.min_elevation, self.magnetic, hint)
             self.hinted += hint is not None
         return p, cam, t, img, alt
@@ -604,9 +666,10 @@ class SequencePipeline(object):
                     self._bin_done[slot] = ev
         self.plans.append(q.last_plan)
         if q.last_plan == 'single-pass':
-            self._hint = (list(q._fused['result'].bbox), q.params)
+            self._hint_prev = self._hint
+            self._hint = (list(q._fused['result'].bbox), q.params, k)
         else:
-            self._hint = None                   # the next frame gets a real pre-pass
+            self._hint = self._hint_prev = None     # the next frame gets a real pre-pass
         return res
 
     def process(self, frames, keep_on_device=True):
@@ -622,7 +685,7 @@ class SequencePipeline(object):
         import torch
         del self.plans[:]
         self.hinted = 0
-        self._hint = None
+        self._hint = self._hint_prev = None
         out = []
         it = iter(frames)
         B = self.batch

@@ -242,3 +242,26 @@ def test_fallback_frames_inside_a_single_pass_sequence_do_not_race_with_the_fina
             for key in KEYS:
                 x = a[key].view(b[key].dtype) if key == 'img' else a[key].astype(b[key].dtype)
                 assert np.array_equal(x, b[key], equal_nan=True), (rep, k, key, seq.plans[k])
+
+
+def test_box_hints_are_extrapolated_at_the_cadence_of_real_sequences():
+    """One frame every 3 s (the ISS sequences of the reference's resources): a frame is prepared 20 s of orbit ahead of
+    the latest finished one, too far for that frame's box but not for the extrapolation of the two latest boxes."""
+    from auromat_amd.pipeline import FramePipeline, SequencePipeline
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    w, h, n = 530, 354, 40
+    frames = []
+    for k in range(n):
+        hdr, cam, t, seed = sequence_frame(3 * k, w, h)
+        frames.append((hdr, cam, t, frame_image(w, h, seed=seed)))
+    one = FramePipeline(w, h)
+    want = [one.run(hd, 110, cam, t, img=img, pxPerDeg=6) for hd, cam, t, img in frames]
+    for batch in (3, 1):
+        seq = SequencePipeline(w, h, pxPerDeg=6, batch=batch)
+        got = [host(r) for r in seq.process(frames)]
+        assert seq.plans == ['single-pass'] * n, seq.plans
+        assert seq.hinted >= n - 3 * 2 * batch - 2, seq.hinted          # all but the frames prepared before two were finished
+        for a, b in zip(got, want):
+            for key in KEYS:
+                x = a[key].view(b[key].dtype) if key == 'img' else a[key].astype(b[key].dtype)
+                assert np.array_equal(x, b[key], equal_nan=True), key
