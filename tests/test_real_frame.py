@@ -141,3 +141,25 @@ def test_sequence_pipeline_on_real_consecutive_frames():
             assert np.max(np.abs(mean[..., 3][ok] - want[..., 3][ok])) < 1e-9, k
             c = grid_coordinates(r)
             assert np.array_equal(c['lat'], z['out_lat_%d' % k]) and np.array_equal(c['lon'], z['out_lon_%d' % k]), k
+
+
+@pytest.mark.gpu
+def test_convert_driver_on_the_references_test_frame(tmp_path):
+    """`auromat-convert --data <folder with ISS030-E-102170_dc.jpg + .wcs> --resample --grid geo --px-per-deg 10`: the file
+    it writes holds the reference's grid (image through Pillow, header cards parsed from the FITS file, single-pass
+    pipeline, netCDF classic writer and reader)."""
+    from auromat_amd.cli.convert import main
+    from auromat_amd.export import _nc3
+    z = load_golden('real_frame_iss030.npz')
+    out = str(tmp_path / 'converted')
+    main(['--data', os.path.join(GOLDEN, 'resources'), '--format', 'netcdf', '--resample', '--grid', 'geo', '--px-per-deg', '10',
+          '--out', out, '--without-mag'])
+    assert os.listdir(out) == ['ISS030-E-102170_dc.nc']
+    f = _nc3.File(os.path.join(out, 'ISS030-E-102170_dc.nc'))
+    assert np.array_equal(f.vars['lat'].data, z['out_lat_c'][:, 0]) and np.array_equal(f.vars['lon'].data, z['out_lon_c'][0, :])
+    mask = z['out_img_mask'][..., 0]
+    for c, name in enumerate(('img_red', 'img_green', 'img_blue')):
+        v = f.vars[name]
+        got = ma.masked_equal(v.data, v.attrs['_FillValue'])
+        assert np.array_equal(ma.getmaskarray(got), mask), name
+        assert np.array_equal(got.filled(0)[~mask], z['out_img'][..., c][~mask]), name
