@@ -7,7 +7,8 @@ part of this package.)
 """
 import json
 
-from .mapping.spacecraft import getPhotoTime, getShiftedSpacecraftPosition, getSpacecraftPosition  # noqa: F401
+from .mapping.spacecraft import (getPhotoTime, getShiftedPhotoTime, getShiftedSpacecraftPosition,  # noqa: F401
+                                 getSpacecraftPosition)
 
 
 def _parse_value(val):
@@ -91,4 +92,5 @@ def writeHeader(filePath, header, overwrite=False):
         fp.write(raw.encode('ascii'))
 
 
-__all__ = ['readHeader', 'writeHeader', 'getPhotoTime', 'getSpacecraftPosition', 'getShiftedSpacecraftPosition']
+__all__ = ['readHeader', 'writeHeader', 'getPhotoTime', 'getShiftedPhotoTime', 'getSpacecraftPosition',
+           'getShiftedSpacecraftPosition']

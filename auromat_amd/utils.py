@@ -159,3 +159,15 @@ def convexHull(points):
 
 
 __all__ = ['outline', 'polygonArea', 'polygonCentroid', 'withoutConsecutiveDuplicates', 'convexHull']
+
+
+def findNearest(a, x):
+    """Index of the item of the sorted list `a` that is closest to `x`; the left one when both neighbours are equally
+    far (reference utils.py:277-296)."""
+    import bisect
+    i = bisect.bisect_left(a, x)
+    if i == len(a):
+        return i - 1
+    if i == 0 or a[i] == x:
+        return i
+    return i - 1 if (x - a[i - 1]) <= (a[i] - x) else i

@@ -3,6 +3,7 @@ CPU-only checks of the product's host side: the C ABI library builds/loads and e
 symbol of include/auromat_hip.h; per-frame host scalars equal the reference's (golden fixtures);
 grid layout logic; no compute entry point works without a GPU (there is no CPU fallback).
 """
+import json
 import os
 import re
 from datetime import datetime
@@ -358,7 +359,9 @@ def test_getMapping_has_the_references_positional_order():
         getMapping(img, hdr, None, 25544)          # positionally, as a caller of the reference would
     with pytest.raises((IOError, OSError)):
         getMapping('no-such-frame.jpg', hdr)       # paths are read (auromat_amd.util.image.loadImage)
-    assert list(inspect.signature(getMappingSequence).parameters)[:2] == ['imageArrays', 'wcsHeaders']
+    assert list(inspect.signature(getMappingSequence).parameters) == ['imagePathsOrArrays', 'wcsPaths', 'metadatas', 'timeshift',
+                                                                       'noradId', 'tleFolder', 'spacetrack', 'altitude', 'parallel',
+                                                                       'fastCenterCalculation']      # spacecraft.py:308-310
 
 
 def test_seq_unpack_and_payload_size_are_host_functions():
@@ -445,3 +448,53 @@ def test_fits_header_files_and_image_paths(tmp_path):
     m = getMapping(str(tmp_path / 'ISS030-E-102170.npy'), str(tmp_path / 'small.wcs'))
     assert m.identifier == 'ISS030-E-102170' and m.altitude == 110
     assert m.photoTime == t and np.array_equal(m.cameraPosGCRS, cam)
+
+
+def test_spacecraft_mapping_providers(tmp_path):
+    """SpacecraftMappingProvider / SpacecraftMappingPathProvider (reference spacecraft.py:40-300) over a folder with the
+    ten real headers of the reference's seq/ resources and an image file each."""
+    from datetime import timedelta
+    from auromat_amd import fits
+    from auromat_amd.mapping.spacecraft import SpacecraftMappingPathProvider, SpacecraftMappingProvider
+    from auromat_amd.utils import findNearest
+    assert [findNearest([1, 3, 7], x) for x in (0, 1, 2, 2.1, 5, 6, 9)] == [0, 0, 0, 1, 1, 2, 2]
+    src = os.path.join(GOLDEN, 'resources', 'seq')
+    d = str(tmp_path / 'frames')
+    os.makedirs(d)
+    names = sorted(os.listdir(src))
+    img = np.zeros((4, 6, 3), np.uint8)
+    for n in names:
+        # the real cards, for a 6 x 4 image (a mapping checks its image against IMAGEW / IMAGEH)
+        hdr = fits.readHeader(os.path.join(src, n))
+        fits.writeHeader(os.path.join(d, n), dict(hdr, IMAGEW=6, IMAGEH=4))
+        np.save(os.path.join(d, n[:-4] + '.npy'), img)
+    np.save(os.path.join(d, 'ISS029-E-9999.npy'), img)               # an image without a solution
+    with open(os.path.join(d, 'metadata.json'), 'w') as fp:
+        json.dump({'sequence_metadata': {'lens': '24mm', 'start': '2011-09-18T11:54:59'},
+                   'image_metadata': {n[:-4]: {'iso': 3200 + k} for k, n in enumerate(names)}}, fp)
+    prov = SpacecraftMappingProvider(d, altitude=120, fastCenterCalculation=True)
+    assert len(prov) == 10 and prov.imageFileExtension == 'npy' and prov.unsolvedIds == ['ISS029-E-9999']
+    assert prov.ids == [n[:-4] for n in names]
+    t0 = fits.getPhotoTime(fits.readHeader(os.path.join(src, names[0])))
+    assert prov.range[0] == t0 and (prov.range[1] - t0).total_seconds() == 27.0
+    assert prov.contains(t0 + timedelta(seconds=1)) and not prov.contains(t0 - timedelta(seconds=4))
+    m = prov.get(t0 + timedelta(seconds=4))                          # nearest within maxTimeOffset = 3 s: the second frame
+    assert m.identifier == 'ISS029-E-8494' and m.altitude == 120 and m.photoTime == t0 + timedelta(seconds=3)
+    assert m.metadata == {'lens': '24mm', 'start': datetime(2011, 9, 18, 11, 54, 59), 'iso': 3201}
+    with pytest.raises(ValueError):
+        prov.get(t0 - timedelta(seconds=10))
+    assert prov.getById('8502').identifier == 'ISS029-E-8502'
+    with pytest.raises(ValueError):
+        prov.getById('ISS029')
+    seq = list(prov.getSequence())
+    assert [q.identifier for q in seq] == prov.ids and all(q.fastCenterCalculation for q in seq)
+    # explicit path lists, deliberately out of order
+    wcs = [os.path.join(d, n) for n in reversed(names)]
+    imgs = [w[:-4] + '.npy' for w in wcs]
+    both = SpacecraftMappingProvider(imgs, wcs)
+    assert both.ids == prov.ids and both.imageFileExtension == 'npy'
+    pp = SpacecraftMappingPathProvider(imgs, wcs, metadataPath=os.path.join(d, 'metadata.json'))
+    assert len(pp) == 10 and pp.range == prov.range and pp.imageFileExtension == 'npy'
+    assert [q.identifier for q in pp.getSequence()] == prov.ids
+    with pytest.raises(NotImplementedError):
+        pp.get(t0)
