@@ -28,6 +28,7 @@ Fixtures
                         pole_frame_magnetic_*: across the geomagnetic pole, the _resample call of resampleMLatMLT
   real_sequence_iss029.npz  the ten consecutive real headers seq/ISS029-E-8493..8502.wcs with synthetic images at full
                         size -> the same flow, per-frame output grids (headers: tests/golden/resources/seq/)
+  real_frame_iss030_{exact,sm}.npz  the same frame with exact centres / on the MLat-MLT grid
   real_frame_iss030.npz the reference's own ISS030-E-102170_dc.jpg + .wcs at full size -> maskedByElevation(10) ->
                         _resample(pxPerDeg=10): complete output (the two data files: tests/golden/resources/)
 """
@@ -926,6 +927,48 @@ def real_sequence():
         print(k, names[-1], case['out_data'].shape, flush=True)
     out['names'] = np.array(names)
     save('real_sequence_iss029.npz', **out)
+
+
+def real_frame_more():
+    """real_frame_iss030_exact.npz / real_frame_iss030_sm.npz: the same frame with exact centres (getMapping's default) on
+    the geographic grid, and with fast centres on the MLat/MLT grid (the _resample call of resampleMLatMLT)."""
+    from PIL import Image
+    from auromat_amd.fits import readHeader
+    from auromat_amd.mapping.spacecraft import getShiftedSpacecraftPosition
+    hdr = readHeader(RES + 'ISS030-E-102170_dc.wcs')
+    img = np.asarray(Image.open(RES + 'ISS030-E-102170_dc.jpg'))
+    cam, t, _ = getShiftedSpacecraftPosition(hdr)
+
+    def finish(case, name, mm):
+        rimg, relev = np.dsplit(case['out_data'], [-1])
+        with np.errstate(invalid='ignore'):
+            rimg = np.round(rimg)
+        rimg = np.require(ma.masked_invalid(rimg, copy=False), np.uint8)
+        del case['outline']
+        out = dict(case)
+        out.update(out_img=rimg.data, out_img_mask=ma.getmaskarray(rimg))
+        out.update(time_arrays(t))
+        out.update(cam=cam, altitude=np.float64(110), min_elev=np.float64(10), ppd=np.array((10, 10), dtype=np.float64),
+                   n_valid=np.int64((~ma.getmaskarray(mm.latsCenter)).sum()))
+        save(name, **out)
+
+    m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'x', fastCenterCalculation=False)
+    mm = m.maskedByElevation(10)
+    mm.checkGuarantees()
+    merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+    finish(_run_resample(mm.lats, mm.lons, mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan), 110, merged, (10, 10)),
+           'real_frame_iss030_exact.npz', mm)
+
+    m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'x', fastCenterCalculation=True)
+    mm = m.maskedByElevation(10)
+    merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+    mlat, mlt = mm.mLatMlt
+    mlat_c, mlt_c = mm.mLatMltCenter
+    mask = ma.getmaskarray(mm.lats)
+    cmask = ma.getmaskarray(mm.latsCenter)
+    sm_lats, sm_lons = ma.masked_array(mlat.data, mask), ma.masked_array(T.mltToSmLon(mlt.data), mask)
+    finish(_run_resample(sm_lats, sm_lons, np.where(cmask, np.nan, mlat_c.data), np.where(cmask, np.nan, T.mltToSmLon(mlt_c.data)),
+                         110, merged, (10, 10)), 'real_frame_iss030_sm.npz', mm)
 
 
 if __name__ == '__main__':

@@ -163,3 +163,50 @@ def test_convert_driver_on_the_references_test_frame(tmp_path):
         got = ma.masked_equal(v.data, v.attrs['_FillValue'])
         assert np.array_equal(ma.getmaskarray(got), mask), name
         assert np.array_equal(got.filled(0)[~mask], z['out_img'][..., c][~mask]), name
+
+
+# ---- the same frame with exact centres (getMapping's default), and on the MLat / MLT grid ----------------------------
+
+@pytest.mark.gpu
+def test_real_frame_with_exact_centres():
+    from auromat_amd.mapping.spacecraft import getMapping
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.resample import resample
+    from auromat_amd.fits import getShiftedSpacecraftPosition, readHeader
+    from auromat_amd.util.image import loadImage
+    z = load_golden('real_frame_iss030_exact.npz')
+    mm = getMapping(JPG, WCS).maskedByElevation(10)                   # fastCenterCalculation=False is the default
+    mm.checkGuarantees()
+    assert int((~ma.getmaskarray(mm.latsCenter)).sum()) == int(z['n_valid'])
+    r = resample(mm, pxPerDeg=10)
+    assert np.array_equal(r.lats.data, z['out_lat']) and np.array_equal(r.lonsCenter.data, z['out_lon_c'])
+    check(r.img.data, ma.getmaskarray(r.img)[..., 0], None, z)
+    hdr, img = readHeader(WCS), loadImage(JPG)
+    cam, t, _ = getShiftedSpacecraftPosition(hdr)
+    for fuse in (True, False):
+        pipe = FramePipeline(4256, 2832, img_dtype=np.uint8)
+        res = pipe.run(hdr, 110, cam, t, img=img, fast=False, min_elevation=10, pxPerDeg=10, fuse=fuse)
+        assert pipe.last_plan == ('single-pass' if fuse else 'two-pass')
+        check(res['img'], res['mask'], res['mean'], z)
+
+
+@pytest.mark.gpu
+def test_real_frame_on_the_mlat_mlt_grid():
+    from auromat_amd.mapping.spacecraft import getMapping
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.resample import resampleMLatMLT
+    from auromat_amd.fits import getShiftedSpacecraftPosition, readHeader
+    from auromat_amd.util.image import loadImage
+    z = load_golden('real_frame_iss030_sm.npz')
+    mm = getMapping(JPG, WCS, fastCenterCalculation=True).maskedByElevation(10)
+    r = resampleMLatMLT(mm, pxPerDeg=10)
+    assert r.img.shape[:2] == z['out_img'].shape[:2]
+    check(r.img.data, ma.getmaskarray(r.img)[..., 0], None, z)
+    hdr, img = readHeader(WCS), loadImage(JPG)
+    cam, t, _ = getShiftedSpacecraftPosition(hdr)
+    for fuse in (True, False):
+        pipe = FramePipeline(4256, 2832, img_dtype=np.uint8, with_mag=True)
+        res = pipe.run(hdr, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, fuse=fuse, magnetic=True)
+        assert pipe.last_plan == ('single-pass' if fuse else 'two-pass')
+        assert np.array_equal(res['lat'], z['out_lat']) and np.array_equal(res['lon_c'], z['out_lon_c'])
+        check(res['img'], res['mask'], res['mean'], z)
