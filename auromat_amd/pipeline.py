@@ -347,16 +347,20 @@ class FramePipeline(object):
         # wrong now and then).  So the outputs are allocated FOR the finalise stream, and the streams that read them
         # are recorded on them.
         cur = torch.cuda.current_stream(ctx.device)
+        # (one allocation for the four arrays: mean | count | image | mask)
+        n = g.ny * g.nx
+        img_t = torch.uint8 if fd.img_dtype_code != 2 else torch.int16
+        img_bytes = 3 * n * (2 if fd.img_dtype_code == 2 else 1)
         with torch.cuda.stream(self._finalize_stream()):
-            mean = ctx.empty((g.ny, g.nx, 4))
-            img = ctx.empty((g.ny, g.nx, 3), torch.uint8 if fd.img_dtype_code != 2 else torch.int16)
-            mask = ctx.empty((g.ny, g.nx), torch.uint8)
-            count = ctx.empty((g.ny, g.nx))
+            buf = torch.empty(40 * n + img_bytes + n, dtype=torch.uint8, device=ctx.device)
+        mean = buf[:32 * n].view(torch.float64).view(g.ny, g.nx, 4)
+        count = buf[32 * n:40 * n].view(torch.float64).view(g.ny, g.nx)
+        img = buf[40 * n:40 * n + img_bytes].view(img_t).view(g.ny, g.nx, 3)
+        mask = buf[40 * n + img_bytes:].view(g.ny, g.nx)
         self._pcall('amt_pipe_finalize', ptr(mean), ptr(img), ptr(mask), ptr(count))
         if not (keep_on_device and self.defer_join):
             self.join()
-        for t_ in (mean, img, mask, count):
-            t_.record_stream(cur)
+        buf.record_stream(cur)
         # (BoundingBox.containsDiscontinuity is true for every box with a pole in it, reference mapping.py:200-206)
         out = dict(has_elev=True, grid=grid, contains_pole=pole, contains_discontinuity=wrapped or pole,
                    altitude=self.altitude)
