@@ -98,3 +98,28 @@ def random_sequence(rng, width, height, max_frames=40):
         else:
             k = int(rng.randint(0, 300))
     return frames[:n]
+
+
+def pole_frame(width=4240, height=2832, south=False):
+    """
+    A frame with a pole in view: camera 400 km above 83 deg latitude looking across the pole, 66 x 53 deg field of view
+    (the geometry of tests/golden/pole_frame_*.npz scaled to `width` x `height`).  Returns (header, camera, time).
+    """
+    from .coordinates import transform as T
+    t = datetime(2012, 1, 25, 9, 26, 55, 60000)
+    m_geo = np.asarray(T.mat_j2000_to_geo(T.date2es(t)))
+    sgn = -1.0 if south else 1.0
+
+    def geo(lat, lon, r):
+        la, lo = np.deg2rad(lat), np.deg2rad(lon)
+        return r * np.array([np.cos(la) * np.cos(lo), np.cos(la) * np.sin(lo), np.sin(la)])
+
+    cam_geo = geo(sgn * 83.0, 30.0, 6360.0 + 400.0)
+    bore = m_geo.T.dot(geo(sgn * 87.5, -140.0, 6360.0 + 110.0) - cam_geo)
+    bore /= np.linalg.norm(bore)
+    s = 200.0 / width
+    hdr = {'CTYPE1': 'RA---TAN', 'CTYPE2': 'DEC--TAN', 'LONPOLE': 180.0, 'LATPOLE': 0.0,
+           'CRVAL1': float(np.rad2deg(np.arctan2(bore[1], bore[0])) % 360), 'CRVAL2': float(np.rad2deg(np.arcsin(bore[2]))),
+           'CRPIX1': width / 2 + 0.5, 'CRPIX2': height / 2 + 0.5, 'CD1_1': -0.33 * s, 'CD1_2': 0.05 * s, 'CD2_1': 0.05 * s,
+           'CD2_2': 0.33 * s, 'IMAGEW': width, 'IMAGEH': height}
+    return hdr, m_geo.T.dot(cam_geo), t

@@ -470,12 +470,21 @@ def main(argv=None):
             torch.cuda.empty_cache()
             variants = {}
             nv_w, nv_k = 9, 96
+            from auromat_amd.synthetic import pole_frame
+            p_hdr, p_cam, p_t = pole_frame(WIDTH, HEIGHT)
             for name, kw in (('exact_centres', dict(fast=False, magnetic=False)),
                              ('configs3_magnetic_3_shells', dict(fast=True, magnetic=True)),
                              # NOT the headline workload: the resampled grids only, no per-pixel coordinate arrays
                              # written (what a convert run needs; SequencePipeline(keep_coordinates=False))
-                             ('grids_only_no_coordinate_arrays', dict(fast=True, magnetic=False, keep=False))):
-                v = timed_run(make_frames(nv_w + nv_k, kw['magnetic']), nv_w, nv_k, kw['fast'], 'fused', kw['magnetic'],
+                             ('grids_only_no_coordinate_arrays', dict(fast=True, magnetic=False, keep=False)),
+                             # a camera that looks across the geographic pole (the same frame, its own image each time):
+                             # the pole plan of the fused kernel, binned in rotated coordinates
+                             ('pole_in_view', dict(fast=True, magnetic=False, pole=True))):
+                if kw.get('pole'):
+                    vframes = [(p_hdr, p_cam, p_t, imgs[k % len(imgs)], None) for k in range(nv_w + nv_k)]
+                else:
+                    vframes = make_frames(nv_w + nv_k, kw['magnetic'])
+                v = timed_run(vframes, nv_w, nv_k, kw['fast'], 'fused', kw['magnetic'],
                               args.batch, args.streams, True, None, own_buffers=False, fence=fence,
                               keep_coordinates=kw.get('keep', True), spinup_ms=args.spinup_ms)
                 vb = ab['mag_shell'] - 24 * (WIDTH + 1) * (HEIGHT + 1) if kw['magnetic'] else ab['georef'] + ab['resample']

@@ -3,32 +3,14 @@ the two-pass plan (georef kernel, whole-array rotation, box reduction, binning k
 SequencePipeline and the big kernel's own time; an ordinary frame of the same size beside them."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from datetime import datetime
 import numpy as np
 import torch
 from auromat_amd.pipeline import SequencePipeline
 from auromat_amd.synthetic import sequence_frame, frame_image
-from auromat_amd.coordinates import transform as T
 
 W, H = 4256, 2832
-t = datetime(2012, 1, 25, 9, 26, 55, 60000)
-m_geo = np.asarray(T.mat_j2000_to_geo(T.date2es(t)))
-
-
-def geo(lat, lon, r):
-    la, lo = np.deg2rad(lat), np.deg2rad(lon)
-    return r * np.array([np.cos(la) * np.cos(lo), np.cos(la) * np.sin(lo), np.sin(la)])
-
-
-cam_geo = geo(83.0, 30.0, 6360.0 + 400.0)
-bore = m_geo.T.dot(geo(87.5, -140.0, 6470.0) - cam_geo)
-bore /= np.linalg.norm(bore)
-s = 200.0 / W
-pole_hdr = {'CTYPE1': 'RA---TAN', 'CTYPE2': 'DEC--TAN', 'LONPOLE': 180.0, 'LATPOLE': 0.0,
-            'CRVAL1': float(np.rad2deg(np.arctan2(bore[1], bore[0])) % 360), 'CRVAL2': float(np.rad2deg(np.arcsin(bore[2]))),
-            'CRPIX1': W / 2 + 0.5, 'CRPIX2': H / 2 + 0.5, 'CD1_1': -0.33 * s, 'CD1_2': 0.05 * s, 'CD2_1': 0.05 * s,
-            'CD2_2': 0.33 * s, 'IMAGEW': W, 'IMAGEH': H}
-pole_cam = m_geo.T.dot(cam_geo)
+from auromat_amd.synthetic import pole_frame
+pole_hdr, pole_cam, t = pole_frame(W, H)
 img = torch.from_numpy(frame_image(W, H).view(np.int16)).cuda()
 hdr, cam, t0, _ = sequence_frame(0, W, H)
 N = 24
