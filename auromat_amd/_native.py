@@ -71,6 +71,7 @@ class PipeResult(C.Structure):
                 ('bbox', C.c_double * 8), ('grid', Grid)]
 
 
+ABI_VERSION = 2          # include/auromat_hip.h AMT_ABI_VERSION
 _I, _L, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p
 _SIGNATURES = {
     'amt_abi_version': ([], _I),
@@ -172,8 +173,9 @@ def lib():
                 fn = getattr(handle, name)
                 fn.argtypes = argtypes
                 fn.restype = restype
-            if handle.amt_abi_version() != 1:
-                raise NativeError('ABI version mismatch')
+            if handle.amt_abi_version() != ABI_VERSION:
+                raise NativeError('ABI version mismatch: the library is %d, this package expects %d (rebuild: '
+                                  'python -c "import __graft_entry__ as g; g.build()")' % (handle.amt_abi_version(), ABI_VERSION))
             _lib = handle
     return _lib
 

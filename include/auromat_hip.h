@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define AMT_ABI_VERSION 1
+/* 2: amt_georef_out grew (bin_pole, altitude); amt_rotate_pole_deg, amt_pipe_finalize_stream, amt_seq_* added (round 2) */
+#define AMT_ABI_VERSION 2
 
 #define AMT_OK 0
 #define AMT_EINVAL (-1)   /* bad argument (NULL pointer, negative size, unsupported dtype ...) */

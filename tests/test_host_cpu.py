@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), 'library does not export ' + name
     assert declared == set(_native.exported_symbols()), declared ^ set(_native.exported_symbols())
-    assert lib.amt_abi_version() == 1
+    assert lib.amt_abi_version() == _native.ABI_VERSION == int(re.search(r'#define AMT_ABI_VERSION (\d+)', text).group(1))
 
 
 def test_struct_layouts_match_header():
