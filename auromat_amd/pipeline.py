@@ -555,6 +555,7 @@ class SequencePipeline(object):
         self.use_hints = True               # sequence coherence instead of the coarse pre-pass where possible
         self._hint = None                   # (exact bbox reduction, amt_frame_params, index) of the latest finished frame
         self._hint_prev = None              # ... and of the one finished before it (for the extrapolation, see _box_hint)
+        self._frames_done = 0               # frames of earlier process() calls (hints count frames across calls)
         self.hinted = 0                     # frames of the last process() call that needed no pre-pass
 
     def _stream_of(self, k):
@@ -597,7 +598,7 @@ class SequencePipeline(object):
             # the superset grid needs an estimate of the frame's bounding box: the exact box of the latest finished
             # frame when this one is its neighbour in the sequence (no kernel at all), else a coarse pre-pass (a
             # tiny kernel on the driver's own stream, which has to find room on a busy GPU)
-            hint = self._box_hint(k, p) if self.use_hints else None
+            hint = self._box_hint(self._frames_done + k, p) if self.use_hints else None
             self.pipes[k % len(self.pipes)].start_coarse(p, self.min_elevation, self.magnetic, hint)
             self.hinted += hint is not None
         return p, cam, t, img, alt
@@ -671,7 +672,7 @@ class SequencePipeline(object):
         self.plans.append(q.last_plan)
         if q.last_plan == 'single-pass':
             self._hint_prev = self._hint
-            self._hint = (list(q._fused['result'].bbox), q.params, k)
+            self._hint = (list(q._fused['result'].bbox), q.params, self._frames_done + k)
         else:
             self._hint = self._hint_prev = None     # the next frame gets a real pre-pass
         return res
@@ -689,15 +690,16 @@ class SequencePipeline(object):
         import torch
         del self.plans[:]
         self.hinted = 0
-        self._hint = self._hint_prev = None
+        # (the box of the latest finished frame stays from the previous call: a sequence handed over in pieces is still
+        # a sequence, and every hint is checked against the new frame's camera before it is used)
         out = []
         it = iter(frames)
         B = self.batch
 
-        def next_batch(k0):
-            """Prepare up to B frames starting at index k0 -> list (empty at the end of the sequence)."""
+        def next_batch(k0, size=B):
+            """Prepare up to `size` frames starting at index k0 -> list (empty at the end of the sequence)."""
             prepared = []
-            for i in range(B):
+            for i in range(size):
                 f = next(it, None)
                 if f is None:
                     break
@@ -705,7 +707,9 @@ class SequencePipeline(object):
             return prepared
 
         k = 0                                    # first frame of the batch that is finished next
-        in_flight = next_batch(0)
+        # the first launch carries one frame only: the GPU starts after one frame's preparation instead of three
+        # (not with two launch streams, where a buffer set must stay on the stream of its batch parity)
+        in_flight = next_batch(0, 1 if self.s_alt is None else B)
         if not in_flight:
             return out
         self._launch(0, in_flight)
@@ -738,4 +742,5 @@ class SequencePipeline(object):
                 for v in (res or {}).values():
                     if isinstance(v, torch.Tensor) and v.is_cuda:
                         v.record_stream(cur)
+        self._frames_done += len(out)
         return out

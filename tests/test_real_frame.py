@@ -128,9 +128,10 @@ def test_sequence_pipeline_on_real_consecutive_frames():
     for keep_coordinates in (True, False):
         seq = SequencePipeline(4256, 2832, pxPerDeg=10, keep_coordinates=keep_coordinates)
         got = seq.process(frames, keep_on_device=True)
-        # a frame is prepared two batches = 6-8 frames = 20 s = 150 km of orbit ahead of the latest finished one: its box
-        # hint is the extrapolation of the two latest finished frames' boxes (the last frame here gets one)
-        assert seq.plans == ['single-pass'] * 10 and seq.hinted >= 1
+        # (a frame is prepared 6-7 frames = 20 s = 150 km of orbit ahead of the latest finished one: box hints at this
+        # cadence are extrapolations of the two latest finished frames' boxes, which a ten-frame sequence is too short to
+        # have in time: tests/test_gpu_sequence.py::test_box_hints_are_extrapolated_at_the_cadence_of_real_sequences)
+        assert seq.plans == ['single-pass'] * 10
         for k, r in enumerate(got):
             want = z['out_data_%d' % k]
             mean, mask = r['mean'].cpu().numpy(), r['mask'].cpu().numpy().astype(bool)
