@@ -365,7 +365,9 @@ class FramePipeline(object):
         out = dict(has_elev=True, grid=grid, contains_pole=pole, contains_discontinuity=wrapped or pole,
                    altitude=self.altitude)
         if keep_on_device:
-            out.update(mean=mean, img=img, mask=mask, count=count)
+            # `packed`: mean and count as they lie in memory, one after the other — the payload of this frame in the
+            # gather's wire format (auromat_amd.sequence.pack_results) without a copy per array
+            out.update(mean=mean, img=img, mask=mask, count=count, packed=buf[:40 * n].view(torch.float64))
             return out
         out.update(grid_coordinates(out))
         out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype), mask=to_host(mask).astype(bool),

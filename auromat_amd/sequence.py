@@ -46,10 +46,14 @@ def pack_results(results, indices, device):
             mean, count = torch.from_numpy(np.ascontiguousarray(mean)), torch.from_numpy(np.ascontiguousarray(count))
         ny, nx, nc = mean.shape
         g = res['grid']
-        descs[i] = [ny, nx, nc, g.lat0, g.lon0, g.latStep, g.lonStep, idx,
+        descs[i] = (ny, nx, nc, g.lat0, g.lon0, g.latStep, g.lonStep, idx,
                     1.0 if res.get('contains_pole') else 0.0, 1.0 if res.get('contains_discontinuity') else 0.0,
-                    float(res.get('altitude') or 0.0), 1.0 if res.get('magnetic') else 0.0]
-        parts += [mean.reshape(-1).to(device), count.reshape(-1).to(device)]
+                    float(res.get('altitude') or 0.0), 1.0 if res.get('magnetic') else 0.0)
+        packed = res.get('packed')
+        if packed is not None and packed.device == mean.device and packed.numel() == ny * nx * (nc + 1):
+            parts.append(packed)        # the single-pass plan lays mean and count out one after the other already
+        else:
+            parts += [mean.reshape(-1).to(device), count.reshape(-1).to(device)]
     payload = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.float64, device=device)
     return torch.from_numpy(descs).to(device), payload
 
