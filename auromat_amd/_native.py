@@ -140,6 +140,7 @@ _SIGNATURES = {
     'amt_pipe_wait': ([_P, C.POINTER(PipeResult)], _I),
     'amt_pipe_finalize': ([_P, _P, _P, _P, _P], _I),
     'amt_pipe_finalize_stream': ([_P, _P], _I),
+    'amt_pipe_finalize_many': ([_P, C.c_int32, _P, _P, _P, _P], _I),
     'amt_pipe_join': ([_P], _I),
     'amt_seq_payload_size': ([C.POINTER(SeqFrame), C.c_int32, C.POINTER(_L)], _I),
     'amt_seq_pack': ([_P, C.POINTER(SeqFrame), C.c_int32, C.c_int32, _P, _L], _I),

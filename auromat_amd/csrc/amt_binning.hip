@@ -354,6 +354,61 @@ __global__ void k_apply_bin_events(const bin_event* __restrict__ events, unsigne
     if (threadIdx.x == 0) *count = 0;
 }
 
+// The finalise step of up to three frames of the single-pass driver in ONE launch (blockIdx.y = frame): crop + mean /
+// image / mask / count as k_bin_finalize with clear = 1, and the on-edge pixels (k_apply_bin_events) folded in —
+// instead of adding them to the accumulators first, every output cell adds the recorded pixels that the
+// right-most-edge rule puts into it (there are a few dozen per frame; integer sums, so the result is the same).
+// n_events is the host's copy of the counter (amt_pipe_wait has read it); the counter is reset for the next frame.
+template <typename IMG_T>
+__global__ void k_pipe_finish(finish_batch B) {
+    const finish_frame& F = B.f[blockIdx.y];
+    const int nch = 3;
+    const int64_t n = (int64_t)F.nx * F.ny, plane = (int64_t)F.acc_nx * F.acc_ny;
+    unsigned long long* __restrict__ acc = F.acc;
+    IMG_T* __restrict__ out_img = static_cast<IMG_T*>(F.img);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / F.nx), c = (int)(i - (int64_t)r * F.nx);
+        const int ax = F.off_x + c, ay = F.off_y + F.ny - 1 - r;
+        const int64_t cell = (int64_t)ax * F.acc_ny + ay;
+        unsigned long long cnt = acc[cell], s0 = acc[plane + cell], s1 = acc[2 * plane + cell], s2 = acc[3 * plane + cell];
+        long long fx = (long long)acc[4 * plane + cell];
+        for (unsigned int e = 0; e < F.n_events; ++e) {
+            const bin_event ev = static_cast<const bin_event*>(F.events)[e];
+            int cx = ev.bx - 1, cy = ev.by - 1;
+            if ((ev.flags & 1u) && cx == F.off_x + F.nx) cx -= 1;
+            if ((ev.flags & 2u) && cy == F.off_y + F.ny) cy -= 1;
+            if (cx == ax && cy == ay) {
+                cnt += 1;
+                s0 += ev.c0, s1 += ev.c1, s2 += ev.c2;
+                fx += ev.el;
+            }
+        }
+        const double dc = (double)cnt;
+        const unsigned long long sums[3] = {s0, s1, s2};
+        for (int k = 0; k < nch; ++k) {
+            const double m = cnt ? (double)sums[k] / dc : NAN;
+            if (F.mean) F.mean[i * (nch + 1) + k] = m;
+            if (out_img) out_img[i * nch + k] = cnt ? (IMG_T)rint(m) : (IMG_T)0;
+        }
+        if (F.mean) F.mean[i * (nch + 1) + nch] = cnt ? ((double)fx / kFix) / dc : NAN;
+        if (F.mask) F.mask[i] = cnt ? 0 : 1;
+        if (F.out_count) F.out_count[i] = dc;
+    }
+    // leave the whole accumulator grid zeroed (as k_bin_finalize: a thread clears the window cells it read itself, and
+    // cells outside the window, which nobody reads)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / F.nx), c = (int)(i - (int64_t)r * F.nx);
+        const int64_t cell = (int64_t)(F.off_x + c) * F.acc_ny + (F.off_y + F.ny - 1 - r);
+        for (int k = 0; k < nch + 2; ++k) acc[(int64_t)k * plane + cell] = 0;
+    }
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < plane; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cx = (int)(i / F.acc_ny), cy = (int)(i - (int64_t)cx * F.acc_ny);
+        if (cx >= F.off_x && cx < F.off_x + F.nx && cy >= F.off_y && cy < F.off_y + F.ny) continue;
+        for (int k = 0; k < nch + 2; ++k) acc[(int64_t)k * plane + i] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && F.count != nullptr) *F.count = 0;
+}
+
 inline dim3 grid_for(int64_t n) {
     int64_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -388,6 +443,28 @@ int amt_bin_finalize_on(amt_ctx* ctx, hipStream_t stream, uint64_t* acc, int32_t
     else
         hipLaunchKernelGGL((k_bin_finalize<uint16_t>), grid, block, 0, stream, a, acc_nx, acc_ny, off_x, off_y, nx, ny,
                            nchan, mean, static_cast<uint16_t*>(out_img), out_mask, out_count, clear);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_pipe_finish_on(amt_ctx* ctx, hipStream_t stream, const finish_batch& B, int32_t img_dtype) {
+    AMT_REQUIRE(ctx, B.n >= 1 && B.n <= 3, "bad batch");
+    AMT_REQUIRE(ctx, img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
+    int64_t most = 1;
+    for (int i = 0; i < B.n; ++i) {
+        const finish_frame& F = B.f[i];
+        AMT_REQUIRE(ctx, F.acc != nullptr && F.nx > 0 && F.ny > 0, "bad frame");
+        AMT_REQUIRE(ctx, F.off_x >= 0 && F.off_y >= 0 && F.off_x + F.nx <= F.acc_nx && F.off_y + F.ny <= F.acc_ny,
+                    "window outside the accumulator grid");
+        AMT_REQUIRE(ctx, F.n_events == 0 || F.events != nullptr, "events missing");
+        most = std::max<int64_t>(most, (int64_t)F.acc_nx * F.acc_ny);
+    }
+    dim3 grid = grid_for(most);
+    grid.y = (unsigned)B.n;
+    if (img_dtype == 1)
+        hipLaunchKernelGGL((k_pipe_finish<uint8_t>), grid, dim3(kBlock), 0, stream, B);
+    else
+        hipLaunchKernelGGL((k_pipe_finish<uint16_t>), grid, dim3(kBlock), 0, stream, B);
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }

@@ -86,6 +86,25 @@ int amt_bin_finalize_on(amt_ctx* ctx, hipStream_t stream, uint64_t* acc, int32_t
                         int32_t off_y, int32_t nx, int32_t ny, int32_t nchan, int32_t img_dtype, double* mean,
                         void* out_img, uint8_t* out_mask, double* out_count, int clear);
 
+// one frame of a batched finalise step (amt_pipe_finalize_many -> k_pipe_finish)
+struct finish_frame {
+    const void* events;        // bin_event records
+    unsigned int* count;
+    unsigned long long* acc;
+    int acc_nx, acc_ny, off_x, off_y, nx, ny;
+    unsigned int n_events;
+    int pad_;
+    double* mean;
+    void* img;
+    uint8_t* mask;
+    double* out_count;
+};
+struct finish_batch {
+    finish_frame f[3];
+    int n, pad_;
+};
+int amt_pipe_finish_on(amt_ctx* ctx, hipStream_t stream, const finish_batch& B, int32_t img_dtype);
+
 // Returns the device workspace of the context's CURRENT stream, at least `bytes` large (grow-only; reallocation
 // synchronises that stream).  The Python host switches the context between torch streams (frame k is binned on one
 // while frame k+1 is georeferenced on another), so scratch memory is kept per stream.

@@ -510,6 +510,45 @@ int amt_pipe_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_
     return AMT_OK;
 }
 
+int amt_pipe_finalize_many(amt_pipe* const* pipes, int32_t n, double* const* mean, void* const* out_img,
+                           uint8_t* const* out_mask, double* const* out_count) {
+    if (pipes == nullptr || n < 1 || pipes[0] == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipes[0]->ctx;
+    AMT_REQUIRE(ctx, n <= AMT_MAX_BATCH, "at most AMT_PIPE_MAX_BATCH frames per call");
+    AMT_REQUIRE(ctx, mean && out_img && out_mask && out_count, "NULL argument");
+    finish_batch B;
+    std::memset(&B, 0, sizeof(B));
+    B.n = n;
+    for (int i = 0; i < n; ++i) {
+        amt_pipe* pipe = pipes[i];
+        AMT_REQUIRE(ctx, pipe != nullptr && pipe->ctx == ctx && pipe->fin_stream == pipes[0]->fin_stream,
+                    "drivers of one call must share the context");
+        for (int k = 0; k < i; ++k) AMT_REQUIRE(ctx, pipes[k] != pipe, "a driver can hold one frame of a call");
+        AMT_REQUIRE(ctx, pipe->ready, "amt_pipe_wait has not returned status 0 for this frame");
+        AMT_REQUIRE(ctx, pipe->img_dtype == pipes[0]->img_dtype, "frames of one call must share the image type");
+        AMT_REQUIRE(ctx, pipe->n_events <= kEventCapacity, "more on-edge pixels than records");
+        finish_frame& F = B.f[i];
+        F.events = pipe->events;
+        F.count = pipe->event_count;
+        F.acc = reinterpret_cast<unsigned long long*>(pipe->acc);
+        F.acc_nx = pipe->super.nx, F.acc_ny = pipe->super.ny;
+        F.off_x = pipe->off_x, F.off_y = pipe->off_y;
+        F.nx = pipe->exact.nx, F.ny = pipe->exact.ny;
+        F.n_events = (unsigned int)pipe->n_events;
+        F.mean = mean[i], F.img = out_img[i], F.mask = out_mask[i], F.out_count = out_count[i];
+    }
+    // one launch for all of them, on the finalise stream (see amt_pipe_finalize)
+    if (int rc = amt_pipe_finish_on(ctx, pipes[0]->fin_stream, B, pipes[0]->img_dtype)) return rc;
+    for (int i = 0; i < n; ++i) {
+        amt_pipe* pipe = pipes[i];
+        pipe->ready = false;
+        pipe->acc_zero = true;
+        AMT_HIP(ctx, hipEventRecord(pipe->tail_done, pipe->fin_stream));
+        pipe->tail_pending = true;
+    }
+    return AMT_OK;
+}
+
 int amt_pipe_finalize_stream(amt_pipe* pipe, void** stream) {
     if (pipe == nullptr || stream == nullptr) return AMT_EINVAL;
     *stream = reinterpret_cast<void*>(pipe->fin_stream);

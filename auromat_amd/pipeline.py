@@ -25,6 +25,7 @@ Two execution plans give identical results:
 and ``auromat_amd.sequence`` shards over GPUs); the mapping classes give the same results lazily.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -325,8 +326,17 @@ class FramePipeline(object):
         self.ctx.call('amt_bbox_corners', ptr(lat), ptr(lon), ptr(corner), ptr(cmask), fd.height, fd.width, ptr(red))
         return to_host(red)
 
-    def _finalize_fused(self, res, pxPerDeg, keep_on_device):
-        """Crop the superset accumulators to the exact grid laid out by amt_pipe_wait."""
+    def fused_ready(self, pxPerDeg, magnetic):
+        """The amt_pipe_result of the single-pass launch in flight when the driver can finalise it for this resolution
+        and grid (waits for the frame's bounding box), else None (no such launch, or the frame needs the general path)."""
+        if self._fused is None or self._fused['pxPerDeg'] != tuple(pxPerDeg) or self._fused['magnetic'] != bool(magnetic):
+            return None
+        res = self._wait_fused()
+        return res if res.status == 0 else None
+
+    def _fused_outputs(self, res, pxPerDeg):
+        """Grid description and output arrays (one allocation for the finalise stream) of a frame amt_pipe_wait has
+        laid out -> (out dict without the arrays, buf, mean, count, img, mask)."""
         import torch
         ctx, fd = self.ctx, self.fd
         g = res.grid
@@ -357,13 +367,16 @@ class FramePipeline(object):
         count = buf[32 * n:40 * n].view(torch.float64).view(g.ny, g.nx)
         img = buf[40 * n:40 * n + img_bytes].view(img_t).view(g.ny, g.nx, 3)
         mask = buf[40 * n + img_bytes:].view(g.ny, g.nx)
-        self._pcall('amt_pipe_finalize', ptr(mean), ptr(img), ptr(mask), ptr(count))
-        if not (keep_on_device and self.defer_join):
-            self.join()
         buf.record_stream(cur)
         # (BoundingBox.containsDiscontinuity is true for every box with a pole in it, reference mapping.py:200-206)
         out = dict(has_elev=True, grid=grid, contains_pole=pole, contains_discontinuity=wrapped or pole,
                    altitude=self.altitude)
+        return out, buf, mean, count, img, mask
+
+    def _fused_wrap(self, out, buf, mean, count, img, mask, keep_on_device):
+        import torch
+        fd = self.fd
+        n = mask.numel()
         if keep_on_device:
             # `packed`: mean and count as they lie in memory, one after the other — the payload of this frame in the
             # gather's wire format (auromat_amd.sequence.pack_results) without a copy per array
@@ -373,6 +386,32 @@ class FramePipeline(object):
         out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype), mask=to_host(mask).astype(bool),
                    count=to_host(count))
         return out
+
+    def _finalize_fused(self, res, pxPerDeg, keep_on_device):
+        """Crop the superset accumulators to the exact grid laid out by amt_pipe_wait."""
+        out, buf, mean, count, img, mask = self._fused_outputs(res, pxPerDeg)
+        self._pcall('amt_pipe_finalize', ptr(mean), ptr(img), ptr(mask), ptr(count))
+        if not (keep_on_device and self.defer_join):
+            self.join()
+        return self._fused_wrap(out, buf, mean, count, img, mask, keep_on_device)
+
+    @staticmethod
+    def finalize_many(pipes, results, pxPerDeg, keep_on_device):
+        """:meth:`_finalize_fused` for the frames of one launch with ONE call and ONE kernel (amt_pipe_finalize_many):
+        `results` are their amt_pipe_results (all status 0) -> list of result dicts."""
+        n = len(pipes)
+        ctx = pipes[0].ctx
+        outs = [q._fused_outputs(r, pxPerDeg) for q, r in zip(pipes, results)]
+        handles = (C.c_void_p * n)(*[q._pipe() for q in pipes])
+        arr = lambda k: (C.c_void_p * n)(*[o[k].data_ptr() for o in outs])
+        ctx.check(ctx._lib.amt_pipe_finalize_many(handles, n, arr(2), arr(4), arr(5), arr(3)))
+        done = []
+        for q, o in zip(pipes, outs):
+            if not (keep_on_device and q.defer_join):
+                q.join()
+            q.last_plan = 'single-pass'
+            done.append(q._fused_wrap(*o, keep_on_device=keep_on_device))
+        return done
 
     def resample(self, pxPerDeg=10, containsPole=None, magnetic=False, keep_on_device=False):
         """Stages 2 + 3.  magnetic=True bins on the (MLat, SM longitude) grid (resampleMLatMLT)."""
@@ -679,6 +718,34 @@ class SequencePipeline(object):
             self._hint = self._hint_prev = None     # the next frame gets a real pre-pass
         return res
 
+    def _finish_batch(self, k0, n, keep_on_device):
+        """The frames k0 .. k0+n-1 of one launch: those the driver can finalise get ONE finalise call and kernel
+        (amt_pipe_finalize_many), the others (general path, no valid pixel) go one by one through :meth:`_finish`."""
+        import torch
+        nb = len(self.pipes)
+        if not self.single_pass or os.environ.get('AMT_SEQ_FINISH_MANY') == '0':      # (the switch: A/B runs)
+            return [self._finish(k0 + i, keep_on_device) for i in range(n)]
+        qs = [self.pipes[(k0 + i) % nb] for i in range(n)]
+        ready = [q.fused_ready(self.pxPerDeg, self.magnetic) for q in qs]
+        idx = [i for i in range(n) if ready[i] is not None]
+        done = {}
+        if idx:
+            with torch.cuda.stream(self._stream_of(k0)):
+                res = FramePipeline.finalize_many([qs[i] for i in idx], [ready[i] for i in idx], self.pxPerDeg, keep_on_device)
+            done = dict(zip(idx, res))
+        out = []
+        for i in range(n):
+            if i not in done:
+                out.append(self._finish(k0 + i, keep_on_device))
+                continue
+            r = done[i]
+            r['magnetic'] = self.magnetic
+            self.plans.append('single-pass')
+            self._hint_prev = self._hint
+            self._hint = (list(ready[i].bbox), qs[i].params, self._frames_done + k0 + i)
+            out.append(r)
+        return out
+
     def process(self, frames, keep_on_device=True):
         """
         frames: iterable of (wcsHeader | amt_frame_params, cameraPosGCRS, photoTime, image | None[, altitude]);
@@ -723,8 +790,7 @@ class SequencePipeline(object):
                 following = next_batch(k + n_now + len(ahead))
             else:
                 following = []
-            for i in range(n_now):
-                out.append(self._finish(k + i, keep_on_device))
+            out.extend(self._finish_batch(k, n_now, keep_on_device))
             k += n_now
             in_flight, ahead = ahead, following
         # order the caller's stream behind everything this call enqueued

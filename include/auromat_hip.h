@@ -499,6 +499,11 @@ int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result);
  * buffers for result->grid of the preceding amt_pipe_wait (any may be NULL).  The kernel runs on the driver's
  * own stream so that it does not sit between two frames' big kernels on the context's stream. */
 int amt_pipe_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_mask, double* out_count);
+/* The same for the n <= AMT_PIPE_MAX_BATCH frames of one launch (arrays of n pointers each; all four kinds of output
+ * are required here): ONE kernel finalises all of them and folds the on-edge pixels in, instead of two launches per
+ * frame — the host side of the frame loop is what bounds short sequences and the grids-only mode. */
+int amt_pipe_finalize_many(amt_pipe* const* pipes, int32_t n, double* const* mean, void* const* out_img,
+                           uint8_t* const* out_mask, double* const* out_count);
 /* The stream (hipStream_t) amt_pipe_finalize enqueues on.  A host whose allocator is stream ordered (PyTorch's caching
  * allocator, hipMallocAsync pools) must allocate the four output buffers FOR THIS STREAM: memory handed out for another
  * stream may still be in use by work queued there (the driver's finalise kernel does not wait for the context's
