@@ -493,6 +493,23 @@ def _close(a, b):
     return True
 
 
+_STREAMS = {}
+
+
+def _shared_stream(device, role):
+    """The stream of a given role (main / alt / bin / copy) on `device`, shared by every SequencePipeline of the process.
+    A GPU serves a process through a handful of hardware queues and HIP maps streams onto them in turn: a pipeline that
+    made streams of its own could end up with its main stream on the queue of the driver's helper streams, whose
+    kernels WAIT for events — the big kernels then queue behind those waits (measured: the bench variant that came
+    second paid 58 us per frame for it, whatever it computed).  With one set of streams per process the mapping is the
+    same for every pipeline."""
+    import torch
+    key = (str(device), role)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=device)
+    return _STREAMS[key]
+
+
 def _steady(a, b, c, n_ab, n_bc):
     """Frames a, b (n_ab frames apart) and c (n_bc frames after b): same frame size, shell and camera model as `_close`
     asks, c within 400 km of b, and the camera has moved from b to c as it did from a to b (20 % + 5 km)?"""
@@ -573,15 +590,15 @@ class SequencePipeline(object):
                 q.fd.img = self.pipes[0].fd.img
         for q in self.pipes:
             q.defer_join = True             # joined once per process() call
-        self.s_main = torch.cuda.Stream(device=self.ctx.device)
+        self.s_main = _shared_stream(self.ctx.device, 'main')
         # launch_streams=2 (single-pass plan): the batches alternate between two streams.  A buffer set is used by every
         # second batch, i.e. always on the same stream, so every ordering between its users stays stream order; what
         # falls away is the order between CONSECUTIVE big kernels, which do not depend on each other: the next one
         # starts while the last waves of the previous one drain.
-        self.s_alt = torch.cuda.Stream(device=self.ctx.device) if (launch_streams == 2 and self.single_pass) else None
+        self.s_alt = _shared_stream(self.ctx.device, 'alt') if (launch_streams == 2 and self.single_pass) else None
         # two-pass plan: the binning kernel is memory bound and the ray casting FP64 bound, so frame k's binning
         # runs beside frame k+1's ray casting on a second stream
-        self.s_bin = torch.cuda.Stream(device=self.ctx.device) if (bin_stream and not self.single_pass) else self.s_main
+        self.s_bin = _shared_stream(self.ctx.device, 'bin') if (bin_stream and not self.single_pass) else self.s_main
         self._geo_done = [torch.cuda.Event() for _ in self.pipes]
         self._bin_done = [None for _ in self.pipes]
         # per-frame images: uploaded on a copy stream of their own (created on first use: every extra stream competes
@@ -663,7 +680,7 @@ class SequencePipeline(object):
                     self._img_busy[slot] = []
                     continue
                 if self.s_copy is None:
-                    self.s_copy = torch.cuda.Stream(device=self.ctx.device)
+                    self.s_copy = _shared_stream(self.ctx.device, 'copy')
                 with torch.cuda.stream(self.s_copy):
                     for busy in self._img_busy[slot]:
                         self.s_copy.wait_event(busy)                 # the buffer's previous image is still being read

@@ -469,6 +469,9 @@ def main(argv=None):
             },
         }
         del run, seq, results
+        import gc
+        gc.collect()        # the pipeline's drivers are freed HERE (hipFree synchronises the device), not whenever the
+                            # cycle collector gets to them in the middle of a later timed region
         if world == 1 and not args.no_variants and shared is None and not (args.exact or args.magnetic or args.upload or not fused):
             # the other configurations of SURVEY 8d on the record of the same run: short runs of the same loop
             torch.cuda.empty_cache()
@@ -476,8 +479,10 @@ def main(argv=None):
             nv_w, nv_k = 9, 96
             from auromat_amd.synthetic import pole_frame
             p_hdr, p_cam, p_t = pole_frame(WIDTH, HEIGHT)
-            for name, kw in (('exact_centres', dict(fast=False, magnetic=False)),
-                             ('configs3_magnetic_3_shells', dict(fast=True, magnetic=True)),
+            # (configs[3] first: its nine arrays per buffer are the largest allocations of the run, and it measured up to
+            # 8 % slower per kernel when it came after the other variants' allocate / free cycles)
+            for name, kw in (('configs3_magnetic_3_shells', dict(fast=True, magnetic=True)),
+                             ('exact_centres', dict(fast=False, magnetic=False)),
                              # NOT the headline workload: the resampled grids only, no per-pixel coordinate arrays
                              # written (what a convert run needs; SequencePipeline(keep_coordinates=False))
                              ('grids_only_no_coordinate_arrays', dict(fast=True, magnetic=False, keep=False)),
@@ -504,6 +509,7 @@ def main(argv=None):
                     # SURVEY 8d config 4 counts 40 Nc + 54 Np per shell (directions read); the kernel generates them
                     variants[name]['frac_contract_3387MB_for_3_shells'] = frac(ab['mag_shell'], v['georef_ms'])
                 del v
+                gc.collect()
                 torch.cuda.empty_cache()
             out['variants'] = variants
         if world == 1 and args.cpu_rows > 0:
