@@ -506,6 +506,9 @@ def _shared_stream(device, role):
     import torch
     key = (str(device), role)
     if key not in _STREAMS:
+        if not _STREAMS:
+            # AMT_STREAM_SHIFT=n (A/B runs): n streams made first, which moves the ones that follow to other hardware queues
+            _STREAMS[('shift', '')] = [torch.cuda.Stream(device=device) for _ in range(int(os.environ.get('AMT_STREAM_SHIFT', '0')))]
         _STREAMS[key] = torch.cuda.Stream(device=device)
     return _STREAMS[key]
 
