@@ -179,6 +179,22 @@ def measured_copy_gbs(device):
     return 10 * 2 * n * 8 / (time.perf_counter() - t0) / 1e9
 
 
+def measured_fill_gbs(device):
+    """Write-only rate of this GPU (torch.fill_ of five arrays of the frame's size, the kernel's own 480 MB of output):
+    what a kernel that only writes can reach here — the dominant kernel's traffic is 86 % writes.  Outside the timed region."""
+    import torch
+    bufs = [torch.empty((HEIGHT + 1) * (WIDTH + 1), dtype=torch.float64, device=device) for _ in range(5)]
+    for b in bufs:
+        b.fill_(1.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        for b in bufs:
+            b.fill_(1.0)
+    torch.cuda.synchronize()
+    return 10 * sum(b.numel() for b in bufs) * 8 / (time.perf_counter() - t0) / 1e9
+
+
 def cpu_model():
     try:
         with open('/proc/cpuinfo') as fp:
@@ -382,6 +398,7 @@ def main(argv=None):
         georef_ms, bin_ms = run['georef_ms'], run['bin_ms']
         npx = WIDTH * HEIGHT
         copy_gbs = measured_copy_gbs(device)
+        fill_gbs = measured_fill_gbs(device)
         ab = algorithmic_bytes(WIDTH, HEIGHT)
         info = ctx.device_info()
         res = results[-1]
@@ -444,7 +461,7 @@ def main(argv=None):
             # how busy the chip is.
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'measured_copy_GBs': copy_gbs, 'fp64_vector_peak_TFLOPs': 78.6,
+                         'measured_copy_GBs': copy_gbs, 'measured_fill_GBs': fill_gbs, 'fp64_vector_peak_TFLOPs': 78.6,
                          # one launch covers `frames_per_launch` frames: bytes, traffic and duration are per launch
                          'frames_per_launch': fpl,
                          # NOT measured in this run: PMC counters of an earlier rocprofv3 pass of the same kernel
