@@ -211,3 +211,24 @@ def test_real_frame_on_the_mlat_mlt_grid():
         assert pipe.last_plan == ('single-pass' if fuse else 'two-pass')
         assert np.array_equal(res['lat'], z['out_lat']) and np.array_equal(res['lon_c'], z['out_lon_c'])
         check(res['img'], res['mask'], res['mean'], z)
+
+
+@pytest.mark.gpu
+def test_folder_provider_on_the_references_resources():
+    """SpacecraftMappingProvider over the folder with the test frame (image + .wcs, as the reference's ISS provider leaves
+    them), wrapped like `auromat-convert` wraps its provider: masked by elevation, resampled — the reference's grid."""
+    from auromat_amd.mapping.mapping import MaskByElevationProvider
+    from auromat_amd.mapping.spacecraft import SpacecraftMappingProvider
+    from auromat_amd.resample import resample
+    z = load_golden('real_frame_iss030.npz')
+    prov = SpacecraftMappingProvider(os.path.join(GOLDEN, 'resources'), fastCenterCalculation=True)
+    assert len(prov) == 1 and prov.imageFileExtension == 'jpg' and prov.ids == ['ISS030-E-102170_dc']
+    t0, t1 = prov.range
+    assert t0 == t1 and t0.isoformat() == str(z['time_iso'])          # the shifted photo time
+    masked = MaskByElevationProvider(prov, 10)
+    m = masked.get(t0)
+    assert m.identifier == 'ISS030-E-102170_dc'
+    assert int((~ma.getmaskarray(m.latsCenter)).sum()) == int(z['n_valid'])
+    r = resample(m, pxPerDeg=10)
+    check(r.img.data, ma.getmaskarray(r.img)[..., 0], None, z)
+    assert [q.identifier for q in masked.getSequence()] == ['ISS030-E-102170_dc']
