@@ -36,14 +36,38 @@ def build(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     tmp = LIB_PATH + '.tmp.%d' % os.getpid()
-    cmd = [HIPCC] + FLAGS + ['-o', tmp] + sources()
-    if verbose:
-        print(' '.join(cmd))
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
-    if res.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise RuntimeError('hipcc failed:\n' + res.stdout)
+    # every source to an object of its own, a few at a time (the row kernel's file takes most of the time, the others
+    # compile beside it), then one link
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = tempfile.mkdtemp(prefix='amt_build_')
+    compile_flags = [f for f in FLAGS if f != '-shared' and not f.startswith('-Wl,')]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + '.o')
+        cmd = [HIPCC] + compile_flags + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+        return obj, res
+
+    try:
+        with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+            done = list(pool.map(compile_one, sources()))
+        for obj, res in done:
+            if res.returncode != 0:
+                raise RuntimeError('hipcc failed:\n' + res.stdout)
+        cmd = [HIPCC] + FLAGS + ['-o', tmp] + [obj for obj, _ in done]
+        if verbose:
+            print(' '.join(cmd))
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+        if res.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError('hipcc (link) failed:\n' + res.stdout)
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
