@@ -206,7 +206,7 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(sample_rows, frames=4):
+def cpu_baseline(sample_rows, frames=4, parity=None):
     """Oracle (NumPy restatement of the reference) on the same workload, 1 core: `frames` frames of the synthetic
     sequence (rows [0, sample_rows) of each), about 12 s of CPU work at the full frame height."""
     from oracle import ref_numpy as O
@@ -226,18 +226,55 @@ def cpu_baseline(sample_rows, frames=4):
         bbox, disc = O.bbox_of_corners(g['lat'], g['lon'], corner_mask)
         data = np.dstack((img.astype(np.float64), g['elev']))
         data[center_mask] = np.nan
-        O.resample_mean(np.where(center_mask, np.nan, g['lat_c']), np.where(center_mask, np.nan, g['lon_c']), ALTITUDE,
-                        data, None, bbox, (PPD, PPD), disc, False)
+        res = O.resample_mean(np.where(center_mask, np.nan, g['lat_c']), np.where(center_mask, np.nan, g['lon_c']),
+                              ALTITUDE, data, None, bbox, (PPD, PPD), disc, False)
         t2 = time.time()
         t_geo += t1 - t0
         t_res += t2 - t1
-        del g, data
+        if k == 0 and parity is not None:
+            parity.update(check_against_oracle(hdr, cam, t, img, g, res))         # the oracle as the checker (untimed)
+        del g, data, res
     npx = WIDTH * sample_rows * frames
     return dict(value=npx / 1e6 / (t_geo + t_res), unit='Mpixels/s', cores=1, kind='port', cpu=cpu_model(),
                 host_cores=os.cpu_count(),
                 sample='%d frames of the sequence, rows 0..%d of %dx%d each (%.1f Mpx): georef %.1f s + mask/resample '
                        '%.1f s, NumPy, 1 thread (the reference is single-threaded NumPy; one process per frame would '
                        'scale it by the core count at best)' % (frames, sample_rows, WIDTH, HEIGHT, npx / 1e6, t_geo, t_res))
+
+
+def check_against_oracle(hdr, cam, t, img, g, res):
+    """BASELINE.json's second figure, max |dlat, dlon| vs ref: the HIP path (single-pass plan) on the frame the CPU
+    baseline has just computed with the oracle — coordinate arrays, NaN patterns and the resampled grid."""
+    from auromat_amd.pipeline import FramePipeline
+    h = int(hdr['IMAGEH'])
+    pipe = FramePipeline(WIDTH, h)
+    got = pipe.run(hdr, ALTITUDE, cam, t, img=img, fast=True, min_elevation=MIN_ELEV, pxPerDeg=PPD, fuse=True)
+    arrays = pipe.host_arrays()
+    out = {'frame': [WIDTH, h], 'plan': pipe.last_plan, 'checker': 'oracle/ref_numpy.py (NumPy restatement of the reference)'}
+    worst = 0.0
+    same_nan = True
+    for name in ('lat', 'lon', 'lat_c', 'lon_c'):
+        a, b = arrays[name], g[name]
+        same_nan = same_nan and bool(np.array_equal(np.isnan(a), np.isnan(b)))
+        d = np.abs(a - b)
+        if name.startswith('lon'):
+            d = np.minimum(d, 360.0 - d)
+        worst = max(worst, float(np.nanmax(d)))
+    out['max_abs_dlat_dlon_deg'] = worst
+    out['max_abs_delevation_deg'] = float(np.nanmax(np.abs(arrays['elev'] - g['elev'])))
+    out['same_nan_pattern'] = same_nan
+    want = res['data']
+    mask = np.isnan(want[..., 0])
+    same_shape = got['mean'].shape == want.shape
+    out['grid'] = list(want.shape)
+    out['grid_mask_cells_differing'] = int((got['mask'] != mask).sum()) if same_shape else -1
+    ok = ~mask & ~got['mask'] if same_shape else None
+    out['grid_rgb_cells_differing'] = int((np.abs(got['mean'][..., :3][ok] - want[..., :3][ok]).max(axis=-1) > 0).sum()) if same_shape else -1
+    out['tolerance_deg'] = 1e-6
+    out['ok'] = bool(same_nan and worst <= 1e-6 and out['max_abs_delevation_deg'] <= 1e-6 and same_shape and
+                     out['grid_mask_cells_differing'] == 0 and out['grid_rgb_cells_differing'] == 0)
+    del pipe
+    return out
 
 
 def resident_images(device, n, first_seed):
@@ -530,7 +567,10 @@ def main(argv=None):
                 torch.cuda.empty_cache()
             out['variants'] = variants
         if world == 1 and args.cpu_rows > 0:
-            out['cpu_baseline'] = cpu_baseline(min(args.cpu_rows, HEIGHT))
+            parity = {}
+            out['cpu_baseline'] = cpu_baseline(min(args.cpu_rows, HEIGHT), parity=parity)
+            # max |dlat, dlon| vs ref (BASELINE.json's metric names it beside the throughput)
+            out['parity'] = parity
         else:
             out['cpu_baseline'] = None
         # the JSON line is the LAST thing on stdout: flush what C libraries have buffered there (RCCL's banner),
