@@ -13,6 +13,7 @@ Note that some functions depend on the IGRF model whose parameters are defined i
 """
 from __future__ import division
 
+import functools
 import math
 from datetime import datetime
 
@@ -416,6 +417,7 @@ def epsilon(et):
     return 23.439 - 0.013 * T0(et)
 
 
+@functools.lru_cache(maxsize=16)     # (several matrices of one frame share it; callers do not modify the result)
 def mat_P(et):
     """J2000 to GEI matrix (reference transform.py:568-581)."""
     t0 = T0(et)
@@ -425,18 +427,21 @@ def mat_P(et):
     return mat[:3, :3]
 
 
+@functools.lru_cache(maxsize=16)     # (several matrices of one frame share it; callers do not modify the result)
 def mat_T1(et):
     """GEI to GEO matrix (reference transform.py:583-590)."""
     theta = 100.461 + 36000.770 * T0(et) + 360.0 * (H(et) / 24.0)
     return rotation_matrix(np.deg2rad(theta), Z)[:3, :3]
 
 
+@functools.lru_cache(maxsize=16)     # (several matrices of one frame share it; callers do not modify the result)
 def mat_T2(et):
     """GEI to GSE matrix (reference transform.py:592-599)."""
     mat = np.dot(rotation_matrix(np.deg2rad(lambda0(et)), Z), rotation_matrix(np.deg2rad(epsilon(et)), X))
     return mat[:3, :3]
 
 
+@functools.lru_cache(maxsize=16)     # (several matrices of one frame share it; callers do not modify the result)
 def vec_Qe(et):
     """Dipole axis in GSE (reference transform.py:601-620)."""
     lat, lon = mag_lat(et), mag_lon(et)
