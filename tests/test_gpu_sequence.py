@@ -265,3 +265,20 @@ def test_box_hints_are_extrapolated_at_the_cadence_of_real_sequences():
             for key in KEYS:
                 x = a[key].view(b[key].dtype) if key == 'img' else a[key].astype(b[key].dtype)
                 assert np.array_equal(x, b[key], equal_nan=True), key
+
+
+def test_two_launch_streams_give_the_same_grids():
+    """launch_streams=2 (batches alternate between two streams; a buffer set stays on the stream of its batch parity)."""
+    from auromat_amd.pipeline import SequencePipeline
+    w, h, n = 530, 354, 20
+    frames = build_sequence(w, h, n, every_pole=6, empty_at=(7,))
+    want = [None if r is None else host(r) for r in SequencePipeline(w, h, pxPerDeg=6).process(frames)]
+    for batch in (3, 2):
+        seq = SequencePipeline(w, h, pxPerDeg=6, batch=batch, launch_streams=2)
+        for rep in range(2):
+            got = [None if r is None else host(r) for r in seq.process(frames)]
+            for a, b in zip(got, want):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    for key in KEYS:
+                        assert np.array_equal(a[key], b[key], equal_nan=True), (batch, rep, key)
