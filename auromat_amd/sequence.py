@@ -107,8 +107,20 @@ class Gathered(object):
     """
 
     def __init__(self, bufs, sizes, max_frames):
-        self.bufs, self.sizes, self.max_frames = bufs, sizes, max_frames
+        self.bufs, self._sizes, self.max_frames = bufs, sizes, max_frames
         self.failed = []            # indices of the frames without any valid pixel (filled by unpack)
+
+    @property
+    def sizes(self):
+        if self._sizes is None:
+            # gathered with an agreed capacity: every buffer ends with its own (frames, payload length)
+            import torch
+            tail = torch.stack([b[-2:] for b in self.bufs]).cpu().numpy()
+            if (tail[:, 0] < 0).any():
+                raise ValueError('gather_device: the grids of rank(s) %s did not fit the agreed capacity'
+                                 % np.nonzero(tail[:, 0] < 0)[0].tolist())
+            self._sizes = tail.astype(np.int64)
+        return self._sizes
 
     @property
     def n_frames(self):
@@ -125,16 +137,58 @@ class Gathered(object):
         return sorted(out, key=lambda f: f['index'])
 
 
-def gather_device(results, indices, device, dst=0, group=None):
+def agree_capacity(results, indices, device, margin=1.25, group=None):
+    """
+    (max_frames, max_payload) over all ranks for results like these, the payload with `margin`: what
+    :func:`gather_device` takes as `capacity` to gather later results of the same kind with ONE collective.  One
+    all_gather of two numbers and a host synchronisation, on every rank.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n_payload = 0
+    for res in results:
+        if res is not None:
+            ny, nx, nc = res['mean'].shape
+            n_payload += ny * nx * (nc + 1)
+    sizes = torch.tensor([len(results), n_payload], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    all_sizes = torch.stack(all_sizes).cpu().numpy()
+    return int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max() * margin) + 1
+
+
+def gather_device(results, indices, device, dst=0, group=None, capacity=None):
     """
     Gather every rank's per-frame grids on rank `dst`, device to device.  Two collectives: an all_gather of the
     (frames, payload length) pair, then one gather of [descriptors | payload] padded to the longest.
+    With `capacity` = (max_frames, max_payload) agreed before (:func:`agree_capacity`; the same on every rank) it is
+    ONE collective and no host synchronisation: every rank sends a buffer of that size which ends with its own
+    (frames, payload length).  A rank whose grids do not fit sends (-1, 0) there and nothing else; the destination
+    raises ValueError when it reads the sizes (no rank is left waiting in a collective).
     Returns a :class:`Gathered` on `dst`, None elsewhere.
     """
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     descs, payload = pack_results(results, indices, device)
+    if capacity is not None:
+        max_frames, max_payload = capacity
+        n = max_frames * DESC_LEN + max_payload
+        buf = torch.zeros(n + 2, dtype=torch.float64, device=device)
+        if descs.shape[0] <= max_frames and payload.numel() <= max_payload:
+            buf[:descs.numel()] = descs.reshape(-1)
+            buf[max_frames * DESC_LEN:max_frames * DESC_LEN + payload.numel()] = payload
+            tail = [float(descs.shape[0]), float(payload.numel())]
+        else:
+            tail = [-1.0, 0.0]
+        buf[n:].copy_(torch.tensor(tail, dtype=torch.float64), non_blocking=True)
+        if rank == dst:
+            bufs = [torch.empty_like(buf) for _ in range(world)]
+            dist.gather(buf, bufs, dst=dst, group=group)
+            return Gathered(bufs, None, max_frames)
+        dist.gather(buf, None, dst=dst, group=group)
+        return None
     sizes = torch.tensor([descs.shape[0], payload.numel()], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)

@@ -373,7 +373,7 @@ def main(argv=None):
         init_dist()
 
     from auromat_amd._native import Context
-    from auromat_amd.sequence import gather_device
+    from auromat_amd.sequence import agree_capacity, gather_device
     from auromat_amd.synthetic import sequence_frame, frame_image
 
     ctx = Context.current()
@@ -405,17 +405,22 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    gather_state = {}
+
     def gather(results, warm):
         # device-to-device over xGMI; rank 0 unpacks to the host after the timed region.  The first call's costs
         # (RCCL channels, allocations) belong to the warm-up.
         if not use_dist:
             return None
+        base = first + (0 if warm else args.warmup)
         if warm:
             # as many frames as the timed gather will carry, so that its buffers (payload, padded send and receive
-            # buffers) come out of the caching allocator instead of hipMalloc inside the timed region
+            # buffers) come out of the caching allocator instead of hipMalloc inside the timed region; and the ranks
+            # agree on a capacity (the longest payload + 25 %) here, so that the timed gather is ONE collective
+            # without a size exchange and its host synchronisation
             results = (results * (args.steps // max(len(results), 1) + 1))[:args.steps]
-        base = first + (0 if warm else args.warmup)
-        return gather_device(results, [base + k for k in range(len(results))], device)
+            gather_state['capacity'] = agree_capacity(results, [base + k for k in range(len(results))], device)
+        return gather_device(results, [base + k for k in range(len(results))], device, capacity=gather_state.get('capacity'))
 
     run = timed_run(make_frames(total, args.magnetic), args.warmup, args.steps, fast, args.plan, args.magnetic,
                     args.batch, args.streams, not args.no_hints, shared, own_buffers=args.upload, fence=fence,

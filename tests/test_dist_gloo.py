@@ -69,6 +69,22 @@ def _worker(rank, world, port, n_frames, out_dir):
         open(os.path.join(out_dir, 'ok'), 'w').write('ok')
     else:
         assert got is None
+    # the same with ONE collective: a capacity agreed beforehand (here from these very results, 25 % margin) ...
+    from auromat_amd.sequence import agree_capacity
+    cap = agree_capacity(results, mine, torch.device('cpu'))
+    assert cap[0] == max(len(shard(n_frames, r, world)) for r in range(world))
+    g2 = gather_device(results, mine, torch.device('cpu'), capacity=cap)
+    if rank == 0:
+        again = g2.unpack()
+        assert g2.n_frames == n_frames and [f['index'] for f in again] == [f['index'] for f in got] and g2.failed == g.failed
+        for a, b in zip(again, got):
+            np.testing.assert_array_equal(a['mean'], b['mean'])
+            np.testing.assert_array_equal(a['count'], b['count'])
+    # ... and a capacity that is too small: nobody hangs, the destination is told
+    g3 = gather_device(results, mine, torch.device('cpu'), capacity=(cap[0], 10))
+    if rank == 0 and n_frames > 1:
+        with pytest.raises(ValueError, match='did not fit'):
+            g3.unpack()
     dist.barrier()
     dist.destroy_process_group()
 
