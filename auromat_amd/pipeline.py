@@ -98,6 +98,9 @@ class FramePipeline(object):
         # current stream is ordered behind them at once.  A pipelined caller sets defer_join and calls join()
         # once before it consumes the results, which keeps the stream of big kernels free of wait packets.
         self.defer_join = False
+        # the stream that will consume keep_on_device results when it is not the one current at finalisation (a pipelined
+        # caller sets it: the outputs are then recorded for it once, at allocation, instead of array by array afterwards)
+        self.consumer_stream = None
         self.params = None
         self.altitude = None
         self.min_elevation = None
@@ -368,6 +371,8 @@ class FramePipeline(object):
         img = buf[40 * n:40 * n + img_bytes].view(img_t).view(g.ny, g.nx, 3)
         mask = buf[40 * n + img_bytes:].view(g.ny, g.nx)
         buf.record_stream(cur)
+        if self.consumer_stream is not None and self.consumer_stream != cur:
+            buf.record_stream(self.consumer_stream)
         # (BoundingBox.containsDiscontinuity is true for every box with a pole in it, reference mapping.py:200-206)
         out = dict(has_elev=True, grid=grid, contains_pole=pole, contains_discontinuity=wrapped or pole,
                    altitude=self.altitude)
@@ -784,6 +789,9 @@ class SequencePipeline(object):
         out = []
         it = iter(frames)
         B = self.batch
+        caller = torch.cuda.current_stream(self.ctx.device)
+        for q in self.pipes:
+            q.consumer_stream = caller
 
         def next_batch(k0, size=B):
             """Prepare up to `size` frames starting at index k0 -> list (empty at the end of the sequence)."""
@@ -817,7 +825,7 @@ class SequencePipeline(object):
         with torch.cuda.stream(self.s_main):
             for q in self.pipes:
                 q.join()
-        cur = torch.cuda.current_stream(self.ctx.device)
+        cur = caller
         cur.wait_stream(self.s_main)
         if self.s_alt is not None:
             cur.wait_stream(self.s_alt)
@@ -825,9 +833,13 @@ class SequencePipeline(object):
             cur.wait_stream(self.s_bin)
         if keep_on_device:
             # the result tensors were allocated on the pipeline's streams: tell the caching allocator that the caller's
-            # stream uses them too, so that their memory is not handed out again while the caller still reads it
+            # stream uses them too, so that their memory is not handed out again while the caller still reads it.
+            # (Single-pass results are ONE allocation, recorded for the caller's stream when it was made — `packed` is
+            # their mark; a call per array here cost 1-2 us each after the last kernel, where nothing hides it.)
             for res in out:
-                for v in (res or {}).values():
+                if res is None or 'packed' in res:
+                    continue
+                for v in res.values():
                     if isinstance(v, torch.Tensor) and v.is_cuda:
                         v.record_stream(cur)
         self._frames_done += len(out)
