@@ -337,9 +337,32 @@ class FramePipeline(object):
         res = self._wait_fused()
         return res if res.status == 0 else None
 
-    def _fused_outputs(self, res, pxPerDeg):
-        """Grid description and output arrays (one allocation for the finalise stream) of a frame amt_pipe_wait has
-        laid out -> (out dict without the arrays, buf, mean, count, img, mask)."""
+    def _fused_nbytes(self, res):
+        """Bytes of one frame's outputs (mean | count | image | mask), padded to 256."""
+        n = res.grid.ny * res.grid.nx
+        return (40 * n + 3 * n * (2 if self.fd.img_dtype_code == 2 else 1) + n + 255) & ~255
+
+    def _fused_alloc(self, nbytes, cur):
+        """Output memory for the finalise stream -> (bytes, the same as float64, the same as the image's type)."""
+        # The finalise kernel runs on the driver's own stream and does not wait for the current one.  The caching
+        # allocator hands out memory per stream: a block freed on the current stream (say the accumulators of a
+        # two-pass frame before this one) may go out again at once while kernels queued there still use it — fine
+        # for consumers on that stream, fatal for a kernel on another one that writes right away (found by
+        # tools/fuzz_sequence.py: frames that fell back to the two-pass plan inside a single-pass sequence came out
+        # wrong now and then).  So the outputs are allocated FOR the finalise stream, and the streams that read them
+        # are recorded on them.
+        import torch
+        with torch.cuda.stream(self._finalize_stream()):
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.ctx.device)
+        buf.record_stream(cur)
+        if self.consumer_stream is not None and self.consumer_stream != cur:
+            buf.record_stream(self.consumer_stream)
+        return buf, buf.view(torch.float64), (buf.view(torch.int16) if self.fd.img_dtype_code == 2 else buf)
+
+    def _fused_outputs(self, res, pxPerDeg, mem=None, offset=0):
+        """Grid description and output arrays (one allocation for the finalise stream; `mem` = a _fused_alloc shared by
+        the frames of a launch, this frame's part starting at byte `offset`) of a frame amt_pipe_wait has laid out ->
+        (out dict without the arrays, packed, mean, count, img, mask)."""
         import torch
         ctx, fd = self.ctx, self.fd
         g = res.grid
@@ -352,40 +375,34 @@ class FramePipeline(object):
         else:
             box = (b[0], b[1], b[2], b[3])
         grid = _GridView(g, pxPerDeg, box)
-        # The finalise kernel runs on the driver's own stream and does not wait for the current one.  The caching
-        # allocator hands out memory per stream: a block freed on the current stream (say the accumulators of a
-        # two-pass frame before this one) may go out again at once while kernels queued there still use it — fine
-        # for consumers on that stream, fatal for a kernel on another one that writes right away (found by
-        # tools/fuzz_sequence.py: frames that fell back to the two-pass plan inside a single-pass sequence came out
-        # wrong now and then).  So the outputs are allocated FOR the finalise stream, and the streams that read them
-        # are recorded on them.
-        cur = torch.cuda.current_stream(ctx.device)
+        if mem is None:
+            mem = self._fused_alloc(self._fused_nbytes(res), torch.cuda.current_stream(ctx.device))
+        buf, b64, bimg = mem
         # (one allocation for the four arrays: mean | count | image | mask)
         n = g.ny * g.nx
-        img_t = torch.uint8 if fd.img_dtype_code != 2 else torch.int16
-        img_bytes = 3 * n * (2 if fd.img_dtype_code == 2 else 1)
-        with torch.cuda.stream(self._finalize_stream()):
-            buf = torch.empty(40 * n + img_bytes + n, dtype=torch.uint8, device=ctx.device)
-        mean = buf[:32 * n].view(torch.float64).view(g.ny, g.nx, 4)
-        count = buf[32 * n:40 * n].view(torch.float64).view(g.ny, g.nx)
-        img = buf[40 * n:40 * n + img_bytes].view(img_t).view(g.ny, g.nx, 3)
-        mask = buf[40 * n + img_bytes:].view(g.ny, g.nx)
-        buf.record_stream(cur)
-        if self.consumer_stream is not None and self.consumer_stream != cur:
-            buf.record_stream(self.consumer_stream)
+        o8 = offset // 8
+        packed = b64[o8:o8 + 5 * n]
+        mean = b64[o8:o8 + 4 * n].view(g.ny, g.nx, 4)
+        count = b64[o8 + 4 * n:o8 + 5 * n].view(g.ny, g.nx)
+        if fd.img_dtype_code == 2:
+            o16 = offset // 2 + 20 * n
+            img = bimg[o16:o16 + 3 * n].view(g.ny, g.nx, 3)
+            om = offset + 46 * n
+        else:
+            img = buf[offset + 40 * n:offset + 43 * n].view(g.ny, g.nx, 3)
+            om = offset + 43 * n
+        mask = buf[om:om + n].view(g.ny, g.nx)
         # (BoundingBox.containsDiscontinuity is true for every box with a pole in it, reference mapping.py:200-206)
         out = dict(has_elev=True, grid=grid, contains_pole=pole, contains_discontinuity=wrapped or pole,
                    altitude=self.altitude)
-        return out, buf, mean, count, img, mask
+        return out, packed, mean, count, img, mask
 
-    def _fused_wrap(self, out, buf, mean, count, img, mask, keep_on_device):
-        import torch
+    def _fused_wrap(self, out, packed, mean, count, img, mask, keep_on_device):
         fd = self.fd
-        n = mask.numel()
         if keep_on_device:
             # `packed`: mean and count as they lie in memory, one after the other — the payload of this frame in the
             # gather's wire format (auromat_amd.sequence.pack_results) without a copy per array
-            out.update(mean=mean, img=img, mask=mask, count=count, packed=buf[:40 * n].view(torch.float64))
+            out.update(mean=mean, img=img, mask=mask, count=count, packed=packed)
             return out
         out.update(grid_coordinates(out))
         out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype), mask=to_host(mask).astype(bool),
@@ -394,19 +411,29 @@ class FramePipeline(object):
 
     def _finalize_fused(self, res, pxPerDeg, keep_on_device):
         """Crop the superset accumulators to the exact grid laid out by amt_pipe_wait."""
-        out, buf, mean, count, img, mask = self._fused_outputs(res, pxPerDeg)
+        out, packed, mean, count, img, mask = self._fused_outputs(res, pxPerDeg)
         self._pcall('amt_pipe_finalize', ptr(mean), ptr(img), ptr(mask), ptr(count))
         if not (keep_on_device and self.defer_join):
             self.join()
-        return self._fused_wrap(out, buf, mean, count, img, mask, keep_on_device)
+        return self._fused_wrap(out, packed, mean, count, img, mask, keep_on_device)
 
     @staticmethod
     def finalize_many(pipes, results, pxPerDeg, keep_on_device):
         """:meth:`_finalize_fused` for the frames of one launch with ONE call and ONE kernel (amt_pipe_finalize_many):
         `results` are their amt_pipe_results (all status 0) -> list of result dicts."""
+        import torch
         n = len(pipes)
         ctx = pipes[0].ctx
-        outs = [q._fused_outputs(r, pxPerDeg) for q, r in zip(pipes, results)]
+        # the outputs of the launch's frames are ONE allocation when their drivers finalise on the same stream (they do:
+        # the tail stream belongs to the context), each frame's part 256-byte aligned
+        sizes = [q._fused_nbytes(r) for q, r in zip(pipes, results)]
+        fin = pipes[0]._finalize_stream().cuda_stream
+        if all(q._finalize_stream().cuda_stream == fin and q.consumer_stream == pipes[0].consumer_stream for q in pipes):
+            mem = pipes[0]._fused_alloc(sum(sizes), torch.cuda.current_stream(ctx.device))
+            offs = [sum(sizes[:i]) for i in range(n)]
+            outs = [q._fused_outputs(r, pxPerDeg, mem, o) for q, r, o in zip(pipes, results, offs)]
+        else:
+            outs = [q._fused_outputs(r, pxPerDeg) for q, r in zip(pipes, results)]
         handles = (C.c_void_p * n)(*[q._pipe() for q in pipes])
         arr = lambda k: (C.c_void_p * n)(*[o[k].data_ptr() for o in outs])
         ctx.check(ctx._lib.amt_pipe_finalize_many(handles, n, arr(2), arr(4), arr(5), arr(3)))
