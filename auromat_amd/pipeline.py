@@ -712,7 +712,6 @@ class SequencePipeline(object):
                     continue
                 if q.is_resident_image(img):
                     q.use_image(img)                                 # in place: nothing is overwritten
-                    self._img_busy[slot] = []
                     continue
                 if self.s_copy is None:
                     self.s_copy = _shared_stream(self.ctx.device, 'copy')
@@ -727,10 +726,15 @@ class SequencePipeline(object):
             if self.single_pass:
                 FramePipeline.georef_many(qs, [pr[0] for pr in prepared], [pr[4] for pr in prepared],
                                           self.min_elevation, self.pxPerDeg, self.magnetic)
-                done = torch.cuda.Event()
-                done.record(s_main)
-                for i in range(len(prepared)):
-                    self._img_busy[(k0 + i) % nb].append(done)
+                # a later upload into a buffer of the pipeline's own must wait until this launch has read it; frames that
+                # read the caller's device-resident images need no event (each one is a packet on the stream of big
+                # kernels: 5 us between two launches)
+                own = [i for i, q in enumerate(qs) if q.fd.img is q._img_own]
+                if own:
+                    done = torch.cuda.Event()
+                    done.record(s_main)
+                    for i in own:
+                        self._img_busy[(k0 + i) % nb].append(done)
             else:
                 for i, (q, (p, cam, t, img, alt)) in enumerate(zip(qs, prepared)):
                     q.georef(None, alt, cam, t, self.fast, self.min_elevation, params=p)
@@ -757,11 +761,13 @@ class SequencePipeline(object):
                 res['magnetic'] = self.magnetic
             if q.last_plan == 'two-pass':
                 # the separate binning kernel reads the buffer's image (and coordinate arrays) on this stream
-                ev = torch.cuda.Event()
-                ev.record(s_bin)
-                self._img_busy[slot].append(ev)
-                if two_streams:
-                    self._bin_done[slot] = ev
+                if two_streams or q.fd.img is q._img_own:
+                    ev = torch.cuda.Event()
+                    ev.record(s_bin)
+                    if q.fd.img is q._img_own:
+                        self._img_busy[slot].append(ev)
+                    if two_streams:
+                        self._bin_done[slot] = ev
         self.plans.append(q.last_plan)
         if q.last_plan == 'single-pass':
             self._hint_prev = self._hint
