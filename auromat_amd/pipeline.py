@@ -101,6 +101,10 @@ class FramePipeline(object):
         # the stream that will consume keep_on_device results when it is not the one current at finalisation (a pipelined
         # caller sets it: the outputs are then recorded for it once, at allocation, instead of array by array afterwards)
         self.consumer_stream = None
+        # rows of ONE frame sharded over several ranks (auromat_amd.sequence.resample_frame_sharded): an object with
+        # box(red) -> red (the 8-number bounding-box reduction combined over the ranks), acc(tensor) (the integer
+        # accumulators summed over the ranks, in place) and pole (pole in view of the WHOLE frame); None = whole frames
+        self.shard = None
         self.params = None
         self.altitude = None
         self.min_elevation = None
@@ -304,6 +308,9 @@ class FramePipeline(object):
         else:
             self._bbox_event.synchronize()
             red = self._bbox_host.numpy().copy()
+            if self.shard is not None:
+                red = self.shard.box(red)
+                self._pole = bool(self.shard.pole)
             if self._pole is None:
                 # pole containment from the camera model (the kernel does not count pole quads)
                 self._pole = pole_in_view(self.params, self.min_elevation)
@@ -485,7 +492,7 @@ class FramePipeline(object):
         pole = bb.containsPole if containsPole is None else containsPole
         self.last_plan = 'two-pass'
         return resample_frame(fd, self.altitude, bb, pxPerDeg, bb.containsDiscontinuity, pole,
-                              min_elevation=self.min_elevation, keep_on_device=keep_on_device)
+                              min_elevation=self.min_elevation, keep_on_device=keep_on_device, shard=self.shard)
 
     def run(self, wcsHeader, altitude, cameraPosGCRS, photoTime, img=None, fast=True, min_elevation=10.0,
             pxPerDeg=10, containsPole=None, magnetic=False, params=None, keep_on_device=False, fuse=False):

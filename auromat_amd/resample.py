@@ -309,7 +309,7 @@ def nearest_indices(ctx, lat_c, lon_c, elev, center_mask, height, width, min_ele
 
 
 def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=False, containsPole=False,
-                   min_elevation=None, keep_on_device=False, method='mean', outline=None):
+                   min_elevation=None, keep_on_device=False, method='mean', outline=None, shard=None):
     """
     ``_resample`` + ``_resampleCenterData(method='mean')`` + the image finalisation of ``resample``
     (reference resample.py:119-136,159-279,301-351) on a device-resident frame.
@@ -320,6 +320,9 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
     :param method: 'mean' (binning) or 'nearest' (closest pixel centre; needs `outline`)
     :param outline: (n,2) [lat,lon] polygon of the mapping (``BaseMapping.outline``) for the interpolating methods:
                     grid cells with a corner outside it are masked (reference resample.py:246-259)
+    :param shard: `fd` holds a band of rows of a frame whose other bands are on other ranks (see
+                  :func:`auromat_amd.sequence.resample_frame_sharded`): shard.box combines the reduction of the rotated
+                  corners, shard.acc sums the integer accumulators over the ranks before the means are taken
     :return: dict(lat, lon, lat_c, lon_c [grid coordinates, host], mean (ny,nx,C+1), img (ny,nx,C),
                   mask (ny,nx), count (ny,nx) ['mean' only], has_elev)
     """
@@ -350,6 +353,8 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
             red = ctx.empty((8,))
             ctx.call('amt_bbox_corners', ptr(rla), ptr(rlo), ptr(corner), ptr(cmask), fd.height, fd.width, ptr(red))
             r = to_host(red)
+            if shard is not None:
+                r = shard.box(r)
             latMin, latMax, lonMin, lonMax = r[0], r[1], r[2], r[3]
         lat_c, lon_c = _rotate_pole_dev(ctx, fd.lat_c, fd.lon_c, altitude, 90)
     elif containsDiscontinuity:
@@ -363,6 +368,7 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
     nch = fd.nchan
     if method == 'nearest':
         assert outline is not None, "method='nearest' needs the outline of the mapping"
+        assert shard is None, "rows of one frame over several ranks: method='mean' only"
         outline = np.array(outline, dtype=np.float64)
         if containsPole:
             outline[:, 0], outline[:, 1] = _rotate_pole_host(outline[:, 0], outline[:, 1], altitude, 90)
@@ -389,6 +395,8 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
     min_el = float('-inf') if min_elevation is None else float(min_elevation)
     ctx.call('amt_bin_frame', ptr(lat_c), ptr(lon_c), ptr(fd.elev), ptr(fd.img), fd.img_dtype_code, nch,
              ptr(fd.center_mask), fd.height, fd.width, min_el, C.byref(xaxis), C.byref(yaxis), lon_wrap, ptr(acc))
+    if shard is not None:
+        shard.acc(acc)          # integer counts and sums: the order of the ranks does not matter
     mean = ctx.empty((grid.ny, grid.nx, nch + 1))
     img = ctx.empty((grid.ny, grid.nx, max(nch, 1)), torch.uint8 if fd.img_dtype_code != 2 else torch.int16)
     mask = ctx.empty((grid.ny, grid.nx), torch.uint8)

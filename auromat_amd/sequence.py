@@ -247,3 +247,91 @@ def run_sequence(frames, width, height, altitude=110, fast=True, min_elevation=1
     if return_failed:
         return out, failed
     return out
+
+
+# ---- ONE frame over several GPUs ("a single very large frame") ----------------------------------------
+
+def row_band(height, rank, world_size, multiple=16):
+    """Rows [y0, y1) of a frame of `height` rows for `rank`: bands of whole chunks of `multiple` rows (the row-marching
+    kernel's work items are 16 rows tall, so a band is cut exactly where the whole frame's chunks are), sizes differing by
+    at most one chunk; the last band takes the remainder."""
+    chunks = (height + multiple - 1) // multiple
+    base, extra = divmod(chunks, world_size)
+    c0 = rank * base + min(rank, extra)
+    c1 = c0 + base + (1 if rank < extra else 0)
+    return min(c0 * multiple, height), min(c1 * multiple, height)
+
+
+class RowShard(object):
+    """The two exchange steps of a frame whose rows are spread over the ranks of `group` (what FramePipeline.shard and
+    resample_frame(shard=...) call): the bounding-box reduction (min / max / count: one all_gather of 8 doubles) and
+    the all-reduce(sum) of the integer accumulators.  Integer sums do not depend on the order of the ranks, so the
+    result is the one a single GPU computes."""
+
+    def __init__(self, pole, group=None):
+        import torch.distributed as dist
+        self.pole = bool(pole)
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+
+    def box(self, red):
+        import torch
+        import torch.distributed as dist
+        mine = torch.as_tensor(np.asarray(red, dtype=np.float64))
+        if self.backend == 'nccl':
+            mine = mine.cuda()
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        a = torch.stack(parts).cpu().numpy()
+        out = np.array(red, dtype=np.float64)
+        for k in (0, 2, 4):
+            out[k] = a[:, k].min()          # lat_min, lon_min, smallest positive longitude (+inf where a band has none)
+        for k in (1, 3, 5):
+            out[k] = a[:, k].max()          # lat_max, lon_max, largest non-positive longitude
+        out[6] = a[:, 6].sum()              # corners kept
+        out[7] = a[:, 7].max()
+        return out
+
+    def acc(self, acc):
+        import torch.distributed as dist
+        if self.backend == 'nccl':
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        host = acc.cpu()                    # (gloo in the tests: through the host)
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+        acc.copy_(host)
+
+
+def resample_frame_sharded(wcsHeader, altitude, cameraPosGCRS, photoTime, img, pxPerDeg=10, min_elevation=10.0,
+                           fast=True, containsPole=None, group=None, device=None, keep_on_device=False):
+    """
+    Georeference and mean-resample ONE frame with its rows spread over the ranks of `group` (every rank calls this
+    with the same arguments; `img` may be the whole (h, w, 3) image or only this rank's rows): each rank computes the
+    coordinate arrays of its band — the corner row between two bands is computed by both, nothing is exchanged for
+    it —, the ranks agree on the bounding box (min / max), bin their pixels on the common grid and all-reduce the
+    integer accumulators; every rank returns the complete grids (reference: resample.py:159-279 on the whole frame).
+
+    :return: (result dict of :func:`auromat_amd.resample.resample_frame`, FramePipeline holding this rank's band of
+             the per-pixel arrays, (y0, y1))
+    """
+    import torch.distributed as dist
+    from .pipeline import FramePipeline, pole_in_view
+    from .mapping.astrometry import frame_params
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    w, h = int(wcsHeader['IMAGEW']), int(wcsHeader['IMAGEH'])
+    y0, y1 = row_band(h, rank, world)
+    assert y1 > y0, 'more ranks than 16-row chunks'
+    band = dict(wcsHeader)
+    band['CRPIX2'] = wcsHeader['CRPIX2'] - y0           # the same camera, rows counted from y0
+    band['IMAGEH'] = y1 - y0
+    img = np.asarray(img)
+    rows = img[y0:y1] if img.shape[0] == h else img
+    assert rows.shape[0] == y1 - y0 and rows.shape[1] == w
+    pipe = FramePipeline(w, y1 - y0, nchan=rows.shape[2], img_dtype=rows.dtype, device=device)
+    # (the pole is in view of the frame, not of a band: decided from the whole frame's camera model on every rank)
+    whole = frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fast)
+    pipe.shard = RowShard(pole_in_view(whole, min_elevation), group)
+    res = pipe.run(band, altitude, cameraPosGCRS, photoTime, img=rows, fast=fast, min_elevation=min_elevation,
+                   pxPerDeg=pxPerDeg, containsPole=containsPole, keep_on_device=keep_on_device, fuse=False)
+    return res, pipe, (y0, y1)

@@ -114,3 +114,32 @@ def test_pack_unpack_roundtrip():
     assert [f['index'] for f in out] == [3, 9]
     for f, r in zip(out, results):
         np.testing.assert_array_equal(f['mean'], r['mean'].numpy())
+
+
+def _shard_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from auromat_amd.sequence import RowShard
+    s = RowShard(pole=False)
+    inf = float('inf')
+    # rank 0: a band over Europe; rank 1: a band of sky (nothing valid: the kernel's neutral elements)
+    mine = [[40.0, 55.0, -5.0, 20.0, 0.5, -0.25, 1234.0, 0.0], [inf, -inf, inf, -inf, inf, -inf, 0.0, 0.0]][rank]
+    red = s.box(np.array(mine))
+    assert red.tolist() == [40.0, 55.0, -5.0, 20.0, 0.5, -0.25, 1234.0, 0.0], red
+    acc = torch.arange(12, dtype=torch.int64).reshape(3, 4) * (rank + 1) - (7 if rank else 0)
+    s.acc(acc)
+    want = torch.arange(12, dtype=torch.int64).reshape(3, 4) * 3 - 7
+    assert torch.equal(acc, want)
+    with open(os.path.join(out_dir, 'shard_ok_%d' % rank), 'w') as fp:
+        fp.write('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_shard_exchange_steps(tmp_path):
+    """The two collectives of a frame whose rows are spread over the ranks (sequence.RowShard): box and accumulators."""
+    world = 2
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(str(tmp_path / ('shard_ok_%d' % r))) for r in range(world))
