@@ -92,3 +92,27 @@ def test_rows_of_one_frame_over_several_ranks(case, world, mode, tmp_path):
         a, b = z['band_lat'], whole['lat'][y0:y1 + 1]
         assert a.shape == b.shape and np.nanmax(np.abs(a - b), initial=0) < 1e-10
     assert rows == h
+
+
+@pytest.mark.gpu
+def test_one_band_over_rccl():
+    """The same two collectives on device tensors over "nccl" (= RCCL), one rank: all_gather of the box reduction,
+    all_reduce(sum) of the int64 accumulators; a pole frame, so that the rotated box is exchanged as well."""
+    import torch
+    import torch.distributed as dist
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.sequence import resample_frame_sharded
+    from auromat_amd.synthetic import frame_image, pole_frame
+    w, h = 400, 320
+    hdr, cam, t = pole_frame(w, h)
+    img = frame_image(w, h, seed=3)
+    ref = FramePipeline(w, h).run(hdr, 110, cam, t, img=img, min_elevation=10, pxPerDeg=8, fuse=False)
+    store = dist.TCPStore('127.0.0.1', 29537, 1, True)
+    dist.init_process_group('nccl', store=store, rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        res, pipe, (y0, y1) = resample_frame_sharded(hdr, 110, cam, t, img, pxPerDeg=8, min_elevation=10)
+    finally:
+        dist.destroy_process_group()
+    assert (y0, y1) == (0, h) and res['contains_pole']
+    for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
+        assert np.array_equal(res[k], ref[k], equal_nan=True), k
