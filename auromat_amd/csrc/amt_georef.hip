@@ -607,6 +607,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
     // pixel to ~1e-11 deg; the few pixels within 1e-7 bins of an edge are re-evaluated with rotate_pole_deg, the very
     // function the two-pass plan uses.
     constexpr bool pole_bin = kPole;
+    const bool geo_pole = kMagPole && !A.bin_magnetic;      // wave-uniform: SECOND = 3 on a geodetic grid (see the corner step)
     int n_valid = 0;
     auto box_add = [&](double la_v, double lo_v) {
         __hip_atomic_fetch_min(&sBox[wave][0][lane], la_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -857,8 +858,10 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
                     if (pole_bin) pole_point(bn, bd, p.x, p.y, sv, sxy); else sm_point(p, sv, sxy);
                     sm_angles(prev.s, prev.sxy, prev.ml, prev.sl, sv, sxy, sml, ssl);
                     if (kMagPole) {
-                        // MLat = atan(s.z / |s.xy|), SM longitude = atan2(s.y, s.x): the same construction on the SM vector
-                        pole_point(sv.z, sxy, sv.x, sv.y, rv, rxy);
+                        // MLat = atan(s.z / |s.xy|), SM longitude = atan2(s.y, s.x): the same construction on the SM vector;
+                        // without bin_magnetic (a geodetic grid with the pole in view whose caller also wants the MLat /
+                        // MLT arrays) the rotated pair is that of (lat, lon), as in the SECOND = 2 variant
+                        if (geo_pole) pole_point(bn, bd, p.x, p.y, rv, rxy); else pole_point(sv.z, sxy, sv.x, sv.y, rv, rxy);
                         sm_angles(prev.r, prev.rxy, prev.rla, prev.rlo, rv, rxy, rla, rlo);
                     }
                 }
@@ -879,7 +882,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
                     bla = sml;
                     blo = ssl;
                 }
-                if (kMagBox && !magbox && !pole_bin) {
+                if (kMagBox && !magbox && !pole_bin && !kMagPole) {
                     bla = la;
                     blo = lo;
                 }
@@ -955,7 +958,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
                         if (kMagPole) {
                             vec3 rc;
                             double rxyc;
-                            pole_point(sc.z, sxyc, sc.x, sc.y, rc, rxyc);
+                            if (geo_pole) pole_point(cn, cd, pc.x, pc.y, rc, rxyc); else pole_point(sc.z, sxyc, sc.x, sc.y, rc, rxyc);
                             sm_angles(rv, rxy, rla, rlo, rc, rxyc, rlac, rloc);
                         }
                     }
@@ -985,7 +988,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
                             if (pole_bin || kMagPole) {
                                 // next to an edge: the rotated coordinates as the two-pass plan computes them
                                 const pole_consts pk = karg_load<pole_consts>(karg_fresh(koff), offsetof(georef_args, pole));
-                                if (kMagPole)
+                                if (kMagPole && !geo_pole)
                                     rotate_pole_deg(pk.w, pk.rot, pk.e2, ml, (mt - 12.0) / (24.0 / 360.0), pk.alt, byv, bxv);
                                 else
                                     rotate_pole_deg(pk.w, pk.rot, pk.e2, lac, loc, pk.alt, byv, bxv);
@@ -1442,10 +1445,9 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     F->tail = tail;
     F->fold = fold;
     F->mag = out->mlat != nullptr || out->mlat_c != nullptr || A.bin_magnetic;
-    AMT_REQUIRE(ctx, !(A.bin_pole && !A.bin_magnetic && F->mag),
-                "bin_pole on a geodetic grid cannot be combined with MLat / MLT outputs");
     AMT_REQUIRE(ctx, !(A.bin_pole && use_tiles), "bin_pole is implemented by the row-marching kernel only");
-    F->second = A.bin_pole ? (A.bin_magnetic ? 3 : 2) : (F->mag ? 1 : 0);
+    // (bin_pole on a geodetic grid with MLat / MLT outputs: the SECOND = 3 variant with the rotated pair taken from (lat, lon))
+    F->second = A.bin_pole ? (F->mag ? 3 : 2) : (F->mag ? 1 : 0);
     F->bin = bin;
     return AMT_OK;
 }

@@ -260,11 +260,10 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
     AMT_REQUIRE(ctx, img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
     magnetic = magnetic ? 1 : 0;
     pipe->pole = pole_in_view < 0 ? (pole_visible(p, min_elevation, magnetic) ? 1 : 0) : (pole_in_view ? 1 : 0);
-    // frames with a pole of their grid in view take a pole plan (binned in rotated coordinates).  (The geodetic one is a
-    // kernel variant without MLat / MLT outputs: a geodetic pole frame of a caller that wants those arrays as well takes
-    // the general path.)
-    const bool mag_arrays = out->mlat != nullptr || out->mlat_c != nullptr;
-    const int mode = magnetic ? (pipe->pole ? 3 : 1) : (pipe->pole && !mag_arrays ? 2 : 0);
+    // frames with a pole of their grid in view take a pole plan (binned in rotated coordinates; a geodetic pole frame of
+    // a caller that wants the MLat / MLT arrays as well runs the kernel variant of the magnetic pole plan with the
+    // rotated pair taken from (lat, lon), see prepare_georef)
+    const int mode = magnetic ? (pipe->pole ? 3 : 1) : (pipe->pole ? 2 : 0);
     pipe->pole_plan = mode >= 2;
     if (!pipe->coarse_pending || pipe->coarse_magnetic != mode) {
         if (pipe->coarse_pending && !pipe->coarse_hinted) AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));

@@ -168,7 +168,8 @@ typedef struct amt_georef_out {
      * resampleMLatMLT does — rotated by +90 deg about x at `altitude`: amt_rotate_pole_deg of the centre coordinates,
      * reference resample.py:176-201 — and bbox[0..5] are reduced over the rotated corners (to ~1e-11 deg: good for laying out the
      * grid unless an extreme sits within that of a grid node, see amt_pipe_wait).  `altitude` [km] is the mapping
-     * altitude the shell (a, b) = (a0, b0) + altitude was built from, as rotatePole takes it. */
+     * altitude the shell (a, b) = (a0, b0) + altitude was built from, as rotatePole takes it.  MLat / MLT outputs can be
+     * combined with either grid. */
     int32_t bin_pole;
     int32_t reserved_pole;
     double altitude;

@@ -378,8 +378,7 @@ def test_c_abi_error_behaviour(native):
     out.bin_img_dtype = 7
     with pytest.raises(NativeError, match='uint8'):
         ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
-    # the pole plan: the altitude must be the one the shell was built from; not with a shifted date line, not with
-    # MLat / MLT arrays on a geodetic grid
+    # the pole plan: the altitude must be the one the shell was built from; not with a shifted date line
     out.bin_img_dtype = 2
     out.bin_pole, out.altitude = 1, 100.0
     with pytest.raises(NativeError, match='altitude does not match'):
@@ -388,10 +387,6 @@ def test_c_abi_error_behaviour(native):
     with pytest.raises(NativeError, match='bin_lon_wrap'):
         ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
     out.bin_lon_wrap = 0
-    out.mlat = out.mlt = lat.data_ptr()
-    with pytest.raises(NativeError, match='MLat'):
-        ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
-    out.mlat = out.mlt = None
     out.bin_pole = 0
     assert lib.amt_pipe_finalize_stream(None, C.byref(C.c_void_p())) < 0
     assert lib.amt_rotate_pole_deg(ctx.handle, None, None, None, C.c_double(110.0), C.c_int64(4), C.c_double(6378.137),

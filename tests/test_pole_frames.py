@@ -187,3 +187,29 @@ def test_single_pass_plan_handles_the_magnetic_pole(mode):
     for r in got:
         for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
             assert np.array_equal(r[k], out[False][k], equal_nan=True), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('side,mode', CASES)
+def test_geodetic_pole_plan_with_mlat_arrays(side, mode):
+    """A pipeline that also writes the MLat / MLT arrays (with_mag) and bins on the GEODETIC grid with the pole in view:
+    the kernel variant of the magnetic pole plan with the rotated pair taken from (lat, lon) — single-pass, identical to
+    the reference fixture and to the two-pass plan, the MLat / MLT arrays included."""
+    from auromat_amd.pipeline import FramePipeline
+    z = load_golden('pole_frame_%s_%s.npz' % (side, mode))
+    hdr = header_from(z)
+    t = parse(z['time_iso'])
+    w, h = hdr['IMAGEW'], hdr['IMAGEH']
+    pipe = FramePipeline(w, h, with_mag=True)
+    two = pipe.run(hdr, 110, z['cam'], t, img=z['img'], fast=mode == 'fast', min_elevation=10, pxPerDeg=8, fuse=False)
+    assert pipe.last_plan == 'two-pass'
+    arrays_two = pipe.host_arrays()
+    one = pipe.run(hdr, 110, z['cam'], t, img=z['img'], fast=mode == 'fast', min_elevation=10, pxPerDeg=8, fuse=True)
+    assert pipe.last_plan == 'single-pass'
+    check_against_fixture(one, z)
+    arrays_one = pipe.host_arrays()
+    for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon', 'lat_c', 'lon_c'):
+        assert np.array_equal(one[k], two[k], equal_nan=True), k
+    for k in ('lat', 'lon', 'lat_c', 'lon_c', 'elev', 'mlat', 'mlt', 'mlat_c', 'mlt_c'):
+        assert np.array_equal(arrays_one[k], arrays_two[k], equal_nan=True), k
+    assert np.isfinite(arrays_one['mlat_c']).sum() > 2000
