@@ -6,12 +6,12 @@ from datetime import timedelta
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from auromat_amd.pipeline import FramePipeline
-from auromat_amd.synthetic import frame_header, frame_image
+from auromat_amd.synthetic import frame_header, frame_image, pole_frame
 from oracle import ref_numpy as O
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-bad = skipped = 0
+bad = skipped = n_single = n_pole = 0
 for case in range(cases):
     big = int(os.environ.get('BIG', '1'))                # BIG=5: frames up to 2100 x 1500
     w, h = int(rng.randint(40, 420 * big)), int(rng.randint(30, 300 * big))
@@ -23,25 +23,41 @@ for case in range(cases):
     thr = [None, 5.0, 10.0, 20.0][rng.randint(4)]
     dtype = (np.uint8, np.uint16)[rng.randint(2)]
     magnetic = rng.randint(4) == 0                     # MLat/MLT grid: the two plans against each other only
+    with_mag = magnetic or rng.randint(3) == 0         # MLat / MLT arrays written beside a geodetic grid as well
     hdr, cam, t = frame_header(w, h, pointing)
     t = t - timedelta(minutes=shift)
+    if rng.randint(6) == 0 and not magnetic:           # a camera looking across a pole (the pole plans)
+        hdr, cam, t = pole_frame(w, h, south=bool(rng.randint(2)))
+        pointing, shift = 'pole', 0.0
     img = frame_image(w, h, seed=case, dtype=dtype)
     tag = '%d: %dx%d %s -%gmin alt %g ppd %s %s thr %s %s%s' % (case, w, h, pointing, shift, alt, ppd,
                                                                  'fast' if fast else 'exact', thr, dtype.__name__,
-                                                                 ' magnetic' if magnetic else '')
-    pipe = FramePipeline(w, h, img_dtype=dtype, with_mag=magnetic)
+                                                                 ' magnetic' if magnetic else (' with_mag' if with_mag else ''))
+    pipe = FramePipeline(w, h, img_dtype=dtype, with_mag=with_mag)
     try:
         two = pipe.run(hdr, alt, cam, t, img=img, fast=fast, min_elevation=thr, pxPerDeg=ppd, fuse=False,
                        magnetic=magnetic)
     except (ValueError, AssertionError) as e:
         skipped += 1                                   # nothing above the threshold / degenerate grid: as the reference
         continue
+    arrays_two = pipe.host_arrays() if with_mag else None
     one = pipe.run(hdr, alt, cam, t, fast=fast, min_elevation=thr, pxPerDeg=ppd, fuse=True, magnetic=magnetic)
     for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
         if not np.array_equal(one[k], two[k], equal_nan=True):
             bad += 1
             print('PLANS DIFFER', tag, k, pipe.last_plan)
             break
+    if with_mag:
+        arrays_one = pipe.host_arrays()
+        for k in ('mlat', 'mlt', 'mlat_c', 'mlt_c', 'lat_c', 'elev'):
+            if not np.array_equal(arrays_one[k], arrays_two[k], equal_nan=True):
+                bad += 1
+                print('ARRAYS DIFFER', tag, k, pipe.last_plan)
+                break
+    n_single += pipe.last_plan == 'single-pass'
+    if pipe.last_plan != 'single-pass' and os.environ.get('SHOW_PLANS'):
+        print('two-pass:', tag, 'pole' if two['contains_pole'] else '', 'dateline' if two['contains_discontinuity'] else '')
+    n_pole += bool(two['contains_pole'])
     if two['contains_pole'] or magnetic:
         continue
     et = O.date2es(t)
@@ -69,5 +85,5 @@ for case in range(cases):
     if ndiff > 2 or imgdiff:
         bad += 1
         print('ORACLE DIFFERS', tag, 'cells', ndiff, 'means', imgdiff, want['count'].sum(), two['count'].sum())
-print('cases', cases, 'skipped', skipped, 'failures', bad)
+print('cases', cases, 'skipped', skipped, 'single-pass', n_single, 'pole', n_pole, 'failures', bad)
 sys.exit(1 if bad else 0)
