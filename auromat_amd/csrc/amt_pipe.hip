@@ -328,8 +328,10 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
         const double lat_abs = std::fmax(std::fabs(c[0]), std::fabs(c[1]));
         const double lon_margin = std::fmin(10.0, kMarginDeg / std::fmax(0.1, std::cos(lat_abs * amt::kDeg2Rad)));
         const double lat_lo = std::fmax(-89.0, c[0] - kMarginDeg), lat_hi = std::fmin(89.0, c[1] + kMarginDeg);
-        const double lon_lo = box_lo - lon_margin, lon_hi = box_hi + lon_margin;
-        fuse = lon_lo > -179.0 && lon_hi < 179.0 &&
+        // (a box whose MARGIN reaches past +-180 deg — a footprint that ends just short of the date line — is cut there: when
+        // the exact box turns out to straddle after all, amt_pipe_wait sees that the coarse pass judged it differently)
+        const double lon_lo = std::fmax(-180.0, box_lo - lon_margin), lon_hi = std::fmin(180.0, box_hi + lon_margin);
+        fuse = box_lo > -179.9 && box_hi < 179.9 &&
                amt_gl::layout(lat_px_per_deg, lon_px_per_deg, lat_lo, lat_hi, lon_lo, lon_hi, &pipe->super);
     }
     if (fuse) {
