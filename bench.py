@@ -570,6 +570,29 @@ def main(argv=None):
                 del v
                 gc.collect()
                 torch.cuda.empty_cache()
+            # BASELINE configs[1]: the intersection + geodetic transform on their own (no image, no resample): the
+            # georeferencing kernel without the fused binning, per-frame host set-up inside the timed region as above
+            from auromat_amd.pipeline import FramePipeline
+            gpipe = FramePipeline(WIDTH, HEIGHT, alloc_image=False)
+            gframes = make_frames(nv_w + nv_k, False)
+            for hdr, cam, t, _, _ in gframes[:nv_w]:
+                gpipe.georef(hdr, ALTITUDE, cam, t, True, MIN_ELEV)
+            gpipe.ctx.timing_enable(1)
+            fence()
+            t0 = time.perf_counter()
+            for hdr, cam, t, _, _ in gframes[nv_w:]:
+                gpipe.georef(hdr, ALTITUDE, cam, t, True, MIN_ELEV)
+            fence()
+            g_el = time.perf_counter() - t0
+            g_total, g_n = gpipe.ctx.timing_read(0)
+            gpipe.ctx.timing_enable(False)
+            assert g_n == nv_k
+            variants['configs1_georef_only'] = {
+                'ms_per_frame': g_el / nv_k * 1e3, 'Mpixels_per_s': nv_k * npx / 1e6 / g_el, 'frames': nv_k,
+                'kernel_ms_per_frame': g_total / g_n, 'algorithmic_bytes_per_frame': ab['georef'],
+                'frac': frac(ab['georef'], g_total / g_n)}
+            del gpipe
+            gc.collect()
             out['variants'] = variants
         if world == 1 and args.cpu_rows > 0:
             parity = {}
