@@ -811,7 +811,12 @@ class SequencePipeline(object):
             out.append(r)
         return out
 
-    def process(self, frames, keep_on_device=True):
+    def finalize_stream(self):
+        """The stream the single-pass results are produced on (the drivers' finalise stream, shared by the pipeline's
+        buffers): consumers that want to touch results before process() returns enqueue there."""
+        return self.pipes[0]._finalize_stream()
+
+    def process(self, frames, keep_on_device=True, on_batch=None):
         """
         frames: iterable of (wcsHeader | amt_frame_params, cameraPosGCRS, photoTime, image | None[, altitude]);
         a fifth element overrides the pipeline's altitude for that frame (several shells in one sequence).
@@ -820,6 +825,8 @@ class SequencePipeline(object):
         Returns the list of per-frame result dicts (see :func:`auromat_amd.resample.resample_frame`) in order;
         with keep_on_device the arrays are device tensors that are valid for work on the current stream.  A frame
         without any valid pixel yields None (the reference raises ValueError for it, mapping.py:858-859).
+        `on_batch(k0, results)` is called with the results of every finished launch (frames k0, k0+1, ... of this call, in
+        order) while later launches run: work on them belongs on :meth:`finalize_stream` (or behind this call's return).
         """
         import torch
         del self.plans[:]
@@ -858,7 +865,10 @@ class SequencePipeline(object):
                 following = next_batch(k + n_now + len(ahead))
             else:
                 following = []
-            out.extend(self._finish_batch(k, n_now, keep_on_device))
+            finished = self._finish_batch(k, n_now, keep_on_device)
+            out.extend(finished)
+            if on_batch is not None:
+                on_batch(k, finished)
             k += n_now
             in_flight, ahead = ahead, following
         # order the caller's stream behind everything this call enqueued

@@ -34,21 +34,16 @@ def pack_results(results, indices, device):
     count (ny*nx).
     """
     import torch
-    descs = np.zeros((len(results), DESC_LEN), dtype=np.float64)
+    descs = describe_results(results, indices)
     parts = []
-    for i, (res, idx) in enumerate(zip(results, indices)):
+    for res in results:
         if res is None:
             # no valid pixel in this frame (maskedByElevation would raise ValueError, reference mapping.py:858-859)
-            descs[i, 7] = idx
             continue
         mean, count = res['mean'], res['count']
         if not isinstance(mean, torch.Tensor):
             mean, count = torch.from_numpy(np.ascontiguousarray(mean)), torch.from_numpy(np.ascontiguousarray(count))
         ny, nx, nc = mean.shape
-        g = res['grid']
-        descs[i] = (ny, nx, nc, g.lat0, g.lon0, g.latStep, g.lonStep, idx,
-                    1.0 if res.get('contains_pole') else 0.0, 1.0 if res.get('contains_discontinuity') else 0.0,
-                    float(res.get('altitude') or 0.0), 1.0 if res.get('magnetic') else 0.0)
         packed = res.get('packed')
         if packed is not None and packed.device == mean.device and packed.numel() == ny * nx * (nc + 1):
             parts.append(packed)        # the single-pass plan lays mean and count out one after the other already
@@ -137,6 +132,102 @@ class Gathered(object):
         return sorted(out, key=lambda f: f['index'])
 
 
+class Packer(object):
+    """
+    The send buffer of :func:`gather_device` with an agreed capacity, filled WHILE the sequence is processed:
+    ``SequencePipeline.process(frames, on_batch=packer.add)`` hands over the frames of every finished launch, and their
+    (mean | count) slices are copied to their place in the buffer on the stream that finalises them (a few microseconds
+    of host time per frame, hidden behind the next launch's kernel), instead of one concatenation of all frames after
+    the last kernel, where nothing hides it.  ``gather_device(..., packer=packer)`` then only writes the descriptors.
+    Frames that did not take the single-pass plan (no `packed` slice) are copied at the end.
+    """
+
+    def __init__(self, capacity, device, stream=None):
+        import torch
+        self.max_frames, self.max_payload = capacity
+        self.device, self.stream = device, stream
+        n = self.max_frames * DESC_LEN + self.max_payload
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                self.buf = torch.empty(n + 2, dtype=torch.float64, device=device)
+        else:
+            self.buf = torch.empty(n + 2, dtype=torch.float64, device=device)
+        self.offset = 0             # payload doubles laid out so far
+        self.frames = 0
+        self.late = []              # (offset, result) of frames copied in finish()
+        self.overflow = False
+
+    def add(self, k0, results):
+        """Frames k0, k0+1, ... of the call (in order, every frame exactly once)."""
+        import torch
+        assert k0 == self.frames, 'frames must arrive in order'
+        todo = []
+        for res in results:
+            self.frames += 1
+            if res is None:
+                continue
+            ny, nx, nc = res['mean'].shape
+            m = ny * nx * (nc + 1)
+            if self.offset + m > self.max_payload or self.frames > self.max_frames:
+                self.overflow = True
+                continue
+            packed = res.get('packed')
+            if packed is not None and packed.numel() == m and packed.device == self.buf.device:
+                todo.append((self.offset, packed))
+            else:
+                self.late.append((self.offset, res))
+            self.offset += m
+        if not todo:
+            return
+        base = self.max_frames * DESC_LEN
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                for off, packed in todo:
+                    self.buf[base + off:base + off + packed.numel()].copy_(packed, non_blocking=True)
+        else:
+            for off, packed in todo:
+                self.buf[base + off:base + off + packed.numel()].copy_(packed)
+
+    def finish(self, results, indices):
+        """Descriptors, late frames and the trailer -> the buffer to send (on the current stream, which must be
+        ordered behind the pipeline's streams: it is once process() has returned)."""
+        import torch
+        assert self.frames == len(results), 'every frame of the call must have been added'
+        buf, base = self.buf, self.max_frames * DESC_LEN
+        if self.stream is not None:
+            buf.record_stream(torch.cuda.current_stream(buf.device))
+        if self.overflow or len(results) > self.max_frames:
+            tail = [-1.0, 0.0]
+        else:
+            descs = describe_results(results, indices)
+            for off, res in self.late:
+                mean, count = res['mean'], res['count']
+                if not isinstance(mean, torch.Tensor):
+                    mean, count = torch.from_numpy(np.ascontiguousarray(mean)), torch.from_numpy(np.ascontiguousarray(count))
+                buf[base + off:base + off + mean.numel()] = mean.reshape(-1).to(buf.device)
+                buf[base + off + mean.numel():base + off + mean.numel() + count.numel()] = count.reshape(-1).to(buf.device)
+            head = np.concatenate([descs.reshape(-1)])
+            buf[:head.size].copy_(torch.from_numpy(head), non_blocking=True)
+            tail = [float(len(results)), float(self.offset)]
+        buf[-2:].copy_(torch.tensor(tail, dtype=torch.float64), non_blocking=True)
+        return buf
+
+
+def describe_results(results, indices):
+    """The descriptor table ((n, DESC_LEN) float64, host) of :func:`pack_results`."""
+    descs = np.zeros((len(results), DESC_LEN), dtype=np.float64)
+    for i, (res, idx) in enumerate(zip(results, indices)):
+        if res is None:
+            descs[i, 7] = idx
+            continue
+        ny, nx, nc = res['mean'].shape
+        g = res['grid']
+        descs[i] = (ny, nx, nc, g.lat0, g.lon0, g.latStep, g.lonStep, idx,
+                    1.0 if res.get('contains_pole') else 0.0, 1.0 if res.get('contains_discontinuity') else 0.0,
+                    float(res.get('altitude') or 0.0), 1.0 if res.get('magnetic') else 0.0)
+    return descs
+
+
 def agree_capacity(results, indices, device, margin=1.25, group=None):
     """
     (max_frames, max_payload) over all ranks for results like these, the payload with `margin`: what
@@ -158,7 +249,7 @@ def agree_capacity(results, indices, device, margin=1.25, group=None):
     return int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max() * margin) + 1
 
 
-def gather_device(results, indices, device, dst=0, group=None, capacity=None):
+def gather_device(results, indices, device, dst=0, group=None, capacity=None, packer=None):
     """
     Gather every rank's per-frame grids on rank `dst`, device to device.  Two collectives: an all_gather of the
     (frames, payload length) pair, then one gather of [descriptors | payload] padded to the longest.
@@ -166,11 +257,21 @@ def gather_device(results, indices, device, dst=0, group=None, capacity=None):
     ONE collective and no host synchronisation: every rank sends a buffer of that size which ends with its own
     (frames, payload length).  A rank whose grids do not fit sends (-1, 0) there and nothing else; the destination
     raises ValueError when it reads the sizes (no rank is left waiting in a collective).
+    With `packer` (a :class:`Packer` that was handed these very results while they were computed) nothing is left to
+    pack but the descriptors.
     Returns a :class:`Gathered` on `dst`, None elsewhere.
     """
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if packer is not None:
+        buf = packer.finish(results, indices)
+        if rank == dst:
+            bufs = [torch.empty_like(buf) for _ in range(world)]
+            dist.gather(buf, bufs, dst=dst, group=group)
+            return Gathered(bufs, None, packer.max_frames)
+        dist.gather(buf, None, dst=dst, group=group)
+        return None
     descs, payload = pack_results(results, indices, device)
     if capacity is not None:
         max_frames, max_payload = capacity

@@ -143,3 +143,54 @@ def test_row_shard_exchange_steps(tmp_path):
     world = 2
     mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(str(tmp_path / ('shard_ok_%d' % r))) for r in range(world))
+
+
+def _packer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from auromat_amd.sequence import Packer, agree_capacity, gather_device, shard
+    n_frames = 7
+    mine = shard(n_frames, rank, world)
+    results = [None if k == 1 else _fake_result(k) for k in mine]
+    for r in results:
+        if r is not None and r['grid'].ny % 2 == 0:
+            # like a single-pass frame: mean and count as one slice
+            r['packed'] = torch.cat([r['mean'].reshape(-1), r['count'].reshape(-1)])
+    cap = agree_capacity(results, mine, torch.device('cpu'))
+    packer = Packer(cap, torch.device('cpu'))
+    # the frames arrive launch by launch, while "later launches run"
+    k = 0
+    for size in (1, 3, 3):
+        if k < len(results):
+            packer.add(k, results[k:k + size])
+            k += len(results[k:k + size])
+    g = gather_device(results, mine, torch.device('cpu'), packer=packer)
+    plain = gather_device(results, mine, torch.device('cpu'), capacity=cap)
+    if rank == 0:
+        got, want = g.unpack(), plain.unpack()
+        assert [f['index'] for f in got] == [f['index'] for f in want] == [0, 2, 3, 4, 5, 6] and g.failed == [1]
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a['mean'], b['mean'])
+            np.testing.assert_array_equal(a['count'], b['count'])
+            for key in ('lat0', 'lon0', 'dlat', 'dlon', 'contains_pole', 'contains_discontinuity', 'altitude', 'magnetic'):
+                assert a[key] == b[key], key
+    # a rank whose grids do not fit says so in its buffer; nobody is left waiting
+    small = Packer((cap[0], 10), torch.device('cpu'))
+    small.add(0, results)
+    g = gather_device(results, mine, torch.device('cpu'), packer=small)
+    if rank == 0:
+        with pytest.raises(ValueError, match='did not fit'):
+            g.unpack()
+    with open(os.path.join(out_dir, 'packer_ok_%d' % rank), 'w') as fp:
+        fp.write('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_from_a_buffer_packed_while_the_frames_were_computed(tmp_path):
+    """sequence.Packer: the send buffer filled launch by launch == the buffer packed afterwards; overflow is reported."""
+    world = 2
+    mp.spawn(_packer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(str(tmp_path / ('packer_ok_%d' % r))) for r in range(world))

@@ -298,3 +298,28 @@ def test_two_launch_streams_give_the_same_grids():
                 if a is not None:
                     for key in KEYS:
                         assert np.array_equal(a[key], b[key], equal_nan=True), (batch, rep, key)
+
+
+def test_send_buffer_packed_while_the_sequence_runs():
+    """sequence.Packer fed by SequencePipeline.process(on_batch=...) on the finalise stream: the buffer equals the one
+    packed after the call (single-pass frames, pole frames, a frame of empty sky)."""
+    import torch
+    from auromat_amd.pipeline import SequencePipeline
+    from auromat_amd.sequence import DESC_LEN, Packer, pack_results
+    w, h = 300, 200
+    frames = build_sequence(w, h, 13, every_pole=5, empty_at=(7,))
+    seq = SequencePipeline(w, h, pxPerDeg=6)
+    first = seq.process(frames)
+    assert any(r is None for r in first) and any(r is not None and r['contains_pole'] for r in first)
+    idx = list(range(100, 100 + len(frames)))
+    descs, payload = pack_results(first, idx, seq.ctx.device)
+    cap = (len(frames) + 2, payload.numel() + 100)
+    for rep in range(3):
+        packer = Packer(cap, seq.ctx.device, seq.finalize_stream())
+        res = seq.process(frames, on_batch=packer.add)
+        buf = packer.finish(res, idx)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+        assert got[-2] == len(frames) and got[-1] == payload.numel()
+        assert np.array_equal(got[:descs.numel()].reshape(descs.shape), descs.cpu().numpy())
+        assert np.array_equal(got[cap[0] * DESC_LEN:cap[0] * DESC_LEN + payload.numel()], payload.cpu().numpy(), equal_nan=True)
