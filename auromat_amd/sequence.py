@@ -35,7 +35,15 @@ def pack_results(results, indices, device):
     """
     import torch
     descs = describe_results(results, indices)
-    parts = []
+    parts, _ = payload_parts(results, device)
+    payload = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.float64, device=device)
+    return torch.from_numpy(descs).to(device), payload
+
+
+def payload_parts(results, device):
+    """The pieces of the payload in order (1-d float64 tensors on `device`) and their total length."""
+    import torch
+    parts, total = [], 0
     for res in results:
         if res is None:
             # no valid pixel in this frame (maskedByElevation would raise ValueError, reference mapping.py:858-859)
@@ -49,8 +57,21 @@ def pack_results(results, indices, device):
             parts.append(packed)        # the single-pass plan lays mean and count out one after the other already
         else:
             parts += [mean.reshape(-1).to(device), count.reshape(-1).to(device)]
-    payload = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.float64, device=device)
-    return torch.from_numpy(descs).to(device), payload
+        total += ny * nx * (nc + 1)
+    return parts, total
+
+
+_ZEROS = {}
+
+
+def _zero_pad(device, n):
+    """n float64 zeros on `device` without a kernel: a slice of a buffer that is kept (and only ever read)."""
+    import torch
+    key = str(device)
+    z = _ZEROS.get(key)
+    if z is None or z.numel() < n:
+        z = _ZEROS[key] = torch.zeros(max(n, 1 << 16), dtype=torch.float64, device=device)
+    return z[:n]
 
 
 def unpack_results(descs, payload, failed=None):
@@ -272,24 +293,27 @@ def gather_device(results, indices, device, dst=0, group=None, capacity=None, pa
             return Gathered(bufs, None, packer.max_frames)
         dist.gather(buf, None, dst=dst, group=group)
         return None
-    descs, payload = pack_results(results, indices, device)
     if capacity is not None:
+        # [descriptors, padded | payload, padded | frames, payload length]: ONE host-to-device copy (descriptors and
+        # trailer) and ONE concatenation straight into that layout (the padding is a slice of a kept zero buffer)
         max_frames, max_payload = capacity
-        n = max_frames * DESC_LEN + max_payload
-        buf = torch.zeros(n + 2, dtype=torch.float64, device=device)
-        if descs.shape[0] <= max_frames and payload.numel() <= max_payload:
-            buf[:descs.numel()] = descs.reshape(-1)
-            buf[max_frames * DESC_LEN:max_frames * DESC_LEN + payload.numel()] = payload
-            tail = [float(descs.shape[0]), float(payload.numel())]
+        parts, total = payload_parts(results, device)
+        head = np.zeros(max_frames * DESC_LEN + 2, dtype=np.float64)
+        if len(results) <= max_frames and total <= max_payload:
+            head[:len(results) * DESC_LEN] = describe_results(results, indices).reshape(-1)
+            head[-2:] = (len(results), total)
         else:
-            tail = [-1.0, 0.0]
-        buf[n:].copy_(torch.tensor(tail, dtype=torch.float64), non_blocking=True)
+            head[-2:] = (-1.0, 0.0)
+            parts, total = [], 0
+        head = torch.from_numpy(head).to(device)
+        buf = torch.cat([head[:-2]] + parts + [_zero_pad(device, max_payload - total), head[-2:]])
         if rank == dst:
             bufs = [torch.empty_like(buf) for _ in range(world)]
             dist.gather(buf, bufs, dst=dst, group=group)
             return Gathered(bufs, None, max_frames)
         dist.gather(buf, None, dst=dst, group=group)
         return None
+    descs, payload = pack_results(results, indices, device)
     sizes = torch.tensor([descs.shape[0], payload.numel()], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)
