@@ -227,8 +227,7 @@ class Packer(object):
                     mean, count = torch.from_numpy(np.ascontiguousarray(mean)), torch.from_numpy(np.ascontiguousarray(count))
                 buf[base + off:base + off + mean.numel()] = mean.reshape(-1).to(buf.device)
                 buf[base + off + mean.numel():base + off + mean.numel() + count.numel()] = count.reshape(-1).to(buf.device)
-            head = np.concatenate([descs.reshape(-1)])
-            buf[:head.size].copy_(torch.from_numpy(head), non_blocking=True)
+            buf[:descs.size].copy_(torch.from_numpy(descs.reshape(-1)), non_blocking=True)
             tail = [float(len(results)), float(self.offset)]
         buf[-2:].copy_(torch.tensor(tail, dtype=torch.float64), non_blocking=True)
         return buf
