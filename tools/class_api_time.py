@@ -1,0 +1,23 @@
+"""Wall time of the user-guide flow through the class API (host arrays in and out, as the reference's users call it) on
+the reference's own test frame: getMapping -> maskedByElevation -> resample / resampleMLatMLT, second call timed."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from auromat_amd.mapping.spacecraft import getMapping
+from auromat_amd.resample import resample, resampleMLatMLT
+R = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'resources')
+img, wcs = os.path.join(R, 'ISS030-E-102170_dc.jpg'), os.path.join(R, 'ISS030-E-102170_dc.wcs')
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m = getMapping(img, wcs, altitude=110, fastCenterCalculation=True)
+    t1 = time.perf_counter()
+    mm = m.maskedByElevation(10)
+    t2 = time.perf_counter()
+    geo = resample(mm, pxPerDeg=10)
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    mag = resampleMLatMLT(mm, pxPerDeg=10)
+    torch.cuda.synchronize(); t4 = time.perf_counter()
+    lat = mm.lats
+    t5 = time.perf_counter()
+    print('getMapping (JPEG decode) %.3f s, maskedByElevation %.3f s, resample %.3f s, resampleMLatMLT %.3f s, lats to host %.3f s'
+          % (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4), geo.img.shape)
