@@ -117,6 +117,10 @@ struct georef_args {
     unsigned long long* bin_acc;
     int bin_lon_wrap, bin_magnetic;
     int item_order, chunk_stride;       // amt_georef_out.item_order; stride of the interleaved chunk order
+    // item_order 4 (two fronts): rows of work items [front_split, n) — the Earth side — are visited from front_split
+    // on, rows [0, front_split) — the sky side — from front_split - 1 backwards, front_e of the one for every front_s
+    // of the other; front_flip mirrors the frame first (Earth above the limb)
+    int front_split, front_e, front_s, front_flip;
     int bin_pole, pad_pole_;            // amt_georef_out.bin_pole: bin (and box) in the coordinates rotated by 90 deg about x
     pole_consts pole;
     bin_event* bin_events;      // optional list for on-edge pixels (amt_georef_out.bin_events)
@@ -462,6 +466,25 @@ constexpr int kBinW = 8, kBinCells = kBinW * kBinW;
 #ifndef AMT_ROWS_MIN_WAVES_POLE
 #define AMT_ROWS_MIN_WAVES_POLE 3       // the pole variants need ~150 VGPRs; at 4 waves (128) they spill 40
 #endif
+// item_order 4: the c-th row of work items in dispatch order -> its row of chunks.  The launch works on two fronts that
+// start at the limb and move apart: the Earth side (VALU-bound rows) and the sky side (rows that only store NaN), so that
+// both kinds are in flight together for most of the launch while each front keeps writing neighbouring rows (an order
+// that scatters the rows in flight over the whole frame, item_order 3, costs the stores their locality: a frame of sky
+// alone takes 113 instead of 96 us).  A bijection of [0, n) for any split in [0, n] and e, s >= 1.
+__host__ __device__ inline int two_front_chunk(int c, int n, int split, int e, int s, int flip) {
+    const int n_e = n - split, n_s = split;
+    const int full = min(n_e / e, n_s / s), per = e + s;
+    int chunk;
+    if (c < full * per) {
+        const int q = c / per, r = c - q * per;
+        chunk = r < e ? split + q * e + r : split - 1 - (q * s + (r - e));
+    } else {
+        const int r = c - full * per, rem_e = n_e - full * e;
+        chunk = r < rem_e ? split + full * e + r : split - 1 - (full * s + (r - rem_e));
+    }
+    return flip ? n - 1 - chunk : chunk;
+}
+
 template <bool FAST, bool DIRS_IN, int SECOND, int BIN>
 __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE : (SECOND == 1 && BIN ? AMT_ROWS_MIN_WAVES_MAG : (BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES))) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
                                                            int n_items, int n_frames) {
@@ -529,6 +552,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
     strip = item - chunk * strips_x;
     if (A.item_order == 2) chunk = chunks_y - 1 - chunk;
     if (A.item_order == 3) chunk = (int)(((long long)chunk * A.chunk_stride) % chunks_y);
+    if (A.item_order == 4) chunk = two_front_chunk(chunk, chunks_y, A.front_split, A.front_e, A.front_s, A.front_flip);
     const int x0 = strip * 63, y0 = chunk * rows_per_chunk;
     const int rows = min(rows_per_chunk, A.height - y0);
     const int gx = x0 + lane;
@@ -816,7 +840,26 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
         vec3 rv = {NAN, NAN, NAN};       // kMagPole: the rotated point and its angles
         double rxy = NAN, rla = NAN, rlo = NAN;
         bool hit = false;
-        if (col_ok) {
+#ifdef AMT_SKIP_TIMING
+        // TIMING-ONLY build (wrong values, the right store / image / binning streams): three rows of every five cost what an
+        // interpolated row would cost — the question whether the Earth part of a frame follows its VALU work
+        const bool skip_row = (r % 5) >= 2;
+#else
+        constexpr bool skip_row = false;
+#endif
+        if (col_ok && skip_row) {
+            hit = prev.la == prev.la;
+            la = prev.la + 1e-4, lo = prev.lo + 1e-4;
+            la = __builtin_fma(la, 1.0000001, prev.bn * 1e-12), lo = __builtin_fma(lo, 1.0000001, prev.bd * 1e-12);
+            p = prev.p, d = prev.d, bn = prev.bn, bd = prev.bd, u = prev.d;
+            if (BIN) take_pixel(r, even, ch0, ch1, ch2);
+            const bool owner = (lane < 63 || gx == frame_w) && (r < rows || gy == frame_h);
+            if (owner) {
+                if (out_lat) at(out_lat, off_corner) = la;
+                if (out_lon) at(out_lon, off_corner) = lo;
+            }
+        }
+        if (col_ok && !skip_row) {
             const shell_ray& ry = ray;
             u = corner_ray(gy, dj);
             const double uu = fx::dot3(u.x, u.y, u.z, u.x, u.y, u.z);
@@ -932,7 +975,12 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
             long long el_fix = 0;
             if (px_ok) {
                 double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN, slc = NAN, rlac = NAN, rloc = NAN;
-                if (pc.x == pc.x) {
+                if (skip_row && pc.x == pc.x) {
+                    // 3 values x (4-term interpolation + one add)
+                    lac = __builtin_fma(la, 0.25, __builtin_fma(prev.la, 0.25, __builtin_fma(pc.x, 1e-9, pc.y * 1e-9))) + la * 0.5;
+                    loc = __builtin_fma(lo, 0.25, __builtin_fma(prev.lo, 0.25, __builtin_fma(pc.y, 1e-9, pc.z * 1e-9))) + lo * 0.5;
+                    el = __builtin_fma(dsum.x, 1e-3, __builtin_fma(dsum.y, 1e-3, __builtin_fma(dsum.z, 1e-3, pc.z * 1e-9))) + 20.0;
+                } else if (pc.x == pc.x) {
                     double inv_r, cn, cd;
                     fx::bowring_nd(bw, pc.x, pc.y, pc.z, cn, cd, inv_r);
                     // relative to this lane's corner of the current row
@@ -1260,6 +1308,14 @@ int nadir_side(const amt_frame_params* p) {
     return (std::fabs(py) >= std::fabs(px) && py > 0) ? 2 : 1;
 }
 
+int forced_order_env() {
+    static const int forced_order = [] {
+        const char* e = std::getenv("AMT_ITEM_ORDER");
+        return e ? std::atoi(e) : 0;
+    }();
+    return forced_order;
+}
+
 // items (waves) of the row-marching launch / tiles of the tile kernel, and the rows per chunk
 struct launch_shape {
     bool use_tiles;
@@ -1305,6 +1361,62 @@ int interleave_stride(int n) {
     if (s < 1) s = 1;
     while (gcd(s, n) != 1) ++s;
     return s % n ? s % n : 1;
+}
+
+// Host copy of the kernel's hit test (shell_t >= 0) for the pixel-corner position (column x, row y).
+bool ray_hits_host(const affine_cam& c, const shell_ray& e, double x, double y) {
+    const double px = x + c.cx, py = y + c.cy;
+    const double ux = c.u0[0] + px * c.ux[0] + py * c.uy[0], uy = c.u0[1] + px * c.ux[1] + py * c.uy[1],
+                 uz = c.u0[2] + px * c.ux[2] + py * c.uy[2];
+    const double uu = ux * ux + uy * uy + uz * uz;
+    const double ku = ux * e.kx + uy * e.ky + uz * e.kz, uo = ux * e.ox + uy * e.oy + uz * e.oz;
+    const double a2 = e.qd * ku * ku + e.qa * uu, nb = -(e.qa * uo + e.qd_ko * ku);
+    const double disc = nb * nb - a2 * e.c0;
+    if (!(disc >= 0)) return false;
+    return (nb + e.root_sign * std::sqrt(disc)) / a2 >= 0;
+}
+
+// item_order 4: where the limb cuts the frame's rows of work items.  The middle row of every chunk is probed in three
+// columns; when the chunks that see the Earth are one run that reaches the first or the last row of chunks and the sky
+// takes at least an eighth of the frame, the launch works on two fronts from the limb (see two_front_chunk), the
+// Earth's rows and the sky's in the proportion that lets both fronts finish together.  Returns false when the frame is
+// not of that kind (all Earth, all sky, Earth to the left or right, a whole disc in view): the caller keeps its order.
+bool two_front_plan(const georef_args& A, const launch_shape& sh, int* split, int* n_e, int* n_s, int* flip) {
+    const int n = sh.chunks_y;
+    if (n < 16) return false;
+    int first = n, last = -1;
+    for (int c = 0; c < n; ++c) {
+        const double y = std::min((double)A.height, (c + 0.5) * sh.rows_per_chunk);
+        int hits = 0;
+        for (int k = 1; k <= 3; ++k) hits += ray_hits_host(A.cam, A.sray, 0.25 * k * A.width, y) ? 1 : 0;
+        if (hits >= 2) {
+            first = std::min(first, c);
+            last = c;
+        }
+    }
+    if (last < 0) return false;
+    // (the conic section that bounds the hits is convex: per column they are one interval)
+    const int earth = last - first + 1, sky = n - earth;
+    if (sky < n / 8 || earth < n / 8) return false;
+    if (last == n - 1) {
+        *flip = 0, *split = first;
+    } else if (first == 0) {
+        *flip = 1, *split = n - 1 - last;       // in the mirrored frame the Earth's chunks are [split, n)
+    } else {
+        return false;
+    }
+    // an Earth row of items costs about 1.6 times a sky row (all-Earth frame 150 us, frame of sky 96 us); small whole
+    // numbers whose ratio is close to (earth : sky) chunks weighted that way
+    const double want = (double)earth / sky;        // Earth rows per sky row so that both fronts end together
+    int best_e = 1, best_s = 1;
+    double best = 1e9;
+    for (int e = 1; e <= 4; ++e)
+        for (int s2 = 1; s2 <= 4; ++s2) {
+            const double d = std::fabs(std::log(((double)e / s2) / want));
+            if (d < best) best = d, best_e = e, best_s = s2;
+        }
+    *n_e = best_e, *n_s = best_s;
+    return true;
 }
 
 // One frame of a launch, validated and with its kernel arguments assembled
@@ -1369,14 +1481,12 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     A.bin_events = nullptr;
     A.bin_event_count = nullptr;
     A.bin_event_cap = 0;
-    // AMT_ITEM_ORDER = 1, 2, 3 overrides the order for A/B runs
-    static const int forced_order = [] {
-        const char* e = std::getenv("AMT_ITEM_ORDER");
-        return e ? std::atoi(e) : 0;
-    }();
+    // AMT_ITEM_ORDER = 1, 2, 3, 4 overrides the order for A/B runs
+    const int forced_order = forced_order_env();
     A.item_order = out->item_order >= 1 && out->item_order <= 3 ? out->item_order : (dirs ? 1 : nadir_side(p));
-    if (forced_order >= 1 && forced_order <= 3) A.item_order = forced_order;
+    if (forced_order >= 1 && forced_order <= 4) A.item_order = forced_order;
     A.chunk_stride = 1;
+    A.front_split = 0, A.front_e = A.front_s = 1, A.front_flip = 0;
     std::memset(&A.bax, 0, sizeof(A.bax));
     std::memset(&A.bay, 0, sizeof(A.bay));
     std::memset(&A.bxl, 0, sizeof(A.bxl));
@@ -1415,6 +1525,24 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     }
     const launch_shape sh = shape_of(p);
     A.chunk_stride = interleave_stride(sh.chunks_y);
+    // two fronts from the limb (item_order 4; AMT_ITEM_ORDER=4, AMT_FRONT_RATIO = "e:s" overrides the proportion of the two
+    // fronts).  Measured (profiles/r3/x_ab_two_front_order.txt): 135 / 168 us (georef only / fused, kernel alone) against
+    // 126 / 153 us for the side-first order — sky rows (stores only) and Earth rows (VALU-bound) in flight TOGETHER are
+    // slower than one after the other, at every proportion; an option for A/B runs, not the default.
+    if (dirs == nullptr && !sh.use_tiles && (forced_order_env() == 4 || out->item_order == 4)) {
+        int split = 0, fe = 1, fs = 1, flip = 0;
+        if (two_front_plan(A, sh, &split, &fe, &fs, &flip)) {
+            A.item_order = 4;
+            A.front_split = split, A.front_e = fe, A.front_s = fs, A.front_flip = flip;
+            static const char* ratio = std::getenv("AMT_FRONT_RATIO");
+            if (ratio != nullptr) {
+                int e2 = 0, s2 = 0;
+                if (std::sscanf(ratio, "%d:%d", &e2, &s2) == 2 && e2 >= 1 && s2 >= 1) A.front_e = e2, A.front_s = s2;
+            }
+        } else if (A.item_order == 4) {
+            A.item_order = nadir_side(p);
+        }
+    }
     const bool use_tiles = sh.use_tiles;
     const int64_t n_items = sh.n_items;
     AMT_REQUIRE(ctx, n_items < (1ll << 31), "frame too large");

@@ -54,7 +54,8 @@ def payload_parts(results, device):
         ny, nx, nc = mean.shape
         packed = res.get('packed')
         if packed is not None and packed.device == mean.device and packed.numel() == ny * nx * (nc + 1):
-            parts.append(packed)        # the single-pass plan lays mean and count out one after the other already
+            # the single-pass plan lays mean and count out one after the other already
+            parts.append(packed if packed.device == torch.device(device) else packed.to(device))
         else:
             parts += [mean.reshape(-1).to(device), count.reshape(-1).to(device)]
         total += ny * nx * (nc + 1)
@@ -210,13 +211,17 @@ class Packer(object):
                 self.buf[base + off:base + off + packed.numel()].copy_(packed)
 
     def finish(self, results, indices):
-        """Descriptors, late frames and the trailer -> the buffer to send (on the current stream, which must be
-        ordered behind the pipeline's streams: it is once process() has returned)."""
+        """Descriptors, late frames and the trailer -> the buffer to send, written on the current stream.  The slices
+        that add() copied sit on the packer's own stream (the pipeline's finalise stream), which process() does NOT join
+        to the caller's stream for work enqueued by on_batch: the current stream is made to wait for it here, so the
+        collective (or any reader on the current stream) sees every frame's payload."""
         import torch
         assert self.frames == len(results), 'every frame of the call must have been added'
         buf, base = self.buf, self.max_frames * DESC_LEN
         if self.stream is not None:
-            buf.record_stream(torch.cuda.current_stream(buf.device))
+            current = torch.cuda.current_stream(buf.device)
+            current.wait_stream(self.stream)
+            buf.record_stream(current)
         if self.overflow or len(results) > self.max_frames:
             tail = [-1.0, 0.0]
         else:
@@ -331,6 +336,14 @@ def gather_device(results, indices, device, dst=0, group=None, capacity=None, pa
     return None
 
 
+def collective_device(compute_device, group=None):
+    """Where the tensors of the gather live: the GPU for "nccl" (= RCCL: device to device over xGMI), the host for
+    "gloo", whose gather takes CPU tensors only (the grids are a few hundred KB per frame)."""
+    import torch
+    import torch.distributed as dist
+    return compute_device if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+
+
 def gather_results(results, indices, device, dst=0, group=None):
     """:func:`gather_device` + unpacking on the host: the list of frame results sorted by frame index on `dst`."""
     g = gather_device(results, indices, device, dst, group)
@@ -357,7 +370,7 @@ def run_sequence(frames, width, height, altitude=110, fast=True, min_elevation=1
                            altitude=altitude, fast=fast, min_elevation=min_elevation, pxPerDeg=pxPerDeg,
                            magnetic=magnetic)
     results = seq.process([frames[k] for k in mine])
-    dev = seq.ctx.device
+    dev = collective_device(seq.ctx.device) if distributed else seq.ctx.device
     # every rank takes part in the collectives whatever its frames did: a frame without a valid pixel travels as
     # an empty descriptor and is reported in `failed`, it does not raise on one rank while the others wait
     failed = []

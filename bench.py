@@ -15,7 +15,7 @@ elevation), maskedByElevation(10), bounding box, 0.1 deg plate-carree grid, binn
 uint16 RGB image + elevation (BASELINE.json configs[2]; configs[1] is its first kernel).  Every frame has its OWN
 image, resident in HBM before the timed region (pointing, time, camera and image differ frame by
 frame); per-frame host set-up (matrices, grid) is inside the timed region.  With N > 1 every rank processes K frames
-of its own (weak scaling; K defaults to 32 so that N = 8 is the 256 frames of configs[4]) and the per-frame grids are
+of its own (weak scaling; K defaults to 192 for every N; `--gpus 8 --steps 32` is the 256 frames of configs[4]) and the per-frame grids are
 gathered on rank 0 over RCCL inside the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -88,6 +88,10 @@ def parse_args(argv=None):
                          'and the memory system are in their sustained state when the timed region starts (a cold chip '
                          'runs its first few dozen launches 3-5 %% slower; MI355X_MICROARCH.md asks for 2 s of back-to-back '
                          'launches before trusting an in-kernel clock); 0 disables')
+    ap.add_argument('--cpu-procs', type=int, default=16,
+                    help='processes of the N-process CPU baseline (cpu_baseline.n_process: one oracle process per frame, the '
+                         'reference\'s only data parallelism, SURVEY 8d (ii)); 0 = skip')
+    ap.add_argument('--cpu-worker', type=int, default=None, help=argparse.SUPPRESS)      # internal: one such process
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / reporting path only: gloo on the CPU, no GPU, a step is a sleep (tests)')
     args = ap.parse_args(argv)
@@ -242,6 +246,58 @@ def cpu_baseline(sample_rows, frames=4, parity=None):
                        'scale it by the core count at best)' % (frames, sample_rows, WIDTH, HEIGHT, npx / 1e6, t_geo, t_res))
 
 
+def cpu_frame(k, sample_rows):
+    """Frame k of the synthetic sequence (rows [0, sample_rows)) through the oracle -> (seconds georef, seconds mask + resample)."""
+    from oracle import ref_numpy as O
+    from auromat_amd.synthetic import sequence_frame, frame_image
+    from auromat_amd.coordinates import transform as T
+    hdr, cam, t, seed = sequence_frame(k, WIDTH, HEIGHT)
+    hdr = dict(hdr, IMAGEH=sample_rows)
+    img = frame_image(WIDTH, HEIGHT, seed=seed)[:sample_rows]
+    t0 = time.time()
+    et = T.date2es(t)
+    g = O.georef_frame(hdr, ALTITUDE, cam, O.mat_j2000_to_geo(et), None, fast=True)
+    t1 = time.time()
+    corner_mask, center_mask = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), MIN_ELEV)
+    bbox, disc = O.bbox_of_corners(g['lat'], g['lon'], corner_mask)
+    data = np.dstack((img.astype(np.float64), g['elev']))
+    data[center_mask] = np.nan
+    O.resample_mean(np.where(center_mask, np.nan, g['lat_c']), np.where(center_mask, np.nan, g['lon_c']),
+                    ALTITUDE, data, None, bbox, (PPD, PPD), disc, False)
+    return t0, t1, time.time()
+
+
+def cpu_worker(k, sample_rows):
+    """`bench.py --cpu-worker k --cpu-rows R`: one process of the N-process CPU baseline; touches no GPU."""
+    t0, t1, t2 = cpu_frame(k, sample_rows)
+    print(json.dumps({'frame': k, 'start': t0, 'georef_done': t1, 'end': t2}))
+
+
+def cpu_baseline_n_process(sample_rows, procs):
+    """The reference's only data parallelism is one process per frame (a plain map over the frames, mapping/spacecraft.py:
+    326-332): `procs` processes, each one frame (rows [0, sample_rows)) through the oracle, started together
+    as children.  The span runs from the first worker's start of compute to the last one's end (interpreter start-up and
+    the image generation are left out, as in the one-core figure)."""
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-rows', str(sample_rows), '--cpu-worker']
+    children = [subprocess.Popen(cmd + [str(k)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, universal_newlines=True)
+                for k in range(procs)]
+    rows = []
+    for c in children:
+        o, _ = c.communicate()
+        if c.returncode != 0:
+            return {'error': 'a worker exited with code %d' % c.returncode}
+        rows.append(json.loads(o.strip().splitlines()[-1]))
+    span = max(r['end'] for r in rows) - min(r['start'] for r in rows)
+    per_proc = sum(r['end'] - r['start'] for r in rows) / len(rows)
+    npx = WIDTH * sample_rows * procs
+    return dict(value=npx / 1e6 / span, unit='Mpixels/s', cores=procs, processes=procs, seconds=span,
+                mean_seconds_per_process=per_proc,
+                sample='%d processes, one frame of the sequence each (rows 0..%d of %dx%d: %.1f Mpx in all), NumPy oracle, '
+                       '1 thread per process; span from the first start of compute to the last end' % (
+                           procs, sample_rows, WIDTH, HEIGHT, npx / 1e6))
+
+
 def check_against_oracle(hdr, cam, t, img, g, res):
     """BASELINE.json's second figure, max |dlat, dlon| vs ref: the HIP path (single-pass plan) on the frame the CPU
     baseline has just computed with the oracle — coordinate arrays, NaN patterns and the resampled grid."""
@@ -346,6 +402,8 @@ def main(argv=None):
     args = parse_args(argv)
     global LAUNCH_STREAMS
     LAUNCH_STREAMS = args.launch_streams
+    if args.cpu_worker is not None:
+        return cpu_worker(args.cpu_worker, min(args.cpu_rows, HEIGHT))
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_children(argv))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -597,6 +655,11 @@ def main(argv=None):
         if world == 1 and args.cpu_rows > 0:
             parity = {}
             out['cpu_baseline'] = cpu_baseline(min(args.cpu_rows, HEIGHT), parity=parity)
+            if args.cpu_procs > 0:
+                # (ii) of SURVEY 8d: the same oracle, one process per frame on `procs` host cores (half the rows each: 16
+                # whole frames at once would need ~50 GB of NumPy temporaries)
+                procs = max(1, min(args.cpu_procs, os.cpu_count() or 1))
+                out['cpu_baseline']['n_process'] = cpu_baseline_n_process(min(args.cpu_rows, HEIGHT // 2), procs)
             # max |dlat, dlon| vs ref (BASELINE.json's metric names it beside the throughput)
             out['parity'] = parity
         else:

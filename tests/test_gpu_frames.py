@@ -560,6 +560,15 @@ def test_sequence_with_a_pole_frame_uint8_and_magnetic():
         assert np.array_equal(a['mean'], b['mean'], equal_nan=True) and np.array_equal(a['count'], b['count'])
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def test_gather_over_rccl_single_rank():
     """run_sequence() with an initialised "nccl" (= RCCL) process group of one rank: the collectives of the gather
     (all_gather of sizes, padded gather of [descriptors | payload]) run on device tensors."""
@@ -573,7 +582,7 @@ def test_gather_over_rccl_single_rank():
         hdr, cam, t, seed = sequence_frame(k, w, h)
         frames.append((hdr, cam, t, frame_image(w, h, seed=seed)))
     plain = run_sequence(frames, w, h, pxPerDeg=6)            # no process group: local packing only
-    store = dist.TCPStore('127.0.0.1', 29533, 1, True)
+    store = dist.TCPStore('127.0.0.1', _free_port(), 1, True)
     dist.init_process_group('nccl', store=store, rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
         got = run_sequence(frames, w, h, pxPerDeg=6)

@@ -107,7 +107,7 @@ def test_one_band_over_rccl():
     hdr, cam, t = pole_frame(w, h)
     img = frame_image(w, h, seed=3)
     ref = FramePipeline(w, h).run(hdr, 110, cam, t, img=img, min_elevation=10, pxPerDeg=8, fuse=False)
-    store = dist.TCPStore('127.0.0.1', 29537, 1, True)
+    store = dist.TCPStore('127.0.0.1', free_port(), 1, True)
     dist.init_process_group('nccl', store=store, rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
         res, pipe, (y0, y1) = resample_frame_sharded(hdr, 110, cam, t, img, pxPerDeg=8, min_elevation=10)
