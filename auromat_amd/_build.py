@@ -25,7 +25,7 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + [os.path.join(CSRC, 'amt_common.h'), os.path.join(CSRC, 'amt_grid.h'),
+    deps = sources() + [os.path.join(CSRC, 'amt_common.h'), os.path.join(CSRC, 'amt_grid.h'), os.path.join(CSRC, 'amt_params.h'),
                         os.path.join(os.path.dirname(PKG_DIR), 'include', 'auromat_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 

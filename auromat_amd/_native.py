@@ -71,7 +71,29 @@ class PipeResult(C.Structure):
                 ('bbox', C.c_double * 8), ('grid', Grid)]
 
 
-ABI_VERSION = 2          # include/auromat_hip.h AMT_ABI_VERSION
+class RunConfig(C.Structure):
+    """amt_run_config"""
+    _fields_ = [(k, C.c_int32) for k in ('width', 'height', 'img_dtype', 'fast_center', 'magnetic', 'batch', 'use_hints',
+                                         'n_slots')] + \
+               [(k, C.c_double) for k in ('altitude', 'min_elevation', 'lat_px_per_deg', 'lon_px_per_deg')] + \
+               [('slots', C.POINTER(GeorefOut))]
+
+
+class RunFrame(C.Structure):
+    """amt_run_frame"""
+    _fields_ = [('crval', C.c_double * 2), ('crpix', C.c_double * 2), ('cd', C.c_double * 4), ('lonpole', C.c_double),
+                ('cam', C.c_double * 3), ('jd', C.c_double), ('altitude', C.c_double), ('img', C.c_void_p)]
+
+
+class RunResult(C.Structure):
+    """amt_run_result"""
+    _fields_ = [(k, C.c_int32) for k in ('status', 'slot', 'ny', 'nx', 'contains_pole', 'lon_wrapped', 'hinted',
+                                         'edge_pixels')] + \
+               [('grid_offset', C.c_int64), ('image_offset', C.c_int64), ('bbox', C.c_double * 8), ('altitude', C.c_double),
+                ('grid', Grid), ('params', FrameParams)]
+
+
+ABI_VERSION = 3          # include/auromat_hip.h AMT_ABI_VERSION
 _I, _L, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p
 _SIGNATURES = {
     'amt_abi_version': ([], _I),
@@ -114,6 +136,7 @@ _SIGNATURES = {
     'amt_georef_frame': ([_P, C.POINTER(FrameParams), C.POINTER(GeorefOut)], _I),
     'amt_georef_frame_dirs': ([_P, C.POINTER(FrameParams), _P, C.POINTER(GeorefOut)], _I),
     'amt_georef_coarse_bbox': ([_P, C.POINTER(FrameParams), C.c_int32, _D, _I, _P], _I),
+    'amt_georef_sky_rows': ([C.POINTER(FrameParams)] + [C.POINTER(C.c_int32)] * 4, _I),
     'amt_mask_by_elevation': ([_P, _P, _P, C.c_int32, C.c_int32, _D, _P, _P, _P], _I),
     'amt_sanitize_masks': ([_P, _P, _P, _P, C.c_int32, C.c_int32, _I], _I),
     'amt_bbox_corners': ([_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P], _I),
@@ -142,6 +165,15 @@ _SIGNATURES = {
     'amt_pipe_finalize_stream': ([_P, _P], _I),
     'amt_pipe_finalize_many': ([_P, C.c_int32, _P, _P, _P, _P], _I),
     'amt_pipe_join': ([_P], _I),
+    'amt_frame_params_from_wcs': ([C.POINTER(RunFrame), C.c_int32, C.c_int32, C.c_int32, _D, C.c_int32,
+                                   C.POINTER(FrameParams)], _I),
+    'amt_run_create': ([_P, C.POINTER(RunConfig), c_void_pp], _I),
+    'amt_run_destroy': ([_P], _I),
+    'amt_run_process': ([_P, C.POINTER(RunFrame), C.c_int32, _P, _L, _P, _L, C.POINTER(RunResult), C.POINTER(C.c_int32)], _I),
+    'amt_run_begin': ([_P, _P, _L, _P, _L, C.POINTER(RunResult), C.c_int32], _I),
+    'amt_run_push': ([_P, C.POINTER(RunFrame)], _I),
+    'amt_run_end': ([_P, C.POINTER(C.c_int32)], _I),
+    'amt_run_reset_hints': ([_P], _I),
     'amt_seq_payload_size': ([C.POINTER(SeqFrame), C.c_int32, C.POINTER(_L)], _I),
     'amt_seq_pack': ([_P, C.POINTER(SeqFrame), C.c_int32, C.c_int32, _P, _L], _I),
     'amt_seq_unpack': ([_P, _L, C.c_int32, C.c_int32, C.POINTER(SeqFrame), C.c_int32, C.POINTER(C.c_int32)], _I),

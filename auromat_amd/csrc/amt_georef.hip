@@ -121,6 +121,9 @@ struct georef_args {
     // on, rows [0, front_split) — the sky side — from front_split - 1 backwards, front_e of the one for every front_s
     // of the other; front_flip mirrors the frame first (Earth above the limb)
     int front_split, front_e, front_s, front_flip;
+    // rows of work items that cannot see the shell (sky_bands(): rows [0, sky_top_end) and [sky_bottom_begin, n)); their
+    // waves write NaN and cast no ray
+    int sky_top_end, sky_bottom_begin;
     int bin_pole, pad_pole_;            // amt_georef_out.bin_pole: bin (and box) in the coordinates rotated by 90 deg about x
     pole_consts pole;
     bin_event* bin_events;      // optional list for on-edge pixels (amt_georef_out.bin_events)
@@ -560,6 +563,43 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
     const bool col_ok = gx <= A.width;                 // this lane's corner column exists
     const bool px_ok = lane < 63 && gx < A.width;      // this lane's pixel column exists (and is owned)
     const bool want_bbox = A.bbox_partials != nullptr;
+
+    if (!DIRS_IN && (chunk < A.sky_top_end || chunk >= A.sky_bottom_begin)) {      // wave-uniform
+        // No ray of this item reaches the shell (the host has bounded the conic section that the limb is in the image,
+        // sky_bands()): its part of every output array is NaN, nothing is binned, its box partial is the empty one.
+        const double nan = NAN;
+        unsigned int oc = (unsigned int)(y0 * W1 + gx) * 8u, op = (unsigned int)((y0 - 1) * A.width + gx) * 8u;
+        const unsigned int pc_ = (unsigned int)W1 * 8u, pp_ = (unsigned int)A.width * 8u;
+        auto at_ = [](double* base, unsigned int byte_offset) -> double& {
+            return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_offset);
+        };
+        const bool mag_out = MAG && !kPole;
+        for (int r = 0; r <= rows; ++r) {
+            const int gy = y0 + r;
+            if (col_ok && (lane < 63 || gx == A.width) && (r < rows || gy == A.height)) {
+                if (A.lat) at_(A.lat, oc) = nan;
+                if (A.lon) at_(A.lon, oc) = nan;
+                if (mag_out && A.mlat) {
+                    at_(A.mlat, oc) = nan;
+                    at_(A.mlt, oc) = nan;
+                }
+            }
+            if (r > 0 && px_ok) {
+                if (A.lat_c) at_(A.lat_c, op) = nan;
+                if (A.lon_c) at_(A.lon_c, op) = nan;
+                if (A.elev) at_(A.elev, op) = nan;
+                if (mag_out && A.mlat_c) {
+                    at_(A.mlat_c, op) = nan;
+                    at_(A.mlt_c, op) = nan;
+                }
+            }
+            oc += pc_;
+            op += pp_;
+        }
+        if (want_bbox && lane < 8)
+            A.bbox_partials[(int64_t)item * 8 + lane] = lane >= 6 ? 0.0 : ((lane & 1) ? -kInf : kInf);
+        return;
+    }
 
     // The constants of the common path are read ONCE, before the row loop, and stay in SGPRs (the compiler parks what
     // does not fit in VGPR lanes, a v_readlane per use).  Re-reading them from the kernel-argument segment in every
@@ -1376,6 +1416,115 @@ bool ray_hits_host(const affine_cam& c, const shell_ray& e, double x, double y) 
     return (nb + e.root_sign * std::sqrt(disc)) / a2 >= 0;
 }
 
+// Which rows of work items cannot see the shell?  A corner (x, y) hits when disc(x, y) >= 0 and the root is in front of
+// the camera, which for a camera outside the shell needs nb(x, y) >= 0 (shell_t: t = (nb - sqrt(disc)) / a2).  With the
+// affine camera model nb is LINEAR and disc QUADRATIC in (x, y) — the limb is a conic section in the image and the set of
+// hits is convex —, so both are bounded exactly over a line: a horizontal band of the frame is free of hits when its two
+// long sides and its two short sides are (a convex set that meets the band without touching its border would have to
+// lie inside it: excluded below by the apparent size of the Earth).  disc is sampled at three columns, each a quadratic
+// in y fitted through three rows; per line of corners that costs three evaluations.  The bands are taken a pixel wider
+// than the rows of an item (exact centre rays lie between the corners) and a line only counts as free of hits when
+// max disc < -1e-9 of its scale or max nb < 0: anything nearer to the limb than that goes the ordinary way.
+void sky_bands(const georef_args& A, const launch_shape& sh, int* top_end, int* bottom_begin) {
+    const int n = sh.chunks_y;
+    *top_end = 0, *bottom_begin = n;
+    const shell_ray& e = A.sray;
+    if (!(e.root_sign < 0)) return;                       // camera inside the shell: every ray hits
+    const double W = A.width, H = A.height;
+    auto eval = [&](double x, double y, double* nb_out) {
+        const affine_cam& c = A.cam;
+        const double px = x + c.cx, py = y + c.cy;
+        const double ux = c.u0[0] + px * c.ux[0] + py * c.uy[0], uy = c.u0[1] + px * c.ux[1] + py * c.uy[1],
+                     uz = c.u0[2] + px * c.ux[2] + py * c.uy[2];
+        const double uu = ux * ux + uy * uy + uz * uz;
+        const double ku = ux * e.kx + uy * e.ky + uz * e.kz, uo = ux * e.ox + uy * e.oy + uz * e.oz;
+        const double a2 = e.qd * ku * ku + e.qa * uu, nb = -(e.qa * uo + e.qd_ko * ku);
+        *nb_out = nb;
+        return nb * nb - a2 * e.c0;
+    };
+    // the Earth must be far larger in the image than a band is tall (see above): apparent radius of the shell against
+    // the angle a band spans
+    {
+        const double oo = std::sqrt(e.ox * e.ox + e.oy * e.oy + e.oz * e.oz);
+        const double sin_rho = std::min(1.0, 1.0 / (std::sqrt(e.qa) * oo));             // ~ a / |camera|
+        const double px_scale = std::sqrt(std::max(A.cam.uy[0] * A.cam.uy[0] + A.cam.uy[1] * A.cam.uy[1] + A.cam.uy[2] * A.cam.uy[2],
+                                                   A.cam.ux[0] * A.cam.ux[0] + A.cam.ux[1] * A.cam.ux[1] + A.cam.ux[2] * A.cam.ux[2])) / kRad2Deg;
+        if (!(std::asin(sin_rho) > 8.0 * (sh.rows_per_chunk + 2) * px_scale)) return;
+    }
+    // quadratic through (t0, f0), (t1, f1), (t2, f2) with t1 the midpoint: coefficients of f(t0 + s), s in [0, L]
+    struct quad {
+        double a, b, c, L;
+        double at(double s) const { return (a * s + b) * s + c; }
+        double max_on(double s0, double s1) const {
+            double m = std::max(at(s0), at(s1));
+            if (a < 0) {
+                const double v = -b / (2 * a);
+                if (v > s0 && v < s1) m = std::max(m, at(v));
+            }
+            return m;
+        }
+    };
+    auto fit = [](double f0, double f1, double f2, double L) {
+        quad q;
+        q.L = L;
+        q.c = f0;
+        q.a = 2 * (f2 - 2 * f1 + f0) / (L * L);
+        q.b = (f2 - f0) / L - q.a * L;
+        return q;
+    };
+    const double x0 = -1.0, xL = W + 2.0, y0 = -1.0, yL = H + 2.0;        // one pixel beyond the corners on every side
+    // disc along three columns (as quadratics in y) and nb as a plane
+    double nb00, nb10, nb01, tmp;
+    quad col[3];
+    double scale = 0;
+    for (int k = 0; k < 3; ++k) {
+        const double x = x0 + 0.5 * k * xL;
+        double f[3];
+        for (int j = 0; j < 3; ++j) {
+            f[j] = eval(x, y0 + 0.5 * j * yL, &tmp);
+            scale = std::max(scale, std::max(std::fabs(f[j]), tmp * tmp));
+        }
+        col[k] = fit(f[0], f[1], f[2], yL);
+    }
+    eval(x0, y0, &nb00);
+    eval(x0 + xL, y0, &nb10);
+    eval(x0, y0 + yL, &nb01);
+    const double nbx = (nb10 - nb00) / xL, nby = (nb01 - nb00) / yL;
+    const double tol = 1e-9 * scale, nb_tol = 1e-9 * std::sqrt(scale);
+    if (!(scale > 0) || !std::isfinite(scale)) return;
+    // a segment [s0, s1] of a line on which disc is the quadratic q and nb = n0 + slope * s: free of hits when disc < 0
+    // wherever nb >= 0 (nb is linear: that part of the segment is an interval)
+    auto segment_free = [&](const quad& q, double n0, double slope, double s0, double s1) {
+        double a = s0, b = s1;                            // the part with nb >= -nb_tol
+        const double na = n0 + slope * s0 + nb_tol, nbv = n0 + slope * s1 + nb_tol;
+        if (na < 0 && nbv < 0) return true;
+        if (na < 0) a = s0 + (s1 - s0) * (-na) / (nbv - na);
+        if (nbv < 0) b = s0 + (s1 - s0) * na / (na - nbv);
+        return q.max_on(a, b) < -tol;
+    };
+    // a horizontal line at height s (above y0): free of hits?
+    auto line_free = [&](double s) {
+        const quad q = fit(col[0].at(s), col[1].at(s), col[2].at(s), xL);
+        return segment_free(q, nb00 + nby * s, nbx, 0.0, xL);
+    };
+    // a piece [s0, s1] of the left (k = 0) or right (k = 2) side: free of hits?
+    auto side_free = [&](int k, double s0, double s1) {
+        return segment_free(col[k], nb00 + (k == 2 ? nbx * xL : 0.0), nby, s0, s1);
+    };
+    auto band_free = [&](int c) {
+        // corner rows c R ... min((c + 1) R, H), a pixel more on both sides; s counts from y0 = -1
+        const double s0 = (double)c * sh.rows_per_chunk, s1 = std::min((double)(c + 1) * sh.rows_per_chunk, H) + 2.0;
+        return line_free(s0) && line_free(s1) && side_free(0, s0, s1) && side_free(2, s0, s1);
+    };
+    int t = 0;
+    while (t < n && band_free(t)) ++t;
+    *top_end = t;
+    if (t == n) return;                                   // a frame of sky: everything is in the first range
+    int b = n;
+    while (b > t && band_free(b - 1)) --b;
+    *bottom_begin = b;
+}
+
 // item_order 4: where the limb cuts the frame's rows of work items.  The middle row of every chunk is probed in three
 // columns; when the chunks that see the Earth are one run that reaches the first or the last row of chunks and the sky
 // takes at least an eighth of the frame, the launch works on two fronts from the limb (see two_front_chunk), the
@@ -1525,6 +1674,9 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     }
     const launch_shape sh = shape_of(p);
     A.chunk_stride = interleave_stride(sh.chunks_y);
+    A.sky_top_end = 0, A.sky_bottom_begin = sh.chunks_y;
+    static const bool no_sky_path = std::getenv("AMT_NO_SKY_PATH") != nullptr;      // A/B runs
+    if (dirs == nullptr && !sh.use_tiles && !no_sky_path) sky_bands(A, sh, &A.sky_top_end, &A.sky_bottom_begin);
     // two fronts from the limb (item_order 4; AMT_ITEM_ORDER=4, AMT_FRONT_RATIO = "e:s" overrides the proportion of the two
     // fronts).  Measured (profiles/r3/x_ab_two_front_order.txt): 135 / 168 us (georef only / fused, kernel alone) against
     // 126 / 153 us for the side-first order — sky rows (stores only) and Earth rows (VALU-bound) in flight TOGETHER are
@@ -1713,6 +1865,32 @@ int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stri
     hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, ctx->stream, partials, nblocks, bbox,
                        (const unsigned int*)nullptr);
     AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_georef_sky_rows(const amt_frame_params* p, int32_t* rows_per_item, int32_t* n_item_rows, int32_t* top_end,
+                        int32_t* bottom_begin) {
+    if (p == nullptr || rows_per_item == nullptr || n_item_rows == nullptr || top_end == nullptr || bottom_begin == nullptr)
+        return AMT_EINVAL;
+    if (p->width <= 0 || p->height <= 0) return AMT_EINVAL;
+    georef_args A;
+    std::memset(&A, 0, sizeof(A));
+    A.wcs = make_tan_wcs(p);
+    double rot_geo[9];
+    mat_mul3(p->m_geo, p->rot, rot_geo);
+    tan_wcs wcs_geo = A.wcs;
+    wcs_geo.rot = make_mat3(rot_geo);
+    A.cam = make_affine_cam(wcs_geo);
+    A.sray = make_shell_ray(p->a, p->b, p->cam, p->m_geo);
+    A.width = p->width;
+    A.height = p->height;
+    const launch_shape sh = shape_of(p);
+    int t = 0, b = sh.chunks_y;
+    sky_bands(A, sh, &t, &b);
+    *rows_per_item = sh.rows_per_chunk;
+    *n_item_rows = sh.chunks_y;
+    *top_end = t;
+    *bottom_begin = b;
     return AMT_OK;
 }
 

@@ -1,0 +1,412 @@
+// Native sequence runner (include/auromat_hip.h, "native sequence runner"): the per-frame host loop of a sequence —
+// host scalars, box hints, launches, waits, grid layouts, finalise kernels — in one C call.  Host orchestration only;
+// it drives the single-pass frame drivers of amt_pipe.hip through their public entry points.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "amt_common.h"
+#include "amt_params.h"
+
+struct amt_run {
+    amt_ctx* ctx;
+    amt_run_config cfg;
+    std::vector<amt_pipe*> pipes;
+    std::vector<amt_georef_out> outs;       // per slot: the caller's arrays (+ the altitude of the frame in the slot)
+    std::vector<amt_frame_params> prm;      // per slot: the frame in flight
+    std::vector<double> alt;                // per slot
+    std::vector<int> hinted;                // per slot
+    hipEvent_t entry;                       // the context's stream at the start of a call (the finalise stream waits for it)
+    // box hints: the two latest frames finished by the single-pass plan (exact reduction, params, running index)
+    struct hint {
+        bool valid;
+        double box[8];
+        amt_frame_params p;
+        long long index;
+    } last, prev;
+    long long frames_done;
+    // the call in progress (amt_run_begin ... amt_run_end)
+    bool active, full;
+    double* grids;
+    char* images;
+    int64_t grids_capacity, images_capacity, grid_used, image_used;
+    amt_run_result* results;
+    int max_frames, n_pushed;
+    int batch_k0, batch_count;              // prepared frames of the batch being collected
+    int launched[2][2], n_launched;         // (first frame, count) of the batches in flight, older first
+    std::vector<const void*> img;           // per slot: the image of the frame in the slot
+};
+
+namespace {
+
+bool all_within(const double* a, const double* b, int n, double tol) {
+    for (int i = 0; i < n; ++i)
+        if (std::fabs(a[i] - b[i]) > tol) return false;
+    return true;
+}
+
+// neighbours in a sequence (auromat_amd/pipeline.py _close): same frame size, camera model within 1 % in scale, camera
+// within 100 km, boresight and Earth rotation within about half a degree, shell within 30 km
+bool close_frames(const amt_frame_params& a, const amt_frame_params& b) {
+    if (a.width != b.width || a.height != b.height || a.fast_center != b.fast_center) return false;
+    if (std::fabs(a.a - b.a) > 30.0 || std::fabs(a.b - b.b) > 30.0) return false;
+    double cd_max = 0;
+    for (int i = 0; i < 4; ++i) cd_max = std::max(cd_max, std::fabs(a.cd[i]));
+    return all_within(a.cam, b.cam, 3, 100.0) && all_within(a.rot, b.rot, 9, 0.01) && all_within(a.m_geo, b.m_geo, 9, 0.01) &&
+           all_within(a.m_sm, b.m_sm, 9, 0.01) && all_within(a.cd, b.cd, 4, 0.01 * cd_max) && all_within(a.crpix, b.crpix, 2, 5.0);
+}
+
+// frames a, b (n_ab apart) and c (n_bc after b): a steady sequence (auromat_amd/pipeline.py _steady)
+bool steady_frames(const amt_frame_params& a, const amt_frame_params& b, const amt_frame_params& c, long long n_ab, long long n_bc) {
+    if (n_ab <= 0 || n_bc <= 0 || n_bc > 16) return false;
+    if (b.width != c.width || b.height != c.height || b.fast_center != c.fast_center) return false;
+    if (std::fabs(b.a - c.a) > 30.0 || std::fabs(b.b - c.b) > 30.0) return false;
+    if (!(all_within(b.cam, c.cam, 3, 400.0) && all_within(b.rot, c.rot, 9, 0.05) && all_within(b.m_geo, c.m_geo, 9, 0.05) &&
+          all_within(b.m_sm, c.m_sm, 9, 0.05) && all_within(b.crpix, c.crpix, 2, 5.0)))
+        return false;
+    const double scale_b = std::sqrt(std::fabs(b.cd[0] * b.cd[3] - b.cd[1] * b.cd[2]));
+    const double scale_c = std::sqrt(std::fabs(c.cd[0] * c.cd[3] - c.cd[1] * c.cd[2]));
+    if (!(scale_b > 0 && std::fabs(scale_c - scale_b) <= 0.01 * scale_b)) return false;
+    for (int i = 0; i < 4; ++i) {
+        const double step = (b.cd[i] - a.cd[i]) / n_ab;
+        if (std::fabs((c.cd[i] - b.cd[i]) - step * n_bc) > 0.3 * std::fabs(step * n_bc) + 0.01 * scale_b) return false;
+    }
+    for (int i = 0; i < 3; ++i) {
+        const double step = (b.cam[i] - a.cam[i]) / n_ab;
+        if (std::fabs((c.cam[i] - b.cam[i]) - step * n_bc) > 0.2 * std::fabs(step * n_bc) + 5.0) return false;
+    }
+    for (int i = 0; i < 9; ++i) {
+        const double step = (b.rot[i] - a.rot[i]) / n_ab;
+        if (std::fabs((c.rot[i] - b.rot[i]) - step * n_bc) > 0.3 * std::fabs(step * n_bc) + 2e-3) return false;
+    }
+    return true;
+}
+
+// estimate of frame k's box reduction from finished frames (auromat_amd/pipeline.py SequencePipeline._box_hint)
+bool box_hint(const amt_run* run, long long k, const amt_frame_params& p, double* est) {
+    const amt_run::hint &last = run->last, &prev = run->prev;
+    if (!last.valid) return false;
+    if (close_frames(last.p, p)) {
+        std::memcpy(est, last.box, sizeof(last.box));
+        return true;
+    }
+    if (!prev.valid || !close_frames(prev.p, last.p) || !steady_frames(prev.p, last.p, p, last.index - prev.index, k - last.index))
+        return false;
+    if ((prev.box[7] != 0) != (last.box[7] != 0) || (last.box[3] - last.box[2] > 180) != (prev.box[3] - prev.box[2] > 180))
+        return false;                               // a pole or the date line came into view between the two
+    const double f = (double)(k - last.index) / (double)(last.index - prev.index);
+    for (int i = 0; i < 6; ++i) est[i] = last.box[i] + f * (last.box[i] - prev.box[i]);
+    est[6] = last.box[6], est[7] = last.box[7];
+    est[0] = std::max(est[0], -90.0), est[1] = std::min(est[1], 90.0);
+    for (int i = 2; i < 6; ++i) est[i] = std::min(std::max(est[i], -180.0), 180.0);
+    return true;
+}
+
+int64_t image_bytes(const amt_run* run, int64_t cells) {
+    return (cells * 3 * (run->cfg.img_dtype == 2 ? 2 : 1) + cells + 255) & ~(int64_t)255;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amt_frame_params_from_wcs(const amt_run_frame* frame, int32_t width, int32_t height, int32_t fast_center,
+                              double altitude, int32_t want_sm, amt_frame_params* out) {
+    if (frame == nullptr || out == nullptr || width <= 0 || height <= 0) return AMT_EINVAL;
+    return amt_prm::frame_params(frame, width, height, fast_center, altitude, want_sm, out);
+}
+
+int amt_run_create(amt_ctx* ctx, const amt_run_config* config, amt_run** out_run) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, config != nullptr && out_run != nullptr, "NULL argument");
+    *out_run = nullptr;
+    AMT_REQUIRE(ctx, config->width > 0 && config->height > 0, "empty frame");
+    AMT_REQUIRE(ctx, config->img_dtype == 1 || config->img_dtype == 2, "img_dtype must be 1 (uint8) or 2 (uint16)");
+    AMT_REQUIRE(ctx, config->batch >= 1 && config->batch <= AMT_PIPE_MAX_BATCH, "batch out of range");
+    AMT_REQUIRE(ctx, config->n_slots >= 2 * config->batch && config->slots != nullptr, "n_slots must be at least 2 * batch");
+    AMT_REQUIRE(ctx, config->lat_px_per_deg > 0 && config->lon_px_per_deg > 0, "px per degree must be positive");
+    amt_run* run = new (std::nothrow) amt_run();
+    if (run == nullptr) return AMT_ENOMEM;
+    run->ctx = ctx;
+    run->cfg = *config;
+    run->entry = nullptr;
+    run->last.valid = run->prev.valid = false;
+    run->frames_done = 0;
+    const int ns = config->n_slots;
+    run->outs.assign(config->slots, config->slots + ns);
+    run->cfg.slots = nullptr;
+    run->prm.resize(ns);
+    run->alt.assign(ns, config->altitude);
+    run->hinted.assign(ns, 0);
+    run->img.assign(ns, nullptr);
+    run->active = run->full = false;
+    run->n_launched = 0, run->batch_count = 0;
+    run->pipes.assign(ns, nullptr);
+    if (amt_set_device(ctx)) {
+        delete run;
+        return AMT_EHIP;
+    }
+    for (int i = 0; i < ns; ++i) {
+        const int rc = amt_pipe_create(ctx, &run->pipes[i]);
+        if (rc != AMT_OK) {
+            amt_run_destroy(run);
+            return rc;
+        }
+    }
+    if (hipEventCreateWithFlags(&run->entry, hipEventDisableTiming) != hipSuccess) {
+        ctx->last_error = "amt_run_create: event creation failed";
+        amt_run_destroy(run);
+        return AMT_EHIP;
+    }
+    *out_run = run;
+    return AMT_OK;
+}
+
+int amt_run_destroy(amt_run* run) {
+    if (run == nullptr) return AMT_EINVAL;
+    for (amt_pipe* p : run->pipes)
+        if (p != nullptr) amt_pipe_destroy(p);
+    if (run->entry) (void)hipEventDestroy(run->entry);
+    delete run;
+    return AMT_OK;
+}
+
+int amt_run_reset_hints(amt_run* run) {
+    if (run == nullptr) return AMT_EINVAL;
+    run->last.valid = run->prev.valid = false;
+    return AMT_OK;
+}
+
+// ---- the loop as a state machine: begin / push (one frame at a time) / end ------------------------------------------
+// The batches in flight form a queue of at most two: when a batch of prepared frames is complete, the older launched
+// batch is finished first if two are in flight (wait for the boxes, lay out the grids, one finalise kernel), then the new
+// batch is launched.  That is the order of the loop `launch(B); prepare(C); finish(A)` with the frames arriving one by
+// one, so the first launch happens after the first frame's preparation whatever the length of the sequence.
+
+namespace {
+
+int run_finish(amt_run* run, int k0, int count) {
+    amt_ctx* ctx = run->ctx;
+    const amt_run_config& cfg = run->cfg;
+    const int ns = cfg.n_slots;
+    amt_pipe* pp[AMT_PIPE_MAX_BATCH];
+    double* mean[AMT_PIPE_MAX_BATCH];
+    void* oimg[AMT_PIPE_MAX_BATCH];
+    uint8_t* omask[AMT_PIPE_MAX_BATCH];
+    double* ocount[AMT_PIPE_MAX_BATCH];
+    int m = 0;
+    (void)ctx;
+    for (int i = 0; i < count; ++i) {
+        const int k = k0 + i, slot = k % ns;
+        amt_run_result& r = run->results[k];
+        std::memset(&r, 0, sizeof(r));
+        r.slot = slot;
+        r.hinted = run->hinted[slot];
+        r.altitude = run->alt[slot];
+        r.params = run->prm[slot];
+        amt_pipe_result pr;
+        if (int rc = amt_pipe_wait(run->pipes[slot], &pr)) return rc;
+        r.status = pr.status;
+        std::memcpy(r.bbox, pr.bbox, sizeof(r.bbox));
+        r.edge_pixels = pr.edge_pixels;
+        if (pr.status != 0) {
+            run->last.valid = run->prev.valid = false;      // the next frame gets a real pre-pass
+            continue;
+        }
+        const int64_t cells = (int64_t)pr.grid.ny * pr.grid.nx;
+        const int64_t ib = image_bytes(run, cells);
+        if (run->full || run->grid_used + 5 * cells > run->grids_capacity || run->image_used + ib > run->images_capacity) {
+            // no room: this frame's accumulators are dropped with the frame (the driver zeroes them before its next
+            // launch); the caller runs the rest again with larger arenas
+            run->full = true;
+            r.status = 3;
+            continue;
+        }
+        r.ny = pr.grid.ny, r.nx = pr.grid.nx;
+        r.contains_pole = pr.bbox[7] != 0 ? 1 : 0;
+        r.lon_wrapped = pr.lon_wrapped;
+        r.grid = pr.grid;
+        r.grid_offset = run->grid_used;
+        r.image_offset = run->image_used;
+        pp[m] = run->pipes[slot];
+        mean[m] = run->grids + run->grid_used;
+        ocount[m] = run->grids + run->grid_used + 4 * cells;
+        oimg[m] = run->images + run->image_used;
+        omask[m] = reinterpret_cast<uint8_t*>(run->images + run->image_used + cells * 3 * (cfg.img_dtype == 2 ? 2 : 1));
+        ++m;
+        run->grid_used += 5 * cells;
+        run->image_used += ib;
+        run->prev = run->last;
+        run->last.valid = true;
+        std::memcpy(run->last.box, pr.bbox, sizeof(pr.bbox));
+        run->last.p = run->prm[slot];
+        run->last.index = run->frames_done + k;
+    }
+    if (m > 0)
+        if (int rc = amt_pipe_finalize_many(pp, m, mean, oimg, omask, ocount)) return rc;
+    return AMT_OK;
+}
+
+int run_launch(amt_run* run, int k0, int count) {
+    amt_ctx* ctx = run->ctx;
+    const amt_run_config& cfg = run->cfg;
+    const int ns = cfg.n_slots;
+    amt_pipe* pp[AMT_PIPE_MAX_BATCH];
+    const amt_frame_params* prm[AMT_PIPE_MAX_BATCH];
+    const amt_georef_out* oo[AMT_PIPE_MAX_BATCH];
+    const void* ii[AMT_PIPE_MAX_BATCH];
+    for (int i = 0; i < count; ++i) {
+        const int slot = (k0 + i) % ns;
+        run->outs[slot].altitude = run->alt[slot];
+        pp[i] = run->pipes[slot], prm[i] = &run->prm[slot], oo[i] = &run->outs[slot], ii[i] = run->img[slot];
+        if (ii[i] == nullptr) {
+            ctx->last_error = "amt_run: a frame has no image";
+            return AMT_EINVAL;
+        }
+    }
+    return amt_pipe_launch_many(pp, count, prm, oo, ii, cfg.img_dtype, cfg.min_elevation, cfg.lat_px_per_deg,
+                                cfg.lon_px_per_deg, -1, cfg.magnetic ? 1 : 0);
+}
+
+// a complete batch of prepared frames (k0, count): finish the older of two batches in flight, then launch it
+int run_batch_ready(amt_run* run, int k0, int count) {
+    if (run->n_launched == 2) {
+        if (int rc = run_finish(run, run->launched[0][0], run->launched[0][1])) return rc;
+        run->launched[0][0] = run->launched[1][0], run->launched[0][1] = run->launched[1][1];
+        run->n_launched = 1;
+    }
+    if (run->full) {
+        // the arenas ran full: frames that were only prepared are reported as not processed
+        for (int i = 0; i < count; ++i) {
+            std::memset(&run->results[k0 + i], 0, sizeof(amt_run_result));
+            run->results[k0 + i].status = 3;
+        }
+        return AMT_OK;
+    }
+    if (int rc = run_launch(run, k0, count)) return rc;
+    run->launched[run->n_launched][0] = k0, run->launched[run->n_launched][1] = count;
+    ++run->n_launched;
+    return AMT_OK;
+}
+
+}  // namespace
+
+int amt_run_begin(amt_run* run, double* grids, int64_t grids_capacity, void* images, int64_t images_capacity,
+                  amt_run_result* results, int32_t max_frames) {
+    if (run == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = run->ctx;
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, !run->active, "amt_run_begin: a call is already in progress (amt_run_end it first)");
+    AMT_REQUIRE(ctx, max_frames >= 0 && (max_frames == 0 || results != nullptr), "NULL argument");
+    AMT_REQUIRE(ctx, max_frames == 0 || (grids != nullptr && images != nullptr), "the arenas are NULL");
+    if (amt_set_device(ctx)) return AMT_EHIP;
+    // the finalise kernels run on a stream of the drivers' own and write into the arenas: whatever the context's stream
+    // has queued on that memory before this call must be done first
+    void* fin = nullptr;
+    if (int rc = amt_pipe_finalize_stream(run->pipes[0], &fin)) return rc;
+    AMT_HIP(ctx, hipEventRecord(run->entry, ctx->stream));
+    AMT_HIP(ctx, hipStreamWaitEvent(static_cast<hipStream_t>(fin), run->entry, 0));
+    run->grids = grids, run->grids_capacity = grids_capacity;
+    run->images = static_cast<char*>(images), run->images_capacity = images_capacity;
+    run->results = results, run->max_frames = max_frames;
+    run->grid_used = run->image_used = 0;
+    run->full = false;
+    run->n_pushed = 0, run->batch_k0 = 0, run->batch_count = 0, run->n_launched = 0;
+    run->active = true;
+    return AMT_OK;
+}
+
+int amt_run_push(amt_run* run, const amt_run_frame* f) {
+    if (run == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = run->ctx;
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, run->active, "amt_run_push without amt_run_begin");
+    AMT_REQUIRE(ctx, f != nullptr, "NULL frame");
+    AMT_REQUIRE(ctx, run->n_pushed < run->max_frames, "more frames than amt_run_begin announced");
+    const amt_run_config& cfg = run->cfg;
+    const int k = run->n_pushed++, slot = k % cfg.n_slots;
+    if (run->full) {
+        std::memset(&run->results[k], 0, sizeof(amt_run_result));
+        run->results[k].status = 3;
+        return AMT_OK;
+    }
+    const int mag = cfg.magnetic ? 1 : 0;
+    const double altitude = f->altitude > 0 ? f->altitude : cfg.altitude;
+    amt_frame_params& p = run->prm[slot];
+    // (the J2000 -> SM matrix only where somebody reads it: MLat / MLT grids or arrays)
+    const int want_sm = mag || run->outs[slot].mlat != nullptr || run->outs[slot].mlat_c != nullptr;
+    int rc = amt_prm::frame_params(f, cfg.width, cfg.height, cfg.fast_center, altitude, want_sm, &p);
+    if (rc != AMT_OK) {
+        ctx->last_error = "amt_run_push: the date of a frame is outside the IGRF table";
+        return rc;
+    }
+    run->alt[slot] = altitude;
+    run->img[slot] = f->img;
+    double est[8];
+    const bool hint = cfg.use_hints && box_hint(run, run->frames_done + k, p, est);
+    rc = hint ? amt_pipe_coarse_hint(run->pipes[slot], est, mag) : amt_pipe_coarse(run->pipes[slot], &p, cfg.min_elevation, mag);
+    if (rc != AMT_OK) return rc;
+    run->hinted[slot] = hint ? 1 : 0;
+    if (run->batch_count == 0) run->batch_k0 = k;
+    ++run->batch_count;
+    // the first launch carries one frame only: the GPU starts after one frame's preparation instead of `batch`
+    if (run->batch_count == (k == 0 ? 1 : cfg.batch)) {
+        rc = run_batch_ready(run, run->batch_k0, run->batch_count);
+        run->batch_count = 0;
+    }
+    return rc;
+}
+
+int amt_run_end(amt_run* run, int32_t* frames_done) {
+    if (run == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = run->ctx;
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, run->active, "amt_run_end without amt_run_begin");
+    run->active = false;
+    int rc_all = AMT_OK;
+    if (run->batch_count > 0) {
+        rc_all = run_batch_ready(run, run->batch_k0, run->batch_count);
+        run->batch_count = 0;
+    }
+    for (int i = 0; i < run->n_launched; ++i) {
+        const int rc = run_finish(run, run->launched[i][0], run->launched[i][1]);
+        if (rc_all == AMT_OK) rc_all = rc;
+    }
+    run->n_launched = 0;
+    // order the context's stream behind every finalise kernel of this call
+    for (amt_pipe* p : run->pipes) {
+        const int rc = amt_pipe_join(p);
+        if (rc_all == AMT_OK) rc_all = rc;
+    }
+    if (rc_all != AMT_OK) return rc_all;
+    const int n = run->n_pushed;
+    int done = n;
+    for (int i = 0; i < n; ++i)
+        if (run->results[i].status == 3) {
+            done = i;
+            break;
+        }
+    for (int i = done; i < n; ++i) run->results[i].status = 3;
+    if (frames_done) *frames_done = done;
+    run->frames_done += done;
+    if (done < n) run->last.valid = run->prev.valid = false;
+    return AMT_OK;
+}
+
+int amt_run_process(amt_run* run, const amt_run_frame* frames, int32_t n, double* grids, int64_t grids_capacity,
+                    void* images, int64_t images_capacity, amt_run_result* results, int32_t* frames_done) {
+    if (run == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = run->ctx;
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, n >= 0 && (n == 0 || frames != nullptr), "NULL argument");
+    if (frames_done) *frames_done = 0;
+    if (n == 0) return AMT_OK;
+    if (int rc = amt_run_begin(run, grids, grids_capacity, images, images_capacity, results, n)) return rc;
+    int rc_all = AMT_OK;
+    for (int i = 0; i < n && rc_all == AMT_OK; ++i) rc_all = amt_run_push(run, frames + i);
+    const int rc = amt_run_end(run, frames_done);
+    return rc_all != AMT_OK ? rc_all : rc;
+}
+
+}  // extern "C"

@@ -16,18 +16,52 @@ import numpy as np
 
 from ..coordinates.geodesic import wgs84A, wgs84B
 from ..coordinates.transform import date2es, mat_j2000_to_geo, mat_j2000_to_sm
-from ..coordinates.wcs import fill_wcs_params, pix2world
+from ..coordinates.wcs import check_tan_header, fill_wcs_params, pix2world
 from ..frame import FrameData
-from .._native import Context, FrameParams, GeorefOut, ptr
+from .._native import Context, FrameParams, GeorefOut, RunFrame, ptr
 from .mapping import BaseMapping, GenericMapping, inflatedEarthIntersection
+
+
+def run_frame(wcsHeader, cameraPosGCRS, photoTime, altitude=0.0, img_ptr=None, out=None):
+    """The amt_run_frame of one frame: the WCS cards, the camera and the photo time as the native side takes them."""
+    from ..coordinates.transform import julian_date
+    check_tan_header(wcsHeader)
+    f = RunFrame() if out is None else out
+    f.crval[0], f.crval[1] = wcsHeader['CRVAL1'], wcsHeader['CRVAL2']
+    f.crpix[0], f.crpix[1] = wcsHeader['CRPIX1'], wcsHeader['CRPIX2']
+    f.cd[0], f.cd[1], f.cd[2], f.cd[3] = wcsHeader['CD1_1'], wcsHeader['CD1_2'], wcsHeader['CD2_1'], wcsHeader['CD2_2']
+    f.lonpole = wcsHeader['LONPOLE']
+    f.cam[0], f.cam[1], f.cam[2] = float(cameraPosGCRS[0]), float(cameraPosGCRS[1]), float(cameraPosGCRS[2])
+    f.jd = julian_date(photoTime)
+    f.altitude = float(altitude)
+    f.img = img_ptr
+    return f
 
 
 def frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fastCenterCalculation, magnetic=True):
     """
-    The amt_frame_params block of one frame: WCS cards + camera + per-frame rotation matrices.
+    The amt_frame_params block of one frame: WCS cards + camera + per-frame rotation matrices (reference wcs.py:133-139,
+    transform.py:525-696), computed by the library's host function amt_frame_params_from_wcs — the one the native
+    sequence runner uses, so that every path sees the same bits; it equals the Python functions of
+    auromat_amd.coordinates.transform, which are pinned to the reference's doubles (tests/test_host_cpu.py).
     magnetic=False skips the J2000->SM matrix (IGRF dipole, four more rotations) when no MLat/MLT
     output is requested.
     """
+    from .. import _native
+    f = run_frame(wcsHeader, cameraPosGCRS, photoTime, altitude)
+    p = FrameParams()
+    rc = _native.lib().amt_frame_params_from_wcs(C.byref(f), int(wcsHeader['IMAGEW']), int(wcsHeader['IMAGEH']),
+                                                 1 if fastCenterCalculation else 0, float(altitude), 1 if magnetic else 0,
+                                                 C.byref(p))
+    if rc != 0:
+        from ..coordinates.igrf import IGRF_DEFINED_UNTIL_YEAR
+        raise ValueError("ERROR: Specified year is greater than IGRF implementation (" + str(IGRF_DEFINED_UNTIL_YEAR) +
+                         "), please update coefficients in auromat_amd.coordinates.igrf module")
+    return p
+
+
+def frame_params_python(wcsHeader, altitude, cameraPosGCRS, photoTime, fastCenterCalculation, magnetic=True):
+    """:func:`frame_params` through the Python functions (what the native host function is checked against)."""
     p = fill_wcs_params(FrameParams(), wcsHeader)
     p.fast_center = 1 if fastCenterCalculation else 0
     p.cam[:] = [float(v) for v in cameraPosGCRS]

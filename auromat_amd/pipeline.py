@@ -30,10 +30,10 @@ import os
 import numpy as np
 
 from .frame import FrameData
-from .mapping.astrometry import frame_params, pole_in_view
+from .mapping.astrometry import frame_params, pole_in_view, run_frame
 from .mapping.mapping import bounding_box_from_reduction, wrap_at_180
 from .resample import cached_grid, grid_coordinates, resample_frame
-from ._native import Context, GeorefOut, PipeResult, ptr, to_host
+from ._native import Context, GeorefOut, PipeResult, RunConfig, RunFrame, RunResult, ptr, to_host
 
 NEG_INF = float('-inf')
 
@@ -587,6 +587,115 @@ def _steady(a, b, c, n_ab, n_bc):
     return True
 
 
+class NativeResults(object):
+    """
+    The results of one :meth:`SequencePipeline.process` call through the native runner (amt_run_process): a read-only
+    sequence of the usual per-frame result dicts (None for a frame without a valid pixel), built when first asked for —
+    the arrays are views into two arenas the call filled (mean | count of all frames back to back, which is the payload of
+    the gather's wire format as it stands; rounded image | mask per frame), so a caller that only gathers the grids
+    (:func:`auromat_amd.sequence.gather_device`) touches no per-frame Python object at all.
+    """
+
+    def __init__(self, seq, records, grids, images, fallbacks, keep_on_device):
+        self._seq, self._rec, self._grids, self._images = seq, records, grids, images
+        self._fallbacks, self._keep = fallbacks, keep_on_device
+        self._cache = {}
+        self._table = np.frombuffer(records, dtype=np.dtype(RunResult)) if len(records) else None
+
+    def __len__(self):
+        return len(self._rec)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        if i not in self._cache:
+            self._cache[i] = self._build(i)
+        return self._cache[i]
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __mul__(self, n):
+        return list(self) * n
+
+    def _build(self, i):
+        import torch
+        r = self._rec[i]
+        if r.status == 2:
+            return None
+        if r.status != 0:
+            return self._fallbacks[i]
+        seq = self._seq
+        fd = seq.pipes[0].fd
+        b = r.bbox
+        wrapped, pole = bool(r.lon_wrapped), bool(r.contains_pole)
+        if wrapped:
+            box = (b[0], b[1], wrap_at_180(b[4] + 180), wrap_at_180(b[5] + 180))
+        else:
+            box = (b[0], b[1], b[2], b[3])
+        grid = _GridView(r.grid, seq.pxPerDeg, box)
+        ny, nx = r.ny, r.nx
+        n = ny * nx
+        o = r.grid_offset
+        packed = self._grids[o:o + 5 * n]
+        mean = self._grids[o:o + 4 * n].view(ny, nx, 4)
+        count = self._grids[o + 4 * n:o + 5 * n].view(ny, nx)
+        ob = r.image_offset
+        if fd.img_dtype != np.uint8:
+            img = self._images[ob:ob + 6 * n].view(torch.int16).view(ny, nx, 3)
+            om = ob + 6 * n
+        else:
+            img = self._images[ob:ob + 3 * n].view(ny, nx, 3)
+            om = ob + 3 * n
+        mask = self._images[om:om + n].view(ny, nx)
+        out = dict(has_elev=True, grid=grid, contains_pole=pole, contains_discontinuity=wrapped or pole,
+                   altitude=r.altitude, magnetic=seq.magnetic)
+        if self._keep:
+            out.update(mean=mean, img=img, mask=mask, count=count, packed=packed)
+            return out
+        out.update(grid_coordinates(out))
+        out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype), mask=to_host(mask).astype(bool),
+                   count=to_host(count))
+        return out
+
+    # ---- what the gather needs, without per-frame objects (auromat_amd.sequence) -----------------------------------
+    def payload(self):
+        """(device tensor, length): mean | count of all frames back to back, or None when a frame took another path."""
+        if self._table is None or not self._keep or np.any(self._table['status'] == 1):
+            return None
+        t = self._table
+        used = int((5 * t['ny'].astype(np.int64) * t['nx']).sum())
+        return self._grids[:used], used
+
+    def descriptors(self, indices):
+        """The (n, 12) descriptor table of auromat_amd.sequence.describe_results."""
+        t = self._table
+        d = np.zeros((len(self), 12), dtype=np.float64)
+        if t is None:
+            return d
+        ok = t['status'] == 0
+        g = t['grid']
+        d[:, 0], d[:, 1] = t['ny'], t['nx']
+        d[:, 2] = np.where(ok, 4, 0)
+        d[:, 3], d[:, 4] = g['lat_center_first'], g['lon_center_first']
+        d[:, 5], d[:, 6] = g['lat_step'], g['lon_step']
+        d[:, 7] = indices
+        d[:, 8] = t['contains_pole']
+        d[:, 9] = (t['lon_wrapped'] != 0) | (t['contains_pole'] != 0)
+        d[:, 10] = t['altitude']
+        d[:, 11] = 1.0 if self._seq.magnetic else 0.0
+        d[~ok, :7] = 0
+        d[~ok, 8:] = 0
+        return d
+
+
 class SequencePipeline(object):
     """
     Software-pipelined processing of a sequence of equally sized frames on one GPU — what the reference does
@@ -657,6 +766,12 @@ class SequencePipeline(object):
         self._hint_prev = None              # ... and of the one finished before it (for the extrapolation, see _box_hint)
         self._frames_done = 0               # frames of earlier process() calls (hints count frames across calls)
         self.hinted = 0                     # frames of the last process() call that needed no pre-pass
+        # the frame loop in the library (amt_run_process) where it applies: device-resident images, no on_batch hook;
+        # AMT_SEQ_NATIVE=0 keeps the Python loop (A/B runs)
+        self.native = os.environ.get('AMT_SEQ_NATIVE', '1') != '0'
+        self._run = None
+        self._run_hints = True
+        self._arena_cells = 1 << 16         # grid cells per frame the arenas of the next call are sized for
 
     def _stream_of(self, k):
         """The stream the batch of frame k is launched on (and its buffers are used on)."""
@@ -811,6 +926,138 @@ class SequencePipeline(object):
             out.append(r)
         return out
 
+    # ---- the frame loop in the library (amt_run_*, include/auromat_hip.h "native sequence runner") --------------------
+    def _native_applies(self, frames):
+        """Device-resident images, header dicts, one launch stream, the single-pass plan: what amt_run_process covers."""
+        if not (self.single_pass and self.s_alt is None and frames):
+            return False
+        q = self.pipes[0]
+        return all(isinstance(f[0], dict) and q.is_resident_image(f[3]) for f in frames)
+
+    def _runner(self):
+        if self._run is None:
+            nb = len(self.pipes)
+            slots = (GeorefOut * nb)()
+            for i, q in enumerate(self.pipes):
+                C.memmove(C.byref(slots[i]), C.byref(q._out), C.sizeof(GeorefOut))
+            q = self.pipes[0]
+            cfg = RunConfig(width=q.width, height=q.height, img_dtype=1 if q.fd.img_dtype == np.uint8 else 2, fast_center=1 if self.fast else 0,
+                            magnetic=1 if self.magnetic else 0, batch=self.batch, use_hints=1 if self.use_hints else 0,
+                            n_slots=nb, altitude=float(self.altitude),
+                            min_elevation=NEG_INF if self.min_elevation is None else float(self.min_elevation),
+                            lat_px_per_deg=float(self.pxPerDeg[0]), lon_px_per_deg=float(self.pxPerDeg[1]), slots=slots)
+            handle = C.c_void_p()
+            self.ctx.call('amt_run_create', C.byref(cfg), C.byref(handle))
+            self._run = handle
+            self._run_hints = self.use_hints
+        return self._run
+
+    def _hint_native_reset(self):
+        self.ctx.check(self.ctx._lib.amt_run_reset_hints(self._run))
+
+    def __del__(self):
+        if getattr(self, '_run', None):
+            try:
+                self.ctx._lib.amt_run_destroy(self._run)
+            except Exception:
+                pass
+            self._run = None
+
+    def _process_native(self, frames, keep_on_device):
+        import torch
+        ctx = self.ctx
+        n = len(frames)
+        if self._run is not None and self._run_hints != self.use_hints:
+            ctx._lib.amt_run_destroy(self._run)           # (use_hints is part of the runner's configuration)
+            self._run = None
+        run = self._runner()
+        if self._hint is not None or self._hint_prev is not None:
+            # the Python loop ran in between: its hints are not the runner's
+            self._hint = self._hint_prev = None
+        rec = (RunResult * n)()
+        one = RunFrame()
+        lib = ctx._lib
+        done_total = 0
+        grids = images = None
+        arenas = []
+        # the big kernels run on the stream all pipelines of the process share (see _shared_stream), behind whatever the
+        # caller's stream has queued (its images); the caller's stream is ordered behind the call's work at the end
+        caller = torch.cuda.current_stream(ctx.device)
+        bpp = 3 if self.pipes[0].fd.img_dtype == np.uint8 else 6
+        self.s_main.wait_stream(caller)
+        with torch.cuda.stream(self.s_main):
+            Context.current(ctx.device)                     # the library enqueues on torch's current stream
+            while done_total < n:
+                m = n - done_total
+                cells = self._arena_cells * m
+                g = torch.empty(5 * cells, dtype=torch.float64, device=ctx.device)
+                im = torch.empty((bpp + 1) * cells + 256 * m, dtype=torch.uint8, device=ctx.device)
+                out = C.cast(C.byref(rec[done_total]), C.POINTER(RunResult))
+                ctx.check(lib.amt_run_begin(run, g.data_ptr(), g.numel(), im.data_ptr(), im.numel(), out, m))
+                try:
+                    # frame by frame: the library launches as soon as a batch is complete, the first after one frame
+                    for f in frames[done_total:]:
+                        alt = f[4] if len(f) > 4 and f[4] is not None else 0.0
+                        ctx.check(lib.amt_run_push(run, C.byref(run_frame(f[0], f[1], f[2], alt, f[3].data_ptr(), out=one))))
+                finally:
+                    done = C.c_int32(0)
+                    rc_end = lib.amt_run_end(run, C.byref(done))
+                ctx.check(rc_end)
+                g.record_stream(caller)
+                im.record_stream(caller)
+                arenas.append((done_total, done.value, g, im))
+                if done.value < m:
+                    self._arena_cells *= 4                    # the grids are larger than assumed: the rest again
+                    if done.value == 0 and self._arena_cells > (1 << 28):
+                        raise MemoryError('amt_run: a single grid does not fit the arena')
+                done_total += done.value
+        caller.wait_stream(self.s_main)
+        if len(arenas) == 1:
+            grids, images = arenas[0][2], arenas[0][3]
+        else:
+            # (rare: the first call met grids larger than assumed) one arena for all frames, offsets shifted
+            grids = torch.cat([a[2][:int(sum(5 * rec[k].ny * rec[k].nx for k in range(a[0], a[0] + a[1])))] for a in arenas])
+            sizes = [max([0] + [rec[k].image_offset + ((bpp + 1) * rec[k].ny * rec[k].nx + 255) // 256 * 256
+                                for k in range(a[0], a[0] + a[1]) if rec[k].status == 0]) for a in arenas]
+            images = torch.cat([a[3][:sz] for a, sz in zip(arenas, sizes)])
+            goff = ioff = 0
+            for a, sz in zip(arenas, sizes):
+                for k in range(a[0], a[0] + a[1]):
+                    rec[k].grid_offset += goff
+                    rec[k].image_offset += ioff
+                goff += int(sum(5 * rec[k].ny * rec[k].nx for k in range(a[0], a[0] + a[1])))
+                ioff += sz
+        # frames the single-pass plan does not cover (box outside its superset grid, ...): the general path, one by one
+        table = np.frombuffer(rec, dtype=np.dtype(RunResult))
+        status = table['status']
+        self.hinted += int(table['hinted'].sum())
+        fallbacks = {}
+        max_cells = int((table['ny'].astype(np.int64) * table['nx']).max()) if n else 1
+        names = {0: 'single-pass', 2: 'empty'}
+        if not status.any():
+            self.plans.extend(['single-pass'] * n)
+        else:
+            for k in range(n):
+                st = int(status[k])
+                if st in names:
+                    self.plans.append(names[st])
+                    continue
+                f = frames[k]
+                q = self.pipes[0]
+                q.use_image(f[3])
+                alt = f[4] if len(f) > 4 and f[4] is not None else self.altitude
+                try:
+                    res = q.run(f[0], alt, f[1], f[2], fast=self.fast, min_elevation=self.min_elevation, pxPerDeg=self.pxPerDeg,
+                                magnetic=self.magnetic, keep_on_device=keep_on_device, fuse=False)
+                    res['magnetic'] = self.magnetic
+                except EmptyFrame:
+                    res = None
+                fallbacks[k] = res
+                self.plans.append(q.last_plan)
+        self._arena_cells = max(self._arena_cells // 2 if len(arenas) == 1 else self._arena_cells, int(max_cells * 1.5) + 64, 1 << 12)
+        self._frames_done += n
+        return NativeResults(self, rec, grids, images, fallbacks, keep_on_device)
+
     def finalize_stream(self):
         """The stream the single-pass results are produced on (the drivers' finalise stream, shared by the pipeline's
         buffers): consumers that want to touch results before process() returns enqueue there."""
@@ -831,6 +1078,12 @@ class SequencePipeline(object):
         import torch
         del self.plans[:]
         self.hinted = 0
+        if on_batch is None and self.native:
+            frames = list(frames)
+            if self._native_applies(frames):
+                return self._process_native(frames, keep_on_device)
+        if self._run is not None:
+            self._hint_native_reset()
         # (the box of the latest finished frame stays from the previous call: a sequence handed over in pieces is still
         # a sequence, and every hint is checked against the new frame's camera before it is used)
         out = []

@@ -43,6 +43,12 @@ def pack_results(results, indices, device):
 def payload_parts(results, device):
     """The pieces of the payload in order (1-d float64 tensors on `device`) and their total length."""
     import torch
+    if hasattr(results, 'payload'):
+        # results of the native runner: mean | count of all frames already lie back to back in one arena
+        whole = results.payload()
+        if whole is not None:
+            buf, total = whole
+            return [buf if buf.device == torch.device(device) else buf.to(device)], total
     parts, total = [], 0
     for res in results:
         if res is None:
@@ -240,6 +246,8 @@ class Packer(object):
 
 def describe_results(results, indices):
     """The descriptor table ((n, DESC_LEN) float64, host) of :func:`pack_results`."""
+    if hasattr(results, 'descriptors') and results.payload() is not None:
+        return results.descriptors(np.asarray(indices, dtype=np.float64))
     descs = np.zeros((len(results), DESC_LEN), dtype=np.float64)
     for i, (res, idx) in enumerate(zip(results, indices)):
         if res is None:
@@ -263,10 +271,14 @@ def agree_capacity(results, indices, device, margin=1.25, group=None):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n_payload = 0
-    for res in results:
-        if res is not None:
-            ny, nx, nc = res['mean'].shape
-            n_payload += ny * nx * (nc + 1)
+    whole = results.payload() if hasattr(results, 'payload') else None
+    if whole is not None:
+        n_payload = whole[1]
+    else:
+        for res in results:
+            if res is not None:
+                ny, nx, nc = res['mean'].shape
+                n_payload += ny * nx * (nc + 1)
     sizes = torch.tensor([len(results), n_payload], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 /* 2: amt_georef_out grew (bin_pole, altitude); amt_rotate_pole_deg, amt_pipe_finalize_stream, amt_seq_* added (round 2) */
-#define AMT_ABI_VERSION 2
+#define AMT_ABI_VERSION 3
 
 #define AMT_OK 0
 #define AMT_EINVAL (-1)   /* bad argument (NULL pointer, negative size, unsupported dtype ...) */
@@ -292,6 +292,15 @@ int amt_georef_frame_dirs(amt_ctx* ctx, const amt_frame_params* p, const double*
  * shell right of (below) the frame centre minus those left of (above) it: the input of amt_georef_out.item_order. */
 int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stride, double min_elevation,
                            int magnetic, double* bbox);
+/* Host function (no GPU call): which rows of amt_georef_frame's work items cannot see the shell.  With the TAN camera
+ * model the limb is a conic section in the image and the set of pixel corners whose ray hits the shell is convex, so
+ * whole bands of the frame are bounded exactly from a handful of evaluations; the waves of such bands write NaN and
+ * cast no ray.  An item is `rows_per_item` pixel rows tall; the frame has `n_item_rows` rows of items; rows
+ * [0, top_end) and [bottom_begin, n_item_rows) are free of hits (conservative: within 1e-9 of the limb a band counts
+ * as seeing the Earth).  Replaces nothing in the reference — it evaluates every ray (wcs.py:18-144,
+ * intersection.py:58-104) — and changes no result. */
+int amt_georef_sky_rows(const amt_frame_params* p, int32_t* rows_per_item, int32_t* n_item_rows, int32_t* top_end,
+                        int32_t* bottom_begin);
 
 /* ---- mask rules ---------------------------------------------------------------------- */
 
@@ -513,6 +522,77 @@ int amt_pipe_finalize_stream(amt_pipe* pipe, void** stream);
 /* Orders the context's stream behind the last amt_pipe_finalize (no-op when it already completed): call it
  * before work on the context's stream — or, after amt_ctx_synchronize, the host — reads the outputs. */
 int amt_pipe_join(amt_pipe* pipe);
+
+/* ---- native sequence runner ---------------------------------------------------------------------------------------
+ * The per-frame loop of a sequence (reference mapping/spacecraft.py:326-332 `map(getMapping, ...)` followed by
+ * cli/convert.py:178-185 `resample`) as ONE call: for every frame the host scalars (ephemeris seconds, the cxform
+ * matrices J2000 -> GEO / SM with the IGRF dipole, the WCS Euler matrix: reference transform.py:491-696, wcs.py:133-139),
+ * the estimate of its bounding box (the boxes of the frames finished before it, where the sequence is coherent; else the
+ * coarse pre-pass), the launch (up to AMT_PIPE_MAX_BATCH frames per launch of the big kernel), the wait for its exact box,
+ * the grid layout and the finalise kernel — software pipelined over `n_slots` frame slots by this one host thread.
+ * Results: frame k's mean (ny, nx, 4) and count (ny, nx) lie one after the other at grids + grid_offset — consecutive
+ * frames back to back, which is the payload of the gather's wire format (amt_seq_pack) without a copy —, its rounded
+ * image (ny, nx, 3) and mask (ny, nx) at images + image_offset (256-byte aligned).
+ * status per frame: 0 done; 1 the frame needs the general path (see amt_pipe_result; nothing of it is in the arenas; its
+ * per-pixel arrays are in its slot unless a later frame has taken the slot); 2 no pixel above the elevation threshold;
+ * 3 the arenas are full (this and the later frames were not processed). */
+typedef struct amt_run amt_run;
+typedef struct amt_run_config {
+    int32_t width, height;
+    int32_t img_dtype;            /* 1 = uint8, 2 = uint16; (height, width, 3) */
+    int32_t fast_center;          /* BaseAstrometryMapping.fastCenterCalculation */
+    int32_t magnetic;             /* grids in (MLat, SM longitude): resampleMLatMLT */
+    int32_t batch;                /* frames per launch, 1 .. AMT_PIPE_MAX_BATCH */
+    int32_t use_hints;            /* 0: coarse pre-pass for every frame */
+    int32_t n_slots;              /* frame slots, >= 2 * batch */
+    double altitude;              /* mapping shell [km] of frames that name none */
+    double min_elevation;         /* maskedByElevation; -inf disables */
+    double lat_px_per_deg, lon_px_per_deg;
+    const amt_georef_out* slots;  /* n_slots blocks: the per-pixel arrays each slot's frames write (NULL = not written);
+                                   * bbox / bin_* fields are managed by the runner */
+} amt_run_config;
+typedef struct amt_run_frame {
+    double crval[2], crpix[2], cd[4], lonpole;   /* the TAN WCS cards (LATPOLE = 0) */
+    double cam[3];                /* cameraPosGCRS [km] */
+    double jd;                    /* photo time, UTC Julian date as ONE double (astropy Time(...).jd, transform.py:529) */
+    double altitude;              /* mapping shell [km]; <= 0: the config's */
+    const void* img;              /* device, (height, width, 3) of img_dtype; read until the call returns */
+} amt_run_frame;
+typedef struct amt_run_result {
+    int32_t status, slot;
+    int32_t ny, nx;
+    int32_t contains_pole;        /* grid laid out in coordinates rotated by +90 deg about x (resample.py:176-201) */
+    int32_t lon_wrapped;          /* grid laid out in longitudes shifted by 180 deg (resample.py:203-218) */
+    int32_t hinted;               /* 1: no coarse pre-pass ran for this frame */
+    int32_t edge_pixels;
+    int64_t grid_offset;          /* doubles */
+    int64_t image_offset;         /* bytes */
+    double bbox[8];               /* amt_pipe_result.bbox */
+    double altitude;
+    amt_grid grid;
+    amt_frame_params params;      /* what the frame was computed with */
+} amt_run_result;
+/* The host scalars of one frame (no GPU call).  AMT_EINVAL: date outside the IGRF table with want_sm. */
+int amt_frame_params_from_wcs(const amt_run_frame* frame, int32_t width, int32_t height, int32_t fast_center,
+                              double altitude, int32_t want_sm, amt_frame_params* out);
+int amt_run_create(amt_ctx* ctx, const amt_run_config* config, amt_run** out_run);
+int amt_run_destroy(amt_run* run);
+/* Processes frames[0 .. n) on the context's stream (+ the drivers' own streams); on return the context's stream is
+ * ordered behind everything the call enqueued.  grids: device, grids_capacity doubles; images: device, images_capacity
+ * bytes; both must stay untouched by other streams during the call.  results: n records (host).  frames_done (optional):
+ * how many leading frames were processed (< n only with status 3).  The box hints carry over from call to call. */
+int amt_run_process(amt_run* run, const amt_run_frame* frames, int32_t n, double* grids, int64_t grids_capacity,
+                    void* images, int64_t images_capacity, amt_run_result* results, int32_t* frames_done);
+/* The same call in pieces, for a host that produces its frames one by one (reading headers, decoding images): begin
+ * with the arenas and room for max_frames results, push the frames in order — a push prepares its frame and, when a batch
+ * is complete, finishes the older batch in flight and launches the new one, so the GPU starts after the first push —,
+ * end to finish what is in flight and order the context's stream behind it.  `frame` is copied. */
+int amt_run_begin(amt_run* run, double* grids, int64_t grids_capacity, void* images, int64_t images_capacity,
+                  amt_run_result* results, int32_t max_frames);
+int amt_run_push(amt_run* run, const amt_run_frame* frame);
+int amt_run_end(amt_run* run, int32_t* frames_done);
+/* Forget the box hints (the next frame gets a coarse pre-pass). */
+int amt_run_reset_hints(amt_run* run);
 
 /* ---- sequences over several GPUs: packing of per-frame grids for the gather ------------------------------------
  * Whole frames are independent (reference mapping/spacecraft.py:326-332 iterates them with a plain `map`,

@@ -498,3 +498,34 @@ def test_spacecraft_mapping_providers(tmp_path):
     assert [q.identifier for q in pp.getSequence()] == prov.ids
     with pytest.raises(NotImplementedError):
         pp.get(t0)
+
+
+def test_native_frame_params_equal_the_python_ones():
+    """amt_frame_params_from_wcs (the host scalars the frame pipelines and the native sequence runner use) against the
+    Python functions, which are pinned to the reference's doubles: WCS rotation, J2000 -> GEO and J2000 -> SM over 24
+    years of dates and random pointings — equal to 4e-16 (most elements to the last bit; NumPy's BLAS and the C++
+    products round alike but for the odd element), the scalar fields exactly."""
+    from datetime import datetime, timedelta
+    from auromat_amd.mapping.astrometry import frame_params, frame_params_python
+    from auromat_amd.synthetic import frame_header
+    rs = np.random.RandomState(7)
+    same = total = 0
+    for k in range(200):
+        hdr, cam, t = frame_header(640, 420, ('iss030', 'iss029')[k % 2])
+        hdr = dict(hdr, CRVAL1=float(rs.uniform(0, 360)), CRVAL2=float(rs.uniform(-89, 89)), LONPOLE=float(rs.choice([180.0, 93.5])))
+        t = datetime(1995, 1, 1) + timedelta(seconds=float(rs.uniform(0, 24 * 365.25 * 86400)))
+        for magnetic in (True, False):
+            a, b = frame_params(hdr, 110 + k, cam, t, k % 3 == 0, magnetic), frame_params_python(hdr, 110 + k, cam, t, k % 3 == 0, magnetic)
+            for name in ('rot', 'm_geo', 'm_sm'):
+                x, y = np.array(getattr(a, name)[:]), np.array(getattr(b, name)[:])
+                assert np.max(np.abs(x - y)) <= 4e-16, (name, k)
+                same += int((x == y).sum())
+                total += x.size
+            for name in ('cd', 'crpix', 'cam'):
+                assert list(getattr(a, name)) == list(getattr(b, name)), name
+            assert (a.a, a.b, a.a0, a.b0, a.width, a.height, a.fast_center) == (b.a, b.b, b.a0, b.b0, b.width, b.height, b.fast_center)
+    assert same > 0.9 * total
+    hdr, cam, t = frame_header(64, 42)
+    with pytest.raises(ValueError, match='IGRF'):
+        frame_params(hdr, 110, cam, datetime(2031, 1, 1), True, magnetic=True)
+    frame_params(hdr, 110, cam, datetime(2031, 1, 1), True, magnetic=False)       # J2000 -> GEO needs no IGRF
