@@ -567,34 +567,34 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
     if (!DIRS_IN && (chunk < A.sky_top_end || chunk >= A.sky_bottom_begin)) {      // wave-uniform
         // No ray of this item reaches the shell (the host has bounded the conic section that the limb is in the image,
         // sky_bands()): its part of every output array is NaN, nothing is binned, its box partial is the empty one.
-        const double nan = NAN;
-        unsigned int oc = (unsigned int)(y0 * W1 + gx) * 8u, op = (unsigned int)((y0 - 1) * A.width + gx) * 8u;
-        const unsigned int pc_ = (unsigned int)W1 * 8u, pp_ = (unsigned int)A.width * 8u;
-        auto at_ = [](double* base, unsigned int byte_offset) -> double& {
-            return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_offset);
+        // The rows of a whole row of items are one contiguous range of each array, so the strips_x waves of the row
+        // share it as contiguous pieces written with 16-byte stores (the pattern of a plain fill: 6 TB/s where the
+        // 504-byte runs of the row-marching pattern reach 5).
+        const int n_corner_rows = rows + (y0 + rows == A.height ? 1 : 0);           // the image's last corner row too
+        auto fill_nan = [&](double* base, int64_t first, int64_t count) {
+            if (base == nullptr) return;
+            int64_t a = first + count * strip / strips_x, b = first + count * (strip + 1) / strips_x;
+            if ((a & 1) && a < b) {                        // 16-byte alignment of the pairs (the arrays are 16-byte aligned)
+                if (lane == 0) base[a] = NAN;
+                ++a;
+            }
+            const double2 two = {NAN, NAN};
+            for (int64_t i = a + 2 * lane; i + 1 < b; i += 128) *reinterpret_cast<double2*>(base + i) = two;
+            if (((b - a) & 1) && lane == 0 && b > a) base[b - 1] = NAN;
         };
         const bool mag_out = MAG && !kPole;
-        for (int r = 0; r <= rows; ++r) {
-            const int gy = y0 + r;
-            if (col_ok && (lane < 63 || gx == A.width) && (r < rows || gy == A.height)) {
-                if (A.lat) at_(A.lat, oc) = nan;
-                if (A.lon) at_(A.lon, oc) = nan;
-                if (mag_out && A.mlat) {
-                    at_(A.mlat, oc) = nan;
-                    at_(A.mlt, oc) = nan;
-                }
-            }
-            if (r > 0 && px_ok) {
-                if (A.lat_c) at_(A.lat_c, op) = nan;
-                if (A.lon_c) at_(A.lon_c, op) = nan;
-                if (A.elev) at_(A.elev, op) = nan;
-                if (mag_out && A.mlat_c) {
-                    at_(A.mlat_c, op) = nan;
-                    at_(A.mlt_c, op) = nan;
-                }
-            }
-            oc += pc_;
-            op += pp_;
+        const int64_t c0 = (int64_t)y0 * W1, cn = (int64_t)n_corner_rows * W1;
+        const int64_t p0 = (int64_t)y0 * A.width, pn = (int64_t)rows * A.width;
+        fill_nan(A.lat, c0, cn);
+        fill_nan(A.lon, c0, cn);
+        fill_nan(A.lat_c, p0, pn);
+        fill_nan(A.lon_c, p0, pn);
+        fill_nan(A.elev, p0, pn);
+        if (mag_out) {
+            fill_nan(A.mlat, c0, cn);
+            fill_nan(A.mlt, c0, cn);
+            fill_nan(A.mlat_c, p0, pn);
+            fill_nan(A.mlt_c, p0, pn);
         }
         if (want_bbox && lane < 8)
             A.bbox_partials[(int64_t)item * 8 + lane] = lane >= 6 ? 0.0 : ((lane & 1) ? -kInf : kInf);
