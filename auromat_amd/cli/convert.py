@@ -73,9 +73,11 @@ def getParser():
     mappingArgs.add_argument('--exact-centers', dest='exactCenters', action='store_true',
                              help='Cast a ray through every pixel centre (the reference\'s getMapping default) instead of '
                                   'averaging the four corner hits.')
-    mappingArgs.add_argument('--min-elevation', dest='minElevation', type=float, default=10.0,
-                             help='Mask pixels seen under a smaller elevation angle before resampling (the user guide\'s '
-                                  'recommendation, docs/userguide: 10 degrees); negative to disable.')
+    mappingArgs.add_argument('--min-elevation', dest='minElevation', type=float, default=-1.0,
+                             help='Mask pixels seen under a smaller elevation angle before resampling (an addition: the '
+                                  'reference\'s auromat-convert resamples the provider\'s mappings unmasked, cli/convert.py:'
+                                  '176-185, and so does this driver by default; the user guide recommends 10 degrees); '
+                                  'negative = no mask.')
     esaIssArgs = parser.add_argument_group('ESA ISS data (accepted for compatibility; RAW development is not part of this package)')
     esaIssArgs.add_argument('--bps', help='bits per sample, default is 16', choices=[8, 16], default=16, type=int)
     esaIssArgs.add_argument('--correctgamma', action='store_true')
@@ -243,6 +245,17 @@ def convert_with_pipeline(args, frames, export):
     distributed = 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) > 1
     rank, world = 0, 1
     if distributed:
+        rank, world = int(os.environ.get('RANK', '0')), int(os.environ['WORLD_SIZE'])
+        # the "file exists, neither --skip nor --overwrite" exit of the reference is decided for ALL frames on EVERY rank
+        # before the process group exists: every rank leaves together and nobody waits in a collective for a rank that
+        # has gone (a check per rank's own share left the others in dist.barrier() until the launcher killed them)
+        if not args.skip and not args.overwrite:
+            for identifier, _, _ in frames:
+                path = os.path.join(args.out, identifier + '.nc')
+                if os.path.exists(path):
+                    print('The file', path, 'already exists.\nPlease use --skip or --overwrite, or a different output folder.',
+                          file=sys.stderr)
+                    sys.exit(1)
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         dist.init_process_group('nccl')
         rank, world = dist.get_rank(), dist.get_world_size()

@@ -91,6 +91,9 @@ class Writer(object):
         self.vars = OrderedDict()
 
     def create_dimension(self, name, size):
+        if int(size) <= 0:
+            # (a length of 0 in the header marks the record (unlimited) dimension for classic readers)
+            raise ValueError('dimension %r of size %r: fixed dimensions need a positive size' % (name, size))
         self.dims[name] = int(size)
 
     def create_variable(self, name, dtype, dims=(), fill_value=None):

@@ -19,7 +19,8 @@ class FrameData(object):
         self.width = int(width)
         for k in self.COORDS:
             setattr(self, k, None)
-        self.img = None            # (H, W, C) uint8 tensor, or int16 tensor holding uint16 bits
+        self._img = None           # (H, W, C) uint8 tensor, or int16 tensor holding uint16 bits (see the `img` property)
+        self._img_host = None      # a host image that has not been uploaded yet (set_image(lazy=True))
         self.img_dtype = None      # numpy dtype of the image
         self.corner_mask = None    # (H+1, W+1) uint8, 1 = masked; None = "NaN latitude"
         self.center_mask = None    # (H, W) uint8
@@ -45,22 +46,39 @@ class FrameData(object):
             fd.center_mask = ctx.to_device(np.asarray(center_mask, dtype=np.uint8), np.uint8)
         return fd
 
-    def set_image(self, img):
+    def set_image(self, img, lazy=False):
+        """`lazy`: the image crosses PCIe when a kernel first needs it (a mapping that is only asked for its coordinate
+        arrays never uploads its 36-72 MB of pixels)."""
         img = np.asarray(img)
         if img.ndim == 2:
             img = img[:, :, None]
         assert img.dtype in (np.uint8, np.uint16), 'image must be uint8 or uint16'
         assert img.shape[:2] == (self.height, self.width) and img.shape[2] <= 4
         self.img_dtype = img.dtype
-        self.img = self.ctx.to_device(img, img.dtype)
+        if lazy:
+            self._img, self._img_host = None, img
+        else:
+            self._img, self._img_host = self.ctx.to_device(img, img.dtype), None
+
+    @property
+    def img(self):
+        if self._img is None and self._img_host is not None:
+            self._img, self._img_host = self.ctx.to_device(self._img_host, self._img_host.dtype), None
+        return self._img
+
+    @img.setter
+    def img(self, tensor):
+        self._img, self._img_host = tensor, None
 
     @property
     def nchan(self):
-        return 0 if self.img is None else int(self.img.shape[2])
+        if self._img is None and self._img_host is not None:
+            return int(self._img_host.shape[2])
+        return 0 if self._img is None else int(self._img.shape[2])
 
     @property
     def img_dtype_code(self):
-        return 0 if self.img is None else (1 if self.img_dtype == np.uint8 else 2)
+        return 0 if (self._img is None and self._img_host is None) else (1 if self.img_dtype == np.uint8 else 2)
 
     def shallow_copy(self):
         return copy.copy(self)
@@ -84,9 +102,11 @@ class FrameData(object):
         return None if t is None else to_host(t)
 
     def host_image(self):
-        if self.img is None:
+        if self._img is None and self._img_host is not None:
+            return self._img_host               # never uploaded: the caller's own array
+        if self._img is None:
             return None
-        return to_host(self.img, dtype=self.img_dtype)
+        return to_host(self._img, dtype=self.img_dtype)
 
     def host_mask(self, which):
         t = self.corner_mask_tensor() if which == 'corner' else self.center_mask_tensor()

@@ -165,6 +165,10 @@ class BaseAstrometryMapping(BaseMapping):
         self.fastCenterCalculation = fastCenterCalculation
         self._frame = None
         self._img_array = None
+        # maskedByElevation(e) of a mapping whose arrays do not exist yet is remembered, not computed: resample() of
+        # such a mapping runs the single-pass plan (one kernel: georeferencing, mask, box, binning), and anything else
+        # that asks for the arrays materialises them, masks included, on first use (see frame())
+        self._lazy_elev = None
 
     @property
     def wcsHeader(self):
@@ -181,7 +185,7 @@ class BaseAstrometryMapping(BaseMapping):
             fd = FrameData(ctx, hdr['IMAGEH'], hdr['IMAGEW'])
             georef_into(fd, self._params(), geo=True)
             if self._img_array is not None:
-                fd.set_image(self._img_array)
+                fd.set_image(self._img_array, lazy=True)
             if not self.fastCenterCalculation:
                 # exact centres carry their own misses: reconcile corner and centre masks
                 # (sanitize_data, reference mapping.py:1063-1125); fast centres are consistent
@@ -189,7 +193,54 @@ class BaseAstrometryMapping(BaseMapping):
                 ctx.call('amt_sanitize_masks', ptr(fd.corner_mask_tensor()), ptr(fd.center_mask_tensor()), None,
                          fd.height, fd.width, 0)
             self._frame = fd
+            if self._lazy_elev is not None:
+                # the remembered maskedByElevation (raises the reference's ValueError when nothing is left)
+                e, self._lazy_elev = self._lazy_elev, None
+                try:
+                    self._frame = BaseMapping.maskedByElevation(self, e)._frame
+                except ValueError:
+                    self._frame, self._lazy_elev = None, e
+                    raise
+                self.setDirty()
         return self._frame
+
+    def maskedByElevation(self, minElevation=10):
+        """
+        BaseMapping.maskedByElevation (reference mapping.py:845-864).  While the arrays of this mapping have not been
+        asked for, the mask is only remembered: ``resample(mapping.maskedByElevation(e), pxPerDeg=...)`` — the call of the
+        reference's user guide — then costs one launch of the fused kernel instead of the array pipeline, and every
+        other use computes arrays and masks on first access.  The reference's ``ValueError`` for a threshold that masks
+        every pixel is raised at that first use (``resample`` included) instead of here.
+        """
+        if self._frame is None and self._lazy_elev is None and self._fusable():
+            import copy
+            m = copy.copy(self)
+            m._lazy_elev = float(minElevation)
+            m.setDirty()
+            return m
+        return BaseMapping.maskedByElevation(self, minElevation)
+
+    def _fusable(self):
+        img = self._img_array
+        return img is not None and getattr(img, 'ndim', 0) == 3 and img.shape[2] == 3 and img.dtype in (np.uint8, np.uint16)
+
+    def _fused_resample(self, pxPerDeg, containsPole=None, magnetic=False):
+        """
+        resample() / resampleMLatMLT() of this mapping through the single-pass plan (FramePipeline.run(fuse=True): the
+        binning inside the georeferencing kernel, no per-pixel array is written or read back) -> the result dict of
+        resample_frame, or None when that does not apply (arrays already exist, masks other than one
+        maskedByElevation, no RGB image).  A frame the plan does not cover takes the two-pass plan inside run().
+        """
+        if self._frame is not None or not self._fusable():
+            return None
+        from ..pipeline import fused_class_pipeline
+        hdr = self._wcsHeader
+        pipe = fused_class_pipeline(hdr['IMAGEW'], hdr['IMAGEH'], self._img_array.dtype, magnetic)
+        res = pipe.run(hdr, self.altitude, self.cameraPosGCRS, self.photoTime, img=self._img_array,
+                       fast=self.fastCenterCalculation, min_elevation=self._lazy_elev, pxPerDeg=pxPerDeg,
+                       containsPole=containsPole, magnetic=magnetic, fuse=True)
+        res['plan'] = pipe.last_plan
+        return res
 
     def _mlatmlt_tensors(self, center):
         """

@@ -1,6 +1,6 @@
 """
 Reads files written by :mod:`auromat_amd.export.netcdf` (or by the reference's exporter, once converted to the
-classic format with ``nccopy -k cdf5``/``-k 64-bit-offset``) back as mappings — reference auromat/mapping/netcdf.py.
+classic format with ``nccopy -k nc6`` (= ``-k 64-bit-offset``, CDF-2) or ``-k classic`` (CDF-1); CDF-5 is not read) back as mappings — reference auromat/mapping/netcdf.py.
 File parsing is host code; the mapping it returns is a :class:`GenericMapping` (device-resident like all others).
 """
 import collections

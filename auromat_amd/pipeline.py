@@ -159,12 +159,12 @@ class FramePipeline(object):
             return
         if isinstance(img, torch.Tensor):
             t = self.ctx.to_device(img, self.fd.img_dtype)
-        else:
-            a = np.ascontiguousarray(img, dtype=self.fd.img_dtype)
-            if not a.flags.writeable:
-                a = a.copy()
-            t = torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)     # one H2D copy, no staging
-        self.fd.img.copy_(t.reshape(self.fd.img.shape))
+            self.fd.img.copy_(t.reshape(self.fd.img.shape))
+            return
+        a = np.ascontiguousarray(img, dtype=self.fd.img_dtype)
+        assert a.size == self.fd.img.numel(), 'image of the wrong size'
+        Context.current(self.ctx.device)
+        self.ctx.upload(a, self.fd.img)          # through page-locked staging pieces (see Context.upload)
 
     def use_image(self, img):
         """Use a device-resident image of the buffer's layout ((h, w, c) uint8, or uint16 bits as int16) in place:
@@ -467,6 +467,11 @@ class FramePipeline(object):
             if res.status == 0 and (containsPole is None or bool(containsPole) == bool(res.bbox[7])):
                 self.last_plan = 'single-pass'
                 return self._finalize_fused(res, tuple(pxPerDeg), keep_on_device)
+            if res.status == 2 or res.bbox[6] == 0:
+                # no pixel above the threshold: known from the kernel's own reduction — a grids-only pipeline does not
+                # allocate (and compute) five per-pixel arrays only to find that out again
+                self.last_plan = 'empty'
+                raise EmptyFrame('minElevation=' + str(self.min_elevation) + ' would mask all pixels!')
         self.coordinates()          # (grids-only pipelines: the arrays the two-pass plan reads are computed now)
         if not self.params.fast_center and fd.center_mask is None:
             # exact centres carry their own misses: a centre also needs its four corners and a corner a centre
@@ -512,6 +517,22 @@ class FramePipeline(object):
         names = ['lat', 'lon', 'lat_c', 'lon_c', 'elev'] + (['mlat', 'mlt', 'mlat_c', 'mlt_c'] if self.with_mag else [])
         self.coordinates()
         return {k: self.fd.host(k) for k in names}
+
+
+_CLASS_PIPES = {}
+
+
+def fused_class_pipeline(width, height, img_dtype, magnetic=False):
+    """The frame pipeline behind the mapping classes' fused resample() (one per frame size / image type / grid kind and
+    device, grids only: its per-pixel arrays are only allocated when a frame has to take the two-pass plan)."""
+    ctx = Context.current()
+    key = (str(ctx.device), int(width), int(height), np.dtype(img_dtype).str, bool(magnetic))
+    pipe = _CLASS_PIPES.get(key)
+    if pipe is None:
+        if len(_CLASS_PIPES) >= 4:
+            _CLASS_PIPES.clear()                # (frames of many sizes: do not hoard their buffers)
+        pipe = _CLASS_PIPES[key] = FramePipeline(width, height, img_dtype=img_dtype, with_mag=bool(magnetic), alloc_coords=False)
+    return pipe
 
 
 def _close(a, b):

@@ -60,9 +60,36 @@ def resampleMLatMLT(mapping, **kw):
 
     See :func:`resample` for parameters.
     """
+    global last_plan
+    fused = getattr(mapping, '_fused_resample', None)
+    if fused is not None and kw.get('method', 'mean') == 'mean' and not kw.get('arcsecPerPx') and \
+            set(kw) <= {'pxPerDeg', 'containsPole', 'method', 'arcsecPerPx'}:
+        # a camera mapping whose arrays nobody has asked for yet: the single-pass plan on the (MLat, SM longitude) grid
+        res = fused(_px_per_deg(kw.get('pxPerDeg', 25)), kw.get('containsPole'), magnetic=True)
+        if res is not None:
+            last_plan = res['plan']
+            img = ma.masked_array(res['img'], mask=np.repeat(res['mask'][:, :, None], res['img'].shape[2], 2))
+            elevation = ma.masked_invalid(res['mean'][:, :, -1], copy=False)
+            from .mapping.mapping import GenericMapping
+            sm = GenericMapping(res['lat'], res['lon'], res['lat_c'], res['lon_c'], elevation, mapping.altitude, img,
+                                mapping.cameraPosGCRS, mapping.photoTime, mapping.identifier)
+            return convertSMMappingToGeo(sm)
     sm = convertMappingToSM(mapping)
     smResampled = resample(sm, **kw)
     return convertSMMappingToGeo(smResampled)
+
+
+# 'single-pass' / 'two-pass': the plan the last resample() of a camera mapping took (None: the array pipeline)
+last_plan = None
+
+
+def _px_per_deg(pxPerDeg):
+    try:
+        _, _ = pxPerDeg
+    except TypeError:
+        assert pxPerDeg is not None
+        pxPerDeg = (pxPerDeg, pxPerDeg)
+    return tuple(pxPerDeg)
 
 
 def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=None, method='mean'):
@@ -88,6 +115,18 @@ def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=No
     _check_method(method)
 
     def doResample(mapping, pxPerDeg, arcsecPerPx, containsPole):
+        global last_plan
+        last_plan = None
+        fused = getattr(mapping, '_fused_resample', None)
+        if fused is not None and method == 'mean' and not arcsecPerPx:
+            # a camera mapping whose arrays nobody has asked for yet (getMapping(...).maskedByElevation(e), the user
+            # guide's flow): georeferencing, mask, bounding box and binning in ONE kernel
+            res = fused(_px_per_deg(pxPerDeg), containsPole)
+            if res is not None:
+                last_plan = res['plan']
+                img = ma.masked_array(res['img'], mask=np.repeat(res['mask'][:, :, None], res['img'].shape[2], 2))
+                elevation = ma.masked_invalid(res['mean'][:, :, -1], copy=False)
+                return mapping.createResampled(res['lat'], res['lon'], res['lat_c'], res['lon_c'], elevation, img)
         if containsPole is None:
             containsPole = mapping.containsPole
         if arcsecPerPx:

@@ -74,7 +74,7 @@ def test_convert_both_routes(tmp_path, capsys):
     d = write_frames(tmp_path)
     # 1. the reference's route: arcsec / px from each frame's box, MLat/MLT grid by default
     out1 = str(tmp_path / 'o1')
-    main(['--data', d, '--format', 'netcdf', '--resample', '--resolution', '900', '--out', out1])
+    main(['--data', d, '--format', 'netcdf', '--resample', '--min-elevation', '10', '--resolution', '900', '--out', out1])
     assert sorted(os.listdir(out1)) == ['frame00.nc', 'frame01.nc', 'frame02.nc']
     hdr = json.load(open(os.path.join(d, 'frame01.json')))
     m = getMapping(np.load(os.path.join(d, 'frame01.npy')), hdr, fastCenterCalculation=True,
@@ -95,12 +95,12 @@ def test_convert_both_routes(tmp_path, capsys):
     assert back.identifier == 'frame01' and back.altitude == 110 and back.photoTime == m.photoTime
     # re-running refuses, --skip skips, --overwrite overwrites
     with pytest.raises(SystemExit):
-        main(['--data', d, '--format', 'netcdf', '--resample', '--resolution', '900', '--out', out1])
-    main(['--data', d, '--format', 'netcdf', '--resample', '--resolution', '900', '--out', out1, '--skip'])
+        main(['--data', d, '--format', 'netcdf', '--resample', '--min-elevation', '10', '--resolution', '900', '--out', out1])
+    main(['--data', d, '--format', 'netcdf', '--resample', '--min-elevation', '10', '--resolution', '900', '--out', out1, '--skip'])
     assert 'skipping' in capsys.readouterr().out
     # 2. the fast route: fixed px/deg through the single-pass sequence pipeline, geographic grid, no bounds
     out2 = str(tmp_path / 'o2')
-    main(['--data', d, '--format', 'netcdf', '--resample', '--grid', 'geo', '--px-per-deg', '5', '--out', out2, '--without-bounds',
+    main(['--data', d, '--format', 'netcdf', '--resample', '--min-elevation', '10', '--grid', 'geo', '--px-per-deg', '5', '--out', out2, '--without-bounds',
           '--without-mag'])
     want = resample(m, pxPerDeg=5)
     f = _nc3.File(os.path.join(out2, 'frame01.nc'))

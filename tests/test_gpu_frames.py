@@ -387,42 +387,51 @@ def test_item_order_is_a_pure_scheduling_hint():
 @pytest.mark.parametrize('altitude', [100, 110, 120])
 def test_config4_mlat_mlt_three_shells_full_size(altitude):
     """
-    BASELINE.json configs[3]: geomagnetic transform + MLat/MLT resample on three altitude shells at full size.
-    The oracle is run on two windows of the frame (a header whose reference pixel is shifted describes exactly the
-    same pixels), the resampling is checked through the class path and through conservation properties.
+    BASELINE.json configs[3]: geomagnetic transform + MLat/MLT resample on three altitude shells at full size, against
+    the oracle over the WHOLE frame: all nine per-pixel arrays (lat, lon, MLat, MLT of corners and centres, elevation)
+    within 1e-6 deg with identical NaN patterns, and the resampled (MLat, SM longitude) grid of every shell — the
+    reference's resampleMLatMLT (resample.py:63-71 -> _resample on (mlat, mltToSmLon(mlt))) — cell for cell: mask,
+    integer channel means, elevation means to 1e-9 deg, grid coordinates.
     """
+    from oracle import ref_numpy as O
     from auromat_amd.pipeline import FramePipeline
     from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
-    from auromat_amd.resample import resampleMLatMLT
+    from auromat_amd.resample import grid_coordinates, resampleMLatMLT
     from auromat_amd.synthetic import frame_header, frame_image
     w, h = 4240, 2832
     hdr, cam, t = frame_header(w, h, 'iss030')
     img = frame_image(w, h, seed=altitude)
     pipe = FramePipeline(w, h, with_mag=True)
-    res = pipe.run(hdr, altitude, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, magnetic=True)
+    res = pipe.run(hdr, altitude, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, magnetic=True, fuse=True)
+    assert pipe.last_plan == 'single-pass'
     got = pipe.host_arrays()
-    # windows: one across the limb (mixed hits / misses), one deep inside the Earth part of the frame
-    hit_rows = np.where(~np.isnan(got['lat'][:, w // 2]))[0]
-    assert len(hit_rows) > 300
-    for x0, y0, ww, wh in ((w // 2 - 60, max(int(hit_rows[0]) - 40, 0), 120, 80), (w - 150, h - 100, 150, 100)):
-        sub = dict(hdr, IMAGEW=ww, IMAGEH=wh, CRPIX1=hdr['CRPIX1'] - x0, CRPIX2=hdr['CRPIX2'] - y0)
-        g = oracle_frame(sub, cam, t, True, alt=altitude)
-        for k in ('lat', 'lon', 'mlat'):
-            nan_close(got[k][y0:y0 + wh + 1, x0:x0 + ww + 1], g[k], TOL_DEG)
-        nan_close(got['mlt'][y0:y0 + wh + 1, x0:x0 + ww + 1], g['mlt'], TOL_DEG * 24 / 360)
-        for k in ('lat_c', 'lon_c', 'elev', 'mlat_c'):
-            nan_close(got[k][y0:y0 + wh, x0:x0 + ww], g[k], TOL_DEG)
-        nan_close(got['mlt_c'][y0:y0 + wh, x0:x0 + ww], g['mlt_c'], TOL_DEG * 24 / 360)
-    # resampled MLat/MLT grid: pixel conservation and exact integer sums
-    keep = got['elev'] >= 10
-    smlon = (got['mlt_c'] - 12) / (24 / 360)
-    g = res['grid']
-    inside = keep & (smlon >= g.xrange[0]) & (smlon < g.xrange[1]) & (got['mlat_c'] >= g.yrange[0]) & \
-        (got['mlat_c'] < g.yrange[1])
-    assert int(res['count'].sum()) == int(inside.sum()) > 1000000
-    filled = res['count'] > 0
-    total = (res['mean'][..., :3][filled] * res['count'][filled][:, None]).sum(axis=0)
-    np.testing.assert_allclose(total, img[inside].astype(np.float64).sum(axis=0), rtol=1e-12)
+    g = oracle_frame(hdr, cam, t, True, alt=altitude)
+    assert int((~np.isnan(g['lat'])).sum()) > 5000000
+    for k in ('lat', 'lon', 'mlat', 'lat_c', 'lon_c', 'elev', 'mlat_c'):
+        nan_close(got[k], g[k], TOL_DEG)
+    for k in ('mlt', 'mlt_c'):
+        nan_close(got[k], g[k], TOL_DEG * 24 / 360)
+    # the oracle's resampleMLatMLT: the box over the corners that survive maskedByElevation, in (MLat, SM longitude)
+    corner_mask, center_mask = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), 10)
+    bbox, disc = O.bbox_of_corners(g['mlat'], O.mlt_to_sm_lon(g['mlt']), corner_mask)
+    data = np.dstack((img.astype(np.float64), g['elev']))
+    data[center_mask] = np.nan
+    outline = np.transpose([g['mlat'][~corner_mask], O.mlt_to_sm_lon(g['mlt'])[~corner_mask]])
+    want = O.resample_mean(np.where(center_mask, np.nan, g['mlat_c']), np.where(center_mask, np.nan, O.mlt_to_sm_lon(g['mlt_c'])),
+                           altitude, data, outline, bbox, (10, 10), disc, False)
+    assert res['mean'].shape == want['data'].shape, (res['mean'].shape, want['data'].shape)
+    mask = np.isnan(want['data'][..., 0])
+    assert np.array_equal(res['mask'], mask) and (~mask).sum() > 2000
+    ok = ~mask
+    assert np.array_equal(res['mean'][..., :3][ok], want['data'][..., :3][ok])           # exact integer sums / counts
+    assert np.max(np.abs(res['mean'][..., 3][ok] - want['data'][..., 3][ok])) < 1e-9    # elevation, fixed-point sums
+    c = grid_coordinates(res)
+    for a, b in (('lat', 'lat'), ('lon', 'lon'), ('lat_c', 'lat_c'), ('lon_c', 'lon_c')):
+        assert np.array_equal(c[a], want[b]), a
+    # the two-pass plan gives the same bits
+    two = pipe.run(hdr, altitude, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, magnetic=True, fuse=False)
+    for k in ('mean', 'count', 'img', 'mask'):
+        assert np.array_equal(two[k], res[k], equal_nan=True), k
     if altitude == 110:
         # the reference's own call sequence (resample.py:63-71) gives the same grid
         m = ArraySpacecraftMapping(hdr, altitude, img, cam, t, 'c4', fastCenterCalculation=True).maskedByElevation(10)

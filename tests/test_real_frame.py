@@ -70,6 +70,42 @@ def test_the_references_call_sequence_on_its_own_test_frame():
 
 
 @pytest.mark.gpu
+def test_user_guide_flow_takes_the_single_pass_plan():
+    """`resample(getMapping(img, wcs).maskedByElevation(10), pxPerDeg=10)` with nothing else asked of the mapping: the mask
+    is only remembered and resample() runs the fused kernel (ONE launch: georeferencing, mask, box, binning) — the
+    reference's grid, cell for cell; the same for resampleMLatMLT; the arrays, asked for afterwards, carry the mask."""
+    import auromat_amd.resample as R
+    from auromat_amd.mapping.spacecraft import getMapping
+    z = load_golden('real_frame_iss030.npz')
+    for fast, name in ((True, 'real_frame_iss030.npz'), (False, 'real_frame_iss030_exact.npz')):
+        z = load_golden(name)
+        mm = getMapping(JPG, WCS, altitude=110, fastCenterCalculation=fast).maskedByElevation(10)
+        assert mm._frame is None and mm._lazy_elev == 10.0
+        r = R.resample(mm, pxPerDeg=10)
+        assert R.last_plan == 'single-pass' and mm._frame is None
+        r.checkGuarantees()
+        assert np.array_equal(r.lats.data, z['out_lat']) and np.array_equal(r.lonsCenter.data, z['out_lon_c'])
+        check(r.img.data, ma.getmaskarray(r.img)[..., 0], None, z)
+        assert r.img.dtype == np.uint8
+    zs = load_golden('real_frame_iss030_sm.npz')
+    mm = getMapping(JPG, WCS, fastCenterCalculation=True).maskedByElevation(10)
+    r = R.resampleMLatMLT(mm, pxPerDeg=10)
+    assert R.last_plan == 'single-pass' and mm._frame is None
+    check(r.img.data, ma.getmaskarray(r.img)[..., 0], None, zs)
+    # ... and the arrays of the lazily masked mapping, on first use
+    z = load_golden('real_frame_iss030.npz')
+    assert int((~ma.getmaskarray(mm.latsCenter)).sum()) == int(z['n_valid'])
+    mm.checkGuarantees()
+    assert R.resample(mm, pxPerDeg=10) is not None and R.last_plan is None          # arrays exist: the array pipeline
+    # a threshold that masks everything: the reference's ValueError, at first use
+    none = getMapping(JPG, WCS, fastCenterCalculation=True).maskedByElevation(89.99)
+    with pytest.raises(ValueError):
+        R.resample(none, pxPerDeg=10)
+    with pytest.raises(ValueError):
+        none.lats
+
+
+@pytest.mark.gpu
 def test_both_plans_on_the_references_test_frame():
     from auromat_amd.fits import getShiftedSpacecraftPosition, readHeader
     from auromat_amd.pipeline import FramePipeline
@@ -153,7 +189,7 @@ def test_convert_driver_on_the_references_test_frame(tmp_path):
     from auromat_amd.export import _nc3
     z = load_golden('real_frame_iss030.npz')
     out = str(tmp_path / 'converted')
-    main(['--data', os.path.join(GOLDEN, 'resources'), '--format', 'netcdf', '--resample', '--grid', 'geo', '--px-per-deg', '10',
+    main(['--data', os.path.join(GOLDEN, 'resources'), '--format', 'netcdf', '--resample', '--min-elevation', '10', '--grid', 'geo', '--px-per-deg', '10',
           '--out', out, '--without-mag'])
     assert os.listdir(out) == ['ISS030-E-102170_dc.nc']
     f = _nc3.File(os.path.join(out, 'ISS030-E-102170_dc.nc'))

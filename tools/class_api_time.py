@@ -21,3 +21,21 @@ for rep in range(3):
     t5 = time.perf_counter()
     print('getMapping (JPEG decode) %.3f s, maskedByElevation %.3f s, resample %.3f s, resampleMLatMLT %.3f s, lats to host %.3f s'
           % (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4), geo.img.shape)
+
+# the same with the image as an array (no JPEG decode in the timing) and nothing asked of the mapping but the resampling:
+# the mask is remembered, resample() runs the single-pass plan; then one per-pixel array to the host
+import numpy as np
+import auromat_amd.resample as R
+from auromat_amd.util.image import loadImage
+arr = loadImage(img)
+for rep in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mm = getMapping(arr, wcs, altitude=110, fastCenterCalculation=True).maskedByElevation(10)
+    t1 = time.perf_counter()
+    geo = resample(mm, pxPerDeg=10)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    plan = R.last_plan
+    lat = mm.latsCenter
+    t3 = time.perf_counter()
+    print('array input: getMapping + maskedByElevation %.2f ms, resample %.2f ms (%s), latsCenter to host (arrays + mask on first use) %.2f ms'
+          % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, plan, (t3 - t2) * 1e3), geo.img.shape)
