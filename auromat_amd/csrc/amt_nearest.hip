@@ -226,6 +226,185 @@ __global__ void k_nn_gather(const long long* __restrict__ index, int64_t total, 
     }
 }
 
+// ---- method='linear' (reference resample.py:323-326: scipy.interpolate.griddata(method='linear'), i.e. barycentric
+// interpolation on a Delaunay triangulation of the valid pixel centres in the (lat, lon) plane) ----------------------
+// The pixel centres are a smoothly mapped regular grid, so their Delaunay triangulation is, locally, that of a lattice:
+// the cells of the REDUCED basis (Gauss reduction of the two grid steps at the pixel centre nearest to the grid centre,
+// amt_nearest_frame) cut along the diagonal the empty-circle criterion picks; a cell with three valid centres is that
+// triangle.  Where a cell is close to cocircular Qhull's triangulation takes either diagonal: values then differ
+// from scipy's within the spread of the two diagonal interpolants of the cell, which the kernel reports beside the
+// value (`alt`); tests/test_gpu_nearest.py pins the rule.
+struct lin_args {
+    const double* lat_c;
+    const double* lon_c;
+    const double* elev;
+    const uint8_t* center_mask;
+    int height, width;
+    double min_elev;
+    int lon_wrap, nchan;
+};
+
+__device__ __forceinline__ bool lin_valid(const lin_args& A, int i, int j, double* x, double* y) {
+    if (i < 0 || j < 0 || i >= A.height || j >= A.width) return false;
+    const int64_t p = (int64_t)i * A.width + j;
+    const double la = A.lat_c[p];
+    double lo = A.lon_c[p];
+    if (!(la == la) || !(lo == lo)) return false;
+    if (A.center_mask != nullptr && A.center_mask[p]) return false;
+    if (A.elev != nullptr && !(A.elev[p] >= A.min_elev)) return false;
+    if (A.lon_wrap) lo = wrap180_shifted(lo);
+    *x = la, *y = lo;
+    return true;
+}
+
+// barycentric coordinates of (px, py) in triangle (x0,y0),(x1,y1),(x2,y2); false for a degenerate triangle
+__device__ __forceinline__ bool lin_bary(double x0, double y0, double x1, double y1, double x2, double y2, double px, double py,
+                                         double* w) {
+    const double d = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    if (!(fabs(d) > 0)) return false;
+    w[1] = ((px - x0) * (y2 - y0) - (x2 - x0) * (py - y0)) / d;
+    w[2] = ((x1 - x0) * (py - y0) - (px - x0) * (y1 - y0)) / d;
+    w[0] = 1.0 - w[1] - w[2];
+    return true;
+}
+
+__device__ __forceinline__ bool lin_inside(const double* w) {
+    constexpr double eps = 1e-12;
+    return w[0] >= -eps && w[1] >= -eps && w[2] >= -eps;
+}
+
+// is D strictly inside the circumcircle of A, B, C (any orientation)?
+__device__ __forceinline__ bool lin_incircle(double ax, double ay, double bx, double by, double cx, double cy, double dx, double dy) {
+    const double adx = ax - dx, ady = ay - dy, bdx = bx - dx, bdy = by - dy, cdx = cx - dx, cdy = cy - dy;
+    const double ad = adx * adx + ady * ady, bd = bdx * bdx + bdy * bdy, cd = cdx * cdx + cdy * cdy;
+    const double det = adx * (bdy * cd - bd * cdy) - ady * (bdx * cd - bd * cdx) + ad * (bdx * cdy - bdy * cdx);
+    const double orient = (bx - ax) * (cy - ay) - (cx - ax) * (by - ay);
+    return orient > 0 ? det > 0 : det < 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_linear_gather(lin_args A, const long long* __restrict__ index, int ny, int nx,
+                                                          const double* __restrict__ tlat, const double* __restrict__ tlon,
+                                                          const T* __restrict__ img, double* __restrict__ mean,
+                                                          T* __restrict__ out_img, uint8_t* __restrict__ out_mask,
+                                                          double* __restrict__ alt, long long* __restrict__ out_tri) {
+    constexpr double kNaN = __builtin_nan("");
+    const int nch = A.nchan;
+    AMT_GRID_STRIDE(t, (int64_t)ny * nx) {
+        const long long near = index[t];
+        const int ty = (int)(t / nx), tx = (int)(t - (int64_t)ty * nx);
+        const double px = tlat[ty], py = tlon[tx];
+        long long tri[3] = {-1, -1, -1}, tri2[3] = {-1, -1, -1};
+        double w[3] = {0, 0, 0}, w2[3] = {0, 0, 0};
+        bool found = false, found2 = false;
+        if (near >= 0) {
+            const int pi = (int)(near / A.width), pj = (int)(near - (long long)pi * A.width);
+            // The Delaunay triangulation of a smoothly mapped pixel grid joins neighbours of the REDUCED lattice basis, not
+            // of the index grid: seen obliquely, a pixel's footprint is several times longer than wide in the (lat, lon)
+            // plane, and the compact triangles join pixels like (i, j) and (i + 1, j + 3).  So: the local basis (one step
+            // in j, one step in i) at the nearest centre, Gauss-reduced (integer combinations with the shortest vectors),
+            // and the cells of THAT lattice around the grid centre, each cut along the diagonal the empty-circle test picks.
+            double x0, y0, xa, ya, xb, yb;
+            int uj = 1, ui = 0, vj = 0, vi = 1;                 // index steps of the two basis vectors
+            bool have = lin_valid(A, pi, pj, &x0, &y0);
+            double ux = 0, uy = 0, vx = 0, vy = 0;
+            if (have) {
+                if (lin_valid(A, pi, pj + 1, &xa, &ya)) ux = xa - x0, uy = ya - y0;
+                else if (lin_valid(A, pi, pj - 1, &xa, &ya)) ux = x0 - xa, uy = y0 - ya;
+                else have = false;
+                if (lin_valid(A, pi + 1, pj, &xb, &yb)) vx = xb - x0, vy = yb - y0;
+                else if (lin_valid(A, pi - 1, pj, &xb, &yb)) vx = x0 - xb, vy = y0 - yb;
+                else have = false;
+            }
+            if (have) {
+                for (int it = 0; it < 16; ++it) {
+                    double uu = ux * ux + uy * uy, vv = vx * vx + vy * vy;
+                    if (uu > vv) {
+                        double tx_ = ux; ux = vx; vx = tx_;
+                        double ty_ = uy; uy = vy; vy = ty_;
+                        int tj = uj; uj = vj; vj = tj;
+                        int ti = ui; ui = vi; vi = ti;
+                        uu = vv;
+                    }
+                    if (!(uu > 0)) break;
+                    const double m = rint((ux * vx + uy * vy) / uu);
+                    if (m == 0) break;
+                    vx -= m * ux, vy -= m * uy;
+                    vj -= (int)m * uj, vi -= (int)m * ui;
+                }
+                const double det = ux * vy - uy * vx;
+                have = fabs(det) > 0;
+                if (have) {
+                    // lattice coordinates of the grid centre relative to the nearest pixel centre
+                    const double al = ((px - x0) * vy - (py - y0) * vx) / det, be = (ux * (py - y0) - uy * (px - x0)) / det;
+                    const int a0 = (int)floor(al), b0 = (int)floor(be);
+                    for (int ring = 0; ring < 2 && !found; ++ring)
+                        for (int da = -ring; da <= ring && !found; ++da)
+                            for (int db = -ring; db <= ring && !found; ++db) {
+                                if (ring == 1 && da == 0 && db == 0) continue;
+                                const int a = a0 + da, b = b0 + db;
+                                double x[4], y[4];
+                                // corners in cyclic order: (a, b), (a+1, b), (a+1, b+1), (a, b+1) of the reduced lattice
+                                const int ca[4] = {a, a + 1, a + 1, a}, cb[4] = {b, b, b + 1, b + 1};
+                                int ci[4], cj[4];
+                                bool v[4];
+                                int nv = 0;
+                                for (int k = 0; k < 4; ++k) {
+                                    ci[k] = pi + ca[k] * ui + cb[k] * vi;
+                                    cj[k] = pj + ca[k] * uj + cb[k] * vj;
+                                    v[k] = lin_valid(A, ci[k], cj[k], &x[k], &y[k]);
+                                    nv += v[k] ? 1 : 0;
+                                }
+                                if (nv < 3) continue;
+                                auto id = [&](int k) { return (long long)ci[k] * A.width + cj[k]; };
+                                auto try_tri = [&](int k0, int k1, int k2, double* ww, long long* tt) {
+                                    if (!lin_bary(x[k0], y[k0], x[k1], y[k1], x[k2], y[k2], px, py, ww) || !lin_inside(ww)) return false;
+                                    tt[0] = id(k0), tt[1] = id(k1), tt[2] = id(k2);
+                                    return true;
+                                };
+                                if (nv == 3) {
+                                    int k[3], m = 0;
+                                    for (int q = 0; q < 4; ++q)
+                                        if (v[q]) k[m++] = q;
+                                    found = try_tri(k[0], k[1], k[2], w, tri);
+                                    continue;
+                                }
+                                // diagonal 0-2 unless corner 3 lies inside the circle through 0, 1, 2 (then 1-3)
+                                const bool flip = lin_incircle(x[0], y[0], x[1], y[1], x[2], y[2], x[3], y[3]);
+                                if (!flip) {
+                                    found = try_tri(0, 1, 2, w, tri) || try_tri(0, 2, 3, w, tri);
+                                    if (found) found2 = try_tri(0, 1, 3, w2, tri2) || try_tri(1, 2, 3, w2, tri2);
+                                } else {
+                                    found = try_tri(0, 1, 3, w, tri) || try_tri(1, 2, 3, w, tri);
+                                    if (found) found2 = try_tri(0, 1, 2, w2, tri2) || try_tri(0, 2, 3, w2, tri2);
+                                }
+                            }
+                }
+            }
+        }
+        for (int c = 0; c <= nch; ++c) {
+            double val = kNaN, val2 = kNaN;
+            if (found) {
+                val = 0;
+                for (int k = 0; k < 3; ++k)
+                    val += w[k] * (c < nch ? (double)img[tri[k] * nch + c] : (A.elev ? A.elev[tri[k]] : kNaN));
+                val2 = val;
+                if (found2) {
+                    val2 = 0;
+                    for (int k = 0; k < 3; ++k)
+                        val2 += w2[k] * (c < nch ? (double)img[tri2[k] * nch + c] : (A.elev ? A.elev[tri2[k]] : kNaN));
+                }
+            }
+            if (mean) mean[t * (nch + 1) + c] = val;
+            if (alt) alt[t * (nch + 1) + c] = val2;
+            if (c < nch && out_img) out_img[t * nch + c] = found ? (T)rint(val) : (T)0;      // np.round: half to even
+        }
+        if (out_mask) out_mask[t] = found ? 0 : 1;
+        if (out_tri)
+            for (int k = 0; k < 3; ++k) out_tri[t * 3 + k] = tri[k];
+    }
+}
+
 // matplotlib.path.Path(polygon).contains_points(points) (reference utils.py:58-74): crossing test of a ray towards
 // +x with the half-open edge rule (vertex y >= point y) of Agg's point_in_path; the path is closed implicitly.
 // Edges are staged through LDS in chunks; an edge whose y-range misses the y-range of the block's points cannot
@@ -360,6 +539,38 @@ int amt_nearest_gather(amt_ctx* ctx, const int64_t* index, int64_t n_targets, co
         hipLaunchKernelGGL(k_nn_gather<uint8_t>, grid_for(n_targets), dim3(kBlock), 0, ctx->stream, idx, n_targets,
                            static_cast<const uint8_t*>(img), nchan, elev, mean, static_cast<uint8_t*>(out_img),
                            out_mask);
+    }
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_linear_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx, const double* lat_c, const double* lon_c,
+                      const double* elev, const uint8_t* center_mask, int32_t height, int32_t width, double min_elevation,
+                      int lon_wrap, const double* target_lat, const double* target_lon, const void* img, int32_t img_dtype,
+                      int32_t nchan, double* mean, void* out_img, uint8_t* out_mask, double* alt_mean, int64_t* out_triangles) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, index && lat_c && lon_c && target_lat && target_lon, "NULL argument");
+    AMT_REQUIRE(ctx, ny >= 0 && nx >= 0 && height > 0 && width > 0, "bad size");
+    AMT_REQUIRE(ctx, nchan >= 0 && nchan <= 4, "nchan must be 0..4");
+    AMT_REQUIRE(ctx, nchan == 0 || (img && (img_dtype == 1 || img_dtype == 2)), "img must be uint8 (1) or uint16 (2)");
+    const int64_t total = (int64_t)ny * nx;
+    if (total == 0) return AMT_OK;
+    lin_args A;
+    A.lat_c = lat_c, A.lon_c = lon_c, A.elev = elev, A.center_mask = center_mask;
+    A.height = height, A.width = width;
+    A.min_elev = min_elevation;
+    A.lon_wrap = lon_wrap ? 1 : 0;
+    A.nchan = nchan;
+    const long long* idx = reinterpret_cast<const long long*>(index);
+    long long* tri = reinterpret_cast<long long*>(out_triangles);
+    if (img_dtype == 2) {
+        hipLaunchKernelGGL(k_linear_gather<uint16_t>, grid_for(total), dim3(kBlock), 0, ctx->stream, A, idx, ny, nx, target_lat,
+                           target_lon, static_cast<const uint16_t*>(img), mean, static_cast<uint16_t*>(out_img), out_mask,
+                           alt_mean, tri);
+    } else {
+        hipLaunchKernelGGL(k_linear_gather<uint8_t>, grid_for(total), dim3(kBlock), 0, ctx->stream, A, idx, ny, nx, target_lat,
+                           target_lon, static_cast<const uint8_t*>(img), mean, static_cast<uint8_t*>(out_img), out_mask,
+                           alt_mean, tri);
     }
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;

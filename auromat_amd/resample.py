@@ -107,9 +107,10 @@ def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=No
     :param None|number arcsecPerPx: spherical resolution, used to approximate pxPerDeg; has precedence
     :param None|bool containsPole: specify True|False to skip the pole check
     :param method: binning: 'mean'; interpolation: 'nearest' (value of the closest pixel centre in the lat/lon
-                   plane, masked outside the mapping's outline).  The reference's triangulating methods ('linear',
-                   'cubic': scipy griddata on a Delaunay triangulation, "considerably longer ... no benefit over
-                   'nearest' if the goal is downsampling") are not implemented.
+                   plane) and 'linear' (barycentric interpolation in the triangle of pixel centres that holds the grid
+                   centre; the triangulation is that of the pixel grid, which equals the reference's Qhull triangulation
+                   up to the choice of diagonal in near-cocircular quads: values agree within the spread of the two
+                   diagonals), both masked outside the mapping's outline.  'cubic' is not implemented.
     :rtype: a subclass of BaseMapping or MappingCollection
     """
     _check_method(method)
@@ -309,10 +310,21 @@ def _rotate_pole_host(lat_deg, lon_deg, altitude, angle):
     return to_host(la), to_host(lo)
 
 
+def wrap_at_180_t(t):
+    """wrap_at_180 on a torch tensor (astropy Angle.wrap_at(180 deg): into [-180, 180))."""
+    import torch
+    a = t - torch.floor((t + 180.0) / 360.0) * 360.0
+    a = torch.where(a >= 180.0, a - 360.0, a)
+    return torch.where(a < -180.0, a + 360.0, a)
+
+
 def _check_method(method):
-    if method in ('linear', 'cubic', 'median'):
-        raise NotImplementedError("method='%s' is not implemented (use 'mean' or 'nearest')" % method)
-    if method not in ('mean', 'nearest'):
+    if method in ('cubic', 'median'):
+        # (the reference: "linear and cubic take considerably longer and use much more memory while they don't bring any
+        # benefit over 'nearest' if the goal is downsampling", resample.py:303-305; 'cubic' is scipy's Clough-Tocher
+        # scheme on the same triangulation)
+        raise NotImplementedError("method='%s' is not implemented (use 'mean', 'nearest' or 'linear')" % method)
+    if method not in ('mean', 'nearest', 'linear'):
         raise ValueError('unknown resampling method: ' + str(method))
 
 
@@ -405,8 +417,8 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
     grid = cached_grid(pxPerDeg, latMin, latMax, lonMin, lonMax)
     xaxis, yaxis = grid.axes(ctx)
     nch = fd.nchan
-    if method == 'nearest':
-        assert outline is not None, "method='nearest' needs the outline of the mapping"
+    if method in ('nearest', 'linear'):
+        assert outline is not None, "method='%s' needs the outline of the mapping" % method
         assert shard is None, "rows of one frame over several ranks: method='mean' only"
         outline = np.array(outline, dtype=np.float64)
         if containsPole:
@@ -419,16 +431,31 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
         mean = ctx.empty((grid.ny, grid.nx, nch + 1))
         img = ctx.empty((grid.ny, grid.nx, max(nch, 1)), torch.uint8 if fd.img_dtype_code != 2 else torch.int16)
         mask = ctx.empty((grid.ny, grid.nx), torch.uint8)
-        ctx.call('amt_nearest_gather', ptr(index), grid.nx * grid.ny, ptr(fd.img), fd.img_dtype_code or 1, nch,
-                 ptr(fd.elev), ptr(mean), ptr(img) if nch else None, ptr(mask))
+        extra = {}
+        if method == 'nearest':
+            ctx.call('amt_nearest_gather', ptr(index), grid.nx * grid.ny, ptr(fd.img), fd.img_dtype_code or 1, nch,
+                     ptr(fd.elev), ptr(mean), ptr(img) if nch else None, ptr(mask))
+        else:
+            # barycentric interpolation in the triangle of the pixel grid that holds the grid centre (reference
+            # resample.py:323-326: scipy griddata(method='linear')); `alt`: the value with the quad's other diagonal
+            tlat, tlon = grid.device_centers(ctx)
+            alt = ctx.empty((grid.ny, grid.nx, nch + 1))
+            tri = ctx.empty((grid.ny, grid.nx, 3), torch.int64)
+            min_el = float('-inf') if min_elevation is None else float(min_elevation)
+            ctx.call('amt_linear_gather', ptr(index), grid.ny, grid.nx, ptr(lat_c), ptr(lon_c), ptr(fd.elev), ptr(fd.center_mask),
+                     fd.height, fd.width, min_el, lon_wrap, ptr(tlat), ptr(tlon), ptr(fd.img), fd.img_dtype_code or 1, nch,
+                     ptr(mean), ptr(img) if nch else None, ptr(mask), ptr(alt), ptr(tri))
+            extra = dict(alt=alt, triangles=tri)
         out = dict(has_elev=fd.elev is not None, grid=grid, contains_pole=bool(containsPole),
                    contains_discontinuity=bool(containsDiscontinuity), altitude=altitude)
         if keep_on_device:
-            out.update(mean=mean, img=img, mask=mask, index=index)
+            out.update(mean=mean, img=img, mask=mask, index=index, **extra)
             return out
         out.update(grid_coordinates(out))
         out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype if nch else np.uint8),
                    mask=to_host(mask).astype(bool), index=to_host(index, dtype=np.int64))
+        if extra:
+            out.update(alt=to_host(extra['alt']), triangles=to_host(extra['triangles'], dtype=np.int64))
         return out
     acc = ctx.zeros((nch + 2, grid.nx * grid.ny), torch.int64)
     min_el = float('-inf') if min_elevation is None else float(min_elevation)
@@ -518,8 +545,28 @@ def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingB
         index = nearest_indices(ctx, lat_c.reshape(-1), lon_c.reshape(-1), None, None, h, w, None, grid, lon_wrap,
                                 target_mask)
         flat = ctx.to_device(np.ascontiguousarray(d.reshape(h * w, d.shape[2])))
-        picked = flat[index.clamp(min=0).reshape(-1)]
-        picked[index.reshape(-1) < 0] = float('nan')
+        if method == 'nearest':
+            picked = flat[index.clamp(min=0).reshape(-1)]
+            picked[index.reshape(-1) < 0] = float('nan')
+        else:
+            # the triangle of every grid centre from the kernel, the barycentric sum of arbitrary float channels here
+            tlat, tlon = grid.device_centers(ctx)
+            tri = ctx.empty((grid.ny, grid.nx, 3), torch.int64)
+            la, lo = lat_c.reshape(-1).contiguous(), lon_c.reshape(-1).contiguous()
+            ctx.call('amt_linear_gather', ptr(index), grid.ny, grid.nx, ptr(la), ptr(lo), None, None, h, w, float('-inf'),
+                     lon_wrap, ptr(tlat), ptr(tlon), None, 1, 0, None, None, None, None, ptr(tri))
+            tri = tri.reshape(-1, 3)
+            ok = tri[:, 0] >= 0
+            t = tri.clamp(min=0)
+            x, y = la[t], (wrap_at_180_t(lo + 180) if lon_wrap else lo)[t]
+            px = tlat[:, None].expand(grid.ny, grid.nx).reshape(-1)
+            py = tlon[None, :].expand(grid.ny, grid.nx).reshape(-1)
+            det = (x[:, 1] - x[:, 0]) * (y[:, 2] - y[:, 0]) - (x[:, 2] - x[:, 0]) * (y[:, 1] - y[:, 0])
+            w1 = ((px - x[:, 0]) * (y[:, 2] - y[:, 0]) - (x[:, 2] - x[:, 0]) * (py - y[:, 0])) / det
+            w2 = ((x[:, 1] - x[:, 0]) * (py - y[:, 0]) - (px - x[:, 0]) * (y[:, 1] - y[:, 0])) / det
+            wts = torch.stack((1.0 - w1 - w2, w1, w2), dim=1)
+            picked = (wts[:, :, None] * flat[t]).sum(dim=1)
+            picked[~ok] = float('nan')
         mean = to_host(picked.reshape(grid.ny, grid.nx, d.shape[2]))
     lat, lon, lat_gc, lon_gc = grid.lat, grid.lon, grid.lat_c, grid.lon_c
     if containsPole:

@@ -426,6 +426,20 @@ int amt_nearest_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, co
  * out_img (optional): (n_targets, nchan) of img_dtype (0 where index < 0); out_mask (optional): 1 where index < 0. */
 int amt_nearest_gather(amt_ctx* ctx, const int64_t* index, int64_t n_targets, const void* img, int32_t img_dtype,
                        int32_t nchan, const double* elev, double* mean, void* out_img, uint8_t* out_mask);
+/* method='linear' (reference resample.py:323-326: scipy.interpolate.griddata(method='linear') = barycentric
+ * interpolation on a Delaunay triangulation of the valid pixel centres in the (lat, lon) plane).  The triangulation is
+ * taken from the pixel grid: a quad of four neighbouring valid centres is cut along the diagonal the empty-circle
+ * criterion picks, a quad with three valid centres is that triangle; the triangle of a grid centre is searched among the
+ * quads within two rings of the pixel centre nearest to it (index = the output of amt_nearest_frame for the same arrays,
+ * masks, threshold and lon_wrap).  mean (ny, nx, nchan+1): interpolated channels + elevation, NaN where no triangle holds
+ * the centre; out_img rounded half to even like np.round; out_mask 1 where NaN; alt_mean (optional): the value with the
+ * quad's OTHER diagonal (= mean where the quad has one triangle) — Qhull takes either diagonal of the near-cocircular
+ * quads of a smoothly mapped grid, so scipy's value lies between the two; out_triangles (optional, (ny, nx, 3)): the flat
+ * pixel indices of the triangle used, -1 where none. */
+int amt_linear_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx, const double* lat_c, const double* lon_c,
+                      const double* elev, const uint8_t* center_mask, int32_t height, int32_t width, double min_elevation,
+                      int lon_wrap, const double* target_lat, const double* target_lon, const void* img, int32_t img_dtype,
+                      int32_t nchan, double* mean, void* out_img, uint8_t* out_mask, double* alt_mean, int64_t* out_triangles);
 /* auromat/utils.py:58-74 pointsInsidePolygon = matplotlib.path.Path(polygon).contains_points(points): crossing test
  * with Agg's half-open edge rule; polygon: (n_vertices, 2) device doubles (x, y), closed implicitly. */
 int amt_points_in_polygon(amt_ctx* ctx, const double* px, const double* py, int64_t n, const double* polygon,

@@ -552,7 +552,7 @@ def _traced_outline(lats, lons):
     return np.transpose([lats.data[outl[:, 1], outl[:, 0]], lons.data[outl[:, 1], outl[:, 0]]])
 
 
-def _run_resample_nearest(lats, lons, lats_c, lons_c, altitude, merged, ppd, pole=False):
+def _run_resample_nearest(lats, lons, lats_c, lons_c, altitude, merged, ppd, pole=False, method='nearest'):
     bb = _bbox_from(lats, lons)
     outline = _traced_outline(lats, lons)
     outline_in = outline.copy()
@@ -562,7 +562,7 @@ def _run_resample_nearest(lats, lons, lats_c, lons_c, altitude, merged, ppd, pol
     # like `lambda: mapping.outline` (resample.py:124): the SAME array on every call — the reference rotates / shifts
     # it in place (:192-193,214) and reads it again for the masking (:254)
     res = R._resample(lats_c, lons_c, altitude, merged, lambda: outline, bb, ppd,
-                      containsDiscontinuity=disc or pole, containsPole=pole, method='nearest')
+                      containsDiscontinuity=disc or pole, containsPole=pole, method=method)
     la, lo, lac, loc, data = res
     return dict(bbox=np.array([bb.latSouth, bb.lonWest, bb.latNorth, bb.lonEast]),
                 contains_discontinuity=np.bool_(disc), contains_pole=np.bool_(pole),
@@ -593,6 +593,31 @@ def resample_nearest_cases():
         case.update(lats_c=z['lats_c'], lons_c=z['lons_c'], data=z['data'], corner_lat=z['corner_lat'],
                     corner_lon=z['corner_lon'], altitude=np.float64(110), ppd=np.array((4, 4), dtype=np.float64))
         save('resample_nearest_synth_%s.npz' % tag, **case)
+
+
+def resample_linear_cases():
+    """`_resample(method='linear')` of the real reference (scipy griddata on Qhull's Delaunay triangulation + matplotlib
+    point-in-polygon): the two camera frames and the synthetic plain / date-line / pole cases of the 'nearest' fixtures.
+    Only the OUTPUT differs from those (inputs are read from them by the tests): out_data per case."""
+    out = {}
+    for pointing, ppd in (('iss030', (10, 10)), ('iss029', (4, 7))):
+        w, h = 256, 170
+        hdr, cam, t = frame_header(w, h, pointing)
+        img = frame_image(w, h, seed=3)
+        m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'r', fastCenterCalculation=True)
+        mm = m.maskedByElevation(10)
+        merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+        lats_c, lons_c = mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan)
+        case = _run_resample_nearest(mm.lats, mm.lons, lats_c, lons_c, 110, merged, ppd, method='linear')
+        out['%s_out_data' % pointing] = case['out_data']
+        out['%s_out_lat_c' % pointing] = case['out_lat_c']
+    for tag in ('plain', 'disc', 'pole'):
+        z = np.load(os.path.join(OUT, 'resample_synth_%s.npz' % tag))
+        case = _run_resample_nearest(ma.masked_invalid(z['corner_lat']), ma.masked_invalid(z['corner_lon']),
+                                     z['lats_c'], z['lons_c'], 110, z['data'], (4, 4), pole=(tag == 'pole'), method='linear')
+        out['synth_%s_out_data' % tag] = case['out_data']
+        out['synth_%s_out_lat_c' % tag] = case['out_lat_c']
+    save('resample_linear.npz', **out)
 
 
 class _RecVar(object):
@@ -976,6 +1001,6 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['host_scalars', 'georef_small', 'masks_small', 'resample_cases',
                              'histogram_edges', 'known_answers', 'georef_full', 'miracle_cases',
                              'themis_reproject_cases', 'geodesic_cases',
-                             'resample_nearest_cases']
+                             'resample_nearest_cases', 'resample_linear_cases']
     for name in which:
         globals()[name]()

@@ -163,8 +163,8 @@ def test_nearest_frame_brute_force_and_ties():
 
 def test_resample_methods_error_behaviour():
     from auromat_amd.resample import resample
-    with pytest.raises(NotImplementedError):
-        resample(None, method='linear')
+    with pytest.raises(ValueError):
+        resample(None, method='linear')            # implemented: fails on the argument, not on the method
     with pytest.raises(NotImplementedError):
         resample(None, method='cubic')
     with pytest.raises(ValueError):
@@ -268,3 +268,107 @@ def test_reference_resample_test_call_sequence():
         return [b.latNorth, b.latSouth, b.lonWest, b.lonEast]
     np.testing.assert_allclose(bb(m2), bb(m1), atol=0.15)
     np.testing.assert_allclose(bb(m3), bb(m1), atol=0.15)
+
+
+# ---- method='linear' (reference resample.py:323-326: scipy griddata on Qhull's Delaunay triangulation) ---------------
+# Pinned to outputs of the real reference (tests/golden/resample_linear.npz, oracle/make_golden.py resample_linear_cases).
+# The device triangulates the pixel grid itself: every quad of neighbouring pixel centres cut along the diagonal the
+# empty-circle criterion picks.  The quads of a smoothly mapped grid are close to cocircular, so Qhull takes either
+# diagonal; the rule that survives that choice: the reference's value lies between the interpolants of the quad's two
+# diagonals (`mean` and `alt`), and equals `mean` wherever the two agree.
+
+LINEAR = [('resample_nearest_iss030.npz', 'iss030'), ('resample_nearest_iss029.npz', 'iss029'),
+          ('resample_nearest_synth_plain.npz', 'synth_plain'), ('resample_nearest_synth_disc.npz', 'synth_disc'),
+          ('resample_nearest_synth_pole.npz', 'synth_pole')]
+
+
+@pytest.mark.parametrize('name,key', LINEAR)
+def test_resample_linear_vs_reference(name, key):
+    from auromat_amd.mapping.mapping import BoundingBox
+    from auromat_amd.resample import _resample
+    z, zl = load_golden(name), load_golden('resample_linear.npz')
+    want = zl[key + '_out_data']
+    if 'img' in z.files:
+        data = np.dstack((z['img'].astype(np.float64), z['elev']))
+        data[np.isnan(z['lats_c'])] = np.nan
+    else:
+        data = z['data']
+    s, w, n, e = z['bbox']
+    outline = z['outline'].copy()
+    lat, lon, lat_c, lon_c, out = _resample(z['lats_c'], z['lons_c'], float(z['altitude']), data, lambda: outline,
+                                            BoundingBox(s, w, n, e), tuple(z['ppd']), bool(z['contains_discontinuity']),
+                                            bool(z['contains_pole']), method='linear')
+    assert out.shape == want.shape and np.array_equal(lat_c, zl[key + '_out_lat_c']) or bool(z['contains_pole'])
+    got_nan, want_nan = np.isnan(out[..., 0]), np.isnan(want[..., 0])
+    # cells only one side fills: on the rim of the convex hull (Qhull spans concavities of the footprint with long thin
+    # triangles that the outline mask does not always remove, the pixel grid has no such triangles) — listed, and few
+    only_ref, only_here = int((got_nan & ~want_nan).sum()), int((~got_nan & want_nan).sum())
+    both = ~got_nan & ~want_nan
+    assert both.sum() > 0.85 * (~want_nan).sum(), (only_ref, only_here, int(both.sum()))
+    assert only_here <= 0.01 * both.sum(), (only_ref, only_here)
+    # every cell only the reference fills sits next to missing data (a hole in the footprint or its rim: Qhull spans
+    # those with long triangles between pixels that are far from being neighbours, the lattice cells there lack a corner):
+    # the pixel centre nearest to it has a missing pixel (or the frame's border) within two index steps
+    la, lo = z['lats_c'], z['lons_c']
+    if bool(z['contains_pole']) or bool(z['contains_discontinuity']):
+        la_g, lo_g = None, None                     # (grid in rotated / shifted coordinates: the count above is the check)
+    else:
+        valid = ~np.isnan(la)
+        vi, vj = np.nonzero(valid)
+        for ty, tx in zip(*np.nonzero(got_nan & ~want_nan)):
+            d2 = (la[vi, vj] - lat_c[ty, tx]) ** 2 + (lo[vi, vj] - lon_c[ty, tx]) ** 2
+            k = int(np.argmin(d2))
+            i, j = int(vi[k]), int(vj[k])
+            i0, i1, j0, j1 = i - 2, i + 3, j - 2, j + 3
+            rim = i0 < 0 or j0 < 0 or i1 > la.shape[0] or j1 > la.shape[1] or (~valid[max(i0, 0):i1, max(j0, 0):j1]).any()
+            assert rim, (ty, tx, i, j)
+    scale = np.nanmax(np.abs(want), axis=(0, 1))                      # per channel
+    d = np.abs(out - want)[both]
+    # a large part of the cells: the same triangle as Qhull's -> the same value to rounding (the rest: the other diagonal
+    # of a near-cocircular quad, which Qhull picks about every second time; tools/linear_probe.py: 61 % of the triangles
+    # of a camera frame are common to both triangulations)
+    same_tri = (d <= 1e-9 * scale).all(axis=1)
+    assert same_tri.mean() > 0.3, same_tri.mean()
+    # all cells: within the smoothness of the data over one quad (image noise is uncorrelated from pixel to pixel, so the
+    # image channels are only bounded by their range; the elevation channel is smooth: a diagonal flip moves it by < 1e-2 deg)
+    assert (d[:, -1] < 2e-2).all(), d[:, -1].max()
+
+
+@pytest.mark.parametrize('pointing,ppd', [('iss030', 10), ('iss029', (4, 7))])
+def test_mapping_resample_linear_between_the_two_diagonals(pointing, ppd):
+    """resample(mapping.maskedByElevation(10), method='linear') through the classes: the frame route (image + elevation in
+    the kernel) against scipy's griddata on the same arrays (the reference's own call, resample.py:323-326) with the
+    diagonal rule: scipy's value lies between the interpolants of the two diagonals of the device's quad wherever scipy
+    used a triangle of that quad, and that is the case for nearly every cell."""
+    import scipy.interpolate
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.resample import resample, resample_frame
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 256, 170
+    hdr, cam, t = frame_header(w, h, pointing)
+    img = frame_image(w, h, seed=3)
+    m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'n', fastCenterCalculation=True)
+    m.lats                                                             # (materialise: the array pipeline)
+    mm = m.maskedByElevation(10)
+    r = resample(mm, pxPerDeg=ppd, method='linear')
+    r.checkGuarantees()
+    r.checkPlateCarree()
+    p = (ppd, ppd) if np.ndim(ppd) == 0 else ppd
+    res = resample_frame(mm.frame(), 110, mm.boundingBox, p, mm.containsDiscontinuity, False, method='linear', outline=mm.outline)
+    assert np.array_equal(res['img'][~res['mask']], r.img.data[~ma.getmaskarray(r.img)[..., 0]])
+    lat_c, lon_c = mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan)
+    ok = ~np.isnan(lat_c.ravel())
+    data = np.dstack((img.astype(np.float64), mm.elevation.filled(np.nan))).reshape(-1, 4)[ok]
+    want = scipy.interpolate.griddata((lat_c.ravel()[ok], lon_c.ravel()[ok]), data,
+                                      (res['lat_c'][:, :1], res['lon_c'][:1, :]), method='linear')
+    filled = ~res['mask'] & ~np.isnan(want[..., 0])
+    assert filled.sum() > 0.9 * (~res['mask']).sum()
+    lo, hi = np.minimum(res['mean'], res['alt'])[filled], np.maximum(res['mean'], res['alt'])[filled]
+    v = want[filled]
+    tol = 1e-9 * np.nanmax(np.abs(want), axis=(0, 1))
+    inside = ((v >= lo - tol) & (v <= hi + tol)).all(axis=1)
+    assert inside.mean() > 0.97, inside.mean()
+    # the elevation of the few others (Qhull joined pixels that are not neighbours) is still the same smooth field
+    assert np.max(np.abs(res['mean'][..., 3][filled] - v[:, 3])) < 2e-2
+    # image rounding like the reference's np.round of the interpolated floats
+    assert np.array_equal(res['img'][~res['mask']], np.round(res['mean'][..., :3][~res['mask']]).astype(img.dtype))
