@@ -43,6 +43,91 @@ def euler_matrix_rzxz(ai, aj, ak):
     return m
 
 
+ZENITHAL = ('TAN', 'SIN', 'ARC', 'STG', 'ZEA')
+
+
+def projection_of(header):
+    """(projection code, has SIP terms) of a celestial WCS header, e.g. ('TAN', False) for RA---TAN / DEC--TAN."""
+    c1, c2 = str(header['CTYPE1']), str(header['CTYPE2'])
+    sip = c1.endswith('-SIP') and c2.endswith('-SIP')
+    if sip:
+        c1, c2 = c1[:-4], c2[:-4]
+    if not (c1.startswith('RA--') and c2.startswith('DEC-') and c1[-3:] == c2[-3:]):
+        raise NotImplementedError('unsupported CTYPE pair %r / %r' % (header['CTYPE1'], header['CTYPE2']))
+    return c1[-3:], sip
+
+
+def is_plain_tan(header):
+    """The headers the fused kernels take (reference wcs.py:50-52: its fast path)."""
+    return header['CTYPE1'] == 'RA---TAN' and header['CTYPE2'] == 'DEC--TAN' and header.get('LATPOLE', 0.0) == 0.0
+
+
+def zenithal_pix2world(header, width, height, startX=0, startY=0, corner=True):
+    """
+    Unit direction vectors (J2000 / ICRS cartesian) of a pixel rectangle for the zenithal projections TAN, SIN (without
+    its slant parameters), ARC, STG and ZEA, with SIP distortion polynomials when the CTYPEs end in -SIP — the headers the
+    reference hands to ``astropy.wcs.WCS(header).all_pix2world`` (wcs.py:54-56; astropy / wcslib are absent here:
+    restated from Calabretta & Greisen 2002, A&A 395, sections 5.1.1-5.1.7, and the SIP convention of Shupe et al.
+    2005).  Host NumPy, row block by row block; the result feeds :class:`DirectionArrayMapping`
+    (``amt_georef_frame_dirs``), like any other camera model.  For a plain TAN header it equals the fused kernels'
+    own camera model to rounding.
+
+    :rtype: float64 array (height + 1, width + 1, 3) if corner else (height, width, 3)
+    """
+    proj, sip = projection_of(header)
+    if proj not in ZENITHAL:
+        raise NotImplementedError('projection %s is not supported (zenithal projections only: %s)' % (proj, ', '.join(ZENITHAL)))
+    if header.get('LATPOLE', 0.0) not in (0.0, 90.0, header['CRVAL2']):
+        raise NotImplementedError('LATPOLE = %r' % header.get('LATPOLE'))
+    cd = np.array([[header['CD1_1'], header['CD1_2']], [header['CD2_1'], header['CD2_2']]], dtype=np.float64)
+    rot = euler_matrix_rzxz(np.deg2rad(header['CRVAL1'] + 90), np.deg2rad(90 - header['CRVAL2']),
+                            np.deg2rad(-(header.get('LONPOLE', 180.0) - 90)))
+    off = -0.5 if corner else 0.0
+    n_rows, n_cols = height + (1 if corner else 0), width + (1 if corner else 0)
+    # 0-based pixel coordinates -> offsets from the reference pixel (CRPIX is 1-based: reference wcs.py:93-99)
+    u_all = np.arange(n_cols, dtype=np.float64) + (startX + off) - header['CRPIX1'] + 1
+    out = np.empty((n_rows, n_cols, 3), dtype=np.float64)
+
+    def sip_poly(prefix, u, v):
+        order = int(header.get(prefix + '_ORDER', 0))
+        f = np.zeros_like(u)
+        for p_ in range(order + 1):
+            for q_ in range(order + 1 - p_):
+                c = header.get('%s_%d_%d' % (prefix, p_, q_))
+                if c:
+                    f = f + c * u ** p_ * v ** q_
+        return f
+
+    k = 180.0 / np.pi
+    block = max(1, (1 << 21) // max(n_cols, 1))
+    for r0 in range(0, n_rows, block):
+        r1 = min(n_rows, r0 + block)
+        v = (np.arange(r0, r1, dtype=np.float64) + (startY + off) - header['CRPIX2'] + 1)[:, None]
+        u = np.broadcast_to(u_all[None, :], (r1 - r0, n_cols))
+        v = np.broadcast_to(v, (r1 - r0, n_cols))
+        if sip:
+            u, v = u + sip_poly('A', u, v), v + sip_poly('B', u, v)
+        x = cd[0, 0] * u + cd[0, 1] * v                     # intermediate world coordinates, degrees
+        y = cd[1, 0] * u + cd[1, 1] * v
+        r = np.sqrt(x * x + y * y)
+        phi = np.arctan2(x, -y)
+        with np.errstate(invalid='ignore'):
+            if proj == 'TAN':
+                theta = np.arctan2(k, r)
+            elif proj == 'SIN':
+                theta = np.arccos(r / k)
+            elif proj == 'ARC':
+                theta = np.deg2rad(90.0 - r)
+            elif proj == 'STG':
+                theta = np.deg2rad(90.0) - 2 * np.arctan(r / (2 * k))
+            else:                                               # ZEA
+                theta = np.deg2rad(90.0) - 2 * np.arcsin(r / (2 * k))
+        ct = np.cos(theta)
+        native = np.stack((ct * np.cos(phi), ct * np.sin(phi), np.sin(theta)), axis=-1)
+        out[r0:r1] = native.dot(rot.T)
+    return out
+
+
 def check_tan_header(header):
     if not (header['CTYPE1'] == 'RA---TAN' and header['CTYPE2'] == 'DEC--TAN' and header['LATPOLE'] == 0.0):
         raise NotImplementedError('only TAN projections with LATPOLE=0 are supported '

@@ -161,6 +161,17 @@ def getMapping(imagePathOrArray, wcsPathOrHeader, timeshift=None, noradId=None, 
     if cam is None:
         raise ValueError('Spacecraft position is missing in the header; pass cameraPosGCRS '
                          '(TLE propagation is not part of this package)')
+    from ..coordinates.wcs import is_plain_tan, zenithal_pix2world
+    if not is_plain_tan(wcsHeader):
+        # another zenithal projection or SIP terms (the reference hands such headers to astropy.wcs, wcs.py:54-56): the
+        # corner directions from the host generator, everything downstream through the directions-in kernel; centres
+        # are the mean of their four corner hits (the fast mode), whatever fastCenterCalculation says
+        from .astrometry import DirectionArrayMapping
+        img = np.asarray(imageArray)
+        dirs = zenithal_pix2world(wcsHeader, img.shape[1], img.shape[0], corner=True)
+        m = DirectionArrayMapping(dirs, altitude, img, cam, photoTime, identifier, metadata)
+        m.originalPhotoTime = originalPhotoTime
+        return m
     return ArraySpacecraftMapping(wcsHeader, altitude, imageArray, cam, photoTime, identifier, metadata,
                                   originalPhotoTime=originalPhotoTime,
                                   fastCenterCalculation=fastCenterCalculation)

@@ -636,6 +636,40 @@ def test_direction_array_mapping_for_other_camera_models():
     assert np.nanmax(np.abs(c.lons.filled(np.nan) - b.lons.filled(np.nan))) > 0.01
 
 
+def test_getMapping_with_a_non_tan_header():
+    """A header with another zenithal projection (reference wcs.py:54-56: astropy.wcs) or SIP terms: getMapping builds the
+    corner directions on the host (coordinates.wcs.zenithal_pix2world) and hands them to the directions-in kernel — the
+    oracle's chain (shell intersection, J2000 -> GEO, Bowring, elevation) on the same directions."""
+    from oracle import ref_numpy as O
+    from auromat_amd.coordinates.wcs import zenithal_pix2world
+    from auromat_amd.mapping.astrometry import DirectionArrayMapping
+    from auromat_amd.mapping.spacecraft import getMapping
+    from auromat_amd.resample import resample
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 200, 140
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    hdr = dict(hdr, CTYPE1='RA---ARC-SIP', CTYPE2='DEC--ARC-SIP', A_ORDER=2, B_ORDER=2, A_2_0=2e-5, B_0_2=-1e-5,
+               **{'DATE-OBS': t.strftime('%Y-%m-%dT%H:%M:%S.%f')})
+    img = frame_image(w, h, seed=9)
+    m = getMapping(img, hdr, cameraPosGCRS=cam, altitude=110, identifier='arc')
+    assert isinstance(m, DirectionArrayMapping)
+    m.checkGuarantees()
+    dirs = zenithal_pix2world(hdr, w, h, corner=True)
+    p = O.inflated_earth_intersection(dirs.reshape(-1, 3), cam, 110).reshape(dirs.shape)
+    lat, lon = O.j2000_to_latlon(p.reshape(-1, 3), O.mat_j2000_to_geo(O.date2es(t)))
+    lat, lon = lat.reshape(h + 1, w + 1), lon.reshape(h + 1, w + 1)
+    assert np.array_equal(ma.getmaskarray(m.lats), np.isnan(lat))
+    ok = ~np.isnan(lat)
+    assert np.max(np.abs(m.lats.data[ok] - lat[ok])) < TOL_DEG and np.max(np.abs(m.lons.data[ok] - lon[ok])) < TOL_DEG
+    # (the ARC frame differs from the TAN one by far more than the tolerance: the generator matters)
+    tan = getMapping(img, dict(hdr, CTYPE1='RA---TAN', CTYPE2='DEC--TAN'), cameraPosGCRS=cam, altitude=110, identifier='tan',
+                     fastCenterCalculation=True)
+    both = ok & ~ma.getmaskarray(tan.lats)
+    assert np.max(np.abs(m.lats.data[both] - tan.lats.data[both])) > 1e-3
+    r = resample(m.maskedByElevation(10), pxPerDeg=10)
+    r.checkGuarantees()
+
+
 def test_single_pass_right_most_edge_rule():
     """
     Pixels that sit on the last edge of the final grid (within the rounding of histogram.py:215-224) belong to the

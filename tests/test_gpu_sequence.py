@@ -324,3 +324,48 @@ def test_send_buffer_packed_while_the_sequence_runs():
         assert got[-2] == len(frames) and got[-1] == payload.numel()
         assert np.array_equal(got[:descs.numel()].reshape(descs.shape), descs.cpu().numpy())
         assert np.array_equal(got[cap[0] * DESC_LEN:cap[0] * DESC_LEN + payload.numel()], payload.cpu().numpy(), equal_nan=True)
+
+
+def test_plain_c_host_runs_a_sequence(tmp_path):
+    """examples/c_sequence_demo.c — C99, no Python / torch / HIP headers — runs a whole sequence through the native runner
+    (amt_run_create / amt_run_process): the grids it writes are the Python host's, bit for bit, pole frame and frame of
+    empty sky included."""
+    import ctypes as C
+    import os
+    import subprocess
+    from conftest import ROOT
+    from auromat_amd._build import LIB_DIR
+    from auromat_amd._native import RunFrame, RunResult
+    from auromat_amd.mapping.astrometry import run_frame
+    from auromat_amd.pipeline import SequencePipeline
+    exe = str(tmp_path / 'c_sequence_demo')
+    build = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-I' + os.path.join(ROOT, 'include'),
+                            os.path.join(ROOT, 'examples', 'c_sequence_demo.c'), '-L' + LIB_DIR, '-lauromat_hip',
+                            '-Wl,-rpath,' + LIB_DIR, '-Wl,-rpath,/opt/rocm/lib', '-lm', '-o', exe],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert build.returncode == 0 and build.stdout.strip() == '', build.stdout
+    w, h, n = 300, 200, 11
+    frames = build_sequence(w, h, n, every_pole=5, empty_at=(7,))
+    arr = (RunFrame * n)()
+    for k, (hdr, cam, t, img) in enumerate(frames):
+        run_frame(hdr, cam, t, 0.0, None, out=arr[k])
+    (tmp_path / 'frames.bin').write_bytes(bytes(C.string_at(C.byref(arr), C.sizeof(arr))))
+    (tmp_path / 'images.bin').write_bytes(b''.join(img.tobytes() for _, _, _, img in frames))
+    run = subprocess.run([exe, str(tmp_path / 'frames.bin'), str(tmp_path / 'images.bin'), str(n), str(w), str(h), '6',
+                          str(tmp_path / 'out.bin')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True,
+                         timeout=120)
+    assert run.returncode == 0 and run.stdout.startswith('ok %d frames' % n), run.stdout
+    raw = (tmp_path / 'out.bin').read_bytes()
+    rec = np.frombuffer(raw[:n * C.sizeof(RunResult)], dtype=np.dtype(RunResult))
+    grids = np.frombuffer(raw[n * C.sizeof(RunResult):], dtype=np.float64)
+    want = SequencePipeline(w, h, pxPerDeg=6).process(frames, keep_on_device=False)
+    assert sum(r is None for r in want) == 1 and sum(1 for r in want if r is not None and r['contains_pole']) == 2
+    for k, r in enumerate(want):
+        if r is None:
+            assert rec['status'][k] == 2
+            continue
+        assert rec['status'][k] == 0 and (rec['ny'][k], rec['nx'][k]) == r['count'].shape
+        assert bool(rec['contains_pole'][k]) == bool(r['contains_pole'])
+        o, cells = int(rec['grid_offset'][k]), int(rec['ny'][k]) * int(rec['nx'][k])
+        assert np.array_equal(grids[o:o + 4 * cells].reshape(r['mean'].shape), r['mean'], equal_nan=True), k
+        assert np.array_equal(grids[o + 4 * cells:o + 5 * cells].reshape(r['count'].shape), r['count']), k

@@ -529,3 +529,53 @@ def test_native_frame_params_equal_the_python_ones():
     with pytest.raises(ValueError, match='IGRF'):
         frame_params(hdr, 110, cam, datetime(2031, 1, 1), True, magnetic=True)
     frame_params(hdr, 110, cam, datetime(2031, 1, 1), True, magnetic=False)       # J2000 -> GEO needs no IGRF
+
+
+def test_zenithal_direction_generator():
+    """coordinates.wcs.zenithal_pix2world (non-TAN headers, which the reference hands to astropy.wcs: wcs.py:54-56;
+    astropy is absent, restated from Calabretta & Greisen 2002): for a TAN header the oracle's pinned TAN directions; for
+    SIN / ARC / STG / ZEA the projection's own radius law R(theta) around the reference pixel, the same position angles as
+    TAN, the reference pixel on CRVAL; SIP terms move a pixel like the polynomial says."""
+    from oracle import ref_numpy as O
+    from auromat_amd.coordinates.wcs import is_plain_tan, projection_of, zenithal_pix2world
+    from auromat_amd.synthetic import frame_header
+    hdr, cam, t = frame_header(96, 64, 'iss030')
+    assert is_plain_tan(hdr) and projection_of(hdr) == ('TAN', False)
+    for corner in (True, False):
+        got = zenithal_pix2world(hdr, 96, 64, corner=corner)
+        want = O.pixel_directions(hdr, corner=corner)
+        assert got.shape == want.shape and np.max(np.abs(got - want)) < 5e-15
+    tan = zenithal_pix2world(hdr, 96, 64, corner=False)
+    a0, d0 = np.deg2rad(hdr['CRVAL1']), np.deg2rad(hdr['CRVAL2'])
+    bore = np.array([np.cos(d0) * np.cos(a0), np.cos(d0) * np.sin(a0), np.sin(d0)])
+    k = 180 / np.pi
+    # offsets of the pixel centres from the reference pixel in intermediate world coordinates (degrees)
+    u = np.arange(96) - hdr['CRPIX1'] + 1
+    v = (np.arange(64) - hdr['CRPIX2'] + 1)[:, None]
+    r = np.sqrt((hdr['CD1_1'] * u + hdr['CD1_2'] * v) ** 2 + (hdr['CD2_1'] * u + hdr['CD2_2'] * v) ** 2)
+    laws = {'SIN': lambda th: k * np.cos(th), 'ARC': lambda th: 90 - np.rad2deg(th),
+            'STG': lambda th: 2 * k * np.tan((np.pi / 2 - th) / 2), 'ZEA': lambda th: 2 * k * np.sin((np.pi / 2 - th) / 2)}
+    for proj, law in laws.items():
+        h2 = dict(hdr, CTYPE1='RA---' + proj, CTYPE2='DEC--' + proj)
+        assert not is_plain_tan(h2)
+        d = zenithal_pix2world(h2, 96, 64, corner=False)
+        assert np.allclose(np.linalg.norm(d, axis=2), 1, atol=1e-14)
+        theta = np.arcsin(np.clip(d.dot(bore), -1, 1))                   # native latitude = 90 deg - distance from CRVAL
+        assert np.max(np.abs(law(theta) - r)) < 1e-9, proj
+        # same position angle about the boresight as TAN: the components perpendicular to it are parallel
+        pt, pd = tan - tan.dot(bore)[..., None] * bore, d - d.dot(bore)[..., None] * bore
+        cosang = (pt * pd).sum(-1) / (np.linalg.norm(pt, axis=2) * np.linalg.norm(pd, axis=2))
+        assert np.min(cosang) > 1 - 1e-12, proj
+    # the reference pixel looks at CRVAL
+    h3 = dict(hdr, CTYPE1='RA---ARC', CTYPE2='DEC--ARC', CRPIX1=11.0, CRPIX2=7.0)
+    assert np.allclose(zenithal_pix2world(h3, 96, 64, corner=False)[6, 10], bore, atol=1e-15)
+    # SIP: u' = u + A_2_0 u^2 — the direction of pixel (x, y) is the undistorted direction of the shifted pixel
+    hs = dict(hdr, CTYPE1='RA---TAN-SIP', CTYPE2='DEC--TAN-SIP', A_ORDER=2, B_ORDER=2, A_2_0=1e-4, B_1_1=-2e-4)
+    assert projection_of(hs) == ('TAN', True) and not is_plain_tan(hs)
+    ds = zenithal_pix2world(hs, 96, 64, corner=False)
+    x, y = 80, 50
+    uu, vv = x - hdr['CRPIX1'] + 1, y - hdr['CRPIX2'] + 1
+    shifted = O.pixel_directions(dict(hdr, IMAGEW=1, IMAGEH=1, CRPIX1=1 - (uu + 1e-4 * uu * uu), CRPIX2=1 - (vv - 2e-4 * uu * vv)), corner=False)[0, 0]
+    assert np.max(np.abs(ds[y, x] - shifted)) < 1e-13
+    with pytest.raises(NotImplementedError):
+        zenithal_pix2world(dict(hdr, CTYPE1='RA---AIT', CTYPE2='DEC--AIT'), 8, 8)
