@@ -996,6 +996,40 @@ def real_frame_more():
                          110, merged, (10, 10)), 'real_frame_iss030_sm.npz', mm)
 
 
+def real_frame_shells():
+    """real_frame_iss030_sm_{100,120}km.npz: BASELINE configs[3]'s other two altitude shells on the reference's own test
+    frame — fast centres -> maskedByElevation(10) -> the _resample call of resampleMLatMLT on the (MLat, SM longitude)
+    grid at 100 and 120 km (110 km: real_frame_iss030_sm.npz)."""
+    from PIL import Image
+    from auromat_amd.fits import readHeader
+    from auromat_amd.mapping.spacecraft import getShiftedSpacecraftPosition
+    hdr = readHeader(RES + 'ISS030-E-102170_dc.wcs')
+    img = np.asarray(Image.open(RES + 'ISS030-E-102170_dc.jpg'))
+    cam, t, _ = getShiftedSpacecraftPosition(hdr)
+    for alt in (100, 120):
+        m = ArraySpacecraftMapping(hdr, alt, img, cam, t, 'x', fastCenterCalculation=True)
+        mm = m.maskedByElevation(10)
+        merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+        mlat, mlt = mm.mLatMlt
+        mlat_c, mlt_c = mm.mLatMltCenter
+        mask = ma.getmaskarray(mm.lats)
+        cmask = ma.getmaskarray(mm.latsCenter)
+        sm_lats, sm_lons = ma.masked_array(mlat.data, mask), ma.masked_array(T.mltToSmLon(mlt.data), mask)
+        case = _run_resample(sm_lats, sm_lons, np.where(cmask, np.nan, mlat_c.data), np.where(cmask, np.nan, T.mltToSmLon(mlt_c.data)),
+                             alt, merged, (10, 10))
+        rimg, relev = np.dsplit(case['out_data'], [-1])
+        with np.errstate(invalid='ignore'):
+            rimg = np.round(rimg)
+        rimg = np.require(ma.masked_invalid(rimg, copy=False), np.uint8)
+        del case['outline']
+        out = dict(case)
+        out.update(out_img=rimg.data, out_img_mask=ma.getmaskarray(rimg))
+        out.update(time_arrays(t))
+        out.update(cam=cam, altitude=np.float64(alt), min_elev=np.float64(10), ppd=np.array((10, 10), dtype=np.float64),
+                   n_valid=np.int64((~ma.getmaskarray(mm.latsCenter)).sum()))
+        save('real_frame_iss030_sm_%dkm.npz' % alt, **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['host_scalars', 'georef_small', 'masks_small', 'resample_cases',

@@ -250,6 +250,32 @@ def test_real_frame_on_the_mlat_mlt_grid():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('altitude', [100, 120])
+def test_real_frame_on_the_mlat_mlt_grid_other_shells(altitude):
+    """BASELINE configs[3]'s other two shells (100 / 120 km) on the reference's own test frame, pinned to the REAL reference
+    (real_frame_iss030_sm_{100,120}km.npz: its resampleMLatMLT chain at that altitude): both plans of the frame pipeline and
+    the class route, cell for cell."""
+    import auromat_amd.resample as R
+    from auromat_amd.mapping.spacecraft import getMapping
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.fits import getShiftedSpacecraftPosition, readHeader
+    from auromat_amd.util.image import loadImage
+    z = load_golden('real_frame_iss030_sm_%dkm.npz' % altitude)
+    hdr, img = readHeader(WCS), loadImage(JPG)
+    cam, t, _ = getShiftedSpacecraftPosition(hdr)
+    for fuse in (True, False):
+        pipe = FramePipeline(4256, 2832, img_dtype=np.uint8, with_mag=True)
+        res = pipe.run(hdr, altitude, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, fuse=fuse, magnetic=True)
+        assert pipe.last_plan == ('single-pass' if fuse else 'two-pass')
+        assert np.array_equal(res['lat'], z['out_lat']) and np.array_equal(res['lon_c'], z['out_lon_c'])
+        check(res['img'], res['mask'], res['mean'], z)
+    mm = getMapping(JPG, WCS, altitude=altitude, fastCenterCalculation=True).maskedByElevation(10)
+    r = R.resampleMLatMLT(mm, pxPerDeg=10)
+    assert R.last_plan == 'single-pass'
+    check(r.img.data, ma.getmaskarray(r.img)[..., 0], None, z)
+
+
+@pytest.mark.gpu
 def test_folder_provider_on_the_references_resources():
     """SpacecraftMappingProvider over the folder with the test frame (image + .wcs, as the reference's ISS provider leaves
     them), wrapped like `auromat-convert` wraps its provider: masked by elevation, resampled — the reference's grid."""
