@@ -347,6 +347,9 @@ class DirectionArrayMapping(BaseAstrometryMapping):
         p.m_sm[:] = list(mat_j2000_to_sm(et).ravel())
         return p
 
+    def _fusable(self):
+        return False            # (the single-pass plan of the mapping classes is built on the TAN camera model)
+
     def _dirs_tensor(self, ctx):
         if self._dirs_dev is None:
             self._dirs_dev = ctx.to_device(self._dirs)

@@ -298,6 +298,19 @@ def cpu_baseline_n_process(sample_rows, procs):
                            procs, sample_rows, WIDTH, HEIGHT, npx / 1e6))
 
 
+def sky_rows_note():
+    import ctypes as C
+    from auromat_amd import _native
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.synthetic import sequence_frame
+    hdr, cam, t, _ = sequence_frame(0, WIDTH, HEIGHT)
+    p = frame_params(hdr, ALTITUDE, cam, t, True)
+    o = [C.c_int32(0) for _ in range(4)]
+    _native.lib().amt_georef_sky_rows(C.byref(p), *[C.byref(v) for v in o])
+    rows, n, top, bottom = [v.value for v in o]
+    return '%d of %d rows of work items (%d pixel rows each) of frame 0 are NaN fills (amt_georef_sky_rows)' % (top + n - bottom, n, rows)
+
+
 def check_against_oracle(hdr, cam, t, img, g, res):
     """BASELINE.json's second figure, max |dlat, dlon| vs ref: the HIP path (single-pass plan) on the frame the CPU
     baseline has just computed with the oracle — coordinate arrays, NaN patterns and the resampled grid."""
@@ -556,6 +569,12 @@ def main(argv=None):
                        # untimed frames run before the W warm-up steps to bring the chip to its sustained state
                        'spinup_frames_untimed': run['spinup_frames'], 'spinup_ms': args.spinup_ms,
                        'parallelism': 'frames sharded over %d GPU(s), RCCL gather of grids' % world,
+                       'frame_loop': 'library (amt_run_*)' if getattr(seq, 'native', False) and args.plan == 'fused' and not args.upload
+                       else 'python',
+                       # transparency: rows of work items whose waves write NaN without casting rays, because the host has
+                       # bounded the limb (a conic section in the image) and no ray of them can hit the shell; every
+                       # output array is still written in full and is identical to the ray-cast result
+                       'sky_item_rows': sky_rows_note(),
                        'device': info['name']},
             # dominant kernel.  It is FP64-VALU bound (see DESIGN.md and profiles/), so the HBM fraction understates
             # how busy the chip is.

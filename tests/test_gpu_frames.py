@@ -668,6 +668,12 @@ def test_getMapping_with_a_non_tan_header():
     assert np.max(np.abs(m.lats.data[both] - tan.lats.data[both])) > 1e-3
     r = resample(m.maskedByElevation(10), pxPerDeg=10)
     r.checkGuarantees()
+    # a fresh mapping of this kind is masked at once (no camera model for the fused plan) and resamples to the same grid
+    import auromat_amd.resample as R
+    fresh = getMapping(img, hdr, cameraPosGCRS=cam, altitude=110, identifier='arc').maskedByElevation(10)
+    assert fresh._frame is not None
+    r2 = R.resample(fresh, pxPerDeg=10)
+    assert R.last_plan is None and np.array_equal(r2.img.filled(0), r.img.filled(0))
 
 
 def test_single_pass_right_most_edge_rule():
