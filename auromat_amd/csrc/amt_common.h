@@ -902,6 +902,16 @@ __device__ __forceinline__ bool on_lower_edge(const axis_dev& ax, int b, double 
 
 constexpr double kFix = 4294967296.0;   // 2^32: elevation sums are kept in signed 31.32 fixed point
 
+// round-to-nearest-even of v * 2^32 as a 64-bit integer for |v * 2^32| < 2^51 (elevations: < 2^39), the value
+// __double2ll_rn(v * kFix) gives: the product is exact, and adding 1.5 * 2^52 rounds it to an integer in the low mantissa
+// bits, of which the constant's own integer is subtracted — one fused multiply-add and one 32-bit subtraction (the
+// constant's low word is zero) instead of the seven instructions of the library conversion.
+__device__ __forceinline__ long long to_fix32(double v) {
+    constexpr double kMagic = 6755399441055744.0;       // 2^52 + 2^51
+    const double t = __builtin_fma(v, kFix, kMagic);
+    return __double_as_longlong(t) - __double_as_longlong(kMagic);
+}
+
 inline void make_axis(const amt_axis* a, axis_dev* out) {
     out->edges = a->edges;
     out->nbin = a->nbin;

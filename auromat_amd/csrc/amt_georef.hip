@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
                         }
                     }
                     if (bx > 0 && by > 0) {
-                        el_fix = __double2ll_rn(el * kFix);
+                        el_fix = to_fix32(el);
                         bin_event* events = nullptr;
                         if (edge_flags) events = karg_load<bin_event*>(karg_fresh(koff), offsetof(georef_args, bin_events));
                         if (events != nullptr) {
