@@ -10,6 +10,7 @@
 #include "amt_common.h"
 
 #include <cmath>
+#include <cstring>
 
 namespace {
 
@@ -405,6 +406,357 @@ __global__ __launch_bounds__(kBlock) void k_linear_gather(lin_args A, const long
     }
 }
 
+// ---- method='cubic' (reference resample.py:323-326: scipy griddata(method='cubic') = CloughTocher2DInterpolator) --------
+// The piecewise cubic, C1 Clough-Tocher interpolant on the same triangulation as 'linear', with the vertex gradients of
+// scipy's global estimator: the gradient at every data point minimises the curvature energy of the cubic Hermite curves
+// along its triangulation edges (Nielson 1983; Renka & Cline 1984), a 2 x 2 system per point coupled to the neighbours'
+// gradients, which scipy relaxes point after point until the largest relative change drops below 1e-6.  Here: one Jacobi
+// sweep per launch over all valid pixels (the 2 x 2 blocks dominate the coupling 2 : 1, so Jacobi converges too), the
+// neighbours of a pixel taken from the reduced lattice around it — the four axis neighbours and, for each of the four
+// cells that meet at the pixel, the partner on the cell's Delaunay diagonal when that diagonal passes through the pixel.
+// The element itself (12 boundary + 7 interior Bezier ordinates per triangle; the three free parameters fixed by making the
+// derivative towards the neighbouring triangle's centroid linear along each edge, which is what makes scipy's element
+// affine invariant) is restated from scipy 1.15's interpnd module and checked against it to rounding on scipy's own
+// triangulation (oracle/ref_numpy.py: clough_tocher_*, tests/test_oracle_golden.py).
+
+struct lat_basis {
+    double x0, y0, ux, uy, vx, vy;
+    int uj, ui, vj, vi;          // index steps of the two reduced basis vectors
+};
+
+// the local lattice basis at pixel (pi, pj) — one step in j, one step in i —, Gauss-reduced (see k_linear_gather)
+__device__ bool lattice_basis(const lin_args& A, int pi, int pj, lat_basis* B) {
+    double xa, ya, xb, yb;
+    if (!lin_valid(A, pi, pj, &B->x0, &B->y0)) return false;
+    double ux, uy, vx, vy;
+    if (lin_valid(A, pi, pj + 1, &xa, &ya)) ux = xa - B->x0, uy = ya - B->y0;
+    else if (lin_valid(A, pi, pj - 1, &xa, &ya)) ux = B->x0 - xa, uy = B->y0 - ya;
+    else return false;
+    if (lin_valid(A, pi + 1, pj, &xb, &yb)) vx = xb - B->x0, vy = yb - B->y0;
+    else if (lin_valid(A, pi - 1, pj, &xb, &yb)) vx = B->x0 - xb, vy = B->y0 - yb;
+    else return false;
+    int uj = 1, ui = 0, vj = 0, vi = 1;
+    for (int it = 0; it < 16; ++it) {
+        double uu = ux * ux + uy * uy, vv = vx * vx + vy * vy;
+        if (uu > vv) {
+            double t = ux; ux = vx; vx = t;
+            t = uy; uy = vy; vy = t;
+            int k = uj; uj = vj; vj = k;
+            k = ui; ui = vi; vi = k;
+            uu = vv;
+        }
+        if (!(uu > 0)) break;
+        const double m = rint((ux * vx + uy * vy) / uu);
+        if (m == 0) break;
+        vx -= m * ux, vy -= m * uy;
+        vj -= (int)m * uj, vi -= (int)m * ui;
+    }
+    if (!(fabs(ux * vy - uy * vx) > 0)) return false;
+    B->ux = ux, B->uy = uy, B->vx = vx, B->vy = vy;
+    B->uj = uj, B->ui = ui, B->vj = vj, B->vi = vi;
+    return true;
+}
+
+// cell (a, b) of the reduced lattice around pixel (pi, pj): corners in cyclic order (a, b), (a+1, b), (a+1, b+1), (a, b+1);
+// flip: cut along 1-3 instead of 0-2 (corner 3 inside the circle through 0, 1, 2), defined for 4 valid corners
+struct lat_cell {
+    int ci[4], cj[4];
+    double x[4], y[4];
+    bool v[4];
+    int nv;
+    bool flip;
+};
+
+__device__ void lattice_cell(const lin_args& A, int pi, int pj, const lat_basis& B, int a, int b, lat_cell* c) {
+    const int ca[4] = {a, a + 1, a + 1, a}, cb[4] = {b, b, b + 1, b + 1};
+    c->nv = 0;
+    for (int k = 0; k < 4; ++k) {
+        c->ci[k] = pi + ca[k] * B.ui + cb[k] * B.vi;
+        c->cj[k] = pj + ca[k] * B.uj + cb[k] * B.vj;
+        c->x[k] = c->y[k] = 0;
+        c->v[k] = lin_valid(A, c->ci[k], c->cj[k], &c->x[k], &c->y[k]);
+        c->nv += c->v[k] ? 1 : 0;
+    }
+    c->flip = c->nv == 4 && lin_incircle(c->x[0], c->y[0], c->x[1], c->y[1], c->x[2], c->y[2], c->x[3], c->y[3]);
+}
+
+// the corner of cell c that completes the triangle on the cell's side s (corners s, s+1); -1: the cell has no such triangle
+__device__ int lattice_third(const lat_cell& c, int s) {
+    if (c.nv == 4) {
+        const int plain[4] = {2, 0, 0, 2}, flipped[4] = {3, 3, 1, 1};
+        return c.flip ? flipped[s] : plain[s];
+    }
+    if (c.nv == 3 && c.v[s] && c.v[(s + 1) & 3]) return c.v[(s + 2) & 3] ? (s + 2) & 3 : (s + 3) & 3;
+    return -1;
+}
+
+constexpr int kCubicNb = 8;
+
+// neighbours of every pixel in the triangulation: flat pixel indices, -1 = none.  Slots: +u, -u, +v, -v, +u+v, -u-v, -u+v, +u-v
+__global__ __launch_bounds__(kBlock) void k_cubic_neighbours(lin_args A, int* __restrict__ nb) {
+    AMT_GRID_STRIDE(p, (int64_t)A.height * A.width) {
+        int out[kCubicNb];
+        for (int k = 0; k < kCubicNb; ++k) out[k] = -1;
+        const int i = (int)(p / A.width), j = (int)(p - (int64_t)i * A.width);
+        lat_basis B;
+        if (lattice_basis(A, i, j, &B)) {
+            lat_cell c00, cm0, cmm, c0m;
+            lattice_cell(A, i, j, B, 0, 0, &c00);        // the pixel is its corner 0
+            lattice_cell(A, i, j, B, -1, 0, &cm0);       // corner 1
+            lattice_cell(A, i, j, B, -1, -1, &cmm);      // corner 2
+            lattice_cell(A, i, j, B, 0, -1, &c0m);       // corner 3
+            auto id = [&](const lat_cell& c, int k) { return c.ci[k] * A.width + c.cj[k]; };
+            if (c00.v[1] && (c00.nv >= 3 || c0m.nv >= 3)) out[0] = id(c00, 1);
+            if (cm0.v[0] && (cm0.nv >= 3 || cmm.nv >= 3)) out[1] = id(cm0, 0);
+            if (c00.v[3] && (c00.nv >= 3 || cm0.nv >= 3)) out[2] = id(c00, 3);
+            if (c0m.v[0] && (c0m.nv >= 3 || cmm.nv >= 3)) out[3] = id(c0m, 0);
+            if (c00.v[2] && ((c00.nv == 4 && !c00.flip) || c00.nv == 3)) out[4] = id(c00, 2);
+            if (cmm.v[0] && ((cmm.nv == 4 && !cmm.flip) || cmm.nv == 3)) out[5] = id(cmm, 0);
+            if (cm0.v[3] && ((cm0.nv == 4 && cm0.flip) || cm0.nv == 3)) out[6] = id(cm0, 3);
+            if (c0m.v[1] && ((c0m.nv == 4 && c0m.flip) || c0m.nv == 3)) out[7] = id(c0m, 1);
+        }
+        for (int k = 0; k < kCubicNb; ++k) nb[p * kCubicNb + k] = out[k];
+    }
+}
+
+constexpr int kCubicMaxChan = 5;      // image channels + elevation
+
+template <typename T>
+__device__ __forceinline__ double cubic_value(const lin_args& A, const T* img, int64_t p, int c) {
+    return c < A.nchan ? (double)img[p * A.nchan + c] : A.elev[p];
+}
+
+// one Jacobi sweep of the gradient estimator (scipy interpnd: _estimate_gradients_2d_global): y_out from y_in; the largest
+// change, relative as scipy measures it, goes to *err (bit pattern of a non-negative double: ordered like an integer)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_cubic_sweep(lin_args A, const int* __restrict__ nb, const T* __restrict__ img,
+                                                        const double* __restrict__ y_in, double* __restrict__ y_out,
+                                                        unsigned long long* __restrict__ err) {
+    const int nc = A.nchan + (A.elev != nullptr ? 1 : 0);
+    double worst = 0;
+    AMT_GRID_STRIDE(p, (int64_t)A.height * A.width) {
+        const int i = (int)(p / A.width), j = (int)(p - (int64_t)i * A.width);
+        double x1, y1;
+        double s0[kCubicMaxChan], s1[kCubicMaxChan], f1[kCubicMaxChan];
+        double q0 = 0, q1 = 0, q3 = 0;
+        for (int c = 0; c < nc; ++c) s0[c] = s1[c] = 0;
+        int used = 0;
+        if (lin_valid(A, i, j, &x1, &y1)) {
+            for (int c = 0; c < nc; ++c) f1[c] = cubic_value(A, img, p, c);
+            for (int k = 0; k < kCubicNb; ++k) {
+                const int q = nb[p * kCubicNb + k];
+                if (q < 0) continue;
+                double x2, y2;
+                const int qi = q / A.width, qj = q - qi * A.width;
+                if (!lin_valid(A, qi, qj, &x2, &y2)) continue;
+                ++used;
+                const double ex = x2 - x1, ey = y2 - y1;
+                const double l2 = ex * ex + ey * ey, l3 = l2 * sqrt(l2);
+                q0 += 4 * ex * ex / l3;
+                q1 += 4 * ex * ey / l3;
+                q3 += 4 * ey * ey / l3;
+                for (int c = 0; c < nc; ++c) {
+                    const double f2 = cubic_value(A, img, (int64_t)q, c);
+                    const double* g2 = y_in + ((int64_t)q * nc + c) * 2;
+                    const double df2 = -ex * g2[0] - ey * g2[1];
+                    const double t = (6 * (f1[c] - f2) - 2 * df2) / l3;
+                    s0[c] += t * ex;
+                    s1[c] += t * ey;
+                }
+            }
+        }
+        const double det = q0 * q3 - q1 * q1;
+        for (int c = 0; c < nc; ++c) {
+            double* g = y_out + (p * nc + c) * 2;
+            if (used < 2 || !(fabs(det) > 0)) {
+                g[0] = g[1] = 0;
+                continue;
+            }
+            const double r0 = (q3 * s0[c] - q1 * s1[c]) / det, r1 = (-q1 * s0[c] + q0 * s1[c]) / det;
+            const double* old = y_in + (p * nc + c) * 2;
+            double change = fmax(fabs(old[0] + r0), fabs(old[1] + r1));
+            change /= fmax(1.0, fmax(fabs(r0), fabs(r1)));
+            if (change == change) worst = fmax(worst, change);
+            g[0] = -r0, g[1] = -r1;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));
+    if ((threadIdx.x & 63) == 0 && worst > 0) atomicMax(err, (unsigned long long)__double_as_longlong(worst));
+}
+
+// value of the Clough-Tocher element of the triangle (x, y)[0..2] at barycentric coordinates b; f: vertex values, d: vertex
+// gradients (dx, dy), n: whether edge k (opposite vertex k) has a neighbouring triangle, (cx, cy)[k] its centroid
+__device__ double clough_tocher(const double* x, const double* y, const double* b, const double* f, const double (*d)[2],
+                                const bool* n, const double* cx, const double* cy) {
+    const double e12x = x[1] - x[0], e12y = y[1] - y[0], e23x = x[2] - x[1], e23y = y[2] - y[1], e31x = x[0] - x[2], e31y = y[0] - y[2];
+    const double f1 = f[0], f2 = f[1], f3 = f[2];
+    const double df12 = d[0][0] * e12x + d[0][1] * e12y, df21 = -(d[1][0] * e12x + d[1][1] * e12y);
+    const double df23 = d[1][0] * e23x + d[1][1] * e23y, df32 = -(d[2][0] * e23x + d[2][1] * e23y);
+    const double df31 = d[2][0] * e31x + d[2][1] * e31y, df13 = -(d[0][0] * e31x + d[0][1] * e31y);
+    const double c3000 = f1, c2100 = (df12 + 3 * c3000) / 3, c2010 = (df13 + 3 * c3000) / 3;
+    const double c0300 = f2, c1200 = (df21 + 3 * c0300) / 3, c0210 = (df23 + 3 * c0300) / 3;
+    const double c0030 = f3, c1020 = (df31 + 3 * c0030) / 3, c0120 = (df32 + 3 * c0030) / 3;
+    const double c2001 = (c2100 + c2010 + c3000) / 3, c0201 = (c1200 + c0300 + c0210) / 3, c0021 = (c1020 + c0120 + c0030) / 3;
+    double g[3];
+    const double det = e12x * (y[2] - y[0]) - (x[2] - x[0]) * e12y;
+    for (int k = 0; k < 3; ++k) {
+        g[k] = -0.5;
+        if (!n[k]) continue;
+        // barycentric coordinates of the neighbour's centroid in this triangle
+        double c[3];
+        c[1] = ((cx[k] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (cy[k] - y[0])) / det;
+        c[2] = (e12x * (cy[k] - y[0]) - (cx[k] - x[0]) * e12y) / det;
+        c[0] = 1.0 - c[1] - c[2];
+        if (k == 0) g[k] = (2 * c[2] + c[1] - 1) / (2 - 3 * c[2] - 3 * c[1]);
+        else if (k == 1) g[k] = (2 * c[0] + c[2] - 1) / (2 - 3 * c[0] - 3 * c[2]);
+        else g[k] = (2 * c[1] + c[0] - 1) / (2 - 3 * c[1] - 3 * c[0]);
+    }
+    const double c0111 = (g[0] * (-c0300 + 3 * c0210 - 3 * c0120 + c0030) + (-c0300 + 2 * c0210 - c0120 + c0021 + c0201)) / 2;
+    const double c1011 = (g[1] * (-c0030 + 3 * c1020 - 3 * c2010 + c3000) + (-c0030 + 2 * c1020 - c2010 + c2001 + c0021)) / 2;
+    const double c1101 = (g[2] * (-c3000 + 3 * c2100 - 3 * c1200 + c0300) + (-c3000 + 2 * c2100 - c1200 + c2001 + c0201)) / 2;
+    const double c1002 = (c1101 + c1011 + c2001) / 3, c0102 = (c1101 + c0111 + c0201) / 3, c0012 = (c1011 + c0111 + c0021) / 3;
+    const double c0003 = (c1002 + c0102 + c0012) / 3;
+    const double m = fmin(b[0], fmin(b[1], b[2]));
+    const double b1 = b[0] - m, b2 = b[1] - m, b3 = b[2] - m, b4 = 3 * m;
+    return b1 * b1 * b1 * c3000 + 3 * b1 * b1 * b2 * c2100 + 3 * b1 * b1 * b3 * c2010 + 3 * b1 * b1 * b4 * c2001 +
+           3 * b1 * b2 * b2 * c1200 + 6 * b1 * b2 * b4 * c1101 + 3 * b1 * b3 * b3 * c1020 + 6 * b1 * b3 * b4 * c1011 +
+           3 * b1 * b4 * b4 * c1002 + b2 * b2 * b2 * c0300 + 3 * b2 * b2 * b3 * c0210 + 3 * b2 * b2 * b4 * c0201 +
+           3 * b2 * b3 * b3 * c0120 + 6 * b2 * b3 * b4 * c0111 + 3 * b2 * b4 * b4 * c0102 + b3 * b3 * b3 * c0030 +
+           3 * b3 * b3 * b4 * c0021 + 3 * b3 * b4 * b4 * c0012 + b4 * b4 * b4 * c0003;
+}
+
+// The triangle (corners k[0..2] of the cell `c` at lattice position (a, b) around pixel (pi, pj)) with everything the element
+// needs: for each edge the neighbouring triangle's centroid — across the cell's diagonal the cell's other triangle, across
+// a side the triangle of the adjacent cell on that side
+template <typename T>
+__device__ void cubic_in_triangle(const lin_args& A, int pi, int pj, const lat_basis& B, int a, int b, const lat_cell& c,
+                                  const int* k, const double* w, const T* img, const double* grad, double* out) {
+    double x[3], y[3], cx[3] = {0, 0, 0}, cy[3] = {0, 0, 0};
+    bool has[3];
+    int64_t pix[3];
+    for (int m = 0; m < 3; ++m) {
+        x[m] = c.x[k[m]], y[m] = c.y[k[m]];
+        pix[m] = (int64_t)c.ci[k[m]] * A.width + c.cj[k[m]];
+    }
+    for (int m = 0; m < 3; ++m) {
+        // edge opposite vertex m: corners p, q
+        const int p = k[(m + 1) % 3], q = k[(m + 2) % 3];
+        has[m] = false;
+        double tx = 0, ty = 0;
+        if (((p - q) & 3) == 2) {
+            // the cell's diagonal: the other triangle is the remaining corner's
+            if (c.nv == 4) {
+                const int r = 6 - k[0] - k[1] - k[2];
+                tx = c.x[r], ty = c.y[r];
+                has[m] = true;
+            }
+        } else {
+            const int s = ((p + 1) & 3) == q ? p : q;                 // side s: corners s, s+1
+            const int da[4] = {0, 1, 0, -1}, db[4] = {-1, 0, 1, 0};
+            lat_cell nbc;
+            lattice_cell(A, pi, pj, B, a + da[s], b + db[s], &nbc);
+            const int r = lattice_third(nbc, (s + 2) & 3);
+            if (r >= 0) {
+                tx = nbc.x[r], ty = nbc.y[r];
+                has[m] = true;
+            }
+        }
+        if (has[m]) {
+            cx[m] = (c.x[p] + c.x[q] + tx) / 3;
+            cy[m] = (c.y[p] + c.y[q] + ty) / 3;
+        }
+    }
+    const int nc = A.nchan + (A.elev != nullptr ? 1 : 0);
+    for (int ch = 0; ch < nc; ++ch) {
+        double f[3], d[3][2];
+        for (int m = 0; m < 3; ++m) {
+            f[m] = cubic_value(A, img, pix[m], ch);
+            d[m][0] = grad[(pix[m] * nc + ch) * 2];
+            d[m][1] = grad[(pix[m] * nc + ch) * 2 + 1];
+        }
+        out[ch] = clough_tocher(x, y, w, f, d, has, cx, cy);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_cubic_gather(lin_args A, const long long* __restrict__ index, int ny, int nx,
+                                                         const double* __restrict__ tlat, const double* __restrict__ tlon,
+                                                         const T* __restrict__ img, const double* __restrict__ grad,
+                                                         double* __restrict__ mean, T* __restrict__ out_img,
+                                                         uint8_t* __restrict__ out_mask, double* __restrict__ alt,
+                                                         long long* __restrict__ out_tri) {
+    constexpr double kNaN = __builtin_nan("");
+    const int nch = A.nchan, nc = nch + (A.elev != nullptr ? 1 : 0);
+    AMT_GRID_STRIDE(t, (int64_t)ny * nx) {
+        const long long near = index[t];
+        const int ty = (int)(t / nx), tx = (int)(t - (int64_t)ty * nx);
+        const double px = tlat[ty], py = tlon[tx];
+        double val[kCubicMaxChan], val2[kCubicMaxChan];
+        long long tri[3] = {-1, -1, -1};
+        bool found = false, found2 = false;
+        if (near >= 0) {
+            const int pi = (int)(near / A.width), pj = (int)(near - (long long)pi * A.width);
+            lat_basis B;
+            if (lattice_basis(A, pi, pj, &B)) {
+                const double det = B.ux * B.vy - B.uy * B.vx;
+                const double al = ((px - B.x0) * B.vy - (py - B.y0) * B.vx) / det, be = (B.ux * (py - B.y0) - B.uy * (px - B.x0)) / det;
+                const int a0 = (int)floor(al), b0 = (int)floor(be);
+                for (int ring = 0; ring < 2 && !found; ++ring)
+                    for (int da = -ring; da <= ring && !found; ++da)
+                        for (int db = -ring; db <= ring && !found; ++db) {
+                            if (ring == 1 && da == 0 && db == 0) continue;
+                            const int a = a0 + da, b = b0 + db;
+                            lat_cell c;
+                            lattice_cell(A, pi, pj, B, a, b, &c);
+                            if (c.nv < 3) continue;
+                            int k[3], k2[3];
+                            double w[3], w2[3];
+                            auto try_tri = [&](int k0, int k1, int k2_, int* kk, double* ww) {
+                                if (!lin_bary(c.x[k0], c.y[k0], c.x[k1], c.y[k1], c.x[k2_], c.y[k2_], px, py, ww) || !lin_inside(ww)) return false;
+                                kk[0] = k0, kk[1] = k1, kk[2] = k2_;
+                                return true;
+                            };
+                            if (c.nv == 3) {
+                                int q[3], m = 0;
+                                for (int r = 0; r < 4; ++r)
+                                    if (c.v[r]) q[m++] = r;
+                                found = try_tri(q[0], q[1], q[2], k, w);
+                            } else if (!c.flip) {
+                                found = try_tri(0, 1, 2, k, w) || try_tri(0, 2, 3, k, w);
+                                if (found) found2 = try_tri(0, 1, 3, k2, w2) || try_tri(1, 2, 3, k2, w2);
+                            } else {
+                                found = try_tri(0, 1, 3, k, w) || try_tri(1, 2, 3, k, w);
+                                if (found) found2 = try_tri(0, 1, 2, k2, w2) || try_tri(0, 2, 3, k2, w2);
+                            }
+                            if (!found) continue;
+                            for (int m = 0; m < 3; ++m) tri[m] = (long long)c.ci[k[m]] * A.width + c.cj[k[m]];
+                            cubic_in_triangle(A, pi, pj, B, a, b, c, k, w, img, grad, val);
+                            if (found2 && alt != nullptr) {
+                                // the cell cut along its other diagonal (what Qhull may have chosen for a near-cocircular quad)
+                                lat_cell c2 = c;
+                                c2.flip = !c.flip;
+                                cubic_in_triangle(A, pi, pj, B, a, b, c2, k2, w2, img, grad, val2);
+                            }
+                        }
+            }
+        }
+        for (int ch = 0; ch < nc; ++ch) {
+            const double v = found ? val[ch] : kNaN;
+            if (mean) mean[t * nc + ch] = v;
+            if (alt) alt[t * nc + ch] = found ? (found2 ? val2[ch] : val[ch]) : kNaN;
+            if (sizeof(T) < 8 && ch < nch && out_img) {
+                // np.round (half to even), then the cast of the reference (resample.py:129-132); a cubic overshoots, and
+                // numpy's cast of an out-of-range float wraps modulo the type's range on x86-64: the same here
+                const double r = found ? rint(v) : 0.0;
+                out_img[t * nch + ch] = (T)(unsigned long long)(long long)r;
+            }
+        }
+        if (out_mask) out_mask[t] = found ? 0 : 1;
+        if (out_tri)
+            for (int m = 0; m < 3; ++m) out_tri[t * 3 + m] = tri[m];
+    }
+}
+
 // matplotlib.path.Path(polygon).contains_points(points) (reference utils.py:58-74): crossing test of a ray towards
 // +x with the half-open edge rule (vertex y >= point y) of Agg's point_in_path; the path is closed implicitly.
 // Edges are staged through LDS in chunks; an edge whose y-range misses the y-range of the block's points cannot
@@ -571,6 +923,113 @@ int amt_linear_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx
         hipLaunchKernelGGL(k_linear_gather<uint8_t>, grid_for(total), dim3(kBlock), 0, ctx->stream, A, idx, ny, nx, target_lat,
                            target_lon, static_cast<const uint8_t*>(img), mean, static_cast<uint8_t*>(out_img), out_mask,
                            alt_mean, tri);
+    }
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_cubic_gradients(amt_ctx* ctx, const double* lat_c, const double* lon_c, const double* elev, const uint8_t* center_mask,
+                        int32_t height, int32_t width, double min_elevation, int lon_wrap, const void* img, int32_t img_dtype,
+                        int32_t nchan, double tolerance, int32_t max_iterations, double* gradients, int32_t* iterations) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, lat_c && lon_c && gradients, "NULL argument");
+    AMT_REQUIRE(ctx, height > 0 && width > 0 && (int64_t)height * width < 2147483647LL, "bad size");
+    AMT_REQUIRE(ctx, nchan >= 0 && nchan + (elev ? 1 : 0) <= kCubicMaxChan && nchan + (elev ? 1 : 0) >= 1,
+                "1..5 channels (image channels + elevation)");
+    AMT_REQUIRE(ctx, nchan == 0 || (img && img_dtype >= 1 && img_dtype <= 3), "img must be uint8 (1), uint16 (2) or float64 (3)");
+    AMT_REQUIRE(ctx, tolerance > 0 && max_iterations >= 1, "tolerance and max_iterations must be positive");
+    lin_args A;
+    A.lat_c = lat_c, A.lon_c = lon_c, A.elev = elev, A.center_mask = center_mask;
+    A.height = height, A.width = width;
+    A.min_elev = min_elevation;
+    A.lon_wrap = lon_wrap ? 1 : 0;
+    A.nchan = nchan;
+    const int64_t n = (int64_t)height * width;
+    const size_t grad_bytes = (size_t)n * (nchan + (elev ? 1 : 0)) * 2 * sizeof(double);
+    const size_t nb_bytes = (size_t)n * kCubicNb * sizeof(int);
+    char* ws = static_cast<char*>(amt_workspace(ctx, grad_bytes + nb_bytes + 64));
+    if (ws == nullptr) {
+        ctx->last_error = "amt_cubic_gradients: workspace allocation failed";
+        return AMT_ENOMEM;
+    }
+    double* other = reinterpret_cast<double*>(ws);
+    int* nb = reinterpret_cast<int*>(ws + grad_bytes);
+    unsigned long long* err = reinterpret_cast<unsigned long long*>(ws + grad_bytes + nb_bytes);
+    if (hipMemsetAsync(gradients, 0, grad_bytes, ctx->stream) != hipSuccess) {
+        ctx->last_error = "amt_cubic_gradients: memset failed";
+        return AMT_EHIP;
+    }
+    hipLaunchKernelGGL(k_cubic_neighbours, grid_for(n), dim3(kBlock), 0, ctx->stream, A, nb);
+    auto sweep = [&](const double* from, double* to) {
+        if (img_dtype == 3)
+            hipLaunchKernelGGL(k_cubic_sweep<double>, grid_for(n), dim3(kBlock), 0, ctx->stream, A, nb,
+                               static_cast<const double*>(img), from, to, err);
+        else if (img_dtype == 2)
+            hipLaunchKernelGGL(k_cubic_sweep<uint16_t>, grid_for(n), dim3(kBlock), 0, ctx->stream, A, nb,
+                               static_cast<const uint16_t*>(img), from, to, err);
+        else
+            hipLaunchKernelGGL(k_cubic_sweep<uint8_t>, grid_for(n), dim3(kBlock), 0, ctx->stream, A, nb,
+                               static_cast<const uint8_t*>(img), from, to, err);
+    };
+    // sweeps in pairs (the result of a pair is in `gradients` again); the second one's largest change decides
+    int done = 0;
+    double worst = 0;
+    while (done < max_iterations) {
+        sweep(gradients, other);
+        if (hipMemsetAsync(err, 0, sizeof(*err), ctx->stream) != hipSuccess) {
+            ctx->last_error = "amt_cubic_gradients: memset failed";
+            return AMT_EHIP;
+        }
+        sweep(other, gradients);
+        done += 2;
+        unsigned long long bits = 0;
+        if (hipMemcpyAsync(&bits, err, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            ctx->last_error = "amt_cubic_gradients: reading the convergence flag failed";
+            return AMT_EHIP;
+        }
+        std::memcpy(&worst, &bits, sizeof(worst));
+        if (worst < tolerance) break;
+    }
+    if (iterations) *iterations = done;
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx, const double* lat_c, const double* lon_c,
+                     const double* elev, const uint8_t* center_mask, int32_t height, int32_t width, double min_elevation,
+                     int lon_wrap, const double* target_lat, const double* target_lon, const void* img, int32_t img_dtype,
+                     int32_t nchan, const double* gradients, double* mean, void* out_img, uint8_t* out_mask, double* alt_mean,
+                     int64_t* out_triangles) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, index && lat_c && lon_c && target_lat && target_lon && gradients, "NULL argument");
+    AMT_REQUIRE(ctx, ny >= 0 && nx >= 0 && height > 0 && width > 0, "bad size");
+    AMT_REQUIRE(ctx, nchan >= 0 && nchan + (elev ? 1 : 0) <= kCubicMaxChan && nchan + (elev ? 1 : 0) >= 1,
+                "1..5 channels (image channels + elevation)");
+    AMT_REQUIRE(ctx, nchan == 0 || (img && img_dtype >= 1 && img_dtype <= 3), "img must be uint8 (1), uint16 (2) or float64 (3)");
+    AMT_REQUIRE(ctx, img_dtype != 3 || out_img == nullptr, "out_img needs an integer image");
+    const int64_t total = (int64_t)ny * nx;
+    if (total == 0) return AMT_OK;
+    lin_args A;
+    A.lat_c = lat_c, A.lon_c = lon_c, A.elev = elev, A.center_mask = center_mask;
+    A.height = height, A.width = width;
+    A.min_elev = min_elevation;
+    A.lon_wrap = lon_wrap ? 1 : 0;
+    A.nchan = nchan;
+    const long long* idx = reinterpret_cast<const long long*>(index);
+    long long* tri = reinterpret_cast<long long*>(out_triangles);
+    if (img_dtype == 3) {
+        hipLaunchKernelGGL(k_cubic_gather<double>, grid_for(total), dim3(kBlock), 0, ctx->stream, A, idx, ny, nx, target_lat,
+                           target_lon, static_cast<const double*>(img), gradients, mean, static_cast<double*>(nullptr), out_mask,
+                           alt_mean, tri);
+    } else if (img_dtype == 2) {
+        hipLaunchKernelGGL(k_cubic_gather<uint16_t>, grid_for(total), dim3(kBlock), 0, ctx->stream, A, idx, ny, nx, target_lat,
+                           target_lon, static_cast<const uint16_t*>(img), gradients, mean, static_cast<uint16_t*>(out_img),
+                           out_mask, alt_mean, tri);
+    } else {
+        hipLaunchKernelGGL(k_cubic_gather<uint8_t>, grid_for(total), dim3(kBlock), 0, ctx->stream, A, idx, ny, nx, target_lat,
+                           target_lon, static_cast<const uint8_t*>(img), gradients, mean, static_cast<uint8_t*>(out_img),
+                           out_mask, alt_mean, tri);
     }
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;

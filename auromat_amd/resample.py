@@ -110,7 +110,9 @@ def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=No
                    plane) and 'linear' (barycentric interpolation in the triangle of pixel centres that holds the grid
                    centre; the triangulation is that of the pixel grid, which equals the reference's Qhull triangulation
                    up to the choice of diagonal in near-cocircular quads: values agree within the spread of the two
-                   diagonals), both masked outside the mapping's outline.  'cubic' is not implemented.
+                   diagonals) and 'cubic' (scipy's Clough-Tocher element with its globally estimated vertex gradients on
+                   the same triangles; an interpolant that overshoots, and an integer image wraps like numpy's cast), all
+                   masked outside the mapping's outline.
     :rtype: a subclass of BaseMapping or MappingCollection
     """
     _check_method(method)
@@ -319,13 +321,25 @@ def wrap_at_180_t(t):
 
 
 def _check_method(method):
-    if method in ('cubic', 'median'):
-        # (the reference: "linear and cubic take considerably longer and use much more memory while they don't bring any
-        # benefit over 'nearest' if the goal is downsampling", resample.py:303-305; 'cubic' is scipy's Clough-Tocher
-        # scheme on the same triangulation)
-        raise NotImplementedError("method='%s' is not implemented (use 'mean', 'nearest' or 'linear')" % method)
-    if method not in ('mean', 'nearest', 'linear'):
-        raise ValueError('unknown resampling method: ' + str(method))
+    # (reference resample.py:353-360: NotImplementedError for 'median' and for anything it does not know)
+    if method not in ('mean', 'nearest', 'linear', 'cubic'):
+        raise NotImplementedError("method='%s' is not implemented (use 'mean', 'nearest', 'linear' or 'cubic')" % method)
+
+
+CUBIC_TOLERANCE = 1e-8      # largest relative change of a gradient in the last Jacobi sweep (scipy relaxes to 1e-6)
+CUBIC_MAX_SWEEPS = 800      # scipy: at most 400 point-after-point relaxations; a Jacobi sweep gains about half as much
+
+
+def cubic_gradients(ctx, lat_c, lon_c, elev, center_mask, height, width, min_elevation, lon_wrap, data, dtype_code, nchan):
+    """Vertex gradients of scipy's Clough-Tocher interpolant (amt_cubic_gradients) -> (tensor (h * w, channels, 2), sweeps)."""
+    import torch
+    nc = nchan + (1 if elev is not None else 0)
+    grad = ctx.empty((height * width, nc, 2))
+    sweeps = C.c_int32(0)
+    min_el = float('-inf') if min_elevation is None else float(min_elevation)
+    ctx.call('amt_cubic_gradients', ptr(lat_c), ptr(lon_c), ptr(elev), ptr(center_mask), height, width, min_el, lon_wrap,
+             ptr(data) if nchan else None, dtype_code, nchan, CUBIC_TOLERANCE, CUBIC_MAX_SWEEPS, ptr(grad), C.byref(sweeps))
+    return grad, sweeps.value
 
 
 def outside_outline_mask(ctx, grid, outline):
@@ -417,7 +431,7 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
     grid = cached_grid(pxPerDeg, latMin, latMax, lonMin, lonMax)
     xaxis, yaxis = grid.axes(ctx)
     nch = fd.nchan
-    if method in ('nearest', 'linear'):
+    if method in ('nearest', 'linear', 'cubic'):
         assert outline is not None, "method='%s' needs the outline of the mapping" % method
         assert shard is None, "rows of one frame over several ranks: method='mean' only"
         outline = np.array(outline, dtype=np.float64)
@@ -442,10 +456,22 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
             alt = ctx.empty((grid.ny, grid.nx, nch + 1))
             tri = ctx.empty((grid.ny, grid.nx, 3), torch.int64)
             min_el = float('-inf') if min_elevation is None else float(min_elevation)
-            ctx.call('amt_linear_gather', ptr(index), grid.ny, grid.nx, ptr(lat_c), ptr(lon_c), ptr(fd.elev), ptr(fd.center_mask),
-                     fd.height, fd.width, min_el, lon_wrap, ptr(tlat), ptr(tlon), ptr(fd.img), fd.img_dtype_code or 1, nch,
-                     ptr(mean), ptr(img) if nch else None, ptr(mask), ptr(alt), ptr(tri))
-            extra = dict(alt=alt, triangles=tri)
+            if method == 'linear':
+                ctx.call('amt_linear_gather', ptr(index), grid.ny, grid.nx, ptr(lat_c), ptr(lon_c), ptr(fd.elev),
+                         ptr(fd.center_mask), fd.height, fd.width, min_el, lon_wrap, ptr(tlat), ptr(tlon), ptr(fd.img),
+                         fd.img_dtype_code or 1, nch, ptr(mean), ptr(img) if nch else None, ptr(mask), ptr(alt), ptr(tri))
+                extra = dict(alt=alt, triangles=tri)
+            else:
+                # scipy's Clough-Tocher element on the same triangles (griddata(method='cubic')): vertex gradients by
+                # Jacobi sweeps of its global estimator, then the element in the triangle of every grid centre
+                assert fd.elev is not None, "method='cubic' on a frame needs the elevation"
+                grad, sweeps = cubic_gradients(ctx, lat_c, lon_c, fd.elev, fd.center_mask, fd.height, fd.width, min_elevation,
+                                               lon_wrap, fd.img, fd.img_dtype_code or 1, nch)
+                ctx.call('amt_cubic_gather', ptr(index), grid.ny, grid.nx, ptr(lat_c), ptr(lon_c), ptr(fd.elev),
+                         ptr(fd.center_mask), fd.height, fd.width, min_el, lon_wrap, ptr(tlat), ptr(tlon), ptr(fd.img),
+                         fd.img_dtype_code or 1, nch, ptr(grad), ptr(mean), ptr(img) if nch else None, ptr(mask), ptr(alt),
+                         ptr(tri))
+                extra = dict(alt=alt, triangles=tri, sweeps=sweeps)
         out = dict(has_elev=fd.elev is not None, grid=grid, contains_pole=bool(containsPole),
                    contains_discontinuity=bool(containsDiscontinuity), altitude=altitude)
         if keep_on_device:
@@ -456,6 +482,8 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
                    mask=to_host(mask).astype(bool), index=to_host(index, dtype=np.int64))
         if extra:
             out.update(alt=to_host(extra['alt']), triangles=to_host(extra['triangles'], dtype=np.int64))
+            if 'sweeps' in extra:
+                out['sweeps'] = extra['sweeps']
         return out
     acc = ctx.zeros((nch + 2, grid.nx * grid.ny), torch.int64)
     min_el = float('-inf') if min_elevation is None else float(min_elevation)
@@ -548,6 +576,20 @@ def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingB
         if method == 'nearest':
             picked = flat[index.clamp(min=0).reshape(-1)]
             picked[index.reshape(-1) < 0] = float('nan')
+        elif method == 'cubic':
+            # arbitrary float channels go to the kernels as they are (img_dtype 3); at most 5 per call
+            tlat, tlon = grid.device_centers(ctx)
+            la, lo = lat_c.reshape(-1).contiguous(), lon_c.reshape(-1).contiguous()
+            parts = []
+            for c0 in range(0, d.shape[2], 5):
+                chunk = flat[:, c0:c0 + 5].contiguous()
+                nchunk = chunk.shape[1]
+                grad, _ = cubic_gradients(ctx, la, lo, None, None, h, w, None, lon_wrap, chunk, 3, nchunk)
+                part = ctx.empty((grid.ny * grid.nx, nchunk))
+                ctx.call('amt_cubic_gather', ptr(index), grid.ny, grid.nx, ptr(la), ptr(lo), None, None, h, w, float('-inf'),
+                         lon_wrap, ptr(tlat), ptr(tlon), ptr(chunk), 3, nchunk, ptr(grad), ptr(part), None, None, None, None)
+                parts.append(part)
+            picked = torch.cat(parts, dim=1)
         else:
             # the triangle of every grid centre from the kernel, the barycentric sum of arbitrary float channels here
             tlat, tlon = grid.device_centers(ctx)

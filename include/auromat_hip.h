@@ -440,6 +440,26 @@ int amt_linear_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx
                       const double* elev, const uint8_t* center_mask, int32_t height, int32_t width, double min_elevation,
                       int lon_wrap, const double* target_lat, const double* target_lon, const void* img, int32_t img_dtype,
                       int32_t nchan, double* mean, void* out_img, uint8_t* out_mask, double* alt_mean, int64_t* out_triangles);
+
+/* method='cubic' (reference resample.py:323-326: scipy.interpolate.griddata(method='cubic') = CloughTocher2DInterpolator:
+ * a C1 piecewise cubic on the Delaunay triangulation with globally estimated vertex gradients).  Two calls on the
+ * triangulation of amt_linear_gather:
+ * amt_cubic_gradients: the gradient (d/dlat, d/dlon) of every channel and of the elevation at every valid pixel centre,
+ *   gradients (height * width, channels, 2), by Jacobi sweeps of scipy's estimator until the largest change (relative,
+ *   as scipy measures it) is below `tolerance` (scipy: 1e-6 with its point-after-point relaxation; pass 1e-8 to be inside
+ *   its noise) or max_iterations (scipy: 400) sweeps are done; *iterations (optional) = sweeps done.  Synchronises the
+ *   context's stream (the convergence flag is read back every second sweep).  img_dtype 3 = float64 channels (arbitrary
+ *   data, as `_resample` takes it); elev may be NULL (then no elevation channel and no threshold): 1..5 channels in all.
+ * amt_cubic_gather: like amt_linear_gather with the Clough-Tocher element instead of the plane; out_img is np.round of the
+ *   value cast like numpy casts (a cubic overshoots: out-of-range values wrap modulo the type's range). */
+int amt_cubic_gradients(amt_ctx* ctx, const double* lat_c, const double* lon_c, const double* elev, const uint8_t* center_mask,
+                        int32_t height, int32_t width, double min_elevation, int lon_wrap, const void* img, int32_t img_dtype,
+                        int32_t nchan, double tolerance, int32_t max_iterations, double* gradients, int32_t* iterations);
+int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx, const double* lat_c, const double* lon_c,
+                     const double* elev, const uint8_t* center_mask, int32_t height, int32_t width, double min_elevation,
+                     int lon_wrap, const double* target_lat, const double* target_lon, const void* img, int32_t img_dtype,
+                     int32_t nchan, const double* gradients, double* mean, void* out_img, uint8_t* out_mask, double* alt_mean,
+                     int64_t* out_triangles);
 /* auromat/utils.py:58-74 pointsInsidePolygon = matplotlib.path.Path(polygon).contains_points(points): crossing test
  * with Agg's half-open edge rule; polygon: (n_vertices, 2) device doubles (x, y), closed implicitly. */
 int amt_points_in_polygon(amt_ctx* ctx, const double* px, const double* py, int64_t n, const double* polygon,

@@ -620,6 +620,38 @@ def resample_linear_cases():
     save('resample_linear.npz', **out)
 
 
+def resample_cubic_cases():
+    """`_resample(method='cubic')` of the real reference (scipy griddata = CloughTocher2DInterpolator on Qhull's triangulation):
+    the cases of resample_linear_cases plus the iss030 frame with a SMOOTH image (stored: `iss030_smooth_img`), on which the
+    image channels can be compared as tightly as the elevation (pixel noise makes the estimated gradients, and with them the
+    values, depend on which diagonal Qhull happened to choose)."""
+    out = {}
+    for pointing, ppd in (('iss030', (10, 10)), ('iss029', (4, 7)), ('iss030_smooth', (10, 10))):
+        w, h = 256, 170
+        hdr, cam, t = frame_header(w, h, pointing.split('_')[0])
+        if pointing.endswith('smooth'):
+            ii, jj = np.mgrid[0:h, 0:w].astype(np.float64)
+            img = np.stack([20000 + 15000 * np.sin(ii / 23.0) * np.cos(jj / 31.0), 30000 + 100 * ii + 40 * jj,
+                            25000 + 20000 * np.cos((ii + jj) / 40.0)], axis=2).round().astype(np.uint16)
+            out['iss030_smooth_img'] = img
+        else:
+            img = frame_image(w, h, seed=3)
+        m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'r', fastCenterCalculation=True)
+        mm = m.maskedByElevation(10)
+        merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+        lats_c, lons_c = mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan)
+        case = _run_resample_nearest(mm.lats, mm.lons, lats_c, lons_c, 110, merged, ppd, method='cubic')
+        out['%s_out_data' % pointing] = case['out_data']
+        out['%s_out_lat_c' % pointing] = case['out_lat_c']
+    for tag in ('plain', 'disc', 'pole'):
+        z = np.load(os.path.join(OUT, 'resample_synth_%s.npz' % tag))
+        case = _run_resample_nearest(ma.masked_invalid(z['corner_lat']), ma.masked_invalid(z['corner_lon']),
+                                     z['lats_c'], z['lons_c'], 110, z['data'], (4, 4), pole=(tag == 'pole'), method='cubic')
+        out['synth_%s_out_data' % tag] = case['out_data']
+        out['synth_%s_out_lat_c' % tag] = case['out_lat_c']
+    save('resample_cubic.npz', **out)
+
+
 class _RecVar(object):
     """Variable of the recording netCDF4.Dataset stand-in."""
 
@@ -1035,6 +1067,6 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['host_scalars', 'georef_small', 'masks_small', 'resample_cases',
                              'histogram_edges', 'known_answers', 'georef_full', 'miracle_cases',
                              'themis_reproject_cases', 'geodesic_cases',
-                             'resample_nearest_cases', 'resample_linear_cases']
+                             'resample_nearest_cases', 'resample_linear_cases', 'resample_cubic_cases']
     for name in which:
         globals()[name]()

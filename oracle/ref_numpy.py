@@ -952,3 +952,86 @@ def bbox_of_corners(lat, lon, corner_mask):
     if lon_max - lon_min > 180:                              # mapping.py:726-734
         return (la.min(), lo[lo > 0].min(), la.max(), lo[~(lo > 0)].max()), True
     return (la.min(), lon_min, la.max(), lon_max), False
+
+
+# ---- scipy.interpolate.griddata(method='cubic') restated (reference resample.py:323-326 calls it) ---------------------------
+# scipy is a third-party dependency of the reference (requirements.txt pins no version; 1.15.3 in this image).  Its 2-D cubic
+# is CloughTocher2DInterpolator (interpnd): vertex gradients from a global curvature-minimising estimator, then the
+# 12-parameter Clough-Tocher element made affine invariant.  The two functions below restate both on a GIVEN triangulation
+# (scipy.spatial.Delaunay's arrays) and are checked against scipy itself to rounding (tests/test_oracle_golden.py); the
+# device kernels (k_cubic_sweep, clough_tocher in csrc/amt_nearest.hip) follow them on the pixel-grid triangulation.
+
+def clough_tocher_gradients(points, indptr, indices, values, maxiter=400, tol=1e-6):
+    """interpnd._estimate_gradients_2d_global: point after point, the 2x2 system of the Hermite-curve energy along the
+    triangulation edges, neighbours' gradients as they are at that moment; stops when the largest relative change < tol.
+    points (n,2); (indptr, indices) = Delaunay.vertex_neighbor_vertices; values (n,).  Returns ((n,2) gradients, sweeps)."""
+    n = len(points)
+    y = np.zeros((n, 2))
+    for it in range(maxiter):
+        err = 0.0
+        for i in range(n):
+            q0 = q1 = q3 = s0 = s1 = 0.0
+            for j in indices[indptr[i]:indptr[i + 1]]:
+                ex, ey = points[j, 0] - points[i, 0], points[j, 1] - points[i, 1]
+                l3 = np.hypot(ex, ey) ** 3
+                df2 = -ex * y[j, 0] - ey * y[j, 1]
+                q0 += 4 * ex * ex / l3
+                q1 += 4 * ex * ey / l3
+                q3 += 4 * ey * ey / l3
+                t = (6 * (values[i] - values[j]) - 2 * df2) / l3
+                s0 += t * ex
+                s1 += t * ey
+            det = q0 * q3 - q1 * q1
+            r0, r1 = (q3 * s0 - q1 * s1) / det, (-q1 * s0 + q0 * s1) / det
+            change = max(abs(y[i, 0] + r0), abs(y[i, 1] + r1)) / max(1.0, abs(r0), abs(r1))
+            y[i] = -r0, -r1
+            err = max(err, change)
+        if err < tol:
+            return y, it + 1
+    return y, maxiter
+
+
+def clough_tocher_value(tri_xy, b, f, grad, neighbour_centroids):
+    """interpnd._clough_tocher_2d_single: the element of triangle tri_xy (3,2) at barycentric coordinates b (3,), vertex values
+    f (3,), vertex gradients grad (3,2); neighbour_centroids[k] = centroid of the triangle across the edge opposite vertex k,
+    or None on the hull."""
+    P = np.asarray(tri_xy, dtype=np.float64)
+    e12, e23, e31 = P[1] - P[0], P[2] - P[1], P[0] - P[2]
+    f1, f2, f3 = f
+    d1, d2, d3 = grad
+    df12, df21 = d1 @ e12, -(d2 @ e12)
+    df23, df32 = d2 @ e23, -(d3 @ e23)
+    df31, df13 = d3 @ e31, -(d1 @ e31)
+    c3000, c2100, c2010 = f1, (df12 + 3 * f1) / 3, (df13 + 3 * f1) / 3
+    c0300, c1200, c0210 = f2, (df21 + 3 * f2) / 3, (df23 + 3 * f2) / 3
+    c0030, c1020, c0120 = f3, (df31 + 3 * f3) / 3, (df32 + 3 * f3) / 3
+    c2001 = (c2100 + c2010 + c3000) / 3
+    c0201 = (c1200 + c0300 + c0210) / 3
+    c0021 = (c1020 + c0120 + c0030) / 3
+    T = np.linalg.inv(np.array([[P[0, 0] - P[2, 0], P[1, 0] - P[2, 0]], [P[0, 1] - P[2, 1], P[1, 1] - P[2, 1]]]))
+    g = [-0.5, -0.5, -0.5]
+    for k in range(3):
+        if neighbour_centroids[k] is None:
+            continue
+        c01 = T @ (np.asarray(neighbour_centroids[k]) - P[2])
+        c = (c01[0], c01[1], 1 - c01[0] - c01[1])
+        if k == 0:
+            g[k] = (2 * c[2] + c[1] - 1) / (2 - 3 * c[2] - 3 * c[1])
+        elif k == 1:
+            g[k] = (2 * c[0] + c[2] - 1) / (2 - 3 * c[0] - 3 * c[2])
+        else:
+            g[k] = (2 * c[1] + c[0] - 1) / (2 - 3 * c[1] - 3 * c[0])
+    c0111 = (g[0] * (-c0300 + 3 * c0210 - 3 * c0120 + c0030) + (-c0300 + 2 * c0210 - c0120 + c0021 + c0201)) / 2
+    c1011 = (g[1] * (-c0030 + 3 * c1020 - 3 * c2010 + c3000) + (-c0030 + 2 * c1020 - c2010 + c2001 + c0021)) / 2
+    c1101 = (g[2] * (-c3000 + 3 * c2100 - 3 * c1200 + c0300) + (-c3000 + 2 * c2100 - c1200 + c2001 + c0201)) / 2
+    c1002 = (c1101 + c1011 + c2001) / 3
+    c0102 = (c1101 + c0111 + c0201) / 3
+    c0012 = (c1011 + c0111 + c0021) / 3
+    c0003 = (c1002 + c0102 + c0012) / 3
+    m = min(b)
+    b1, b2, b3, b4 = b[0] - m, b[1] - m, b[2] - m, 3 * m
+    return (b1 ** 3 * c3000 + 3 * b1 ** 2 * b2 * c2100 + 3 * b1 ** 2 * b3 * c2010 + 3 * b1 ** 2 * b4 * c2001
+            + 3 * b1 * b2 ** 2 * c1200 + 6 * b1 * b2 * b4 * c1101 + 3 * b1 * b3 ** 2 * c1020 + 6 * b1 * b3 * b4 * c1011
+            + 3 * b1 * b4 ** 2 * c1002 + b2 ** 3 * c0300 + 3 * b2 ** 2 * b3 * c0210 + 3 * b2 ** 2 * b4 * c0201
+            + 3 * b2 * b3 ** 2 * c0120 + 6 * b2 * b3 * b4 * c0111 + 3 * b2 * b4 ** 2 * c0102 + b3 ** 3 * c0030
+            + 3 * b3 ** 2 * b4 * c0021 + 3 * b3 * b4 ** 2 * c0012 + b4 ** 3 * c0003)

@@ -163,12 +163,12 @@ def test_nearest_frame_brute_force_and_ties():
 
 def test_resample_methods_error_behaviour():
     from auromat_amd.resample import resample
-    with pytest.raises(ValueError):
-        resample(None, method='linear')            # implemented: fails on the argument, not on the method
-    with pytest.raises(NotImplementedError):
-        resample(None, method='cubic')
-    with pytest.raises(ValueError):
-        resample(None, method='bogus')
+    for method in ('linear', 'cubic'):
+        with pytest.raises(ValueError):
+            resample(None, method=method)          # implemented: fails on the argument, not on the method
+    for method in ('median', 'bogus'):             # reference resample.py:353-360
+        with pytest.raises(NotImplementedError):
+            resample(None, method=method)
 
 
 def test_nearest_full_size_properties():
@@ -372,3 +372,193 @@ def test_mapping_resample_linear_between_the_two_diagonals(pointing, ppd):
     assert np.max(np.abs(res['mean'][..., 3][filled] - v[:, 3])) < 2e-2
     # image rounding like the reference's np.round of the interpolated floats
     assert np.array_equal(res['img'][~res['mask']], np.round(res['mean'][..., :3][~res['mask']]).astype(img.dtype))
+
+
+# ---- method='cubic' (reference resample.py:323-326: scipy griddata(method='cubic') = CloughTocher2DInterpolator) -----------
+# Three layers: (1) the algorithm against scipy itself where the triangulation is unambiguous (a sheared lattice: the device's
+# triangles ARE Qhull's, so gradients and values must agree to the solvers' tolerances); (2) outputs of the real reference
+# (tests/golden/resample_cubic.npz, oracle/make_golden.py resample_cubic_cases) on camera frames, where Qhull's choice of
+# diagonal in near-cocircular quads changes neighbours and with them the estimated gradients: smooth channels agree tightly,
+# pixel noise only within its range; (3) the classes.
+
+def _sheared_lattice(h, w):
+    ii, jj = np.mgrid[0:h, 0:w].astype(np.float64)
+    lat = 40.0 + 0.10 * ii + 0.03 * jj
+    lon = 10.0 + 0.02 * ii + 0.10 * jj
+    rng = np.random.RandomState(5)
+    data = np.stack([np.sin(lat / 1.3) * np.cos(lon / 0.9) * 100, 0.5 * lat * lat - 3 * lon + 0.2 * lat * lon,
+                     rng.rand(h, w) * 50], axis=2)
+    return lat, lon, data
+
+
+def test_cubic_gradients_and_values_equal_scipy_on_an_unambiguous_triangulation():
+    import scipy.interpolate
+    import scipy.spatial
+    from auromat_amd._native import Context, ptr, to_host
+    from auromat_amd.mapping.mapping import BoundingBox
+    from auromat_amd.resample import _resample, cubic_gradients
+    h, w = 56, 64
+    lat, lon, data = _sheared_lattice(h, w)
+    pts = np.column_stack((lat.ravel(), lon.ravel()))
+    tri = scipy.spatial.Delaunay(pts)
+    ref = scipy.interpolate.CloughTocher2DInterpolator(tri, data.reshape(-1, 3), tol=1e-10, maxiter=4000)
+    ctx = Context.current()
+    grad, sweeps = cubic_gradients(ctx, ctx.to_device(lat.ravel()), ctx.to_device(lon.ravel()), None, None, h, w, None, 0,
+                                   ctx.to_device(np.ascontiguousarray(data.reshape(-1, 3))), 3, 3)
+    assert 2 <= sweeps < 800, sweeps
+    got = to_host(grad).reshape(h, w, 3, 2)
+    want = ref.grad.reshape(h, w, 3, 2)
+    # Qhull closes the hull of the lattice with its own triangles; the difference decays by about a factor of three per ring
+    inner = (slice(14, h - 14), slice(14, w - 14))
+    scale = np.abs(want[inner]).max(axis=(0, 1, 3))
+    err = np.abs(got[inner] - want[inner]).max(axis=(0, 1, 3)) / scale
+    assert (err < 1e-6).all(), err
+    # values through the array-level API on a grid inside the lattice's footprint
+    s_, n_ = lat[14, 14] + 0.3, lat[h - 15, w - 15] - 0.3
+    w_, e_ = lon[14, w - 15] - 2.0, lon[14, w - 15] - 1.0
+    outline = np.array([[lat[0, 0], lon[0, 0]], [lat[0, -1], lon[0, -1]], [lat[-1, -1], lon[-1, -1]], [lat[-1, 0], lon[-1, 0]]])
+    _, _, lat_c, lon_c, out = _resample(lat, lon, 110.0, data, lambda: outline, BoundingBox(s_, w_, n_, e_), (20, 20),
+                                        False, False, method='cubic')
+    want_v = ref(np.column_stack((np.repeat(lat_c[:, 0], lon_c.shape[1]), np.tile(lon_c[0], lat_c.shape[0])))).reshape(out.shape)
+    filled = ~np.isnan(out[..., 0])
+    assert filled.sum() > 100 and not np.isnan(want_v[filled]).any()
+    rel = np.abs(out - want_v)[filled].max(axis=0) / np.abs(want_v[filled]).max(axis=0)
+    assert (rel < 1e-7).all(), rel
+
+
+CUBIC = LINEAR + [('resample_nearest_iss030.npz', 'iss030_smooth')]
+
+
+@pytest.mark.parametrize('name,key', CUBIC)
+def test_resample_cubic_vs_reference(name, key):
+    from auromat_amd.mapping.mapping import BoundingBox
+    from auromat_amd.resample import _resample
+    z, zc = load_golden(name), load_golden('resample_cubic.npz')
+    want = zc[key + '_out_data']
+    if 'img' in z.files:
+        img = zc['iss030_smooth_img'] if key.endswith('smooth') else z['img']
+        data = np.dstack((img.astype(np.float64), z['elev']))
+        data[np.isnan(z['lats_c'])] = np.nan
+    else:
+        data = z['data']
+    s, w, n, e = z['bbox']
+    outline = z['outline'].copy()
+    lat, lon, lat_c, lon_c, out = _resample(z['lats_c'], z['lons_c'], float(z['altitude']), data, lambda: outline,
+                                            BoundingBox(s, w, n, e), tuple(z['ppd']), bool(z['contains_discontinuity']),
+                                            bool(z['contains_pole']), method='cubic')
+    assert out.shape == want.shape
+    got_nan, want_nan = np.isnan(out[..., 0]), np.isnan(want[..., 0])
+    only_ref, only_here = int((got_nan & ~want_nan).sum()), int((~got_nan & want_nan).sum())
+    both = ~got_nan & ~want_nan
+    assert both.sum() > 0.85 * (~want_nan).sum(), (only_ref, only_here, int(both.sum()))
+    assert only_here <= 0.01 * both.sum(), (only_ref, only_here)
+    d = np.abs(out - want)[both]
+    span = np.nanmax(want, axis=(0, 1)) - np.nanmin(want, axis=(0, 1))
+    print(key, 'cells', int(both.sum()), 'only ref / here', only_ref, only_here, 'max |d| / span', d.max(axis=0) / span,
+          'median', np.median(d, axis=0) / span)
+    # the smooth channels (the elevation everywhere; all channels of the smooth image): a flipped diagonal changes a gradient
+    # estimate in the third order of the pixel spacing
+    smooth = [3] if not key.endswith('smooth') else [0, 1, 2, 3]
+    if 'img' not in z.files:
+        smooth = []                               # (the synthetic cases carry noise in every channel)
+    for c in smooth:
+        assert np.median(d[:, c]) < 1e-5 * span[c], (c, np.median(d[:, c]) / span[c])
+        assert np.quantile(d[:, c], 0.99) < 2e-3 * span[c], (c, np.quantile(d[:, c], 0.99) / span[c])
+    # every channel: bounded by the range of the data (pixel noise makes the gradients depend on the diagonal chosen), and
+    # most cells agree in every channel to the solvers' tolerance — the device's triangles are Qhull's there
+    assert (np.median(d, axis=0) < 0.2 * span).all()
+    agree = (d <= 1e-5 * span).all(axis=1).mean()
+    print(key, 'cells equal to 1e-5 of the span in every channel: %.3f' % agree)
+    assert agree > (0.5 if 'img' in z.files else 0.3), agree
+
+
+@pytest.mark.parametrize('pointing,ppd', [('iss030', 10)])
+def test_mapping_resample_cubic_through_the_classes(pointing, ppd):
+    """resample(mapping.maskedByElevation(10), method='cubic'): the frame route (integer image + elevation in the kernels)
+    against the array-level route on the same arrays (float64 channels), and numpy's rounding / cast of the image."""
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.resample import resample, resample_frame, _resample
+    from auromat_amd.synthetic import frame_header
+    w, h = 256, 170
+    hdr, cam, t = frame_header(w, h, pointing)
+    img = load_golden('resample_cubic.npz')['iss030_smooth_img']
+    m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'n', fastCenterCalculation=True)
+    m.lats
+    mm = m.maskedByElevation(10)
+    r = resample(mm, pxPerDeg=ppd, method='cubic')
+    r.checkGuarantees()
+    r.checkPlateCarree()
+    res = resample_frame(mm.frame(), 110, mm.boundingBox, (ppd, ppd), mm.containsDiscontinuity, False, method='cubic',
+                         outline=mm.outline)
+    assert 2 <= res['sweeps'] < 800
+    keep = ~res['mask']
+    assert keep.sum() > 1000
+    assert np.array_equal(res['img'][keep], r.img.data[~ma.getmaskarray(r.img)[..., 0]])
+    with np.errstate(invalid='ignore'):
+        assert np.array_equal(res['img'][keep], np.round(res['mean'][..., :3][keep]).astype(np.int64).astype(img.dtype))
+    data = np.dstack((img.astype(np.float64), mm.elevation.filled(np.nan)))
+    lat_c, lon_c = mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan)
+    data[np.isnan(lat_c)] = np.nan
+    outline = np.array(mm.outline)
+    _, _, _, _, out = _resample(lat_c, lon_c, 110.0, data, lambda: outline, mm.boundingBox, (ppd, ppd), False, False,
+                                method='cubic')
+    span = np.nanmax(out, axis=(0, 1)) - np.nanmin(out, axis=(0, 1))
+    assert np.array_equal(np.isnan(out[..., 0]), res['mask'])
+    assert (np.abs(out - res['mean'])[keep].max(axis=0) < 1e-9 * span).all()
+
+
+def test_cubic_full_size_reproduces_a_plane():
+    """BASELINE full-size frame (12 M pixel centres as data points): the gradient estimator and the element reproduce a
+    linear function of (lat, lon) exactly, whatever the neighbours of a pixel are — the gradients are its coefficients at
+    every valid pixel and the grid carries its values; a second channel, quadratic, bounds the interpolation error by
+    the curvature times the squared pixel spacing."""
+    import time
+    import torch
+    from auromat_amd._native import Context, ptr, to_host
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.resample import cubic_gradients, nearest_indices, outside_outline_mask, cached_grid
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 4240, 2832
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    m = ArraySpacecraftMapping(hdr, 110, frame_image(w, h, seed=1), cam, t, 'f', fastCenterCalculation=True).maskedByElevation(10)
+    fd = m.frame()
+    ctx = fd.ctx
+    bb = m.boundingBox
+    grid = cached_grid((10, 10), bb.latSouth, bb.latNorth, bb.lonWest, bb.lonEast)
+    lat_c, lon_c = fd.lat_c.reshape(-1), fd.lon_c.reshape(-1)
+    plane = 3.0 + 2.0 * lat_c - 0.5 * lon_c
+    quad = 0.01 * (lat_c - 50.0) ** 2 + 0.02 * (lon_c + 95.0) ** 2
+    data = torch.stack((plane, quad), dim=1).contiguous()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    grad, sweeps = cubic_gradients(ctx, lat_c, lon_c, fd.elev.reshape(-1), fd.center_mask, h, w, 10.0, 0, data, 3, 2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print('full size: %d sweeps, %.1f ms (%.2f ms per sweep, neighbour lists included)' % (sweeps, dt * 1e3, dt * 1e3 / sweeps))
+    assert 2 <= sweeps < 800
+    valid = ~(fd.center_mask_tensor().bool().reshape(-1) | ~(fd.elev.reshape(-1) >= 10.0))
+    g = grad.reshape(h * w, 3, 2)[valid]
+    # pixels with fewer than two usable neighbours keep a zero gradient: isolated specks at the rim, a handful at most
+    lonely = (g[:, 0, :] == 0).all(dim=1)
+    assert int(lonely.sum()) < 100
+    g = g[~lonely]
+    assert float((g[:, 0, 0] - 2.0).abs().max()) < 1e-6 and float((g[:, 0, 1] + 0.5).abs().max()) < 1e-6
+    target_mask = outside_outline_mask(ctx, grid, np.array(m.outline, dtype=np.float64))
+    index = nearest_indices(ctx, lat_c, lon_c, fd.elev, fd.center_mask, h, w, 10.0, grid, 0, target_mask)
+    tlat, tlon = grid.device_centers(ctx)
+    mean = ctx.empty((grid.ny, grid.nx, 3))
+    mask = ctx.empty((grid.ny, grid.nx), torch.uint8)
+    ctx.call('amt_cubic_gather', ptr(index), grid.ny, grid.nx, ptr(lat_c), ptr(lon_c), ptr(fd.elev), ptr(fd.center_mask), h, w,
+             10.0, 0, ptr(tlat), ptr(tlon), ptr(data), 3, 2, ptr(grad), ptr(mean), None, ptr(mask), None, None)
+    out, keep = to_host(mean), to_host(mask) == 0
+    assert keep.sum() > 0.5 * keep.size
+    glat, glon = to_host(tlat)[:, None], to_host(tlon)[None, :]
+    want_plane = 3.0 + 2.0 * glat - 0.5 * glon + 0 * out[..., 0]
+    assert np.abs(out[..., 0] - want_plane)[keep].max() < 1e-7
+    want_quad = 0.01 * (glat - 50.0) ** 2 + 0.02 * (glon + 95.0) ** 2 + 0 * out[..., 1]
+    assert np.abs(out[..., 1] - want_quad)[keep].max() < 1e-4            # pixel spacing ~0.01-0.05 deg, curvature 0.04
+    # the elevation channel: smooth, so within a hair of the linear interpolant on the same triangles
+    lin = ctx.empty((grid.ny, grid.nx, 1))
+    ctx.call('amt_linear_gather', ptr(index), grid.ny, grid.nx, ptr(lat_c), ptr(lon_c), ptr(fd.elev), ptr(fd.center_mask), h, w,
+             10.0, 0, ptr(tlat), ptr(tlon), None, 1, 0, ptr(lin), None, None, None, None)
+    assert np.abs(to_host(lin)[..., 0] - out[..., 2])[keep].max() < 1e-3

@@ -300,3 +300,33 @@ def test_resample_nearest_oracle_vs_reference(name):
         same(res[k], z['out_' + k], 0.0 if not bool(z['contains_pole']) else 1e-12)
     same(res['data'], z['out_data'])
     assert not np.isnan(res['data'][..., 0]).all()
+
+
+def test_clough_tocher_restatement_equals_scipy():
+    """griddata(method='cubic') (reference resample.py:323-326) is scipy's CloughTocher2DInterpolator: the restatement of
+    its gradient estimator and of its element (oracle/ref_numpy.py), on scipy's own triangulation, against scipy."""
+    from scipy.interpolate import CloughTocher2DInterpolator
+    from scipy.spatial import Delaunay
+    rng = np.random.RandomState(3)
+    pts = rng.rand(70, 2)
+    vals = np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.1 * rng.rand(70)
+    tri = Delaunay(pts)
+    ref = CloughTocher2DInterpolator(tri, vals)
+    indptr, indices = tri.vertex_neighbor_vertices
+    grad, sweeps = O.clough_tocher_gradients(pts, indptr, indices, vals)
+    assert 2 <= sweeps < 400
+    assert np.max(np.abs(grad - ref.grad[:, 0, :])) < 1e-13
+    q = rng.rand(150, 2)
+    want = ref(q)
+    simplex = tri.find_simplex(q)
+    assert np.array_equal(simplex < 0, np.isnan(want))
+    for p, s, w in zip(q, simplex, want):
+        if s < 0:
+            continue
+        v = tri.simplices[s]
+        T = tri.transform[s]
+        c = T[:2].dot(p - T[2])
+        b = (c[0], c[1], 1 - c.sum())
+        cent = [None if n < 0 else pts[tri.simplices[n]].mean(axis=0) for n in tri.neighbors[s]]
+        got = O.clough_tocher_value(pts[v], b, vals[v], grad[v], cent)
+        assert abs(got - w) < 1e-13
