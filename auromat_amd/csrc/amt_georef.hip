@@ -1243,6 +1243,38 @@ __global__ __launch_bounds__(kThreads) void k_bbox_fold(const double* __restrict
 constexpr int kTW = 64, kTH = 8;
 constexpr int kFoldBlocks = 64;
 
+// The folds of up to kMaxBatch frames in one launch per stage (grid: blocks x frames; two launches behind a launch of three
+// frames where there were six).  stage 0: every block folds its share of a frame's partials into one row of the frame's
+// scratch; stage 1 (one block per frame): the rows into the frame's box.  (Both stages in ONE launch — the block that
+// arrives last at a counter folds the rows — was measured and is slower for the whole pipeline by 15 %: every block needs
+// a device-scope release before the counter, which on this chip writes back the L2 of its XCD, 768 times per launch of
+// three frames, while the next big kernel is filling those L2s with its stores; profiles/r3/x_ab_fold_variants.txt.)
+struct fold_batch {
+    const double* in[kMaxBatch];
+    double* out[kMaxBatch];
+    const unsigned int* extra[kMaxBatch];   // see k_bbox_fold
+};
+
+__global__ __launch_bounds__(kThreads) void k_bbox_fold_batch(fold_batch Bf, int n) {
+    __shared__ double sRed[8][kThreads / 64];
+    const int f = blockIdx.y;
+    const double* partials = Bf.in[f];
+    double v[8] = {kInf, -kInf, kInf, -kInf, kInf, -kInf, 0, 0};
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const double* q = partials + (int64_t)i * 8;
+        v[0] = fmin(v[0], q[0]);
+        v[1] = fmax(v[1], q[1]);
+        v[2] = fmin(v[2], q[2]);
+        v[3] = fmax(v[3], q[3]);
+        v[4] = fmin(v[4], q[4]);
+        v[5] = fmax(v[5], q[5]);
+        v[6] += q[6];
+        v[7] += q[7];
+    }
+    if (Bf.extra[f] != nullptr) v[7] = threadIdx.x == 0 ? (double)*Bf.extra[f] : 0.0;     // slot 7 is summed over the block
+    block_reduce8<kThreads>(v, Bf.out[f] + (int64_t)blockIdx.x * 8, sRed);
+}
+
 // start / stop: events attached to the dispatch (timing, and the hand-over to the driver's tail stream) or NULL
 struct launch_events {
     hipEvent_t start, stop;
@@ -1783,18 +1815,25 @@ int launch_prepared(amt_ctx* ctx, int n, prepared_frame* F) {
         }
     }
     AMT_LAUNCH_CHECK(ctx);
+    // the folds: one launch per stage for all frames whose folds run on the same stream (the frame drivers of a context
+    // share theirs)
+    bool folded[kMaxBatch] = {false, false, false};
     for (int i = 0; i < n; ++i) {
-        if (!F[i].out->bbox) continue;
-        hipStream_t fs = ctx->stream;
-        if (F[i].tail) {
-            AMT_HIP(ctx, hipStreamWaitEvent(F[i].tail->stream, ev.stop, 0));
-            fs = F[i].tail->stream;
+        if (!F[i].out->bbox || folded[i]) continue;
+        hipStream_t fs = F[i].tail ? F[i].tail->stream : ctx->stream;
+        if (F[i].tail) AMT_HIP(ctx, hipStreamWaitEvent(fs, ev.stop, 0));
+        fold_batch s0, s1;
+        int m = 0;
+        for (int k = 0; k < kMaxBatch; ++k) s0.in[k] = s1.in[k] = nullptr, s0.out[k] = s1.out[k] = nullptr, s0.extra[k] = s1.extra[k] = nullptr;
+        for (int k = i; k < n; ++k) {
+            if (!F[k].out->bbox || folded[k] || (F[k].tail ? F[k].tail->stream : ctx->stream) != fs) continue;
+            s0.in[m] = F[k].A.bbox_partials, s0.out[m] = F[k].fold;
+            s1.in[m] = F[k].fold, s1.out[m] = F[k].out->bbox, s1.extra[m] = F[k].A.bin_event_count;
+            folded[k] = true;
+            ++m;
         }
-        hipLaunchKernelGGL(k_bbox_fold, dim3(kFoldBlocks), dim3(kThreads), 0, fs, F[i].A.bbox_partials, (int)n_items,
-                           F[i].fold, (const unsigned int*)nullptr);
-        AMT_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, fs, F[i].fold, kFoldBlocks, F[i].out->bbox,
-                           (const unsigned int*)F[i].A.bin_event_count);
+        hipLaunchKernelGGL(k_bbox_fold_batch, dim3(kFoldBlocks, m), dim3(kThreads), 0, fs, s0, (int)n_items);
+        hipLaunchKernelGGL(k_bbox_fold_batch, dim3(1, m), dim3(kThreads), 0, fs, s1, kFoldBlocks);
         AMT_LAUNCH_CHECK(ctx);
     }
     return AMT_OK;
