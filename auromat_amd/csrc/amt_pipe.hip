@@ -178,8 +178,9 @@ int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe) {
               hipEventCreateWithFlags(&pipe->bbox_done, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&pipe->tail_done, hipEventDisableTiming) == hipSuccess &&
               hipMalloc(&pipe->events, kEventCapacity * 32) == hipSuccess &&
+              // (zeroed on the context's stream before the first fused launch, see pipe_prepare: a memset on the null stream
+              // here is not ordered against the context's non-blocking stream and may run late when processes share the GPU)
               hipMalloc(reinterpret_cast<void**>(&pipe->event_count), sizeof(uint32_t)) == hipSuccess &&
-              hipMemset(pipe->event_count, 0, sizeof(uint32_t)) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&pipe->host_small), 16 * sizeof(double), hipHostMallocMapped) ==
                   hipSuccess &&
               hipHostGetDevicePointer(reinterpret_cast<void**>(&pipe->host_small_dev), pipe->host_small, 0) == hipSuccess;
