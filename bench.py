@@ -432,23 +432,33 @@ def main(argv=None):
 
     import torch
     import torch.distributed as dist
+    # Rehearsal of the N-rank run on a box with ONE GPU (tests/test_gpu_bench_ranks.py): AMT_BENCH_ONE_GPU=1 puts every rank on
+    # cuda:0 and AMT_BENCH_BACKEND=gloo takes the collectives through the host (RCCL refuses two ranks on one device) — the
+    # sharding, the capacity agreement, the gather, the barriers and the max over the ranks are the code of the real run
+    backend = os.environ.get('AMT_BENCH_BACKEND', 'nccl')
+    if os.environ.get('AMT_BENCH_ONE_GPU'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # AMT_BENCH_FORCE_DIST=1 exercises the RCCL gather path with a single rank (boxes with one GPU)
     use_dist = world > 1 or bool(os.environ.get('AMT_BENCH_FORCE_DIST'))
     def init_dist():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29541')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if use_dist:
         init_dist()
 
     from auromat_amd._native import Context
-    from auromat_amd.sequence import agree_capacity, gather_device
+    from auromat_amd.sequence import agree_capacity, collective_device, gather_device
     from auromat_amd.synthetic import sequence_frame, frame_image
 
     ctx = Context.current()
     device = ctx.device
+    cdev = collective_device(device) if use_dist else device      # where the collectives' tensors live (the GPU for RCCL)
     fast = not args.exact
     total = args.warmup + args.steps
     first = rank * total                    # this rank's block of the synthetic sequence
@@ -490,15 +500,15 @@ def main(argv=None):
             # agree on a capacity (the longest payload + 25 %) here, so that the timed gather is ONE collective
             # without a size exchange and its host synchronisation
             results = (results * (args.steps // max(len(results), 1) + 1))[:args.steps]
-            gather_state['capacity'] = agree_capacity(results, [base + k for k in range(len(results))], device)
-        return gather_device(results, [base + k for k in range(len(results))], device, capacity=gather_state.get('capacity'))
+            gather_state['capacity'] = agree_capacity(results, [base + k for k in range(len(results))], cdev)
+        return gather_device(results, [base + k for k in range(len(results))], cdev, capacity=gather_state.get('capacity'))
 
     run = timed_run(make_frames(total, args.magnetic), args.warmup, args.steps, fast, args.plan, args.magnetic,
                     args.batch, args.streams, not args.no_hints, shared, own_buffers=args.upload, fence=fence,
                     after=gather, spinup_ms=args.spinup_ms)
     elapsed = run['elapsed']
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         if rank == 0:
@@ -568,7 +578,7 @@ def main(argv=None):
                        'frames_total': world * args.steps,
                        # untimed frames run before the W warm-up steps to bring the chip to its sustained state
                        'spinup_frames_untimed': run['spinup_frames'], 'spinup_ms': args.spinup_ms,
-                       'parallelism': 'frames sharded over %d GPU(s), RCCL gather of grids' % world,
+                       'parallelism': 'frames sharded over %d GPU(s), %s gather of grids' % (world, 'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'),
                        'frame_loop': 'library (amt_run_*)' if getattr(seq, 'native', False) and args.plan == 'fused' and not args.upload
                        else 'python',
                        # transparency: rows of work items whose waves write NaN without casting rays, because the host has

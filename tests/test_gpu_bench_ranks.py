@@ -1,0 +1,38 @@
+"""
+The N-rank form of bench.py rehearsed on ONE GPU: `python bench.py --gpus N` starts its ranks itself (a child
+`torch.distributed.run`, exactly what the driver's launcher does), every rank shards the synthetic sequence, the ranks agree on
+a gather capacity in the warm-up, rank 0 gathers all grids inside the timed region, the time is the maximum over the ranks and
+rank 0 prints the one JSON line.  RCCL refuses two ranks on one device, so the rehearsal takes the collectives through gloo
+(AMT_BENCH_BACKEND=gloo) and puts every rank on cuda:0 (AMT_BENCH_ONE_GPU=1); everything else is the code of the real run.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('world,steps', [(2, 8), (4, 5)])
+def test_bench_with_several_ranks_on_one_gpu(world, steps):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(AMT_BENCH_BACKEND='gloo', AMT_BENCH_ONE_GPU='1')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', str(steps), '--warmup', '2',
+                          '--cpu-rows', '0', '--no-variants'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == world and out['steps'] == steps and out['warmup'] == 2
+    assert out['scaling'] == 'weak' and out['higher_is_better'] is True
+    # whole-job value: all ranks' frames over the slowest rank's time
+    npx = 4240 * 2832
+    assert abs(out['value'] - world * steps * npx / 1e6 / (out['ms_per_step'] * steps * 1e-3)) < 1e-6 * out['value']
+    assert out['config']['workload'].startswith('configs[')
+    assert out['roofline']['frac'] > 0 and out['roofline']['bound'] == 'hbm'
+    assert out['config']['frames_total'] == world * steps and out['config']['single_pass_frames'] == steps
