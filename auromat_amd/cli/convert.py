@@ -96,6 +96,10 @@ def getParser():
     outputArgs.add_argument('--skip', help='Skips already converted files.', action='store_true')
     outputArgs.add_argument('--format', help='Data format of converted files', choices=[Format.cdf, Format.netcdf],
                             required=True)
+    outputArgs.add_argument('--netcdf-container', dest='netcdfContainer', choices=['netcdf4', 'classic'], default='netcdf4',
+                            help='netCDF files: the netCDF-4 / HDF5 container the reference writes (zlib, one row per chunk; '
+                                 'default) or netCDF classic with 64-bit offsets (no compression). Not an option of the '
+                                 'reference.')
     outputArgs.add_argument('--without-bounds', dest='withoutBounds', action='store_true',
                             help='Do not include coordinates of pixel corners. If set, then only the pixel center '
                                  'coordinates are written, otherwise both.')
@@ -317,7 +321,8 @@ def main(argv=None):
     if not frames:
         raise NotImplementedError('No <id>.wcs / <id>.json + <id>.npy (or .jpg / .png / .tif) frames found in ' + args.data)
     export = partial(write, includeBounds=not args.withoutBounds, includeMagCoords=not args.withoutMag,
-                     includeGeoCoords=not args.withoutGeo)
+                     includeGeoCoords=not args.withoutGeo,
+                     format='NETCDF4' if args.netcdfContainer == 'netcdf4' else 'NETCDF3_64BIT')
     os.makedirs(args.out, exist_ok=True)
     if args.resample and args.pxPerDeg:
         convert_with_pipeline(args, frames, export)

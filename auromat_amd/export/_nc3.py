@@ -1,12 +1,11 @@
 """
 Minimal writer / reader of the netCDF classic format with 64-bit offsets (CDF-2), NumPy only.
 
-The reference writes its files with the netCDF4 library (HDF5 container, zlib-compressed, chunked); neither that
-library nor h5py exists in this environment, and nothing the reference stores needs netCDF-4 features: every variable
-is byte / int / float / double and every attribute a string or a small numeric array.  The classic format holds the
+The reference writes its files with the netCDF4 library (HDF5 container, zlib-compressed, chunked; here:
+:mod:`auromat_amd.export._nc4`, the default of the exporter).  Nothing the reference stores needs netCDF-4 features: every
+variable is byte / int / float / double and every attribute a string or a small numeric array.  The classic format holds the
 same dimensions, variables, attributes and ``_FillValue`` s, is read by netCDF4 / xarray / GDAL / ncdump like any other
-netCDF file (so the reference's own ``NetCDFMapping`` reader opens it), and has no compression and no chunking — the
-only two things of the reference's files that are lost.
+netCDF file (so the reference's own ``NetCDFMapping`` reader opens it), and has no compression and no chunking.
 
 Format: https://docs.unidata.ucar.edu/netcdf-c/current/file_format_specifications.html (classic, CDF-2).
 """
@@ -96,7 +95,8 @@ class Writer(object):
             raise ValueError('dimension %r of size %r: fixed dimensions need a positive size' % (name, size))
         self.dims[name] = int(size)
 
-    def create_variable(self, name, dtype, dims=(), fill_value=None):
+    def create_variable(self, name, dtype, dims=(), fill_value=None, zlib=False, chunksizes=None):
+        # (zlib, chunksizes: options of the netCDF-4 writer, :mod:`auromat_amd.export._nc4`; the classic format has neither)
         if isinstance(dims, str):
             dims = (dims,)
         for d in dims:

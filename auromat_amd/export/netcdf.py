@@ -1,9 +1,9 @@
 """
 Exports mappings into the netCDF file format following the CF 1.6 and NODC conventions, one self-contained file per
 mapping — the layout of the reference's exporter (auromat/export/netcdf.py:24-386): same dimensions, variables,
-data types, ``_FillValue`` s and attributes, created in the same order.  The container is netCDF classic with 64-bit
-offsets instead of netCDF-4 (see :mod:`auromat_amd.export._nc3`): no compression, no chunking, nothing else differs;
-``compress`` is accepted for compatibility and ignored.
+data types, ``_FillValue`` s and attributes, created in the same order, in the same container: netCDF-4 (an HDF5 file laid
+out by :mod:`auromat_amd.export._nc4`, zlib-compressed in the reference's chunks) or, on request, netCDF classic with 64-bit
+offsets (:mod:`auromat_amd.export._nc3`: no compression, no chunking).
 
 Pure host code: it takes any object with the attributes of ``BaseMapping`` (masked NumPy arrays), so the small
 resampled grids of the frame pipeline go to disk without ever materialising per-pixel arrays on the host.
@@ -12,13 +12,13 @@ from datetime import datetime
 
 import numpy as np
 
-from . import _nc3
+from . import _nc3, _nc4
 from ..coordinates.transform import northGeomagneticPoleLocation
 from ..mapping.mapping import isPlateCarree
 
 
 def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords=True, includeGeoCoords=True,
-          use1dIfPossible=True, compress=True):
+          use1dIfPossible=True, compress=True, format='NETCDF4'):
     """
     :param str outputPath:
     :param auromat_amd.mapping.mapping.BaseMapping mapping:
@@ -26,11 +26,19 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
                           attributes (see http://wiki.esipfed.org/index.php/Attribute_Convention_for_Data_Discovery)
     :param bool includeBounds: stores the coordinates of each pixel corner (in addition to the center)
     :param bool includeMagCoords: include geomagnetic latitude-magnetic local time coordinates
-    :param bool compress: ignored (the classic format has no compression)
+    :param bool compress: zlib-compress the arrays (netCDF-4 only; deflate level 4 behind the byte shuffle, the defaults of
+                          the netCDF4 library the reference calls with ``zlib=compress``)
+    :param str format: 'NETCDF4' (the reference's container: HDF5, chunked like the reference's files — one row of the arrays
+                       per chunk —, written by :mod:`auromat_amd.export._nc4`) or 'NETCDF3_64BIT' (classic format with 64-bit
+                       offsets, :mod:`auromat_amd.export._nc3`: no compression, no chunking; what
+                       :class:`auromat_amd.mapping.netcdf.NetCDFMapping` reads)
     """
     if not includeGeoCoords:
         raise ValueError('Geodetic coordinates cannot be disabled for netCDF as they are essential to the format')
-    root = _nc3.Writer()
+    if format not in ('NETCDF4', 'NETCDF3_64BIT'):
+        raise ValueError("format must be 'NETCDF4' or 'NETCDF3_64BIT'")
+    root = _nc4.Writer() if format == 'NETCDF4' else _nc3.Writer()
+    z = bool(compress)
     # ROOT ATTRIBUTES (reference netcdf.py:50-72)
     root.attrs['Conventions'] = 'CF-1.6'
     metadata = dict(list((mapping.metadata or {}).items()) + list(metadata.items()))
@@ -39,6 +47,7 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
             v = np.uint8(v)
         try:
             _nc3._attr_values(v)
+            _nc4.check_attribute(v)
         except TypeError:
             raise TypeError('Cannot store global attribute "{}" with value {}'.format(k, repr(v)))
         root.attrs[k] = v
@@ -86,18 +95,18 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
     if isLatLonPlateCarree:
         # the unmasked arrays: CF coordinate arrays have no missing values
         latsCenter, lonsCenter = mapping.latsCenter.data[:, 0], mapping.lonsCenter.data[0, :]
-        lat = root.create_variable('lat', np.float64, ('lats',))
+        lat = root.create_variable('lat', np.float64, ('lats',), zlib=z)
         lat.attrs['actual_range'] = np.float64([latsCenter[-1], latsCenter[0]])
         lat.set(latsCenter)
-        lon = root.create_variable('lon', np.float64, ('lons',))
+        lon = root.create_variable('lon', np.float64, ('lons',), zlib=z)
         lon.attrs['actual_range'] = np.float64([lonsCenter[0], lonsCenter[-1]])
         lon.set(lonsCenter)
     else:
         # auxiliary 2D coordinate variables with missing values (a documented deviation of the reference from CF 1.6)
-        lat = root.create_variable('lat', np.float64, ('y', 'x'))
+        lat = root.create_variable('lat', np.float64, ('y', 'x'), zlib=z, chunksizes=(1, w))
         lat.attrs['actual_range'] = np.float64([np.min(mapping.latsCenter), np.max(mapping.latsCenter)])
         lat.set(mapping.latsCenter.filled(np.nan))
-        lon = root.create_variable('lon', np.float64, ('y', 'x'))
+        lon = root.create_variable('lon', np.float64, ('y', 'x'), zlib=z, chunksizes=(1, w))
         lon.attrs['actual_range'] = np.float64([np.min(mapping.lonsCenter), np.max(mapping.lonsCenter)])
         lon.set(mapping.lonsCenter.filled(np.nan))
 
@@ -128,28 +137,28 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
         lat.attrs['bounds'] = 'lat_bounds'
         lon.attrs['bounds'] = 'lon_bounds'
         if isLatLonPlateCarree:
-            root.create_variable('lat_bounds', np.float64, ('lats', 'vertex2')).set(_bounds1d(mapping.lats.data[:, 0]))
-            root.create_variable('lon_bounds', np.float64, ('lons', 'vertex2')).set(_bounds1d(mapping.lons.data[0, :]))
+            root.create_variable('lat_bounds', np.float64, ('lats', 'vertex2'), zlib=z, chunksizes=(h, 2)).set(_bounds1d(mapping.lats.data[:, 0]))
+            root.create_variable('lon_bounds', np.float64, ('lons', 'vertex2'), zlib=z, chunksizes=(w, 2)).set(_bounds1d(mapping.lons.data[0, :]))
         else:
-            root.create_variable('lat_bounds', np.float64, ('y', 'x', 'vertex4')).set(_bounds2d(mapping.lats.filled(np.nan)))
-            root.create_variable('lon_bounds', np.float64, ('y', 'x', 'vertex4')).set(_bounds2d(mapping.lons.filled(np.nan)))
+            root.create_variable('lat_bounds', np.float64, ('y', 'x', 'vertex4'), zlib=z, chunksizes=(1, w, 4)).set(_bounds2d(mapping.lats.filled(np.nan)))
+            root.create_variable('lon_bounds', np.float64, ('y', 'x', 'vertex4'), zlib=z, chunksizes=(1, w, 4)).set(_bounds2d(mapping.lons.filled(np.nan)))
 
     if includeMagCoords:
         # non-standard: CF 1.6 has no convention for coordinates in a second system (reference netcdf.py:203-277)
         mlats, mlts = mapping.mLatMltCenter
         if isMLatMltPlateCarree:
             mlatsCenter, mltsCenter = mlats.data[:, 0], mlts.data[0, :]
-            mlat = root.create_variable('mlat', np.float64, ('mlats',))
+            mlat = root.create_variable('mlat', np.float64, ('mlats',), zlib=z)
             mlat.attrs['actual_range'] = np.float64([mlatsCenter[-1], mlatsCenter[0]])
             mlat.set(mlatsCenter)
-            mlt = root.create_variable('mlt', np.float64, ('mlts',))
+            mlt = root.create_variable('mlt', np.float64, ('mlts',), zlib=z)
             mlt.attrs['actual_range'] = np.float64([mltsCenter[0], mltsCenter[-1]])
             mlt.set(mltsCenter)
         else:
-            mlat = root.create_variable('mlat', np.float64, ('y', 'x'))
+            mlat = root.create_variable('mlat', np.float64, ('y', 'x'), zlib=z, chunksizes=(1, w))
             mlat.attrs['actual_range'] = np.float64([np.min(mlats), np.max(mlats)])
             mlat.set(mlats.filled(np.nan))
-            mlt = root.create_variable('mlt', np.float64, ('y', 'x'))
+            mlt = root.create_variable('mlt', np.float64, ('y', 'x'), zlib=z, chunksizes=(1, w))
             mlt.attrs['actual_range'] = np.float64([np.min(mlts), np.max(mlts)])
             mlt.set(mlts.filled(np.nan))
         mlat.attrs['long_name'] = 'Geomagnetic latitude'
@@ -167,11 +176,11 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
             mlt.attrs['bounds'] = 'mlt_bounds'
             mlats, mlts = mapping.mLatMlt
             if isMLatMltPlateCarree:
-                root.create_variable('mlat_bounds', np.float64, ('mlats', 'vertex2')).set(_bounds1d(mlats.data[:, 0]))
-                root.create_variable('mlt_bounds', np.float64, ('mlts', 'vertex2')).set(_bounds1d(mlts.data[0, :]))
+                root.create_variable('mlat_bounds', np.float64, ('mlats', 'vertex2'), zlib=z, chunksizes=(h, 2)).set(_bounds1d(mlats.data[:, 0]))
+                root.create_variable('mlt_bounds', np.float64, ('mlts', 'vertex2'), zlib=z, chunksizes=(w, 2)).set(_bounds1d(mlts.data[0, :]))
             else:
-                root.create_variable('mlat_bounds', np.float64, ('y', 'x', 'vertex4')).set(_bounds2d(mlats.filled(np.nan)))
-                root.create_variable('mlt_bounds', np.float64, ('y', 'x', 'vertex4')).set(_bounds2d(mlts.filled(np.nan)))
+                root.create_variable('mlat_bounds', np.float64, ('y', 'x', 'vertex4'), zlib=z, chunksizes=(1, w, 4)).set(_bounds2d(mlats.filled(np.nan)))
+                root.create_variable('mlt_bounds', np.float64, ('y', 'x', 'vertex4'), zlib=z, chunksizes=(1, w, 4)).set(_bounds2d(mlts.filled(np.nan)))
         magPoleLat, magPoleLon = northGeomagneticPoleLocation(mapping.photoTime)
         mcrs = root.create_variable('mcrs', np.int8)        # holds no actual data
         mcrs.attrs['north_geomagnetic_pole_lat'] = np.float64(magPoleLat)
@@ -195,7 +204,7 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
     else:
         raise NotImplementedError
     for i, band in enumerate(bands):
-        img = root.create_variable(band, imgDtype, (y, x), fill_value=imgFillval)
+        img = root.create_variable(band, imgDtype, (y, x), fill_value=imgFillval, zlib=z, chunksizes=(1, w))
         img.attrs['units'] = 'unitless'
         img.attrs['valid_min'] = imgDtype(np.iinfo(mapping.img.dtype).min)
         img.attrs['valid_max'] = imgDtype(np.iinfo(mapping.img.dtype).max)
@@ -206,7 +215,7 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
 
     # netCDF-CF knows no elevation angle but a zenith angle
     zena = 90 - mapping.elevation
-    zenith_angle = root.create_variable('zenith_angle', np.float32, (y, x))
+    zenith_angle = root.create_variable('zenith_angle', np.float32, (y, x), zlib=z, chunksizes=(1, w))
     zenith_angle.attrs['units'] = 'degrees'
     zenith_angle.attrs['cell_methods'] = 'time: lat: lon: point' if isLatLonPlateCarree else 'time: y: x: point'
     zenith_angle.attrs['valid_min'] = np.float32(0)

@@ -1,6 +1,8 @@
 """
-Reads files written by :mod:`auromat_amd.export.netcdf` (or by the reference's exporter, once converted to the
-classic format with ``nccopy -k nc6`` (= ``-k 64-bit-offset``, CDF-2) or ``-k classic`` (CDF-1); CDF-5 is not read) back as mappings — reference auromat/mapping/netcdf.py.
+Reads files written by :mod:`auromat_amd.export.netcdf` — netCDF-4 as laid out by :mod:`auromat_amd.export._nc4` or netCDF
+classic — back as mappings (reference auromat/mapping/netcdf.py).  Files of the reference's exporter come from the netCDF
+library, whose HDF5 structures (version-2 object headers) are not parsed here: convert them to the classic format with
+``nccopy -k nc6`` (= ``-k 64-bit-offset``, CDF-2) or ``-k classic`` (CDF-1); CDF-5 is not read.
 File parsing is host code; the mapping it returns is a :class:`GenericMapping` (device-resident like all others).
 """
 import collections
@@ -10,7 +12,7 @@ from datetime import datetime, timedelta
 import numpy as np
 import numpy.ma as ma
 
-from ..export import _nc3
+from ..export import _nc4
 from .mapping import BaseMappingProvider, GenericMapping
 
 
@@ -20,7 +22,7 @@ def read_arrays(path):
     exported mapping, as the reference's ``NetCDFMapping.__init__`` assembles them (mapping/netcdf.py:96-157): corner
     grids rebuilt from the cell bounds, images back to their unsigned type, elevation = 90 - zenith angle.
     """
-    f = _nc3.File(path)
+    f = _nc4.open_file(path)
     var = f.vars
     altitude = var['altitude'].data / 1000
     cameraPosGCRS = np.array(var['camera_pos'].data)

@@ -67,7 +67,7 @@ def test_header_cards_and_frame_listing(tmp_path):
 @pytest.mark.gpu
 def test_convert_both_routes(tmp_path, capsys):
     from auromat_amd.cli.convert import main
-    from auromat_amd.export import _nc3
+    from auromat_amd.export import _nc4
     from auromat_amd.mapping.netcdf import NetCDFMapping, read_arrays
     from auromat_amd.mapping.spacecraft import getMapping
     from auromat_amd.resample import resample, resampleMLatMLT
@@ -84,7 +84,7 @@ def test_convert_both_routes(tmp_path, capsys):
     assert np.array_equal(got['lats'].filled(np.nan), want.lats.filled(np.nan), equal_nan=True)
     assert np.array_equal(got['img'].filled(0), want.img.filled(0)) and np.array_equal(ma.getmaskarray(got['img']), ma.getmaskarray(want.img))
     assert np.allclose(got['elevation'].filled(-1), want.elevation.filled(-1), atol=1e-4)       # stored as float32 zenith angle
-    f = _nc3.File(os.path.join(out1, 'frame01.nc'))
+    f = _nc4.open_file(os.path.join(out1, 'frame01.nc'))
     # (the geodetic coordinates of an MLat/MLT grid are curvilinear; and the MLat/MLT the exporter recomputes from them at the
     # mapping altitude are not exactly regular either, in the reference as here: smToLatLon goes through a point 1 km
     # from the Earth's centre, transform.py:472-480 — so both systems are stored as 2-D arrays with cell bounds)
@@ -103,7 +103,7 @@ def test_convert_both_routes(tmp_path, capsys):
     main(['--data', d, '--format', 'netcdf', '--resample', '--min-elevation', '10', '--grid', 'geo', '--px-per-deg', '5', '--out', out2, '--without-bounds',
           '--without-mag'])
     want = resample(m, pxPerDeg=5)
-    f = _nc3.File(os.path.join(out2, 'frame01.nc'))
+    f = _nc4.open_file(os.path.join(out2, 'frame01.nc'))
     assert f.vars['lat'].dims == ('lats',) and 'lat_bounds' not in f.vars and 'mlat' not in f.vars
     assert np.array_equal(f.vars['lat'].data, want.latsCenter.data[:, 0]) and np.array_equal(f.vars['lon'].data, want.lonsCenter.data[0, :])
     red = ma.masked_equal(f.vars['img_red'].data, f.vars['img_red'].attrs['_FillValue'])
@@ -113,7 +113,7 @@ def test_convert_both_routes(tmp_path, capsys):
     out3 = str(tmp_path / 'o3')
     main(['--data', d, '--format', 'netcdf', '--out', out3, '--end', '2012-01-25T09:26:56'])
     assert os.listdir(out3) == ['frame00.nc']
-    f = _nc3.File(os.path.join(out3, 'frame00.nc'))
+    f = _nc4.open_file(os.path.join(out3, 'frame00.nc'))
     assert f.vars['lat'].dims == ('y', 'x') and f.vars['lat_bounds'].data.shape == (170, 256, 4)
 
 

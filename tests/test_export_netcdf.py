@@ -47,13 +47,14 @@ class Mapping(object):
         self.identifier = identifier
 
 
-def value_of(rec):
+def value_of(rec, classic=True):
     v = rec['value']
-    return v if rec['dtype'] == 'str' else np.asarray(v, dtype=CLASSIC.get(rec['dtype'], rec['dtype']))
+    # (the classic format has no unsigned types: the next larger signed one; netCDF-4 keeps the reference's)
+    return v if rec['dtype'] == 'str' else np.asarray(v, dtype=CLASSIC.get(rec['dtype'], rec['dtype']) if classic else rec['dtype'])
 
 
-def same_attr(got, rec, what):
-    want = value_of(rec)
+def same_attr(got, rec, what, classic=True):
+    want = value_of(rec, classic)
     if isinstance(want, str):
         assert got == want, what
     else:
@@ -62,9 +63,10 @@ def same_attr(got, rec, what):
         assert np.array_equal(np.atleast_1d(got), np.atleast_1d(want), equal_nan=True), what
 
 
+@pytest.mark.parametrize('fmt', ['NETCDF4', 'NETCDF3_64BIT'])
 @pytest.mark.parametrize('case', CASES)
-def test_written_file_has_the_references_layout_and_data(case, tmp_path):
-    from auromat_amd.export import _nc3
+def test_written_file_has_the_references_layout_and_data(case, fmt, tmp_path):
+    from auromat_amd.export import _nc4
     from auromat_amd.export.netcdf import write
     layout = json.load(open(os.path.join(GOLDEN, 'netcdf_layout_%s.json' % case)))
     z = load_golden('netcdf_case_%s.npz' % case)
@@ -76,16 +78,18 @@ def test_written_file_has_the_references_layout_and_data(case, tmp_path):
     if case.endswith('_includeMagCoords'):
         opts['includeMagCoords'] = False
     path = str(tmp_path / (case + '.nc'))
-    write(path, m, metadata={'Source_name': 'test'}, **opts)
-    f = _nc3.File(path)
+    write(path, m, metadata={'Source_name': 'test'}, format=fmt, **opts)
+    f = _nc4.open_file(path)
+    classic = fmt != 'NETCDF4'
     # dimensions: names, sizes, order
     assert [[k, v] for k, v in f.dims.items()] == layout['dims']
     # global attributes: names, order, values, types
     assert list(f.attrs) == [k for k, _ in layout['attrs']]
     for k, rec in layout['attrs']:
-        same_attr(f.attrs[k], rec, k)
+        same_attr(f.attrs[k], rec, k, classic)
     # variables: names and order, types, dimensions, _FillValue, attributes, data
-    assert list(f.vars) == [v['name'] for v in layout['vars']]
+    # (an HDF5 group of the old kind lists its members by name; the classic format keeps the order of creation)
+    assert (list(f.vars) if classic else sorted(f.vars)) == (lambda names: names if classic else sorted(names))([v['name'] for v in layout['vars']])
     for rec in layout['vars']:
         v = f.vars[rec['name']]
         assert v.data.dtype == np.dtype(rec['dtype']), rec['name']
@@ -96,13 +100,13 @@ def test_written_file_has_the_references_layout_and_data(case, tmp_path):
             names = ['_FillValue'] + names
         assert list(v.attrs) == names, rec['name']
         for k, a in rec['attrs']:
-            same_attr(v.attrs[k], a, rec['name'] + '.' + k)
+            same_attr(v.attrs[k], a, rec['name'] + '.' + k, classic)
         if 'var_' + rec['name'] not in z.files:
             continue                                        # crs / mcrs hold no data
         want = z['var_' + rec['name']]
         assert np.array_equal(v.data, np.asarray(want, dtype=v.data.dtype).reshape(v.data.shape), equal_nan=True), rec['name']
-    assert layout['format'] == 'NETCDF4'                    # the reference's container; here: classic, 64-bit offsets
-    assert open(path, 'rb').read(4) == b'CDF\x02'
+    assert layout['format'] == 'NETCDF4'                    # the reference's container
+    assert open(path, 'rb').read(8) == (b'CDF\x02' + open(path, 'rb').read(8)[4:] if classic else b'\x89HDF\r\n\x1a\n')
 
 
 def test_rejects_what_the_reference_rejects(tmp_path):

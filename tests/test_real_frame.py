@@ -186,13 +186,13 @@ def test_convert_driver_on_the_references_test_frame(tmp_path):
     it writes holds the reference's grid (image through Pillow, header cards parsed from the FITS file, single-pass
     pipeline, netCDF classic writer and reader)."""
     from auromat_amd.cli.convert import main
-    from auromat_amd.export import _nc3
+    from auromat_amd.export import _nc4
     z = load_golden('real_frame_iss030.npz')
     out = str(tmp_path / 'converted')
     main(['--data', os.path.join(GOLDEN, 'resources'), '--format', 'netcdf', '--resample', '--min-elevation', '10', '--grid', 'geo', '--px-per-deg', '10',
           '--out', out, '--without-mag'])
     assert os.listdir(out) == ['ISS030-E-102170_dc.nc']
-    f = _nc3.File(os.path.join(out, 'ISS030-E-102170_dc.nc'))
+    f = _nc4.open_file(os.path.join(out, 'ISS030-E-102170_dc.nc'))
     assert np.array_equal(f.vars['lat'].data, z['out_lat_c'][:, 0]) and np.array_equal(f.vars['lon'].data, z['out_lon_c'][0, :])
     mask = z['out_img_mask'][..., 0]
     for c, name in enumerate(('img_red', 'img_green', 'img_blue')):
