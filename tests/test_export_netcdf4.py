@@ -246,3 +246,56 @@ def test_export_formats_and_sizes(tmp_path):
         assert f4.vars[k].dims == v.dims, k
         assert list(f4.vars[k].attrs) == list(v.attrs), k
     assert os.path.getsize(p4) < os.path.getsize(p3) * 1.5                # (small grids: the HDF5 structures weigh in)
+
+
+@needs_h5py
+def test_random_layouts_through_the_hdf5_library(tmp_path):
+    """Forty random variables — ranks 0 to 3, every type, chunked or not, filtered or not, chunk shapes that do and do not divide
+    the array, with and without a fill value, up to a few thousand chunks — in one file: the HDF5 library and the reader here
+    return every array as it went in."""
+    from auromat_amd.export import _nc4
+    rng = np.random.RandomState(11)
+    w = _nc4.Writer()
+    sizes = dict(a=1, b=2, c=7, d=33, e=64, f=65, g=130, h=1000, i=2049)
+    for d, n in sizes.items():
+        w.create_dimension(d, n)
+    types = [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.float32, np.float64]
+    data = {}
+    for k in range(40):
+        rank = int(rng.randint(0, 4))
+        dims = tuple(str(d) for d in rng.choice(list(sizes), rank, replace=True)) if rank else ()
+        shape = tuple(sizes[d] for d in dims)
+        if int(np.prod(shape)) > 3_000_000:
+            dims, shape = dims[:2], shape[:2]
+        dt = np.dtype(types[int(rng.randint(len(types)))])
+        arr = np.asarray(rng.rand(*shape) * 200 - (0 if dt.kind == 'u' else 100)).astype(dt)
+        chunks, zlib = None, False
+        if shape and rng.rand() < 0.7:
+            zlib = bool(rng.rand() < 0.7)
+            if rng.rand() < 0.8:
+                chunks = tuple(int(rng.randint(1, n + 1)) for n in shape)
+                while int(np.prod([-(-n // c) for n, c in zip(shape, chunks)])) > 6000:
+                    chunks = tuple(min(n, c * 2) for n, c in zip(shape, chunks))
+            elif not zlib:
+                chunks = None
+        fill = dt.type(3) if rng.rand() < 0.4 else None
+        name = 'v%02d' % k
+        v = w.create_variable(name, dt, dims, fill_value=fill, zlib=zlib, chunksizes=chunks)
+        v.attrs['k'] = np.int32(k)
+        v.set(arr)
+        data[name] = (arr, dims, chunks, zlib)
+    path = str(tmp_path / 'r.nc')
+    w.write(path)
+    f = _nc4.open_file(path)
+    for name, (arr, dims, chunks, zlib) in data.items():
+        assert f.vars[name].dims == dims and np.array_equal(f.vars[name].data, arr) and f.vars[name].attrs['k'] == int(name[1:]), name
+    out = json.loads(h5(DUMP, path, str(tmp_path)))
+    for name, (arr, dims, chunks, zlib) in data.items():
+        s = out['sets'][name]
+        assert 'error' not in s, (name, s)
+        got = np.load(str(tmp_path / (name + '.npy')))
+        assert got.dtype == arr.dtype and np.array_equal(got, arr), name
+        assert s['dims'] == [['/' + d] for d in dims], name
+        assert (s['compression'] == 'gzip') == (zlib and bool(dims)), name
+        if chunks is not None:
+            assert s['chunks'] == list(chunks), name
