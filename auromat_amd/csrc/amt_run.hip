@@ -181,8 +181,9 @@ int amt_run_reset_hints(amt_run* run) {
 // ---- the loop as a state machine: begin / push (one frame at a time) / end ------------------------------------------
 // The batches in flight form a queue of at most two: when a batch of prepared frames is complete, the older launched
 // batch is finished first if two are in flight (wait for the boxes, lay out the grids, one finalise kernel), then the new
-// batch is launched.  That is the order of the loop `launch(B); prepare(C); finish(A)` with the frames arriving one by
-// one, so the first launch happens after the first frame's preparation whatever the length of the sequence.
+// batch is launched; and a frame whose slot still belongs to a frame in flight finishes that frame's batch first
+// (amt_run_push).  The frames arrive one by one, so the first launch happens after the first frame's preparation whatever
+// the length of the sequence.
 
 namespace {
 
@@ -326,10 +327,17 @@ int amt_run_push(amt_run* run, const amt_run_frame* f) {
     AMT_REQUIRE(ctx, run->n_pushed < run->max_frames, "more frames than amt_run_begin announced");
     const amt_run_config& cfg = run->cfg;
     const int k = run->n_pushed++, slot = k % cfg.n_slots;
-    if (run->full) {
-        std::memset(&run->results[k], 0, sizeof(amt_run_result));
-        run->results[k].status = 3;
-        return AMT_OK;
+    std::memset(&run->results[k], 0, sizeof(amt_run_result));
+    run->results[k].status = 3;                     // "not processed" until the frame is finished (also if this call fails)
+    if (run->full) return AMT_OK;
+    // the slot's previous frame (k - n_slots) may still be in flight: it is finished before its slot — parameters, shell,
+    // driver — takes the new frame.  (With n_slots = 2 * batch that is the batch launched before the one now running, so
+    // nothing waits that the loop `launch(B); finish(A); prepare(C)` would not wait for.)
+    while (run->n_launched > 0 && run->launched[0][0] <= k - cfg.n_slots) {
+        if (int rc = run_finish(run, run->launched[0][0], run->launched[0][1])) return rc;
+        run->launched[0][0] = run->launched[1][0], run->launched[0][1] = run->launched[1][1];
+        --run->n_launched;
+        if (run->full) return AMT_OK;
     }
     const int mag = cfg.magnetic ? 1 : 0;
     const double altitude = f->altitude > 0 ? f->altitude : cfg.altitude;

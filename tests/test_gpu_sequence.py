@@ -369,3 +369,32 @@ def test_plain_c_host_runs_a_sequence(tmp_path):
         o, cells = int(rec['grid_offset'][k]), int(rec['ny'][k]) * int(rec['nx'][k])
         assert np.array_equal(grids[o:o + 4 * cells].reshape(r['mean'].shape), r['mean'], equal_nan=True), k
         assert np.array_equal(grids[o + 4 * cells:o + 5 * cells].reshape(r['count'].shape), r['count']), k
+
+
+def test_native_runner_reports_every_frame_with_its_own_shell_and_parameters():
+    """17 frames through the library's frame loop, every one on a shell of its own (and a pole frame now and then, whose cell
+    coordinates depend on the shell): the result of frame k carries frame k's altitude, its amt_frame_params and its hint flag —
+    also when the slot of the frame is taken by a later frame before the frame is finished (slots = 2 x frames per launch)."""
+    import torch
+    from auromat_amd._native import RunResult
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.pipeline import FramePipeline, NativeResults, SequencePipeline
+    from auromat_amd.resample import grid_coordinates
+    w, h, n = 530, 354, 17
+    frames = build_sequence(w, h, n, every_pole=4)
+    feed = [(hd, c, t, torch.from_numpy(im.view(np.int16)).cuda(), 95.0 + 2.5 * k) for k, (hd, c, t, im) in enumerate(frames)]
+    seq = SequencePipeline(w, h, pxPerDeg=6, own_image_buffers=False)
+    got = seq.process(feed, keep_on_device=True)
+    assert isinstance(got, NativeResults) and seq.plans == ['single-pass'] * n
+    table = np.frombuffer(got._rec, dtype=np.dtype(RunResult))
+    single = FramePipeline(w, h)
+    for k, (hd, c, t, im) in enumerate(frames):
+        alt = 95.0 + 2.5 * k
+        assert got[k]['altitude'] == alt, (k, got[k]['altitude'])
+        p = frame_params(hd, alt, c, t, True)
+        assert np.array_equal(np.array(table['params']['cam'][k]), np.array(p.cam)) and table['params']['a'][k] == p.a, k
+        want = single.run(hd, alt, c, t, img=im, pxPerDeg=6)
+        r = host(got[k])
+        assert np.array_equal(r['mean'], want['mean'], equal_nan=True) and np.array_equal(r['count'], want['count']), k
+        cg, cw = grid_coordinates(r), grid_coordinates(want)
+        assert np.array_equal(cg['lat_c'], cw['lat_c']) and np.array_equal(cg['lon_c'], cw['lon_c']), k
