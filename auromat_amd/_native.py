@@ -74,7 +74,7 @@ class PipeResult(C.Structure):
 class RunConfig(C.Structure):
     """amt_run_config"""
     _fields_ = [(k, C.c_int32) for k in ('width', 'height', 'img_dtype', 'fast_center', 'magnetic', 'batch', 'use_hints',
-                                         'n_slots')] + \
+                                         'n_slots', 'two_pass', 'reserved_')] + \
                [(k, C.c_double) for k in ('altitude', 'min_elevation', 'lat_px_per_deg', 'lon_px_per_deg')] + \
                [('slots', C.POINTER(GeorefOut))]
 
@@ -88,7 +88,7 @@ class RunFrame(C.Structure):
 class RunResult(C.Structure):
     """amt_run_result"""
     _fields_ = [(k, C.c_int32) for k in ('status', 'slot', 'ny', 'nx', 'contains_pole', 'lon_wrapped', 'hinted',
-                                         'edge_pixels')] + \
+                                         'edge_pixels', 'two_pass', 'reserved_')] + \
                [('grid_offset', C.c_int64), ('image_offset', C.c_int64), ('bbox', C.c_double * 8), ('altitude', C.c_double),
                 ('grid', Grid), ('params', FrameParams)]
 
@@ -171,6 +171,9 @@ _SIGNATURES = {
     'amt_pipe_finalize_stream': ([_P, _P], _I),
     'amt_pipe_finalize_many': ([_P, C.c_int32, _P, _P, _P, _P], _I),
     'amt_pipe_join': ([_P], _I),
+    'amt_pipe_set_plan': ([_P, _I], _I),
+    'amt_pipe_general_layout': ([_P, C.POINTER(PipeResult)], _I),
+    'amt_pipe_general_finalize': ([_P, _P, _P, _P, _P], _I),
     'amt_frame_params_from_wcs': ([C.POINTER(RunFrame), C.c_int32, C.c_int32, C.c_int32, _D, C.c_int32,
                                    C.POINTER(FrameParams)], _I),
     'amt_run_create': ([_P, C.POINTER(RunConfig), c_void_pp], _I),

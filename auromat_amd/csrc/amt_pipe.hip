@@ -39,6 +39,15 @@ struct amt_pipe {
     int pole;
     bool pole_plan;                // this frame is binned in the coordinates rotated by 90 deg about x (bin_pole)
     int img_dtype;
+    // the two-pass plan on the driver's streams (amt_pipe_general_layout / _finalize): the frame's coordinate arrays, image
+    // and size as the big kernel was given them
+    bool two_pass;                 // amt_pipe_set_plan: never fuse the binning into the big kernel
+    bool general_ready;            // amt_pipe_general_layout has laid out the exact grid of the frame in flight
+    const double* g_lat_c;
+    const double* g_lon_c;
+    const double* g_elev;
+    const void* g_img;
+    int g_width, g_height, g_fast, g_mode;      // g_mode: 0 geodetic grid without a pole in view (see pipe_prepare's mode)
 };
 
 namespace {
@@ -288,7 +297,9 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
         // wait packet between two big kernels lengthens their boundary by 3-4 us (kernel trace: 27 us per boundary
         // with three of them, 15-16 us with none)
         bool done = hipEventQuery(pipe->tail_done) == hipSuccess;
-        if (!done) {
+        // (two-pass plan: what the buffer waits for is its previous frame's binning pass, a kernel as long as the big one —
+        // the wait goes on the stream at once)
+        if (!done && !pipe->two_pass) {
             const auto t0 = std::chrono::steady_clock::now();
             while (!done && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(150))
                 done = hipEventQuery(pipe->tail_done) == hipSuccess;
@@ -319,9 +330,12 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
         o.item_order = (ax | ay) == 0 ? 0 : ((ay >= ax && sy > 0) ? 2 : 1);
     }
 
+    pipe->g_lat_c = out->lat_c, pipe->g_lon_c = out->lon_c, pipe->g_elev = out->elev, pipe->g_img = img;
+    pipe->g_width = p->width, pipe->g_height = p->height, pipe->g_fast = p->fast_center, pipe->g_mode = mode;
+    pipe->general_ready = false;
     // coarse [lat_min, lat_max, lon_min, lon_max, lon_min_positive, lon_max_nonpositive, n, hint]
     const double* c = pipe->host_small;
-    bool fuse = c[6] > 0 && (!pipe->pole || pipe->pole_plan);
+    bool fuse = !pipe->two_pass && c[6] > 0 && (!pipe->pole || pipe->pole_plan);
     pipe->lon_wrap = 0;
     double box_lo = c[2], box_hi = c[3];
     if (fuse && pipe->pole_plan && c[3] - c[2] > 180) fuse = false;      // (cannot happen: the rotated frame sits at the equator)
@@ -558,6 +572,70 @@ int amt_pipe_finalize_many(amt_pipe* const* pipes, int32_t n, double* const* mea
         AMT_HIP(ctx, hipEventRecord(pipe->tail_done, pipe->fin_stream));
         pipe->tail_pending = true;
     }
+    return AMT_OK;
+}
+
+int amt_pipe_set_plan(amt_pipe* pipe, int two_pass) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    pipe->two_pass = two_pass != 0;
+    return AMT_OK;
+}
+
+int amt_pipe_general_layout(amt_pipe* pipe, amt_pipe_result* result) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipe->ctx;
+    AMT_REQUIRE(ctx, result != nullptr, "result is NULL");
+    pipe->general_ready = false;
+    if (result->status != 1) return AMT_OK;
+    // what the kernels of this path do not cover stays with the caller: a pole in view (binned in rotated coordinates),
+    // exact centres (their masks are reconciled first), MLat / MLT grids, frames whose coordinate arrays were not written
+    if (pipe->pole || !pipe->g_fast || pipe->g_mode != 0 || !pipe->g_lat_c || !pipe->g_lon_c || !pipe->g_elev) return AMT_OK;
+    const double* b = result->bbox;
+    if (!(b[6] > 0)) return AMT_OK;
+    // BaseMapping.boundingBox + the date-line branch of _resample (reference mapping.py:711-741, resample.py:203-218)
+    const bool straddles = b[3] - b[2] > 180;
+    double lon_lo = b[2], lon_hi = b[3];
+    if (straddles) {
+        if (!(std::isfinite(b[4]) && std::isfinite(b[5]))) return AMT_OK;
+        lon_lo = wrap_at_180(b[4] + 180.0);
+        lon_hi = wrap_at_180(b[5] + 180.0);
+    }
+    amt_grid g;
+    if (!amt_gl::layout(pipe->lat_ppd, pipe->lon_ppd, b[0], b[1], lon_lo, lon_hi, &g)) return AMT_OK;
+    if (g.nx >= 65535 || g.ny >= 65535) return AMT_OK;
+    result->grid = g;
+    result->lon_wrapped = straddles ? 1 : 0;
+    result->status = 0;
+    pipe->exact = g;
+    pipe->lon_wrap = straddles ? 1 : 0;
+    pipe->general_ready = true;
+    return AMT_OK;
+}
+
+int amt_pipe_general_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_mask, double* out_count) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipe->ctx;
+    AMT_REQUIRE(ctx, pipe->general_ready, "amt_pipe_general_layout has not laid out this frame");
+    AMT_REQUIRE(ctx, mean && out_img && out_mask && out_count, "NULL argument");
+    pipe->general_ready = false;
+    const amt_grid& g = pipe->exact;
+    const size_t cells = (size_t)g.nx * g.ny;
+    if (int rc = ensure_acc(pipe, cells)) return rc;
+    // The binning pass and the finalise kernel go on the context's stream, IN LINE with the big kernels (behind this frame's,
+    // which has finished: the host has its box; in a sequence behind the next frame's, which is running or queued).  Beside
+    // a big kernel — on the finalise stream — the two slow each other down by more than they overlap (kernel trace of a
+    // two-pass sequence: binning 82 -> 190-240 us, big kernel 118 -> 140-245 us; profiles/r3/x_two_pass_timeline.txt).
+    hipStream_t fs = ctx->stream;
+    AMT_HIP(ctx, hipMemsetAsync(pipe->acc, 0, cells * 5 * sizeof(uint64_t), fs));
+    int rc = amt_bin_frame(ctx, pipe->g_lat_c, pipe->g_lon_c, pipe->g_elev, pipe->g_img, pipe->img_dtype, 3, nullptr, pipe->g_height,
+                           pipe->g_width, pipe->min_elev, &g.xaxis, &g.yaxis, pipe->lon_wrap, pipe->acc);
+    if (rc != AMT_OK) return rc;
+    rc = amt_bin_finalize_on(ctx, fs, pipe->acc, g.nx, g.ny, 0, 0, g.nx, g.ny, 3, pipe->img_dtype, mean, out_img, out_mask,
+                             out_count, 0);
+    if (rc != AMT_OK) return rc;
+    pipe->acc_zero = false;
+    AMT_HIP(ctx, hipEventRecord(pipe->tail_done, fs));
+    pipe->tail_pending = true;
     return AMT_OK;
 }
 

@@ -148,7 +148,8 @@ int amt_run_create(amt_ctx* ctx, const amt_run_config* config, amt_run** out_run
         return AMT_EHIP;
     }
     for (int i = 0; i < ns; ++i) {
-        const int rc = amt_pipe_create(ctx, &run->pipes[i]);
+        int rc = amt_pipe_create(ctx, &run->pipes[i]);
+        if (rc == AMT_OK) rc = amt_pipe_set_plan(run->pipes[i], config->two_pass);
         if (rc != AMT_OK) {
             amt_run_destroy(run);
             return rc;
@@ -208,7 +209,14 @@ int run_finish(amt_run* run, int k0, int count) {
         r.params = run->prm[slot];
         amt_pipe_result pr;
         if (int rc = amt_pipe_wait(run->pipes[slot], &pr)) return rc;
+        bool general = false;
+        if (pr.status == 1) {
+            // the two-pass plan, natively, when the frame's coordinate arrays exist and nothing else is needed
+            if (int rc = amt_pipe_general_layout(run->pipes[slot], &pr)) return rc;
+            general = pr.status == 0;
+        }
         r.status = pr.status;
+        r.two_pass = general ? 1 : 0;
         std::memcpy(r.bbox, pr.bbox, sizeof(r.bbox));
         r.edge_pixels = pr.edge_pixels;
         if (pr.status != 0) {
@@ -230,12 +238,16 @@ int run_finish(amt_run* run, int k0, int count) {
         r.grid = pr.grid;
         r.grid_offset = run->grid_used;
         r.image_offset = run->image_used;
-        pp[m] = run->pipes[slot];
-        mean[m] = run->grids + run->grid_used;
-        ocount[m] = run->grids + run->grid_used + 4 * cells;
-        oimg[m] = run->images + run->image_used;
-        omask[m] = reinterpret_cast<uint8_t*>(run->images + run->image_used + cells * 3 * (cfg.img_dtype == 2 ? 2 : 1));
-        ++m;
+        double* f_mean = run->grids + run->grid_used;
+        void* f_img = run->images + run->image_used;
+        uint8_t* f_mask = reinterpret_cast<uint8_t*>(run->images + run->image_used + cells * 3 * (cfg.img_dtype == 2 ? 2 : 1));
+        if (general) {
+            if (int rc = amt_pipe_general_finalize(run->pipes[slot], f_mean, f_img, f_mask, f_mean + 4 * cells)) return rc;
+        } else {
+            pp[m] = run->pipes[slot];
+            mean[m] = f_mean, ocount[m] = f_mean + 4 * cells, oimg[m] = f_img, omask[m] = f_mask;
+            ++m;
+        }
         run->grid_used += 5 * cells;
         run->image_used += ib;
         run->prev = run->last;

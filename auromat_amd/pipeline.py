@@ -743,7 +743,9 @@ class SequencePipeline(object):
         self.single_pass = plan == 'single-pass' and nchan == 3
         self.magnetic = bool(magnetic)          # grids in (MLat, SM longitude): resampleMLatMLT
         # single-pass plan: `batch` frames share one launch of the big kernel (amt_pipe_launch_many; batch frames in
-        # flight + batch being prepared = 2 * batch buffers).  The 14-17 us between two launches on a stream are
+        # flight + batch being prepared = 2 * batch buffers).  Two-pass plan: one frame per launch and four buffers — a
+        # buffer's binning pass, which runs beside the NEXT frame's big kernel, must be over before the buffer's next frame
+        # starts, and with four that pass was enqueued two frames earlier.  The 14-17 us between two launches on a stream are
         # paid once per batch and the end of a launch is better filled: 0.207 -> 0.200 -> 0.198 ms per frame for
         # 1, 2, 3 frames per launch.
         self.batch = max(1, min(int(batch), 3)) if self.single_pass else 1
@@ -753,7 +755,7 @@ class SequencePipeline(object):
         self.pipes = [FramePipeline(width, height, nchan, img_dtype, device, with_mag=self.magnetic,
                                     alloc_image=own_image_buffers and (shared_image is None or i == 0),
                                     alloc_coords=keep_coordinates or not self.single_pass)
-                      for i in range(2 * self.batch)]
+                      for i in range(2 * self.batch if self.single_pass else 4)]
         self.ctx = self.pipes[0].ctx
         if shared_image is not None:
             # every frame shows the same image (synthetic benchmarks): upload it once, both buffers alias it
@@ -949,10 +951,13 @@ class SequencePipeline(object):
 
     # ---- the frame loop in the library (amt_run_*, include/auromat_hip.h "native sequence runner") --------------------
     def _native_applies(self, frames):
-        """Device-resident images, header dicts, one launch stream, the single-pass plan: what amt_run_process covers."""
-        if not (self.single_pass and self.s_alt is None and frames):
-            return False
+        """Device-resident images, header dicts, one launch stream; the single-pass plan or, for RGB frames with fast centres on
+        a geodetic grid, the two-pass plan: what amt_run_process covers."""
         q = self.pipes[0]
+        two_pass_ok = (not self.single_pass and q.fd.nchan == 3 and self.fast and not self.magnetic and
+                       os.environ.get('AMT_SEQ_NATIVE_TWO_PASS', '1') != '0')
+        if not ((self.single_pass or two_pass_ok) and self.s_alt is None and frames):
+            return False
         return all(isinstance(f[0], dict) and q.is_resident_image(f[3]) for f in frames)
 
     def _runner(self):
@@ -964,7 +969,7 @@ class SequencePipeline(object):
             q = self.pipes[0]
             cfg = RunConfig(width=q.width, height=q.height, img_dtype=1 if q.fd.img_dtype == np.uint8 else 2, fast_center=1 if self.fast else 0,
                             magnetic=1 if self.magnetic else 0, batch=self.batch, use_hints=1 if self.use_hints else 0,
-                            n_slots=nb, altitude=float(self.altitude),
+                            n_slots=nb, two_pass=0 if self.single_pass else 1, altitude=float(self.altitude),
                             min_elevation=NEG_INF if self.min_elevation is None else float(self.min_elevation),
                             lat_px_per_deg=float(self.pxPerDeg[0]), lon_px_per_deg=float(self.pxPerDeg[1]), slots=slots)
             handle = C.c_void_p()
@@ -1055,13 +1060,13 @@ class SequencePipeline(object):
         fallbacks = {}
         max_cells = int((table['ny'].astype(np.int64) * table['nx']).max()) if n else 1
         names = {0: 'single-pass', 2: 'empty'}
-        if not status.any():
+        if not status.any() and not table['two_pass'].any():
             self.plans.extend(['single-pass'] * n)
         else:
             for k in range(n):
                 st = int(status[k])
                 if st in names:
-                    self.plans.append(names[st])
+                    self.plans.append('two-pass' if st == 0 and table['two_pass'][k] else names[st])
                     continue
                 f = frames[k]
                 q = self.pipes[0]

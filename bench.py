@@ -579,8 +579,8 @@ def main(argv=None):
                        # untimed frames run before the W warm-up steps to bring the chip to its sustained state
                        'spinup_frames_untimed': run['spinup_frames'], 'spinup_ms': args.spinup_ms,
                        'parallelism': 'frames sharded over %d GPU(s), %s gather of grids' % (world, 'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'),
-                       'frame_loop': 'library (amt_run_*)' if getattr(seq, 'native', False) and args.plan == 'fused' and not args.upload
-                       else 'python',
+                       'frame_loop': 'library (amt_run_*)' if getattr(seq, 'native', False) and not args.upload and
+                       (args.plan == 'fused' or (fast and not args.magnetic)) else 'python',
                        # transparency: rows of work items whose waves write NaN without casting rays, because the host has
                        # bounded the limb (a conic section in the image) and no ray of them can hit the shell; every
                        # output array is still written in full and is identical to the ray-cast result

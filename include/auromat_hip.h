@@ -556,6 +556,17 @@ int amt_pipe_finalize_stream(amt_pipe* pipe, void** stream);
 /* Orders the context's stream behind the last amt_pipe_finalize (no-op when it already completed): call it
  * before work on the context's stream — or, after amt_ctx_synchronize, the host — reads the outputs. */
 int amt_pipe_join(amt_pipe* pipe);
+/* The two-pass plan on the driver's streams, for frames amt_pipe_wait hands back with status 1 and for sequences that ask for
+ * it (reference resample.py:159-279 as two steps: the coordinate arrays, then `_resampleCenterData`):
+ *   amt_pipe_set_plan(pipe, 1)     the big kernel never bins (it writes the coordinate arrays of amt_georef_out and the box);
+ *   amt_pipe_general_layout        after amt_pipe_wait: lays out the exact grid from the frame's box — result->grid,
+ *                                  lon_wrapped, status 0 — unless the frame needs what only the caller has (a pole in view,
+ *                                  exact centres, an MLat / MLT grid, no coordinate arrays): then status stays 1;
+ *   amt_pipe_general_finalize      zeroes the accumulators, bins the frame's arrays (amt_bin_frame) and finalises into the
+ *                                  caller's arrays (sized from result->grid), on the context's stream. */
+int amt_pipe_set_plan(amt_pipe* pipe, int two_pass);
+int amt_pipe_general_layout(amt_pipe* pipe, amt_pipe_result* result);
+int amt_pipe_general_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8_t* out_mask, double* out_count);
 
 /* ---- native sequence runner ---------------------------------------------------------------------------------------
  * The per-frame loop of a sequence (reference mapping/spacecraft.py:326-332 `map(getMapping, ...)` followed by
@@ -567,8 +578,9 @@ int amt_pipe_join(amt_pipe* pipe);
  * Results: frame k's mean (ny, nx, 4) and count (ny, nx) lie one after the other at grids + grid_offset — consecutive
  * frames back to back, which is the payload of the gather's wire format (amt_seq_pack) without a copy —, its rounded
  * image (ny, nx, 3) and mask (ny, nx) at images + image_offset (256-byte aligned).
- * status per frame: 0 done; 1 the frame needs the general path (see amt_pipe_result; nothing of it is in the arenas; its
- * per-pixel arrays are in its slot unless a later frame has taken the slot); 2 no pixel above the elevation threshold;
+ * status per frame: 0 done (two_pass = 1: by the two-pass plan, which frames the single-pass plan hands back take when their
+ * slot has coordinate arrays); 1 the frame needs the caller's general path (a pole in view that the pole plan does not cover,
+ * ...; nothing of it is in the arenas); 2 no pixel above the elevation threshold;
  * 3 the arenas are full (this and the later frames were not processed). */
 typedef struct amt_run amt_run;
 typedef struct amt_run_config {
@@ -579,6 +591,8 @@ typedef struct amt_run_config {
     int32_t batch;                /* frames per launch, 1 .. AMT_PIPE_MAX_BATCH */
     int32_t use_hints;            /* 0: coarse pre-pass for every frame */
     int32_t n_slots;              /* frame slots, >= 2 * batch */
+    int32_t two_pass;             /* 1: the two-pass plan for every frame (needs the slots' lat_c / lon_c / elev arrays) */
+    int32_t reserved_;
     double altitude;              /* mapping shell [km] of frames that name none */
     double min_elevation;         /* maskedByElevation; -inf disables */
     double lat_px_per_deg, lon_px_per_deg;
@@ -599,6 +613,8 @@ typedef struct amt_run_result {
     int32_t lon_wrapped;          /* grid laid out in longitudes shifted by 180 deg (resample.py:203-218) */
     int32_t hinted;               /* 1: no coarse pre-pass ran for this frame */
     int32_t edge_pixels;
+    int32_t two_pass;             /* 1: binned by the separate pass (amt_pipe_general_*), 0: by the fused kernel */
+    int32_t reserved_;
     int64_t grid_offset;          /* doubles */
     int64_t image_offset;         /* bytes */
     double bbox[8];               /* amt_pipe_result.bbox */
