@@ -10,6 +10,7 @@ run python tools/fuzz_ops.py 800 $S
 run python tools/fuzz_sequence.py 80 $S
 run python tools/fuzz_mapping.py 800 $S
 run python tools/fuzz_cubic.py 100 $S
+METHOD=linear run python tools/fuzz_cubic.py 100 $S
 PIN=1 run python tools/stress_sequence.py 300 530 354
 run python tools/stress_params.py
 exit $rc

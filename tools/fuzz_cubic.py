@@ -2,7 +2,7 @@
 CloughTocher2DInterpolator: random sheared / stretched / gently warped lattices (unambiguous Delaunay diagonals), smooth and noisy
 channels, optional holes in the footprint.  Away from the hull and from holes the two must agree to the solvers' tolerances; next
 to them scipy's triangles differ (Qhull spans holes) and only finiteness is asked for.
-usage: fuzz_cubic.py [rounds] [seed]"""
+usage: fuzz_cubic.py [rounds] [seed]      (METHOD=linear: the same against scipy's LinearNDInterpolator, to 1e-9)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +12,8 @@ from auromat_amd.resample import _resample
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+method = os.environ.get('METHOD', 'cubic')
+limit = 5e-5 if method == 'cubic' else 1e-9
 fails = 0
 worst = 0.0
 compared = cells = 0
@@ -35,7 +37,9 @@ for it in range(rounds):
     lo[~valid] = np.nan
     d[~valid] = np.nan
     pts = np.column_stack((lat[valid], lon[valid]))
-    ref = scipy.interpolate.CloughTocher2DInterpolator(scipy.spatial.Delaunay(pts), data[valid], tol=1e-10, maxiter=4000)
+    tri_ = scipy.spatial.Delaunay(pts)
+    ref = scipy.interpolate.CloughTocher2DInterpolator(tri_, data[valid], tol=1e-10, maxiter=4000) if method == 'cubic' else \
+        scipy.interpolate.LinearNDInterpolator(tri_, data[valid])
     # targets: a grid over the middle of the footprint
     m = 10
     box = BoundingBox(lat[m, m] + step, min(lon[m, m], lon[h - m, m]) + step * aspect, lat[h - m, w - m] - step,
@@ -45,7 +49,7 @@ for it in range(rounds):
     ppd = (round(2.0 / step), round(2.0 / (step * aspect)))
     outline = np.array([[lat[0, 0], lon[0, 0]], [lat[0, -1], lon[0, -1]], [lat[-1, -1], lon[-1, -1]], [lat[-1, 0], lon[-1, 0]]])
     try:
-        _, _, lat_c, lon_c, out = _resample(la, lo, 110.0, d, lambda: outline, box, ppd, False, False, method='cubic')
+        _, _, lat_c, lon_c, out = _resample(la, lo, 110.0, d, lambda: outline, box, ppd, False, False, method=method)
     except AssertionError as e:
         if 'nLon' in str(e) or 'nLat' in str(e) or 'nlon' in str(e) or 'nlat' in str(e):
             continue
@@ -71,12 +75,12 @@ for it in range(rounds):
             bad = True
         rel = (np.abs(out - want)[deep & got_ok] / span).max() if (deep & got_ok).any() else 0.0
         worst = max(worst, rel)
-        if rel > 5e-5:
+        if rel > limit:
             print('round', it, 'h w', h, w, 'shear %.2f aspect %.2f hole %s: max relative difference %.2e' % (shear, aspect, hole, rel))
             bad = True
     if not np.isfinite(out[got_ok]).all():
         print('round', it, 'non-finite values')
         bad = True
     fails += bad
-print('rounds', rounds, 'compared', compared, 'cells', cells, 'failures', fails, 'worst relative difference deep inside %.2e' % worst)
+print(method, 'rounds', rounds, 'compared', compared, 'cells', cells, 'failures', fails, 'worst relative difference deep inside %.2e' % worst)
 sys.exit(1 if fails else 0)
