@@ -741,6 +741,7 @@ class SequencePipeline(object):
         self.pxPerDeg = tuple(pxPerDeg)
         self.altitude, self.fast, self.min_elevation = altitude, fast, min_elevation
         self.single_pass = plan == 'single-pass' and nchan == 3
+        self.nchan = nchan
         self.magnetic = bool(magnetic)          # grids in (MLat, SM longitude): resampleMLatMLT
         # single-pass plan: `batch` frames share one launch of the big kernel (amt_pipe_launch_many; batch frames in
         # flight + batch being prepared = 2 * batch buffers).  Two-pass plan: one frame per launch and four buffers — a
@@ -954,7 +955,7 @@ class SequencePipeline(object):
         """Device-resident images, header dicts, one launch stream; the single-pass plan or, for RGB frames with fast centres on
         a geodetic grid, the two-pass plan: what amt_run_process covers."""
         q = self.pipes[0]
-        two_pass_ok = (not self.single_pass and q.fd.nchan == 3 and self.fast and not self.magnetic and
+        two_pass_ok = (not self.single_pass and self.nchan == 3 and self.fast and not self.magnetic and
                        os.environ.get('AMT_SEQ_NATIVE_TWO_PASS', '1') != '0')
         if not ((self.single_pass or two_pass_ok) and self.s_alt is None and frames):
             return False

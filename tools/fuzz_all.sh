@@ -8,6 +8,7 @@ run python tools/fuzz_frames.py 800 $S
 run python tools/fuzz_widened.py 800 $S
 run python tools/fuzz_ops.py 800 $S
 run python tools/fuzz_sequence.py 80 $S
+RESIDENT=1 run python tools/fuzz_sequence.py 80 $S
 run python tools/fuzz_mapping.py 800 $S
 run python tools/fuzz_cubic.py 100 $S
 METHOD=linear run python tools/fuzz_cubic.py 100 $S

@@ -1,6 +1,8 @@
 """Sequence fuzz: frames that do NOT follow each other smoothly (random pointings, times up to 95 min apart — date-line
 and pole frames included —, jumps back and forth, repeated frames) through SequencePipeline with every plan / batch
-size and hints on, against one frame at a time.  usage: fuzz_sequence.py [sequences] [seed]"""
+size and hints on, against one frame at a time.  usage: fuzz_sequence.py [sequences] [seed]
+RESIDENT=1: the images are device tensors, which sends the sequence through the frame loop in the library (amt_run_*: the
+single-pass plan, its hand-backs and the two-pass plan natively) instead of the Python loop."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +13,7 @@ nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 w, h = 250, 168
 bad = 0
+native = 0
 for s in range(nseq):
     frames = random_sequence(rng, w, h)
     n = len(frames)
@@ -23,7 +26,13 @@ for s in range(nseq):
         # the production mode: nothing synchronises between frames, results come to the host after process() returns
         import torch
         from auromat_amd.resample import grid_coordinates
-        out = seq.process(frames, keep_on_device=True)
+        feed = frames
+        if os.environ.get('RESIDENT'):
+            feed = [(hd, cam, t, torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img).cuda()) for hd, cam, t, img in frames]
+            seq = SequencePipeline(w, h, pxPerDeg=ppd, plan=plan, batch=batch, magnetic=magnetic, own_image_buffers=False,
+                                   img_dtype=frames[0][3].dtype)
+        out = seq.process(feed, keep_on_device=True)
+        native += type(out).__name__ == 'NativeResults'
         out = [dict({key: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for key, v in r.items()}, **grid_coordinates(r))
                for r in out]
         for i, (a, b) in enumerate(zip(out, ref)):
@@ -37,5 +46,5 @@ for s in range(nseq):
                           'cells differing', int((~np.isclose(x, b[key], equal_nan=True)).sum()) if x.shape == b[key].shape else -1,
                           'plans', seq.plans)
                     break
-print('sequences', nseq, 'failures', bad)
+print('sequences', nseq, 'through the library loop', native, 'of', 4 * nseq, 'runs; failures', bad)
 sys.exit(1 if bad else 0)
