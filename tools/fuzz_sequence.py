@@ -19,8 +19,12 @@ for s in range(nseq):
     n = len(frames)
     magnetic = bool(rng.randint(2))
     ppd = float(rng.choice([4, 8, 10]))
+    # a shell of its own for every frame (the altitude travels with the frame through the loop, and a pole frame's cell
+    # coordinates depend on it)
+    alts = [float(a) for a in rng.choice([95.0, 100.0, 110.0, 117.5, 120.0], n)]
     ref_pipe = FramePipeline(w, h, with_mag=magnetic)
-    ref = [ref_pipe.run(hd, 110, cam, t, img=img, pxPerDeg=ppd, magnetic=magnetic) for hd, cam, t, img in frames]
+    ref = [ref_pipe.run(hd, alt, cam, t, img=img, pxPerDeg=ppd, magnetic=magnetic) for (hd, cam, t, img), alt in zip(frames, alts)]
+    frames = [f + (alt,) for f, alt in zip(frames, alts)]
     for plan, batch in (('single-pass', 1), ('single-pass', 2), ('single-pass', 3), ('two-pass', 1)):
         seq = SequencePipeline(w, h, pxPerDeg=ppd, plan=plan, batch=batch, magnetic=magnetic)
         # the production mode: nothing synchronises between frames, results come to the host after process() returns
@@ -28,7 +32,8 @@ for s in range(nseq):
         from auromat_amd.resample import grid_coordinates
         feed = frames
         if os.environ.get('RESIDENT'):
-            feed = [(hd, cam, t, torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img).cuda()) for hd, cam, t, img in frames]
+            feed = [(hd, cam, t, torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img).cuda()) for hd, cam, t, img, alt in frames]
+            feed = [f + (alt,) for f, alt in zip(feed, alts)]
             seq = SequencePipeline(w, h, pxPerDeg=ppd, plan=plan, batch=batch, magnetic=magnetic, own_image_buffers=False,
                                    img_dtype=frames[0][3].dtype)
         out = seq.process(feed, keep_on_device=True)
