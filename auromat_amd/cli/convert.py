@@ -260,8 +260,10 @@ def convert_with_pipeline(args, frames, export):
                     print('The file', path, 'already exists.\nPlease use --skip or --overwrite, or a different output folder.',
                           file=sys.stderr)
                     sys.exit(1)
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group('nccl')
+        # (AMT_CONVERT_ONE_GPU=1 AMT_CONVERT_BACKEND=gloo: several ranks on one GPU, for rehearsals — the ranks only meet in the
+        # closing barrier)
+        torch.cuda.set_device(0 if os.environ.get('AMT_CONVERT_ONE_GPU') else int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group(os.environ.get('AMT_CONVERT_BACKEND', 'nccl'))
         rank, world = dist.get_rank(), dist.get_world_size()
     todo = []
     for identifier, hdr, img_path in [frames[k] for k in shard(len(frames), rank, world)]:

@@ -10,6 +10,8 @@ import numpy as np
 import numpy.ma as ma
 import pytest
 
+from conftest import ROOT
+
 
 def write_frames(tmp_path, n=3, w=256, h=170):
     from auromat_amd.synthetic import frame_image, sequence_frame
@@ -150,3 +152,37 @@ def test_image_files_next_to_the_header(tmp_path):
         json.dump(hdr, fp)
     frames = list_frames(d)
     assert [f[0] for f in frames] == ['a'] and frames[0][2].endswith('a.png')
+
+
+@pytest.mark.gpu
+def test_convert_under_a_launcher_with_two_ranks(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m auromat_amd.cli.convert ... --px-per-deg 8`: every rank converts and
+    writes its share of the frames (rehearsed on the one GPU: both ranks on cuda:0, the closing barrier through gloo); the files
+    equal those of a single process; a second run without --skip / --overwrite leaves on every rank before the group exists."""
+    import socket
+    import subprocess
+    import sys
+    from auromat_amd.cli.convert import main
+    from auromat_amd.export import _nc4
+    d = write_frames(tmp_path)
+    single, multi = str(tmp_path / 'single'), str(tmp_path / 'multi')
+    flags = ['--data', d, '--format', 'netcdf', '--resample', '--min-elevation', '10', '--grid', 'geo', '--px-per-deg', '8']
+    main(flags + ['--out', single])
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(AMT_CONVERT_ONE_GPU='1', AMT_CONVERT_BACKEND='gloo', PYTHONPATH=os.pathsep.join([ROOT, env.get('PYTHONPATH', '')]))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), '-m', 'auromat_amd.cli.convert'] + flags + ['--out', multi]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert sorted(os.listdir(multi)) == sorted(os.listdir(single)) == ['frame00.nc', 'frame01.nc', 'frame02.nc']
+    for name in os.listdir(single):
+        a, b = _nc4.open_file(os.path.join(single, name)), _nc4.open_file(os.path.join(multi, name))
+        assert list(a.vars) == list(b.vars)
+        for k, v in a.vars.items():
+            assert np.array_equal(v.data, b.vars[k].data, equal_nan=True), (name, k)
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert res.returncode != 0 and 'already exists' in res.stderr
