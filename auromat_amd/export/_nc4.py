@@ -573,8 +573,10 @@ class File(object):
 
     def _dataset(self, name, address):
         buf = self.buf
-        shape, dt, layout, filters, attrs, dimlist = (), None, None, [], OrderedDict(), None
+        shape, dt, layout, filters, attrs, dimlist, fill = (), None, None, [], OrderedDict(), None, None
         for t, pos, size in self._messages(address):
+            if t == 0x0005 and buf[pos] in (1, 2) and (buf[pos] == 1 or buf[pos + 3]):
+                fill = (pos + 8, struct.unpack_from('<I', buf, pos + 4)[0])          # (position, size) of the fill value
             if t == 0x0001:
                 rank = buf[pos + 1]
                 shape = tuple(struct.unpack_from('<%dQ' % rank, buf, pos + 8)) if rank else ()
@@ -613,7 +615,10 @@ class File(object):
             data = np.frombuffer(buf, dt, n, layout[1]).reshape(shape)
         else:
             chunk = tuple(layout[2][:-1])
-            data = np.empty(shape, dt)
+            # (chunks that were never written read as the fill value)
+            data = np.zeros(shape, dt)
+            if fill is not None and fill[1] == dt.itemsize:
+                data[...] = np.frombuffer(buf, dt, 1, fill[0])[0]
             self._read_chunks(layout[1], len(shape), chunk, dt, filters, data)
         if data is not None:
             data = data.astype(dt.newbyteorder('='))

@@ -200,6 +200,8 @@ with h5py.File(sys.argv[1], 'w') as f:
     da = f.create_dataset('a', data=a, chunks=(7, 40), compression='gzip', compression_opts=6, shuffle=True)
     db = f.create_dataset('b', data=b, chunks=(64, 16), compression='gzip')
     dc = f.create_dataset('c', data=np.float64([1.5, 2.5]))
+    dp = f.create_dataset('p', shape=(100, 8), dtype='i4', chunks=(10, 8), compression='gzip', fillvalue=-7)
+    dp[20:30] = np.arange(80, dtype=np.int32).reshape(10, 8)          # one chunk of ten is ever written
     da.attrs['units'] = np.string_('m'); da.attrs['range'] = np.float64([0, 1])
     for ds in (da, db):
         ds.dims[0].attach_scale(y); ds.dims[1].attach_scale(x)
@@ -210,6 +212,8 @@ with h5py.File(sys.argv[1], 'w') as f:
     assert f.vars['a'].attrs['units'] == 'm' and f.vars['a'].attrs['range'].tolist() == [0.0, 1.0]
     assert f.vars['a'].dims == ('y', 'x') and f.vars['b'].dims == ('y', 'x')
     assert np.array_equal(f.vars['y'].data, np.arange(300, dtype=np.float32))               # a coordinate variable
+    p = f.vars['p'].data
+    assert np.array_equal(p[20:30], np.arange(80).reshape(10, 8)) and (p[:20] == -7).all() and (p[30:] == -7).all()
 
 
 def test_files_of_the_netcdf_library_are_refused_with_a_reason(tmp_path):
