@@ -93,7 +93,7 @@ class RunResult(C.Structure):
                 ('grid', Grid), ('params', FrameParams)]
 
 
-ABI_VERSION = 3          # include/auromat_hip.h AMT_ABI_VERSION
+ABI_VERSION = 4          # include/auromat_hip.h AMT_ABI_VERSION
 _I, _L, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p
 _SIGNATURES = {
     'amt_abi_version': ([], _I),
@@ -115,6 +115,7 @@ _SIGNATURES = {
     'amt_event_elapsed_ms': ([_P, _P, _P, C.POINTER(C.c_float)], _I),
     'amt_timing_enable': ([_P, _I], _I),
     'amt_timing_read': ([_P, _I, C.POINTER(C.c_double), C.POINTER(_I)], _I),
+    'amt_georef_last_variant': ([_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], _I),
     'amt_directions_tan': ([_P, C.POINTER(FrameParams), _I, _P], _I),
     'amt_directions_tan_points': ([_P, C.POINTER(FrameParams), _P, _P, _L, _I, _P], _I),
     'amt_intersect_ellipsoid': ([_P, _D, _D, c_double_p, _P, _L, _I, _P], _I),
@@ -352,6 +353,12 @@ class Context(object):
         ms, n = C.c_double(), C.c_int()
         self.call('amt_timing_read', kernel, C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+    def last_variant(self):
+        """(second, bin, frames) of the latest launch of the frame kernel: amt_georef_last_variant."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self.call('amt_georef_last_variant', C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
 
     # -- events -------------------------------------------------------------------------------
     def event(self):

@@ -34,6 +34,7 @@ struct amt_ctx {
     // are served in order, so a kernel can get stuck behind another stream's wait
     hipStream_t aux_pre, aux_tail, aux_fin;     // coarse pre-pass | folds behind a big kernel | crop/finalise
     // optional per-kernel timing (amt_timing_*): event pairs recorded around the dominant kernels
+    int last_second, last_bin, last_frames;     // amt_georef_last_variant
     int timing;                       // 0 = off, n = bracket every n-th launch of each kind
     size_t tlaunch[2];                // launches seen per kind since timing was enabled
     int tframes[2];                   // frames covered by the timed launches

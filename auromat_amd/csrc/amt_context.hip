@@ -17,6 +17,7 @@ int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ct
     ctx->owns_stream = false;
     ctx->scratch = nullptr;
     ctx->timing = 0;
+    ctx->last_second = ctx->last_bin = ctx->last_frames = -1;
     ctx->aux_pre = ctx->aux_tail = ctx->aux_fin = nullptr;
     ctx->tlaunch[0] = ctx->tlaunch[1] = 0;
     ctx->tframes[0] = ctx->tframes[1] = 0;
@@ -195,6 +196,13 @@ int amt_timing_read(amt_ctx* ctx, int kernel, double* total_ms, int* launches) {
     }
     *total_ms = sum;
     *launches = ctx->tframes[kernel];     // frames: a launch of the frame driver can cover more than one
+    return AMT_OK;
+}
+
+int amt_georef_last_variant(amt_ctx* ctx, int32_t* second, int32_t* bin, int32_t* frames) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, second && bin && frames, "NULL argument");
+    *second = ctx->last_second, *bin = ctx->last_bin, *frames = ctx->last_frames;
     return AMT_OK;
 }
 

@@ -469,6 +469,14 @@ constexpr int kBinW = 8, kBinCells = kBinW * kBinW;
 #ifndef AMT_ROWS_MIN_WAVES_POLE
 #define AMT_ROWS_MIN_WAVES_POLE 3       // the pole variants need ~150 VGPRs; at 4 waves (128) they spill 40
 #endif
+// SECOND = 4, "MLat / MLT only": what resampleMLatMLT consumes and nothing else (reference resample.py:63-71,
+// mapping.py:1519-1547: mLatMlt, mLatMltCenter, elevation, image) — ray -> shell -> SM rotation -> (MLat, SM longitude)
+// small angles -> elevation -> bin on the (MLat, SM longitude) grid.  No Bowring step, no geodetic small angles, no geodetic
+// box, no lat / lon / lat_c / lon_c stores (those outputs must be NULL); MLat / MLT / elevation come out bit-identical to
+// SECOND = 1 (their arithmetic never touched the geodetic pair).  Fused binning with the camera model only.
+#ifndef AMT_ROWS_MIN_WAVES_MAGONLY
+#define AMT_ROWS_MIN_WAVES_MAGONLY 4
+#endif
 // item_order 4: the c-th row of work items in dispatch order -> its row of chunks.  The launch works on two fronts that
 // start at the limb and move apart: the Earth side (VALU-bound rows) and the sky side (rows that only store NaN), so that
 // both kinds are in flight together for most of the launch while each front keeps writing neighbouring rows (an order
@@ -489,10 +497,11 @@ __host__ __device__ inline int two_front_chunk(int c, int n, int split, int e, i
 }
 
 template <bool FAST, bool DIRS_IN, int SECOND, int BIN>
-__global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE : (SECOND == 1 && BIN ? AMT_ROWS_MIN_WAVES_MAG : (BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES))) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
+__global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGONLY : (SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE : (SECOND == 1 && BIN ? AMT_ROWS_MIN_WAVES_MAG : (BIN ? AMT_ROWS_MIN_WAVES_BIN : AMT_ROWS_MIN_WAVES)))) void k_georef_rows(georef_batch B, int rows_per_chunk, int strips_x,
                                                            int n_items, int n_frames) {
-    constexpr bool MAG = SECOND != 0, kPole = SECOND == 2, kMagPole = SECOND == 3;
+    constexpr bool MAG = SECOND != 0, kPole = SECOND == 2, kMagPole = SECOND == 3, kMagOnly = SECOND == 4;
     static_assert(!(kPole || kMagPole) || (BIN != 0 && !DIRS_IN), "the pole plans exist for fused binning with the camera model only");
+    static_assert(!kMagOnly || (BIN != 0 && !DIRS_IN), "the MLat / MLT-only mode exists for fused binning with the camera model only");
     constexpr int kBinWaves = BIN ? kRowsThreads / 64 : 1, kBinSlots = BIN ? kBinCells : 1;
     __shared__ unsigned int sCnt[kBinWaves][kBinSlots];
     __shared__ unsigned int sCh[kBinWaves][3][kBinSlots];
@@ -916,27 +925,29 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
             }
             if (hit) {
                 p = shell_point(ry, u, t);           // already in GEO
-                double ir;
-                fx::bowring_nd(bw, p.x, p.y, p.z, bn, bd, ir);
-                double dla, dlo;
-                bool ok;
-                fx::small_angles(prev.bd, prev.bn, bd, bn, prev.p.x, prev.p.y, p.x, p.y, small_table().c, dla, dlo, ok);
-                ok = ok && fabs(prev.lo) < 178.0;
-                la = prev.la + dla;
-                lo = prev.lo + dlo;
-                if (!ok) full_angles(bn, bd, p.x, p.y, la, lo);
+                if (!kMagOnly) {
+                    double ir;
+                    fx::bowring_nd(bw, p.x, p.y, p.z, bn, bd, ir);
+                    double dla, dlo;
+                    bool ok;
+                    fx::small_angles(prev.bd, prev.bn, bd, bn, prev.p.x, prev.p.y, p.x, p.y, small_table().c, dla, dlo, ok);
+                    ok = ok && fabs(prev.lo) < 178.0;
+                    la = prev.la + dla;
+                    lo = prev.lo + dlo;
+                    if (!ok) full_angles(bn, bd, p.x, p.y, la, lo);
+                }
             }
             if (BIN) take_pixel(r, even, ch0, ch1, ch2);
             // the last corner row of a chunk is the first of the next one (which owns it) unless it is
             // the image's last; lane 63's column likewise belongs to the next strip unless it is the last
             const bool owner = (lane < 63 || gx == frame_w) && (r < rows || gy == frame_h);
-            if (owner) {
+            if (!kMagOnly && owner) {
                 if (out_lat) at(out_lat, off_corner) = la;
                 if (out_lon) at(out_lon, off_corner) = lo;
             }
             if (MAG) {
                 // with bin_magnetic the bounding box is reduced over (MLat, SM longitude) as well
-                const bool magbox = BIN && !kPole && A.bin_magnetic;
+                const bool magbox = kMagOnly || (BIN && !kPole && A.bin_magnetic);
                 if (hit) {
                     if (pole_bin) pole_point(bn, bd, p.x, p.y, sv, sxy); else sm_point(p, sv, sxy);
                     sm_angles(prev.s, prev.sxy, prev.ml, prev.sl, sv, sxy, sml, ssl);
@@ -1021,16 +1032,22 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
                     loc = __builtin_fma(lo, 0.25, __builtin_fma(prev.lo, 0.25, __builtin_fma(pc.y, 1e-9, pc.z * 1e-9))) + lo * 0.5;
                     el = __builtin_fma(dsum.x, 1e-3, __builtin_fma(dsum.y, 1e-3, __builtin_fma(dsum.z, 1e-3, pc.z * 1e-9))) + 20.0;
                 } else if (pc.x == pc.x) {
-                    double inv_r, cn, cd;
-                    fx::bowring_nd(bw, pc.x, pc.y, pc.z, cn, cd, inv_r);
-                    // relative to this lane's corner of the current row
-                    double dla, dlo;
-                    bool ok;
-                    fx::small_angles(bd, bn, cd, cn, p.x, p.y, pc.x, pc.y, small_table().c, dla, dlo, ok);
-                    ok = ok && fabs(lo) < 178.0;
-                    lac = la + dla;
-                    loc = lo + dlo;
-                    if (!ok) full_angles(cn, cd, pc.x, pc.y, lac, loc);
+                    double inv_r, cn = NAN, cd = NAN;
+                    if (kMagOnly) {
+                        // 1 / |P| exactly as the Bowring step computes it (fx::bowring_nd): the elevation keeps its bits
+#pragma clang fp contract(off)
+                        inv_r = fx::rsqrt_n(__builtin_fma(pc.z, pc.z, __builtin_fma(pc.x, pc.x, pc.y * pc.y)));
+                    } else {
+                        fx::bowring_nd(bw, pc.x, pc.y, pc.z, cn, cd, inv_r);
+                        // relative to this lane's corner of the current row
+                        double dla, dlo;
+                        bool ok;
+                        fx::small_angles(bd, bn, cd, cn, p.x, p.y, pc.x, pc.y, small_table().c, dla, dlo, ok);
+                        ok = ok && fabs(lo) < 178.0;
+                        lac = la + dla;
+                        loc = lo + dlo;
+                        if (!ok) full_angles(cn, cd, pc.x, pc.y, lac, loc);
+                    }
                     // reference astrometry.py:200-212, utils.py:33-46: 90 - angle(-d, P/|P|) = asin(-d.P/|P|)
                     // (dot products do not depend on the frame; 1/|P| is a by-product of the Bowring step)
                     double c = -(fx::dot3(dsum.x, dsum.y, dsum.z, pc.x, pc.y, pc.z) * dscale) * inv_r;
@@ -1051,8 +1068,8 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
                         }
                     }
                 }
-                if (out_lat_c) at(out_lat_c, off_pixel) = lac;
-                if (out_lon_c) at(out_lon_c, off_pixel) = loc;
+                if (!kMagOnly && out_lat_c) at(out_lat_c, off_pixel) = lac;
+                if (!kMagOnly && out_lon_c) at(out_lon_c, off_pixel) = loc;
                 if (out_elev) at(out_elev, off_pixel) = el;
                 if (MAG && !kPole && A.mlat_c) {
                     at(A.mlat_c, off_pixel) = ml;
@@ -1062,8 +1079,9 @@ __global__ __launch_bounds__(kRowsThreads, SECOND >= 2 ? AMT_ROWS_MIN_WAVES_POLE
                 if (BIN && valid) {
                     // reference resample.py:301-351 on (lon, lat) or, for resampleMLatMLT, on
                     // (SM longitude = mltToSmLon(mlt), MLat) (mapping.py:1519-1547, transform.py:388-401)
-                    double bxv = (MAG && !kPole && A.bin_magnetic) ? (mt - 12.0) / (24.0 / 360.0) : loc;
-                    double byv = (MAG && !kPole && A.bin_magnetic) ? ml : lac;
+                    const bool bin_mag = kMagOnly || (MAG && !kPole && A.bin_magnetic);
+                    double bxv = bin_mag ? (mt - 12.0) / (24.0 / 360.0) : loc;
+                    double byv = bin_mag ? ml : lac;
                     if (pole_bin) bxv = slc, byv = ml;
                     if (kMagPole) bxv = rloc, byv = rlac;
                     if (lon_wrap) bxv = wrap180_shifted(bxv);
@@ -1289,12 +1307,16 @@ void launch_variant(amt_ctx* ctx, const georef_args& A, dim3 grid, bool mag, lau
         hipExtLaunchKernelGGL((k_georef<kTW, kTH, FAST, DIRS_IN, false>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, A);
 }
 
-// second: 0 / 1 / 2 as the kernel's SECOND
+// second: 0 ... 4 as the kernel's SECOND
 template <bool FAST, bool DIRS_IN, int BIN>
 void launch_rows_bin(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 grid, int second, int rows, int strips_x,
                      int n_items, launch_events ev) {
     const dim3 block(kRowsThreads);
-    if (second == 3) {
+    if (second == 4) {
+        if constexpr (BIN != 0 && !DIRS_IN)
+            hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, 4, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
+                                  rows, strips_x, n_items, n_frames);
+    } else if (second == 3) {
         if constexpr (BIN != 0 && !DIRS_IN)
             hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, 3, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
                                   rows, strips_x, n_items, n_frames);
@@ -1760,6 +1782,12 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     AMT_REQUIRE(ctx, !(A.bin_pole && use_tiles), "bin_pole is implemented by the row-marching kernel only");
     // (bin_pole on a geodetic grid with MLat / MLT outputs: the SECOND = 3 variant with the rotated pair taken from (lat, lon))
     F->second = A.bin_pole ? (F->mag ? 3 : 2) : (F->mag ? 1 : 0);
+    // MLat / MLT only (SECOND = 4): a (MLat, SM longitude) grid without a pole plan whose caller wants none of the four
+    // geodetic arrays — what resampleMLatMLT consumes (reference mapping.py:1519-1547); AMT_NO_MAG_ONLY=1: A/B runs
+    static const bool no_mag_only = std::getenv("AMT_NO_MAG_ONLY") != nullptr;
+    if (F->second == 1 && bin && A.bin_magnetic && dirs == nullptr && !use_tiles && !no_mag_only && !A.lat && !A.lon && !A.lat_c &&
+        !A.lon_c)
+        F->second = 4;
     F->bin = bin;
     return AMT_OK;
 }
@@ -1804,6 +1832,7 @@ int launch_prepared(amt_ctx* ctx, int n, prepared_frame* F) {
         }
     } else {
         georef_batch B;
+        ctx->last_second = F[0].second, ctx->last_bin = bin, ctx->last_frames = n;
         for (int i = 0; i < kMaxBatch; ++i) B.f[i] = F[i < n ? i : 0].A;
         B.math = fx::make_math_table();
         if (dirs) {

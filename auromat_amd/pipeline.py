@@ -65,19 +65,26 @@ class _GridView(object):
 
 class FramePipeline(object):
     def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, with_mag=False, alloc_image=True,
-                 alloc_coords=True):
+                 alloc_coords=True, with_geo=True):
         import torch
         self.ctx = ctx = Context.current(device)
         self.width, self.height = int(width), int(height)
         h, w = self.height, self.width
         fd = self.fd = FrameData(ctx, h, w)
         self.with_mag = with_mag
+        # with_geo=False (needs with_mag): "MLat / MLT only" — the pipeline keeps mlat, mlt, mlat_c, mlt_c and the elevation,
+        # which is all resampleMLatMLT consumes (reference resample.py:63-71, mapping.py:1519-1547), and the single-pass
+        # launch on the (MLat, SM longitude) grid runs the kernel variant that skips the geodetic half of the arithmetic
+        # and its four stores (k_georef_rows<SECOND = 4>).  The geodetic arrays are allocated, and the frame georeferenced
+        # again into all nine, only when a frame takes the two-pass plan or somebody asks for them (coordinates()).
+        self.with_geo = bool(with_geo) or not with_mag
         self._out = GeorefOut()
         # alloc_coords=False ("grids only"): the single-pass plan then writes no per-pixel coordinate arrays at all (its
         # kernel bins every pixel as soon as its coordinates exist; 480 MB per frame of stores fall away) and the
         # arrays are only allocated, and the frame georeferenced again into them, when a frame has to take the
         # two-pass plan (pole in view, ...) or somebody asks for them
         self._coords_valid = False
+        self._kept_valid = False    # the arrays a with_geo=False pipeline keeps hold the last frame
         if alloc_coords:
             self._alloc_coords()
         fd.bbox = ctx.empty((8,))
@@ -110,29 +117,44 @@ class FramePipeline(object):
         self.min_elevation = None
         self._out.bbox = fd.bbox.data_ptr()
 
-    def _alloc_coords(self):
-        fd, ctx, out = self.fd, self.ctx, self._out
-        if fd.lat is not None:
-            return
+    def _alloc_coords(self, full=False):
+        """Allocate the per-pixel arrays the pipeline keeps (`full`: the geodetic ones of a with_geo=False pipeline too)."""
+        fd, ctx = self.fd, self.ctx
         h, w = self.height, self.width
-        fd.lat, fd.lon = ctx.empty((h + 1, w + 1)), ctx.empty((h + 1, w + 1))
-        fd.lat_c, fd.lon_c, fd.elev = ctx.empty((h, w)), ctx.empty((h, w)), ctx.empty((h, w))
-        out.lat, out.lon, out.lat_c, out.lon_c, out.elev = (t.data_ptr() for t in (fd.lat, fd.lon, fd.lat_c, fd.lon_c, fd.elev))
-        if self.with_mag:
-            fd.mlat, fd.mlt = ctx.empty((h + 1, w + 1)), ctx.empty((h + 1, w + 1))
-            fd.mlat_c, fd.mlt_c = ctx.empty((h, w)), ctx.empty((h, w))
-            out.mlat, out.mlt, out.mlat_c, out.mlt_c = (t.data_ptr() for t in (fd.mlat, fd.mlt, fd.mlat_c, fd.mlt_c))
+        if fd.elev is None:
+            fd.elev = ctx.empty((h, w))
+            if self.with_mag:
+                fd.mlat, fd.mlt = ctx.empty((h + 1, w + 1)), ctx.empty((h + 1, w + 1))
+                fd.mlat_c, fd.mlt_c = ctx.empty((h, w)), ctx.empty((h, w))
+        if (full or self.with_geo) and fd.lat is None:
+            fd.lat, fd.lon = ctx.empty((h + 1, w + 1)), ctx.empty((h + 1, w + 1))
+            fd.lat_c, fd.lon_c = ctx.empty((h, w)), ctx.empty((h, w))
+        self._set_out(full)
+
+    def _set_out(self, full=False):
+        """Output pointers of the next launch: every array the pipeline holds, the geodetic ones of a with_geo=False
+        pipeline only with `full` (a NULL output is not computed: amt_georef_out)."""
+        fd, out = self.fd, self._out
+        for k in FrameData.COORDS:
+            t = getattr(fd, k)
+            if k in ('lat', 'lon', 'lat_c', 'lon_c') and not (full or self.with_geo):
+                t = None
+            setattr(out, k, None if t is None else t.data_ptr())
+
+    def _has_all(self):
+        return self.fd.elev is not None and self.fd.lat is not None
 
     def coordinates(self):
         """Make sure the per-pixel coordinate arrays of the last frame exist (grids-only pipelines compute them on
         demand: one more run of the georeferencing kernel) -> the FrameData."""
         if not self._coords_valid:
-            self._alloc_coords()
+            self._alloc_coords(full=True)
             Context.current(self.ctx.device)
             self._out.bbox_min_elevation = NEG_INF if self.min_elevation is None else float(self.min_elevation)
             self.ctx.call('amt_georef_frame', C.byref(self.params), C.byref(self._out))
+            self._set_out()
             self.fd.corner_mask = self.fd.center_mask = None
-            self._coords_valid = True
+            self._coords_valid = self._kept_valid = True
         return self.fd
 
     def __del__(self):
@@ -252,14 +274,16 @@ class FramePipeline(object):
                         fd.img_dtype_code, min_elev, float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1, mag)
             self._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
             fd.corner_mask = fd.center_mask = None
-            self._coords_valid = fd.lat is not None
+            self._coords_valid = fd.lat is not None and self.with_geo
+            self._kept_valid = fd.elev is not None
             return fd
-        self._alloc_coords()
-        self._coords_valid = True
+        self._alloc_coords(full=True)
+        self._coords_valid = self._kept_valid = True
         self._fused = None
         self._pole = None                                # decided lazily in bounding_box()
         out.bbox_min_elevation = min_elev
         self.ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
+        self._set_out()
         fd.corner_mask = fd.center_mask = None
         # the 8 reduction doubles travel to pinned host memory right behind the kernel; the event lets
         # bounding_box() wait for exactly this point while later launches keep the GPU busy
@@ -292,7 +316,8 @@ class FramePipeline(object):
             q.params, q.altitude, q.min_elevation = p, altitude, min_elevation
             q._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
             q.fd.corner_mask = q.fd.center_mask = None
-            q._coords_valid = q.fd.lat is not None
+            q._coords_valid = q.fd.lat is not None and q.with_geo
+            q._kept_valid = q.fd.elev is not None
 
     def bounding_box(self):
         """Waits for the fused reduction of the last georef() -> BoundingBox; ValueError if nothing is valid."""
@@ -512,10 +537,15 @@ class FramePipeline(object):
                     fuse_pxPerDeg=pxPerDeg if fuse else None, fuse_magnetic=bool(magnetic))
         return self.resample(pxPerDeg, containsPole, magnetic, keep_on_device=keep_on_device)
 
-    def host_arrays(self):
-        """Raw (NaN = missing) coordinate arrays of the last frame as NumPy arrays."""
-        names = ['lat', 'lon', 'lat_c', 'lon_c', 'elev'] + (['mlat', 'mlt', 'mlat_c', 'mlt_c'] if self.with_mag else [])
-        self.coordinates()
+    def host_arrays(self, kept_only=False):
+        """Raw (NaN = missing) coordinate arrays of the last frame as NumPy arrays.  `kept_only`: only the arrays the
+        pipeline's own launches write (a with_geo=False pipeline: elevation, MLat, MLT), without computing the others."""
+        geo = ['lat', 'lon', 'lat_c', 'lon_c']
+        names = geo + ['elev'] + (['mlat', 'mlt', 'mlat_c', 'mlt_c'] if self.with_mag else [])
+        if kept_only and not self.with_geo and self._kept_valid:
+            names = names[4:]
+        else:
+            self.coordinates()
         return {k: self.fd.host(k) for k in names}
 
 
@@ -731,7 +761,8 @@ class SequencePipeline(object):
 
     def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, altitude=110, fast=True,
                  min_elevation=10.0, pxPerDeg=10, plan='single-pass', bin_stream=True, shared_image=None,
-                 magnetic=False, batch=3, own_image_buffers=True, keep_coordinates=True, launch_streams=1):
+                 magnetic=False, batch=3, own_image_buffers=True, keep_coordinates=True, launch_streams=1,
+                 geodetic_arrays=None):
         import torch
         assert plan in ('single-pass', 'two-pass')
         try:
@@ -753,9 +784,14 @@ class SequencePipeline(object):
         # own_image_buffers=False: every frame of process() brings a device-resident image that is used in place
         # (no per-slot image buffer is allocated).  keep_coordinates=False ("grids only", what a convert run needs):
         # the single-pass plan writes no per-pixel latitude / longitude / elevation arrays, see FramePipeline.
+        # geodetic_arrays (magnetic sequences): None / False = the buffers keep what resampleMLatMLT consumes — MLat, MLT
+        # (corners and centres) and the elevation — and the single-pass kernel skips the geodetic half of its work
+        # (FramePipeline(with_geo=False)); True = all nine per-pixel arrays, for callers that ask for both.  The grids are the
+        # same bit for bit either way.
+        self.geodetic_arrays = (not self.magnetic) or bool(geodetic_arrays) or not self.single_pass
         self.pipes = [FramePipeline(width, height, nchan, img_dtype, device, with_mag=self.magnetic,
                                     alloc_image=own_image_buffers and (shared_image is None or i == 0),
-                                    alloc_coords=keep_coordinates or not self.single_pass)
+                                    alloc_coords=keep_coordinates or not self.single_pass, with_geo=self.geodetic_arrays)
                       for i in range(2 * self.batch if self.single_pass else 4)]
         self.ctx = self.pipes[0].ctx
         if shared_image is not None:

@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 /* 2: amt_georef_out grew (bin_pole, altitude); amt_rotate_pole_deg, amt_pipe_finalize_stream, amt_seq_* added (round 2) */
-#define AMT_ABI_VERSION 3
+/* 4: amt_georef_last_variant; the MLat / MLT-only mode of the fused frame kernel (see amt_georef_out) (round 4) */
+#define AMT_ABI_VERSION 4
 
 #define AMT_OK 0
 #define AMT_EINVAL (-1)   /* bad argument (NULL pointer, negative size, unsupported dtype ...) */
@@ -81,6 +82,11 @@ int amt_event_elapsed_ms(amt_ctx* ctx, void* start, void* stop, float* out_ms); 
 #define AMT_KERNEL_BIN 1
 int amt_timing_enable(amt_ctx* ctx, int enable);
 int amt_timing_read(amt_ctx* ctx, int kernel, double* total_ms, int* launches);
+/* Which variant of the frame kernel the context's latest amt_georef_frame[_dirs] / amt_pipe_launch[_many] / amt_run_* launch
+ * ran (diagnostics; tests assert on it): *second = 0 (lat, lon) only, 1 + (MLat, MLT), 2 / 3 the pole plans, 4 the
+ * MLat / MLT-only mode (see amt_georef_out); *bin = 0 no fused binning, 1 uint8, 2 uint16 image; *frames = frames in that
+ * launch.  -1 in all three before the first launch. */
+int amt_georef_last_variant(amt_ctx* ctx, int32_t* second, int32_t* bin, int32_t* frames);
 
 /* ---- per-frame parameter block --------------------------------------------------------
  * Host scalars the reference derives once per frame:
@@ -136,7 +142,11 @@ typedef struct amt_georef_out {
      * arrays need not be read back (and need not be written at all: lat_c/lon_c/elev may be NULL).
      * The grid must be known before the launch: callers use a superset of the final grid, aligned to the
      * same global nodes (amt_georef_coarse_bbox), and crop in amt_bin_frame_finalize_window.
-     * Both axes must be uniform; bin_img is (height, width, 3) uint8 (dtype 1) or uint16 (dtype 2). */
+     * Both axes must be uniform; bin_img is (height, width, 3) uint8 (dtype 1) or uint16 (dtype 2).
+     * MLat / MLT-only mode: with bin_magnetic, no bin_pole and lat = lon = lat_c = lon_c = NULL the kernel computes what
+     * resampleMLatMLT consumes and nothing else (reference resample.py:63-71, mapping.py:1519-1547: mLatMlt, mLatMltCenter,
+     * elevation, image) — ray, shell, SM rotation, (MLat, SM longitude), elevation, bin; no ECEF -> geodetic step at all.
+     * mlat / mlt / mlat_c / mlt_c / elev (each optional) and the grids are bit-identical to the nine-array mode. */
     const struct amt_axis* bin_xaxis;     /* host pointers */
     const struct amt_axis* bin_yaxis;
     const void* bin_img;

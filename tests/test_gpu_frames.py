@@ -428,10 +428,30 @@ def test_config4_mlat_mlt_three_shells_full_size(altitude):
     c = grid_coordinates(res)
     for a, b in (('lat', 'lat'), ('lon', 'lon'), ('lat_c', 'lat_c'), ('lon_c', 'lon_c')):
         assert np.array_equal(c[a], want[b]), a
+    assert pipe.ctx.last_variant()[0] == 1                   # nine arrays: the (lat, lon) + (MLat, MLT) variant
     # the two-pass plan gives the same bits
     two = pipe.run(hdr, altitude, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, magnetic=True, fuse=False)
     for k in ('mean', 'count', 'img', 'mask'):
         assert np.array_equal(two[k], res[k], equal_nan=True), k
+    # MLat / MLT-only mode (what resampleMLatMLT consumes, reference resample.py:63-71 + mapping.py:1519-1547; the kernel
+    # skips the geodetic half of its arithmetic and its four stores): the same grid and the same five arrays, bit for bit
+    lean = FramePipeline(w, h, with_mag=True, with_geo=False)
+    res5 = lean.run(hdr, altitude, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, magnetic=True, fuse=True)
+    assert lean.last_plan == 'single-pass' and lean.ctx.last_variant()[0] == 4 and lean.fd.lat is None
+    for k in ('mean', 'count', 'img', 'mask'):
+        assert np.array_equal(res5[k], res[k], equal_nan=True), k
+    kept = lean.host_arrays(kept_only=True)
+    assert sorted(kept) == ['elev', 'mlat', 'mlat_c', 'mlt', 'mlt_c'] and lean.fd.lat is None
+    for k, v in kept.items():
+        assert np.array_equal(v, got[k], equal_nan=True), k
+    if altitude == 120:
+        # ... and a caller that does ask such a pipeline for the geodetic arrays gets them (computed on demand)
+        full = lean.host_arrays()
+        for k, v in full.items():
+            assert np.array_equal(v, got[k], equal_nan=True), k
+        again = lean.run(hdr, altitude, cam, t, fast=True, min_elevation=10, pxPerDeg=10, magnetic=True, fuse=True)
+        assert lean.ctx.last_variant()[0] == 4 and np.array_equal(again['mean'], res['mean'], equal_nan=True)
+    del lean
     if altitude == 110:
         # the reference's own call sequence (resample.py:63-71) gives the same grid
         m = ArraySpacecraftMapping(hdr, altitude, img, cam, t, 'c4', fastCenterCalculation=True).maskedByElevation(10)

@@ -241,10 +241,12 @@ def test_real_frame_on_the_mlat_mlt_grid():
     check(r.img.data, ma.getmaskarray(r.img)[..., 0], None, z)
     hdr, img = readHeader(WCS), loadImage(JPG)
     cam, t, _ = getShiftedSpacecraftPosition(hdr)
-    for fuse in (True, False):
-        pipe = FramePipeline(4256, 2832, img_dtype=np.uint8, with_mag=True)
+    for fuse, geo in ((True, True), (False, True), (True, False)):
+        # (with_geo=False: the MLat / MLT-only mode of the fused kernel — no ECEF -> geodetic step, five arrays kept)
+        pipe = FramePipeline(4256, 2832, img_dtype=np.uint8, with_mag=True, with_geo=geo)
         res = pipe.run(hdr, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, fuse=fuse, magnetic=True)
         assert pipe.last_plan == ('single-pass' if fuse else 'two-pass')
+        assert not fuse or pipe.ctx.last_variant()[0] == (1 if geo else 4)
         assert np.array_equal(res['lat'], z['out_lat']) and np.array_equal(res['lon_c'], z['out_lon_c'])
         check(res['img'], res['mask'], res['mean'], z)
 
@@ -263,15 +265,18 @@ def test_real_frame_on_the_mlat_mlt_grid_other_shells(altitude):
     z = load_golden('real_frame_iss030_sm_%dkm.npz' % altitude)
     hdr, img = readHeader(WCS), loadImage(JPG)
     cam, t, _ = getShiftedSpacecraftPosition(hdr)
-    for fuse in (True, False):
-        pipe = FramePipeline(4256, 2832, img_dtype=np.uint8, with_mag=True)
+    for fuse, geo in ((True, True), (False, True), (True, False)):
+        pipe = FramePipeline(4256, 2832, img_dtype=np.uint8, with_mag=True, with_geo=geo)
         res = pipe.run(hdr, altitude, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, fuse=fuse, magnetic=True)
         assert pipe.last_plan == ('single-pass' if fuse else 'two-pass')
+        assert not fuse or pipe.ctx.last_variant()[0] == (1 if geo else 4)
         assert np.array_equal(res['lat'], z['out_lat']) and np.array_equal(res['lon_c'], z['out_lon_c'])
         check(res['img'], res['mask'], res['mean'], z)
     mm = getMapping(JPG, WCS, altitude=altitude, fastCenterCalculation=True).maskedByElevation(10)
     r = R.resampleMLatMLT(mm, pxPerDeg=10)
     assert R.last_plan == 'single-pass'
+    from auromat_amd._native import Context
+    assert Context.current().last_variant()[0] == 4          # the class route: MLat / MLT only (grids-only pipeline)
     check(r.img.data, ma.getmaskarray(r.img)[..., 0], None, z)
 
 
