@@ -64,6 +64,9 @@ def parse_args(argv=None):
     ap.add_argument('--magnetic', action='store_true',
                     help='configs[3] instead of configs[2]: MLat/MLT outputs and the (MLat, SM longitude) grid of '
                          'resampleMLatMLT; the three altitude shells 100/110/120 km alternate frame by frame')
+    ap.add_argument('--nine-arrays', action='store_true',
+                    help='with --magnetic: also write lat, lon, lat_c, lon_c (nine per-pixel arrays instead of the five '
+                         'BASELINE.md\'s configs[3] row lists; the kernel then runs both coordinate chains)')
     ap.add_argument('--plan', default='fused', choices=('fused', 'two-pass'),
                     help='fused: binning inside the georeferencing kernel (superset grid + crop); '
                          'two-pass: separate binning kernel that re-reads the centre arrays')
@@ -155,14 +158,21 @@ def dry_run(args, world, rank):
     if os.environ.get('AMT_BENCH_DRYRUN_FAIL_RANK') == str(rank):
         raise SystemExit(3)
     elapsed = time.perf_counter() - t0
+    records, ranks, backend = None, 1, None
     if world > 1:
+        own = elapsed
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        records = [None] * world
+        dist.all_gather_object(records, dict(rank=rank, host=socket.gethostname(), pid=os.getpid(), elapsed_ms=own * 1e3,
+                                             frames=args.steps))
+        ranks, backend = dist.get_world_size(), dist.get_backend()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({'metric': 'dry run (no GPU work)', 'value': world * args.steps / elapsed, 'unit': 'steps/s',
-                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'dry_run': True}))
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'dry_run': True,
+                          'ranks': ranks, 'backend': backend, 'per_rank': records}))
         sys.stdout.flush()
 
 
@@ -197,6 +207,20 @@ def measured_fill_gbs(device):
             b.fill_(1.0)
     torch.cuda.synchronize()
     return 10 * sum(b.numel() for b in bufs) * 8 / (time.perf_counter() - t0) / 1e9
+
+
+def device_description(device):
+    """Name, PCI address and uuid of a torch device (the N-rank line lists one per rank)."""
+    import torch
+    props = torch.cuda.get_device_properties(device)
+    out = {'index': device.index, 'name': props.name}
+    dom, bus, dev = (getattr(props, k, None) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id'))
+    if bus is not None:
+        out['pci_bus_id'] = '%04x:%02x:%02x.0' % (dom or 0, bus, dev or 0)
+    uuid = getattr(props, 'uuid', None)
+    if uuid is not None:
+        out['uuid'] = str(uuid)
+    return out
 
 
 def cpu_model():
@@ -359,7 +383,7 @@ def resident_images(device, n, first_seed):
 
 
 def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_hints, shared_image, own_buffers,
-              fence, after=None, keep_coordinates=True, spinup_ms=0.0):
+              fence, after=None, keep_coordinates=True, spinup_ms=0.0, geodetic_arrays=None):
     """
     W untimed + K timed frames through a fresh SequencePipeline.  Returns dict(elapsed, georef_ms, bin_ms, plans,
     hinted, seq, results, extra) — georef_ms / bin_ms are per FRAME, from HIP events on the dispatch packets.
@@ -369,7 +393,7 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
     seq = SequencePipeline(WIDTH, HEIGHT, altitude=ALTITUDE, fast=fast, min_elevation=MIN_ELEV, pxPerDeg=PPD,
                            plan='single-pass' if plan == 'fused' else 'two-pass', bin_stream=streams == 2,
                            shared_image=shared_image, magnetic=magnetic, batch=batch, own_image_buffers=own_buffers,
-                           keep_coordinates=keep_coordinates, launch_streams=LAUNCH_STREAMS)
+                           keep_coordinates=keep_coordinates, launch_streams=LAUNCH_STREAMS, geodetic_arrays=geodetic_arrays)
     seq.use_hints = use_hints
     ctx = seq.ctx
     spun = 0
@@ -407,7 +431,9 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
     n_timed = (steps + TIMING_EVERY - 1) // TIMING_EVERY
     assert g_n == n_timed and b_n in (0, n_timed), (g_n, b_n)
     return dict(elapsed=elapsed, georef_ms=g_total / g_n, bin_ms=(b_total / b_n if b_n else 0.0), plans=plans,
-                hinted=hinted, seq=seq, results=results, extra=extra, spinup_frames=spun)
+                hinted=hinted, seq=seq, results=results, extra=extra, spinup_frames=spun,
+                process_ms=(t_proc - t0) * 1e3, after_ms=(t_after - t_proc) * 1e3, fence_ms=(t0 + elapsed - t_after) * 1e3,
+                variant=ctx.last_variant())
 
 
 def main(argv=None):
@@ -505,12 +531,28 @@ def main(argv=None):
 
     run = timed_run(make_frames(total, args.magnetic), args.warmup, args.steps, fast, args.plan, args.magnetic,
                     args.batch, args.streams, not args.no_hints, shared, own_buffers=args.upload, fence=fence,
-                    after=gather, spinup_ms=args.spinup_ms)
+                    after=gather, spinup_ms=args.spinup_ms, geodetic_arrays=args.nine_arrays)
     elapsed = run['elapsed']
+    rank_records = None
     if use_dist:
+        own_elapsed = elapsed
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # what every rank saw, so that the line itself shows that N ranks on N distinct devices took part (after the timed
+        # region; all_gather_object is a collective of its own on every backend)
+        whole = run['results'].payload() if hasattr(run['results'], 'payload') else None
+        cap = gather_state.get('capacity')
+        from auromat_amd.sequence import DESC_LEN
+        mine = dict(rank=rank, local_rank=int(os.environ.get('LOCAL_RANK', '0')), host=socket.gethostname(), pid=os.getpid(),
+                    device=device_description(device), frames=args.steps, first_frame=first + args.warmup,
+                    elapsed_ms=own_elapsed * 1e3, process_ms=run['process_ms'], gather_ms=run['after_ms'],
+                    closing_fence_ms=run['fence_ms'], kernel_us_per_frame=run['georef_ms'] * 1e3,
+                    single_pass_frames=sum(1 for q in run['plans'] if q == 'single-pass'),
+                    payload_bytes=None if whole is None else int(whole[1]) * 8,
+                    gather_bytes=None if cap is None else (cap[0] * DESC_LEN + cap[1] + 2) * 8)
+        rank_records = [None] * world
+        dist.all_gather_object(rank_records, mine)
         if rank == 0:
             gathered = run['extra']
             assert gathered.n_frames == world * args.steps and len(gathered.unpack()) == world * args.steps
@@ -547,8 +589,11 @@ def main(argv=None):
             kname, tkey = 'k_georef_rows (amt_georef_frame)', 'k_georef_rows'
             kbytes = moved = ab['georef']
         if args.magnetic:
-            moved += ab['mag']           # this variant writes MLat/MLT beside lat/lon (more than the contract counts)
-            tkey += '_mag'
+            # BASELINE.md's configs[3] row: mlat, mlt (corners), mlat_c, mlt_c, elev written = 16 Nc + 24 Np, the byte counts of
+            # the geodetic row; --nine-arrays writes lat, lon, lat_c, lon_c beside them (more than the contract counts)
+            tkey += '_mag' if args.nine_arrays else '_mag_only'
+            if args.nine_arrays:
+                moved += ab['mag']
         achieved = kbytes / (georef_ms * 1e-3) / 1e9
         fpl = seq.batch if fused else 1
         tr = traffic.get(tkey, {})
@@ -563,8 +608,9 @@ def main(argv=None):
             'data': 'synthetic; ' + ('image of every frame uploaded from pinned host memory' if args.upload else
                                      'one image shared by all frames, resident in HBM' if shared is not None else
                                      'a distinct image per frame (%d resident in HBM before the timed region)' % len(imgs)),
-            'config': {'workload': ('configs[3]: as configs[2] on shells 100/110/120 km + MLat/MLT of corners and centres, '
+            'config': {'workload': ('configs[3]: shells 100/110/120 km, MLat/MLT of corners and centres + elevation%s, '
                                     'mean-resample on the 0.1 deg (MLat, SM longitude) grid (resampleMLatMLT)'
+                                    % (' + lat/lon of corners and centres (nine arrays)' if args.nine_arrays else '')
                                     if args.magnetic else
                                     'configs[2]: 4240x2832 ISS-like frame, WCS ray cast + WGS84(+110 km) '
                                     'intersection + geodetic transform + elevation (%s centres), '
@@ -585,6 +631,7 @@ def main(argv=None):
                        # bounded the limb (a conic section in the image) and no ray of them can hit the shell; every
                        # output array is still written in full and is identical to the ray-cast result
                        'sky_item_rows': sky_rows_note(),
+                       'kernel_variant': dict(zip(('second', 'bin', 'frames_in_last_launch'), run['variant'])),
                        'device': info['name']},
             # dominant kernel.  It is FP64-VALU bound (see DESIGN.md and profiles/), so the HBM fraction understates
             # how busy the chip is.
@@ -614,6 +661,16 @@ def main(argv=None):
                 'pipeline_frac_directions_in_1129.0MB': frac(ab['georef_dirs_in'] + ab['resample'], georef_ms + bin_ms),
             },
         }
+        if use_dist:
+            # the N-rank line describes itself: who took part, on which device, and what each rank measured
+            out['ranks'] = dist.get_world_size()
+            out['backend'] = dist.get_backend()
+            out['per_rank'] = rank_records
+            out['distinct_devices'] = len(set((r['host'], r['device'].get('pci_bus_id') or r['device'].get('uuid') or r['device']['index'])
+                                              for r in rank_records))
+            out['gather_bytes_received'] = sum(r['gather_bytes'] or 0 for r in rank_records)
+            out['timed_region_ms'] = {'max_over_ranks': elapsed * 1e3, 'rank0_process': run['process_ms'],
+                                      'rank0_gather': run['after_ms'], 'rank0_closing_fence': run['fence_ms']}
         del run, seq, results
         import gc
         gc.collect()        # the pipeline's drivers are freed HERE (hipFree synchronises the device), not whenever the
@@ -628,6 +685,10 @@ def main(argv=None):
             # (configs[3] first: its nine arrays per buffer are the largest allocations of the run, and it measured up to
             # 8 % slower per kernel when it came after the other variants' allocate / free cycles)
             for name, kw in (('configs3_magnetic_3_shells', dict(fast=True, magnetic=True)),
+                             # the same with lat, lon, lat_c, lon_c written beside MLat / MLT (nine arrays, both chains)
+                             ('configs3_nine_arrays', dict(fast=True, magnetic=True, nine=True)),
+                             # the headline workload over 192 frames (the driver's 20-step run times 7 launches)
+                             ('configs2_long', dict(fast=True, magnetic=False, frames=192)),
                              ('exact_centres', dict(fast=False, magnetic=False)),
                              # NOT the headline workload: the resampled grids only, no per-pixel coordinate arrays
                              # written (what a convert run needs; SequencePipeline(keep_coordinates=False))
@@ -635,13 +696,14 @@ def main(argv=None):
                              # a camera that looks across the geographic pole (the same frame, its own image each time):
                              # the pole plan of the fused kernel, binned in rotated coordinates
                              ('pole_in_view', dict(fast=True, magnetic=False, pole=True))):
+                nv_k = kw.get('frames', 96)
                 if kw.get('pole'):
                     vframes = [(p_hdr, p_cam, p_t, imgs[k % len(imgs)], None) for k in range(nv_w + nv_k)]
                 else:
                     vframes = make_frames(nv_w + nv_k, kw['magnetic'])
                 v = timed_run(vframes, nv_w, nv_k, kw['fast'], 'fused', kw['magnetic'],
                               args.batch, args.streams, True, None, own_buffers=False, fence=fence,
-                              keep_coordinates=kw.get('keep', True), spinup_ms=args.spinup_ms)
+                              keep_coordinates=kw.get('keep', True), spinup_ms=args.spinup_ms, geodetic_arrays=kw.get('nine', False))
                 vb = ab['mag_shell'] - 24 * (WIDTH + 1) * (HEIGHT + 1) if kw['magnetic'] else ab['georef'] + ab['resample']
                 if not kw.get('keep', True):
                     vb = ab['image']            # all it has to move: the image
@@ -650,6 +712,7 @@ def main(argv=None):
                     'frames': nv_k, 'kernel_ms_per_frame': v['georef_ms'],
                     'single_pass_frames': sum(1 for q in v['plans'] if q == 'single-pass'),
                     'algorithmic_bytes_per_frame': vb, 'frac': frac(vb, v['georef_ms']),
+                    'kernel_variant_second': v['variant'][0],
                 }
                 if kw['magnetic']:
                     # SURVEY 8d config 4 counts 40 Nc + 54 Np per shell (directions read); the kernel generates them
@@ -660,6 +723,7 @@ def main(argv=None):
             # BASELINE configs[1]: the intersection + geodetic transform on their own (no image, no resample): the
             # georeferencing kernel without the fused binning, per-frame host set-up inside the timed region as above
             from auromat_amd.pipeline import FramePipeline
+            nv_k = 96
             gpipe = FramePipeline(WIDTH, HEIGHT, alloc_image=False)
             gframes = make_frames(nv_w + nv_k, False)
             for hdr, cam, t, _, _ in gframes[:nv_w]:

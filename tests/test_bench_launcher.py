@@ -25,6 +25,10 @@ def test_plain_invocation_with_two_ranks_prints_one_json_line():
     assert len(lines) == 1, res.stdout
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['dry_run'] is True and out['value'] > 0
+    # the line says who took part: two ranks, two processes, each with its own time
+    assert out['ranks'] == 2 and out['backend'] == 'gloo'
+    assert [r['rank'] for r in out['per_rank']] == [0, 1] and len(set(r['pid'] for r in out['per_rank'])) == 2
+    assert all(r['elapsed_ms'] > 0 and r['frames'] == 3 for r in out['per_rank'])
 
 
 def test_a_failing_rank_fails_the_whole_run():

@@ -36,3 +36,18 @@ def test_bench_with_several_ranks_on_one_gpu(world, steps):
     assert out['config']['workload'].startswith('configs[')
     assert out['roofline']['frac'] > 0 and out['roofline']['bound'] == 'hbm'
     assert out['config']['frames_total'] == world * steps and out['config']['single_pass_frames'] == steps
+    # the line describes its ranks: N of them reported, each with its device, its own times and what it sent
+    assert out['ranks'] == world and out['backend'] == 'gloo'
+    per = out['per_rank']
+    assert [r['rank'] for r in per] == list(range(world)) and len(set(r['pid'] for r in per)) == world
+    for r in per:
+        assert r['frames'] == steps and r['single_pass_frames'] == steps
+        assert r['device']['name'] and ('pci_bus_id' in r['device'] or 'uuid' in r['device'])
+        assert 0 < r['process_ms'] <= r['elapsed_ms'] and r['gather_ms'] >= 0 and r['kernel_us_per_frame'] > 50
+        assert r['payload_bytes'] > 0 and r['gather_bytes'] >= r['payload_bytes']
+        assert r['elapsed_ms'] <= out['timed_region_ms']['max_over_ranks'] + 1e-6
+    # (the rehearsal puts every rank on the box's one GPU: one distinct device; the driver's run must show N)
+    assert out['distinct_devices'] == 1 and out['gather_bytes_received'] == sum(r['gather_bytes'] for r in per)
+    # disjoint blocks of the synthetic sequence
+    firsts = sorted(r['first_frame'] for r in per)
+    assert all(b - a >= steps for a, b in zip(firsts, firsts[1:]))
