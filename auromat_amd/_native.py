@@ -115,6 +115,10 @@ _SIGNATURES = {
     'amt_event_elapsed_ms': ([_P, _P, _P, C.POINTER(C.c_float)], _I),
     'amt_timing_enable': ([_P, _I], _I),
     'amt_timing_read': ([_P, _I, C.POINTER(C.c_double), C.POINTER(_I)], _I),
+    'amt_pipe_launch_box': ([_P, C.POINTER(FrameParams), _D, _I], _I),
+    'amt_pipe_launch_box_many': ([c_void_pp, C.c_int32, c_void_pp, _D, _I], _I),
+    'amt_pipe_launch_many_res': ([c_void_pp, C.c_int32, c_void_pp, c_void_pp, c_void_pp, C.c_int32, _D, c_double_p, c_double_p, _I, _I], _I),
+    'amt_plate_carree_resolution': ([_D, _D, _D, _D, _D, c_double_p, c_double_p], _I),
     'amt_georef_last_variant': ([_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], _I),
     'amt_directions_tan': ([_P, C.POINTER(FrameParams), _I, _P], _I),
     'amt_directions_tan_points': ([_P, C.POINTER(FrameParams), _P, _P, _L, _I, _P], _I),

@@ -238,7 +238,9 @@ def grid_mapping(res, cam, t, altitude, identifier, magnetic):
 
 
 def convert_with_pipeline(args, frames, export):
-    """The whole sequence through the single-pass frame pipeline at a fixed px/deg; this rank's share of the frames."""
+    """The whole sequence through the single-pass frame pipeline — at a fixed px/deg (--px-per-deg) or, the reference's
+    flags, at --resolution arcsec per pixel, where every frame's px/deg follows from its own bounding box (the box-first plan
+    of SequencePipeline(arcsecPerPx=...)) —; this rank's share of the frames."""
     import torch
     import torch.distributed as dist
     from ..mapping.spacecraft import frame_inputs
@@ -276,7 +278,8 @@ def convert_with_pipeline(args, frames, export):
         seq = SequencePipeline(first.shape[1], first.shape[0], nchan=first.shape[2], img_dtype=first.dtype,
                                altitude=args.altitude, fast=not args.exactCenters,
                                min_elevation=args.minElevation if args.minElevation >= 0 else None,
-                               pxPerDeg=args.pxPerDeg, magnetic=magnetic, keep_coordinates=False)
+                               pxPerDeg=args.pxPerDeg or 10, magnetic=magnetic, keep_coordinates=False,
+                               arcsecPerPx=None if args.pxPerDeg else args.resolution)
 
         def feed():
             # decoding a 12 Mpx JPEG takes ~100 ms of host time, the GPU 0.2 ms per frame: images are read ahead on a
@@ -301,9 +304,11 @@ def convert_with_pipeline(args, frames, export):
 
         metas = [frame_inputs(hdr) for _, hdr, _, _ in todo]
         results = seq.process(feed(), keep_on_device=True)
-        for (identifier, hdr, img_path, path), (cam, t), res in zip(todo, metas, results):
+        for k, ((identifier, hdr, img_path, path), (cam, t), res) in enumerate(zip(todo, metas, results)):
             if res is None:
-                print('no valid pixel in', identifier, file=sys.stderr)
+                why = 'a pole in view: --resolution yields no longitude resolution for' if \
+                    seq.plans[k] == 'pole-without-resolution' else 'no valid pixel in'
+                print(why, identifier, file=sys.stderr)
                 continue
             host = dict(res)
             host.update(grid_coordinates(res))
@@ -326,7 +331,10 @@ def main(argv=None):
                      includeGeoCoords=not args.withoutGeo,
                      format='NETCDF4' if args.netcdfContainer == 'netcdf4' else 'NETCDF3_64BIT')
     os.makedirs(args.out, exist_ok=True)
-    if args.resample and args.pxPerDeg:
+    # --resample, with the reference's --resolution (default 100 arcsec per pixel) or with --px-per-deg: the sequence pipeline;
+    # without --resample the frames are exported as they are, through the mapping classes (AMT_CONVERT_CLASSES=1 sends
+    # resampling runs that way too: the reference's flow frame by frame, for A/B runs)
+    if args.resample and not os.environ.get('AMT_CONVERT_CLASSES'):
         convert_with_pipeline(args, frames, export)
     else:
         convert_with_classes(args, frames, export)

@@ -501,7 +501,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
                                                            int n_items, int n_frames) {
     constexpr bool MAG = SECOND != 0, kPole = SECOND == 2, kMagPole = SECOND == 3, kMagOnly = SECOND == 4;
     static_assert(!(kPole || kMagPole) || (BIN != 0 && !DIRS_IN), "the pole plans exist for fused binning with the camera model only");
-    static_assert(!kMagOnly || (BIN != 0 && !DIRS_IN), "the MLat / MLT-only mode exists for fused binning with the camera model only");
+    static_assert(!kMagOnly || !DIRS_IN, "the MLat / MLT-only mode exists for the camera model only");
     constexpr int kBinWaves = BIN ? kRowsThreads / 64 : 1, kBinSlots = BIN ? kBinCells : 1;
     __shared__ unsigned int sCnt[kBinWaves][kBinSlots];
     __shared__ unsigned int sCh[kBinWaves][3][kBinSlots];
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
     // range-reduced 9-term arctangents), and a centre's as its corner's plus a small angle.  The full arctangent
     // runs where that does not apply: first row of a chunk, previous row missed the shell, steps above 1.7 deg at
     // the limb, within 2 deg of the date line.
-    constexpr bool kMagBox = MAG && BIN != 0;      // the box may be asked for in (MLat, SM longitude): bla / blo
+    constexpr bool kMagBox = (MAG && BIN != 0) || kMagOnly;      // the box may be asked for in (MLat, SM longitude): bla / blo
     // Pole plan (bin_pole; SECOND = 2, the machinery of the MLat / MLT variants on another second pair of angles): the reference rotates a
     // frame with a pole in view by +90 deg about x before binning (resample.py:176-201: geodetic -> ECEF at the mapping
     // altitude -> rotation -> geodetic).  Here: the point is rebuilt from the Bowring numerator / denominator of its
@@ -1313,7 +1313,7 @@ void launch_rows_bin(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 gri
                      int n_items, launch_events ev) {
     const dim3 block(kRowsThreads);
     if (second == 4) {
-        if constexpr (BIN != 0 && !DIRS_IN)
+        if constexpr (!DIRS_IN)
             hipExtLaunchKernelGGL((k_georef_rows<FAST, DIRS_IN, 4, BIN>), grid, block, 0, ctx->stream, ev.start, ev.stop, 0, B,
                                   rows, strips_x, n_items, n_frames);
     } else if (second == 3) {
@@ -1725,6 +1725,12 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
             A.bin_event_cap = out->bin_event_capacity;
         }
         bin = out->bin_img_dtype;
+    } else if (out->bin_magnetic) {
+        // without fused binning: the bounding box alone in (MLat, SM longitude) — the MLat / MLT-only variant without an image
+        // (the box pass of resampleMLatMLT(arcsecPerPx=...), amt_pipe_launch_box)
+        AMT_REQUIRE(ctx, dirs == nullptr && !out->lat && !out->lon && !out->lat_c && !out->lon_c,
+                    "bin_magnetic without bin_acc (the box in MLat / SM longitude) excludes the geodetic outputs and caller-supplied directions");
+        A.bin_magnetic = 1;
     }
     const launch_shape sh = shape_of(p);
     A.chunk_stride = interleave_stride(sh.chunks_y);
@@ -1785,9 +1791,13 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     // MLat / MLT only (SECOND = 4): a (MLat, SM longitude) grid without a pole plan whose caller wants none of the four
     // geodetic arrays — what resampleMLatMLT consumes (reference mapping.py:1519-1547); AMT_NO_MAG_ONLY=1: A/B runs
     static const bool no_mag_only = std::getenv("AMT_NO_MAG_ONLY") != nullptr;
-    if (F->second == 1 && bin && A.bin_magnetic && dirs == nullptr && !use_tiles && !no_mag_only && !A.lat && !A.lon && !A.lat_c &&
-        !A.lon_c)
-        F->second = 4;
+    const bool no_geo_out = !A.lat && !A.lon && !A.lat_c && !A.lon_c;
+    if (F->second == 1 && dirs == nullptr && !use_tiles && no_geo_out) {
+        // fused binning on the MLat / MLT grid; without binning: the box in (MLat, SM longitude) (bin_magnetic alone), or
+        // MLat / MLT arrays and no box at all (what BaseAstrometryMapping.mLatMlt asks for)
+        if (bin ? (A.bin_magnetic && !no_mag_only) : (A.bin_magnetic || (!out->bbox && !no_mag_only))) F->second = 4;
+    }
+    AMT_REQUIRE(ctx, bin || !A.bin_magnetic || F->second == 4, "bin_magnetic without bin_acc needs the row-marching kernel");
     F->bin = bin;
     return AMT_OK;
 }

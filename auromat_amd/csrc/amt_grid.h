@@ -103,4 +103,93 @@ inline bool layout(double lat_ppd, double lon_ppd, double lat_min, double lat_ma
     return true;
 }
 
+
+// ---- plateCarreeResolution (reference auromat/resample.py:36-61) ------------------------------------------------------
+// The same arithmetic as auromat_amd/coordinates/geodesic.py angularDistanceOnParallel + auromat_amd/resample.py
+// plateCarreeResolution (see there: the a12 of geographiclib's Inverse for two points on one parallel, from Karney's
+// integral formulation with 48-point Gauss-Legendre quadrature and a bisection for the azimuth at the node), so that a C
+// host — and the sequence runner — derives px/deg from a frame's own bounding box like `resample(arcsecPerPx=...)` does.
+inline void gauss_legendre(int n, double* x, double* w) {
+    for (int i = 0; i < (n + 1) / 2; ++i) {
+        double z = std::cos(M_PI * (i + 0.75) / (n + 0.5)), pp = 1;
+        for (int it = 0; it < 100; ++it) {
+            double p1 = 1, p2 = 0;
+            for (int j = 0; j < n; ++j) {
+                const double p3 = p2;
+                p2 = p1;
+                p1 = ((2 * j + 1) * z * p2 - j * p3) / (j + 1);
+            }
+            pp = n * (z * p1 - p2) / (z * z - 1);
+            const double z1 = z;
+            z = z1 - p1 / pp;
+            if (std::fabs(z - z1) < 1e-16) break;
+        }
+        x[i] = -z, x[n - 1 - i] = z;
+        w[i] = w[n - 1 - i] = 2 / ((1 - z * z) * pp * pp);
+    }
+}
+
+// angularDistance(Location(lat, lon0), Location(lat, lon0 + dlon)) in degrees, |dlon| < 180; false when there is no
+// symmetric geodesic for that longitude difference (the Python function raises ValueError there)
+inline bool angular_distance_on_parallel(double lat, double dlon, double* out) {
+    constexpr int kN = 48;
+    static double nodes[kN], weights[kN];
+    static const bool ready = (gauss_legendre(kN, nodes, weights), true);
+    (void)ready;
+    dlon = std::fabs(dlon);
+    if (dlon == 0) {
+        *out = 0;
+        return true;
+    }
+    if (!(dlon < 180)) return false;
+    const double f = 1 / 298.257223563;
+    const double ep2 = f * (2 - f) / ((1 - f) * (1 - f));
+    const double beta = std::atan((1 - f) * std::tan(std::fabs(lat) * M_PI / 180.0));
+    const double lam = dlon * M_PI / 180.0;
+    const double sb = std::sin(beta);
+    if (sb < 1e-12) {
+        if (!(dlon <= 180 * (1 - f))) return false;
+        *out = dlon / (1 - f);
+        return true;
+    }
+    auto lam_of = [&](double ca0, double* sigma12) {
+        const double sa0 = std::sqrt(std::fmax(0.0, 1 - ca0 * ca0));
+        const double s_p = ca0 > 0 ? std::asin(std::fmin(1.0, sb / ca0)) : M_PI / 2;
+        const double om_p = std::atan2(sa0 * std::sin(s_p), std::cos(s_p));
+        const double half = (M_PI / 2 - s_p) / 2, mid = (M_PI / 2 + s_p) / 2;
+        const double k2 = ep2 * ca0 * ca0;
+        double sum = 0;
+        for (int i = 0; i < kN; ++i) {
+            const double sn = std::sin(mid + half * nodes[i]);
+            sum += weights[i] * (2 - f) / (1 + (1 - f) * std::sqrt(1 + k2 * sn * sn));
+        }
+        *sigma12 = M_PI - 2 * s_p;
+        return 2 * (M_PI / 2 - om_p) - f * sa0 * 2 * (half * sum);
+    };
+    double lo = std::fmax(sb, 1e-300), hi = 1.0, sig;
+    if (lam_of(hi, &sig) < lam) return false;
+    for (int it = 0; it < 200; ++it) {
+        const double midc = 0.5 * (lo + hi);
+        if (lam_of(midc, &sig) < lam) lo = midc; else hi = midc;
+        if (hi - lo <= 4e-16 * hi) break;
+    }
+    lam_of(0.5 * (lo + hi), &sig);
+    *out = sig * 180.0 / M_PI;
+    return true;
+}
+
+// (latPxPerDeg, lonPxPerDeg) for a BoundingBox(latSouth, lonWest, latNorth, lonEast) and a spherical resolution
+inline bool plate_carree_resolution(double lat_south, double lon_west, double lat_north, double lon_east, double arcsec_per_px,
+                                    double* lat_ppd, double* lon_ppd) {
+    if (!(arcsec_per_px > 0)) return false;
+    const double deg_per_px = arcsec_per_px / 3600.0;
+    const double lat_middle = (lat_north + lat_south) / 2;
+    const double lons = lon_west > lon_east ? lon_east + 360 - lon_west : lon_east - lon_west;
+    double dist;
+    if (!(lons > 0) || !angular_distance_on_parallel(lat_middle, std::fmin(lons, 360 - lons), &dist)) return false;
+    *lat_ppd = 1 / deg_per_px;
+    *lon_ppd = (dist / deg_per_px) / lons;
+    return true;
+}
+
 }  // namespace amt_gl

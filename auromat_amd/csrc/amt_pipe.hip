@@ -164,6 +164,13 @@ int amt_grid_layout(double lat_px_per_deg, double lon_px_per_deg, double lat_min
                                                                                                        : AMT_EINVAL;
 }
 
+int amt_plate_carree_resolution(double lat_south, double lon_west, double lat_north, double lon_east, double arcsec_per_px,
+                                double* lat_px_per_deg, double* lon_px_per_deg) {
+    if (lat_px_per_deg == nullptr || lon_px_per_deg == nullptr) return AMT_EINVAL;
+    return amt_gl::plate_carree_resolution(lat_south, lon_west, lat_north, lon_east, arcsec_per_px, lat_px_per_deg,
+                                           lon_px_per_deg) ? AMT_OK : AMT_EINVAL;
+}
+
 int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe) {
     AMT_CHECK_CTX(ctx);
     AMT_REQUIRE(ctx, out_pipe != nullptr, "out_pipe is NULL");
@@ -261,6 +268,11 @@ int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevat
 
 namespace {
 
+int pipe_wait_tail(amt_pipe* pipe);
+int pipe_prepare_rest(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
+                      int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
+                      int magnetic, int mode, amt_georef_out* o_out, amt_georef_tail* tail_out);
+
 // Everything amt_pipe_launch does before the big kernel: wait for the coarse box, superset grid, accumulators,
 // kernel outputs (`o`) and the tail description for this frame.
 int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
@@ -289,7 +301,15 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
     pipe->img_dtype = img_dtype;
     pipe->fused = false;
 
-    // the folds / finalise of the previous frame on this driver still use the partials and the accumulators
+    if (int rc = pipe_wait_tail(pipe)) return rc;
+    if (int rc = ensure_partials(pipe, amt_georef_partials_bytes(p))) return rc;
+    return pipe_prepare_rest(pipe, p, out, img, img_dtype, min_elevation, lat_px_per_deg, lon_px_per_deg, magnetic, mode, o_out,
+                             tail_out);
+}
+
+// the folds / finalise of the previous frame on this driver still use the partials and the accumulators
+int pipe_wait_tail(amt_pipe* pipe) {
+    amt_ctx* ctx = pipe->ctx;
     if (pipe->tail_pending) {
         // usually long finished (the host saw the frame's bounding box): then no packet goes on the stream.  A host
         // that is quick (the native sequence runner launches the next batch microseconds after it enqueued this driver's
@@ -307,8 +327,13 @@ int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out
         if (!done) AMT_HIP(ctx, hipStreamWaitEvent(ctx->stream, pipe->tail_done, 0));
         pipe->tail_pending = false;
     }
-    if (int rc = ensure_partials(pipe, amt_georef_partials_bytes(p))) return rc;
+    return AMT_OK;
+}
 
+int pipe_prepare_rest(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
+                      int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
+                      int magnetic, int mode, amt_georef_out* o_out, amt_georef_tail* tail_out) {
+    amt_ctx* ctx = pipe->ctx;
     amt_georef_out& o = *o_out;
     o = *out;
     o.bbox = pipe->host_small_dev + 8;          // the last fold writes straight into pinned host memory
@@ -423,10 +448,19 @@ int amt_pipe_launch_many(amt_pipe* const* pipes, int32_t n, const amt_frame_para
                          const amt_georef_out* const* out, const void* const* img, int32_t img_dtype,
                          double min_elevation, double lat_px_per_deg, double lon_px_per_deg, int pole_in_view,
                          int magnetic) {
+    double la[AMT_MAX_BATCH], lo[AMT_MAX_BATCH];
+    for (int i = 0; i < AMT_MAX_BATCH; ++i) la[i] = lat_px_per_deg, lo[i] = lon_px_per_deg;
+    return amt_pipe_launch_many_res(pipes, n, p, out, img, img_dtype, min_elevation, la, lo, pole_in_view, magnetic);
+}
+
+int amt_pipe_launch_many_res(amt_pipe* const* pipes, int32_t n, const amt_frame_params* const* p,
+                             const amt_georef_out* const* out, const void* const* img, int32_t img_dtype,
+                             double min_elevation, const double* lat_px_per_deg, const double* lon_px_per_deg,
+                             int pole_in_view, int magnetic) {
     if (pipes == nullptr || n < 1 || pipes[0] == nullptr) return AMT_EINVAL;
     amt_ctx* ctx = pipes[0]->ctx;
     AMT_REQUIRE(ctx, n <= AMT_MAX_BATCH, "at most AMT_PIPE_MAX_BATCH frames per launch");
-    AMT_REQUIRE(ctx, p && out && img, "NULL argument");
+    AMT_REQUIRE(ctx, p && out && img && lat_px_per_deg && lon_px_per_deg, "NULL argument");
     amt_georef_out o[AMT_MAX_BATCH];
     amt_georef_tail tails[AMT_MAX_BATCH];
     const amt_georef_out* op[AMT_MAX_BATCH];
@@ -434,8 +468,8 @@ int amt_pipe_launch_many(amt_pipe* const* pipes, int32_t n, const amt_frame_para
     for (int i = 0; i < n; ++i) {
         AMT_REQUIRE(ctx, pipes[i] != nullptr && pipes[i]->ctx == ctx, "drivers of one launch must share the context");
         for (int k = 0; k < i; ++k) AMT_REQUIRE(ctx, pipes[k] != pipes[i], "a driver can hold one frame of a launch");
-        if (int rc = pipe_prepare(pipes[i], p[i], out[i], img[i], img_dtype, min_elevation, lat_px_per_deg,
-                                  lon_px_per_deg, pole_in_view, magnetic, &o[i], &tails[i]))
+        if (int rc = pipe_prepare(pipes[i], p[i], out[i], img[i], img_dtype, min_elevation, lat_px_per_deg[i],
+                                  lon_px_per_deg[i], pole_in_view, magnetic, &o[i], &tails[i]))
             return rc;
         op[i] = &o[i];
         tp[i] = &tails[i];
@@ -444,6 +478,57 @@ int amt_pipe_launch_many(amt_pipe* const* pipes, int32_t n, const amt_frame_para
     for (int i = 0; i < n; ++i)
         if (int rc = pipe_after_launch(pipes[i])) return rc;
     return AMT_OK;
+}
+
+int amt_pipe_launch_box_many(amt_pipe* const* pipes, int32_t n, const amt_frame_params* const* p, double min_elevation,
+                             int magnetic) {
+    if (pipes == nullptr || n < 1 || pipes[0] == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipes[0]->ctx;
+    AMT_REQUIRE(ctx, n <= AMT_MAX_BATCH, "at most AMT_PIPE_MAX_BATCH frames per launch");
+    AMT_REQUIRE(ctx, p != nullptr, "NULL argument");
+    magnetic = magnetic ? 1 : 0;
+    amt_georef_out o[AMT_MAX_BATCH];
+    amt_georef_tail tails[AMT_MAX_BATCH];
+    const amt_georef_out* op[AMT_MAX_BATCH];
+    const amt_georef_tail* tp[AMT_MAX_BATCH];
+    for (int i = 0; i < n; ++i) {
+        amt_pipe* pipe = pipes[i];
+        AMT_REQUIRE(ctx, pipe != nullptr && pipe->ctx == ctx && p[i] != nullptr, "drivers of one launch must share the context");
+        for (int k = 0; k < i; ++k) AMT_REQUIRE(ctx, pipes[k] != pipe, "a driver can hold one frame of a launch");
+        // (an estimate that is still pending belongs to another plan of this frame: dropped)
+        if (pipe->coarse_pending && !pipe->coarse_hinted) AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
+        pipe->coarse_pending = pipe->coarse_hinted = false;
+        pipe->pole = pole_visible(p[i], min_elevation, magnetic) ? 1 : 0;
+        pipe->pole_plan = false;
+        pipe->lat_ppd = pipe->lon_ppd = 0;
+        pipe->min_elev = min_elevation;
+        pipe->fused = false;
+        pipe->general_ready = false;
+        pipe->lon_wrap = 0;
+        pipe->g_lat_c = pipe->g_lon_c = pipe->g_elev = nullptr;
+        pipe->g_img = nullptr;
+        if (int rc = pipe_wait_tail(pipe)) return rc;
+        if (int rc = ensure_partials(pipe, amt_georef_partials_bytes(p[i]))) return rc;
+        std::memset(&o[i], 0, sizeof(o[i]));
+        o[i].bbox = pipe->host_small_dev + 8;
+        o[i].bbox_min_elevation = min_elevation;
+        o[i].bin_magnetic = magnetic;          // without bin_acc: the box in (MLat, SM longitude)
+        tails[i].stream = pipe->tail_stream;
+        tails[i].kernel_done = pipe->kernel_done;
+        tails[i].partials = pipe->partials;
+        tails[i].partials_bytes = pipe->partials_bytes;
+        op[i] = &o[i];
+        tp[i] = &tails[i];
+    }
+    if (int rc = amt_georef_launch_many(ctx, n, p, op, tp)) return rc;
+    for (int i = 0; i < n; ++i)
+        if (int rc = pipe_after_launch(pipes[i])) return rc;
+    return AMT_OK;
+}
+
+int amt_pipe_launch_box(amt_pipe* pipe, const amt_frame_params* p, double min_elevation, int magnetic) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    return amt_pipe_launch_box_many(&pipe, 1, &p, min_elevation, magnetic);
 }
 
 int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,

@@ -224,7 +224,7 @@ class BaseAstrometryMapping(BaseMapping):
         img = self._img_array
         return img is not None and getattr(img, 'ndim', 0) == 3 and img.shape[2] == 3 and img.dtype in (np.uint8, np.uint16)
 
-    def _fused_resample(self, pxPerDeg, containsPole=None, magnetic=False):
+    def _fused_resample(self, pxPerDeg, containsPole=None, magnetic=False, arcsecPerPx=None):
         """
         resample() / resampleMLatMLT() of this mapping through the single-pass plan (FramePipeline.run(fuse=True): the
         binning inside the georeferencing kernel, no per-pixel array is written or read back) -> the result dict of
@@ -236,9 +236,18 @@ class BaseAstrometryMapping(BaseMapping):
         from ..pipeline import fused_class_pipeline
         hdr = self._wcsHeader
         pipe = fused_class_pipeline(hdr['IMAGEW'], hdr['IMAGEH'], self._img_array.dtype, magnetic)
+        params = None
+        if arcsecPerPx:
+            # the reference's own call form (cli/convert.py:176-185, test/mapping_test.py:24-42): px/deg from this frame's
+            # bounding box — the box-first plan (FramePipeline.run).  With a pole in view the reference's
+            # plateCarreeResolution has no longitude resolution to offer: that case stays with the array route
+            params = frame_params(hdr, self.altitude, self.cameraPosGCRS, self.photoTime, self.fastCenterCalculation,
+                                  magnetic=bool(magnetic))
+            if pole_in_view(params, self._lazy_elev, magnetic=bool(magnetic)):
+                return None
         res = pipe.run(hdr, self.altitude, self.cameraPosGCRS, self.photoTime, img=self._img_array,
                        fast=self.fastCenterCalculation, min_elevation=self._lazy_elev, pxPerDeg=pxPerDeg,
-                       containsPole=containsPole, magnetic=magnetic, fuse=True)
+                       containsPole=containsPole, magnetic=magnetic, fuse=True, arcsecPerPx=arcsecPerPx, params=params)
         res['plan'] = pipe.last_plan
         return res
 

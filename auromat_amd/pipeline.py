@@ -239,6 +239,34 @@ class FramePipeline(object):
             self._pcall('amt_pipe_coarse', C.byref(params),
                         NEG_INF if min_elevation is None else float(min_elevation), 1 if magnetic else 0)
 
+    def box_first(self, params, min_elevation, magnetic=False):
+        """
+        The box pass of the box-first plan (amt_pipe_launch_box): the frame kernel without any output array, image or
+        binning -> the exact 8-number bounding-box reduction of the corners that survive maskedByElevation, in (lat, lon) or,
+        with `magnetic`, (MLat, SM longitude); [7] = 1 when a pole of those coordinates is in view (camera model).  One
+        host synchronisation.  Raises EmptyFrame when no pixel is valid.
+        """
+        Context.current(self.ctx.device)
+        self._pcall('amt_pipe_launch_box', C.byref(params), NEG_INF if min_elevation is None else float(min_elevation),
+                    1 if magnetic else 0)
+        res = PipeResult()
+        self._pcall('amt_pipe_wait', C.byref(res))
+        if res.status == 2 or res.bbox[6] == 0:
+            self.last_plan = 'empty'
+            raise EmptyFrame('minElevation=' + str(min_elevation) + ' would mask all pixels!')
+        return list(res.bbox)
+
+    def resolution_from_box(self, params, min_elevation, arcsecPerPx, magnetic=False):
+        """
+        `resample(mapping, arcsecPerPx=R)` derives px/deg from the mapping's own bounding box (reference resample.py:36-61,
+        104-107): the box pass, plateCarreeResolution on its BoundingBox -> ((latPxPerDeg, lonPxPerDeg), reduction).  The
+        reduction is what the following single-pass launch takes as its estimate (`hint`), so that launch needs no
+        pre-pass and its superset grid always holds the exact one.
+        """
+        from .resample import plateCarreeResolution
+        red = self.box_first(params, min_elevation, magnetic)
+        return plateCarreeResolution(bounding_box_from_reduction(red), arcsecPerPx), red
+
     def _wait_fused(self):
         """amt_pipe_wait once per launch -> the amt_pipe_result."""
         f = self._fused
@@ -310,11 +338,19 @@ class FramePipeline(object):
         pp = (C.c_void_p * n)(*[C.addressof(p) for p in params])
         oo = (C.c_void_p * n)(*[C.addressof(q._out) for q in pipes])
         ii = (C.c_void_p * n)(*[q.fd.img.data_ptr() for q in pipes])
-        ctx.check(ctx._lib.amt_pipe_launch_many(handles, n, pp, oo, ii, pipes[0].fd.img_dtype_code, min_elev,
-                                                float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1, mag))
-        for q, p, altitude in zip(pipes, params, altitudes):
+        # one resolution for all frames, or a list with one (latPxPerDeg, lonPxPerDeg) per frame (arcsecPerPx: every frame's
+        # px/deg follows from its own bounding box)
+        per_frame = isinstance(fuse_pxPerDeg, list)
+        ppd = [tuple(v) for v in fuse_pxPerDeg] if per_frame else [tuple(fuse_pxPerDeg)] * n
+        if per_frame:
+            la, lo = (C.c_double * n)(*[float(v[0]) for v in ppd]), (C.c_double * n)(*[float(v[1]) for v in ppd])
+            ctx.check(ctx._lib.amt_pipe_launch_many_res(handles, n, pp, oo, ii, pipes[0].fd.img_dtype_code, min_elev, la, lo, -1, mag))
+        else:
+            ctx.check(ctx._lib.amt_pipe_launch_many(handles, n, pp, oo, ii, pipes[0].fd.img_dtype_code, min_elev,
+                                                    float(ppd[0][0]), float(ppd[0][1]), -1, mag))
+        for q, p, altitude, v in zip(pipes, params, altitudes, ppd):
             q.params, q.altitude, q.min_elevation = p, altitude, min_elevation
-            q._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
+            q._fused = dict(pxPerDeg=v, magnetic=bool(mag), result=None)
             q.fd.corner_mask = q.fd.center_mask = None
             q._coords_valid = q.fd.lat is not None and q.with_geo
             q._kept_valid = q.fd.elev is not None
@@ -363,8 +399,10 @@ class FramePipeline(object):
 
     def fused_ready(self, pxPerDeg, magnetic):
         """The amt_pipe_result of the single-pass launch in flight when the driver can finalise it for this resolution
-        and grid (waits for the frame's bounding box), else None (no such launch, or the frame needs the general path)."""
-        if self._fused is None or self._fused['pxPerDeg'] != tuple(pxPerDeg) or self._fused['magnetic'] != bool(magnetic):
+        (None: whatever resolution it was launched with) and grid (waits for the frame's bounding box), else None (no such
+        launch, or the frame needs the general path)."""
+        if self._fused is None or self._fused['magnetic'] != bool(magnetic) or \
+                (pxPerDeg is not None and self._fused['pxPerDeg'] != tuple(pxPerDeg)):
             return None
         res = self._wait_fused()
         return res if res.status == 0 else None
@@ -463,9 +501,9 @@ class FramePipeline(object):
         if all(q._finalize_stream().cuda_stream == fin and q.consumer_stream == pipes[0].consumer_stream for q in pipes):
             mem = pipes[0]._fused_alloc(sum(sizes), torch.cuda.current_stream(ctx.device))
             offs = [sum(sizes[:i]) for i in range(n)]
-            outs = [q._fused_outputs(r, pxPerDeg, mem, o) for q, r, o in zip(pipes, results, offs)]
+            outs = [q._fused_outputs(r, pxPerDeg or q._fused['pxPerDeg'], mem, o) for q, r, o in zip(pipes, results, offs)]
         else:
-            outs = [q._fused_outputs(r, pxPerDeg) for q, r in zip(pipes, results)]
+            outs = [q._fused_outputs(r, pxPerDeg or q._fused['pxPerDeg']) for q, r in zip(pipes, results)]
         handles = (C.c_void_p * n)(*[q._pipe() for q in pipes])
         arr = lambda k: (C.c_void_p * n)(*[o[k].data_ptr() for o in outs])
         ctx.check(ctx._lib.amt_pipe_finalize_many(handles, n, arr(2), arr(4), arr(5), arr(3)))
@@ -525,17 +563,34 @@ class FramePipeline(object):
                               min_elevation=self.min_elevation, keep_on_device=keep_on_device, shard=self.shard)
 
     def run(self, wcsHeader, altitude, cameraPosGCRS, photoTime, img=None, fast=True, min_elevation=10.0,
-            pxPerDeg=10, containsPole=None, magnetic=False, params=None, keep_on_device=False, fuse=False):
-        """One frame end to end; returns the dict of :func:`auromat_amd.resample.resample_frame`."""
+            pxPerDeg=10, containsPole=None, magnetic=False, params=None, keep_on_device=False, fuse=False,
+            arcsecPerPx=None):
+        """One frame end to end; returns the dict of :func:`auromat_amd.resample.resample_frame`.  `arcsecPerPx` (has
+        precedence over pxPerDeg, like the reference's resample()): the box-first plan — a box pass, px/deg from the frame's
+        own bounding box, then the single-pass launch (``fuse``) or the two-pass plan; the px/deg pair used is in the
+        result as 'pxPerDeg'."""
         if img is not None:
             self.set_image(img)
+        coarse_started = False
+        if arcsecPerPx:
+            if params is None:
+                params = frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fast, magnetic=self.with_mag)
+            pxPerDeg, red = self.resolution_from_box(params, min_elevation, arcsecPerPx, magnetic)
+            # (a pole in view: the reference's plateCarreeResolution gives no longitude resolution for a box that goes all
+            # around, resample.py:47-61 — nothing to bin into, there as here)
+            assert pxPerDeg[1] > 0, 'arcsecPerPx with a pole in view: plateCarreeResolution yields lonPxPerDeg = 0 (as the reference)'
+            if fuse and not red[7]:
+                self.start_coarse(params, min_elevation, magnetic, hint=red)
+                coarse_started = True
         try:
             _, _ = pxPerDeg
         except TypeError:
             pxPerDeg = (pxPerDeg, pxPerDeg)
         self.georef(wcsHeader, altitude, cameraPosGCRS, photoTime, fast, min_elevation, params=params,
-                    fuse_pxPerDeg=pxPerDeg if fuse else None, fuse_magnetic=bool(magnetic))
-        return self.resample(pxPerDeg, containsPole, magnetic, keep_on_device=keep_on_device)
+                    fuse_pxPerDeg=pxPerDeg if fuse else None, fuse_magnetic=bool(magnetic), coarse_started=coarse_started)
+        res = self.resample(pxPerDeg, containsPole, magnetic, keep_on_device=keep_on_device)
+        res['pxPerDeg'] = tuple(pxPerDeg)
+        return res
 
     def host_arrays(self, kept_only=False):
         """Raw (NaN = missing) coordinate arrays of the last frame as NumPy arrays.  `kept_only`: only the arrays the
@@ -762,7 +817,7 @@ class SequencePipeline(object):
     def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, altitude=110, fast=True,
                  min_elevation=10.0, pxPerDeg=10, plan='single-pass', bin_stream=True, shared_image=None,
                  magnetic=False, batch=3, own_image_buffers=True, keep_coordinates=True, launch_streams=1,
-                 geodetic_arrays=None):
+                 geodetic_arrays=None, arcsecPerPx=None):
         import torch
         assert plan in ('single-pass', 'two-pass')
         try:
@@ -770,6 +825,14 @@ class SequencePipeline(object):
         except TypeError:
             pxPerDeg = (pxPerDeg, pxPerDeg)
         self.pxPerDeg = tuple(pxPerDeg)
+        # arcsecPerPx (has precedence over pxPerDeg, like the reference's resample(); what `auromat-convert --resample
+        # --resolution R` passes, cli/convert.py:176-185): every frame's px/deg follows from its own bounding box
+        # (plateCarreeResolution, resample.py:36-61) — the box-first plan: a box pass of the frame kernel two batches ahead of
+        # the frame's single-pass launch, which takes the exact box as its estimate (process -> _process_box_first)
+        self.arcsecPerPx = float(arcsecPerPx) if arcsecPerPx else None
+        if self.arcsecPerPx:
+            assert plan == 'single-pass' and nchan == 3, 'arcsecPerPx: the box-first plan is a single-pass plan (RGB images)'
+            self.pxPerDeg = None
         self.altitude, self.fast, self.min_elevation = altitude, fast, min_elevation
         self.single_pass = plan == 'single-pass' and nchan == 3
         self.nchan = nchan
@@ -792,7 +855,7 @@ class SequencePipeline(object):
         self.pipes = [FramePipeline(width, height, nchan, img_dtype, device, with_mag=self.magnetic,
                                     alloc_image=own_image_buffers and (shared_image is None or i == 0),
                                     alloc_coords=keep_coordinates or not self.single_pass, with_geo=self.geodetic_arrays)
-                      for i in range(2 * self.batch if self.single_pass else 4)]
+                      for i in range((3 if self.arcsecPerPx else 2) * self.batch if self.single_pass else 4)]
         self.ctx = self.pipes[0].ctx
         if shared_image is not None:
             # every frame shows the same image (synthetic benchmarks): upload it once, both buffers alias it
@@ -878,8 +941,9 @@ class SequencePipeline(object):
             self.hinted += hint is not None
         return p, cam, t, img, alt
 
-    def _launch(self, k0, prepared):
-        """Launch the frames k0, k0+1, ... (one batch; prepared = their _prepare results)."""
+    def _launch(self, k0, prepared, pxPerDeg=None):
+        """Launch the frames k0, k0+1, ... (one batch; prepared = their _prepare results).  `pxPerDeg`: a list with one
+        resolution per frame instead of the pipeline's."""
         import torch
         nb = len(self.pipes)
         qs = [self.pipes[(k0 + i) % nb] for i in range(len(prepared))]
@@ -907,7 +971,7 @@ class SequencePipeline(object):
                 s_main.wait_event(uploaded)
             if self.single_pass:
                 FramePipeline.georef_many(qs, [pr[0] for pr in prepared], [pr[4] for pr in prepared],
-                                          self.min_elevation, self.pxPerDeg, self.magnetic)
+                                          self.min_elevation, pxPerDeg if pxPerDeg is not None else self.pxPerDeg, self.magnetic)
                 # a later upload into a buffer of the pipeline's own must wait until this launch has read it; frames that
                 # read the caller's device-resident images need no event (each one is a packet on the stream of big
                 # kernels: 5 us between two launches)
@@ -933,7 +997,8 @@ class SequencePipeline(object):
             if two_streams:
                 s_bin.wait_event(self._geo_done[slot])
             try:
-                res = q.resample(self.pxPerDeg, magnetic=self.magnetic, keep_on_device=keep_on_device)
+                res = q.resample(self.pxPerDeg if self.pxPerDeg is not None else q._fused['pxPerDeg'], magnetic=self.magnetic,
+                                 keep_on_device=keep_on_device)
             except EmptyFrame:
                 # no pixel of this frame is valid (looking off the limb, or min_elevation masks everything; the
                 # reference raises ValueError there, mapping.py:858-859): the sequence goes on, the frame's place in
@@ -1121,6 +1186,137 @@ class SequencePipeline(object):
         self._frames_done += n
         return NativeResults(self, rec, grids, images, fallbacks, keep_on_device)
 
+    def _process_box_first(self, frames, keep_on_device, on_batch=None):
+        """
+        process() with a resolution per frame (arcsecPerPx).  Three stages per batch of frames, software-pipelined over 3 x
+        batch frame buffers so that the GPU never waits for the host:
+
+            box(j)     the box pass of the batch's frames (ONE launch of the frame kernel without outputs, image or binning:
+                       amt_pipe_launch_box_many), enqueued two batches ahead
+            launch(j)  wait for those boxes (long finished), plateCarreeResolution per frame, the exact box as the estimate
+                       of the single-pass launch (no pre-pass; its superset grid always holds the exact grid), ONE launch of
+                       the fused kernel with a resolution per frame (amt_pipe_launch_many_res)
+            finish(j)  wait for the exact boxes of the fused launch, lay out the grids, one finalise kernel
+
+        in the order box(0) box(1) | launch(j) finish(j-1) box(j+2) | ..., i.e. on the stream: box(j+1), fused(j), box(j+2),
+        fused(j+1), ...  A frame with a pole of its grid in view has no longitude resolution under plateCarreeResolution
+        (reference resample.py:47-61: its box goes all around; the class API and the reference fail on it): its place in
+        the results holds None and its entry in `plans` reads 'pole-without-resolution'; a frame without a valid pixel
+        yields None / 'empty' as always.
+        """
+        import torch
+        from .resample import plateCarreeResolution
+        if self._run is not None:
+            self._hint_native_reset()
+        self._hint = self._hint_prev = None
+        out = []
+        it = iter(frames)
+        B, nb = self.batch, len(self.pipes)
+        caller = torch.cuda.current_stream(self.ctx.device)
+        for q in self.pipes:
+            q.consumer_stream = caller
+        min_elev = NEG_INF if self.min_elevation is None else float(self.min_elevation)
+        mag = 1 if self.magnetic else 0
+        lib, ctx = self.ctx._lib, self.ctx
+
+        def box(k0):
+            """Parameters + box pass of up to B frames starting at k0 -> list of (p, cam, t, img, alt), empty at the end."""
+            prepared = []
+            for i in range(B):
+                f = next(it, None)
+                if f is None:
+                    break
+                hdr, cam, t, img = f[:4]
+                alt = f[4] if len(f) > 4 and f[4] is not None else self.altitude
+                p = hdr if not isinstance(hdr, dict) else frame_params(hdr, alt, cam, t, self.fast, magnetic=self.magnetic)
+                prepared.append((p, cam, t, img, alt))
+            if prepared:
+                n = len(prepared)
+                qs = [self.pipes[(k0 + i) % nb] for i in range(n)]
+                with torch.cuda.stream(self.s_main):
+                    Context.current(ctx.device)
+                    handles = (C.c_void_p * n)(*[q._pipe() for q in qs])
+                    pp = (C.c_void_p * n)(*[C.addressof(pr[0]) for pr in prepared])
+                    ctx.check(lib.amt_pipe_launch_box_many(handles, n, pp, min_elev, mag))
+            return prepared
+
+        def launch(k0, prepared):
+            """-> per frame None (no valid pixel) or its (latPxPerDeg, lonPxPerDeg); the others are launched."""
+            ppd, live = [], []
+            for i, pr in enumerate(prepared):
+                q = self.pipes[(k0 + i) % nb]
+                res = PipeResult()
+                q._pcall('amt_pipe_wait', C.byref(res))
+                if res.status == 2 or res.bbox[6] == 0:
+                    ppd.append(None)
+                    continue
+                red = list(res.bbox)
+                v = plateCarreeResolution(bounding_box_from_reduction(red), self.arcsecPerPx)
+                if red[7] or not v[1] > 0:
+                    ppd.append('pole')
+                    continue
+                q.start_coarse(pr[0], self.min_elevation, self.magnetic, hint=red)
+                ppd.append(v)
+                live.append(i)
+            # the frames of the batch that have a valid pixel, as consecutive runs (a launch takes consecutive buffers)
+            i = 0
+            while i < len(live):
+                j = i
+                while j + 1 < len(live) and live[j + 1] == live[j] + 1:
+                    j += 1
+                self._launch(k0 + live[i], [prepared[m] for m in live[i:j + 1]], pxPerDeg=[ppd[m] for m in live[i:j + 1]])
+                i = j + 1
+            return ppd
+
+        def finish(k0, ppd):
+            res = []
+            i = 0
+            while i < len(ppd):
+                if ppd[i] is None or ppd[i] == 'pole':
+                    self.plans.append('empty' if ppd[i] is None else 'pole-without-resolution')
+                    res.append(None)
+                    i += 1
+                    continue
+                j = i
+                while j + 1 < len(ppd) and isinstance(ppd[j + 1], tuple):
+                    j += 1
+                part = self._finish_batch(k0 + i, j - i + 1, keep_on_device)
+                for r, v in zip(part, ppd[i:j + 1]):
+                    if r is not None:
+                        r['pxPerDeg'] = v
+                res.extend(part)
+                i = j + 1
+            return res
+
+        batches = {0: box(0)}
+        batches[1] = box(len(batches[0])) if batches[0] else []
+        starts = {0: 0, 1: len(batches[0])}
+        launched = {}
+        j = 0
+        while batches.get(j):
+            launched[j] = launch(starts[j], batches[j])
+            if j >= 1:
+                done = finish(starts[j - 1], launched.pop(j - 1))
+                out.extend(done)
+                if on_batch is not None:
+                    on_batch(starts[j - 1], done)
+                del batches[j - 1]
+            starts[j + 2] = starts[j + 1] + len(batches[j + 1])
+            batches[j + 2] = box(starts[j + 2]) if batches[j + 1] else []
+            j += 1
+        if j >= 1:
+            done = finish(starts[j - 1], launched.pop(j - 1))
+            out.extend(done)
+            if on_batch is not None:
+                on_batch(starts[j - 1], done)
+        with torch.cuda.stream(self.s_main):
+            for q in self.pipes:
+                q.join()
+        caller.wait_stream(self.s_main)
+        self._hint = self._hint_prev = None
+        self._frames_done += len(out)
+        return out
+
     def finalize_stream(self):
         """The stream the single-pass results are produced on (the drivers' finalise stream, shared by the pipeline's
         buffers): consumers that want to touch results before process() returns enqueue there."""
@@ -1141,8 +1337,12 @@ class SequencePipeline(object):
         import torch
         del self.plans[:]
         self.hinted = 0
-        if on_batch is None and self.native:
-            frames = list(frames)
+        if self.arcsecPerPx:
+            return self._process_box_first(frames, keep_on_device, on_batch)
+        if on_batch is None and self.native and isinstance(frames, (list, tuple)):
+            # (an iterator — the convert driver's read-ahead generator of decoded host images — is consumed frame by frame
+            # below: its images are not device-resident anyway, and materialising it would hold every decoded image of the
+            # sequence in host memory before the first launch)
             if self._native_applies(frames):
                 return self._process_native(frames, keep_on_device)
         if self._run is not None:

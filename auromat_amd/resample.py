@@ -37,10 +37,26 @@ def plateCarreeResolution(boundingBox, arcsecPerPx):
     from Karney's integral formulation to ~1e-14 relative, so ``round(pxPerDeg * 360 + 1)`` and with it the
     grid come out the same.
 
+    The arithmetic runs in the library (``amt_plate_carree_resolution``, csrc/amt_grid.h: the same formulation in C++, host
+    code, no GPU; microseconds where the NumPy bisection below takes a millisecond), so that the mapping classes, the
+    sequence pipeline's box-first plan and the native sequence runner all derive a frame's px/deg from ONE implementation;
+    :func:`plateCarreeResolution_py` is the Python restatement the tests pin it to.
+
     :type boundingBox: auromat_amd.mapping.mapping.BoundingBox
     :param arcsecPerPx: spherical resolution
     :rtype: tuple (latPxPerDeg, lonPxPerDeg)
     """
+    from ._native import lib
+    lat_ppd, lon_ppd = C.c_double(), C.c_double()
+    rc = lib().amt_plate_carree_resolution(float(boundingBox.latSouth), float(boundingBox.lonWest), float(boundingBox.latNorth),
+                                           float(boundingBox.lonEast), float(arcsecPerPx), C.byref(lat_ppd), C.byref(lon_ppd))
+    if rc != 0:
+        return plateCarreeResolution_py(boundingBox, arcsecPerPx)      # (raises what the Python restatement raises)
+    return lat_ppd.value, lon_ppd.value
+
+
+def plateCarreeResolution_py(boundingBox, arcsecPerPx):
+    """:func:`plateCarreeResolution` in Python (the restatement the library's C++ is checked against)."""
     degPerPx = arcsecPerPx / 3600.0
     latPxPerDeg = 1 / degPerPx
     latMiddle = (boundingBox.latNorth + boundingBox.latSouth) / 2
@@ -62,10 +78,13 @@ def resampleMLatMLT(mapping, **kw):
     """
     global last_plan
     fused = getattr(mapping, '_fused_resample', None)
-    if fused is not None and kw.get('method', 'mean') == 'mean' and not kw.get('arcsecPerPx') and \
+    if fused is not None and kw.get('method', 'mean') == 'mean' and \
             set(kw) <= {'pxPerDeg', 'containsPole', 'method', 'arcsecPerPx'}:
         # a camera mapping whose arrays nobody has asked for yet: the single-pass plan on the (MLat, SM longitude) grid
-        res = fused(_px_per_deg(kw.get('pxPerDeg', 25)), kw.get('containsPole'), magnetic=True)
+        # (arcsecPerPx: box-first, px/deg from the frame's own box in (MLat, SM longitude))
+        arcsec = kw.get('arcsecPerPx')
+        res = fused(None if arcsec else _px_per_deg(kw.get('pxPerDeg', 25)), kw.get('containsPole'), magnetic=True,
+                    arcsecPerPx=arcsec)
         if res is not None:
             last_plan = res['plan']
             img = ma.masked_array(res['img'], mask=np.repeat(res['mask'][:, :, None], res['img'].shape[2], 2))
@@ -121,10 +140,11 @@ def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=No
         global last_plan
         last_plan = None
         fused = getattr(mapping, '_fused_resample', None)
-        if fused is not None and method == 'mean' and not arcsecPerPx:
+        if fused is not None and method == 'mean':
             # a camera mapping whose arrays nobody has asked for yet (getMapping(...).maskedByElevation(e), the user
-            # guide's flow): georeferencing, mask, bounding box and binning in ONE kernel
-            res = fused(_px_per_deg(pxPerDeg), containsPole)
+            # guide's flow): georeferencing, mask, bounding box and binning in ONE kernel; with arcsecPerPx (the call form
+            # of the reference's CLI and tests) a box pass of the same kernel comes first (box-first plan)
+            res = fused(None if arcsecPerPx else _px_per_deg(pxPerDeg), containsPole, arcsecPerPx=arcsecPerPx)
             if res is not None:
                 last_plan = res['plan']
                 img = ma.masked_array(res['img'], mask=np.repeat(res['mask'][:, :, None], res['img'].shape[2], 2))

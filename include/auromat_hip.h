@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 /* 2: amt_georef_out grew (bin_pole, altitude); amt_rotate_pole_deg, amt_pipe_finalize_stream, amt_seq_* added (round 2) */
-/* 4: amt_georef_last_variant; the MLat / MLT-only mode of the fused frame kernel (see amt_georef_out) (round 4) */
+/* 4: amt_georef_last_variant; the MLat / MLT-only mode of the fused frame kernel (see amt_georef_out); the box-first plan
+ *    (amt_pipe_launch_box[_many], amt_pipe_launch_many_res, amt_plate_carree_resolution) (round 4) */
 #define AMT_ABI_VERSION 4
 
 #define AMT_OK 0
@@ -153,7 +154,9 @@ typedef struct amt_georef_out {
     uint64_t* bin_acc;
     int32_t bin_img_dtype;
     int32_t bin_lon_wrap;
-    int32_t bin_magnetic;          /* != 0: x = SM longitude (mltToSmLon(mlt)), y = MLat; bbox[0..6] then refer to these too */
+    int32_t bin_magnetic;          /* != 0: x = SM longitude (mltToSmLon(mlt)), y = MLat; bbox[0..6] then refer to these too.
+                                    * Without bin_acc: only that — the box in (MLat, SM longitude); lat, lon, lat_c, lon_c
+                                    * must then be NULL (MLat / MLT-only mode without binning) */
     /* Scheduling hint, no effect on results: order in which the frame's work items (strips of 63 columns x 16
      * rows, row-major) are dispatched.  1 = rows top to bottom, 2 = bottom to top, 3 = interleaved (rows of items in
      * the order (k * s) mod n with s near n / golden ratio; measured 7 % slower than 1 / 2 for a kernel run alone, equal
@@ -548,6 +551,30 @@ int amt_pipe_launch_many(amt_pipe* const* pipes, int32_t n, const amt_frame_para
                          const amt_georef_out* const* out, const void* const* img, int32_t img_dtype,
                          double min_elevation, double lat_px_per_deg, double lon_px_per_deg, int pole_in_view,
                          int magnetic);
+/* The same with a resolution per frame (lat_px_per_deg[n], lon_px_per_deg[n]): what `resample(arcsecPerPx=...)` needs,
+ * where px/deg follows from each frame's own bounding box (amt_plate_carree_resolution). */
+int amt_pipe_launch_many_res(amt_pipe* const* pipes, int32_t n, const amt_frame_params* const* p,
+                             const amt_georef_out* const* out, const void* const* img, int32_t img_dtype,
+                             double min_elevation, const double* lat_px_per_deg, const double* lon_px_per_deg,
+                             int pole_in_view, int magnetic);
+/* Box-first plan — `resample(mapping, arcsecPerPx=R)`, the reference's own call form (auromat/cli/convert.py:176-185,
+ * test/mapping_test.py:24-42): plateCarreeResolution (resample.py:36-61) needs the frame's EXACT bounding box before a grid
+ * can be laid out.  amt_pipe_launch_box enqueues the frame kernel with no output array, no image and no binning — ray,
+ * shell, coordinates, elevation mask, box reduction only — on the context's stream; the following amt_pipe_wait returns
+ * status 1 (or 2: no valid pixel) with bbox[0..6] = the exact reduction in (lat, lon), or with magnetic != 0 in (MLat,
+ * SM longitude), never rotated, and bbox[7] = pole in view (camera model).  The caller derives px/deg
+ * (amt_plate_carree_resolution on the BoundingBox of that reduction), hands the box back as the estimate
+ * (amt_pipe_coarse_hint with bbox[7] = 0; a pole frame runs amt_pipe_coarse instead: its grid lives in rotated coordinates)
+ * and launches the ordinary single-pass plan, whose superset grid then always contains the exact one. */
+int amt_pipe_launch_box(amt_pipe* pipe, const amt_frame_params* p, double min_elevation, int magnetic);
+int amt_pipe_launch_box_many(amt_pipe* const* pipes, int32_t n, const amt_frame_params* const* p, double min_elevation,
+                             int magnetic);
+/* auromat/resample.py:36-61 plateCarreeResolution(BoundingBox(latSouth, lonWest, latNorth, lonEast), arcsecPerPx) ->
+ * (latPxPerDeg, lonPxPerDeg); geodesic.angularDistance (geographiclib's a12 in the reference) restated from Karney's
+ * integral formulation for two points on one parallel.  Host arithmetic, no GPU.  AMT_EINVAL when the box is 180 deg
+ * wide or more or the resolution is not positive. */
+int amt_plate_carree_resolution(double lat_south, double lon_west, double lat_north, double lon_east, double arcsec_per_px,
+                                double* lat_px_per_deg, double* lon_px_per_deg);
 int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result);
 /* mean (ny,nx,4) f64, out_img (ny,nx,3) of img_dtype, out_mask (ny,nx) u8, out_count (ny,nx) f64: device
  * buffers for result->grid of the preceding amt_pipe_wait (any may be NULL).  The kernel runs on the driver's

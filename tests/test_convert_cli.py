@@ -155,10 +155,15 @@ def test_image_files_next_to_the_header(tmp_path):
 
 
 @pytest.mark.gpu
-def test_convert_under_a_launcher_with_two_ranks(tmp_path):
-    """`python -m torch.distributed.run --nproc-per-node 2 -m auromat_amd.cli.convert ... --px-per-deg 8`: every rank converts and
+@pytest.mark.parametrize('resolution_flags', [['--grid', 'geo', '--px-per-deg', '8'], ['--resolution', '600'], []],
+                         ids=['px-per-deg', 'resolution', 'reference-defaults'])
+def test_convert_under_a_launcher_with_two_ranks(tmp_path, resolution_flags):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m auromat_amd.cli.convert ... --resample [--px-per-deg 8 | --resolution R |
+    nothing: the reference's defaults, 100 arcsec per pixel on the MLat/MLT grid]`: every rank converts and
     writes its share of the frames (rehearsed on the one GPU: both ranks on cuda:0, the closing barrier through gloo); the files
-    equal those of a single process; a second run without --skip / --overwrite leaves on every rank before the group exists."""
+    equal those of a single process — which, for --resolution, is the sequence pipeline's box-first plan and equals the mapping
+    classes frame by frame (AMT_CONVERT_CLASSES=1) —; a second run without --skip / --overwrite leaves on every rank before the
+    group exists."""
     import socket
     import subprocess
     import sys
@@ -166,8 +171,24 @@ def test_convert_under_a_launcher_with_two_ranks(tmp_path):
     from auromat_amd.export import _nc4
     d = write_frames(tmp_path)
     single, multi = str(tmp_path / 'single'), str(tmp_path / 'multi')
-    flags = ['--data', d, '--format', 'netcdf', '--resample', '--min-elevation', '10', '--grid', 'geo', '--px-per-deg', '8']
+    flags = ['--data', d, '--format', 'netcdf', '--resample', '--min-elevation', '10'] + resolution_flags
     main(flags + ['--out', single])
+    if '--px-per-deg' not in resolution_flags:
+        from auromat_amd.pipeline import SequencePipeline       # the resolution per frame came from the box-first plan
+        classes = str(tmp_path / 'classes')
+        os.environ['AMT_CONVERT_CLASSES'] = '1'
+        try:
+            main(flags + ['--out', classes])
+        finally:
+            del os.environ['AMT_CONVERT_CLASSES']
+        for name in sorted(os.listdir(classes)):
+            a, b = _nc4.open_file(os.path.join(single, name)), _nc4.open_file(os.path.join(classes, name))
+            assert list(a.vars) == list(b.vars)
+            for k, v in a.vars.items():
+                if k == 'zenith_angle':
+                    assert np.allclose(v.data, b.vars[k].data, atol=1e-4, equal_nan=True), (name, k)
+                else:
+                    assert np.array_equal(v.data, b.vars[k].data, equal_nan=True), (name, k)
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]

@@ -508,6 +508,44 @@ def test_single_pass_plan_across_the_dateline(width, height):
     assert one['lon_c'].min() < -170 and one['lon_c'].max() > 170
 
 
+@pytest.mark.parametrize('magnetic', [False, True])
+def test_box_first_plan_across_the_dateline_and_with_a_pole(magnetic):
+    """arcsecPerPx on the frame pipeline: a date-line frame takes the box-first plan (its box is (smallest positive,
+    largest non-positive) longitude) and equals the two-pass plan at the same px/deg; with a pole in view the reference's
+    plateCarreeResolution has no longitude resolution (resample.py:47-61: the box goes all around), here as there."""
+    from datetime import timedelta
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.resample import plateCarreeResolution
+    from auromat_amd.synthetic import frame_header, frame_image, pole_frame
+    w, h = 253, 171
+    hdr, cam, t = frame_header(w, h, 'iss029')
+    if not magnetic:
+        t = t - timedelta(minutes=80)              # geodetic longitudes across +-180 (the SM longitudes cross as they are)
+    img = frame_image(w, h, seed=32)
+    pipe = FramePipeline(w, h, with_mag=magnetic)
+    one = pipe.run(hdr, 110, cam, t, img=img, min_elevation=10, arcsecPerPx=400, magnetic=magnetic, fuse=True)
+    assert pipe.last_plan == 'single-pass' and one['contains_discontinuity']
+    assert one['pxPerDeg'][0] == 9.0 and 2 < one['pxPerDeg'][1] < 9
+    two = pipe.run(hdr, 110, cam, t, min_elevation=10, pxPerDeg=one['pxPerDeg'], magnetic=magnetic, fuse=False)
+    assert pipe.last_plan == 'two-pass'
+    if not magnetic:
+        assert one['pxPerDeg'] == plateCarreeResolution(pipe.bounding_box(), 400)
+    for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon', 'lat_c', 'lon_c'):
+        assert np.array_equal(one[k], two[k], equal_nan=True), k
+    also = pipe.run(hdr, 110, cam, t, min_elevation=10, arcsecPerPx=400, magnetic=magnetic, fuse=False)
+    assert pipe.last_plan == 'two-pass' and also['pxPerDeg'] == one['pxPerDeg']
+    assert np.array_equal(also['mean'], one['mean'], equal_nan=True)
+    if not magnetic:
+        p_hdr, p_cam, p_t = pole_frame(w, h)
+        with pytest.raises(AssertionError):
+            pipe.run(p_hdr, 110, p_cam, p_t, img=img, min_elevation=10, arcsecPerPx=400, fuse=True)
+    # no valid pixel: the reference's ValueError
+    up = np.asarray(cam, dtype=np.float64) / np.linalg.norm(cam)                                # looking at the zenith
+    z_hdr = dict(hdr, CRVAL1=float(np.rad2deg(np.arctan2(up[1], up[0])) % 360), CRVAL2=float(np.rad2deg(np.arcsin(up[2]))))
+    with pytest.raises(ValueError):
+        pipe.run(z_hdr, 110, cam, t, img=img, min_elevation=10, arcsecPerPx=400, magnetic=magnetic, fuse=True)
+
+
 def test_batched_launch_and_sequence_hints_change_nothing():
     """Two frames per launch of the big kernel (amt_pipe_launch_many) and bounding-box hints from the previous
     frame instead of the coarse pre-pass give the same bits as one frame at a time with pre-passes."""

@@ -455,3 +455,17 @@ def test_reference_mapping_test_call_sequence(native, pointing):
     assert b3.latSouth >= b1.latSouth - 0.15 and b3.latNorth <= b1.latNorth + 0.15
     # the resampled image only holds values of the source image's range, and something was binned
     assert m3.img.count() > 0 and m3.img.max() <= m2.img.max()
+    # The same call on a mapping whose arrays nobody has asked for (what auromat-convert does, cli/convert.py:176-185):
+    # the box-first plan — a box pass of the frame kernel, plateCarreeResolution of that box, then the single-pass launch —
+    # and the same mapping bit for bit
+    import auromat_amd.resample as R
+    fresh = ArraySpacecraftMapping(hdr, 110, frame_image(w, h, seed=9), cam, t, pointing, fastCenterCalculation=True)
+    f3 = resample(fresh.maskedByElevation(10), arcsecPerPx=100, method='mean')
+    assert R.last_plan == 'single-pass'
+    for name in ('lats', 'lons', 'latsCenter', 'lonsCenter', 'img', 'elevation'):
+        a, b = getattr(f3, name), getattr(m3, name)
+        assert np.array_equal(ma.getmaskarray(a), ma.getmaskarray(b)), name
+        if name == 'elevation':
+            assert np.max(np.abs(a.compressed() - b.compressed())) < 1e-9          # fixed-point sums
+        else:
+            assert np.array_equal(a.filled(0), b.filled(0)), name

@@ -225,6 +225,34 @@ def test_angular_distance_on_parallel_against_geodesic_integration():
         plateCarreeResolution(BoundingBox(-5, -10, 5, 10), 200)
 
 
+def test_native_plate_carree_resolution_equals_the_python_restatement(lib):
+    """amt_plate_carree_resolution (csrc/amt_grid.h; what resample(arcsecPerPx=...), the sequence pipeline's box-first plan
+    and the native runner call) against the Python restatement of reference resample.py:36-61 on random boxes: the latitude
+    part equal, the longitude part to 1e-12 for boxes of a camera frame's width (the arc of a box a fraction of a degree wide
+    is ill-conditioned in both: 1e-9), and the number of global grid nodes, which is all the grid layout takes from it, the
+    same; boxes across the date line; a box that goes all around (a pole in view) has no longitude resolution in either."""
+    import random
+    from auromat_amd.mapping.mapping import BoundingBox
+    from auromat_amd.resample import plateCarreeResolution, plateCarreeResolution_py
+    rnd = random.Random(5)
+    for i in range(400):
+        ls = rnd.uniform(-89, 85)
+        ln = ls + rnd.uniform(0.01, min(40, 89.9 - ls))
+        lw = rnd.uniform(-180, 180)
+        width = rnd.uniform(0.05, 170) if i % 4 else rnd.uniform(5, 80)
+        le = lw + width
+        if le > 180:
+            le -= 360
+        arc = rnd.choice([100, 50, 200, 360, 13.7])
+        box = BoundingBox(ls, lw, ln, le)
+        got, want = plateCarreeResolution(box, arc), plateCarreeResolution_py(box, arc)
+        assert got[0] == want[0] == 3600.0 / arc
+        assert abs(got[1] - want[1]) <= (1e-12 if width > 5 else 1e-9) * want[1], (ls, lw, ln, le)
+        assert round(got[1] * 360 + 1) == round(want[1] * 360 + 1)
+    assert plateCarreeResolution(BoundingBox(-5, 170, 5, -170), 200) == plateCarreeResolution(BoundingBox(-5, -10, 5, 10), 200)
+    assert plateCarreeResolution(BoundingBox(60, -180, 90, 180), 100) == plateCarreeResolution_py(BoundingBox(60, -180, 90, 180), 100) == (36.0, 0.0)
+
+
 def test_public_header_is_plain_c():
     """include/auromat_hip.h is the C ABI: it must compile as C99 (and C++) without a HIP toolchain."""
     import subprocess

@@ -181,6 +181,64 @@ def test_sequence_pipeline_on_real_consecutive_frames():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('magnetic', [False, True])
+def test_sequence_pipeline_with_arcsec_per_px_on_real_consecutive_frames(magnetic):
+    """`auromat-convert --resample --resolution 100` as the reference runs it (cli/convert.py:176-185: `map(partial(resample_,
+    arcsecPerPx=R), mappings)`) on the ten real consecutive headers at full size, with a frame of empty sky and a frame with the
+    pole in view inserted: SequencePipeline(arcsecPerPx=100) — the box-first plan, a resolution per frame — gives, frame for
+    frame, the grid the mapping classes' array route gives (materialised mapping: bounding box from the arrays,
+    plateCarreeResolution, two-pass binning), bit for bit; images resident on the device and from host memory."""
+    import torch
+    import auromat_amd.resample as R
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    from auromat_amd.pipeline import SequencePipeline
+    from auromat_amd.resample import grid_coordinates
+    from auromat_amd.synthetic import pole_frame
+    frames = real_sequence()
+    up = np.asarray(frames[3][1], dtype=np.float64) / np.linalg.norm(frames[3][1])
+    sky = dict(frames[3][0], CRVAL1=float(np.rad2deg(np.arctan2(up[1], up[0])) % 360), CRVAL2=float(np.rad2deg(np.arcsin(up[2]))))
+    frames.insert(4, (sky, frames[3][1], frames[3][2], frames[3][3]))
+    if not magnetic:
+        p_hdr, p_cam, p_t = pole_frame(4256, 2832)
+        frames.insert(7, (p_hdr, p_cam, p_t, frames[0][3]))
+    seq = SequencePipeline(4256, 2832, arcsecPerPx=100, keep_coordinates=False, magnetic=magnetic)
+    assert len(seq.pipes) == 9
+    got = seq.process(frames, keep_on_device=True)
+    want_plans = ['single-pass'] * len(frames)
+    want_plans[4] = 'empty'
+    if not magnetic:
+        want_plans[7] = 'pole-without-resolution'
+    assert seq.plans == want_plans
+    assert seq.ctx.last_variant()[0] == (4 if magnetic else 0)
+    dev = [(h, c, t, torch.from_numpy(img.view(np.int16)).cuda()) for h, c, t, img in frames]
+    again = seq.process(dev, keep_on_device=True)
+    fn = R.resampleMLatMLT if magnetic else R.resample
+    res = set()
+    for k, (r, r2, (hdr, cam, t, img)) in enumerate(zip(got, again, frames)):
+        if want_plans[k] != 'single-pass':
+            assert r is None and r2 is None
+            continue
+        for key in ('mean', 'count', 'img', 'mask'):
+            assert torch.equal(r[key], r2[key]) or key == 'mean' and np.array_equal(r[key].cpu().numpy(), r2[key].cpu().numpy(), equal_nan=True), (k, key)
+        assert r['pxPerDeg'] == r2['pxPerDeg'] and r['pxPerDeg'][0] == 36.0
+        res.add(r['pxPerDeg'][1])
+        if k % 3 != 0 and k != len(frames) - 1:
+            continue                                        # (the class route takes seconds per full-size frame)
+        m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'f%d' % k, fastCenterCalculation=True).maskedByElevation(10)
+        m.latsCenter                                        # materialise: the array route
+        want = fn(m, arcsecPerPx=100)
+        assert R.last_plan != 'single-pass'
+        assert np.array_equal(r['img'].cpu().numpy().view(np.uint16), want.img.filled(0)), k
+        assert np.array_equal(r['mask'].cpu().numpy().astype(bool), ma.getmaskarray(want.img)[..., 0]), k
+        if not magnetic:
+            c = grid_coordinates(r)
+            assert np.array_equal(c['lat_c'], want.latsCenter.data) and np.array_equal(c['lon'], want.lons.data), k
+        el = r['mean'][..., 3].cpu().numpy()
+        assert np.max(np.abs(el[~ma.getmaskarray(want.elevation)] - want.elevation.compressed())) < 1e-9, k
+    assert len(res) >= 5                                    # every frame really had a resolution of its own
+
+
+@pytest.mark.gpu
 def test_convert_driver_on_the_references_test_frame(tmp_path):
     """`auromat-convert --data <folder with ISS030-E-102170_dc.jpg + .wcs> --resample --grid geo --px-per-deg 10`: the file
     it writes holds the reference's grid (image through Pillow, header cards parsed from the FITS file, single-pass
@@ -278,6 +336,39 @@ def test_real_frame_on_the_mlat_mlt_grid_other_shells(altitude):
     from auromat_amd._native import Context
     assert Context.current().last_variant()[0] == 4          # the class route: MLat / MLT only (grids-only pipeline)
     check(r.img.data, ma.getmaskarray(r.img)[..., 0], None, z)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('magnetic', [False, True])
+def test_arcsec_per_px_on_the_real_frame_takes_the_box_first_plan(magnetic):
+    """The reference's own call form — `resample(mapping, arcsecPerPx=100)` in test/mapping_test.py:24-42 and
+    `partial(resample_, arcsecPerPx=args.resolution)` in cli/convert.py:176-185 — on its own test frame at full size: on a
+    mapping nobody has materialised it runs the box-first plan (box pass, plateCarreeResolution, single-pass launch) and
+    gives the grid of the array route (a materialised mapping: bounding box from the arrays, two-pass binning) bit for bit,
+    on the geodetic and on the MLat / MLT grid, with and without maskedByElevation."""
+    import auromat_amd.resample as R
+    from auromat_amd._native import Context
+    from auromat_amd.mapping.spacecraft import getMapping
+    fn = R.resampleMLatMLT if magnetic else R.resample
+    for elev in (10, None):
+        mm = getMapping(JPG, WCS, fastCenterCalculation=True)
+        ref = getMapping(JPG, WCS, fastCenterCalculation=True)
+        if elev is not None:
+            mm, ref = mm.maskedByElevation(elev), ref.maskedByElevation(elev)
+        ref.latsCenter                                   # materialise: the array route
+        want = fn(ref, arcsecPerPx=100)
+        assert R.last_plan != 'single-pass'
+        got = fn(mm, arcsecPerPx=100)
+        assert R.last_plan == 'single-pass'
+        assert Context.current().last_variant()[0] == (4 if magnetic else 0)
+        assert got.img.shape == want.img.shape and got.img.shape[0] > 200
+        for name in ('lats', 'lons', 'latsCenter', 'lonsCenter', 'img', 'elevation'):
+            a, b = getattr(got, name), getattr(want, name)
+            assert np.array_equal(ma.getmaskarray(a), ma.getmaskarray(b)), name
+            if name == 'elevation':
+                assert np.max(np.abs(a.compressed() - b.compressed())) < 1e-9
+            else:
+                assert np.array_equal(a.filled(0), b.filled(0)), name
 
 
 @pytest.mark.gpu

@@ -39,3 +39,25 @@ for rep in range(4):
     t3 = time.perf_counter()
     print('array input: getMapping + maskedByElevation %.2f ms, resample %.2f ms (%s), latsCenter to host (arrays + mask on first use) %.2f ms'
           % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, plan, (t3 - t2) * 1e3), geo.img.shape)
+
+# The reference's own call form: resample(mapping, arcsecPerPx=100) (test/mapping_test.py:24-42, cli/convert.py:176-185).
+# (a) the array route — what every arcsecPerPx call took before round 4 and what a materialised mapping still takes: all five
+# per-pixel arrays, the box reduced from them, plateCarreeResolution, two-pass binning; (b) the box-first plan on a mapping
+# nobody has materialised: box pass + single-pass launch of the fused kernel.
+for magnetic in (False, True):
+    fn = resampleMLatMLT if magnetic else resample
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        mm = getMapping(arr, wcs, altitude=110, fastCenterCalculation=True).maskedByElevation(10)
+        mm.latsCenter
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        a = fn(mm, arcsecPerPx=100)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        plan_a = R.last_plan
+        mm = getMapping(arr, wcs, altitude=110, fastCenterCalculation=True).maskedByElevation(10)
+        t3 = time.perf_counter()
+        b = fn(mm, arcsecPerPx=100)
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        print('%s(arcsecPerPx=100): array route (round 3: every such call) materialise %.2f ms + resample %.2f ms (%s); box-first '
+              'plan %.2f ms (%s); same image %s' % (fn.__name__, (t1 - t0) * 1e3, (t2 - t1) * 1e3, plan_a, (t4 - t3) * 1e3, R.last_plan,
+                                                    bool(np.array_equal(a.img.filled(0), b.img.filled(0)))), b.img.shape)
