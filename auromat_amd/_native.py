@@ -76,7 +76,7 @@ class RunConfig(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ('width', 'height', 'img_dtype', 'fast_center', 'magnetic', 'batch', 'use_hints',
                                          'n_slots', 'two_pass', 'reserved_')] + \
                [(k, C.c_double) for k in ('altitude', 'min_elevation', 'lat_px_per_deg', 'lon_px_per_deg')] + \
-               [('slots', C.POINTER(GeorefOut))]
+               [('slots', C.POINTER(GeorefOut)), ('arcsec_per_px', C.c_double)]
 
 
 class RunFrame(C.Structure):
@@ -90,7 +90,8 @@ class RunResult(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ('status', 'slot', 'ny', 'nx', 'contains_pole', 'lon_wrapped', 'hinted',
                                          'edge_pixels', 'two_pass', 'reserved_')] + \
                [('grid_offset', C.c_int64), ('image_offset', C.c_int64), ('bbox', C.c_double * 8), ('altitude', C.c_double),
-                ('grid', Grid), ('params', FrameParams)]
+                ('grid', Grid), ('params', FrameParams), ('lat_px_per_deg', C.c_double), ('lon_px_per_deg', C.c_double),
+                ('retried', C.c_int32), ('reserved2_', C.c_int32)]
 
 
 ABI_VERSION = 4          # include/auromat_hip.h AMT_ABI_VERSION

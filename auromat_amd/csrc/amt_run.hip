@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "amt_common.h"
+#include "amt_grid.h"
 #include "amt_params.h"
 
 struct amt_run {
@@ -36,6 +37,11 @@ struct amt_run {
     int batch_k0, batch_count;              // prepared frames of the batch being collected
     int launched[2][2], n_launched;         // (first frame, count) of the batches in flight, older first
     std::vector<const void*> img;           // per slot: the image of the frame in the slot
+    // box-first plan (cfg.arcsec_per_px > 0): batches whose box pass is in flight, older first; per slot the resolution the
+    // frame's box gave, and what became of a frame that was not launched (2 no valid pixel, 4 a pole in view, 0 launched)
+    int boxed[2][2], n_boxed;
+    std::vector<double> ppd_lat, ppd_lon;
+    std::vector<int> pre_status;
 };
 
 namespace {
@@ -125,7 +131,9 @@ int amt_run_create(amt_ctx* ctx, const amt_run_config* config, amt_run** out_run
     AMT_REQUIRE(ctx, config->img_dtype == 1 || config->img_dtype == 2, "img_dtype must be 1 (uint8) or 2 (uint16)");
     AMT_REQUIRE(ctx, config->batch >= 1 && config->batch <= AMT_PIPE_MAX_BATCH, "batch out of range");
     AMT_REQUIRE(ctx, config->n_slots >= 2 * config->batch && config->slots != nullptr, "n_slots must be at least 2 * batch");
-    AMT_REQUIRE(ctx, config->lat_px_per_deg > 0 && config->lon_px_per_deg > 0, "px per degree must be positive");
+    AMT_REQUIRE(ctx, config->arcsec_per_px > 0 || (config->lat_px_per_deg > 0 && config->lon_px_per_deg > 0), "px per degree must be positive");
+    AMT_REQUIRE(ctx, !(config->arcsec_per_px > 0) || (!config->two_pass && config->n_slots >= 3 * config->batch),
+                "arcsec_per_px: the box-first plan is a single-pass plan and needs n_slots >= 3 * batch");
     amt_run* run = new (std::nothrow) amt_run();
     if (run == nullptr) return AMT_ENOMEM;
     run->ctx = ctx;
@@ -140,8 +148,11 @@ int amt_run_create(amt_ctx* ctx, const amt_run_config* config, amt_run** out_run
     run->alt.assign(ns, config->altitude);
     run->hinted.assign(ns, 0);
     run->img.assign(ns, nullptr);
+    run->ppd_lat.assign(ns, config->lat_px_per_deg);
+    run->ppd_lon.assign(ns, config->lon_px_per_deg);
+    run->pre_status.assign(ns, 0);
     run->active = run->full = false;
-    run->n_launched = 0, run->batch_count = 0;
+    run->n_launched = 0, run->batch_count = 0, run->n_boxed = 0;
     run->pipes.assign(ns, nullptr);
     if (amt_set_device(ctx)) {
         delete run;
@@ -207,8 +218,28 @@ int run_finish(amt_run* run, int k0, int count) {
         r.hinted = run->hinted[slot];
         r.altitude = run->alt[slot];
         r.params = run->prm[slot];
+        r.lat_px_per_deg = run->ppd_lat[slot], r.lon_px_per_deg = run->ppd_lon[slot];
+        if (run->pre_status[slot] != 0) {
+            // box-first plan: the box pass found no valid pixel (2) or a pole in view (4); nothing was launched
+            r.status = run->pre_status[slot];
+            run->last.valid = run->prev.valid = false;
+            continue;
+        }
         amt_pipe_result pr;
         if (int rc = amt_pipe_wait(run->pipes[slot], &pr)) return rc;
+        if (pr.status == 1 && pr.fused && !cfg.two_pass && pr.bbox[6] > 0 && pr.edge_pixels <= 16384) {
+            // handed back although the launch was fused — the exact box does not fit the superset grid of a poor estimate,
+            // the date line judged differently —: once more, with the exact box (in the coordinates of the plan: bbox[7])
+            // as the estimate.  On the context's stream, behind the batch launched after this one; rare.
+            const int mag = cfg.magnetic ? 1 : 0;
+            run->outs[slot].altitude = run->alt[slot];
+            if (int rc = amt_pipe_coarse_hint(run->pipes[slot], pr.bbox, mag)) return rc;
+            if (int rc = amt_pipe_launch(run->pipes[slot], &run->prm[slot], &run->outs[slot], run->img[slot], cfg.img_dtype,
+                                         cfg.min_elevation, run->ppd_lat[slot], run->ppd_lon[slot], -1, mag))
+                return rc;
+            if (int rc = amt_pipe_wait(run->pipes[slot], &pr)) return rc;
+            r.retried = 1;
+        }
         bool general = false;
         if (pr.status == 1) {
             // the two-pass plan, natively, when the frame's coordinate arrays exist and nothing else is needed
@@ -269,21 +300,122 @@ int run_launch(amt_run* run, int k0, int count) {
     const amt_frame_params* prm[AMT_PIPE_MAX_BATCH];
     const amt_georef_out* oo[AMT_PIPE_MAX_BATCH];
     const void* ii[AMT_PIPE_MAX_BATCH];
+    double la[AMT_PIPE_MAX_BATCH], lo[AMT_PIPE_MAX_BATCH];
+    // the frames of the batch that are launched (box-first plan: not those without a valid pixel or with a pole in view),
+    // as runs of consecutive frames
+    int i = 0;
+    while (i < count) {
+        if (run->pre_status[(k0 + i) % ns] != 0) {
+            ++i;
+            continue;
+        }
+        int m = 0;
+        while (i < count && run->pre_status[(k0 + i) % ns] == 0) {
+            const int slot = (k0 + i) % ns;
+            run->outs[slot].altitude = run->alt[slot];
+            pp[m] = run->pipes[slot], prm[m] = &run->prm[slot], oo[m] = &run->outs[slot], ii[m] = run->img[slot];
+            la[m] = run->ppd_lat[slot], lo[m] = run->ppd_lon[slot];
+            if (ii[m] == nullptr) {
+                ctx->last_error = "amt_run: a frame has no image";
+                return AMT_EINVAL;
+            }
+            ++m, ++i;
+        }
+        if (int rc = amt_pipe_launch_many_res(pp, m, prm, oo, ii, cfg.img_dtype, cfg.min_elevation, la, lo, -1, cfg.magnetic ? 1 : 0))
+            return rc;
+    }
+    return AMT_OK;
+}
+
+// ---- box-first plan (cfg.arcsec_per_px > 0) --------------------------------------------------------------------------
+// box(b): ONE launch of the frame kernel without outputs for the batch's frames (amt_pipe_launch_box_many)
+int run_box(amt_run* run, int k0, int count) {
+    const amt_run_config& cfg = run->cfg;
+    const int ns = cfg.n_slots;
+    amt_pipe* pp[AMT_PIPE_MAX_BATCH];
+    const amt_frame_params* prm[AMT_PIPE_MAX_BATCH];
     for (int i = 0; i < count; ++i) {
         const int slot = (k0 + i) % ns;
-        run->outs[slot].altitude = run->alt[slot];
-        pp[i] = run->pipes[slot], prm[i] = &run->prm[slot], oo[i] = &run->outs[slot], ii[i] = run->img[slot];
-        if (ii[i] == nullptr) {
-            ctx->last_error = "amt_run: a frame has no image";
-            return AMT_EINVAL;
-        }
+        pp[i] = run->pipes[slot], prm[i] = &run->prm[slot];
+        run->pre_status[slot] = 0;
     }
-    return amt_pipe_launch_many(pp, count, prm, oo, ii, cfg.img_dtype, cfg.min_elevation, cfg.lat_px_per_deg,
-                                cfg.lon_px_per_deg, -1, cfg.magnetic ? 1 : 0);
+    return amt_pipe_launch_box_many(pp, count, prm, cfg.min_elevation, cfg.magnetic ? 1 : 0);
+}
+
+// the boxes of a boxed batch -> px/deg per frame (BaseMapping.boundingBox of the reduction, reference mapping.py:711-741, then
+// plateCarreeResolution, resample.py:36-61), the exact box as the estimate of the single-pass launch
+int run_resolve(amt_run* run, int k0, int count) {
+    const amt_run_config& cfg = run->cfg;
+    const int ns = cfg.n_slots, mag = cfg.magnetic ? 1 : 0;
+    for (int i = 0; i < count; ++i) {
+        const int slot = (k0 + i) % ns;
+        amt_pipe_result pr;
+        if (int rc = amt_pipe_wait(run->pipes[slot], &pr)) return rc;
+        const double* b = pr.bbox;
+        if (pr.status == 2 || !(b[6] > 0)) {
+            run->pre_status[slot] = 2;
+            continue;
+        }
+        const bool straddles = b[3] - b[2] > 180;
+        const double west = straddles ? b[4] : b[2], east = straddles ? b[5] : b[3];
+        double la = 0, lo = 0;
+        if (b[7] != 0 || !amt_gl::plate_carree_resolution(b[0], west, b[1], east, cfg.arcsec_per_px, &la, &lo) || !(lo > 0)) {
+            run->pre_status[slot] = 4;
+            continue;
+        }
+        run->ppd_lat[slot] = la, run->ppd_lon[slot] = lo;
+        if (int rc = amt_pipe_coarse_hint(run->pipes[slot], b, mag)) return rc;
+        run->hinted[slot] = 1;
+    }
+    return AMT_OK;
+}
+
+void pop_front(int (*q)[2], int* n) {
+    q[0][0] = q[1][0], q[0][1] = q[1][1];
+    --*n;
+}
+
+// box-first plan: the oldest boxed batch -> resolutions, its single-pass launch; then at most one batch stays in flight
+int run_launch_boxed(amt_run* run) {
+    const int k0 = run->boxed[0][0], count = run->boxed[0][1];
+    pop_front(run->boxed, &run->n_boxed);
+    if (int rc = run_resolve(run, k0, count)) return rc;
+    if (!run->full)
+        if (int rc = run_launch(run, k0, count)) return rc;
+    // (arenas full: the frames are reported as not processed by run_finish's capacity check... they were not launched:
+    // mark them here)
+    if (run->full)
+        for (int i = 0; i < count; ++i)
+            if (run->pre_status[(k0 + i) % run->cfg.n_slots] == 0) run->pre_status[(k0 + i) % run->cfg.n_slots] = 3;
+    run->launched[run->n_launched][0] = k0, run->launched[run->n_launched][1] = count;
+    ++run->n_launched;
+    while (run->n_launched > 1) {
+        if (int rc = run_finish(run, run->launched[0][0], run->launched[0][1])) return rc;
+        pop_front(run->launched, &run->n_launched);
+    }
+    return AMT_OK;
+}
+
+// box-first plan, a complete batch b of prepared frames: launch(b - 2), finish(b - 3), box(b)
+int run_batch_ready_box(amt_run* run, int k0, int count) {
+    if (run->n_boxed == 2)
+        if (int rc = run_launch_boxed(run)) return rc;
+    if (run->full) {
+        for (int i = 0; i < count; ++i) {
+            std::memset(&run->results[k0 + i], 0, sizeof(amt_run_result));
+            run->results[k0 + i].status = 3;
+        }
+        return AMT_OK;
+    }
+    if (int rc = run_box(run, k0, count)) return rc;
+    run->boxed[run->n_boxed][0] = k0, run->boxed[run->n_boxed][1] = count;
+    ++run->n_boxed;
+    return AMT_OK;
 }
 
 // a complete batch of prepared frames (k0, count): finish the older of two batches in flight, then launch it
 int run_batch_ready(amt_run* run, int k0, int count) {
+    if (run->cfg.arcsec_per_px > 0) return run_batch_ready_box(run, k0, count);
     if (run->n_launched == 2) {
         if (int rc = run_finish(run, run->launched[0][0], run->launched[0][1])) return rc;
         run->launched[0][0] = run->launched[1][0], run->launched[0][1] = run->launched[1][1];
@@ -325,13 +457,22 @@ int amt_run_begin(amt_run* run, double* grids, int64_t grids_capacity, void* ima
     run->results = results, run->max_frames = max_frames;
     run->grid_used = run->image_used = 0;
     run->full = false;
-    run->n_pushed = 0, run->batch_k0 = 0, run->batch_count = 0, run->n_launched = 0;
+    run->n_pushed = 0, run->batch_k0 = 0, run->batch_count = 0, run->n_launched = 0, run->n_boxed = 0;
     run->active = true;
     return AMT_OK;
 }
 
+static int run_push_impl(amt_run* run, const amt_run_frame* f);
+
 int amt_run_push(amt_run* run, const amt_run_frame* f) {
     if (run == nullptr) return AMT_EINVAL;
+    const int rc = run_push_impl(run, f);
+    //  a failed push leaves no hints behind whose indices refer to frames that were never counted
+    if (rc != AMT_OK) run->last.valid = run->prev.valid = false;
+    return rc;
+}
+
+static int run_push_impl(amt_run* run, const amt_run_frame* f) {
     amt_ctx* ctx = run->ctx;
     AMT_CHECK_CTX(ctx);
     AMT_REQUIRE(ctx, run->active, "amt_run_push without amt_run_begin");
@@ -345,11 +486,18 @@ int amt_run_push(amt_run* run, const amt_run_frame* f) {
     // the slot's previous frame (k - n_slots) may still be in flight: it is finished before its slot — parameters, shell,
     // driver — takes the new frame.  (With n_slots = 2 * batch that is the batch launched before the one now running, so
     // nothing waits that the loop `launch(B); finish(A); prepare(C)` would not wait for.)
-    while (run->n_launched > 0 && run->launched[0][0] <= k - cfg.n_slots) {
-        if (int rc = run_finish(run, run->launched[0][0], run->launched[0][1])) return rc;
-        run->launched[0][0] = run->launched[1][0], run->launched[0][1] = run->launched[1][1];
-        --run->n_launched;
-        if (run->full) return AMT_OK;
+    for (;;) {
+        if (run->n_launched > 0 && run->launched[0][0] <= k - cfg.n_slots) {
+            if (int rc = run_finish(run, run->launched[0][0], run->launched[0][1])) return rc;
+            pop_front(run->launched, &run->n_launched);
+            if (run->full) return AMT_OK;
+            continue;
+        }
+        if (run->n_boxed > 0 && run->boxed[0][0] <= k - cfg.n_slots) {
+            if (int rc = run_launch_boxed(run)) return rc;      // (cannot happen with n_slots >= 3 * batch)
+            continue;
+        }
+        break;
     }
     const int mag = cfg.magnetic ? 1 : 0;
     const double altitude = f->altitude > 0 ? f->altitude : cfg.altitude;
@@ -363,15 +511,18 @@ int amt_run_push(amt_run* run, const amt_run_frame* f) {
     }
     run->alt[slot] = altitude;
     run->img[slot] = f->img;
-    double est[8];
-    const bool hint = cfg.use_hints && box_hint(run, run->frames_done + k, p, est);
-    rc = hint ? amt_pipe_coarse_hint(run->pipes[slot], est, mag) : amt_pipe_coarse(run->pipes[slot], &p, cfg.min_elevation, mag);
-    if (rc != AMT_OK) return rc;
-    run->hinted[slot] = hint ? 1 : 0;
+    run->pre_status[slot] = 0;
+    if (!(cfg.arcsec_per_px > 0)) {
+        double est[8];
+        const bool hint = cfg.use_hints && box_hint(run, run->frames_done + k, p, est);
+        rc = hint ? amt_pipe_coarse_hint(run->pipes[slot], est, mag) : amt_pipe_coarse(run->pipes[slot], &p, cfg.min_elevation, mag);
+        if (rc != AMT_OK) return rc;
+        run->hinted[slot] = hint ? 1 : 0;
+    }
     if (run->batch_count == 0) run->batch_k0 = k;
     ++run->batch_count;
     // the first launch carries one frame only: the GPU starts after one frame's preparation instead of `batch`
-    if (run->batch_count == (k == 0 ? 1 : cfg.batch)) {
+    if (run->batch_count == (k == 0 && !(cfg.arcsec_per_px > 0) ? 1 : cfg.batch)) {
         rc = run_batch_ready(run, run->batch_k0, run->batch_count);
         run->batch_count = 0;
     }
@@ -389,17 +540,23 @@ int amt_run_end(amt_run* run, int32_t* frames_done) {
         rc_all = run_batch_ready(run, run->batch_k0, run->batch_count);
         run->batch_count = 0;
     }
+    while (run->n_boxed > 0 && rc_all == AMT_OK) rc_all = run_launch_boxed(run);
     for (int i = 0; i < run->n_launched; ++i) {
         const int rc = run_finish(run, run->launched[i][0], run->launched[i][1]);
         if (rc_all == AMT_OK) rc_all = rc;
     }
-    run->n_launched = 0;
+    run->n_launched = run->n_boxed = 0;
     // order the context's stream behind every finalise kernel of this call
     for (amt_pipe* p : run->pipes) {
         const int rc = amt_pipe_join(p);
         if (rc_all == AMT_OK) rc_all = rc;
     }
-    if (rc_all != AMT_OK) return rc_all;
+    if (rc_all != AMT_OK) {
+        //  a failed call leaves no half-valid state behind: no hints, nothing counted
+        run->last.valid = run->prev.valid = false;
+        if (frames_done) *frames_done = 0;
+        return rc_all;
+    }
     const int n = run->n_pushed;
     int done = n;
     for (int i = 0; i < n; ++i)

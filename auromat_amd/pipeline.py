@@ -526,6 +526,16 @@ class FramePipeline(object):
         if self._fused is not None and self._fused['pxPerDeg'] == tuple(pxPerDeg) and \
                 self._fused['magnetic'] == bool(magnetic):
             res = self._wait_fused()
+            if res.status == 1 and res.fused and res.bbox[6] > 0 and res.edge_pixels <= 16384 and not self._fused.get('retried') \
+                    and self.shard is None:
+                # handed back although the launch was fused (the exact box does not fit the superset grid of a poor estimate,
+                # the date line judged differently by the pre-pass): once more with the exact box — in the coordinates of
+                # the plan, res.bbox[7] — as the estimate, instead of five per-pixel arrays and a separate binning pass
+                self.start_coarse(self.params, self.min_elevation, magnetic, hint=list(res.bbox))
+                self.georef(None, self.altitude, None, None, bool(self.params.fast_center), self.min_elevation,
+                            params=self.params, fuse_pxPerDeg=tuple(pxPerDeg), coarse_started=True, fuse_magnetic=bool(magnetic))
+                self._fused['retried'] = True
+                res = self._wait_fused()
             # status 0: the driver could finalise the frame; a caller's containsPole must agree with its decision
             if res.status == 0 and (containsPole is None or bool(containsPole) == bool(res.bbox[7])):
                 self.last_plan = 'single-pass'
@@ -734,7 +744,7 @@ class NativeResults(object):
     def _build(self, i):
         import torch
         r = self._rec[i]
-        if r.status == 2:
+        if r.status in (2, 4):
             return None
         if r.status != 0:
             return self._fallbacks[i]
@@ -746,7 +756,8 @@ class NativeResults(object):
             box = (b[0], b[1], wrap_at_180(b[4] + 180), wrap_at_180(b[5] + 180))
         else:
             box = (b[0], b[1], b[2], b[3])
-        grid = _GridView(r.grid, seq.pxPerDeg, box)
+        ppd = (r.lat_px_per_deg, r.lon_px_per_deg)
+        grid = _GridView(r.grid, ppd, box)
         ny, nx = r.ny, r.nx
         n = ny * nx
         o = r.grid_offset
@@ -762,7 +773,7 @@ class NativeResults(object):
             om = ob + 3 * n
         mask = self._images[om:om + n].view(ny, nx)
         out = dict(has_elev=True, grid=grid, contains_pole=pole, contains_discontinuity=wrapped or pole,
-                   altitude=r.altitude, magnetic=seq.magnetic)
+                   altitude=r.altitude, magnetic=seq.magnetic, pxPerDeg=ppd)
         if self._keep:
             out.update(mean=mean, img=img, mask=mask, count=count, packed=packed)
             return out
@@ -1073,7 +1084,9 @@ class SequencePipeline(object):
                             magnetic=1 if self.magnetic else 0, batch=self.batch, use_hints=1 if self.use_hints else 0,
                             n_slots=nb, two_pass=0 if self.single_pass else 1, altitude=float(self.altitude),
                             min_elevation=NEG_INF if self.min_elevation is None else float(self.min_elevation),
-                            lat_px_per_deg=float(self.pxPerDeg[0]), lon_px_per_deg=float(self.pxPerDeg[1]), slots=slots)
+                            lat_px_per_deg=float(self.pxPerDeg[0]) if self.pxPerDeg else 0.0,
+                            lon_px_per_deg=float(self.pxPerDeg[1]) if self.pxPerDeg else 0.0, slots=slots,
+                            arcsec_per_px=self.arcsecPerPx or 0.0)
             handle = C.c_void_p()
             self.ctx.call('amt_run_create', C.byref(cfg), C.byref(handle))
             self._run = handle
@@ -1161,7 +1174,7 @@ class SequencePipeline(object):
         self.hinted += int(table['hinted'].sum())
         fallbacks = {}
         max_cells = int((table['ny'].astype(np.int64) * table['nx']).max()) if n else 1
-        names = {0: 'single-pass', 2: 'empty'}
+        names = {0: 'single-pass', 2: 'empty', 4: 'pole-without-resolution'}
         if not status.any() and not table['two_pass'].any():
             self.plans.extend(['single-pass'] * n)
         else:
@@ -1175,7 +1188,8 @@ class SequencePipeline(object):
                 q.use_image(f[3])
                 alt = f[4] if len(f) > 4 and f[4] is not None else self.altitude
                 try:
-                    res = q.run(f[0], alt, f[1], f[2], fast=self.fast, min_elevation=self.min_elevation, pxPerDeg=self.pxPerDeg,
+                    ppd = (table['lat_px_per_deg'][k], table['lon_px_per_deg'][k]) if self.arcsecPerPx else self.pxPerDeg
+                    res = q.run(f[0], alt, f[1], f[2], fast=self.fast, min_elevation=self.min_elevation, pxPerDeg=ppd,
                                 magnetic=self.magnetic, keep_on_device=keep_on_device, fuse=False)
                     res['magnetic'] = self.magnetic
                 except EmptyFrame:
@@ -1337,14 +1351,14 @@ class SequencePipeline(object):
         import torch
         del self.plans[:]
         self.hinted = 0
-        if self.arcsecPerPx:
-            return self._process_box_first(frames, keep_on_device, on_batch)
         if on_batch is None and self.native and isinstance(frames, (list, tuple)):
             # (an iterator — the convert driver's read-ahead generator of decoded host images — is consumed frame by frame
             # below: its images are not device-resident anyway, and materialising it would hold every decoded image of the
             # sequence in host memory before the first launch)
             if self._native_applies(frames):
                 return self._process_native(frames, keep_on_device)
+        if self.arcsecPerPx:
+            return self._process_box_first(frames, keep_on_device, on_batch)
         if self._run is not None:
             self._hint_native_reset()
         # (the box of the latest finished frame stays from the previous call: a sequence handed over in pieces is still

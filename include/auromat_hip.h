@@ -618,7 +618,16 @@ int amt_pipe_general_finalize(amt_pipe* pipe, double* mean, void* out_img, uint8
  * status per frame: 0 done (two_pass = 1: by the two-pass plan, which frames the single-pass plan hands back take when their
  * slot has coordinate arrays); 1 the frame needs the caller's general path (a pole in view that the pole plan does not cover,
  * ...; nothing of it is in the arenas); 2 no pixel above the elevation threshold;
- * 3 the arenas are full (this and the later frames were not processed). */
+ * 3 the arenas are full (this and the later frames were not processed); 4 (arcsec_per_px only) a pole of the grid's
+ * coordinates is in view, for which plateCarreeResolution has no longitude resolution (reference resample.py:47-61: the box
+ * goes all around; the reference fails on such a frame).
+ * A frame the single-pass plan hands back although its launch was fused (its exact box does not fit the superset grid of a
+ * poor estimate, the date line judged differently) is launched once more with its exact box as the estimate before it
+ * takes any other path.
+ * arcsec_per_px > 0 — `resample(mapping, arcsecPerPx=R)`, what the reference's auromat-convert runs (cli/convert.py:176-185) —:
+ * every frame's px/deg follows from its own bounding box (amt_plate_carree_resolution; lat / lon_px_per_deg of the config are
+ * ignored, the frame's pair is in its result): the box-first plan (amt_pipe_launch_box), the box pass of a batch two batches
+ * ahead of its single-pass launch; needs n_slots >= 3 * batch. */
 typedef struct amt_run amt_run;
 typedef struct amt_run_config {
     int32_t width, height;
@@ -635,6 +644,7 @@ typedef struct amt_run_config {
     double lat_px_per_deg, lon_px_per_deg;
     const amt_georef_out* slots;  /* n_slots blocks: the per-pixel arrays each slot's frames write (NULL = not written);
                                    * bbox / bin_* fields are managed by the runner */
+    double arcsec_per_px;         /* > 0: a resolution per frame from its own bounding box (see above); 0: the fixed pair */
 } amt_run_config;
 typedef struct amt_run_frame {
     double crval[2], crpix[2], cd[4], lonpole;   /* the TAN WCS cards (LATPOLE = 0) */
@@ -658,6 +668,8 @@ typedef struct amt_run_result {
     double altitude;
     amt_grid grid;
     amt_frame_params params;      /* what the frame was computed with */
+    double lat_px_per_deg, lon_px_per_deg;   /* the resolution the frame was binned at */
+    int32_t retried, reserved2_;  /* retried = 1: launched a second time with its exact box as the estimate */
 } amt_run_result;
 /* The host scalars of one frame (no GPU call).  AMT_EINVAL: date outside the IGRF table with want_sm. */
 int amt_frame_params_from_wcs(const amt_run_frame* frame, int32_t width, int32_t height, int32_t fast_center,

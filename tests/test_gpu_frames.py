@@ -546,6 +546,31 @@ def test_box_first_plan_across_the_dateline_and_with_a_pole(magnetic):
         pipe.run(z_hdr, 110, cam, t, img=img, min_elevation=10, arcsecPerPx=400, magnetic=magnetic, fuse=True)
 
 
+def test_a_frame_handed_back_because_of_a_poor_estimate_is_relaunched_with_its_exact_box():
+    """A single-pass launch whose superset grid (laid out from an estimate of the box: here a deliberately wrong one) does not
+    hold the exact grid hands the frame back (status 1).  It is launched once more with the exact box as the estimate — no
+    per-pixel array is allocated for it in a grids-only pipeline — and gives the grid of an ordinary launch."""
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 400, 270
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    img = frame_image(w, h, seed=77)
+    for magnetic in (False, True):
+        pipe = FramePipeline(w, h, alloc_coords=False, with_mag=magnetic)
+        ref = pipe.run(hdr, 110, cam, t, img=img, min_elevation=10, pxPerDeg=10, magnetic=magnetic, fuse=True)
+        assert pipe.last_plan == 'single-pass' and not pipe._fused.get('retried')
+        box = list(pipe._fused['result'].bbox)
+        bad = [box[0] + 7, box[1] + 7, box[2] - 9, box[3] - 9, box[4], box[5], 1.0, 0.0]
+        p = frame_params(hdr, 110, cam, t, True, magnetic=magnetic)
+        pipe.start_coarse(p, 10, magnetic, hint=bad)
+        pipe.georef(hdr, 110, cam, t, True, 10, params=p, fuse_pxPerDeg=(10, 10), coarse_started=True, fuse_magnetic=magnetic)
+        res = pipe.resample(10, magnetic=magnetic)
+        assert pipe.last_plan == 'single-pass' and pipe._fused.get('retried') and pipe.fd.lat is None
+        for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
+            assert np.array_equal(res[k], ref[k], equal_nan=True), k
+
+
 def test_batched_launch_and_sequence_hints_change_nothing():
     """Two frames per launch of the big kernel (amt_pipe_launch_many) and bounding-box hints from the previous
     frame instead of the coarse pre-pass give the same bits as one frame at a time with pre-passes."""

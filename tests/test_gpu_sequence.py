@@ -245,6 +245,7 @@ def test_fallback_frames_inside_a_single_pass_sequence_do_not_race_with_the_fina
         res = ready(self, pxPerDeg, magnetic)
         if k in fall_back and res is not None:
             res.status = 1                                  # "the driver cannot finalise this frame": the general path
+            res.edge_pixels = 1 << 20                       # (as if for more on-edge pixels than records: no second launch)
             return None
         return res
     monkeypatch.setattr(FramePipeline, 'fused_ready', withheld)
