@@ -681,6 +681,10 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
     // function the two-pass plan uses.
     constexpr bool pole_bin = kPole;
     const bool geo_pole = kMagPole && !A.bin_magnetic;      // wave-uniform: SECOND = 3 on a geodetic grid (see the corner step)
+    // a centre's coordinates are computed when somebody takes them: the fused binning, or an output array.  The box pass of
+    // the box-first plan (amt_pipe_launch_box: no output, no binning) needs a centre's elevation only — the box is reduced
+    // over the corners — and skips a quarter of the arithmetic (wave-uniform)
+    const bool centre_coords = BIN != 0 || A.lat_c != nullptr || A.lon_c != nullptr || (MAG && A.mlat_c != nullptr);
     int n_valid = 0;
     auto box_add = [&](double la_v, double lo_v) {
         __hip_atomic_fetch_min(&sBox[wave][0][lane], la_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1033,7 +1037,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
                     el = __builtin_fma(dsum.x, 1e-3, __builtin_fma(dsum.y, 1e-3, __builtin_fma(dsum.z, 1e-3, pc.z * 1e-9))) + 20.0;
                 } else if (pc.x == pc.x) {
                     double inv_r, cn = NAN, cd = NAN;
-                    if (kMagOnly) {
+                    if (kMagOnly || !centre_coords) {
                         // 1 / |P| exactly as the Bowring step computes it (fx::bowring_nd): the elevation keeps its bits
 #pragma clang fp contract(off)
                         inv_r = fx::rsqrt_n(__builtin_fma(pc.z, pc.z, __builtin_fma(pc.x, pc.x, pc.y * pc.y)));
@@ -1053,7 +1057,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
                     double c = -(fx::dot3(dsum.x, dsum.y, dsum.z, pc.x, pc.y, pc.z) * dscale) * inv_r;
                     c = fmin(1.0, fmax(-1.0, c));
                     el = fx::asin_deg(c, atan_table().c);
-                    if (MAG) {
+                    if (MAG && centre_coords) {
                         // relative to this lane's corner of the current row, like latitude and longitude
                         vec3 sc;
                         double sxyc;
