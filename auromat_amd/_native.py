@@ -7,6 +7,7 @@ compute entry point raises.  PyTorch is used only for device memory and the curr
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -120,6 +121,8 @@ _SIGNATURES = {
     'amt_pipe_launch_box_many': ([c_void_pp, C.c_int32, c_void_pp, _D, _I], _I),
     'amt_pipe_launch_many_res': ([c_void_pp, C.c_int32, c_void_pp, c_void_pp, c_void_pp, C.c_int32, _D, c_double_p, c_double_p, _I, _I], _I),
     'amt_plate_carree_resolution': ([_D, _D, _D, _D, _D, c_double_p, c_double_p], _I),
+    'amt_upload_staged': ([_P, _P, _P, C.c_size_t], _I),
+    'amt_download_staged': ([_P, _P, _P, C.c_size_t], _I),
     'amt_georef_last_variant': ([_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], _I),
     'amt_directions_tan': ([_P, C.POINTER(FrameParams), _I, _P], _I),
     'amt_directions_tan_points': ([_P, C.POINTER(FrameParams), _P, _P, _L, _I, _P], _I),
@@ -315,7 +318,8 @@ class Context(object):
         if a.nbytes >= _PIN_MIN_BYTES and np.dtype(a.dtype) in _TORCH_DTYPES:
             out = torch.empty(a.shape, dtype=_torch_dtype(a.dtype), device=self.device)
             self.upload(a, out)
-            return out
+            # (a bool array is a torch.bool tensor whatever its size: the small ones go through torch.from_numpy)
+            return out.view(torch.bool) if a.dtype == np.bool_ else out
         if not a.flags.writeable:          # torch refuses to wrap read-only memory silently (e.g. np.load results)
             a = a.copy()
         return torch.from_numpy(a).to(self.device)
@@ -327,26 +331,12 @@ class Context(object):
         whole costs about one host memcpy (a pageable hipMemcpy stages through a small internal buffer at 5-8 GB/s).
         Returns when the last piece has been handed to the DMA engine; the device side is ordered on the current stream.
         """
-        import torch
-        src = np.ascontiguousarray(array).reshape(-1).view(np.uint8)
-        dst = out.reshape(-1).view(torch.uint8)
-        assert dst.numel() == src.size, 'upload: sizes differ'
-        piece = 8 << 20
-        st = self._staging
-        if st is None:
-            st = self._staging = dict(buf=[torch.empty(piece, dtype=torch.uint8, pin_memory=True) for _ in range(3)],
-                                      done=[None, None, None], k=0)
-        for lo in range(0, src.size, piece):
-            i = st['k'] % 3
-            st['k'] += 1
-            if st['done'][i] is not None:
-                st['done'][i].synchronize()           # the DMA out of this staging piece has finished
-            n = min(piece, src.size - lo)
-            st['buf'][i].numpy()[:n] = src[lo:lo + n]
-            dst[lo:lo + n].copy_(st['buf'][i][:n], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            st['done'][i] = ev
+        src = np.ascontiguousarray(array)
+        assert out.is_contiguous() and out.numel() * out.element_size() == src.nbytes, 'upload: sizes differ'
+        # amt_upload_staged: a few host threads copy every n-th piece through page-locked staging pieces of their own and
+        # hand it to the DMA engine on the current stream (one thread's memcpy into page-locked memory is half the link's rate)
+        Context.current(self.device)
+        self.call('amt_upload_staged', C.c_void_p(out.data_ptr()), C.c_void_p(src.ctypes.data), src.nbytes)
 
     # -- per-kernel timing ----------------------------------------------------------------------
     def timing_enable(self, enable=True):
@@ -411,6 +401,24 @@ def host9(m):
 
 
 _PIN_MIN_BYTES = 1 << 20
+# page-locked bytes that to_host() hands out as result arrays at any one time (beyond it: pageable arrays)
+_PINNED_RESULT_LIMIT = int(float(os.environ.get('AMT_PINNED_RESULT_GB', '2')) * (1 << 30))
+_pinned_out = {'bytes': 0}
+
+
+def _pinned_release(nbytes):
+    _pinned_out['bytes'] -= nbytes
+
+
+class _NumpyOfTorch(dict):
+    def __missing__(self, key):
+        import torch
+        self.update({torch.float64: np.float64, torch.uint8: np.uint8, torch.int16: np.int16, torch.int64: np.int64,
+                     torch.int32: np.int32, torch.float32: np.float32, torch.bool: np.bool_, torch.int8: np.int8})
+        return dict.__getitem__(self, key)
+
+
+_NUMPY_OF_TORCH = _NumpyOfTorch()
 
 
 def to_host(tensor, dtype=None, shape=None):
@@ -419,12 +427,24 @@ def to_host(tensor, dtype=None, shape=None):
     torch's caching host allocator takes the block back when the array is freed, so a loop that reads one array per
     frame pays the page-locking once."""
     import torch
-    if tensor.is_cuda and tensor.numel() * tensor.element_size() >= _PIN_MIN_BYTES:
+    nbytes = tensor.numel() * tensor.element_size()
+    if tensor.is_cuda and nbytes >= _PIN_MIN_BYTES:
         t = tensor if tensor.is_contiguous() else tensor.contiguous()
-        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        host.copy_(t, non_blocking=True)
-        torch.cuda.current_stream(t.device).synchronize()
-        a = host.numpy()
+        if _pinned_out['bytes'] + nbytes <= _PINNED_RESULT_LIMIT:
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            host.copy_(t, non_blocking=True)
+            torch.cuda.current_stream(t.device).synchronize()
+            a = host.numpy()
+            # (ADVICE r3) page-locked memory handed out as results is bounded: a caller that keeps many mappings' arrays
+            # alive gets ordinary pageable arrays beyond the limit instead of pinning tens of GB
+            _pinned_out['bytes'] += nbytes
+            weakref.finalize(a, _pinned_release, nbytes)     # (views of `a` keep it alive through their base)
+        else:
+            # pageable result through the library's staged copy (worker threads + page-locked pieces: the link's rate
+            # once the pages exist; a fresh allocation also pays its page faults)
+            ctx = Context.current(t.device)
+            a = np.empty(tuple(t.shape), dtype=_NUMPY_OF_TORCH[t.dtype])
+            ctx.call('amt_download_staged', C.c_void_p(a.ctypes.data), C.c_void_p(t.data_ptr()), nbytes)
     else:
         a = tensor.cpu().numpy()
     if dtype is not None and a.dtype != np.dtype(dtype):

@@ -13,8 +13,12 @@
 
 #include "../../include/auromat_hip.h"
 
+struct amt_copier;                       // staged host <-> device copies (amt_copy.hip)
+void amt_copier_destroy(amt_copier* c);
+
 struct amt_ctx {
     int device;
+    amt_copier* copier;
     hipStream_t stream;
     bool owns_stream;
     double* scratch;        // small device scratch (counters)

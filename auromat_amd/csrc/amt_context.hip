@@ -17,6 +17,7 @@ int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ct
     ctx->owns_stream = false;
     ctx->scratch = nullptr;
     ctx->timing = 0;
+    ctx->copier = nullptr;
     ctx->last_second = ctx->last_bin = ctx->last_frames = -1;
     ctx->aux_pre = ctx->aux_tail = ctx->aux_fin = nullptr;
     ctx->tlaunch[0] = ctx->tlaunch[1] = 0;
@@ -47,6 +48,7 @@ int amt_ctx_create(int device_id, void* stream, int own_stream, amt_ctx** out_ct
 int amt_ctx_destroy(amt_ctx* ctx) {
     AMT_CHECK_CTX(ctx);
     (void)hipSetDevice(ctx->device);
+    amt_copier_destroy(ctx->copier);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (auto& w : ctx->workspaces)
         if (w.ptr) (void)hipFree(w.ptr);

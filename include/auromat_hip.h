@@ -68,6 +68,13 @@ int amt_free(amt_ctx* ctx, void* dptr);
 int amt_memcpy_h2d(amt_ctx* ctx, void* dst, const void* src, size_t bytes);   /* async on the stream */
 int amt_memcpy_d2h(amt_ctx* ctx, void* dst, const void* src, size_t bytes);   /* synchronises */
 int amt_memset(amt_ctx* ctx, void* dst, int value, size_t bytes);
+/* Whole arrays between PAGEABLE host memory and the device at the rate of the link: a few host threads (AMT_COPY_THREADS,
+ * default 8) each copy every n-th 4 MiB piece through page-locked staging pieces of their own and hand it to the DMA engine
+ * on the context's stream (what a NumPy-array API like the reference's needs at its boundary: mapping.py:318-337 takes the
+ * image as an array, every property returns one).  amt_upload_staged returns when the last piece has been handed over (the
+ * source may be reused; the device side is ordered on the stream); amt_download_staged returns when dst_host is complete. */
+int amt_upload_staged(amt_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+int amt_download_staged(amt_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
 /* HIP-event timing on the context's stream (bench.py measures kernels with these). */
 int amt_event_create(amt_ctx* ctx, void** out_event);
 int amt_event_destroy(amt_ctx* ctx, void* event);

@@ -571,6 +571,48 @@ def test_a_frame_handed_back_because_of_a_poor_estimate_is_relaunched_with_its_e
             assert np.array_equal(res[k], ref[k], equal_nan=True), k
 
 
+def test_staged_copies_between_pageable_memory_and_the_device():
+    """amt_upload_staged / amt_download_staged (worker threads, page-locked pieces): odd sizes, sizes below and above one
+    piece and above one round of all workers' pieces, repeated use of the staging buffers; to_device / to_host on top of
+    them, the bound on page-locked result memory included."""
+    import ctypes as C
+    import torch
+    import auromat_amd._native as N
+    ctx = N.Context.current()
+    rs = np.random.RandomState(4)
+    for nbytes in (1, 4097, (4 << 20) - 1, 4 << 20, (4 << 20) + 5, (37 << 20) + 3, 72 * 1000 * 1000):
+        src = rs.randint(0, 256, nbytes).astype(np.uint8)
+        dev = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+        ctx.call('amt_upload_staged', C.c_void_p(dev.data_ptr()), C.c_void_p(src.ctypes.data), nbytes)
+        assert np.array_equal(dev.cpu().numpy(), src)
+        back = np.zeros(nbytes, dtype=np.uint8)
+        ctx.call('amt_download_staged', C.c_void_p(back.ctypes.data), C.c_void_p(dev.data_ptr()), nbytes)
+        assert np.array_equal(back, src)
+    a = rs.rand(1200, 1300)
+    t = ctx.to_device(a)
+    assert np.array_equal(N.to_host(t), a)
+    m = rs.rand(1500, 1400) > 0.5
+    assert ctx.to_device(m, np.bool_).dtype == torch.bool and ctx.to_device(m[:10, :10], np.bool_).dtype == torch.bool
+    assert np.array_equal(N.to_host(ctx.to_device(m, np.bool_)).astype(bool), m)
+    # beyond the limit of page-locked result memory the arrays are pageable ones, equal all the same
+    limit = N._PINNED_RESULT_LIMIT
+    try:
+        N._PINNED_RESULT_LIMIT = 0
+        b = N.to_host(t)
+        assert np.array_equal(b, a) and b.flags.owndata
+        i16 = torch.arange(-3000000, 3000000, dtype=torch.int64, device='cuda').to(torch.int16)
+        assert np.array_equal(N.to_host(i16, dtype=np.uint16), i16.cpu().numpy().view(np.uint16))
+    finally:
+        N._PINNED_RESULT_LIMIT = limit
+    held = N._pinned_out['bytes']
+    c = N.to_host(t)
+    assert N._pinned_out['bytes'] == held + a.nbytes
+    del c
+    import gc
+    gc.collect()
+    assert N._pinned_out['bytes'] == held
+
+
 def test_batched_launch_and_sequence_hints_change_nothing():
     """Two frames per launch of the big kernel (amt_pipe_launch_many) and bounding-box hints from the previous
     frame instead of the coarse pre-pass give the same bits as one frame at a time with pre-passes."""
