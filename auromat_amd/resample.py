@@ -544,7 +544,7 @@ def grid_coordinates(res):
 
 
 def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingBox, pxPerDeg,
-              containsDiscontinuity=False, containsPole=False, method='mean'):
+              containsDiscontinuity=False, containsPole=False, method='mean', _alt_out=None):
     """
     Array-level resampling with the reference's signature (resample.py:159-279): every channel of
     `data` (float, NaN = missing) is binned on its own.
@@ -554,6 +554,9 @@ def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingB
     :param outlineLatLonFn: callable returning (n,2) [lat,lon] points whose min/max bound the data
                             (only used in the pole / discontinuity branches)
     :param pxPerDeg: tuple (latPxPerDeg, lonPxPerDeg)
+    :param _alt_out: (not in the reference; method='linear' only) a list that receives the (ny, nx, n) array of the values
+                     with the OTHER diagonal of every grid centre's lattice cell (see amt_linear_gather: Qhull takes either
+                     diagonal of a near-cocircular cell; the tests bound the reference's values by the two)
     :rtype: tuple (lat, lon, latCenter, lonCenter, data)
     """
     _check_method(method)
@@ -629,6 +632,16 @@ def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingB
             wts = torch.stack((1.0 - w1 - w2, w1, w2), dim=1)
             picked = (wts[:, :, None] * flat[t]).sum(dim=1)
             picked[~ok] = float('nan')
+            if _alt_out is not None:
+                # channel by channel through the kernel's own interpolation (the channel in the place of the elevation)
+                alt = ctx.empty((grid.ny * grid.nx, d.shape[2]))
+                for c in range(d.shape[2]):
+                    chan = flat[:, c].contiguous()
+                    m1, a1 = ctx.empty((grid.ny * grid.nx,)), ctx.empty((grid.ny * grid.nx,))
+                    ctx.call('amt_linear_gather', ptr(index), grid.ny, grid.nx, ptr(la), ptr(lo), ptr(chan), None, h, w,
+                             float('-inf'), lon_wrap, ptr(tlat), ptr(tlon), None, 1, 0, ptr(m1), None, None, ptr(a1), None)
+                    alt[:, c] = a1
+                _alt_out.append(to_host(alt.reshape(grid.ny, grid.nx, d.shape[2])))
         mean = to_host(picked.reshape(grid.ny, grid.nx, d.shape[2]))
     lat, lon, lat_gc, lon_gc = grid.lat, grid.lon, grid.lat_c, grid.lon_c
     if containsPole:

@@ -277,6 +277,29 @@ def test_reference_resample_test_call_sequence():
 # diagonal; the rule that survives that choice: the reference's value lies between the interpolants of the quad's two
 # diagonals (`mean` and `alt`), and equals `mean` wherever the two agree.
 
+# Share of the cells whose value equals the reference's to 1e-9 in every channel (the same triangle as Qhull's), and of those
+# whose value lies between the interpolants of the cell's two diagonals.  Observed on MI355X (round 4, the reduced-lattice
+# triangulation): 1.0000 for both in all five cases — the thresholds leave room for a handful of cells.
+SAME_TRIANGLE = {'iss030': 0.998, 'iss029': 0.998, 'synth_plain': 0.995, 'synth_disc': 0.995, 'synth_pole': 0.99}
+BETWEEN = SAME_TRIANGLE
+
+
+def local_variation(lat_px, lon_px, data, lat_g, lon_g, ring=3):
+    """(ny, nx, n): max - min of every channel of `data` (h, w, n; NaN = missing) over the (2 ring + 1)^2 pixels around the
+    pixel centre nearest to each grid centre (nearest in the (lat, lon cos lat) plane, longitudes compared modulo 360)."""
+    h, w = lat_px.shape
+    vi, vj = np.nonzero(~np.isnan(lat_px))
+    pla, plo = lat_px[vi, vj], lon_px[vi, vj]
+    out = np.full(lat_g.shape + (data.shape[2],), np.nan)
+    for ty in range(lat_g.shape[0]):
+        for tx in range(lat_g.shape[1]):
+            dlo = (plo - lon_g[ty, tx] + 180.0) % 360.0 - 180.0
+            k = int(np.argmin((pla - lat_g[ty, tx]) ** 2 + (dlo * np.cos(np.deg2rad(lat_g[ty, tx]))) ** 2))
+            i, j = int(vi[k]), int(vj[k])
+            win = data[max(i - ring, 0):i + ring + 1, max(j - ring, 0):j + ring + 1].reshape(-1, data.shape[2])
+            with np.errstate(all='ignore'):
+                out[ty, tx] = np.nanmax(win, axis=0) - np.nanmin(win, axis=0)
+    return out
 LINEAR = [('resample_nearest_iss030.npz', 'iss030'), ('resample_nearest_iss029.npz', 'iss029'),
           ('resample_nearest_synth_plain.npz', 'synth_plain'), ('resample_nearest_synth_disc.npz', 'synth_disc'),
           ('resample_nearest_synth_pole.npz', 'synth_pole')]
@@ -295,10 +318,18 @@ def test_resample_linear_vs_reference(name, key):
         data = z['data']
     s, w, n, e = z['bbox']
     outline = z['outline'].copy()
+    alt = []
     lat, lon, lat_c, lon_c, out = _resample(z['lats_c'], z['lons_c'], float(z['altitude']), data, lambda: outline,
                                             BoundingBox(s, w, n, e), tuple(z['ppd']), bool(z['contains_discontinuity']),
-                                            bool(z['contains_pole']), method='linear')
-    assert out.shape == want.shape and np.array_equal(lat_c, zl[key + '_out_lat_c']) or bool(z['contains_pole'])
+                                            bool(z['contains_pole']), method='linear', _alt_out=alt)
+    alt = alt[0]
+    assert out.shape == want.shape == alt.shape
+    if bool(z['contains_pole']):
+        # the grid is laid out in rotated coordinates and turned back (resample.py:262-273): equal to the rounding of the
+        # two rotations
+        assert np.max(np.abs(lat_c - zl[key + '_out_lat_c'])) < 1e-9
+    else:
+        assert np.array_equal(lat_c, zl[key + '_out_lat_c'])
     got_nan, want_nan = np.isnan(out[..., 0]), np.isnan(want[..., 0])
     # cells only one side fills: on the rim of the convex hull (Qhull spans concavities of the footprint with long thin
     # triangles that the outline mask does not always remove, the pixel grid has no such triangles) — listed, and few
@@ -328,10 +359,19 @@ def test_resample_linear_vs_reference(name, key):
     # of a near-cocircular quad, which Qhull picks about every second time; tools/linear_probe.py: 61 % of the triangles
     # of a camera frame are common to both triangulations)
     same_tri = (d <= 1e-9 * scale).all(axis=1)
-    assert same_tri.mean() > 0.3, same_tri.mean()
-    # all cells: within the smoothness of the data over one quad (image noise is uncorrelated from pixel to pixel, so the
-    # image channels are only bounded by their range; the elevation channel is smooth: a diagonal flip moves it by < 1e-2 deg)
+    # EVERY channel of every cell against the reference: its value lies between the interpolants of the two diagonals of
+    # the device's lattice cell (`out` and `alt`) unless Qhull joined pixels that are not corners of one cell
+    lo_v, hi_v = np.minimum(out, alt)[both], np.maximum(out, alt)[both]
+    v = want[both]
+    between = ((v >= lo_v - 1e-9 * scale) & (v <= hi_v + 1e-9 * scale)).all(axis=1)
+    print(key, 'cells', int(both.sum()), 'same triangle %.4f' % same_tri.mean(), 'between the two diagonals %.4f' % between.mean(),
+          'largest elevation difference %.3g' % d[:, -1].max())
+    assert same_tri.mean() > SAME_TRIANGLE[key], same_tri.mean()
+    assert between.mean() > BETWEEN[key], between.mean()
+    # the others: within the smoothness of the data over one cell (image noise is uncorrelated from pixel to pixel, so their
+    # image channels are only bounded by the data's range; the elevation channel is smooth: < 2e-2 deg)
     assert (d[:, -1] < 2e-2).all(), d[:, -1].max()
+    assert (np.abs(v[~between]) <= scale * (1 + 1e-12)).all()
 
 
 @pytest.mark.parametrize('pointing,ppd', [('iss030', 10), ('iss029', (4, 7))])
@@ -427,6 +467,10 @@ def test_cubic_gradients_and_values_equal_scipy_on_an_unambiguous_triangulation(
 
 
 CUBIC = LINEAR + [('resample_nearest_iss030.npz', 'iss030_smooth')]
+# |difference to the reference| <= this x the channel's variation over the 7 x 7 pixels around the cell (a cubic overshoots:
+# observed on MI355X up to 2.34 for the pixel noise of the camera frames, 0.19 for the synthetic cases, 0.012 for smooth
+# channels)
+CUBIC_LOCAL, CUBIC_LOCAL_SMOOTH = 3.0, 0.05
 
 
 @pytest.mark.parametrize('name,key', CUBIC)
@@ -464,9 +508,17 @@ def test_resample_cubic_vs_reference(name, key):
     for c in smooth:
         assert np.median(d[:, c]) < 1e-5 * span[c], (c, np.median(d[:, c]) / span[c])
         assert np.quantile(d[:, c], 0.99) < 2e-3 * span[c], (c, np.quantile(d[:, c], 0.99) / span[c])
-    # every channel: bounded by the range of the data (pixel noise makes the gradients depend on the diagonal chosen), and
-    # most cells agree in every channel to the solvers' tolerance — the device's triangles are Qhull's there
-    assert (np.median(d, axis=0) < 0.2 * span).all()
+    # every channel of every cell: where Qhull chose the other diagonal of a near-cocircular cell the estimated gradients and
+    # the element change with the NEIGHBOURS' values, i.e. by a fraction of what the channel varies by over the few pixels
+    # around the cell (pixel noise: up to its range; a smooth channel: next to nothing) — bounded by that local variation,
+    # not by the channel's span; and most cells agree in every channel to the solvers' tolerance (the device's triangles are
+    # Qhull's there), so the median difference is at rounding level
+    local = local_variation(z['lats_c'], z['lons_c'], data, lat_c, lon_c)[both]
+    ratio = (d - 1e-5 * span) / np.where(local > 0, local, np.inf)
+    print(key, 'largest difference in units of the local variation (7 x 7 pixels), per channel', np.nanmax(ratio, axis=0))
+    assert (np.nanmax(ratio, axis=0) < CUBIC_LOCAL).all(), np.nanmax(ratio, axis=0)
+    assert (np.nanmax(ratio, axis=0)[smooth] < CUBIC_LOCAL_SMOOTH).all(), np.nanmax(ratio, axis=0)
+    assert (np.median(d, axis=0) < (1e-7 if 'img' in z.files else 5e-5) * span).all(), np.median(d, axis=0) / span
     agree = (d <= 1e-5 * span).all(axis=1).mean()
     print(key, 'cells equal to 1e-5 of the span in every channel: %.3f' % agree)
     assert agree > (0.5 if 'img' in z.files else 0.3), agree
