@@ -583,7 +583,9 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
         auto fill_nan = [&](double* base, int64_t first, int64_t count) {
             if (base == nullptr) return;
             int64_t a = first + count * strip / strips_x, b = first + count * (strip + 1) / strips_x;
-            if ((a & 1) && a < b) {                        // 16-byte alignment of the pairs (the arrays are 16-byte aligned)
+            // 16-byte alignment of the pairs, from the address itself: an output array may start at any multiple of 8 bytes
+            // (a row slice of a larger array handed to the C API)
+            if ((reinterpret_cast<uintptr_t>(base + a) & 15) != 0 && a < b) {
                 if (lane == 0) base[a] = NAN;
                 ++a;
             }

@@ -15,6 +15,7 @@ Same interface as :mod:`auromat_amd.export._nc3` (create_dimension / create_vari
 options the reference uses: ``zlib`` (deflate level 4 behind the byte shuffle, netCDF4-python's defaults) and ``chunksizes``.
 Checked by reading the files back with HDF5 1.10 (h5py, h5dump, h5ls) where that exists (tests/test_export_netcdf4.py).
 """
+import os
 import struct
 import zlib as _zlib
 from collections import OrderedDict
@@ -25,7 +26,9 @@ UNDEF = 0xFFFFFFFFFFFFFFFF
 _GROUP_K = 16            # group B-tree K (internal) — one node with one child is all this writer makes
 _CHUNK_K = 32            # chunk B-tree K: the library's default for superblock version 0 (which has no field for it)
 _DEFLATE_LEVEL = 4       # netCDF4-python's default complevel
-_THREADS = 8             # threads that compress the chunks of a large array
+# threads that compress the chunks of a large array (deflate releases the interpreter lock); AMT_NC4_THREADS overrides
+_THREADS = max(1, min(16, int(os.environ.get('AMT_NC4_THREADS', '0')) or (os.cpu_count() or 1)))
+_ROWS_PER_TASK = 32      # chunks of one row: rows a task shuffles at once (one NumPy copy) and then deflates one by one
 
 NOT_A_VARIABLE = 'This is a netCDF dimension but not a netCDF variable.%10d'
 # the library's default fill values (netcdf.h NC_FILL_*): the HDF5 fill value of a variable without a _FillValue
@@ -87,6 +90,10 @@ def _dataspace(shape):
 
 def _message(mtype, data, flags=0):
     data = _pad8(data)
+    if len(data) > 0xFFF8:
+        # the size field of a version-1 header message has 16 bits (a larger attribute would need a dense attribute
+        # storage or a continuation per message, which this writer does not lay out)
+        raise ValueError('header message of %d bytes: an attribute must stay below 64 KiB' % len(data))
     return struct.pack('<HHB3x', mtype, len(data), flags) + data
 
 
@@ -109,13 +116,16 @@ def _attr_message(name, value):
         a = a.astype(np.int8)
     if a.dtype.kind not in 'iuf':
         raise TypeError('no netCDF-4 attribute type for ' + repr(value))
+    if a.size == 0:
+        raise ValueError('an empty numeric attribute (%r) cannot be stored' % name)
     a = a.astype(a.dtype.newbyteorder('<'))
     # (netCDF attributes are one-dimensional; a single number is an array of one)
     return _attribute(name, datatype_message(a.dtype), (max(a.size, 1),) if a.ndim else (1,), np.atleast_1d(a).tobytes())
 
 
 def check_attribute(value):
-    """raises TypeError for values that cannot be stored (what export.netcdf checks before it writes anything)"""
+    """raises TypeError / ValueError for values that cannot be stored — an unsupported type, an empty array, 64 KiB or more —
+    (what export.netcdf checks before it writes anything)"""
     _attr_message('x', value)
 
 
@@ -187,11 +197,29 @@ class _Dataset(object):
             return off, raw
 
         todo = list(np.ndindex(*grid))
-        if zlib and len(todo) >= 64 and a.nbytes >= (1 << 22):
-            # deflate releases the interpreter lock: the chunks of a large array are compressed by a few threads
+        rows = tuple(chunks) == (1,) + tuple(shape[1:]) and len(shape) >= 2
+        if zlib and rows and shape[0] >= 64 and a.nbytes >= (1 << 22):
+            # The reference's layout — one row per chunk (export/netcdf.py:128-326: chunksizes=(1, w)) — for a large array:
+            # a task takes a block of rows, shuffles all of them with ONE NumPy copy (per-chunk Python work under the
+            # interpreter lock was what bound the first version: 34 000 chunks per frame, 8 threads, 6.4 of 8.4 s) and
+            # deflates them row by row, which releases the lock; the blocks run on a few threads
+            from concurrent.futures import ThreadPoolExecutor
+            zero = (0,) * (len(shape) - 1)
+
+            def block(r0):
+                blk = a[r0:r0 + _ROWS_PER_TASK]
+                n = blk.shape[0]
+                by = blk.view(np.uint8).reshape(n, -1, itemsize)
+                sh = np.ascontiguousarray(by.transpose(0, 2, 1)).reshape(n, -1) if itemsize > 1 else by.reshape(n, -1)
+                return [((r0 + i,) + zero, _zlib.compress(sh[i], _DEFLATE_LEVEL)) for i in range(n)]
+
+            with ThreadPoolExecutor(max_workers=_THREADS) as pool:
+                self.chunks = [c for part in pool.map(block, range(0, shape[0], _ROWS_PER_TASK)) for c in part]
+        elif zlib and len(todo) >= 64 and a.nbytes >= (1 << 22):
+            # (other chunk shapes) deflate releases the interpreter lock: the chunks are compressed by a few threads
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=_THREADS) as pool:
-                self.chunks = list(pool.map(one, todo, chunksize=32))
+                self.chunks = list(pool.map(one, todo))
         else:
             self.chunks = [one(idx) for idx in todo]
 
@@ -279,6 +307,14 @@ class _Dataset(object):
         return out + b''.join(_pad8(raw) for _, raw in self.chunks)
 
 
+class _Sized(object):
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+
 class Writer(object):
     """Collects dimensions, global attributes and variables, then writes the file in one go."""
 
@@ -338,7 +374,7 @@ class Writer(object):
         gcol_size = max(4096, 16 + 24 * heap_objects + 16)
         gcol_size += -gcol_size % 8
 
-        def build(addr):
+        def build(addr, sizes_only=False):
             """every piece with the addresses of `addr` (dataset name -> header address, plus 'gcol') -> ordered list of
             (name, bytes)"""
             for name, ds in datasets.items():
@@ -389,12 +425,14 @@ class Writer(object):
             for name, ds in datasets.items():
                 pieces.append((name, ds.header(addr.get(name + ':data', 0))))
                 if ds.layout != 'unallocated':
-                    pieces.append((name + ':data', ds.data_blob(addr.get(name + ':data', 0))))
+                    # (the sizing pass only asks for the length: the blob of a large array is hundreds of MB of joins)
+                    pieces.append((name + ':data', _Sized(ds.data_size()) if sizes_only else
+                                   ds.data_blob(addr.get(name + ':data', 0))))
             return pieces
 
         # first pass: sizes (they do not depend on the addresses), then the addresses, then the real thing
         addr = {k: 0 for k in list(datasets) + ['gcol', 'btree', 'heap', 'snod']}
-        sizes = [(name, len(b)) for name, b in build(addr)]
+        sizes = [(name, len(b)) for name, b in build(addr, sizes_only=True)]
         pos = 96                                   # behind the superblock
         for name, n in sizes:
             addr[name] = pos

@@ -179,6 +179,32 @@ def test_exported_mapping_through_the_hdf5_library(case, tmp_path):
 
 
 @needs_h5py
+def test_attributes_the_container_cannot_hold_are_refused_before_anything_is_written(tmp_path):
+    """A version-1 header message has a 16-bit size: an attribute of 64 KiB or more (a long history string) and an empty
+    numeric attribute are refused with a clear error by check_attribute — what export.netcdf.write calls for every global
+    attribute before it writes — and by the writer itself, instead of a struct.error in the middle of write()."""
+    from auromat_amd.export import _nc4
+    _nc4.check_attribute('x' * 60000)                              # just below the limit: fine
+    _nc4.check_attribute(np.arange(8000, dtype=np.float64))
+    with pytest.raises(ValueError, match='64 KiB'):
+        _nc4.check_attribute('history ' * 9000)                    # 72 KB
+    with pytest.raises(ValueError, match='64 KiB'):
+        _nc4.check_attribute(np.zeros(9000))
+    with pytest.raises(ValueError, match='empty'):
+        _nc4.check_attribute(np.zeros(0))
+    with pytest.raises(TypeError):
+        _nc4.check_attribute(object())
+    w = _nc4.Writer()
+    primitives(w)
+    w.attrs['history'] = 'h' * 70000
+    path = str(tmp_path / 'big_attr.nc')
+    with pytest.raises(ValueError, match='64 KiB'):
+        w.write(path)
+    w.attrs['history'] = 'h' * 50000
+    w.write(path)
+    assert _nc4.open_file(path).attrs['history'] == 'h' * 50000
+
+
 def test_own_reader_reads_a_file_of_the_hdf5_library(tmp_path):
     """The reader against the other implementation: a file h5py wrote with its default (oldest) structures, chunked, shuffled,
     deflated, with attributes and attached dimension scales."""
