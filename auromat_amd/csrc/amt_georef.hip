@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void k_georef(georef_args A) {
 //
 // All arithmetic is in fx:: (amt_common.h): explicit fma / mul / add in a fixed order, so that every variant of the
 // kernel gives the same bits (the two execution plans of the pipeline are tested for bit-identical grids).
-// What round 2 measured about this kernel: it is not FP64-issue bound any more; straight-line
+// What round 2 measured about this kernel (profiles/NOTEBOOK_r1-r3.md 4.1a): it is not FP64-issue bound any more; straight-line
 // "speculative" and per-phase wave-uniform variants of the row step (no NaN presets, no exec-mask regions) were
 // built and were SLOWER than this plain divergent form (register pressure, code size), so they were dropped.
 // ------------------------------------------------------------------------------------------
