@@ -759,8 +759,14 @@ def main(argv=None):
             out['cpu_baseline'] = None
         # the JSON line is the LAST thing on stdout: flush what C libraries have buffered there (RCCL's banner),
         # print, and close the descriptor for whatever they print while shutting down
+        # (RCCL's banner sits in the C library's buffer for stdout: it is flushed to stderr, so that stdout carries the one line)
         import ctypes
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
         ctypes.CDLL(None).fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
         print(json.dumps(out))
         sys.stdout.flush()
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)

@@ -5,7 +5,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, 'gpurun_out', 'r4', 'final'), os.path.join(ROOT, 'profiles', 'r4')
 os.makedirs(DST, exist_ok=True)
 for name in sorted(os.listdir(SRC)):
-    if name.endswith('.json') or name == 'e_pmc_summary_per_launch.txt':
+    if name.endswith('.json'):
+        # (a line of its own: whatever a library printed before it is dropped)
+        lines = [ln for ln in open(os.path.join(SRC, name)).read().splitlines() if ln.startswith('{"metric"')]
+        if lines:
+            open(os.path.join(DST, name), 'w').write(lines[-1] + '\n')
+    elif name == 'e_pmc_summary_per_launch.txt':
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
 shutil.copy(os.path.join(ROOT, 'tools', 'profile_r4.sh'), os.path.join(DST, 'a_cmd.sh'))
 

@@ -11,7 +11,7 @@ from oracle import ref_numpy as O
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-bad = skipped = n_single = n_pole = 0
+bad = skipped = n_single = n_pole = n_box_first = 0
 for case in range(cases):
     big = int(os.environ.get('BIG', '1'))                # BIG=5: frames up to 2100 x 1500
     w, h = int(rng.randint(40, 420 * big)), int(rng.randint(30, 300 * big))
@@ -41,6 +41,7 @@ for case in range(cases):
         skipped += 1                                   # nothing above the threshold / degenerate grid: as the reference
         continue
     arrays_two = pipe.host_arrays() if with_mag else None
+    pole_two_pass = bool(two['contains_pole'])
     one = pipe.run(hdr, alt, cam, t, fast=fast, min_elevation=thr, pxPerDeg=ppd, fuse=True, magnetic=magnetic)
     for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
         if not np.array_equal(one[k], two[k], equal_nan=True):
@@ -54,6 +55,40 @@ for case in range(cases):
                 bad += 1
                 print('ARRAYS DIFFER', tag, k, pipe.last_plan)
                 break
+    if magnetic:
+        # round 4, MLat / MLT-only mode (k_georef_rows<SECOND = 4>): the same grid, and the five arrays it keeps, bit for bit
+        lean = FramePipeline(w, h, img_dtype=dtype, with_mag=True, with_geo=False)
+        five = lean.run(hdr, alt, cam, t, img=img, fast=fast, min_elevation=thr, pxPerDeg=ppd, fuse=True, magnetic=True)
+        for k in ('mean', 'count', 'img', 'mask'):
+            if not np.array_equal(five[k], two[k], equal_nan=True):
+                bad += 1
+                print('MLAT/MLT-ONLY GRID DIFFERS', tag, k, lean.last_plan, lean.ctx.last_variant())
+                break
+        if lean.last_plan == 'single-pass' and not five['contains_pole']:
+            kept = lean.host_arrays(kept_only=True)
+            for k, v in kept.items():
+                if not np.array_equal(v, arrays_two[k], equal_nan=True):
+                    bad += 1
+                    print('MLAT/MLT-ONLY ARRAYS DIFFER', tag, k)
+                    break
+        del lean
+    if not two['contains_pole'] and rng.randint(2) == 0:
+        # round 4, box-first plan: arcsecPerPx -> a box pass, px/deg from the frame's own box, the single-pass launch; against
+        # the two-pass plan at that px/deg
+        arcsec = float(rng.choice([150, 300, 600, 1200]))
+        try:
+            bf = pipe.run(hdr, alt, cam, t, fast=fast, min_elevation=thr, arcsecPerPx=arcsec, fuse=True, magnetic=magnetic)
+            plan_bf = pipe.last_plan
+            tp = pipe.run(hdr, alt, cam, t, fast=fast, min_elevation=thr, pxPerDeg=bf['pxPerDeg'], fuse=False, magnetic=magnetic)
+            for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
+                if not np.array_equal(bf[k], tp[k], equal_nan=True):
+                    bad += 1
+                    print('BOX-FIRST DIFFERS', tag, 'arcsec', arcsec, k, plan_bf, bf['pxPerDeg'])
+                    break
+            n_box_first += plan_bf == 'single-pass'
+        except AssertionError:
+            pass                                       # (a degenerate grid at that resolution: as the reference)
+        pipe.run(hdr, alt, cam, t, fast=fast, min_elevation=thr, pxPerDeg=ppd, fuse=True, magnetic=magnetic)   # (last_plan below)
     n_single += pipe.last_plan == 'single-pass'
     if pipe.last_plan != 'single-pass' and os.environ.get('SHOW_PLANS'):
         print('two-pass:', tag, 'pole' if two['contains_pole'] else '', 'dateline' if two['contains_discontinuity'] else '')
@@ -85,5 +120,5 @@ for case in range(cases):
     if ndiff > 2 or imgdiff:
         bad += 1
         print('ORACLE DIFFERS', tag, 'cells', ndiff, 'means', imgdiff, want['count'].sum(), two['count'].sum())
-print('cases', cases, 'skipped', skipped, 'single-pass', n_single, 'pole', n_pole, 'failures', bad)
+print('cases', cases, 'skipped', skipped, 'single-pass', n_single, 'pole', n_pole, 'box-first single-pass', n_box_first, 'failures', bad)
 sys.exit(1 if bad else 0)

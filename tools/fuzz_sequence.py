@@ -51,5 +51,39 @@ for s in range(nseq):
                           'cells differing', int((~np.isclose(x, b[key], equal_nan=True)).sum()) if x.shape == b[key].shape else -1,
                           'plans', seq.plans)
                     break
-print('sequences', nseq, 'through the library loop', native, 'of', 4 * nseq, 'runs; failures', bad)
+    # round 4, box-first plan: a resolution per frame from its own box (arcsecPerPx) — the sequence loop (Python for host images,
+    # the library's for resident ones) against one frame at a time through FramePipeline.run(arcsecPerPx=..., fuse=False)
+    arcsec = float(rng.choice([300, 600, 900]))
+    ref_bf = []
+    for (hd, cam, t, img, alt) in frames:
+        try:
+            ref_bf.append(ref_pipe.run(hd, alt, cam, t, img=img, arcsecPerPx=arcsec, magnetic=magnetic, fuse=False))
+        except (ValueError, AssertionError):
+            ref_bf.append(None)                     # no valid pixel / a pole in view: no resolution (as the reference)
+    for batch in (1, 3):
+        feed = frames
+        kw = {}
+        if os.environ.get('RESIDENT'):
+            feed = [(hd, cam, t, torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img).cuda(), alt)
+                    for hd, cam, t, img, alt in frames]
+            kw = dict(own_image_buffers=False, img_dtype=frames[0][3].dtype)
+        seq = SequencePipeline(w, h, arcsecPerPx=arcsec, batch=batch, magnetic=magnetic, **kw)
+        out = seq.process(feed, keep_on_device=True)
+        native += type(out).__name__ == 'NativeResults'
+        for i, (r, b) in enumerate(zip(out, ref_bf)):
+            if (r is None) != (b is None):
+                bad += 1
+                print('BOX-FIRST: frame %d of seq %d present on one side only' % (i, s), seq.plans[i], b is None)
+                continue
+            if r is None:
+                continue
+            a = dict({key: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for key, v in r.items()}, **grid_coordinates(r))
+            for key in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
+                x = a[key].view(b[key].dtype) if key == 'img' else (a[key].astype(b[key].dtype) if key == 'mask' else a[key])
+                if not np.array_equal(x, b[key], equal_nan=True):
+                    bad += 1
+                    print('BOX-FIRST MISMATCH seq %d magnetic %s batch %d frame %d %s plan %s ppd %s / %s' % (
+                        s, magnetic, batch, i, key, seq.plans[i], r['pxPerDeg'], b['pxPerDeg']))
+                    break
+print('sequences', nseq, 'through the library loop', native, 'of', 6 * nseq, 'runs; failures', bad)
 sys.exit(1 if bad else 0)
