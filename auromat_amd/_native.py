@@ -43,6 +43,17 @@ class GeorefOut(C.Structure):
                 ('bin_pole', C.c_int32), ('reserved_pole', C.c_int32), ('altitude', C.c_double)]
 
 
+SIP_MAX = 10
+
+
+class ZenithalWcs(C.Structure):
+    """amt_zenithal_wcs"""
+    _fields_ = [(k, C.c_int32) for k in ('width', 'height', 'corner', 'projection')] + \
+               [('cd', C.c_double * 4), ('crpix', C.c_double * 2), ('rot', C.c_double * 9), ('start_x', C.c_double),
+                ('start_y', C.c_double), ('sip_order_a', C.c_int32), ('sip_order_b', C.c_int32),
+                ('sip_a', (C.c_double * SIP_MAX) * SIP_MAX), ('sip_b', (C.c_double * SIP_MAX) * SIP_MAX)]
+
+
 class Axis(C.Structure):
     """amt_axis"""
     _fields_ = [('edges', C.c_void_p), ('nbin', C.c_int32), ('uniform', C.c_int32),
@@ -125,6 +136,7 @@ _SIGNATURES = {
     'amt_download_staged': ([_P, _P, _P, C.c_size_t], _I),
     'amt_georef_last_variant': ([_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], _I),
     'amt_directions_tan': ([_P, C.POINTER(FrameParams), _I, _P], _I),
+    'amt_directions_zenithal': ([_P, C.POINTER(ZenithalWcs), _P], _I),
     'amt_directions_tan_points': ([_P, C.POINTER(FrameParams), _P, _P, _L, _I, _P], _I),
     'amt_intersect_ellipsoid': ([_P, _D, _D, c_double_p, _P, _L, _I, _P], _I),
     'amt_intersects_ellipsoid': ([_P, _D, _D, c_double_p, _P, _L, _I, _P], _I),

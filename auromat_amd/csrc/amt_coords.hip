@@ -33,6 +33,60 @@ __global__ void k_directions_tan(tan_wcs w, int width, int height, int corner, d
     }
 }
 
+// Zenithal projections other than plain TAN, with SIP distortion (reference wcs.py:54-56 hands such headers to
+// astropy.wcs.WCS(header).all_pix2world): Calabretta & Greisen 2002, sections 5.1.1-5.1.7, native spherical angles
+// (phi, theta) from the intermediate world coordinates (x, y) in degrees, then the native -> celestial rotation.  The SIP
+// polynomials f(u, v) = sum A_p_q u^p v^q (Shupe et al. 2005) act on the pixel offsets from CRPIX.
+struct zen_args {
+    amt_zenithal_wcs w;
+};
+
+__device__ __forceinline__ double sip_eval(const double (&c)[AMT_SIP_MAX][AMT_SIP_MAX], int order, double u, double v) {
+    double f = 0, up = 1;
+    for (int p = 0; p <= order; ++p) {
+        double g = 0, vq = 1;
+        for (int q = 0; q <= order - p; ++q) {
+            g = fma(c[p][q], vq, g);
+            vq *= v;
+        }
+        f = fma(g, up, f);
+        up *= u;
+    }
+    return f;
+}
+
+__global__ void k_directions_zenithal(zen_args A, double* __restrict__ out) {
+    const amt_zenithal_wcs& w = A.w;
+    const int corner = w.corner ? 1 : 0, cols = w.width + corner;
+    const int64_t n = (int64_t)(w.height + corner) * cols;
+    const double off = corner ? -0.5 : 0.0, k = kRad2Deg;
+    AMT_GRID_STRIDE(i, n) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        double u = (double)c + (w.start_x + off) - w.crpix[0] + 1.0, v = (double)r + (w.start_y + off) - w.crpix[1] + 1.0;
+        if (w.sip_order_a > 0 || w.sip_order_b > 0) {
+            const double fu = w.sip_order_a > 0 ? sip_eval(w.sip_a, w.sip_order_a, u, v) : 0.0;
+            const double fv = w.sip_order_b > 0 ? sip_eval(w.sip_b, w.sip_order_b, u, v) : 0.0;
+            u += fu, v += fv;
+        }
+        const double x = w.cd[0] * u + w.cd[1] * v, y = w.cd[2] * u + w.cd[3] * v;
+        const double rr = sqrt(x * x + y * y);
+        const double phi = atan2(x, -y);
+        double theta;
+        switch (w.projection) {
+            case 0: theta = atan2(k, rr); break;                                   // TAN
+            case 1: theta = acos(rr / k); break;                                   // SIN (no slant)
+            case 2: theta = (90.0 - rr) * kDeg2Rad; break;                         // ARC
+            case 3: theta = 90.0 * kDeg2Rad - 2.0 * atan(rr / (2.0 * k)); break;   // STG
+            default: theta = 90.0 * kDeg2Rad - 2.0 * asin(rr / (2.0 * k)); break;  // ZEA
+        }
+        const double ct = cos(theta);
+        const double nx = ct * cos(phi), ny = ct * sin(phi), nz = sin(theta);
+        out[3 * i + 0] = w.rot[0] * nx + w.rot[1] * ny + w.rot[2] * nz;
+        out[3 * i + 1] = w.rot[3] * nx + w.rot[4] * ny + w.rot[5] * nz;
+        out[3 * i + 2] = w.rot[6] * nx + w.rot[7] * ny + w.rot[8] * nz;
+    }
+}
+
 __global__ void k_directions_tan_points(tan_wcs w, const double* __restrict__ px, const double* __restrict__ py,
                                         int64_t n, double shift, double* __restrict__ out) {
     AMT_GRID_STRIDE(i, n) {
@@ -311,6 +365,22 @@ int amt_directions_tan(amt_ctx* ctx, const amt_frame_params* p, int corner, doub
     const int64_t n = (int64_t)(p->height + corner) * (p->width + corner);
     hipLaunchKernelGGL(k_directions_tan, grid_for(n), dim3(kBlock), 0, ctx->stream, w, p->width, p->height, corner,
                        out_dirs);
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_directions_zenithal(amt_ctx* ctx, const amt_zenithal_wcs* w, double* out_dirs) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, w && out_dirs, "NULL argument");
+    AMT_REQUIRE(ctx, w->width > 0 && w->height > 0, "empty frame");
+    AMT_REQUIRE(ctx, w->projection >= 0 && w->projection <= 4, "projection must be 0 TAN, 1 SIN, 2 ARC, 3 STG or 4 ZEA");
+    AMT_REQUIRE(ctx, w->sip_order_a >= 0 && w->sip_order_a < AMT_SIP_MAX && w->sip_order_b >= 0 && w->sip_order_b < AMT_SIP_MAX,
+                "SIP order out of range");
+    zen_args A;
+    A.w = *w;
+    const int corner = w->corner ? 1 : 0;
+    const int64_t n = (int64_t)(w->height + corner) * (w->width + corner);
+    hipLaunchKernelGGL(k_directions_zenithal, grid_for(n), dim3(kBlock), 0, ctx->stream, A, out_dirs);
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }

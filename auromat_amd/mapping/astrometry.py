@@ -332,15 +332,18 @@ class DirectionArrayMapping(BaseAstrometryMapping):
     """
 
     def __init__(self, cornerDirections, alti, img, cameraPosGCRS, photoTime, identifier, metadata=None):
-        d = np.ascontiguousarray(cornerDirections, dtype=np.float64)
+        """`cornerDirections`: (h + 1, w + 1, 3) array, or a float64 device tensor of that shape (e.g. from
+        ``coordinates.wcs.zenithal_directions_device``), which is used where it lies."""
         img = np.asarray(img)
+        on_device = hasattr(cornerDirections, 'is_cuda') and cornerDirections.is_cuda
+        d = cornerDirections.contiguous() if on_device else np.ascontiguousarray(cornerDirections, dtype=np.float64)
         assert d.ndim == 3 and d.shape[2] == 3 and img.ndim == 3
-        assert d.shape[:2] == (img.shape[0] + 1, img.shape[1] + 1), 'one direction per pixel corner'
+        assert tuple(d.shape[:2]) == (img.shape[0] + 1, img.shape[1] + 1), 'one direction per pixel corner'
         hdr = {'IMAGEW': img.shape[1], 'IMAGEH': img.shape[0]}
         BaseAstrometryMapping.__init__(self, hdr, alti, cameraPosGCRS, photoTime, identifier, metadata or {},
                                        fastCenterCalculation=True)
-        self._dirs = d
-        self._dirs_dev = None
+        self._dirs = None if on_device else d
+        self._dirs_dev = d if on_device else None
         self._img_array = img
 
     def _params(self):
@@ -381,11 +384,14 @@ class DirectionArrayMapping(BaseAstrometryMapping):
 
     @property
     def cameraToPixelCornerDirection(self):
+        if self._dirs is None:
+            from .._native import to_host
+            self._dirs = to_host(self._dirs_dev)
         return self._dirs
 
     @property
     def cameraToPixelCenterDirection(self):
-        return self._cached('dir_center', lambda: self._calcCenters(self._dirs.copy()))
+        return self._cached('dir_center', lambda: self._calcCenters(self.cameraToPixelCornerDirection.copy()))
 
 
 def pixelDirection(fitsWcsHeader, corner=True):

@@ -161,14 +161,15 @@ def getMapping(imagePathOrArray, wcsPathOrHeader, timeshift=None, noradId=None, 
     if cam is None:
         raise ValueError('Spacecraft position is missing in the header; pass cameraPosGCRS '
                          '(TLE propagation is not part of this package)')
-    from ..coordinates.wcs import is_plain_tan, zenithal_pix2world
+    from ..coordinates.wcs import is_plain_tan, zenithal_directions_device
     if not is_plain_tan(wcsHeader):
         # another zenithal projection or SIP terms (the reference hands such headers to astropy.wcs, wcs.py:54-56): the
-        # corner directions from the host generator, everything downstream through the directions-in kernel; centres
-        # are the mean of their four corner hits (the fast mode), whatever fastCenterCalculation says
+        # corner directions from the device generator (amt_directions_zenithal; coordinates.wcs.zenithal_pix2world is its
+        # NumPy restatement), everything downstream through the directions-in kernel; centres are the mean of their four
+        # corner hits (the fast mode), whatever fastCenterCalculation says
         from .astrometry import DirectionArrayMapping
         img = np.asarray(imageArray)
-        dirs = zenithal_pix2world(wcsHeader, img.shape[1], img.shape[0], corner=True)
+        dirs = zenithal_directions_device(wcsHeader, img.shape[1], img.shape[0], corner=True)
         m = DirectionArrayMapping(dirs, altitude, img, cam, photoTime, identifier, metadata)
         m.originalPhotoTime = originalPhotoTime
         return m

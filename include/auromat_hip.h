@@ -201,6 +201,21 @@ typedef struct amt_georef_out {
  * auromat/mapping/astrometry.py:245-269 pixelDirection: unit direction of every pixel corner
  * (corner=1: (height+1, width+1, 3)) or centre (corner=0: (height, width, 3)), AoS. */
 int amt_directions_tan(amt_ctx* ctx, const amt_frame_params* p, int corner, double* out_dirs);
+/* auromat/coordinates/wcs.py:54-56: headers that are not plain TAN go to astropy.wcs.WCS(header).all_pix2world in the reference.
+ * The zenithal family (Calabretta & Greisen 2002, 5.1: TAN, SIN without slant, ARC, STG, ZEA) with SIP distortion polynomials
+ * (CTYPE "...-SIP": A_p_q / B_p_q, Shupe et al. 2005) on the device: unit direction (J2000) of every pixel corner (corner = 1:
+ * (height+1, width+1, 3)) or centre of the rectangle that starts at pixel (start_x, start_y).  rot: native -> celestial
+ * rotation, euler_matrix(RA+90, 90-Dec, -(LONPOLE-90), 'rzxz') as for amt_frame_params.  sip_a[p][q] multiplies u^p v^q
+ * (u, v: pixel offsets from CRPIX), zero beyond the order; order 0 = no distortion.  The result feeds amt_georef_frame_dirs. */
+#define AMT_SIP_MAX 10
+typedef struct amt_zenithal_wcs {
+    int32_t width, height, corner, projection;      /* projection: 0 TAN, 1 SIN, 2 ARC, 3 STG, 4 ZEA */
+    double cd[4], crpix[2], rot[9];
+    double start_x, start_y;
+    int32_t sip_order_a, sip_order_b;
+    double sip_a[AMT_SIP_MAX][AMT_SIP_MAX], sip_b[AMT_SIP_MAX][AMT_SIP_MAX];
+} amt_zenithal_wcs;
+int amt_directions_zenithal(amt_ctx* ctx, const amt_zenithal_wcs* w, double* out_dirs);
 /* auromat/coordinates/wcs.py:66-144 tan_pix2world(header, px, py, origin, ascartesian=True) for arbitrary
  * pixel coordinates (origin 0 or 1 as in FITS/astropy); out (n,3) AoS.  Uses cd, crpix, rot of p only. */
 int amt_directions_tan_points(amt_ctx* ctx, const amt_frame_params* p, const double* px, const double* py,

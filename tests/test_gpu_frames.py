@@ -761,6 +761,32 @@ def test_direction_array_mapping_for_other_camera_models():
     assert np.nanmax(np.abs(c.lons.filled(np.nan) - b.lons.filled(np.nan))) > 0.01
 
 
+@pytest.mark.parametrize('proj', ['TAN', 'SIN', 'ARC', 'STG', 'ZEA'])
+def test_device_generator_for_zenithal_headers_equals_the_numpy_restatement(proj):
+    """amt_directions_zenithal (what getMapping runs for a header that is not plain TAN — the reference hands those to
+    astropy.wcs, wcs.py:54-56) against coordinates.wcs.zenithal_pix2world, the NumPy restatement the CPU tests pin to the
+    projections' laws: corners and centres, a sub-rectangle, with and without SIP polynomials of order 3, LONPOLE != 180."""
+    from auromat_amd._native import to_host
+    from auromat_amd.coordinates.wcs import zenithal_directions_device, zenithal_pix2world
+    from auromat_amd.synthetic import frame_header
+    w, h = 300, 210
+    hdr, cam, t = frame_header(w, h, 'iss029')
+    for sip in (False, True):
+        hd = dict(hdr, CTYPE1='RA---' + proj + ('-SIP' if sip else ''), CTYPE2='DEC--' + proj + ('-SIP' if sip else ''), LONPOLE=173.0)
+        if sip:
+            hd.update(A_ORDER=3, B_ORDER=2, A_2_0=2e-5, A_1_1=-7e-6, A_0_3=3e-8, A_3_0=-2e-8, B_0_2=-1e-5, B_1_1=4e-6, B_2_0=9e-6)
+        for corner, sx, sy, ww, hh in ((True, 0, 0, w, h), (False, 0, 0, w, h), (True, 17, 5, 120, 90)):
+            want = zenithal_pix2world(hd, ww, hh, startX=sx, startY=sy, corner=corner)
+            got = to_host(zenithal_directions_device(hd, ww, hh, startX=sx, startY=sy, corner=corner))
+            assert got.shape == want.shape
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+            # (rounding level; SIN's arccos and ZEA's arcsin amplify it towards the rim of the projection, which this wide
+            # frame reaches: 3 % of the SIN frame lies beyond it and is NaN on both sides)
+            assert np.nanmax(np.abs(got - want)) < (1e-12 if proj in ('SIN', 'ZEA') else 1e-14), (proj, sip, corner, np.nanmax(np.abs(got - want)))
+            n = np.sqrt((got ** 2).sum(axis=-1))
+            assert np.nanmax(np.abs(n - 1)) < 1e-15
+
+
 def test_getMapping_with_a_non_tan_header():
     """A header with another zenithal projection (reference wcs.py:54-56: astropy.wcs) or SIP terms: getMapping builds the
     corner directions on the host (coordinates.wcs.zenithal_pix2world) and hands them to the directions-in kernel — the
