@@ -261,6 +261,42 @@ def test_fallback_frames_inside_a_single_pass_sequence_do_not_race_with_the_fina
                 assert np.array_equal(x, b[key], equal_nan=True), (rep, k, key, seq.plans[k])
 
 
+@pytest.mark.parametrize('arcsec', [None, 600])
+def test_an_iterator_of_frames_is_consumed_as_the_sequence_advances(arcsec):
+    """process() used to turn its iterable into a list before it decided on a loop — a convert run's read-ahead
+    generator of decoded host images (36-72 MB each) then held the whole sequence in memory before the first launch.  A
+    generator is pulled a few batches ahead of the frames that are finished, never to its end; results as for a list."""
+    from auromat_amd.pipeline import SequencePipeline
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    w, h, n = 250, 168, 30
+    frames = []
+    for k in range(n):
+        hdr, cam, t, seed = sequence_frame(k, w, h)
+        frames.append((hdr, cam, t, frame_image(w, h, seed=seed)))
+    kw = dict(arcsecPerPx=arcsec) if arcsec else dict(pxPerDeg=8)
+    want = SequencePipeline(w, h, **kw).process(frames, keep_on_device=False)
+    pulled, seen = [0], []
+
+    def feed():
+        for f in frames:
+            pulled[0] += 1
+            yield f
+
+    def on_batch(k0, results):
+        seen.append((k0 + len(results), pulled[0]))
+
+    seq = SequencePipeline(w, h, **kw)
+    got = seq.process(feed(), keep_on_device=False, on_batch=on_batch)
+    assert len(got) == n and seen[-1][0] == n
+    ahead = max(p - done for done, p in seen[:-3])
+    assert ahead <= 3 * seq.batch + 1 and seen[0][1] < n // 2, seen
+    pulled[0] = 0
+    again = seq.process(feed(), keep_on_device=False)          # without a hook: the same lazy loop for an iterator
+    for a, b, c in zip(got, want, again):
+        for key in ('mean', 'count', 'img', 'mask'):
+            assert np.array_equal(a[key], b[key], equal_nan=True) and np.array_equal(c[key], b[key], equal_nan=True), key
+
+
 def test_box_hints_are_extrapolated_at_the_cadence_of_real_sequences():
     """One frame every 3 s (the ISS sequences of the reference's resources): a frame is prepared 20 s of orbit ahead of
     the latest finished one, too far for that frame's box but not for the extrapolation of the two latest boxes."""
