@@ -703,6 +703,17 @@ def _steady(a, b, c, n_ab, n_bc):
     return True
 
 
+_RUN_RESULT_DTYPE = []
+
+
+def _run_result_dtype():
+    """np.dtype of amt_run_result (built once: the conversion of the nested ctypes structure takes ~60 us, which a
+    20-frame call would pay twice)."""
+    if not _RUN_RESULT_DTYPE:
+        _RUN_RESULT_DTYPE.append(np.dtype(RunResult))
+    return _RUN_RESULT_DTYPE[0]
+
+
 class NativeResults(object):
     """
     The results of one :meth:`SequencePipeline.process` call through the native runner (amt_run_process): a read-only
@@ -716,7 +727,7 @@ class NativeResults(object):
         self._seq, self._rec, self._grids, self._images = seq, records, grids, images
         self._fallbacks, self._keep = fallbacks, keep_on_device
         self._cache = {}
-        self._table = np.frombuffer(records, dtype=np.dtype(RunResult)) if len(records) else None
+        self._table = np.frombuffer(records, dtype=_run_result_dtype()) if len(records) else None
 
     def __len__(self):
         return len(self._rec)
@@ -1071,7 +1082,14 @@ class SequencePipeline(object):
                        os.environ.get('AMT_SEQ_NATIVE_TWO_PASS', '1') != '0')
         if not ((self.single_pass or two_pass_ok) and self.s_alt is None and frames):
             return False
-        return all(isinstance(f[0], dict) and q.is_resident_image(f[3]) for f in frames)
+        # (the checks of FramePipeline.is_resident_image, inlined: this runs for every frame of every call)
+        dt, numel = q._img_torch_dtype, int(np.prod(q._img_shape))
+        for f in frames:
+            img = f[3]
+            if not (type(f[0]) is dict and getattr(img, 'is_cuda', False) and img.dtype == dt and img.numel() == numel and
+                    img.is_contiguous()):
+                return False
+        return True
 
     def _runner(self):
         if self._run is None:
@@ -1140,10 +1158,20 @@ class SequencePipeline(object):
                     for f in frames[done_total:]:
                         alt = f[4] if len(f) > 4 and f[4] is not None else 0.0
                         ctx.check(lib.amt_run_push(run, C.byref(run_frame(f[0], f[1], f[2], alt, f[3].data_ptr(), out=one))))
-                finally:
-                    done = C.c_int32(0)
-                    rc_end = lib.amt_run_end(run, C.byref(done))
-                ctx.check(rc_end)
+                except Exception:
+                    #  a call that failed leaves the runner in no state to go on from: the next call makes a new one
+                    lib.amt_run_end(run, None)
+                    lib.amt_run_destroy(run)
+                    self._run = None
+                    raise
+                done = C.c_int32(0)
+                rc_end = lib.amt_run_end(run, C.byref(done))
+                try:
+                    ctx.check(rc_end)
+                except Exception:
+                    lib.amt_run_destroy(run)
+                    self._run = None
+                    raise
                 g.record_stream(caller)
                 im.record_stream(caller)
                 arenas.append((done_total, done.value, g, im))
@@ -1169,7 +1197,7 @@ class SequencePipeline(object):
                 goff += int(sum(5 * rec[k].ny * rec[k].nx for k in range(a[0], a[0] + a[1])))
                 ioff += sz
         # frames the single-pass plan does not cover (box outside its superset grid, ...): the general path, one by one
-        table = np.frombuffer(rec, dtype=np.dtype(RunResult))
+        table = np.frombuffer(rec, dtype=_run_result_dtype())
         status = table['status']
         self.hinted += int(table['hinted'].sum())
         fallbacks = {}
