@@ -894,7 +894,11 @@ def convertSMMappingToGeo(mapping):
     """Inverse operation to :func:`convertMappingToSM` (reference mapping.py:1549-1559)."""
     smlats, smlons = mapping.lats.data, mapping.lons.data
     smlatsCenter, smlonsCenter = mapping.latsCenter.data, mapping.lonsCenter.data
-    lats, lons = smToLatLon(smlats, smlons, mapping.photoTime)
-    latsCenter, lonsCenter = smToLatLon(smlatsCenter, smlonsCenter, mapping.photoTime)
+    # corners and centres in ONE call (per point the same arithmetic: one round trip to the device instead of two)
+    nc = smlats.size
+    la, lo = smToLatLon(np.concatenate((smlats.ravel(), smlatsCenter.ravel())),
+                        np.concatenate((smlons.ravel(), smlonsCenter.ravel())), mapping.photoTime)
+    lats, lons = la[:nc].reshape(smlats.shape), lo[:nc].reshape(smlons.shape)
+    latsCenter, lonsCenter = la[nc:].reshape(smlatsCenter.shape), lo[nc:].reshape(smlonsCenter.shape)
     return GenericMapping(lats, lons, latsCenter, lonsCenter, mapping.elevation, mapping.altitude,
                           mapping.img, mapping.cameraPosGCRS, mapping.photoTime, mapping.identifier)

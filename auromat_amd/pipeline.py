@@ -465,18 +465,27 @@ class FramePipeline(object):
         # (BoundingBox.containsDiscontinuity is true for every box with a pole in it, reference mapping.py:200-206)
         out = dict(has_elev=True, grid=grid, contains_pole=pole, contains_discontinuity=wrapped or pole,
                    altitude=self.altitude)
+        # (the frame's bytes as they lie in the allocation: mean | count | image | mask — one copy takes all four to the host)
+        out['_block'] = buf[offset:om + n]
         return out, packed, mean, count, img, mask
 
     def _fused_wrap(self, out, packed, mean, count, img, mask, keep_on_device):
         fd = self.fd
+        block = out.pop('_block')
         if keep_on_device:
             # `packed`: mean and count as they lie in memory, one after the other — the payload of this frame in the
             # gather's wire format (auromat_amd.sequence.pack_results) without a copy per array
             out.update(mean=mean, img=img, mask=mask, count=count, packed=packed)
             return out
         out.update(grid_coordinates(out))
-        out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype), mask=to_host(mask).astype(bool),
-                   count=to_host(count))
+        # ONE device-to-host copy (and one synchronisation) for the four arrays, views on the host
+        host = block.cpu().numpy()
+        ny, nx = mean.shape[0], mean.shape[1]
+        n = ny * nx
+        isz = fd.img_dtype.itemsize
+        out.update(mean=host[:32 * n].view(np.float64).reshape(ny, nx, 4), count=host[32 * n:40 * n].view(np.float64).reshape(ny, nx),
+                   img=host[40 * n:40 * n + 3 * isz * n].view(fd.img_dtype).reshape(ny, nx, 3),
+                   mask=host[40 * n + 3 * isz * n:40 * n + 3 * isz * n + n].astype(bool).reshape(ny, nx))
         return out
 
     def _finalize_fused(self, res, pxPerDeg, keep_on_device):

@@ -89,10 +89,16 @@ def resampleMLatMLT(mapping, **kw):
             last_plan = res['plan']
             img = ma.masked_array(res['img'], mask=np.repeat(res['mask'][:, :, None], res['img'].shape[2], 2))
             elevation = ma.masked_invalid(res['mean'][:, :, -1], copy=False)
+            # convertSMMappingToGeo (reference mapping.py:1549-1559) on the grid's arrays as they are: building the SM mapping
+            # first would send the grid to the device and back through its properties, for the same numbers
+            from .coordinates.transform import smToLatLon
             from .mapping.mapping import GenericMapping
-            sm = GenericMapping(res['lat'], res['lon'], res['lat_c'], res['lon_c'], elevation, mapping.altitude, img,
-                                mapping.cameraPosGCRS, mapping.photoTime, mapping.identifier)
-            return convertSMMappingToGeo(sm)
+            nc = res['lat'].size
+            la, lo = smToLatLon(np.concatenate((res['lat'].ravel(), res['lat_c'].ravel())),
+                                np.concatenate((res['lon'].ravel(), res['lon_c'].ravel())), mapping.photoTime)
+            return GenericMapping(la[:nc].reshape(res['lat'].shape), lo[:nc].reshape(res['lon'].shape),
+                                  la[nc:].reshape(res['lat_c'].shape), lo[nc:].reshape(res['lon_c'].shape), elevation,
+                                  mapping.altitude, img, mapping.cameraPosGCRS, mapping.photoTime, mapping.identifier)
     sm = convertMappingToSM(mapping)
     smResampled = resample(sm, **kw)
     return convertSMMappingToGeo(smResampled)
