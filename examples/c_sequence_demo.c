@@ -8,6 +8,9 @@
  *
  *   cc -std=c99 -Iinclude examples/c_sequence_demo.c -Lauromat_amd/lib -lauromat_hip -Wl,-rpath,$PWD/auromat_amd/lib -lm
  *   ./a.out frames.bin images_u16.bin n width height px_per_deg out.bin
+ * A NEGATIVE px_per_deg is a resolution in arcsec per pixel — `auromat-convert --resolution R`, the reference's own call form
+ * `resample(mapping, arcsecPerPx=R)` (cli/convert.py:176-185): every frame's px/deg then follows from its own bounding box
+ * (amt_run_config.arcsec_per_px: the box-first plan; the pair a frame was binned at is in its result record).
  */
 #include <math.h>
 #include <stdio.h>
@@ -51,18 +54,19 @@ int main(int argc, char** argv) {
     CHECK(amt_ctx_create(0, NULL, 1, &ctx));                       /* device 0, a stream owned by the library */
     void* d_images;
     CHECK(amt_malloc(ctx, (size_t)n * img_bytes, &d_images));
-    CHECK(amt_memcpy_h2d(ctx, d_images, images, (size_t)n * img_bytes));
+    CHECK(amt_upload_staged(ctx, d_images, images, (size_t)n * img_bytes));      /* pageable memory at the link's rate */
     for (int k = 0; k < n; ++k) frames[k].img = (const char*)d_images + (size_t)k * img_bytes;
 
     /* grids only: no per-pixel array is written (NULL pointers in every slot) */
-    enum { BATCH = 3, SLOTS = 2 * BATCH };
+    enum { BATCH = 3, SLOTS = 3 * BATCH };      /* 2 x BATCH for a fixed px/deg, 3 x BATCH for the box-first plan */
     amt_georef_out slots[SLOTS];
     memset(slots, 0, sizeof slots);
     amt_run_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.width = width, cfg.height = height, cfg.img_dtype = 2, cfg.fast_center = 1, cfg.magnetic = 0;
     cfg.batch = BATCH, cfg.use_hints = 1, cfg.n_slots = SLOTS;
-    cfg.altitude = 110.0, cfg.min_elevation = 10.0, cfg.lat_px_per_deg = ppd, cfg.lon_px_per_deg = ppd;
+    cfg.altitude = 110.0, cfg.min_elevation = 10.0;
+    if (ppd < 0) cfg.arcsec_per_px = -ppd; else cfg.lat_px_per_deg = cfg.lon_px_per_deg = ppd;
     cfg.slots = slots;
     amt_run* run = NULL;
     CHECK(amt_run_create(ctx, &cfg, &run));

@@ -388,24 +388,34 @@ def test_plain_c_host_runs_a_sequence(tmp_path):
         run_frame(hdr, cam, t, 0.0, None, out=arr[k])
     (tmp_path / 'frames.bin').write_bytes(bytes(C.string_at(C.byref(arr), C.sizeof(arr))))
     (tmp_path / 'images.bin').write_bytes(b''.join(img.tobytes() for _, _, _, img in frames))
-    run = subprocess.run([exe, str(tmp_path / 'frames.bin'), str(tmp_path / 'images.bin'), str(n), str(w), str(h), '6',
-                          str(tmp_path / 'out.bin')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True,
-                         timeout=120)
-    assert run.returncode == 0 and run.stdout.startswith('ok %d frames' % n), run.stdout
-    raw = (tmp_path / 'out.bin').read_bytes()
-    rec = np.frombuffer(raw[:n * C.sizeof(RunResult)], dtype=np.dtype(RunResult))
-    grids = np.frombuffer(raw[n * C.sizeof(RunResult):], dtype=np.float64)
-    want = SequencePipeline(w, h, pxPerDeg=6).process(frames, keep_on_device=False)
-    assert sum(r is None for r in want) == 1 and sum(1 for r in want if r is not None and r['contains_pole']) == 2
-    for k, r in enumerate(want):
-        if r is None:
-            assert rec['status'][k] == 2
-            continue
-        assert rec['status'][k] == 0 and (rec['ny'][k], rec['nx'][k]) == r['count'].shape
-        assert bool(rec['contains_pole'][k]) == bool(r['contains_pole'])
-        o, cells = int(rec['grid_offset'][k]), int(rec['ny'][k]) * int(rec['nx'][k])
-        assert np.array_equal(grids[o:o + 4 * cells].reshape(r['mean'].shape), r['mean'], equal_nan=True), k
-        assert np.array_equal(grids[o + 4 * cells:o + 5 * cells].reshape(r['count'].shape), r['count']), k
+    for resolution, kw in (('6', dict(pxPerDeg=6)), ('-600', dict(arcsecPerPx=600))):
+        # (a negative "px per degree" is arcsec per pixel: the reference's own call form, every frame at the px/deg of its box)
+        run = subprocess.run([exe, str(tmp_path / 'frames.bin'), str(tmp_path / 'images.bin'), str(n), str(w), str(h), resolution,
+                              str(tmp_path / 'out.bin')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True,
+                             timeout=120)
+        assert run.returncode == 0 and run.stdout.startswith('ok %d frames' % n), run.stdout
+        raw = (tmp_path / 'out.bin').read_bytes()
+        rec = np.frombuffer(raw[:n * C.sizeof(RunResult)], dtype=np.dtype(RunResult))
+        grids = np.frombuffer(raw[n * C.sizeof(RunResult):], dtype=np.float64)
+        seq = SequencePipeline(w, h, **kw)
+        want = seq.process(frames, keep_on_device=False)
+        n_pole = 2
+        if 'arcsecPerPx' in kw:
+            # a pole in view: no longitude resolution (status 4 from the C host, None here)
+            assert seq.plans.count('pole-without-resolution') == n_pole and sum(r is None for r in want) == 1 + n_pole
+        else:
+            assert sum(r is None for r in want) == 1 and sum(1 for r in want if r is not None and r['contains_pole']) == n_pole
+        for k, r in enumerate(want):
+            if r is None:
+                assert rec['status'][k] == (4 if seq.plans[k] == 'pole-without-resolution' else 2)
+                continue
+            assert rec['status'][k] == 0 and (rec['ny'][k], rec['nx'][k]) == r['count'].shape
+            assert bool(rec['contains_pole'][k]) == bool(r['contains_pole'])
+            if 'arcsecPerPx' in kw:
+                assert (rec['lat_px_per_deg'][k], rec['lon_px_per_deg'][k]) == r['pxPerDeg']
+            o, cells = int(rec['grid_offset'][k]), int(rec['ny'][k]) * int(rec['nx'][k])
+            assert np.array_equal(grids[o:o + 4 * cells].reshape(r['mean'].shape), r['mean'], equal_nan=True), (resolution, k)
+            assert np.array_equal(grids[o + 4 * cells:o + 5 * cells].reshape(r['count'].shape), r['count']), (resolution, k)
 
 
 def test_native_runner_reports_every_frame_with_its_own_shell_and_parameters():
