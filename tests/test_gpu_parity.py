@@ -418,6 +418,42 @@ def test_c_abi_error_behaviour(native):
     assert torch.isfinite(lat).any()
 
 
+def test_output_arrays_may_start_at_any_multiple_of_eight_bytes(native):
+    """the sky rows of a frame are written as 16-byte NaN fills; the pairs' alignment comes from the ADDRESS, so a
+    caller of the C API may hand in arrays that start at an odd multiple of 8 bytes (a slice of a larger array).  Every one of
+    the nine outputs shifted by one double, a frame with sky above the limb: the same arrays, and nothing written outside."""
+    import ctypes as C
+    import torch
+    from auromat_amd._native import Context, GeorefOut
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.synthetic import frame_header
+    ctx = native
+    w, h = 611, 403                                   # odd sizes: odd row lengths as well
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    p = frame_params(hdr, 110, cam, t, True, magnetic=True)
+    rows = [C.c_int32(0) for _ in range(4)]
+    ctx._lib.amt_georef_sky_rows(C.byref(p), *[C.byref(v) for v in rows])
+    assert rows[2].value > 0 or rows[3].value < rows[1].value, 'the frame has no sky band'
+    names = ('lat', 'lon', 'mlat', 'mlt', 'lat_c', 'lon_c', 'elev', 'mlat_c', 'mlt_c')
+    sizes = [(h + 1) * (w + 1)] * 4 + [h * w] * 5
+    results = []
+    for shift in (0, 1):
+        bufs = [torch.full((n + 3,), -7.0, dtype=torch.float64, device='cuda') for n in sizes]
+        out = GeorefOut()
+        for name, b in zip(names, bufs):
+            assert b.data_ptr() % 16 == 0
+            setattr(out, name, b.data_ptr() + 8 * shift)
+        ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
+        ctx.synchronize()
+        host = [b.cpu().numpy() for b in bufs]
+        for a, n in zip(host, sizes):
+            assert (a[:shift] == -7.0).all() and (a[shift + n:] == -7.0).all()          # nothing outside the array
+        results.append([a[shift:shift + n] for a, n in zip(host, sizes)])
+    for name, a, b in zip(names, results[0], results[1]):
+        assert np.array_equal(a, b, equal_nan=True), name
+        assert np.isnan(a).any() and np.isfinite(a).any(), name
+
+
 @pytest.mark.parametrize('pointing', ['iss030', 'iss029'])
 def test_reference_mapping_test_call_sequence(native, pointing):
     """
