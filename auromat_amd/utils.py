@@ -171,3 +171,74 @@ def findNearest(a, x):
     if i == 0 or a[i] == x:
         return i
     return i - 1 if (x - a[i - 1]) <= (a[i] - x) else i
+
+
+# ---- small vector helpers of the reference (utils.py:28-75,294-305) ------------------------------------------------------
+# NumPy in -> NumPy out, torch device tensor in -> tensor out, like the operator-level mirrors (auromat_amd._ops).  The frame
+# kernels do not call them (elevation, masks and the outside-outline test are fused there); they are here for code written
+# against the reference's module.
+
+def _staged(*arrays):
+    from ._ops import Staged
+    return Staged(*arrays)
+
+
+def vectorLengths(vectors):
+    """``np.linalg.norm(vectors, axis=1)`` (reference utils.py:28-31)."""
+    import torch
+    st = _staged(vectors)
+    v = st.inp(vectors)
+    return st.result(torch.sqrt((v * v).sum(dim=1)))
+
+
+def unitVectors(vectors):
+    """The unit vectors of an array of vectors (reference utils.py:33-36)."""
+    import torch
+    st = _staged(vectors)
+    v = st.inp(vectors)
+    return st.result(v / torch.sqrt((v * v).sum(dim=1))[..., None])
+
+
+def angleBetween(v1, v2):
+    """Angles in radians, in [0, pi], between two unit vector arrays; the dot product is clipped to [-1, 1] before the
+    arccosine, as in the reference (utils.py:38-46)."""
+    import torch
+    st = _staged(v1, v2)
+    a, b = st.inp(v1), st.inp(v2)
+    return st.result(torch.arccos(torch.clamp((a * b).sum(dim=-1), -1.0, 1.0)))
+
+
+def signedAngleBetween(v1, v2):
+    """Angles in radians, in [-pi, pi], between two 2D vector arrays (reference utils.py:48-56)."""
+    import torch
+    st = _staged(v1, v2)
+    a, b = st.inp(v1), st.inp(v2)
+    return st.result(torch.atan2(a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0], a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]))
+
+
+def pointsInsidePolygon(points, polygon):
+    """For each point whether it lies inside the polygon — ``matplotlib.path.Path(polygon).contains_points(points)`` in the
+    reference (utils.py:58-74) —: ``amt_points_in_polygon``, the crossing test with Agg's half-open edge rule, which equals
+    matplotlib also for points on vertices and edges (tests/test_gpu_nearest.py).
+
+    :param points: shape (n, 2)
+    :param polygon: unclosed, shape (m, 2)
+    :rtype: boolean array of shape (n,)
+    """
+    import torch
+    st = _staged(points)
+    p = st.inp(points)
+    ctx = st.ctx
+    poly = ctx.to_device(np.ascontiguousarray(polygon, dtype=np.float64))
+    x, y = p[:, 0].contiguous(), p[:, 1].contiguous()
+    inside = ctx.empty((p.shape[0],), torch.uint8)
+    ctx.call('amt_points_in_polygon', ptr(x), ptr(y), x.numel(), ptr(poly), int(poly.shape[0]), ptr(inside))
+    if st.on_device:
+        return inside.to(torch.bool)
+    return to_host(inside).astype(bool)
+
+
+def extend(instance, new_class):
+    """Apply inheritance after object creation (reference utils.py:294-305)."""
+    instance.__class__ = type('%s_extended_with_%s' % (instance.__class__.__name__, new_class.__name__),
+                              (new_class, instance.__class__), {})

@@ -270,6 +270,41 @@ def test_reference_resample_test_call_sequence():
     np.testing.assert_allclose(bb(m3), bb(m1), atol=0.15)
 
 
+def test_small_vector_helpers_of_the_references_utils():
+    """auromat.utils.vectorLengths / unitVectors / angleBetween / signedAngleBetween / pointsInsidePolygon / extend (reference
+    utils.py:28-75,294-305) against their NumPy / matplotlib definitions; NumPy in -> NumPy out, device tensor in -> tensor out."""
+    import matplotlib.path
+    import torch
+    from auromat_amd import utils as U
+    rs = np.random.RandomState(8)
+    v, w = rs.randn(500, 3), rs.randn(500, 3)
+    assert np.allclose(U.vectorLengths(v), np.linalg.norm(v, axis=1), rtol=1e-15)
+    u, x = U.unitVectors(v), U.unitVectors(w)
+    assert np.allclose(np.linalg.norm(u, axis=1), 1, atol=1e-15) and np.allclose(u * np.linalg.norm(v, axis=1)[:, None], v, rtol=1e-14)
+    want = np.arccos(np.clip((u * x).sum(axis=1), -1, 1))
+    assert np.allclose(U.angleBetween(u, x), want, atol=1e-14)
+    assert U.angleBetween(u[:3], u[:3]).max() < 1e-7                       # equal vectors: clipped, never NaN
+    a2, b2 = rs.randn(300, 2), rs.randn(300, 2)
+    want = np.arctan2(a2[:, 0] * b2[:, 1] - a2[:, 1] * b2[:, 0], a2[:, 0] * b2[:, 0] + a2[:, 1] * b2[:, 1])
+    assert np.allclose(U.signedAngleBetween(a2, b2), want, atol=1e-14)
+    t = U.vectorLengths(torch.from_numpy(v).cuda())
+    assert isinstance(t, torch.Tensor) and t.is_cuda and np.allclose(t.cpu().numpy(), np.linalg.norm(v, axis=1))
+    poly = np.array([[0, 0], [4, 0], [4, 3], [2, 5], [0, 3]], dtype=np.float64)
+    pts = np.concatenate((rs.rand(2000, 2) * 7 - 1, poly, [[2, 0], [4, 1.5], [1, 4]]))       # vertices and edge points too
+    assert np.array_equal(U.pointsInsidePolygon(pts, poly), matplotlib.path.Path(poly).contains_points(pts))
+
+    class Base(object):
+        def who(self):
+            return 'base'
+
+    class Extra(object):
+        def who(self):
+            return 'extra over ' + super(Extra, self).who()
+    obj = Base()
+    U.extend(obj, Extra)
+    assert obj.who() == 'extra over base' and isinstance(obj, Base) and isinstance(obj, Extra)
+
+
 # ---- method='linear' (reference resample.py:323-326: scipy griddata on Qhull's Delaunay triangulation) ---------------
 # Pinned to outputs of the real reference (tests/golden/resample_linear.npz, oracle/make_golden.py resample_linear_cases).
 # The device triangulates the pixel grid itself: every quad of neighbouring pixel centres cut along the diagonal the
