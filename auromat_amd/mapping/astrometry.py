@@ -295,6 +295,14 @@ class BaseAstrometryMapping(BaseMapping):
             return inflatedEarthIntersection(d.reshape(-1, 3), self.cameraPosGCRS, self.altitude).reshape(d.shape)
         return self._cached('p_center', make)
 
+    @property
+    def distance(self):
+        """Distance for each pixel center between camera and intersection point, (h, w) in km.  For debugging purposes
+        only! (reference astrometry.py:108-116)"""
+        from ..utils import vectorLengths
+        p = self.intersectionInflatedCenter
+        return vectorLengths((p - np.asarray(self.cameraPosGCRS)).reshape(-1, 3)).reshape(p.shape[0], p.shape[1])
+
     @staticmethod
     def _calcCenters(corners):
         centers = corners[:-1, :-1] + corners[:-1, 1:]

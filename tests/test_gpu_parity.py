@@ -115,6 +115,13 @@ def test_building_blocks_vs_reference(native):
     close(mlt, z['mlt'].ravel()[valid], 1e-11)
     hit = I.ellipsoidLineIntersects(wgs84A + 110, wgs84B + 110, z['cam'], z['dir_corner'].reshape(-1, 3))
     assert np.array_equal(hit, valid)
+    # the debugging properties of the mapping class: centre hits and their distance from the camera (astrometry.py:86-116)
+    from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
+    m = ArraySpacecraftMapping(hdr, float(z['altitude']), np.zeros((hdr['IMAGEH'], hdr['IMAGEW'], 3), np.uint8), z['cam'], t, 'd',
+                               fastCenterCalculation=False)
+    close(m.intersectionInflatedCenter, z['p_center'], 1e-7)
+    want = np.sqrt(((z['p_center'] - z['cam']) ** 2).sum(axis=-1))
+    close(m.distance, want, 1e-7)
     # ra/dec surface
     ra, dec = W.pix2world(hdr, hdr['IMAGEW'], hdr['IMAGEH'])
     d = z['dir_corner']
