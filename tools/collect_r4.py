@@ -58,3 +58,35 @@ for name in ('a_bench_default_n1', 'a3_bench_driver_command_steps20', 'c_bench_m
         d = json.load(open(p))
         print(name, '%.0f Mpx/s' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'kernel us/frame %.1f' % (d['kernels']['k_georef_rows']['ms'] * 1e3),
               'frac %.3f' % d['roofline']['frac'])
+
+# PMC per FRAME: every counter's sum over the launches of the fused kernel divided by the frames those launches covered
+# (a launch covers grid size / one frame's grid size frames)
+import collections
+acc = collections.defaultdict(lambda: [0.0, 0])
+for path in glob.glob(os.path.join(SRC, 'e_pmc', '**', '*counter_collection.csv'), recursive=True):
+    rows = [r for r in csv.DictReader(open(path)) if 'k_georef_rows' in r['Kernel_Name']]
+    if not rows:
+        continue
+    one = min(int(r['Grid_Size']) for r in rows)
+    for r in rows:
+        a = acc[r['Counter_Name']]
+        a[0] += float(r['Counter_Value'])
+        a[1] += int(round(int(r['Grid_Size']) / float(one)))
+if acc:
+    with open(os.path.join(DST, 'e_pmc_per_frame.txt'), 'w') as fp:
+        fp.write('k_georef_rows<true, false, 0, 2> (bench.py default workload), PMC per FRAME (sum over launches / frames covered)\n')
+        for k in sorted(acc):
+            fp.write('   %-28s %.5g  (frames %d)\n' % (k, acc[k][0] / acc[k][1], acc[k][1]))
+        w, f = acc.get('WRITE_SIZE'), acc.get('FETCH_SIZE')
+        if w and f:
+            hbm = (w[0] / w[1] + 2 * f[0] / f[1]) * 1024
+            fp.write('HBM traffic per frame: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 half count) = %.1f MB\n' % (hbm / 1e6))
+        v, g = acc.get('SQ_ACTIVE_INST_VALU'), acc.get('GRBM_GUI_ACTIVE')
+        if v and g:
+            fp.write('VALU busy = 4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x 1024) = %.3f\n' % (4 * (v[0] / v[1]) / ((g[0] / g[1]) / 8 * 1024)))
+        n, fma, mul, add = (acc.get(k) for k in ('SQ_INSTS_VALU', 'SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_ADD_F64'))
+        if n and fma and mul and add:
+            per = n[0] / n[1]
+            fp.write('VALU instructions per frame %.4g: FP64 fma %.1f %%, mul %.1f %%, add %.1f %%\n' % (
+                per, 100 * fma[0] / fma[1] / per, 100 * mul[0] / mul[1] / per, 100 * add[0] / add[1] / per))
+    print(open(os.path.join(DST, 'e_pmc_per_frame.txt')).read())
