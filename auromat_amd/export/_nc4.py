@@ -29,6 +29,16 @@ _DEFLATE_LEVEL = 4       # netCDF4-python's default complevel
 # threads that compress the chunks of a large array (deflate releases the interpreter lock); AMT_NC4_THREADS overrides
 _THREADS = max(1, min(16, int(os.environ.get('AMT_NC4_THREADS', '0')) or (os.cpu_count() or 1)))
 _ROWS_PER_TASK = 32      # chunks of one row: rows a task shuffles at once (one NumPy copy) and then deflates one by one
+_POOL = []
+
+
+def _pool():
+    """The threads that deflate (one pool per process, made on first use: a resampled grid has a few hundred one-row chunks
+    per variable and twenty variables per file — a pool per variable cost more than it gave)."""
+    if not _POOL:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL.append(ThreadPoolExecutor(max_workers=_THREADS))
+    return _POOL[0]
 
 NOT_A_VARIABLE = 'This is a netCDF dimension but not a netCDF variable.%10d'
 # the library's default fill values (netcdf.h NC_FILL_*): the HDF5 fill value of a variable without a _FillValue
@@ -167,7 +177,7 @@ class _Dataset(object):
         self.extra = []                      # attribute messages that need addresses (made in the second pass)
         n = int(np.prod(shape)) if shape else 1
         if data is None:
-            self.layout, self.raw, self.chunks = 'unallocated', b'', []
+            self.layout, self.raw, self._chunks = 'unallocated', b'', []
             self.nbytes = n * self.dtype.itemsize
             return
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(data), shape) if np.size(data) == 1 else
@@ -175,7 +185,7 @@ class _Dataset(object):
         if chunks is None and zlib and shape:
             chunks = shape                       # (small fixed dimensions: the library's default is one chunk)
         if not chunks or not shape:
-            self.layout, self.raw, self.chunks = 'contiguous', a.tobytes(), []
+            self.layout, self.raw, self._chunks = 'contiguous', a.tobytes(), []
             self.nbytes = len(self.raw)
             return
         assert len(chunks) == len(shape) and all(c >= 1 for c in chunks)
@@ -198,12 +208,12 @@ class _Dataset(object):
 
         todo = list(np.ndindex(*grid))
         rows = tuple(chunks) == (1,) + tuple(shape[1:]) and len(shape) >= 2
-        if zlib and rows and shape[0] >= 64 and a.nbytes >= (1 << 22):
+        if zlib and rows and shape[0] > _ROWS_PER_TASK:
             # The reference's layout — one row per chunk (export/netcdf.py:128-326: chunksizes=(1, w)) — for a large array:
             # a task takes a block of rows, shuffles all of them with ONE NumPy copy (per-chunk Python work under the
             # interpreter lock was what bound the first version: 34 000 chunks per frame, 8 threads, 6.4 of 8.4 s) and
-            # deflates them row by row, which releases the lock; the blocks run on a few threads
-            from concurrent.futures import ThreadPoolExecutor
+            # deflates them row by row, which releases the lock; the blocks run on a few threads.  (Small arrays too: the
+            # resampled grid of a convert run has ~240 rows x 6 variables, and deflate's set-up per 2-KB chunk is 20 us.)
             zero = (0,) * (len(shape) - 1)
 
             def block(r0):
@@ -213,15 +223,21 @@ class _Dataset(object):
                 sh = np.ascontiguousarray(by.transpose(0, 2, 1)).reshape(n, -1) if itemsize > 1 else by.reshape(n, -1)
                 return [((r0 + i,) + zero, _zlib.compress(sh[i], _DEFLATE_LEVEL)) for i in range(n)]
 
-            with ThreadPoolExecutor(max_workers=_THREADS) as pool:
-                self.chunks = [c for part in pool.map(block, range(0, shape[0], _ROWS_PER_TASK)) for c in part]
+            # (handed to the pool here, collected when the file is laid out: the variables of a file deflate side by side)
+            pool = _pool()
+            self._chunks, self._blocks = None, [pool.submit(block, r0) for r0 in range(0, shape[0], _ROWS_PER_TASK)]
         elif zlib and len(todo) >= 64 and a.nbytes >= (1 << 22):
             # (other chunk shapes) deflate releases the interpreter lock: the chunks are compressed by a few threads
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=_THREADS) as pool:
-                self.chunks = list(pool.map(one, todo))
+            self._chunks = list(_pool().map(one, todo))
         else:
-            self.chunks = [one(idx) for idx in todo]
+            self._chunks = [one(idx) for idx in todo]
+
+    @property
+    def chunks(self):
+        if self._chunks is None:
+            self._chunks = [c for part in self._blocks for c in part.result()]
+            self._blocks = None
+        return self._chunks
 
     # -- sizes (known before any address is) ----------------------------------------------------------------------------
     def _key_size(self):
