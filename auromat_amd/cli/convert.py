@@ -1,6 +1,6 @@
 """
 ``auromat-convert`` on the MI355X path: georeference (and optionally resample) a sequence of frames and write one
-netCDF file per frame — the flag set and the flow of the reference's console script (auromat/cli/convert.py:58-219).
+CDF or netCDF file per frame — the flag set and the flow of the reference's console script (auromat/cli/convert.py:58-219).
 
 What differs, and why:
 
@@ -11,14 +11,15 @@ What differs, and why:
   there (ESA ISS ``api.json``, THEMIS ``thg_l1_*`` CDFs): downloads, RAW development and the CDF library are its I/O
   layer, not part of this package — ``--bps``, ``--correctgamma`` and ``--autobright`` belong to that layer and are
   accepted but have nothing to act on.
-* ``--format netcdf`` only (``cdf`` needs NASA's CDF library through spacepy); the files are netCDF classic
-  (:mod:`auromat_amd.export._nc3`).
-* ``--resample`` with ``--resolution`` (arcsec / px, the reference's flag) goes frame by frame through the mapping
-  classes, because the reference derives the grid's px/deg from each frame's own bounding box
-  (``plateCarreeResolution``).  ``--px-per-deg N`` (an addition) fixes the grid instead and runs the sequence through
-  the single-pass frame pipeline (:class:`auromat_amd.pipeline.SequencePipeline`, grids only: no per-pixel array is
-  ever written or copied to the host); with several GPUs (``torchrun --nproc-per-node N -m auromat_amd.cli.convert``)
-  the frames are sharded over the ranks and every rank writes the files of its own frames.
+* ``--format netcdf``: netCDF-4 / HDF5 as the reference's files (:mod:`auromat_amd.export._nc4`) or, with
+  ``--netcdf-container classic``, netCDF classic (:mod:`auromat_amd.export._nc3`).  ``--format cdf``: a version-3 CDF laid out
+  by :mod:`auromat_amd.export._cdf3` without NASA's CDF library — read that module's header: no CDF library has opened
+  these files yet.
+* ``--resample`` runs the sequence through the single-pass frame pipeline (:class:`auromat_amd.pipeline.SequencePipeline`,
+  grids only: no per-pixel array is ever written or copied to the host): with ``--resolution`` (arcsec / px, the
+  reference's flag and default) every frame's px/deg follows from its own bounding box (``plateCarreeResolution``, the
+  box-first plan); ``--px-per-deg N`` (an addition) fixes the grid instead.  With several GPUs (``torchrun --nproc-per-node N
+  -m auromat_amd.cli.convert``) the frames are sharded over the ranks and every rank writes the files of its own frames.
 """
 from __future__ import print_function
 
@@ -31,7 +32,7 @@ from datetime import datetime, timedelta
 import numpy as np
 import numpy.ma as ma
 
-description = 'Georeference frames on the GPU, optionally resample them, and store them as netCDF files.'
+description = 'Georeference frames on the GPU, optionally resample them, and store them as CDF or netCDF files.'
 
 epilog = '''
 Resample on the geomagnetic grid with the reference's resolution rule:
@@ -42,6 +43,9 @@ auromat-convert --data frames/ --format netcdf --resample --grid geo --px-per-de
 
 Don't store pixel corner coordinates:
 auromat-convert --data frames/ --format netcdf --without-bounds
+
+CDF files (version 3, laid out without NASA's CDF library), MLat/MLT coordinates only:
+auromat-convert --data frames/ --format cdf --resample --without-geo
 '''
 
 
@@ -124,8 +128,6 @@ def parseargs(argv=None):
         parser.error('only one of --overwrite and --skip is allowed')
     if args.withoutGeo and args.format == Format.netcdf:
         parser.error('--without-geo is only usable with --format cdf')
-    if args.format == Format.cdf:
-        parser.error('--format cdf needs NASA\'s CDF library (spacepy.pycdf), which this package does not wrap; use netcdf')
     return args
 
 
@@ -188,7 +190,7 @@ def list_frames(data_dir, start=None, end=None):
 
 def target_path(args, identifier):
     """-> path to write, or None when the frame is to be skipped; exits like the reference when the file exists."""
-    path = os.path.join(args.out, identifier + '.nc')
+    path = os.path.join(args.out, identifier + extension(args))
     if os.path.exists(path):
         if args.skip:
             print('skipping', path)
@@ -200,6 +202,10 @@ def target_path(args, identifier):
                   file=sys.stderr)
             sys.exit(1)
     return path
+
+
+def extension(args):
+    return '.cdf' if args.format == Format.cdf else '.nc'
 
 
 # ---- the two ways through the GPU ----------------------------------------------------------------------------
@@ -257,7 +263,7 @@ def convert_with_pipeline(args, frames, export):
         # has gone (a check per rank's own share left the others in dist.barrier() until the launcher killed them)
         if not args.skip and not args.overwrite:
             for identifier, _, _ in frames:
-                path = os.path.join(args.out, identifier + '.nc')
+                path = os.path.join(args.out, identifier + extension(args))
                 if os.path.exists(path):
                     print('The file', path, 'already exists.\nPlease use --skip or --overwrite, or a different output folder.',
                           file=sys.stderr)
@@ -323,13 +329,18 @@ def convert_with_pipeline(args, frames, export):
 def main(argv=None):
     args = parseargs(argv)
     from functools import partial
-    from ..export.netcdf import write
     frames = list_frames(args.data, args.start, args.end)
     if not frames:
         raise NotImplementedError('No <id>.wcs / <id>.json + <id>.npy (or .jpg / .png / .tif) frames found in ' + args.data)
-    export = partial(write, includeBounds=not args.withoutBounds, includeMagCoords=not args.withoutMag,
-                     includeGeoCoords=not args.withoutGeo,
-                     format='NETCDF4' if args.netcdfContainer == 'netcdf4' else 'NETCDF3_64BIT')
+    if args.format == Format.cdf:
+        from ..export.cdf import write
+        export = partial(write, includeBounds=not args.withoutBounds, includeMagCoords=not args.withoutMag,
+                         includeGeoCoords=not args.withoutGeo)
+    else:
+        from ..export.netcdf import write
+        export = partial(write, includeBounds=not args.withoutBounds, includeMagCoords=not args.withoutMag,
+                         includeGeoCoords=not args.withoutGeo,
+                         format='NETCDF4' if args.netcdfContainer == 'netcdf4' else 'NETCDF3_64BIT')
     os.makedirs(args.out, exist_ok=True)
     # --resample, with the reference's --resolution (default 100 arcsec per pixel) or with --px-per-deg: the sequence pipeline;
     # without --resample the frames are exported as they are, through the mapping classes (AMT_CONVERT_CLASSES=1 sends

@@ -45,8 +45,9 @@ def test_flags_are_the_references():
         assert flag in opts, flag
     a = parseargs(['--data', '/x', '--format', 'netcdf'])
     assert a.out == '/x/converted' and a.altitude == 110 and a.resolution == 100 and a.grid == 'mag' and not a.resample
-    for bad in (['--format', 'netcdf', '--overwrite', '--skip'], ['--format', 'netcdf', '--without-geo'], ['--format', 'cdf'],
-                ['--data', '/x']):
+    assert parseargs(['--data', '/x', '--format', 'cdf', '--without-geo']).withoutGeo
+    for bad in (['--data', '/x', '--format', 'netcdf', '--overwrite', '--skip'], ['--data', '/x', '--format', 'netcdf', '--without-geo'],
+                ['--data', '/x', '--format', 'hdf'], ['--data', '/x']):
         with pytest.raises(SystemExit):
             parseargs(bad)
     with pytest.raises(SystemExit):
@@ -117,6 +118,43 @@ def test_convert_both_routes(tmp_path, capsys):
     assert os.listdir(out3) == ['frame00.nc']
     f = _nc4.open_file(os.path.join(out3, 'frame00.nc'))
     assert f.vars['lat'].dims == ('y', 'x') and f.vars['lat_bounds'].data.shape == (170, 256, 4)
+
+
+@pytest.mark.gpu
+def test_convert_to_cdf(tmp_path):
+    """--format cdf (the format of every example in the reference's own help text, cli/convert.py:35-44): the same mappings as
+    --format netcdf, in version-3 CDF files (container: see export/_cdf3.py's header — unpinned)."""
+    from auromat_amd.cli.convert import main
+    from auromat_amd.export import _cdf3
+    from auromat_amd.mapping.cdf import CDFMapping
+    from auromat_amd.mapping.netcdf import read_arrays
+    d = write_frames(tmp_path)
+    flags = ['--data', d, '--resample', '--min-elevation', '10', '--resolution', '900']
+    out_nc, out_cdf, out_mag = str(tmp_path / 'nc'), str(tmp_path / 'cdf'), str(tmp_path / 'mag')
+    main(flags + ['--format', 'netcdf', '--out', out_nc])
+    main(flags + ['--format', 'cdf', '--out', out_cdf])
+    assert sorted(os.listdir(out_cdf)) == ['frame00.cdf', 'frame01.cdf', 'frame02.cdf']
+    for k in range(3):
+        want = read_arrays(os.path.join(out_nc, 'frame%02d.nc' % k))
+        got = CDFMapping(os.path.join(out_cdf, 'frame%02d.cdf' % k))
+        got.checkGuarantees()
+        for key in ('lats', 'lons', 'latsCenter', 'lonsCenter'):
+            assert np.array_equal(getattr(got, key).filled(np.nan), want[key].filled(np.nan), equal_nan=True), key
+        # (both store a float32 zenith angle: netCDF float32(90 - elevation), CDF 90 - float32(elevation), as the reference's two)
+        assert np.allclose(got.elevation.filled(-1), want['elevation'].filled(-1), atol=1e-4)
+        assert np.array_equal(got.img.filled(0), want['img'].filled(0)) and np.array_equal(ma.getmaskarray(got.img), ma.getmaskarray(want['img']))
+        assert got.photoTime == want['photoTime'] and got.altitude == want['altitude'] and got.identifier == 'frame%02d' % k
+    # --without-geo (CDF only): MLat/MLT coordinates without the geodetic ones; re-running refuses as for netCDF
+    main(flags + ['--format', 'cdf', '--out', out_mag, '--without-geo', '--without-bounds'])
+    r = _cdf3.Reader(os.path.join(out_mag, 'frame01.cdf'))
+    assert 'lat' not in r and 'mlat' in r and 'mlat_bounds' not in r and r['mlat'].compressed == 5
+    with pytest.raises(SystemExit):
+        main(flags + ['--format', 'cdf', '--out', out_mag, '--without-geo', '--without-bounds'])
+    # the unresampled mapping of a frame
+    out_raw = str(tmp_path / 'raw')
+    main(['--data', d, '--format', 'cdf', '--out', out_raw, '--end', '2012-01-25T09:26:56'])
+    r = _cdf3.Reader(os.path.join(out_raw, 'frame00.cdf'))
+    assert r['lat'].dims == (170, 256) and r['lat_bounds'].dims == (171, 257) and r['img_red'].type in (_cdf3.CDF_INT4, _cdf3.CDF_UINT2)
 
 
 def test_image_files_next_to_the_header(tmp_path):
