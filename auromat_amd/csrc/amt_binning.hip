@@ -144,6 +144,15 @@ __global__ __launch_bounds__(kBlock) void k_bin_frame(bin_args A) {
         if (n_row > 0) {
             const int64_t g0 = (int64_t)gy * A.width + gx0;
             load_run<VEC>(A.lat_c + g0, lane, n_row, la);
+        }
+        // a pixel without a latitude is not binned (resample.py:315-321): where a wave's whole tile row has none — the sky
+        // above the limb, 30-40 % of an ISS frame — its longitudes, elevations and image bytes (22 of the 30 B per pixel)
+        // are not read at all
+        bool any_lat = false;
+#pragma unroll
+        for (int j = 0; j < kPPT; ++j) any_lat = any_lat || la[j] == la[j];
+        if (n_row > 0 && __any(any_lat)) {
+            const int64_t g0 = (int64_t)gy * A.width + gx0;
             load_run<VEC>(A.lon_c + g0, lane, n_row, lo);
             if (A.elev) load_run<VEC>(A.elev + g0, lane, n_row, ev);
             if (A.mask) {
