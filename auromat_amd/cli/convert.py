@@ -243,6 +243,20 @@ def grid_mapping(res, cam, t, altitude, identifier, magnetic):
     return GenericMapping(lat, lon, lat_c, lon_c, ma.masked_invalid(res['mean'][:, :, -1]), altitude, img, cam, t, identifier)
 
 
+def host_snapshot(mapping, with_mag):
+    """What the exporters read of a mapping, evaluated HERE (the device work of a mapping — MLat/MLT of the grid, the traced
+    outline behind the bounding box — stays on the thread that owns the GPU context) and held as plain host arrays: such a
+    snapshot can be written by another thread while the next frames are processed."""
+    from types import SimpleNamespace
+    snap = SimpleNamespace(lats=mapping.lats, lons=mapping.lons, latsCenter=mapping.latsCenter, lonsCenter=mapping.lonsCenter,
+                           elevation=mapping.elevation, img=mapping.img, boundingBox=mapping.boundingBox,
+                           photoTime=mapping.photoTime, altitude=mapping.altitude, cameraPosGCRS=mapping.cameraPosGCRS,
+                           metadata=mapping.metadata, identifier=mapping.identifier)
+    if with_mag:
+        snap.mLatMlt, snap.mLatMltCenter = mapping.mLatMlt, mapping.mLatMltCenter
+    return snap
+
+
 def convert_with_pipeline(args, frames, export):
     """The whole sequence through the single-pass frame pipeline — at a fixed px/deg (--px-per-deg) or, the reference's
     flags, at --resolution arcsec per pixel, where every frame's px/deg follows from its own bounding box (the box-first plan
@@ -310,17 +324,36 @@ def convert_with_pipeline(args, frames, export):
 
         metas = [frame_inputs(hdr) for _, hdr, _, _ in todo]
         results = seq.process(feed(), keep_on_device=True)
-        for k, ((identifier, hdr, img_path, path), (cam, t), res) in enumerate(zip(todo, metas, results)):
-            if res is None:
-                why = 'a pole in view: --resolution yields no longitude resolution for' if \
-                    seq.plans[k] == 'pole-without-resolution' else 'no valid pixel in'
-                print(why, identifier, file=sys.stderr)
-                continue
-            host = dict(res)
-            host.update(grid_coordinates(res))
-            host.update(mean=to_host(res['mean']), img=to_host(res['img'], dtype=first.dtype), mask=to_host(res['mask']).astype(bool))
-            print('storing', path)
-            export(path, grid_mapping(host, cam, t, args.altitude, identifier, magnetic))
+        # the files are written by a few threads (deflate releases the interpreter lock; AMT_CONVERT_WRITERS=0: in line): a
+        # resampled grid takes 6 ms to compute and 20-odd to compress and lay out
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        n_writers = max(0, int(os.environ.get('AMT_CONVERT_WRITERS', '4')))
+        writers = ThreadPoolExecutor(max_workers=n_writers) if n_writers else None
+        written = deque()
+        try:
+            for k, ((identifier, hdr, img_path, path), (cam, t), res) in enumerate(zip(todo, metas, results)):
+                if res is None:
+                    why = 'a pole in view: --resolution yields no longitude resolution for' if \
+                        seq.plans[k] == 'pole-without-resolution' else 'no valid pixel in'
+                    print(why, identifier, file=sys.stderr)
+                    continue
+                host = dict(res)
+                host.update(grid_coordinates(res))
+                host.update(mean=to_host(res['mean']), img=to_host(res['img'], dtype=first.dtype), mask=to_host(res['mask']).astype(bool))
+                print('storing', path)
+                mapping = grid_mapping(host, cam, t, args.altitude, identifier, magnetic)
+                if writers is None:
+                    export(path, mapping)
+                    continue
+                written.append(writers.submit(export, path, host_snapshot(mapping, not args.withoutMag)))
+                while len(written) > 2 * n_writers:
+                    written.popleft().result()
+            while written:
+                written.popleft().result()                # (an exporter's exception surfaces here)
+        finally:
+            if writers is not None:
+                writers.shutdown(wait=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,67 @@
+"""
+The writers' host helper ``libauromat_io.so`` (``export/csrc/amt_io.cpp``: HDF5's shuffle + deflate over the chunks of a
+variable, on threads, outside the interpreter lock): built in-tree with g++ against the system's zlib, loaded through ctypes.
+It only makes file writing faster — the same zlib at the same level gives the same bytes as the writers' Python path, which
+they take when the helper cannot be built or loaded (``AMT_IO_HELPER=0`` forces that, for A/B runs and tests).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'amt_io.cpp')
+LIB_PATH = os.path.join(_PKG, 'lib', 'libauromat_io.so')
+_lib = []
+
+
+def build(force=False):
+    """g++ -O2 -shared -fPIC amt_io.cpp -lz -> auromat_amd/lib/libauromat_io.so; returns the path."""
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= os.path.getmtime(SRC):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    tmp = LIB_PATH + '.tmp.%d' % os.getpid()
+    cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', '-Wextra', SRC, '-lz', '-o', tmp]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise RuntimeError('g++ failed:\n' + res.stdout)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+def lib():
+    """the loaded helper, or None (not built and not buildable here, or switched off)"""
+    if not _lib:
+        handle = None
+        if os.environ.get('AMT_IO_HELPER', '1') != '0':
+            try:
+                handle = C.CDLL(build())
+                handle.amt_io_deflate_bound.restype = C.c_int64
+                handle.amt_io_deflate_bound.argtypes = [C.c_int64]
+                handle.amt_io_deflate_chunks.restype = C.c_int
+                handle.amt_io_deflate_chunks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+            except (OSError, RuntimeError):
+                handle = None
+        _lib.append(handle)
+    return _lib[0]
+
+
+def deflate_rows(a, level, shuffle, threads):
+    """``a``: C-contiguous array, one chunk per index of its first axis -> list of the chunks' zlib streams (bytes), or None
+    when the helper is not there.  ctypes releases the interpreter lock for the call."""
+    h = lib()
+    if h is None or a.shape[0] == 0:
+        return None
+    n, chunk_bytes = a.shape[0], a.nbytes // a.shape[0]
+    stride = int(h.amt_io_deflate_bound(chunk_bytes))
+    out = np.empty((n, stride), np.uint8)
+    sizes = np.empty(n, np.int64)
+    rc = h.amt_io_deflate_chunks(a.ctypes.data, n, chunk_bytes, a.dtype.itemsize, level, 1 if shuffle else 0, out.ctypes.data, stride,
+                                 sizes.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError('zlib error %d' % rc)
+    return [out[i, :sizes[i]].tobytes() for i in range(n)]

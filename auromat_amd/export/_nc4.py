@@ -22,6 +22,8 @@ from collections import OrderedDict
 
 import numpy as np
 
+from . import _io
+
 UNDEF = 0xFFFFFFFFFFFFFFFF
 _GROUP_K = 16            # group B-tree K (internal) — one node with one child is all this writer makes
 _CHUNK_K = 32            # chunk B-tree K: the library's default for superblock version 0 (which has no field for it)
@@ -225,7 +227,15 @@ class _Dataset(object):
 
             # (handed to the pool here, collected when the file is laid out: the variables of a file deflate side by side)
             pool = _pool()
-            self._chunks, self._blocks = None, [pool.submit(block, r0) for r0 in range(0, shape[0], _ROWS_PER_TASK)]
+            if _io.lib() is not None:
+                # the helper library shuffles and deflates all rows of the variable outside the interpreter lock, on threads of
+                # its own (export/csrc/amt_io.cpp: same zlib, same level, same bytes)
+                def rows():
+                    nt = max(1, min(_THREADS, a.nbytes >> 17))
+                    return [((i,) + zero, raw) for i, raw in enumerate(_io.deflate_rows(a.reshape(shape[0], -1), _DEFLATE_LEVEL, True, nt))]
+                self._chunks, self._blocks = None, [pool.submit(rows)]
+            else:
+                self._chunks, self._blocks = None, [pool.submit(block, r0) for r0 in range(0, shape[0], _ROWS_PER_TASK)]
         elif zlib and len(todo) >= 64 and a.nbytes >= (1 << 22):
             # (other chunk shapes) deflate releases the interpreter lock: the chunks are compressed by a few threads
             self._chunks = list(_pool().map(one, todo))
@@ -257,7 +267,7 @@ class _Dataset(object):
 
     def data_size(self):
         if self.layout == 'chunked':
-            return sum(self._tree_levels()) * self._node_size() + sum(len(_pad8(raw)) for _, raw in self.chunks)
+            return sum(self._tree_levels()) * self._node_size() + sum(len(raw) + (-len(raw) % 8) for _, raw in self.chunks)
         return len(_pad8(self.raw))
 
     # -- serialisation -----------------------------------------------------------------------------------------------------
@@ -296,7 +306,7 @@ class _Dataset(object):
         chunk_addr = []
         for _, raw in self.chunks:
             chunk_addr.append(a)
-            a += len(_pad8(raw))
+            a += len(raw) + (-len(raw) % 8)
 
         def key(size, offsets):
             return struct.pack('<II', size, 0) + b''.join(struct.pack('<Q', o) for o in offsets) + struct.pack('<Q', 0)
@@ -319,8 +329,26 @@ class _Dataset(object):
                 blobs[node_addr[level][i]] = body + b'\0' * (ns - len(body))
                 parents.append((mine[0][0], node_addr[level][i]))
             children = parents
-        out = b''.join(blobs[x] for x in sorted(blobs))
-        return out + b''.join(_pad8(raw) for _, raw in self.chunks)
+        # (the chunks themselves are not joined: 700 MB of copies for a full frame — the file takes them one by one)
+        parts = [b''.join(blobs[x] for x in sorted(blobs))]
+        for _, raw in self.chunks:
+            parts.append(raw)
+            if len(raw) % 8:
+                parts.append(_ZEROS[-len(raw) % 8])
+        return _Parts(parts)
+
+
+_ZEROS = [b'\0' * k for k in range(8)]
+
+
+class _Parts(object):
+    """bytes in pieces, for file.writelines"""
+
+    def __init__(self, parts):
+        self.parts, self.n = parts, sum(len(q) for q in parts)
+
+    def __len__(self):
+        return self.n
 
 
 class _Sized(object):
@@ -465,7 +493,10 @@ class Writer(object):
             fp.write(sb)
             for name, b in pieces:
                 assert fp.tell() == addr[name], name
-                fp.write(b)
+                if isinstance(b, _Parts):
+                    fp.writelines(b.parts)
+                else:
+                    fp.write(b)
                 fp.write(b'\0' * (-len(b) % 8))
             assert fp.tell() == eof
 

@@ -17,6 +17,19 @@ from ..coordinates.transform import northGeomagneticPoleLocation
 from ..mapping.mapping import isPlateCarree
 
 
+def _with_range(var, masked):
+    """sets ``actual_range`` = [min, max] over the unmasked values (reference netcdf.py:114-126: np.min / np.max of the masked
+    array) and returns the array with NaN where masked — min and max taken from that one NaN-filled copy (a masked-array
+    reduction of 12 M values costs 13 ms, the NaN-skipping one 3)"""
+    filled = np.ma.filled(masked, np.nan)
+    with np.errstate(all='ignore'):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            var.attrs['actual_range'] = np.float64([np.nanmin(filled), np.nanmax(filled)])
+    return filled
+
+
 def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords=True, includeGeoCoords=True,
           use1dIfPossible=True, compress=True, format='NETCDF4'):
     """
@@ -104,11 +117,9 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
     else:
         # auxiliary 2D coordinate variables with missing values (a documented deviation of the reference from CF 1.6)
         lat = root.create_variable('lat', np.float64, ('y', 'x'), zlib=z, chunksizes=(1, w))
-        lat.attrs['actual_range'] = np.float64([np.min(mapping.latsCenter), np.max(mapping.latsCenter)])
-        lat.set(mapping.latsCenter.filled(np.nan))
+        lat.set(_with_range(lat, mapping.latsCenter))
         lon = root.create_variable('lon', np.float64, ('y', 'x'), zlib=z, chunksizes=(1, w))
-        lon.attrs['actual_range'] = np.float64([np.min(mapping.lonsCenter), np.max(mapping.lonsCenter)])
-        lon.set(mapping.lonsCenter.filled(np.nan))
+        lon.set(_with_range(lon, mapping.lonsCenter))
 
     lat.attrs['units'] = 'degrees_north'
     lat.attrs['valid_min'] = np.float64(-90)
@@ -156,11 +167,9 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
             mlt.set(mltsCenter)
         else:
             mlat = root.create_variable('mlat', np.float64, ('y', 'x'), zlib=z, chunksizes=(1, w))
-            mlat.attrs['actual_range'] = np.float64([np.min(mlats), np.max(mlats)])
-            mlat.set(mlats.filled(np.nan))
+            mlat.set(_with_range(mlat, mlats))
             mlt = root.create_variable('mlt', np.float64, ('y', 'x'), zlib=z, chunksizes=(1, w))
-            mlt.attrs['actual_range'] = np.float64([np.min(mlts), np.max(mlts)])
-            mlt.set(mlts.filled(np.nan))
+            mlt.set(_with_range(mlt, mlts))
         mlat.attrs['long_name'] = 'Geomagnetic latitude'
         mlat.attrs['units'] = 'degrees'
         mlat.attrs['valid_min'] = np.float64(-90)

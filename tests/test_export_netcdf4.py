@@ -329,3 +329,36 @@ def test_random_layouts_through_the_hdf5_library(tmp_path):
         assert (s['compression'] == 'gzip') == (zlib and bool(dims)), name
         if chunks is not None:
             assert s['chunks'] == list(chunks), name
+
+
+def test_host_helper_gives_the_python_paths_bytes(tmp_path, monkeypatch):
+    """export/csrc/amt_io.cpp (shuffle + deflate of a variable's rows on threads, outside the interpreter lock) against
+    zlib.compress of the shuffled rows, and a whole file written with and without it."""
+    import zlib
+    from auromat_amd.export import _io, _nc4
+    if _io.lib() is None:
+        pytest.skip('libauromat_io.so not built / switched off')
+    rs = np.random.RandomState(5)
+    for dtype, shape in (('f8', (70, 33)), ('f4', (40, 17)), ('i4', (35, 5, 3)), ('i2', (3, 1000)), ('i1', (64, 64))):
+        a = np.ascontiguousarray((np.cumsum(rs.rand(*shape), axis=1) * 50).astype(dtype))
+        it = a.dtype.itemsize
+        for threads in (1, 5):
+            got = _io.deflate_rows(a.reshape(shape[0], -1), 4, True, threads)
+            want = [zlib.compress(np.ascontiguousarray(a[i].reshape(-1).view(np.uint8).reshape(-1, it).T).tobytes(), 4) for i in range(shape[0])]
+            assert got == want, (dtype, threads)
+        assert _io.deflate_rows(a.reshape(shape[0], -1), 6, False, 2) == [zlib.compress(a[i].tobytes(), 6) for i in range(shape[0])]
+
+    def write(path):
+        w = _nc4.Writer()
+        w.create_dimension('y', 90)
+        w.create_dimension('x', 41)
+        w.create_dimension('c', 3)
+        rs = np.random.RandomState(6)
+        w.create_variable('a', 'f8', ('y', 'x'), zlib=True, chunksizes=(1, 41)).set(np.cumsum(rs.rand(90, 41), axis=1))
+        w.create_variable('b', 'i4', ('y', 'x', 'c'), zlib=True, chunksizes=(1, 41, 3), fill_value=-1).set(rs.randint(0, 9, (90, 41, 3)))
+        w.write(path)
+    write(str(tmp_path / 'with.nc'))
+    monkeypatch.setattr(_io, '_lib', [None])
+    assert _io.lib() is None
+    write(str(tmp_path / 'without.nc'))
+    assert open(str(tmp_path / 'with.nc'), 'rb').read() == open(str(tmp_path / 'without.nc'), 'rb').read()
