@@ -40,6 +40,11 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
     def nan(a):
         return np.ma.filled(a, np.nan)
 
+    def put(var, *pairs):
+        for key, value in pairs:
+            var.attrs[key] = value
+        return var
+
     # ROOT ATTRIBUTES (reference cdf.py:62-80)
     metadata = dict(list((mapping.metadata or {}).items()) + list(metadata.items()))
     for k, v in metadata.items():
@@ -59,23 +64,16 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
     root.attrs['geospatial_lon_units'] = 'degrees_east'
 
     # VARIABLES (reference cdf.py:82-285)
-    time = root.new('Epoch', [mapping.photoTime], type=_cdf3.CDF_TIME_TT2000 if useTT2000 else _cdf3.CDF_EPOCH)
-    time.attrs['VAR_TYPE'] = 'support_data'
+    put(root.new('Epoch', [mapping.photoTime], type=_cdf3.CDF_TIME_TT2000 if useTT2000 else _cdf3.CDF_EPOCH),
+        ('VAR_TYPE', 'support_data'))
 
     def coordinate(name, data, depend, units, lo, hi, fieldnam, notes, crs):
-        v = root.new(name, nan(data)[np.newaxis, :], compress=z)
-        v.attrs['VAR_TYPE'] = 'data'
-        v.attrs['DEPEND_0'] = 'Epoch'
-        v.attrs['DEPEND_1'] = 'y_' + depend
-        v.attrs['DEPEND_2'] = 'x_' + depend
-        v.attrs['UNITS'] = units
-        v.attrs['VALIDMIN'] = lo
-        v.attrs['VALIDMAX'] = hi
-        v.attrs['FIELDNAM'] = fieldnam
+        v = put(root.new(name, nan(data)[np.newaxis, :], compress=z), ('VAR_TYPE', 'data'), ('DEPEND_0', 'Epoch'),
+                ('DEPEND_1', 'y_' + depend), ('DEPEND_2', 'x_' + depend), ('UNITS', units), ('VALIDMIN', lo), ('VALIDMAX', hi),
+                ('FIELDNAM', fieldnam))
         if notes is not None:
-            v.attrs['VAR_NOTES'] = notes
-        v.attrs['crs'] = crs
-        return v
+            put(v, ('VAR_NOTES', notes))
+        return put(v, ('crs', crs))
 
     if includeGeoCoords:
         lat = coordinate('lat', mapping.latsCenter, 'pixel', 'degrees', -90.0, 90.0, 'Latitude of pixel center',
@@ -90,11 +88,8 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
             coordinate('lon_bounds', mapping.lons, 'corner', 'degrees', -180.0, 180.0, 'Longitude of pixel corner',
                        'Geodetic longitude', 'crs')
 
-    altitude = root.new('altitude', float(mapping.altitude * 1000), recVary=False)
-    altitude.attrs['VAR_TYPE'] = 'support_data'
-    altitude.attrs['UNITS'] = 'meters'
-    altitude.attrs['FIELDNAM'] = 'Height above reference ellipsoid'
-    altitude.attrs['crs'] = 'crs'
+    put(root.new('altitude', float(mapping.altitude * 1000), recVary=False), ('VAR_TYPE', 'support_data'), ('UNITS', 'meters'),
+        ('FIELDNAM', 'Height above reference ellipsoid'), ('crs', 'crs'))
 
     if includeMagCoords:
         mlats, mlts = mapping.mLatMltCenter
@@ -108,11 +103,10 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
             coordinate('mlat_bounds', mlats, 'corner', 'degrees', -90.0, 90.0, 'Geomagnetic latitude of pixel corner', '', 'mcrs')
             coordinate('mlt_bounds', mlts, 'corner', 'hours', 0.0, 24.0, 'Magnetic local time of pixel corner', None, 'mcrs')
         magPoleLat, magPoleLon = northGeomagneticPoleLocation(mapping.photoTime)
-        mcrs = root.new('mcrs', 0, recVary=False)               # holds no actual data
-        mcrs.attrs['VAR_TYPE'] = 'support_data'
-        mcrs.attrs['north_geomagnetic_pole_lat'] = float(magPoleLat)
-        mcrs.attrs['north_geomagnetic_pole_lon'] = float(magPoleLon)
-        mcrs.attrs['VAR_NOTES'] = 'Geocentric MLat/MLT system based on the given geomagnetic pole position'
+        put(root.new('mcrs', 0, recVary=False),                 # (holds no data: a carrier of attributes)
+            ('VAR_TYPE', 'support_data'), ('north_geomagnetic_pole_lat', float(magPoleLat)),
+            ('north_geomagnetic_pole_lon', float(magPoleLon)),
+            ('VAR_NOTES', 'Geocentric MLat/MLT system based on the given geomagnetic pole position'))
 
     img = mapping.img
     if np.any(np.ma.getmaskarray(img)):
@@ -133,40 +127,21 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
     else:
         raise NotImplementedError
     for i, band in enumerate(bands):
-        v = root.new(band, img_[np.newaxis, :, :, i], compress=z)
-        v.attrs['VAR_TYPE'] = 'data'
-        v.attrs['DEPEND_0'] = 'Epoch'
-        v.attrs['DEPEND_1'] = 'y_pixel'
-        v.attrs['DEPEND_2'] = 'x_pixel'
-        v.attrs['FIELDNAM'] = ''
-        v.attrs['VALIDMIN'] = int(np.iinfo(img.dtype).min)
-        v.attrs['VALIDMAX'] = int(np.iinfo(img.dtype).max)
+        v = put(root.new(band, img_[np.newaxis, :, :, i], compress=z), ('VAR_TYPE', 'data'), ('DEPEND_0', 'Epoch'),
+                ('DEPEND_1', 'y_pixel'), ('DEPEND_2', 'x_pixel'), ('FIELDNAM', ''), ('VALIDMIN', int(np.iinfo(img.dtype).min)),
+                ('VALIDMAX', int(np.iinfo(img.dtype).max)))
         if imgFillval:
-            v.attrs['FILLVAL'] = imgFillval
-        v.attrs['UNITS'] = 'unitless'
+            put(v, ('FILLVAL', imgFillval))
+        put(v, ('UNITS', 'unitless'))
 
     zen = 90 - nan(mapping.elevation)[np.newaxis, :].astype(np.float32)
-    zenith_angle = root.new('zenith_angle', zen, compress=z)
-    zenith_angle.attrs['VAR_TYPE'] = 'data'
-    zenith_angle.attrs['DEPEND_0'] = 'Epoch'
-    zenith_angle.attrs['DEPEND_1'] = 'y_pixel'
-    zenith_angle.attrs['DEPEND_2'] = 'x_pixel'
-    zenith_angle.attrs['UNITS'] = 'degrees'
-    zenith_angle.attrs['VALIDMIN'] = 0.0
-    zenith_angle.attrs['VALIDMAX'] = 90.0
-    zenith_angle.attrs['FIELDNAM'] = 'Absolute sensor zenith angle of pixel center'
-
-    cameraPos = root.new('camera_pos', np.array([mapping.cameraPosGCRS], np.float64))
-    cameraPos.attrs['VAR_TYPE'] = 'support_data'
-    cameraPos.attrs['DEPEND_0'] = 'Epoch'
-    cameraPos.attrs['UNITS'] = 'kilometers'
-    cameraPos.attrs['FIELDNAM'] = 'Camera position in cartesian GCRS coordinates'
-    cameraPos.attrs['VAR_NOTES'] = 'Axis order: xyz'
-
-    crs = root.new('crs', 0, recVary=False)                     # holds no actual data
-    crs.attrs['VAR_TYPE'] = 'support_data'
-    crs.attrs['semi_major_axis'] = 6378137.0
-    crs.attrs['inverse_flattening'] = 298.257223563
-    crs.attrs['VAR_NOTES'] = 'Geographic Coordinate System, WGS 84'
+    put(root.new('zenith_angle', zen, compress=z), ('VAR_TYPE', 'data'), ('DEPEND_0', 'Epoch'), ('DEPEND_1', 'y_pixel'),
+        ('DEPEND_2', 'x_pixel'), ('UNITS', 'degrees'), ('VALIDMIN', 0.0), ('VALIDMAX', 90.0),
+        ('FIELDNAM', 'Absolute sensor zenith angle of pixel center'))
+    put(root.new('camera_pos', np.array([mapping.cameraPosGCRS], np.float64)), ('VAR_TYPE', 'support_data'), ('DEPEND_0', 'Epoch'),
+        ('UNITS', 'kilometers'), ('FIELDNAM', 'Camera position in cartesian GCRS coordinates'), ('VAR_NOTES', 'Axis order: xyz'))
+    put(root.new('crs', 0, recVary=False),                      # (holds no data: a carrier of attributes)
+        ('VAR_TYPE', 'support_data'), ('semi_major_axis', 6378137.0), ('inverse_flattening', 298.257223563),
+        ('VAR_NOTES', 'Geographic Coordinate System, WGS 84'))
 
     root.write(outputPath, pool=_pool() if compress else None)
