@@ -24,6 +24,7 @@ Only what the exporter needs is written: zVariables (the only kind spacepy creat
 compression per variable.  The reader follows the same subset plus big-endian encodings, rVariables-free files, nested
 VXRs and uncompressed / compressed blocks.
 """
+import os
 import struct
 import zlib as _zlib
 from collections import OrderedDict
@@ -55,6 +56,7 @@ _LITTLE = (4, 6, 13, 14, 15, 16, 17, 19, 20, 21)      # DECSTATION, IBMPC, ALPHA
 _BIG = (1, 2, 5, 7, 9, 11, 12, 18)                    # NETWORK, SUN, SGi, IBMRS, PPC, HP, NeXT, ARM_BIG
 GZIP_COMPRESSION = 5
 _VXR_ENTRIES = 7
+_GZIP_THREADS = max(1, min(16, int(os.environ.get('AMT_NC4_THREADS', '0')) or (os.cpu_count() or 1)))
 _NONE = 0xFFFFFFFFFFFFFFFF
 _LEAP_TABLE_DATE = 20170101
 
@@ -249,8 +251,15 @@ class Writer(object):
             per = v.records[0].nbytes
             out = []
             for r in range(v.records.shape[0]):                      # blocking factor 1: one gzip stream per record
-                c = _zlib.compressobj(v.compress, _zlib.DEFLATED, 31)
-                out.append((r, r, _CVVR, c.compress(raw[r * per:(r + 1) * per]) + c.flush()))
+                z = None
+                if per >= (1 << 22):
+                    # a large record: still ONE gzip member, its deflate blocks made side by side (export/csrc/amt_io.cpp)
+                    from . import _io
+                    z = _io.gzip_parallel(v.records[r], v.compress, _GZIP_THREADS)
+                if z is None:
+                    c = _zlib.compressobj(v.compress, _zlib.DEFLATED, 31)
+                    z = c.compress(raw[r * per:(r + 1) * per]) + c.flush()
+                out.append((r, r, _CVVR, z))
             return out
         if pool is not None:
             blocks = list(pool.map(block, self.vars.values()))

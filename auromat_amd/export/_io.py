@@ -44,7 +44,12 @@ def lib():
                 handle.amt_io_deflate_chunks.restype = C.c_int
                 handle.amt_io_deflate_chunks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
-            except (OSError, RuntimeError):
+                handle.amt_io_gzip_bound.restype = C.c_int64
+                handle.amt_io_gzip_bound.argtypes = [C.c_int64, C.c_int64]
+                handle.amt_io_gzip_parallel.restype = C.c_int
+                handle.amt_io_gzip_parallel.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                                        C.c_int32]
+            except (OSError, RuntimeError, AttributeError):
                 handle = None
         _lib.append(handle)
     return _lib[0]
@@ -65,3 +70,19 @@ def deflate_rows(a, level, shuffle, threads):
     if rc != 0:
         raise RuntimeError('zlib error %d' % rc)
     return [out[i, :sizes[i]].tobytes() for i in range(n)]
+
+
+def gzip_parallel(a, level, threads, block_bytes=1 << 20):
+    """the bytes of the C-contiguous array ``a`` as ONE gzip member, deflated in blocks of ``block_bytes`` on ``threads`` threads
+    (amt_io_gzip_parallel: pigz's layout) -> bytes, or None when the helper is not there"""
+    h = lib()
+    if h is None:
+        return None
+    n = a.nbytes
+    cap = int(h.amt_io_gzip_bound(n, block_bytes))
+    out = np.empty(cap, np.uint8)
+    out_len = C.c_int64(0)
+    rc = h.amt_io_gzip_parallel(a.ctypes.data, n, level, block_bytes, out.ctypes.data, cap, C.byref(out_len), threads)
+    if rc != 0:
+        raise RuntimeError('zlib error %d' % rc)
+    return out[:out_len.value].tobytes()

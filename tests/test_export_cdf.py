@@ -283,3 +283,32 @@ def test_exporter_options(tmp_path):
     assert len(prov) == 1 and prov.range == (t, t) and prov.contains(t + timedelta(seconds=2)) and not prov.contains(t + timedelta(seconds=9))
     with pytest.raises(ValueError):
         CDFMappingProvider([p, p1])
+
+
+def test_large_records_are_one_gzip_member_made_in_blocks(tmp_path):
+    """A record of 4 MB or more is deflated in 1-MB blocks side by side by the writers' helper (pigz's layout: one gzip member,
+    every block ending on a byte boundary): any inflate reads it as one stream."""
+    from auromat_amd.export import _cdf3 as C, _io
+    if _io.lib() is None:
+        pytest.skip('libauromat_io.so not built / switched off')
+    rs = np.random.RandomState(1)
+    a = np.cumsum(rs.rand(1, 700, 1000), axis=2)                     # 5.6 MB
+    a[0, :100] = np.nan
+    w = C.Writer()
+    w.new('big', a, compress=C.GZIP_COMPRESSION)
+    w.new('small', a[:, :10], compress=C.GZIP_COMPRESSION)
+    path = str(tmp_path / 'big.cdf')
+    w.write(path)
+    buf, recs = scan(path)
+    blocks = [(o, s) for o, s, k in recs if k == 13]
+    assert len(blocks) == 2
+    o, s = blocks[0]
+    csize, = struct.unpack_from('>q', buf, o + 16)
+    assert gzip.decompress(buf[o + 24:o + 24 + csize]) == a[0].astype('<f8').tobytes()
+    single = len(gzip.compress(a[0].tobytes(), 5))
+    assert csize < single * 1.01                                         # (no history across the cuts: a few tenths of a percent)
+    r = C.Reader(path)
+    assert np.array_equal(r['big'].data, a, equal_nan=True) and np.array_equal(r['small'].data, a[:, :10], equal_nan=True)
+    for n in (0, 1, (1 << 16) + 3):
+        b = rs.randint(0, 255, n).astype(np.uint8)
+        assert gzip.decompress(_io.gzip_parallel(b, 5, 3, 1 << 16)) == b.tobytes()
