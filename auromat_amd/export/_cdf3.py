@@ -52,7 +52,8 @@ _OF_DTYPE = {'i1': CDF_INT1, 'i2': CDF_INT2, 'i4': CDF_INT4, 'i8': CDF_INT8, 'u1
 _CDR, _GDR, _RVDR, _ADR, _AGREDR, _VXR, _VVR, _ZVDR, _AZEDR, _CCR, _CPR, _SPR, _CVVR = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 
 IBMPC_ENCODING, NETWORK_ENCODING = 6, 1
-_LITTLE = (4, 6, 13, 14, 15, 16, 17, 19, 20, 21)      # DECSTATION, IBMPC, ALPHA*, ARM_LITTLE, IA64VMS*
+_LITTLE = (4, 6, 13, 16, 17, 19)                      # DECSTATION, IBMPC, ALPHAOSF1, ALPHAVMSi, ARM_LITTLE, IA64VMSi (IEEE; the
+                                                      # VAX encodings 3, 14, 15, 20, 21 have D / G floats and are refused)
 _BIG = (1, 2, 5, 7, 9, 11, 12, 18)                    # NETWORK, SUN, SGi, IBMRS, PPC, HP, NeXT, ARM_BIG
 GZIP_COMPRESSION = 5
 _VXR_ENTRIES = 7
