@@ -58,7 +58,6 @@ _BIG = (1, 2, 5, 7, 9, 11, 12, 18)                    # NETWORK, SUN, SGi, IBMRS
 GZIP_COMPRESSION = 5
 _VXR_ENTRIES = 7
 _GZIP_THREADS = max(1, min(16, int(os.environ.get('AMT_NC4_THREADS', '0')) or (os.cpu_count() or 1)))
-_NONE = 0xFFFFFFFFFFFFFFFF
 _LEAP_TABLE_DATE = 20170101
 
 # TAI - UTC in whole seconds from the given day on (IERS Bulletin C; the table the CDF library carries for TT2000)

@@ -13,7 +13,6 @@ or a reading of the real library (parity of the container: unpinned).  What is h
 CPU only (the exporter is host code).
 """
 import gzip
-import os
 import struct
 from datetime import datetime, timedelta
 
