@@ -24,7 +24,6 @@ What differs, and why:
 from __future__ import print_function
 
 import argparse
-import json
 import os
 import sys
 from datetime import datetime, timedelta
