@@ -149,8 +149,9 @@ def _object_header(messages):
 # ---- the pieces of the file ------------------------------------------------------------------------------------------
 
 class Variable(object):
-    def __init__(self, name, dtype, dims, fill_value=None, zlib=False, chunksizes=None):
+    def __init__(self, name, dtype, dims, fill_value=None, zlib=False, chunksizes=None, shape=None):
         self.name, self.dims = name, tuple(dims)
+        self.shape, self.early = shape, None
         self.dtype = np.dtype(dtype).newbyteorder('<')
         datatype_message(self.dtype)
         self.attrs = OrderedDict()
@@ -159,7 +160,14 @@ class Variable(object):
         self.data = None
 
     def set(self, data):
+        """``data`` must not change between this call and ``Writer.write`` (it is not copied)"""
         self.data = np.asarray(data)
+        self.early = None
+        if self.zlib and self.shape and self.data.nbytes >= (1 << 22):
+            # a large compressed array starts to deflate NOW, on the pool's threads, while the caller prepares the next
+            # variable (NaN fills, cell bounds: 0.6 s of NumPy per full frame, beside 0.8 s of deflate); write() picks the
+            # dataset up and gives it its attributes
+            self.early = _Dataset(self.name, self.dtype, self.shape, self.data, self.fill_value, True, self.chunksizes, None)
 
 
 def _shuffle(raw, itemsize):
@@ -380,7 +388,7 @@ class Writer(object):
                 raise KeyError('unknown dimension ' + d)
         if name in self.dims and tuple(dims) != (name,):
             raise ValueError('a variable named like a dimension must be its coordinate variable')
-        v = self.vars[name] = Variable(name, dtype, dims, fill_value, zlib, chunksizes)
+        v = self.vars[name] = Variable(name, dtype, dims, fill_value, zlib, chunksizes, tuple(self.dims[d] for d in dims))
         return v
 
     def write(self, path):
@@ -398,7 +406,11 @@ class Writer(object):
             attrs = OrderedDict(v.attrs)
             if v.fill_value is not None:
                 attrs = OrderedDict([('_FillValue', v.fill_value)] + list(attrs.items()))
-            datasets[v.name] = _Dataset(v.name, v.dtype, shape, data, v.fill_value, v.zlib, v.chunksizes, attrs)
+            if v.early is not None:
+                datasets[v.name] = v.early
+                v.early.attrs = attrs
+            else:
+                datasets[v.name] = _Dataset(v.name, v.dtype, shape, data, v.fill_value, v.zlib, v.chunksizes, attrs)
         names = sorted(datasets, key=lambda s: s.encode('utf-8'))
         if len(names) > 2 * 32767:
             raise ValueError('too many objects for one symbol-table node')
