@@ -164,10 +164,13 @@ class Writer(object):
     of ``spacepy.pycdf.CDF`` the reference's exporter uses: ``attrs[...] = value``, ``new(name, data, type=..., recVary=...,
     compress=...)`` and ``var.attrs[...] = value``."""
 
-    def __init__(self, tt2000=True):
+    def __init__(self, tt2000=True, pool=None):
+        """``pool``: a ``concurrent.futures`` executor; a large compressed variable then starts to compress when it is created
+        (``new``), beside whatever the caller does to prepare the next one, and ``write`` collects the streams."""
         self.attrs = OrderedDict()
         self.vars = OrderedDict()
         self.tt2000 = tt2000
+        self.pool = pool
 
     def __getitem__(self, name):
         return self.vars[name]
@@ -216,6 +219,9 @@ class Writer(object):
             raise ValueError('only GZIP compression is written')
         v = self.vars[name] = Var(name, type, 1, dims, bool(recVary), records,
                                   int(compress_param) if compress == GZIP_COMPRESSION else None)
+        v.blocks = None
+        if self.pool is not None and v.compress is not None and records.nbytes >= (1 << 22):
+            v.blocks = self.pool.submit(_blocks_of, v)           # (`data` must not change until write())
         return v
 
     # -- layout -------------------------------------------------------------------------------------------------------------
@@ -244,27 +250,10 @@ class Writer(object):
             return [infer(value, self.tt2000)]
 
         # variable data first (sizes of the compressed blocks are needed for the addresses)
-        def block(v):
-            raw = v.records.tobytes()
-            if v.compress is None:
-                return [(0, v.records.shape[0] - 1, _VVR, raw)]
-            per = v.records[0].nbytes
-            out = []
-            for r in range(v.records.shape[0]):                      # blocking factor 1: one gzip stream per record
-                z = None
-                if per >= (1 << 22):
-                    # a large record: still ONE gzip member, its deflate blocks made side by side (export/csrc/amt_io.cpp)
-                    from . import _io
-                    z = _io.gzip_parallel(v.records[r], v.compress, _GZIP_THREADS)
-                if z is None:
-                    c = _zlib.compressobj(v.compress, _zlib.DEFLATED, 31)
-                    z = c.compress(raw[r * per:(r + 1) * per]) + c.flush()
-                out.append((r, r, _CVVR, z))
-            return out
-        if pool is not None:
-            blocks = list(pool.map(block, self.vars.values()))
-        else:
-            blocks = [block(v) for v in self.vars.values()]
+        pool = pool or self.pool
+        todo = [v for v in self.vars.values() if getattr(v, 'blocks', None) is None]
+        fresh = dict(zip([v.name for v in todo], pool.map(_blocks_of, todo) if pool is not None else map(_blocks_of, todo)))
+        blocks = [fresh[v.name] if v.name in fresh else v.blocks.result() for v in self.vars.values()]
 
         # pass 1: the size of every record, in file order -> addresses
         pieces = []                                               # (key, size)
@@ -355,6 +344,26 @@ class Writer(object):
             for b in out:
                 f.write(b)
         assert sum(len(b) for b in out) == eof
+
+
+def _blocks_of(v):
+    """the records of a variable as the blocks its VXR lists: [(first record, last record, record type, bytes)]"""
+    raw = v.records.tobytes()
+    if v.compress is None:
+        return [(0, v.records.shape[0] - 1, _VVR, raw)]
+    per = v.records[0].nbytes
+    out = []
+    for r in range(v.records.shape[0]):                      # blocking factor 1: one gzip stream per record
+        z = None
+        if per >= (1 << 22):
+            # a large record: still ONE gzip member, its deflate blocks made side by side (export/csrc/amt_io.cpp)
+            from . import _io
+            z = _io.gzip_parallel(v.records[r], v.compress, _GZIP_THREADS)
+        if z is None:
+            c = _zlib.compressobj(v.compress, _zlib.DEFLATED, 31)
+            z = c.compress(raw[r * per:(r + 1) * per]) + c.flush()
+        out.append((r, r, _CVVR, z))
+    return out
 
 
 class ReadVar(object):

@@ -35,7 +35,7 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
     :param bool useTT2000: CDF_TIME_TT2000 for times (else CDF_EPOCH); needs CDF 3.4.0 or higher for reading
     """
     z = _cdf3.GZIP_COMPRESSION if compress else None
-    root = _cdf3.Writer(tt2000=bool(useTT2000))
+    root = _cdf3.Writer(tt2000=bool(useTT2000), pool=_pool() if compress else None)
 
     def nan(a):
         return np.ma.filled(a, np.nan)
@@ -144,4 +144,4 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
         ('VAR_TYPE', 'support_data'), ('semi_major_axis', 6378137.0), ('inverse_flattening', 298.257223563),
         ('VAR_NOTES', 'Geographic Coordinate System, WGS 84'))
 
-    root.write(outputPath, pool=_pool() if compress else None)
+    root.write(outputPath)
