@@ -157,6 +157,9 @@ _SIGNATURES = {
     'amt_georef_frame': ([_P, C.POINTER(FrameParams), C.POINTER(GeorefOut)], _I),
     'amt_georef_frame_dirs': ([_P, C.POINTER(FrameParams), _P, C.POINTER(GeorefOut)], _I),
     'amt_georef_coarse_bbox': ([_P, C.POINTER(FrameParams), C.c_int32, _D, _I, _P], _I),
+    'amt_georef_coarse_bbox_dirs': ([_P, C.POINTER(FrameParams), _P, C.c_int32, _D, _I, _P], _I),
+    'amt_pipe_coarse_dirs': ([_P, C.POINTER(FrameParams), _P, _D, _I], _I),
+    'amt_pipe_launch_dirs': ([_P, C.POINTER(FrameParams), _P, C.POINTER(GeorefOut), _P, C.c_int32, _D, _D, _D, _I, _I], _I),
     'amt_georef_sky_rows': ([C.POINTER(FrameParams)] + [C.POINTER(C.c_int32)] * 4, _I),
     'amt_mask_by_elevation': ([_P, _P, _P, C.c_int32, C.c_int32, _D, _P, _P, _P], _I),
     'amt_sanitize_masks': ([_P, _P, _P, _P, C.c_int32, C.c_int32, _I], _I),

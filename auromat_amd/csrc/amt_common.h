@@ -725,7 +725,8 @@ __device__ __forceinline__ double asin_deg_any(double c, const double (&k)[9]) {
 }
 
 __device__ __forceinline__ double asin_deg(double c, const double (&k)[9]) {
-    return fabs(c) <= kSin45 ? asin_deg_low(c, k) : asin_deg_any(c, k);
+    // (a NaN takes the short form and stays NaN)
+    return fabs(c) > kSin45 ? asin_deg_any(c, k) : asin_deg_low(c, k);
 }
 
 }  // namespace fx

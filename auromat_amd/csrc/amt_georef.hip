@@ -368,17 +368,33 @@ __global__ __launch_bounds__(kThreads) void k_georef(georef_args A) {
 constexpr int kDppWaveShl1 = 0x130;   // lane i <- lane i+1
 constexpr int kDppWaveShr1 = 0x138;   // lane i <- lane i-1
 
+// (bound_ctrl: a lane without a source lane — lane 63 — reads 0, so the destination needs no initial value and the
+// compiler emits no v_mov_b32 0 in front of every DPP move; lane 63's centres are never used: it owns no pixel)
 __device__ __forceinline__ double from_next_lane(double v) {
     const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), kDppWaveShl1, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), kDppWaveShl1, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), kDppWaveShl1, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), kDppWaveShl1, 0xf, 0xf, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ int from_next_lane(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, kDppWaveShl1, 0xf, 0xf, false);
+    return __builtin_amdgcn_mov_dpp(v, kDppWaveShl1, 0xf, 0xf, true);
 }
 __device__ __forceinline__ int from_prev_lane(int v) {   // lane 0 receives 0
     return __builtin_amdgcn_update_dpp(0, v, kDppWaveShr1, 0xf, 0xf, false);
+}
+
+// v, or NaN where `keep` is false: ONE v_cndmask_b32 on the high word (0x7ff80000 over any low word is a quiet NaN)
+__device__ __forceinline__ double nan_unless(bool keep, double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned int hi = keep ? (unsigned int)(b >> 32) : 0x7ff80000u;
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (b & 0xffffffffull)));
+}
+
+// NaN in a register pair the optimiser cannot see through: assignments from it stay in the block they are written in
+__device__ __forceinline__ double opaque_nan() {
+    double n = __builtin_nan("");
+    asm volatile("" : "+v"(n));
+    return n;
 }
 
 // Scalar re-loads of the per-frame constants.  The ~60 constant doubles plus the 64-bit literals of the
@@ -803,15 +819,16 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
         sv.x = gx, sv.y = -gz, sv.z = rn;
         sxy = rd;
     };
-    auto sm_angles = [&](const vec3& ref, double ref_sxy, double ref_ml, double ref_sl, const vec3& sv, double sxy, double& ml,
-                         double& sl) {
+    // `live`: the point exists (lanes without one carry NaN through the small-angle path and must not ask for the full one)
+    auto sm_angles = [&](const vec3& ref, double ref_sxy, double ref_ml, double ref_sl, const vec3& sv, double sxy, bool live,
+                         double& ml, double& sl) {
         double dml, dsl;
         bool ok;
         fx::small_angles(ref_sxy, ref.z, sxy, sv.z, ref.x, ref.y, sv.x, sv.y, small_table().c, dml, dsl, ok);
         ok = ok && fabs(ref_sl) < 178.0;
         ml = ref_ml + dml;
         sl = ref_sl + dsl;
-        if (!ok) {
+        if (live && !ok) {
             const c9 k = atan_table();
             ml = fx::atan_pos_deg(sv.z, sxy, k.c);
             sl = fx::atan2_deg(sv.y, sv.x, k.c);
@@ -884,108 +901,103 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
     };
 
     // ---- one corner row + the centre row above it --------------------------------------------------------------
+    // There is no lane-divergent region around the arithmetic (round 5).  A ray that misses the shell gets the parameter
+    // NaN, and the NaN runs through the whole chain — point, Bowring pair, small angles, sums, elevation — so a miss comes
+    // out as NaN without a "preset NaN, overwrite under the exec mask" pair per value (the earlier form spent 34 + 20
+    // v_mov_b32 per row step on those presets, a sixth of its VALU instructions).  What NaN does NOT pass through by
+    // itself is guarded: the comparisons that select the full arctangents (`live`), v_min / v_max of the elevation clamp
+    // (nan_unless), the `q > 0 ? sqrt : 0` forms (their products with the NaN point are NaN again).  Rows of a wave none of
+    // whose lanes hits take a wave-uniform shortcut.
+    struct corner_vals {
+        vec3 p;
+        double la, lo, bn, bd, bla, blo;
+        vec3 sv;
+        double sxy, sml, ssl;
+        vec3 rv;
+        double rxy, rla, rlo;
+    };
     auto step = [&](const int r, const bool even, const vec3& dj, const row_state& prev, row_state& cur) {
         const int gy = y0 + r;
         unsigned int ch0 = 0, ch1 = 0, ch2 = 0;          // image pixel (gy-1, gx)
         // ---- corner (gy, gx) ------------------------------------------------------------------
-        vec3 d = {NAN, NAN, NAN}, p = {NAN, NAN, NAN}, u = {NAN, NAN, NAN};
-        double la = NAN, lo = NAN, bn = NAN, bd = NAN, bla = NAN, blo = NAN;
-        vec3 sv = {NAN, NAN, NAN};       // MAG: the corner in SM coordinates
-        double sxy = NAN, sml = NAN, ssl = NAN;
-        vec3 rv = {NAN, NAN, NAN};       // kMagPole: the rotated point and its angles
-        double rxy = NAN, rla = NAN, rlo = NAN;
-        bool hit = false;
-#ifdef AMT_SKIP_TIMING
-        // TIMING-ONLY build (wrong values, the right store / image / binning streams): three rows of every five cost what an
-        // interpolated row would cost — the question whether the Earth part of a frame follows its VALU work
-        const bool skip_row = (r % 5) >= 2;
-#else
-        constexpr bool skip_row = false;
-#endif
-        if (col_ok && skip_row) {
-            hit = prev.la == prev.la;
-            la = prev.la + 1e-4, lo = prev.lo + 1e-4;
-            la = __builtin_fma(la, 1.0000001, prev.bn * 1e-12), lo = __builtin_fma(lo, 1.0000001, prev.bd * 1e-12);
-            p = prev.p, d = prev.d, bn = prev.bn, bd = prev.bd, u = prev.d;
-            if (BIN) take_pixel(r, even, ch0, ch1, ch2);
-            const bool owner = (lane < 63 || gx == frame_w) && (r < rows || gy == frame_h);
-            if (owner) {
-                if (out_lat) at(out_lat, off_corner) = la;
-                if (out_lon) at(out_lon, off_corner) = lo;
-            }
-        }
-        if (col_ok && !skip_row) {
-            const shell_ray& ry = ray;
-            u = corner_ray(gy, dj);
-            const double uu = fx::dot3(u.x, u.y, u.z, u.x, u.y, u.z);
-            const double t = shell_t(ry, u, uu);
-            hit = t >= 0.0;
-            // unit direction (what the centre's elevation averages, reference astrometry.py:154-160); caller-supplied
-            // directions are used as they are, like the reference does
-            if (DIRS_IN) {
-                d = u;
-            } else {
+        // (lanes beyond the last corner column: the camera model extrapolates, caller-supplied directions are NaN there;
+        // either way they count as misses and own nothing)
+        const shell_ray& ry = ray;
+        const vec3 u = corner_ray(gy, dj);
+        const double uu = fx::dot3(u.x, u.y, u.z, u.x, u.y, u.z);
+        const double t = shell_t(ry, u, uu);
+        const bool hit = col_ok && t >= 0.0;
+        // unit direction (what the centre's elevation averages, reference astrometry.py:154-160); caller-supplied
+        // directions are used as they are, like the reference does
+        vec3 d;
+        if (DIRS_IN) {
+            d = u;
+        } else {
 #pragma clang fp contract(off)
-                const double rs = fx::rsqrt_n(uu);
-                d.x = u.x * rs, d.y = u.y * rs, d.z = u.z * rs;
+            const double rs = fx::rsqrt_n(uu);
+            d.x = u.x * rs, d.y = u.y * rs, d.z = u.z * rs;
+        }
+        corner_vals c;
+        // with bin_magnetic the bounding box is reduced over (MLat, SM longitude) as well
+        const bool magbox = MAG && (kMagOnly || (BIN && !kPole && A.bin_magnetic));
+        if (__builtin_amdgcn_ballot_w64(hit) != 0) {     // wave-uniform
+            c.p = shell_point(ry, u, nan_unless(hit, t));         // already in GEO; NaN for a miss
+            c.la = c.lo = c.bn = c.bd = NAN;
+            if (!kMagOnly) {
+                double ir;
+                fx::bowring_nd(bw, c.p.x, c.p.y, c.p.z, c.bn, c.bd, ir);
+                double dla, dlo;
+                bool ok;
+                fx::small_angles(prev.bd, prev.bn, c.bd, c.bn, prev.p.x, prev.p.y, c.p.x, c.p.y, small_table().c, dla, dlo, ok);
+                ok = ok && fabs(prev.lo) < 178.0;
+                c.la = prev.la + dla;
+                c.lo = prev.lo + dlo;
+                if (hit && !ok) full_angles(c.bn, c.bd, c.p.x, c.p.y, c.la, c.lo);
             }
-            if (hit) {
-                p = shell_point(ry, u, t);           // already in GEO
-                if (!kMagOnly) {
-                    double ir;
-                    fx::bowring_nd(bw, p.x, p.y, p.z, bn, bd, ir);
-                    double dla, dlo;
-                    bool ok;
-                    fx::small_angles(prev.bd, prev.bn, bd, bn, prev.p.x, prev.p.y, p.x, p.y, small_table().c, dla, dlo, ok);
-                    ok = ok && fabs(prev.lo) < 178.0;
-                    la = prev.la + dla;
-                    lo = prev.lo + dlo;
-                    if (!ok) full_angles(bn, bd, p.x, p.y, la, lo);
-                }
-            }
-            if (BIN) take_pixel(r, even, ch0, ch1, ch2);
-            // the last corner row of a chunk is the first of the next one (which owns it) unless it is
-            // the image's last; lane 63's column likewise belongs to the next strip unless it is the last
-            const bool owner = (lane < 63 || gx == frame_w) && (r < rows || gy == frame_h);
-            if (!kMagOnly && owner) {
-                if (out_lat) at(out_lat, off_corner) = la;
-                if (out_lon) at(out_lon, off_corner) = lo;
-            }
+            c.sv = {NAN, NAN, NAN}, c.sxy = c.sml = c.ssl = NAN;
+            c.rv = {NAN, NAN, NAN}, c.rxy = c.rla = c.rlo = NAN;
             if (MAG) {
-                // with bin_magnetic the bounding box is reduced over (MLat, SM longitude) as well
-                const bool magbox = kMagOnly || (BIN && !kPole && A.bin_magnetic);
-                if (hit) {
-                    if (pole_bin) pole_point(bn, bd, p.x, p.y, sv, sxy); else sm_point(p, sv, sxy);
-                    sm_angles(prev.s, prev.sxy, prev.ml, prev.sl, sv, sxy, sml, ssl);
-                    if (kMagPole) {
-                        // MLat = atan(s.z / |s.xy|), SM longitude = atan2(s.y, s.x): the same construction on the SM vector;
-                        // without bin_magnetic (a geodetic grid with the pole in view whose caller also wants the MLat /
-                        // MLT arrays) the rotated pair is that of (lat, lon), as in the SECOND = 2 variant
-                        if (geo_pole) pole_point(bn, bd, p.x, p.y, rv, rxy); else pole_point(sv.z, sxy, sv.x, sv.y, rv, rxy);
-                        sm_angles(prev.r, prev.rxy, prev.rla, prev.rlo, rv, rxy, rla, rlo);
-                    }
-                }
-                const double mt = ssl * (24.0 / 360.0) + 12.0;
-                if (!kPole && owner && A.mlat) {
-                    at(A.mlat, off_corner) = sml;
-                    at(A.mlt, off_corner) = mt;
-                }
-                if (magbox) {
-                    bla = sml;
-                    blo = (mt - 12.0) / (24.0 / 360.0);       // mltToSmLon, reference transform.py:388-401
-                }
+                if (pole_bin) pole_point(c.bn, c.bd, c.p.x, c.p.y, c.sv, c.sxy); else sm_point(c.p, c.sv, c.sxy);
+                sm_angles(prev.s, prev.sxy, prev.ml, prev.sl, c.sv, c.sxy, hit, c.sml, c.ssl);
                 if (kMagPole) {
-                    bla = rla;
-                    blo = rlo;
+                    // MLat = atan(s.z / |s.xy|), SM longitude = atan2(s.y, s.x): the same construction on the SM vector;
+                    // without bin_magnetic (a geodetic grid with the pole in view whose caller also wants the MLat /
+                    // MLT arrays) the rotated pair is that of (lat, lon), as in the SECOND = 2 variant
+                    if (geo_pole) pole_point(c.bn, c.bd, c.p.x, c.p.y, c.rv, c.rxy); else pole_point(c.sv.z, c.sxy, c.sv.x, c.sv.y, c.rv, c.rxy);
+                    sm_angles(prev.r, prev.rxy, prev.rla, prev.rlo, c.rv, c.rxy, hit, c.rla, c.rlo);
                 }
-                if (pole_bin) {
-                    bla = sml;
-                    blo = ssl;
-                }
-                if (kMagBox && !magbox && !pole_bin && !kMagPole) {
-                    bla = la;
-                    blo = lo;
-                }
+            }
+        } else {
+            // a row of sky inside a chunk that sees the Earth: everything is NaN (taken from an opaque register pair, so
+            // that these assignments stay in this rarely taken block instead of becoming presets in front of the branch)
+            const double n = opaque_nan();
+            c.p = {n, n, n}, c.la = c.lo = c.bn = c.bd = n;
+            c.sv = {n, n, n}, c.sxy = c.sml = c.ssl = n;
+            c.rv = {n, n, n}, c.rxy = c.rla = c.rlo = n;
+        }
+        const double mt_corner = MAG ? c.ssl * (24.0 / 360.0) + 12.0 : NAN;
+        c.bla = c.blo = NAN;
+        if (MAG) {
+            if (magbox) {
+                c.bla = c.sml;
+                c.blo = (mt_corner - 12.0) / (24.0 / 360.0);       // mltToSmLon, reference transform.py:388-401
+            }
+            if (kMagPole) c.bla = c.rla, c.blo = c.rlo;
+            if (pole_bin) c.bla = c.sml, c.blo = c.ssl;
+            if (kMagBox && !magbox && !pole_bin && !kMagPole) c.bla = c.la, c.blo = c.lo;
+        }
+        if (BIN) take_pixel(r, even, ch0, ch1, ch2);
+        // the last corner row of a chunk is the first of the next one (which owns it) unless it is
+        // the image's last; lane 63's column likewise belongs to the next strip unless it is the last
+        const bool owner = col_ok && (lane < 63 || gx == frame_w) && (r < rows || gy == frame_h);
+        if (owner) {
+            if (!kMagOnly) {
+                if (out_lat) at(out_lat, off_corner) = c.la;
+                if (out_lon) at(out_lon, off_corner) = c.lo;
+            }
+            if (MAG && !kPole && A.mlat) {
+                at(A.mlat, off_corner) = c.sml;
+                at(A.mlt, off_corner) = mt_corner;
             }
         }
         int flag_cur = 0;
@@ -997,7 +1009,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
             if (FAST) {
                 // mean of the 4 corner hits / directions (reference astrometry.py:154-160); the summation
                 // order differs from the reference's by rounding only (<= 1e-12 deg)
-                const double sx = prev.p.x + p.x, sy = prev.p.y + p.y, sz = prev.p.z + p.z;
+                const double sx = prev.p.x + c.p.x, sy = prev.p.y + c.p.y, sz = prev.p.z + c.p.z;
                 const double tx = prev.d.x + d.x, ty = prev.d.y + d.y, tz = prev.d.z + d.z;
                 pc.x = (sx + from_next_lane(sx)) * 0.25;
                 pc.y = (sy + from_next_lane(sy)) * 0.25;
@@ -1008,7 +1020,6 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
                 dscale = 0.25;
             } else {
                 // the pixel's own ray (exact centres): the corner's plus half a column minus half a row
-                const shell_ray& ry = ray;
                 vec3 uc;
                 double uuc;
                 {
@@ -1020,60 +1031,57 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
                 }
                 dscale = 1.0;
                 const double tc = shell_t(ry, uc, uuc);
-                pc = shell_point(ry, uc, tc >= 0.0 ? tc : NAN);
+                pc = shell_point(ry, uc, nan_unless(tc >= 0.0, tc));
                 if (want_bbox) {
                     // after sanitisation a centre also needs its 4 corners (reference mapping.py:1093-1101)
-                    const int h = (prev.p.x == prev.p.x) && (p.x == p.x);
+                    const int h = (prev.p.x == prev.p.x) && (c.p.x == c.p.x);
                     corners_ok = h && from_next_lane(h);
                 }
             }
-            bool valid = false;
-            int bin_x = 0, bin_y = 0;            // 1-based bin indices of this pixel, 0 = not binned
-            long long el_fix = 0;
-            if (px_ok) {
-                double lac = NAN, loc = NAN, el = NAN, ml = NAN, mt = NAN, slc = NAN, rlac = NAN, rloc = NAN;
-                if (skip_row && pc.x == pc.x) {
-                    // 3 values x (4-term interpolation + one add)
-                    lac = __builtin_fma(la, 0.25, __builtin_fma(prev.la, 0.25, __builtin_fma(pc.x, 1e-9, pc.y * 1e-9))) + la * 0.5;
-                    loc = __builtin_fma(lo, 0.25, __builtin_fma(prev.lo, 0.25, __builtin_fma(pc.y, 1e-9, pc.z * 1e-9))) + lo * 0.5;
-                    el = __builtin_fma(dsum.x, 1e-3, __builtin_fma(dsum.y, 1e-3, __builtin_fma(dsum.z, 1e-3, pc.z * 1e-9))) + 20.0;
-                } else if (pc.x == pc.x) {
-                    double inv_r, cn = NAN, cd = NAN;
-                    if (kMagOnly || !centre_coords) {
-                        // 1 / |P| exactly as the Bowring step computes it (fx::bowring_nd): the elevation keeps its bits
+            const bool live = px_ok && pc.x == pc.x;          // this lane's pixel exists and its centre hit the shell
+            double lac, loc, el, ml = NAN, mt = NAN, slc = NAN, rlac = NAN, rloc = NAN;
+            if (__builtin_amdgcn_ballot_w64(live) != 0) {      // wave-uniform
+                double inv_r, cn = NAN, cd = NAN;
+                if (kMagOnly || !centre_coords) {
+                    // 1 / |P| exactly as the Bowring step computes it (fx::bowring_nd): the elevation keeps its bits
 #pragma clang fp contract(off)
-                        inv_r = fx::rsqrt_n(__builtin_fma(pc.z, pc.z, __builtin_fma(pc.x, pc.x, pc.y * pc.y)));
-                    } else {
-                        fx::bowring_nd(bw, pc.x, pc.y, pc.z, cn, cd, inv_r);
-                        // relative to this lane's corner of the current row
-                        double dla, dlo;
-                        bool ok;
-                        fx::small_angles(bd, bn, cd, cn, p.x, p.y, pc.x, pc.y, small_table().c, dla, dlo, ok);
-                        ok = ok && fabs(lo) < 178.0;
-                        lac = la + dla;
-                        loc = lo + dlo;
-                        if (!ok) full_angles(cn, cd, pc.x, pc.y, lac, loc);
-                    }
-                    // reference astrometry.py:200-212, utils.py:33-46: 90 - angle(-d, P/|P|) = asin(-d.P/|P|)
-                    // (dot products do not depend on the frame; 1/|P| is a by-product of the Bowring step)
-                    double c = -(fx::dot3(dsum.x, dsum.y, dsum.z, pc.x, pc.y, pc.z) * dscale) * inv_r;
-                    c = fmin(1.0, fmax(-1.0, c));
-                    el = fx::asin_deg(c, atan_table().c);
-                    if (MAG && centre_coords) {
-                        // relative to this lane's corner of the current row, like latitude and longitude
-                        vec3 sc;
-                        double sxyc;
-                        if (pole_bin) pole_point(cn, cd, pc.x, pc.y, sc, sxyc); else sm_point(pc, sc, sxyc);
-                        sm_angles(sv, sxy, sml, ssl, sc, sxyc, ml, slc);
-                        mt = slc * (24.0 / 360.0) + 12.0;
-                        if (kMagPole) {
-                            vec3 rc;
-                            double rxyc;
-                            if (geo_pole) pole_point(cn, cd, pc.x, pc.y, rc, rxyc); else pole_point(sc.z, sxyc, sc.x, sc.y, rc, rxyc);
-                            sm_angles(rv, rxy, rla, rlo, rc, rxyc, rlac, rloc);
-                        }
+                    inv_r = fx::rsqrt_n(__builtin_fma(pc.z, pc.z, __builtin_fma(pc.x, pc.x, pc.y * pc.y)));
+                    lac = loc = kMagOnly ? NAN : opaque_nan();
+                } else {
+                    fx::bowring_nd(bw, pc.x, pc.y, pc.z, cn, cd, inv_r);
+                    // relative to this lane's corner of the current row
+                    double dla, dlo;
+                    bool ok;
+                    fx::small_angles(c.bd, c.bn, cd, cn, c.p.x, c.p.y, pc.x, pc.y, small_table().c, dla, dlo, ok);
+                    ok = ok && fabs(c.lo) < 178.0;
+                    lac = c.la + dla;
+                    loc = c.lo + dlo;
+                    if (live && !ok) full_angles(cn, cd, pc.x, pc.y, lac, loc);
+                }
+                // reference astrometry.py:200-212, utils.py:33-46: 90 - angle(-d, P/|P|) = asin(-d.P/|P|)
+                // (dot products do not depend on the frame; 1/|P| is a by-product of the Bowring step)
+                double cs = -(fx::dot3(dsum.x, dsum.y, dsum.z, pc.x, pc.y, pc.z) * dscale) * inv_r;
+                cs = nan_unless(live, fmin(1.0, fmax(-1.0, cs)));          // (v_min / v_max drop a NaN operand)
+                el = fx::asin_deg(cs, atan_table().c);
+                if (MAG && centre_coords) {
+                    // relative to this lane's corner of the current row, like latitude and longitude
+                    vec3 sc;
+                    double sxyc;
+                    if (pole_bin) pole_point(cn, cd, pc.x, pc.y, sc, sxyc); else sm_point(pc, sc, sxyc);
+                    sm_angles(c.sv, c.sxy, c.sml, c.ssl, sc, sxyc, live, ml, slc);
+                    mt = slc * (24.0 / 360.0) + 12.0;
+                    if (kMagPole) {
+                        vec3 rc;
+                        double rxyc;
+                        if (geo_pole) pole_point(cn, cd, pc.x, pc.y, rc, rxyc); else pole_point(sc.z, sxyc, sc.x, sc.y, rc, rxyc);
+                        sm_angles(c.rv, c.rxy, c.rla, c.rlo, rc, rxyc, live, rlac, rloc);
                     }
                 }
+            } else {
+                const double n = opaque_nan();
+                lac = loc = el = ml = mt = slc = rlac = rloc = n;
+            }
+            if (px_ok) {
                 if (!kMagOnly && out_lat_c) at(out_lat_c, off_pixel) = lac;
                 if (!kMagOnly && out_lon_c) at(out_lon_c, off_pixel) = loc;
                 if (out_elev) at(out_elev, off_pixel) = el;
@@ -1081,55 +1089,57 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
                     at(A.mlat_c, off_pixel) = ml;
                     at(A.mlt_c, off_pixel) = mt;
                 }
-                valid = (el >= min_elev) && corners_ok;
-                if (BIN && valid) {
-                    // reference resample.py:301-351 on (lon, lat) or, for resampleMLatMLT, on
-                    // (SM longitude = mltToSmLon(mlt), MLat) (mapping.py:1519-1547, transform.py:388-401)
-                    const bool bin_mag = kMagOnly || (MAG && !kPole && A.bin_magnetic);
-                    double bxv = bin_mag ? (mt - 12.0) / (24.0 / 360.0) : loc;
-                    double byv = bin_mag ? ml : lac;
-                    if (pole_bin) bxv = slc, byv = ml;
-                    if (kMagPole) bxv = rloc, byv = rlac;
-                    if (lon_wrap) bxv = wrap180_shifted(bxv);
-                    int bx, by;
-                    bool slow;
-                    bin_common(bxv, byv, bx, by, slow);
-                    unsigned int edge_flags = 0;
-                    if (__ballot(slow)) {          // wave-uniform and rare
-                        if (slow) {
-                            if (pole_bin || kMagPole) {
-                                // next to an edge: the rotated coordinates as the two-pass plan computes them
-                                const pole_consts pk = karg_load<pole_consts>(karg_fresh(koff), offsetof(georef_args, pole));
-                                if (kMagPole && !geo_pole)
-                                    rotate_pole_deg(pk.w, pk.rot, pk.e2, ml, (mt - 12.0) / (24.0 / 360.0), pk.alt, byv, bxv);
-                                else
-                                    rotate_pole_deg(pk.w, pk.rot, pk.e2, lac, loc, pk.alt, byv, bxv);
-                            }
-                            bin_slow(bxv, byv, bx, by, edge_flags);
+            }
+            const bool valid = px_ok && (el >= min_elev) && corners_ok;
+            int bin_x = 0, bin_y = 0;            // 1-based bin indices of this pixel, 0 = not binned
+            long long el_fix = 0;
+            if (BIN && valid) {
+                // reference resample.py:301-351 on (lon, lat) or, for resampleMLatMLT, on
+                // (SM longitude = mltToSmLon(mlt), MLat) (mapping.py:1519-1547, transform.py:388-401)
+                const bool bin_mag = kMagOnly || (MAG && !kPole && A.bin_magnetic);
+                double bxv = bin_mag ? (mt - 12.0) / (24.0 / 360.0) : loc;
+                double byv = bin_mag ? ml : lac;
+                if (pole_bin) bxv = slc, byv = ml;
+                if (kMagPole) bxv = rloc, byv = rlac;
+                if (lon_wrap) bxv = wrap180_shifted(bxv);
+                int bx, by;
+                bool slow;
+                bin_common(bxv, byv, bx, by, slow);
+                unsigned int edge_flags = 0;
+                if (__ballot(slow)) {          // wave-uniform and rare
+                    if (slow) {
+                        if (pole_bin || kMagPole) {
+                            // next to an edge: the rotated coordinates as the two-pass plan computes them
+                            const pole_consts pk = karg_load<pole_consts>(karg_fresh(koff), offsetof(georef_args, pole));
+                            if (kMagPole && !geo_pole)
+                                rotate_pole_deg(pk.w, pk.rot, pk.e2, ml, (mt - 12.0) / (24.0 / 360.0), pk.alt, byv, bxv);
+                            else
+                                rotate_pole_deg(pk.w, pk.rot, pk.e2, lac, loc, pk.alt, byv, bxv);
                         }
+                        bin_slow(bxv, byv, bx, by, edge_flags);
                     }
-                    if (bx > 0 && by > 0) {
-                        el_fix = to_fix32(el);
-                        bin_event* events = nullptr;
-                        if (edge_flags) events = karg_load<bin_event*>(karg_fresh(koff), offsetof(georef_args, bin_events));
-                        if (events != nullptr) {
-                            // on an edge in the sense of the right-most-edge rule: which bin it belongs to depends on
-                            // the final grid, so it is recorded instead of binned (see bin_event)
-                            karg_ptr KE = karg_fresh(koff);
-                            unsigned int* cnt = karg_load<unsigned int*>(KE, offsetof(georef_args, bin_event_count));
-                            const long long cap = karg_load<long long>(KE, offsetof(georef_args, bin_event_cap));
-                            const unsigned int slot = atomicAdd(cnt, 1u);
-                            if ((long long)slot < cap) {
-                                bin_event ev;
-                                ev.bx = bx, ev.by = by, ev.flags = edge_flags;
-                                ev.c0 = ch0, ev.c1 = ch1, ev.c2 = ch2;
-                                ev.el = el_fix;
-                                events[slot] = ev;
-                            }
-                        } else {
-                            bin_x = bx;
-                            bin_y = by;
+                }
+                if (bx > 0 && by > 0) {
+                    el_fix = to_fix32(el);
+                    bin_event* events = nullptr;
+                    if (edge_flags) events = karg_load<bin_event*>(karg_fresh(koff), offsetof(georef_args, bin_events));
+                    if (events != nullptr) {
+                        // on an edge in the sense of the right-most-edge rule: which bin it belongs to depends on
+                        // the final grid, so it is recorded instead of binned (see bin_event)
+                        karg_ptr KE = karg_fresh(koff);
+                        unsigned int* cnt = karg_load<unsigned int*>(KE, offsetof(georef_args, bin_event_count));
+                        const long long cap = karg_load<long long>(KE, offsetof(georef_args, bin_event_cap));
+                        const unsigned int slot = atomicAdd(cnt, 1u);
+                        if ((long long)slot < cap) {
+                            bin_event ev;
+                            ev.bx = bx, ev.by = by, ev.flags = edge_flags;
+                            ev.c0 = ch0, ev.c1 = ch1, ev.c2 = ch2;
+                            ev.el = el_fix;
+                            events[slot] = ev;
                         }
+                    } else {
+                        bin_x = bx;
+                        bin_y = by;
                     }
                 }
             }
@@ -1147,27 +1157,27 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
                 }
             }
         }
-        cur.p = p;
+        cur.p = c.p;
         cur.d = d;
-        cur.la = la;
-        cur.lo = lo;
-        cur.bn = bn;
-        cur.bd = bd;
+        cur.la = c.la;
+        cur.lo = c.lo;
+        cur.bn = c.bn;
+        cur.bd = c.bd;
         if (kMagBox) {
-            cur.bla = bla;
-            cur.blo = blo;
+            cur.bla = c.bla;
+            cur.blo = c.blo;
         }
         if (MAG) {
-            cur.s = sv;
-            cur.sxy = sxy;
-            cur.ml = sml;
-            cur.sl = ssl;
+            cur.s = c.sv;
+            cur.sxy = c.sxy;
+            cur.ml = c.sml;
+            cur.sl = c.ssl;
         }
         if (kMagPole) {
-            cur.r = rv;
-            cur.rxy = rxy;
-            cur.rla = rla;
-            cur.rlo = rlo;
+            cur.r = c.rv;
+            cur.rxy = c.rxy;
+            cur.rla = c.rla;
+            cur.rlo = c.rlo;
         }
         cur.flag = flag_cur;
     };
@@ -1353,6 +1363,8 @@ void launch_rows(amt_ctx* ctx, const georef_batch& B, int n_frames, dim3 grid, i
 // One thread per lattice corner (every `stride`-th pixel corner): bounding box of the corners whose own ray
 // has an elevation >= min_elev, in (lat, lon), (MLat, SM longitude) [magnetic = 1] or (lat, lon) rotated by 90 deg
 // about x [magnetic = 2, the pole plan; 3: (MLat, SM longitude) rotated likewise].  Partials per workgroup.
+// DIRS: the corner's direction is read from A.dirs_in (caller-supplied unit vectors, J2000) instead of the TAN model.
+template <bool DIRS>
 __global__ __launch_bounds__(kThreads) void k_coarse_bbox(georef_args A, int stride, int magnetic, double min_elev,
                                                            double* __restrict__ partials) {
     __shared__ double sRed[8][kThreads / 64];
@@ -1362,7 +1374,13 @@ __global__ __launch_bounds__(kThreads) void k_coarse_bbox(georef_args A, int str
     if (i < nxl * nyl) {
         const int iy = i / nxl, ix = i - iy * nxl;
         const int gx = min(ix * stride, A.width), gy = min(iy * stride, A.height);
-        const vec3 d = tan_direction_fast(A.wcs, gx - 0.5, gy - 0.5);
+        vec3 d;
+        if (DIRS) {
+            const double* q = A.dirs_in + 3 * ((int64_t)gy * (A.width + 1) + gx);
+            d.x = q[0], d.y = q[1], d.z = q[2];
+        } else {
+            d = tan_direction_fast(A.wcs, gx - 0.5, gy - 0.5);
+        }
         const double t = ray_param_fast(A.ray, d);
         if (t == t) {
             // where the expensive rays are, relative to the frame centre (scheduling hint for the full kernel)
@@ -1921,9 +1939,30 @@ int amt_georef_frame(amt_ctx* ctx, const amt_frame_params* p, const amt_georef_o
     return launch_georef(ctx, p, nullptr, out);
 }
 
+namespace {
+int coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, int32_t stride, double min_elevation, int magnetic,
+                double* bbox);
+}
+
 int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stride, double min_elevation,
                            int magnetic, double* bbox) {
     AMT_CHECK_CTX(ctx);
+    return coarse_bbox(ctx, p, nullptr, stride, min_elevation, magnetic, bbox);
+}
+
+int amt_georef_coarse_bbox_dirs(amt_ctx* ctx, const amt_frame_params* p, const double* corner_dirs, int32_t stride,
+                                double min_elevation, int magnetic, double* bbox) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, corner_dirs != nullptr, "corner_dirs is NULL");
+    AMT_REQUIRE(ctx, magnetic == 0 || magnetic == 1, "direction arrays have no pole plan: magnetic must be 0 or 1");
+    return coarse_bbox(ctx, p, corner_dirs, stride, min_elevation, magnetic, bbox);
+}
+
+}  // extern "C"
+
+namespace {
+int coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, int32_t stride, double min_elevation, int magnetic,
+                double* bbox) {
     AMT_REQUIRE(ctx, p && bbox, "NULL argument");
     AMT_REQUIRE(ctx, p->width > 0 && p->height > 0 && stride > 0, "bad frame or stride");
     georef_args A;
@@ -1943,14 +1982,21 @@ int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stri
         ctx->last_error = "amt_georef_coarse_bbox: workspace allocation failed";
         return AMT_ENOMEM;
     }
-    hipLaunchKernelGGL(k_coarse_bbox, dim3(nblocks), dim3(kThreads), 0, ctx->stream, A, stride,
-                       (magnetic == 2 || magnetic == 3) ? magnetic : (magnetic ? 1 : 0), min_elevation, partials);
+    A.dirs_in = dirs;
+    const int mode = (magnetic == 2 || magnetic == 3) ? magnetic : (magnetic ? 1 : 0);
+    if (dirs)
+        hipLaunchKernelGGL(k_coarse_bbox<true>, dim3(nblocks), dim3(kThreads), 0, ctx->stream, A, stride, mode, min_elevation, partials);
+    else
+        hipLaunchKernelGGL(k_coarse_bbox<false>, dim3(nblocks), dim3(kThreads), 0, ctx->stream, A, stride, mode, min_elevation, partials);
     AMT_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(kThreads), 0, ctx->stream, partials, nblocks, bbox,
                        (const unsigned int*)nullptr);
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int amt_georef_sky_rows(const amt_frame_params* p, int32_t* rows_per_item, int32_t* n_item_rows, int32_t* top_end,
                         int32_t* bottom_begin) {

@@ -37,6 +37,7 @@ struct amt_pipe {
     int32_t off_x, off_y;          // window of the exact grid inside the superset
     double lat_ppd, lon_ppd, min_elev;
     int pole;
+    bool pole_unknown;             // direction arrays without a decision of the caller: see amt_pipe_launch_dirs
     bool pole_plan;                // this frame is binned in the coordinates rotated by 90 deg about x (bin_pole)
     int img_dtype;
     // the two-pass plan on the driver's streams (amt_pipe_general_layout / _finalize): the frame's coordinate arrays, image
@@ -55,6 +56,7 @@ namespace {
 constexpr int kCoarseStride = 16;      // every 16th pixel corner at most; >= 128 lattice points on the short side
 constexpr long long kEventCapacity = 16384;   // on-edge pixels per frame (a few dozen in practice)
 constexpr double kMarginDeg = 1.0;     // safety margin around the coarse box (> 3 lattice steps on the ground)
+constexpr double kPoleGuardDeg = 85.0; // direction arrays, pole unknown: boxes that reach beyond this latitude are not fused
 
 int ensure_acc(amt_pipe* pipe, size_t cells) {
     if (cells <= pipe->acc_cells) return AMT_OK;
@@ -232,7 +234,7 @@ int amt_pipe_destroy(amt_pipe* pipe) {
 namespace {
 
 // coarse box in the coordinates of `mode` (see amt_pipe.coarse_magnetic)
-int pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation, int mode) {
+int pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation, int mode, const double* dirs = nullptr) {
     amt_ctx* ctx = pipe->ctx;
     // the pre-pass runs on the driver's own stream (and with that stream's workspace, see amt_workspace): the
     // context's stream is busy with the previous frames' kernels
@@ -241,7 +243,8 @@ int pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation,
     const double thr = std::isinf(min_elevation) ? min_elevation : min_elevation - 0.5;
     const int shorter = p->width < p->height ? p->width : p->height;
     const int stride = std::max(1, std::min(kCoarseStride, shorter / 128));
-    int rc = amt_georef_coarse_bbox(ctx, p, stride, thr, mode, pipe->host_small_dev);
+    int rc = dirs ? amt_georef_coarse_bbox_dirs(ctx, p, dirs, stride, thr, mode, pipe->host_small_dev)
+                  : amt_georef_coarse_bbox(ctx, p, stride, thr, mode, pipe->host_small_dev);
     ctx->stream = saved;
     if (rc != AMT_OK) return rc;
     AMT_HIP(ctx, hipEventRecord(pipe->coarse_done, pipe->pre_stream));
@@ -254,6 +257,14 @@ int pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation,
 }  // namespace
 
 extern "C" {
+
+int amt_pipe_coarse_dirs(amt_pipe* pipe, const amt_frame_params* p, const double* corner_dirs, double min_elevation,
+                         int magnetic) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipe->ctx;
+    AMT_REQUIRE(ctx, p != nullptr && corner_dirs != nullptr, "NULL argument");
+    return pipe_coarse(pipe, p, min_elevation, magnetic ? 1 : 0, corner_dirs);
+}
 
 int amt_pipe_coarse(amt_pipe* pipe, const amt_frame_params* p, double min_elevation, int magnetic) {
     if (pipe == nullptr) return AMT_EINVAL;
@@ -277,20 +288,23 @@ int pipe_prepare_rest(amt_pipe* pipe, const amt_frame_params* p, const amt_geore
 // kernel outputs (`o`) and the tail description for this frame.
 int pipe_prepare(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
                  int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
-                 int pole_in_view, int magnetic, amt_georef_out* o_out, amt_georef_tail* tail_out) {
+                 int pole_in_view, int magnetic, amt_georef_out* o_out, amt_georef_tail* tail_out,
+                 const double* dirs = nullptr) {
     amt_ctx* ctx = pipe->ctx;
     AMT_REQUIRE(ctx, p && out && img, "NULL argument");
     AMT_REQUIRE(ctx, img_dtype == 1 || img_dtype == 2, "img must be uint8 (1) or uint16 (2)");
     magnetic = magnetic ? 1 : 0;
-    pipe->pole = pole_in_view < 0 ? (pole_visible(p, min_elevation, magnetic) ? 1 : 0) : (pole_in_view ? 1 : 0);
+    // (direction arrays: there is no camera model to project the pole through — the caller decides, or nobody does)
+    pipe->pole_unknown = dirs != nullptr && pole_in_view < 0;
+    pipe->pole = pole_in_view < 0 ? (dirs == nullptr && pole_visible(p, min_elevation, magnetic) ? 1 : 0) : (pole_in_view ? 1 : 0);
     // frames with a pole of their grid in view take a pole plan (binned in rotated coordinates; a geodetic pole frame of
     // a caller that wants the MLat / MLT arrays as well runs the kernel variant of the magnetic pole plan with the
-    // rotated pair taken from (lat, lon), see prepare_georef)
-    const int mode = magnetic ? (pipe->pole ? 3 : 1) : (pipe->pole ? 2 : 0);
+    // rotated pair taken from (lat, lon), see prepare_georef); direction arrays have none: their pole frames are not fused
+    const int mode = dirs ? magnetic : (magnetic ? (pipe->pole ? 3 : 1) : (pipe->pole ? 2 : 0));
     pipe->pole_plan = mode >= 2;
     if (!pipe->coarse_pending || pipe->coarse_magnetic != mode) {
         if (pipe->coarse_pending && !pipe->coarse_hinted) AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
-        if (int rc = pipe_coarse(pipe, p, min_elevation, mode)) return rc;
+        if (int rc = pipe_coarse(pipe, p, min_elevation, mode, dirs)) return rc;
     }
     if (!pipe->coarse_hinted) AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
     pipe->coarse_pending = false;
@@ -361,6 +375,7 @@ int pipe_prepare_rest(amt_pipe* pipe, const amt_frame_params* p, const amt_geore
     // coarse [lat_min, lat_max, lon_min, lon_max, lon_min_positive, lon_max_nonpositive, n, hint]
     const double* c = pipe->host_small;
     bool fuse = !pipe->two_pass && c[6] > 0 && (!pipe->pole || pipe->pole_plan);
+    if (pipe->pole_unknown && !(c[0] > -kPoleGuardDeg && c[1] < kPoleGuardDeg)) fuse = false;
     pipe->lon_wrap = 0;
     double box_lo = c[2], box_hi = c[3];
     if (fuse && pipe->pole_plan && c[3] - c[2] > 180) fuse = false;      // (cannot happen: the rotated frame sits at the equator)
@@ -480,6 +495,23 @@ int amt_pipe_launch_many_res(amt_pipe* const* pipes, int32_t n, const amt_frame_
     return AMT_OK;
 }
 
+int amt_pipe_launch_dirs(amt_pipe* pipe, const amt_frame_params* p, const double* corner_dirs, const amt_georef_out* out,
+                         const void* img, int32_t img_dtype, double min_elevation, double lat_px_per_deg,
+                         double lon_px_per_deg, int pole_in_view, int magnetic) {
+    if (pipe == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipe->ctx;
+    AMT_REQUIRE(ctx, p && corner_dirs && out && img, "NULL argument");
+    AMT_REQUIRE(ctx, p->fast_center, "caller-supplied directions need fast_center");
+    amt_georef_out o;
+    amt_georef_tail tail;
+    if (int rc = pipe_prepare(pipe, p, out, img, img_dtype, min_elevation, lat_px_per_deg, lon_px_per_deg, pole_in_view, magnetic,
+                              &o, &tail, corner_dirs))
+        return rc;
+    pipe->g_mode = -1;                    // (amt_pipe_general_layout: the pole of a direction-array frame is the caller's business)
+    if (int rc = amt_georef_launch(ctx, p, corner_dirs, &o, &tail)) return rc;
+    return pipe_after_launch(pipe);
+}
+
 int amt_pipe_launch_box_many(amt_pipe* const* pipes, int32_t n, const amt_frame_params* const* p, double min_elevation,
                              int magnetic) {
     if (pipes == nullptr || n < 1 || pipes[0] == nullptr) return AMT_EINVAL;
@@ -499,6 +531,7 @@ int amt_pipe_launch_box_many(amt_pipe* const* pipes, int32_t n, const amt_frame_
         if (pipe->coarse_pending && !pipe->coarse_hinted) AMT_HIP(ctx, hipEventSynchronize(pipe->coarse_done));
         pipe->coarse_pending = pipe->coarse_hinted = false;
         pipe->pole = pole_visible(p[i], min_elevation, magnetic) ? 1 : 0;
+        pipe->pole_unknown = false;
         pipe->pole_plan = false;
         pipe->lat_ppd = pipe->lon_ppd = 0;
         pipe->min_elev = min_elevation;
@@ -562,6 +595,8 @@ int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result) {
     if (!pipe->fused || (pipe->pole && !pipe->pole_plan)) return AMT_OK;
     result->edge_pixels = (int32_t)(pipe->n_events > 2000000000ll ? 2000000000ll : pipe->n_events);
     if (pipe->n_events > kEventCapacity) return AMT_OK;         // more on-edge pixels than records: general path
+    // direction arrays whose caller left the pole open: a box that comes near a pole goes back to the caller (status 1)
+    if (pipe->pole_unknown && !(b[0] > -kPoleGuardDeg && b[1] < kPoleGuardDeg)) return AMT_OK;
     const bool straddles = b[3] - b[2] > 180;
     if (straddles != (pipe->lon_wrap != 0)) return AMT_OK;      // the coarse pass judged the discontinuity differently
     if (pipe->pole_plan) {

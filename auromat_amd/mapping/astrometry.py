@@ -193,16 +193,19 @@ class BaseAstrometryMapping(BaseMapping):
                 ctx.call('amt_sanitize_masks', ptr(fd.corner_mask_tensor()), ptr(fd.center_mask_tensor()), None,
                          fd.height, fd.width, 0)
             self._frame = fd
-            if self._lazy_elev is not None:
-                # the remembered maskedByElevation (raises the reference's ValueError when nothing is left)
-                e, self._lazy_elev = self._lazy_elev, None
-                try:
-                    self._frame = BaseMapping.maskedByElevation(self, e)._frame
-                except ValueError:
-                    self._frame, self._lazy_elev = None, e
-                    raise
-                self.setDirty()
+            self._apply_lazy_elevation()
         return self._frame
+
+    def _apply_lazy_elevation(self):
+        if self._lazy_elev is not None:
+            # the remembered maskedByElevation (raises the reference's ValueError when nothing is left)
+            e, self._lazy_elev = self._lazy_elev, None
+            try:
+                self._frame = BaseMapping.maskedByElevation(self, e)._frame
+            except ValueError:
+                self._frame, self._lazy_elev = None, e
+                raise
+            self.setDirty()
 
     def maskedByElevation(self, minElevation=10):
         """
@@ -367,8 +370,23 @@ class DirectionArrayMapping(BaseAstrometryMapping):
         p.m_sm[:] = list(mat_j2000_to_sm(et).ravel())
         return p
 
-    def _fusable(self):
-        return False            # (the single-pass plan of the mapping classes is built on the TAN camera model)
+    def _fused_resample(self, pxPerDeg, containsPole=None, magnetic=False, arcsecPerPx=None):
+        """
+        The single-pass plan on the direction array (amt_pipe_launch_dirs: shell intersection, coordinates, mask, box and
+        binning in one kernel that reads the (h + 1, w + 1, 3) directions once).  Not with arcsecPerPx (the box-first plan is
+        built on the camera model) -> None: the array route.  A frame whose box comes near a pole of the grid's coordinates
+        is decided from its corner quads by the two-pass plan inside run().
+        """
+        if self._frame is not None or not self._fusable() or arcsecPerPx:
+            return None
+        from ..pipeline import fused_class_pipeline
+        hdr = self._wcsHeader
+        pipe = fused_class_pipeline(hdr['IMAGEW'], hdr['IMAGEH'], self._img_array.dtype, magnetic)
+        res = pipe.run(None, self.altitude, self.cameraPosGCRS, self.photoTime, img=self._img_array, fast=True,
+                       min_elevation=self._lazy_elev, pxPerDeg=pxPerDeg, containsPole=containsPole, magnetic=magnetic, fuse=True,
+                       params=self._params(), dirs=self._dirs_tensor(pipe.ctx))
+        res['plan'] = pipe.last_plan
+        return res
 
     def _dirs_tensor(self, ctx):
         if self._dirs_dev is None:
@@ -382,6 +400,7 @@ class DirectionArrayMapping(BaseAstrometryMapping):
             georef_into(fd, self._params(), geo=True, dirs=self._dirs_tensor(ctx))
             fd.set_image(self._img_array)
             self._frame = fd
+            self._apply_lazy_elevation()
         return self._frame
 
     def _mlatmlt_tensors(self, center):

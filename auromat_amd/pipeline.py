@@ -115,6 +115,9 @@ class FramePipeline(object):
         self.params = None
         self.altitude = None
         self.min_elevation = None
+        # corner directions of the last frame when they came from the caller ((h + 1, w + 1, 3) float64 device tensor, J2000;
+        # the directions-in form of the pipeline, reference astrometry.py:49-64 with any camera model) instead of the TAN model
+        self._dirs = None
         self._out.bbox = fd.bbox.data_ptr()
 
     def _alloc_coords(self, full=False):
@@ -151,7 +154,10 @@ class FramePipeline(object):
             self._alloc_coords(full=True)
             Context.current(self.ctx.device)
             self._out.bbox_min_elevation = NEG_INF if self.min_elevation is None else float(self.min_elevation)
-            self.ctx.call('amt_georef_frame', C.byref(self.params), C.byref(self._out))
+            if self._dirs is not None:
+                self.ctx.call('amt_georef_frame_dirs', C.byref(self.params), ptr(self._dirs), C.byref(self._out))
+            else:
+                self.ctx.call('amt_georef_frame', C.byref(self.params), C.byref(self._out))
             self._set_out()
             self.fd.corner_mask = self.fd.center_mask = None
             self._coords_valid = self._kept_valid = True
@@ -228,13 +234,17 @@ class FramePipeline(object):
             Context.current(self.ctx.device)
             self._pcall('amt_pipe_join')
 
-    def start_coarse(self, params, min_elevation, magnetic=False, hint=None):
+    def start_coarse(self, params, min_elevation, magnetic=False, hint=None, dirs=None):
         """
         Enqueue the coarse bounding-box pre-pass for `params` (asynchronous, on the driver's own stream), or, with
         `hint` (the 8 reduction numbers of a neighbouring frame's exact box), skip it: amt_pipe_coarse_hint.
+        `dirs`: the frame's corner directions come from the caller (amt_pipe_coarse_dirs samples that array).
         """
         if hint is not None:
             self._pcall('amt_pipe_coarse_hint', (C.c_double * 8)(*hint), 1 if magnetic else 0)
+        elif dirs is not None:
+            self._pcall('amt_pipe_coarse_dirs', C.byref(params), ptr(dirs),
+                        NEG_INF if min_elevation is None else float(min_elevation), 1 if magnetic else 0)
         else:
             self._pcall('amt_pipe_coarse', C.byref(params),
                         NEG_INF if min_elevation is None else float(min_elevation), 1 if magnetic else 0)
@@ -278,11 +288,14 @@ class FramePipeline(object):
 
     # -- stages ---------------------------------------------------------------------------------
     def georef(self, wcsHeader, altitude, cameraPosGCRS, photoTime, fast=True, min_elevation=10.0, params=None,
-               fuse_pxPerDeg=None, coarse_started=False, fuse_magnetic=False):
+               fuse_pxPerDeg=None, coarse_started=False, fuse_magnetic=False, dirs=None, pole_in_view=-1):
         """
         Stage 1.  `params` (an amt_frame_params made by :func:`frame_params`) skips the host set-up.
         `fuse_pxPerDeg` = (latPxPerDeg, lonPxPerDeg) selects the single-pass plan for that resolution, on the
         geodetic grid or, with `fuse_magnetic`, on the (MLat, SM longitude) grid of resampleMLatMLT.
+        `dirs`: (h + 1, w + 1, 3) float64 device tensor of corner directions (J2000) that replaces the TAN camera model
+        (`params` then carries camera position, shell and rotations only; fast centres); `pole_in_view` 0 / 1 is the caller's
+        knowledge about a pole of the grid's coordinates in such a frame, -1 = unknown (amt_pipe_launch_dirs).
         """
         assert wcsHeader is None or (wcsHeader['IMAGEW'], wcsHeader['IMAGEH']) == (self.width, self.height)
         p = params if params is not None else frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fast,
@@ -292,15 +305,23 @@ class FramePipeline(object):
         out = self._out
         min_elev = NEG_INF if min_elevation is None else float(min_elevation)
         self.params, self.altitude, self.min_elevation = p, altitude, min_elevation
+        if dirs is not None:
+            assert dirs.is_cuda and dirs.is_contiguous() and tuple(dirs.shape) == (self.height + 1, self.width + 1, 3), \
+                'one direction per pixel corner, (h + 1, w + 1, 3) float64 on the device'
+        self._dirs = dirs
         if fuse_pxPerDeg is not None and fd.nchan == 3 and (self.with_mag or not fuse_magnetic):
             # coarse pre-pass (unless already enqueued), superset grid, fused kernel, bbox copy: all in the driver
             mag = 1 if fuse_magnetic else 0
             if not coarse_started:
-                self.start_coarse(p, min_elevation, mag)
+                self.start_coarse(p, min_elevation, mag, dirs=dirs)
             out.altitude = float(altitude)
-            self._pcall('amt_pipe_launch', C.byref(p), C.byref(out), fd.img.data_ptr(),
-                        fd.img_dtype_code, min_elev, float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1, mag)
-            self._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None)
+            if dirs is not None:
+                self._pcall('amt_pipe_launch_dirs', C.byref(p), ptr(dirs), C.byref(out), fd.img.data_ptr(),
+                            fd.img_dtype_code, min_elev, float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), int(pole_in_view), mag)
+            else:
+                self._pcall('amt_pipe_launch', C.byref(p), C.byref(out), fd.img.data_ptr(),
+                            fd.img_dtype_code, min_elev, float(fuse_pxPerDeg[0]), float(fuse_pxPerDeg[1]), -1, mag)
+            self._fused = dict(pxPerDeg=tuple(fuse_pxPerDeg), magnetic=bool(mag), result=None, pole_in_view=int(pole_in_view))
             fd.corner_mask = fd.center_mask = None
             self._coords_valid = fd.lat is not None and self.with_geo
             self._kept_valid = fd.elev is not None
@@ -310,7 +331,10 @@ class FramePipeline(object):
         self._fused = None
         self._pole = None                                # decided lazily in bounding_box()
         out.bbox_min_elevation = min_elev
-        self.ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
+        if dirs is not None:
+            self.ctx.call('amt_georef_frame_dirs', C.byref(p), ptr(dirs), C.byref(out))
+        else:
+            self.ctx.call('amt_georef_frame', C.byref(p), C.byref(out))
         self._set_out()
         fd.corner_mask = fd.center_mask = None
         # the 8 reduction doubles travel to pinned host memory right behind the kernel; the event lets
@@ -350,6 +374,7 @@ class FramePipeline(object):
                                                     float(ppd[0][0]), float(ppd[0][1]), -1, mag))
         for q, p, altitude, v in zip(pipes, params, altitudes, ppd):
             q.params, q.altitude, q.min_elevation = p, altitude, min_elevation
+            q._dirs = None
             q._fused = dict(pxPerDeg=v, magnetic=bool(mag), result=None)
             q.fd.corner_mask = q.fd.center_mask = None
             q._coords_valid = q.fd.lat is not None and q.with_geo
@@ -357,7 +382,14 @@ class FramePipeline(object):
 
     def bounding_box(self):
         """Waits for the fused reduction of the last georef() -> BoundingBox; ValueError if nothing is valid."""
-        if self._fused is not None and not self._fused['magnetic'] and not \
+        if self._dirs is not None:
+            # caller-supplied directions: no camera model to project a pole through — the corner quads decide
+            # (amt_bbox_corners counts those that wind around a pole, reference geodesic.py:183 / mapping.py:705-721)
+            if self._fused is not None:
+                self._wait_fused()
+            self.coordinates()
+            red = self._reduce_bbox(self.fd.lat, self.fd.lon)
+        elif self._fused is not None and not self._fused['magnetic'] and not \
                 (self._wait_fused().fused and self._wait_fused().bbox[7]):
             red = np.array(self._wait_fused().bbox[:])
         elif self._fused is not None:
@@ -542,7 +574,8 @@ class FramePipeline(object):
                 # the plan, res.bbox[7] — as the estimate, instead of five per-pixel arrays and a separate binning pass
                 self.start_coarse(self.params, self.min_elevation, magnetic, hint=list(res.bbox))
                 self.georef(None, self.altitude, None, None, bool(self.params.fast_center), self.min_elevation,
-                            params=self.params, fuse_pxPerDeg=tuple(pxPerDeg), coarse_started=True, fuse_magnetic=bool(magnetic))
+                            params=self.params, fuse_pxPerDeg=tuple(pxPerDeg), coarse_started=True, fuse_magnetic=bool(magnetic),
+                            dirs=self._dirs, pole_in_view=self._fused.get('pole_in_view', -1))
                 self._fused['retried'] = True
                 res = self._wait_fused()
             # status 0: the driver could finalise the frame; a caller's containsPole must agree with its decision
@@ -583,7 +616,7 @@ class FramePipeline(object):
 
     def run(self, wcsHeader, altitude, cameraPosGCRS, photoTime, img=None, fast=True, min_elevation=10.0,
             pxPerDeg=10, containsPole=None, magnetic=False, params=None, keep_on_device=False, fuse=False,
-            arcsecPerPx=None):
+            arcsecPerPx=None, dirs=None):
         """One frame end to end; returns the dict of :func:`auromat_amd.resample.resample_frame`.  `arcsecPerPx` (has
         precedence over pxPerDeg, like the reference's resample()): the box-first plan — a box pass, px/deg from the frame's
         own bounding box, then the single-pass launch (``fuse``) or the two-pass plan; the px/deg pair used is in the
@@ -591,6 +624,7 @@ class FramePipeline(object):
         if img is not None:
             self.set_image(img)
         coarse_started = False
+        assert not (arcsecPerPx and dirs is not None), 'arcsecPerPx: the box-first plan is built on the camera model'
         if arcsecPerPx:
             if params is None:
                 params = frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fast, magnetic=self.with_mag)
@@ -606,7 +640,8 @@ class FramePipeline(object):
         except TypeError:
             pxPerDeg = (pxPerDeg, pxPerDeg)
         self.georef(wcsHeader, altitude, cameraPosGCRS, photoTime, fast, min_elevation, params=params,
-                    fuse_pxPerDeg=pxPerDeg if fuse else None, fuse_magnetic=bool(magnetic), coarse_started=coarse_started)
+                    fuse_pxPerDeg=pxPerDeg if fuse else None, fuse_magnetic=bool(magnetic), coarse_started=coarse_started,
+                    dirs=dirs, pole_in_view=-1 if containsPole is None else int(bool(containsPole)))
         res = self.resample(pxPerDeg, containsPole, magnetic, keep_on_device=keep_on_device)
         res['pxPerDeg'] = tuple(pxPerDeg)
         return res

@@ -436,6 +436,84 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
                 variant=ctx.last_variant())
 
 
+def directions_in_run(imgs, first, warmup, steps, fence, n_dirs=6, depth=3):
+    """
+    The pipeline in the form north_star words it — "coalesced HBM reads of the (H+1) x (W+1) corner arrays": every frame's
+    corner directions ((H+1, W+1, 3) float64, J2000; reference astrometry.py:49-64 cameraToPixelCornerDirection) are resident
+    in HBM like its image, and ONE kernel (k_georef_rows<DIRS_IN, BIN>, amt_pipe_launch_dirs) reads them, intersects the
+    shell, writes the five coordinate arrays and bins.  `n_dirs` distinct frames (direction arrays are 288 MB each) are cycled,
+    each time with another image; `depth` frame buffers in flight; a frame's estimate is its own exact box from the cycle
+    before (the first cycle, inside the warm-up, runs the coarse pre-pass on the direction array).
+    """
+    import torch
+    from auromat_amd.coordinates.wcs import pix2world
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import sequence_frame
+    pipes = [FramePipeline(WIDTH, HEIGHT, alloc_image=False) for _ in range(depth)]
+    ctx = pipes[0].ctx
+    for q in pipes:
+        q.defer_join = True
+    frames = []
+    for k in range(n_dirs):
+        hdr, cam, t, _ = sequence_frame(first + k, WIDTH, HEIGHT)
+        frames.append((frame_params(hdr, ALTITUDE, cam, t, True, magnetic=False), cam, t,
+                       pix2world(hdr, WIDTH, HEIGHT, corner=True, ascartesian=True, device=ctx.device)))
+    hints = [None] * n_dirs
+    plans = []
+
+    def launch(k):
+        q = pipes[k % depth]
+        p, cam, t, dirs = frames[k % n_dirs]
+        q.use_image(imgs[k % len(imgs)])
+        hint = hints[k % n_dirs]
+        q.start_coarse(p, MIN_ELEV, False, hint=hint, dirs=dirs)
+        q.georef(None, ALTITUDE, cam, t, True, MIN_ELEV, params=p, fuse_pxPerDeg=(PPD, PPD), coarse_started=True, dirs=dirs,
+                 pole_in_view=0)
+
+    def finish(k):
+        q = pipes[k % depth]
+        res = q.resample((PPD, PPD), keep_on_device=True)
+        plans.append(q.last_plan)
+        if q.last_plan == 'single-pass':
+            hints[k % n_dirs] = list(q._fused['result'].bbox)
+        return res
+
+    def run(n, k0):
+        out = []
+        for k in range(k0, k0 + n):
+            launch(k)
+            if k - k0 >= depth - 1:
+                out.append(finish(k - depth + 1))
+        for k in range(max(k0, k0 + n - depth + 1), k0 + n):
+            out.append(finish(k))
+        for q in pipes:
+            q.join()
+        return out
+
+    run(max(warmup, n_dirs + depth), 0)          # every frame of the cycle has its hint now
+    t_end = time.perf_counter() + 0.4
+    while time.perf_counter() < t_end:
+        run(n_dirs, 0)
+        torch.cuda.synchronize()
+    del plans[:]
+    ctx.timing_enable(1)
+    fence()
+    t0 = time.perf_counter()
+    results = run(steps, 0)
+    fence()
+    elapsed = time.perf_counter() - t0
+    g_total, g_n = ctx.timing_read(0)
+    ctx.timing_enable(False)
+    assert g_n == steps and len(results) == steps, (g_n, len(results))
+    variant = ctx.last_variant()
+    grid = list(results[-1]['mean'].shape)
+    del results, frames
+    for q in pipes:
+        del q
+    return dict(elapsed=elapsed, georef_ms=g_total / g_n, plans=plans, variant=variant, grid=grid)
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -744,6 +822,24 @@ def main(argv=None):
                 'frac': frac(ab['georef'], g_total / g_n)}
             del gpipe
             gc.collect()
+            torch.cuda.empty_cache()
+            # the directions-in form (SURVEY 8d contract row "directions-in" + "resample-mean" = 1129.0 MB per frame: 24 B per
+            # corner read beside the WCS-fused rows' bytes; the kernel has to MOVE 288.4 MB of directions + 552.5 MB)
+            nv_k = 96
+            dr = directions_in_run(imgs, first, nv_w, nv_k, fence)
+            d_contract = ab['georef_dirs_in'] + ab['resample']
+            d_moved = ab['georef_dirs_in'] + ab['image']
+            variants['directions_in'] = {
+                'ms_per_frame': dr['elapsed'] / nv_k * 1e3, 'Mpixels_per_s': nv_k * npx / 1e6 / dr['elapsed'], 'frames': nv_k,
+                'kernel_ms_per_frame': dr['georef_ms'], 'single_pass_frames': sum(1 for q in dr['plans'] if q == 'single-pass'),
+                'algorithmic_bytes_per_frame': d_contract, 'frac': frac(d_contract, dr['georef_ms']),
+                'bytes_moved_min': d_moved, 'frac_bytes_moved_min': frac(d_moved, dr['georef_ms']),
+                'kernel': 'k_georef_rows<FAST, DIRS_IN, 0, BIN=uint16> (amt_pipe_launch_dirs), one frame per launch',
+                'kernel_variant': dict(zip(('second', 'bin', 'frames_in_last_launch'), dr['variant'])), 'grid': dr['grid'],
+                'direction_arrays_resident': 6}
+            del dr
+            gc.collect()
+            torch.cuda.empty_cache()
             out['variants'] = variants
         if world == 1 and args.cpu_rows > 0:
             parity = {}

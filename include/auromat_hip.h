@@ -327,6 +327,11 @@ int amt_georef_frame_dirs(amt_ctx* ctx, const amt_frame_params* p, const double*
  * shell right of (below) the frame centre minus those left of (above) it: the input of amt_georef_out.item_order. */
 int amt_georef_coarse_bbox(amt_ctx* ctx, const amt_frame_params* p, int32_t stride, double min_elevation,
                            int magnetic, double* bbox);
+/* The same estimate for caller-supplied corner directions (amt_georef_frame_dirs): every `stride`-th direction of
+ * corner_dirs ((height+1, width+1, 3), J2000) is cast instead of the TAN model's.  magnetic 0 or 1 (direction arrays have
+ * no pole plan). */
+int amt_georef_coarse_bbox_dirs(amt_ctx* ctx, const amt_frame_params* p, const double* corner_dirs, int32_t stride,
+                                double min_elevation, int magnetic, double* bbox);
 /* Host function (no GPU call): which rows of amt_georef_frame's work items cannot see the shell.  With the TAN camera
  * model the limb is a conic section in the image and the set of pixel corners whose ray hits the shell is convex, so
  * whole bands of the frame are bounded exactly from a handful of evaluations; the waves of such bands write NaN and
@@ -564,6 +569,20 @@ int amt_pipe_coarse_hint(amt_pipe* pipe, const double* bbox, int magnetic);
 int amt_pipe_launch(amt_pipe* pipe, const amt_frame_params* p, const amt_georef_out* out, const void* img,
                     int32_t img_dtype, double min_elevation, double lat_px_per_deg, double lon_px_per_deg,
                     int pole_in_view, int magnetic);
+/* The single-pass plan for caller-supplied corner directions — north_star's "(H+1) x (W+1) corner arrays" form of the
+ * pipeline, reference astrometry.py:49-64,86-106 with any camera model (BaseAstrometryMapping over pixelDirection's
+ * array; here DirectionArrayMapping): amt_pipe_coarse_dirs samples the direction array for the estimate (or
+ * amt_pipe_coarse_hint), amt_pipe_launch_dirs runs amt_georef_frame_dirs with the binning fused in; amt_pipe_wait /
+ * amt_pipe_finalize as above.  p: width, height, cam, a, b, a0, b0, m_geo, m_sm and fast_center = 1 are read (the TAN
+ * block is not).  There is no camera model to project a pole through: pole_in_view 0 / 1 is the caller's decision (1: the
+ * frame is not fused, amt_pipe_wait returns status 1), < 0 = unknown — then a frame whose estimated or exact box comes
+ * within 5 deg of a pole of its grid's coordinates is handed back with status 1 and the caller decides from the corner
+ * arrays (amt_bbox_corners counts the quads that wind around a pole). */
+int amt_pipe_coarse_dirs(amt_pipe* pipe, const amt_frame_params* p, const double* corner_dirs, double min_elevation,
+                         int magnetic);
+int amt_pipe_launch_dirs(amt_pipe* pipe, const amt_frame_params* p, const double* corner_dirs, const amt_georef_out* out,
+                         const void* img, int32_t img_dtype, double min_elevation, double lat_px_per_deg,
+                         double lon_px_per_deg, int pole_in_view, int magnetic);
 /* The same for n <= AMT_PIPE_MAX_BATCH frames, one per driver (all on one context), with ONE launch of the big
  * kernel when the frames are equally sized and take the same kernel variant (their constants sit side by side in
  * the kernel-argument segment; otherwise one launch each): the 14-17 us between two big kernels on a stream are

@@ -761,6 +761,78 @@ def test_direction_array_mapping_for_other_camera_models():
     assert np.nanmax(np.abs(c.lons.filled(np.nan) - b.lons.filled(np.nan))) > 0.01
 
 
+@pytest.mark.parametrize('pointing', ['iss030', 'iss029', 'pole', 'south-pole'])
+def test_direction_array_single_pass_equals_the_array_route(pointing):
+    """The single-pass plan on a direction array (amt_pipe_launch_dirs; north_star's "(H+1) x (W+1) corner arrays" form,
+    reference astrometry.py:49-64,86-106 + resample.py:301-351): resample() / resampleMLatMLT() of a DirectionArrayMapping
+    whose arrays nobody has asked for run ONE kernel and give the bits of the array route (georeference into arrays, mask,
+    box, separate binning pass).  A frame with a pole in view has no camera model to say so: its box comes within the guard
+    band and the corner quads decide (two-pass plan)."""
+    import auromat_amd.resample as R
+    from auromat_amd.mapping.astrometry import DirectionArrayMapping, pixelDirection
+    from auromat_amd.synthetic import frame_header, frame_image, pole_frame
+    w, h = 640, 420
+    if pointing in ('pole', 'south-pole'):
+        hdr, cam, t = pole_frame(w, h, south=pointing == 'south-pole')
+    else:
+        hdr, cam, t = frame_header(w, h, pointing)
+    img = frame_image(w, h, seed=11)
+    dirs = pixelDirection(hdr, corner=True)
+    for magnetic in (False, True):
+        fn = R.resampleMLatMLT if magnetic else R.resample
+        fused = DirectionArrayMapping(dirs, 110, img, cam, t, 'fused').maskedByElevation(10)
+        got = fn(fused, pxPerDeg=10)
+        plan = R.last_plan
+        arrays = DirectionArrayMapping(dirs, 110, img, cam, t, 'arrays')
+        arrays.lats                                     # materialise: the array route from here on
+        want = fn(arrays.maskedByElevation(10), pxPerDeg=10)
+        if pointing in ('iss030', 'iss029'):
+            assert plan == 'single-pass', (plan, magnetic)
+        elif not magnetic:
+            assert plan == 'two-pass', plan             # the geographic pole is in view: decided from the corner quads
+        assert fused._frame is None or plan != 'single-pass'
+        for name in ('lats', 'lons', 'latsCenter', 'lonsCenter', 'elevation', 'img'):
+            a, b = getattr(got, name), getattr(want, name)
+            assert a.shape == b.shape, (name, a.shape, b.shape)
+            assert np.array_equal(ma.getmaskarray(a), ma.getmaskarray(b)), (name, magnetic)
+            if name == 'elevation':
+                assert np.max(np.abs(a.compressed() - b.compressed())) < 1e-9
+            else:
+                assert np.array_equal(a.compressed(), b.compressed()), (name, magnetic)
+
+
+def test_direction_array_single_pass_full_size_equals_the_camera_model():
+    """BASELINE configs[2] in its directions-in form at full size: FramePipeline.run(dirs=pix2world(...)) against the same
+    frame through the TAN model — the direction arrays differ from the in-kernel affine model by rounding, so the grids are
+    compared cell by cell: same shape, same mask, counts equal but for pixels within rounding of a bin edge."""
+    import torch
+    from auromat_amd.coordinates.wcs import pix2world
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_header, frame_image
+    w, h = 4240, 2832
+    hdr, cam, t = frame_header(w, h, 'iss030')
+    img = frame_image(w, h, seed=5)
+    pipe = FramePipeline(w, h, alloc_coords=False)
+    dirs = pix2world(hdr, w, h, corner=True, ascartesian=True, device=pipe.ctx.device)
+    p = frame_params(hdr, 110, cam, t, True, magnetic=False)
+    a = pipe.run(None, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, fuse=True, params=p, dirs=dirs)
+    assert pipe.last_plan == 'single-pass' and pipe.ctx.last_variant()[1] == 2
+    b = pipe.run(hdr, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, fuse=True)
+    assert pipe.last_plan == 'single-pass'
+    assert a['mean'].shape == b['mean'].shape and np.array_equal(a['mask'], b['mask'])
+    assert int((a['count'] != b['count']).sum()) <= 4
+    same = a['count'] == b['count']
+    assert np.array_equal(a['mean'][..., :3][same], b['mean'][..., :3][same], equal_nan=True)
+    # ... and the two-pass plan on the same directions gives the single-pass bits
+    c = pipe.run(None, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=10, fuse=False, params=p, dirs=dirs)
+    assert pipe.last_plan == 'two-pass'
+    for k in ('mean', 'count', 'img', 'mask'):
+        assert np.array_equal(a[k], c[k], equal_nan=True), k
+    del dirs
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('proj', ['TAN', 'SIN', 'ARC', 'STG', 'ZEA'])
 def test_device_generator_for_zenithal_headers_equals_the_numpy_restatement(proj):
     """amt_directions_zenithal (what getMapping runs for a header that is not plain TAN — the reference hands those to
