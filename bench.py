@@ -635,6 +635,45 @@ def main(argv=None):
             gathered = run['extra']
             assert gathered.n_frames == world * args.steps and len(gathered.unpack()) == world * args.steps
 
+    upload = None
+    if not args.no_variants and not args.upload and shared is None and args.plan == 'fused' and not args.exact:
+        # The PCIe-inclusive form of the same job (never the headline value): every rank streams its frames'
+        # images from its OWN pinned host buffers (four distinct 72 MB images, cycled), uploaded on a copy stream beside the
+        # previous frames' kernels, instead of finding them resident in HBM — what a real 256-frame run does, and what
+        # eight ranks do to the host's memory system at once.  Same loop, gather included, barrier + max over the ranks.
+        u_steps = min(args.steps, 96)
+        host_imgs = [torch.from_numpy(frame_image(WIDTH, HEIGHT, seed=100 + 4 * rank + i).view(np.int16)).pin_memory() for i in range(4)]
+        u_frames = []
+        for k in range(args.warmup + u_steps):
+            hdr, cam, t, _ = sequence_frame(first + k, WIDTH, HEIGHT)
+            u_frames.append((hdr, cam, t, host_imgs[k % 4], SHELLS[k % 3] if args.magnetic else None))
+        u_first = first
+        saved_steps = args.steps
+        args.steps = u_steps                  # (the gather's warm-up sizes its buffers from args.steps)
+        u = timed_run(u_frames, args.warmup, u_steps, fast, 'fused', args.magnetic, args.batch, args.streams, not args.no_hints,
+                      None, own_buffers=True, fence=fence, after=gather, spinup_ms=min(args.spinup_ms, 100.0),
+                      geodetic_arrays=args.nine_arrays)
+        args.steps = saved_steps
+        u_own = u['elapsed']
+        u_elapsed = u_own
+        u_rates = [u_steps * WIDTH * HEIGHT * 6 / u_own / 1e9]
+        if use_dist:
+            tmax = torch.tensor([u_own], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            u_elapsed = float(tmax.item())
+            rates = [None] * world
+            dist.all_gather_object(rates, u_rates[0])
+            u_rates = rates
+        upload = {'Mpixels_per_s': world * u_steps * WIDTH * HEIGHT / 1e6 / u_elapsed, 'ms_per_frame': u_elapsed / u_steps * 1e3,
+                  'frames_per_rank': u_steps, 'kernel_ms_per_frame': u['georef_ms'],
+                  'single_pass_frames': sum(1 for q in u['plans'] if q == 'single-pass'),
+                  'image_bytes_per_frame': WIDTH * HEIGHT * 6, 'pcie_GBs_per_rank': u_rates, 'pcie_GBs_total': float(sum(u_rates)),
+                  'source': 'four distinct uint16 RGB images per rank in page-locked host memory, cycled; one upload per frame on a '
+                            'copy stream (SequencePipeline, Python loop), gather of the grids included'}
+        del u, u_frames, host_imgs
+        import gc
+        gc.collect()
+
     if rank == 0:
         fused = args.plan == 'fused'
         seq, results, plans = run['seq'], run['results'], run['plans']
@@ -841,6 +880,8 @@ def main(argv=None):
             gc.collect()
             torch.cuda.empty_cache()
             out['variants'] = variants
+        if upload is not None:
+            out.setdefault('variants', {})['upload'] = upload
         if world == 1 and args.cpu_rows > 0:
             parity = {}
             out['cpu_baseline'] = cpu_baseline(min(args.cpu_rows, HEIGHT), parity=parity)

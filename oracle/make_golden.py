@@ -1062,6 +1062,84 @@ def real_frame_shells():
         save('real_frame_iss030_sm_%dkm.npz' % alt, **out)
 
 
+def _finish_real(case, name, mm, t, cam, altitude=110):
+    rimg, relev = np.dsplit(case['out_data'], [-1])
+    with np.errstate(invalid='ignore'):
+        rimg = np.round(rimg)
+    rimg = np.require(ma.masked_invalid(rimg, copy=False), np.uint8)
+    del case['outline']
+    out = dict(case)
+    out.update(out_img=rimg.data, out_img_mask=ma.getmaskarray(rimg))
+    out.update(time_arrays(t))
+    out.update(cam=cam, altitude=np.float64(altitude), min_elev=np.float64(10), ppd=np.array((10, 10), dtype=np.float64),
+               n_valid=np.int64((~ma.getmaskarray(mm.latsCenter)).sum()))
+    save(name, **out)
+
+
+def real_frame_south():
+    """real_frame_iss029{,_exact,_sm}.npz: the OTHER frame the reference's mapping test runs (test/mapping_test.py:36-42
+    testSpacecraftMappingSouth): test/resources/ISS029-E-8492.jpg + .wcs at full size (4256 x 2832, southern hemisphere) ->
+    fast centres -> maskedByElevation(10) -> _resample(pxPerDeg=10, 'mean') on the geographic grid; the same with exact
+    centres; and the _resample call of resampleMLatMLT on the (MLat, SM longitude) grid, whose box straddles +-180 deg of SM
+    longitude there or not as the reference's bounding-box rule decides (mapping.py:726-734, resample.py:203-218).  Copies
+    of the two data files: tests/golden/resources/."""
+    from PIL import Image
+    from auromat_amd.fits import readHeader
+    from auromat_amd.mapping.spacecraft import getSpacecraftPosition
+    hdr = readHeader(RES + 'ISS029-E-8492.wcs')
+    img = np.asarray(Image.open(RES + 'ISS029-E-8492.jpg'))
+    cam, t = getSpacecraftPosition(hdr)
+    for fast, name in ((True, 'real_frame_iss029.npz'), (False, 'real_frame_iss029_exact.npz')):
+        m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'ISS029-E-8492', fastCenterCalculation=fast)
+        mm = m.maskedByElevation(10)
+        merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+        case = _run_resample(mm.lats, mm.lons, mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan), 110, merged, (10, 10))
+        print(name, case['bbox'], bool(case['contains_discontinuity']), case['out_data'].shape, flush=True)
+        _finish_real(case, name, mm, t, cam)
+    m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 'ISS029-E-8492', fastCenterCalculation=True)
+    mm = m.maskedByElevation(10)
+    merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+    mlat, mlt = mm.mLatMlt
+    mlat_c, mlt_c = mm.mLatMltCenter
+    mask = ma.getmaskarray(mm.lats)
+    cmask = ma.getmaskarray(mm.latsCenter)
+    sm_lats, sm_lons = ma.masked_array(mlat.data, mask), ma.masked_array(T.mltToSmLon(mlt.data), mask)
+    case = _run_resample(sm_lats, sm_lons, np.where(cmask, np.nan, mlat_c.data), np.where(cmask, np.nan, T.mltToSmLon(mlt_c.data)),
+                         110, merged, (10, 10))
+    print('sm', case['bbox'], bool(case['contains_discontinuity']), case['out_data'].shape, flush=True)
+    _finish_real(case, 'real_frame_iss029_sm.npz', mm, t, cam)
+
+
+def real_sequences_more():
+    """real_sequence_seq2.npz / real_sequence_seq3.npz: the reference's other two header sequences, test/resources/seq2/
+    ISS030-E-229356 ... 229359.wcs and seq3/ISS030-E-102170 ... 102172.wcs (4256 x 2832), each frame with the synthetic
+    image frame_image(4256, 2832, seed=k): fast centres -> maskedByElevation(10) -> _resample(pxPerDeg=10, 'mean'), as
+    real_sequence() does for seq/.  Copies of the headers: tests/golden/resources/seq2/, seq3/."""
+    import glob
+    from auromat_amd.fits import readHeader
+    from auromat_amd.mapping.spacecraft import getSpacecraftPosition
+    for seq in ('seq2', 'seq3'):
+        out = {}
+        names = []
+        for k, path in enumerate(sorted(glob.glob(RES + seq + '/*.wcs'))):
+            hdr = readHeader(path)
+            cam, t = getSpacecraftPosition(hdr)
+            img = frame_image(4256, 2832, seed=k)
+            m = ArraySpacecraftMapping(hdr, 110, img, cam, t, 's', fastCenterCalculation=True)
+            mm = m.maskedByElevation(10)
+            merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+            case = _run_resample(mm.lats, mm.lons, mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan), 110, merged, (10, 10))
+            out['bbox_%d' % k] = case['bbox']
+            out['disc_%d' % k] = case['contains_discontinuity']
+            out['out_data_%d' % k] = case['out_data']
+            out['out_lat_%d' % k] = case['out_lat']
+            out['out_lon_%d' % k] = case['out_lon']
+            names.append(os.path.basename(path))
+            print(seq, k, names[-1], case['bbox'], case['out_data'].shape, flush=True)
+        out['names'] = np.array(names)
+        save('real_sequence_%s.npz' % seq, **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['host_scalars', 'georef_small', 'masks_small', 'resample_cases',

@@ -194,3 +194,78 @@ def test_gather_from_a_buffer_packed_while_the_frames_were_computed(tmp_path):
     world = 2
     mp.spawn(_packer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(str(tmp_path / ('packer_ok_%d' % r))) for r in range(world))
+
+
+# ---- BASELINE configs[4] as far as it goes without eight GPUs: 256 frames over 8 ranks ------------------------------------------
+
+def _config5_result(k):
+    """What rank r's pipeline would hand over for frame k of the synthetic sequence: the frame's REAL
+    0.1 deg grid — its bounding box from the oracle on the frame's own header at 1/40 of the resolution (the box of the
+    masked footprint does not depend on the sampling beyond a pixel) — filled with seeded numbers."""
+    from oracle import ref_numpy as O
+    from auromat_amd.coordinates import transform as T
+    from auromat_amd.resample import _Grid
+    from auromat_amd.synthetic import sequence_frame
+    hdr, cam, t, _ = sequence_frame(k, 106, 71)
+    g = O.georef_frame(hdr, 110.0, cam, O.mat_j2000_to_geo(T.date2es(t)), None, fast=True)
+    corner_mask, _ = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), 10)
+    (lat_s, lon_w, lat_n, lon_e), disc = O.bbox_of_corners(g['lat'], g['lon'], corner_mask)
+    assert not disc
+    grid = _Grid((10, 10), lat_s, lat_n, lon_w, lon_e)
+    rs = np.random.RandomState(k)
+    mean = rs.uniform(0, 65535, (grid.ny, grid.nx, 4))
+    mean[rs.rand(grid.ny, grid.nx) < 0.1] = np.nan
+    count = rs.randint(0, 400, (grid.ny, grid.nx)).astype(np.float64)
+    return dict(mean=torch.from_numpy(mean), count=torch.from_numpy(count), grid=grid, contains_pole=False,
+                contains_discontinuity=False, altitude=110.0, magnetic=False)
+
+
+def _config5_worker(rank, world, port, n_frames, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from auromat_amd.sequence import DESC_LEN, agree_capacity, gather_device, shard
+    mine = shard(n_frames, rank, world)
+    # config 5: 32 CONSECUTIVE frames per rank (a rank's box hints come from its own neighbouring frames)
+    assert mine == list(range(32 * rank, 32 * rank + 32))
+    results = [_config5_result(k) for k in mine]
+    # the warm-up's agreement: every rank ends up with the same (frames, payload) capacity, large enough for the longest
+    cap = agree_capacity(results, mine, torch.device('cpu'))
+    own = sum(r['mean'].numel() + r['count'].numel() for r in results)
+    caps = [None] * world
+    dist.all_gather_object(caps, (cap, own))
+    assert all(c[0] == cap for c in caps) and cap[0] == 32 and cap[1] >= max(c[1] for c in caps)
+    assert cap[1] <= 1.25 * max(c[1] for c in caps) + 2
+    # the timed gather: ONE collective of fixed size
+    g = gather_device(results, mine, torch.device('cpu'), capacity=cap)
+    if rank == 0:
+        got = g.unpack()
+        assert g.n_frames == n_frames and g.failed == []
+        assert [f['index'] for f in got] == list(range(n_frames))
+        shapes = set()
+        for f in got[::17] + got[-1:]:
+            ref = _config5_result(f['index'])
+            np.testing.assert_array_equal(f['mean'], ref['mean'].numpy())
+            np.testing.assert_array_equal(f['count'], ref['count'].numpy())
+            assert (f['lat0'], f['lon0'], f['dlat'], f['dlon']) == (ref['grid'].lat0, ref['grid'].lon0, ref['grid'].latStep, ref['grid'].lonStep)
+            shapes.add(f['mean'].shape)
+        assert len(shapes) > 1                                   # the footprint moves: the grids differ frame by frame
+        per_rank_bytes = (cap[0] * DESC_LEN + cap[1] + 2) * 8
+        with open(os.path.join(out_dir, 'ok'), 'w') as fp:
+            fp.write('%d' % (per_rank_bytes * world))
+    else:
+        assert g is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config5_sharding_and_gather_world8(tmp_path):
+    """256 frames of the synthetic sequence over 8 ranks (gloo; one process per rank as on the 8-GPU node): contiguous blocks
+    of 32, the capacity agreement of the warm-up, ONE fixed-size gather of all 256 grids on rank 0 (about 2 MB per rank
+    and 17 MB in all at 0.1 deg)."""
+    world = 8
+    mp.spawn(_config5_worker, args=(world, _free_port(), 256, str(tmp_path)), nprocs=world, join=True)
+    total = int((tmp_path / 'ok').read_text())
+    assert 8e6 < total < 1e8, total

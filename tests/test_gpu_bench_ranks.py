@@ -51,3 +51,27 @@ def test_bench_with_several_ranks_on_one_gpu(world, steps):
     # disjoint blocks of the synthetic sequence
     firsts = sorted(r['first_frame'] for r in per)
     assert all(b - a >= steps for a, b in zip(firsts, firsts[1:]))
+
+
+def test_n_rank_line_carries_the_upload_variant():
+    """Without --no-variants the N-rank line also holds `variants.upload`: the same job with every rank streaming its frames'
+    images from its own page-locked host buffers (what a real 256-frame run does), with the PCIe rate each rank reached."""
+    world, steps = 2, 6
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(AMT_BENCH_BACKEND='gloo', AMT_BENCH_ONE_GPU='1')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', str(steps), '--warmup', '2',
+                          '--cpu-rows', '0'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == world and out['config']['frames_total'] == world * steps
+    up = out['variants']['upload']
+    assert up['frames_per_rank'] == steps and up['single_pass_frames'] == steps
+    assert len(up['pcie_GBs_per_rank']) == world and all(0.5 < v < 70 for v in up['pcie_GBs_per_rank'])
+    assert abs(up['pcie_GBs_total'] - sum(up['pcie_GBs_per_rank'])) < 1e-9
+    npx = 4240 * 2832
+    assert abs(up['Mpixels_per_s'] - world * steps * npx / 1e6 / (up['ms_per_frame'] * steps * 1e-3)) < 1e-6 * up['Mpixels_per_s']
+    # PCIe-inclusive: slower than the HBM-resident figure of the same line
+    assert up['Mpixels_per_s'] < out['value']
