@@ -71,37 +71,32 @@ class BoundingBox(object):
     @property
     def _minSphericalRectangle(self):
         """
-        (center, Size(width, height) in km) of the minimum spherical rectangle that fits the box (reference
-        mapping.py:118-170; sizes are only meaningful for boxes spanning less than 180 degrees of longitude).
+        (center, Size(width, height) in km) of the smallest "rectangle" of great-circle sides around the box — the
+        parameters of a stereographic view of it (same values as the reference's property, mapping.py:118-170; sizes are
+        meaningful for boxes narrower than 180 degrees of longitude).
+
+        The geometry: of the two parallels that bound the box, the one nearer the equator is the longer and bulges OUT of
+        the great circle through its end points, the one nearer the pole is shorter and its great circle bulges out beyond
+        it.  So the rectangle is as wide as the equatorward edge's geodesic, and it reaches from that parallel at the box's
+        central meridian to the midpoint of the poleward edge's geodesic.  A cap around a pole is a square of twice the
+        geodesic from the pole to its bounding parallel.
         """
         from ..coordinates import geodesic
         if self.containsPole:
-            if self.latNorth == 90:                      # north pole
-                center = Location(90, 0)
-                width = geodesic.distance(center, Location(self.latSouth, 0)) * 2
-            else:                                        # south pole
-                center = Location(-90, 0)
-                width = geodesic.distance(center, Location(self.latNorth, 0)) * 2
-            height = width
-        else:
-            lonWest, lonEast = self.lonWest, self.lonEast
-            if lonWest > lonEast:
-                lonEast += 360
-            lonc = wrap_at_180((lonWest + lonEast) / 2)
-            width = geodesic.distance(self.bottomLeft, self.bottomRight)
-            width2 = geodesic.distance(self.topLeft, self.topRight)
-            if width2 > width:                           # southern hemisphere
-                width = width2
-                bottomCenter = geodesic.intermediate(self.bottomLeft, self.bottomRight, 0.5)
-                topDataCenter = Location(self.latNorth, lonc)
-                height = geodesic.distance(topDataCenter, bottomCenter)
-                center = geodesic.intermediate(topDataCenter, bottomCenter, 0.5)
-            else:                                        # northern hemisphere
-                topCenter = geodesic.intermediate(self.topLeft, self.topRight, 0.5)
-                bottomDataCenter = Location(self.latSouth, lonc)
-                height = geodesic.distance(bottomDataCenter, topCenter)
-                center = geodesic.intermediate(bottomDataCenter, topCenter, 0.5)
-        return center, Size(width / 1000, height / 1000)
+            pole_lat, rim_lat = (90, self.latSouth) if self.latNorth == 90 else (-90, self.latNorth)
+            side = 2 * geodesic.distance(Location(pole_lat, 0), Location(rim_lat, 0))
+            return Location(pole_lat, 0), Size(side / 1000, side / 1000)
+        east = self.lonEast + (360 if self.lonWest > self.lonEast else 0)
+        mid_lon = wrap_at_180((self.lonWest + east) / 2)
+        span = {lat: geodesic.distance(Location(lat, self.lonWest), Location(lat, self.lonEast))
+                for lat in (self.latSouth, self.latNorth)}
+        # (equal spans — a box symmetric about the equator, or a point — count as "north of the equator")
+        equatorward = self.latNorth if span[self.latNorth] > span[self.latSouth] else self.latSouth
+        poleward = self.latSouth if equatorward == self.latNorth and self.latNorth != self.latSouth else self.latNorth
+        on_parallel = Location(equatorward, mid_lon)
+        on_geodesic = geodesic.intermediate(Location(poleward, self.lonWest), Location(poleward, self.lonEast), 0.5)
+        height = geodesic.distance(on_parallel, on_geodesic)
+        return geodesic.intermediate(on_parallel, on_geodesic, 0.5), Size(span[equatorward] / 1000, height / 1000)
 
     @property
     def center(self):
@@ -125,28 +120,39 @@ class BoundingBox(object):
 
     @staticmethod
     def minimumBoundingBox(latLons):
-        return BoundingBox.mergedBoundingBoxes([BoundingBox(lat, lon, lat, lon) for [lat, lon] in latLons])
+        """The smallest box around (lat, lon) pairs."""
+        return BoundingBox.mergedBoundingBoxes(BoundingBox(lat, lon, lat, lon) for lat, lon in latLons)
 
     @staticmethod
     def mergedBoundingBoxes(boundingBoxes):
-        boundingBoxes = list(boundingBoxes)
-        lats = [bb.latSouth for bb in boundingBoxes] + [bb.latNorth for bb in boundingBoxes]
-        lonWest, lonEast = BoundingBox._minimumBoundingBoxLons([(bb.lonWest, bb.lonEast) for bb in boundingBoxes])
-        return BoundingBox(np.min(lats), lonWest, np.max(lats), lonEast)
+        """The smallest box around the given boxes: the latitude extremes, and in longitude the complement of the widest
+        arc of the circle that no box touches."""
+        boxes = list(boundingBoxes)
+        south = min(b.latSouth for b in boxes)
+        north = max(b.latNorth for b in boxes)
+        west, east = BoundingBox._minimumBoundingBoxLons([(b.lonWest, b.lonEast) for b in boxes])
+        return BoundingBox(south, west, north, east)
 
     @staticmethod
     def _minimumBoundingBoxLons(lons):
-        # biggest uncovered gap on the circle (reference mapping.py:250-277)
-        lons = np.asarray(lons, dtype=np.float64)
-        xs = np.sort(lons.ravel())
-        xs = np.concatenate((xs, [xs[0] + 360]))
-        unwrapped = np.rad2deg(np.unwrap(np.deg2rad(lons)))
-        covered = np.zeros(len(xs) - 1, dtype=bool)
-        for i in range(1, len(xs)):
-            covered[i - 1] = any(bb[0] <= xs[i - 1] and bb[1] >= xs[i] for bb in unwrapped)
-        gaps = ma.masked_array(xs[1:] - xs[:-1], covered)
-        k = int(np.argmax(gaps))
-        return wrap_at_180(xs[k + 1]), wrap_at_180(xs[k])
+        """
+        (lonWest, lonEast) of the shortest arc that holds every [west, east] arc of `lons` (degrees).  The end points cut
+        the circle into pieces; a piece inside one of the arcs is occupied, and the answer starts where the longest free
+        piece ends and ends where it starts (the first such piece in ascending order of longitude when several tie, as
+        the reference's argmax does, mapping.py:250-277).  An arc runs eastwards from its west end over less than half the
+        circle (the reference unwraps each pair that way).
+        """
+        arcs = np.asarray(lons, dtype=np.float64).reshape(-1, 2)
+        # eastwards of `west`, the nearer way round.  Both ends go through radians and back, as the reference's do: the round
+        # trip can move an end by an ulp, and whether an arc then still "holds" the piece that starts at its own west end
+        # decides ties the reference's way
+        west, east = np.rad2deg(np.unwrap(np.deg2rad(arcs), axis=1)).T
+        cuts = np.sort(arcs.ravel())
+        ends = np.concatenate((cuts[1:], [cuts[0] + 360.0]))                    # piece k = [cuts[k], ends[k]]
+        occupied = ((west[:, None] <= cuts[None, :]) & (east[:, None] >= ends[None, :])).any(axis=0)
+        free = np.where(occupied, -np.inf, ends - cuts)
+        k = int(np.argmax(free))
+        return wrap_at_180(ends[k]), wrap_at_180(cuts[k])
 
     def __eq__(self, obj):
         return isinstance(obj, BoundingBox) and \

@@ -631,7 +631,9 @@ class FramePipeline(object):
             pxPerDeg, red = self.resolution_from_box(params, min_elevation, arcsecPerPx, magnetic)
             # (a pole in view: the reference's plateCarreeResolution gives no longitude resolution for a box that goes all
             # around, resample.py:47-61 — nothing to bin into, there as here)
-            assert pxPerDeg[1] > 0, 'arcsecPerPx with a pole in view: plateCarreeResolution yields lonPxPerDeg = 0 (as the reference)'
+            if not pxPerDeg[1] > 0:
+                # (the reference fails on its `assert nLon > 1`, resample.py:226-227; raised explicitly: python -O strips asserts)
+                raise AssertionError('arcsecPerPx with a pole in view: plateCarreeResolution yields lonPxPerDeg = 0 (as the reference)')
             if fuse and not red[7]:
                 self.start_coarse(params, min_elevation, magnetic, hint=red)
                 coarse_started = True

@@ -53,6 +53,17 @@ def algorithmic_bytes(width, height, nchan=3, pix_bytes=2):
                 mag_shell=40 * nc + 54 * npx)
 
 
+def kernel_sources_sha16():
+    """Identifies the kernel sources a PMC pass was made on (profiles/traffic.json records it per entry): traffic counted on
+    another version of the kernels is not reported as this run's."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ('amt_georef.hip', 'amt_common.h', 'amt_binning.hip'):
+        with open(os.path.join(ROOT, 'auromat_amd', 'csrc', name), 'rb') as fp:
+            h.update(fp.read())
+    return h.hexdigest()[:16]
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -714,6 +725,8 @@ def main(argv=None):
         achieved = kbytes / (georef_ms * 1e-3) / 1e9
         fpl = seq.batch if fused else 1
         tr = traffic.get(tkey, {})
+        sha = kernel_sources_sha16()
+        tr_fresh = bool(tr) and tr.get('sources_sha16') == sha
         out = {
             'metric': 'Mpixels/s georef+resample, 4240x2832 frame',
             'value': world * args.steps * npx / 1e6 / elapsed,
@@ -758,20 +771,25 @@ def main(argv=None):
                          # one launch covers `frames_per_launch` frames: bytes, traffic and duration are per launch
                          'frames_per_launch': fpl,
                          # NOT measured in this run: PMC counters of an earlier rocprofv3 pass of the same kernel
-                         'traffic': (tr.get('hbm_bytes') or 0) * fpl or None,
-                         'traffic_source': 'profiles/traffic.json (%s), per frame x frames_per_launch'
-                                           % tr.get('source', 'rocprofv3 --pmc pass, see its _comment'),
+                         # (null when that pass was made on other kernel sources than the ones this run was built from)
+                         'traffic': ((tr.get('hbm_bytes') or 0) * fpl or None) if tr_fresh else None,
+                         'traffic_source': ('profiles/traffic.json (%s), per frame x frames_per_launch'
+                                            % tr.get('source', 'rocprofv3 --pmc pass, see its _comment')) if tr_fresh else
+                                           ('none: the PMC pass recorded in profiles/traffic.json[%s] was made on kernel sources %s, '
+                                            'this run on %s' % (tkey, tr.get('sources_sha16', '(unrecorded)'), sha)),
+                         'kernel_sources_sha16': sha,
                          'algorithmic_bytes': kbytes * fpl, 'ms_per_launch': georef_ms * fpl,
                          # the bytes this kernel has to move at the very least, and the same fraction on that basis
                          'bytes_moved_min': moved * fpl, 'frac_bytes_moved_min': frac(moved, georef_ms),
-                         'frames_timed': args.steps, 'valu_busy': tr.get('valu_busy'),
+                         'frames_timed': args.steps, 'valu_busy': tr.get('valu_busy') if tr_fresh else None,
                          'valu_busy_source': 'profiles/traffic.json'},
             'kernels': {
                 'k_georef_rows': {'ms': georef_ms, 'algorithmic_bytes': kbytes, 'frac_hbm_peak': frac(kbytes, georef_ms),
                                   'bytes_moved_min': moved},
                 'k_bin_frame': ({'ms': bin_ms, 'algorithmic_bytes': ab['resample'],
                                  'frac_hbm_peak': frac(ab['resample'], bin_ms),
-                                 'traffic': traffic.get('k_bin_frame', {}).get('hbm_bytes')} if bin_ms else
+                                 'traffic': traffic.get('k_bin_frame', {}).get('hbm_bytes')
+                                 if traffic.get('k_bin_frame', {}).get('sources_sha16') == sha else None} if bin_ms else
                                 'not launched: binning is fused into k_georef_rows (plan=fused)'),
                 # SURVEY.md 8d contract figures for the whole pipeline against the time of the kernel(s) that do it
                 'pipeline_frac_wcs_fused_840.6MB': frac(ab['georef'] + ab['resample'], georef_ms + bin_ms),

@@ -612,8 +612,11 @@ int amt_pipe_launch_box_many(amt_pipe* const* pipes, int32_t n, const amt_frame_
                              int magnetic);
 /* auromat/resample.py:36-61 plateCarreeResolution(BoundingBox(latSouth, lonWest, latNorth, lonEast), arcsecPerPx) ->
  * (latPxPerDeg, lonPxPerDeg); geodesic.angularDistance (geographiclib's a12 in the reference) restated from Karney's
- * integral formulation for two points on one parallel.  Host arithmetic, no GPU.  AMT_EINVAL when the box is 180 deg
- * wide or more or the resolution is not positive. */
+ * integral formulation for two points on one parallel.  Host arithmetic, no GPU.  A box wider than 180 deg is measured the
+ * shorter way round, as the reference does (min(lons, 360 - lons)); for a box that goes all the way around (a pole in view)
+ * that gives AMT_OK with *lon_px_per_deg = 0, which no grid can be laid out for — the caller checks (the reference fails
+ * downstream on `assert nLon > 1`, resample.py:226-227).  AMT_EINVAL when the resolution is not positive or the box has no
+ * width. */
 int amt_plate_carree_resolution(double lat_south, double lon_west, double lat_north, double lon_east, double arcsec_per_px,
                                 double* lat_px_per_deg, double* lon_px_per_deg);
 int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result);
