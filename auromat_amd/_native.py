@@ -157,6 +157,14 @@ _SIGNATURES = {
     'amt_georef_frame': ([_P, C.POINTER(FrameParams), C.POINTER(GeorefOut)], _I),
     'amt_georef_frame_dirs': ([_P, C.POINTER(FrameParams), _P, C.POINTER(GeorefOut)], _I),
     'amt_georef_coarse_bbox': ([_P, C.POINTER(FrameParams), C.c_int32, _D, _I, _P], _I),
+    'amt_delaunay_create': ([_P, C.c_int64, C.POINTER(C.c_void_p)], _I),
+    'amt_delaunay_destroy': ([_P], _I),
+    'amt_delaunay_sizes': ([_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], _I),
+    'amt_delaunay_triangles': ([_P, _P, _P], _I),
+    'amt_delaunay_vertex_neighbours': ([_P, _P, _P], _I),
+    'amt_delaunay_locate': ([_P, _P, C.c_int64, _P, _P, _P], _I),
+    'amt_cubic_gradients_csr': ([_P, _P, C.c_int64, _P, _P, _P, C.c_int32, _P, C.c_int32, _D, C.c_int32, _P, _P], _I),
+    'amt_cubic_eval': ([_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P], _I),
     'amt_georef_coarse_bbox_dirs': ([_P, C.POINTER(FrameParams), _P, C.c_int32, _D, _I, _P], _I),
     'amt_pipe_coarse_dirs': ([_P, C.POINTER(FrameParams), _P, _D, _I], _I),
     'amt_pipe_launch_dirs': ([_P, C.POINTER(FrameParams), _P, C.POINTER(GeorefOut), _P, C.c_int32, _D, _D, _D, _I, _I], _I),

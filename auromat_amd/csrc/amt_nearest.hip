@@ -757,6 +757,125 @@ __global__ __launch_bounds__(kBlock) void k_cubic_gather(lin_args A, const long 
     }
 }
 
+// ---- method='cubic' on the EXACT triangulation (round 5) ---------------------------------------------------------------------
+// scipy's estimator is a Gauss-Seidel relaxation: point after point in the order of the input points, every point's 2 x 2
+// system built from its neighbours' gradients AS THEY ARE AT THAT MOMENT — already updated in this sweep for neighbours with a
+// smaller index, still the previous sweep's for the others —, repeated until the largest relative change of a sweep is below
+// the tolerance.  The result depends on that order (the sweeps stop at 1e-6, far from the fixed point), so it is reproduced:
+//   * neighbours from the Delaunay triangulation itself (amt_delaunay_vertex_neighbours: Qhull's hull-closing triangles and
+//     its filling of holes included — their long edges pull on the border pixels' gradients, and the pull decays by a factor
+//     of about three per ring of pixels, which is what kept the lattice-only estimate of rounds 3-4 from agreeing);
+//   * one WAVE per pixel row walks its row's points in order; lanes are channels (each channel is its own relaxation with its
+//     own stopping sweep, as scipy runs them one after the other).  A neighbour with a smaller index in ANOTHER row has been
+//     written by another wave: the walker waits for that point's stamp (= this sweep's number, stored with release order
+//     after the point's gradients) and reads the new array; neighbours with a larger index are read from the previous
+//     sweep's array — two arrays, so nobody can overtake.  Rows are handed out by a ticket in increasing order: a wave only
+//     ever waits for rows that were taken before its own, whose waves are running or done, so the lowest unfinished row
+//     always advances.
+struct gs_args {
+    const double* xy;                // (n, 2) points: lat, lon as the reference hands them to griddata
+    const long long* indptr;         // (n + 1)
+    const int* indices;
+    const long long* row_start;      // (n_rows + 1): first point of every pixel row (points are in row-major pixel order)
+    int n_rows, nchan;
+    const double* values;            // (n, nchan)
+    const double* y_old;             // (n, nchan, 2)
+    double* y_new;
+    unsigned int* stamp;             // (n): number of the sweep that last wrote the point
+    unsigned int sweep;
+    unsigned int* ticket;
+    unsigned long long* err;         // (nchan): largest relative change of the sweep (bits of a non-negative double)
+    const unsigned char* active;     // (nchan): 0 = this channel has converged: its gradients are carried over
+};
+
+__global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
+    const int lane = threadIdx.x;
+    int row = 0;
+    if (lane == 0) row = (int)atomicAdd(A.ticket, 1u);
+    row = __builtin_amdgcn_readfirstlane(row);
+    if (row >= A.n_rows) return;
+    const long long v0 = A.row_start[row], v1 = A.row_start[row + 1];
+    const bool chan = lane < A.nchan;
+    const bool live = chan && A.active[lane] != 0;
+    double worst = 0;
+    for (long long v = v0; v < v1; ++v) {
+        const long long b = A.indptr[v], e = A.indptr[v + 1];
+        // neighbours of earlier rows must have been written in this sweep (those of this row were: by this wave)
+        for (long long k = b; k < e; ++k) {
+            const long long j = A.indices[k];
+            if (j < v0)
+                while (__hip_atomic_load(&A.stamp[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != A.sweep)
+                    __builtin_amdgcn_s_sleep(2);
+        }
+        if (chan) {
+            const long long o = (v * A.nchan + lane) * 2;
+            double g0 = A.y_old[o], g1 = A.y_old[o + 1];
+            if (live) {
+                const double xi = A.xy[2 * v], yi = A.xy[2 * v + 1], fi = A.values[v * A.nchan + lane];
+                double q0 = 0, q1 = 0, q3 = 0, s0 = 0, s1 = 0;
+                for (long long k = b; k < e; ++k) {
+                    const long long j = A.indices[k];
+                    const double ex = A.xy[2 * j] - xi, ey = A.xy[2 * j + 1] - yi;
+                    const double l = sqrt(ex * ex + ey * ey), l3 = l * l * l;
+                    const double* yj = (j < v ? A.y_new : A.y_old) + (j * A.nchan + lane) * 2;
+                    const double df2 = -ex * yj[0] - ey * yj[1];
+                    q0 += 4 * ex * ex / l3;
+                    q1 += 4 * ex * ey / l3;
+                    q3 += 4 * ey * ey / l3;
+                    const double t = (6 * (fi - A.values[j * A.nchan + lane]) - 2 * df2) / l3;
+                    s0 += t * ex;
+                    s1 += t * ey;
+                }
+                const double det = q0 * q3 - q1 * q1;
+                const double r0 = (q3 * s0 - q1 * s1) / det, r1 = (-q1 * s0 + q0 * s1) / det;
+                double change = fmax(fabs(g0 + r0), fabs(g1 + r1));
+                change /= fmax(1.0, fmax(fabs(r0), fabs(r1)));
+                if (change == change) worst = fmax(worst, change);
+                g0 = -r0, g1 = -r1;
+            }
+            A.y_new[o] = g0, A.y_new[o + 1] = g1;
+        }
+        // every lane's stores before the stamp (one wave: program order per lane, the release makes them visible)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(&A.stamp[v], A.sweep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (live && worst > 0) atomicMax(&A.err[lane], (unsigned long long)__double_as_longlong(worst));
+}
+
+// The element in the triangle amt_delaunay_locate found for every target (vertices -1: outside the hull -> NaN)
+__global__ __launch_bounds__(kBlock) void k_cubic_eval(int64_t m, const double* __restrict__ targets, const int* __restrict__ vertices,
+                                                        const double* __restrict__ centroids, const unsigned char* __restrict__ has_nb,
+                                                        const double* __restrict__ xy, const double* __restrict__ values,
+                                                        const double* __restrict__ grad, int nchan, double* __restrict__ out) {
+    AMT_GRID_STRIDE(t, m) {
+        const int* w = vertices + 3 * t;
+        if (w[0] < 0) {
+            for (int c = 0; c < nchan; ++c) out[t * nchan + c] = NAN;
+            continue;
+        }
+        double x[3], y[3], cx[3], cy[3], b[3];
+        bool n[3];
+        for (int k = 0; k < 3; ++k) {
+            x[k] = xy[2 * (int64_t)w[k]], y[k] = xy[2 * (int64_t)w[k] + 1];
+            n[k] = has_nb[3 * t + k] != 0;
+            cx[k] = centroids[6 * t + 2 * k], cy[k] = centroids[6 * t + 2 * k + 1];
+        }
+        const double px = targets[2 * t], py = targets[2 * t + 1];
+        const double det = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+        b[1] = ((px - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (py - y[0])) / det;
+        b[2] = ((x[1] - x[0]) * (py - y[0]) - (px - x[0]) * (y[1] - y[0])) / det;
+        b[0] = 1.0 - b[1] - b[2];
+        for (int c = 0; c < nchan; ++c) {
+            double f[3], d[3][2];
+            for (int k = 0; k < 3; ++k) {
+                f[k] = values[(int64_t)w[k] * nchan + c];
+                d[k][0] = grad[((int64_t)w[k] * nchan + c) * 2], d[k][1] = grad[((int64_t)w[k] * nchan + c) * 2 + 1];
+            }
+            out[t * nchan + c] = clough_tocher(x, y, b, f, d, n, cx, cy);
+        }
+    }
+}
+
 // matplotlib.path.Path(polygon).contains_points(points) (reference utils.py:58-74): crossing test of a ray towards
 // +x with the half-open edge rule (vertex y >= point y) of Agg's point_in_path; the path is closed implicitly.
 // Edges are staged through LDS in chunks; an edge whose y-range misses the y-range of the block's points cannot
@@ -1031,6 +1150,81 @@ int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx,
                            target_lon, static_cast<const uint8_t*>(img), gradients, mean, static_cast<uint8_t*>(out_img),
                            out_mask, alt_mean, tri);
     }
+    AMT_LAUNCH_CHECK(ctx);
+    return AMT_OK;
+}
+
+int amt_cubic_gradients_csr(amt_ctx* ctx, const double* xy, int64_t n, const int64_t* indptr, const int32_t* indices,
+                            const int64_t* row_start, int32_t n_rows, const double* values, int32_t nchan, double tolerance,
+                            int32_t max_iterations, double* gradients, int32_t* iterations) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, xy && indptr && indices && row_start && values && gradients && iterations, "NULL argument");
+    AMT_REQUIRE(ctx, n >= 3 && n < 2147483647LL && n_rows >= 1, "bad size");
+    AMT_REQUIRE(ctx, nchan >= 1 && nchan <= 64, "1..64 channels");
+    AMT_REQUIRE(ctx, tolerance > 0 && max_iterations >= 1, "tolerance and max_iterations must be positive");
+    const size_t grad_bytes = (size_t)n * nchan * 2 * sizeof(double);
+    const size_t stamp_bytes = ((size_t)n * sizeof(unsigned int) + 63) & ~(size_t)63;
+    char* ws = static_cast<char*>(amt_workspace(ctx, grad_bytes + stamp_bytes + 1024));
+    if (ws == nullptr) {
+        ctx->last_error = "amt_cubic_gradients_csr: workspace allocation failed";
+        return AMT_ENOMEM;
+    }
+    double* other = reinterpret_cast<double*>(ws);
+    unsigned int* stamp = reinterpret_cast<unsigned int*>(ws + grad_bytes);
+    unsigned long long* err = reinterpret_cast<unsigned long long*>(ws + grad_bytes + stamp_bytes);      // [64]
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(ws + grad_bytes + stamp_bytes + 512);
+    unsigned char* active = reinterpret_cast<unsigned char*>(ws + grad_bytes + stamp_bytes + 576);      // [64]
+    AMT_HIP(ctx, hipMemsetAsync(gradients, 0, grad_bytes, ctx->stream));
+    AMT_HIP(ctx, hipMemsetAsync(other, 0, grad_bytes, ctx->stream));
+    AMT_HIP(ctx, hipMemsetAsync(stamp, 0, stamp_bytes, ctx->stream));
+    unsigned char host_active[64];
+    for (int c = 0; c < 64; ++c) host_active[c] = c < nchan ? 1 : 0;
+    for (int c = 0; c < nchan; ++c) iterations[c] = 0;
+    AMT_HIP(ctx, hipMemcpyAsync(active, host_active, 64, hipMemcpyHostToDevice, ctx->stream));
+    gs_args A;
+    A.xy = xy, A.indptr = reinterpret_cast<const long long*>(indptr), A.indices = indices;
+    A.row_start = reinterpret_cast<const long long*>(row_start), A.n_rows = n_rows, A.nchan = nchan;
+    A.values = values, A.stamp = stamp, A.ticket = ticket, A.err = err, A.active = active;
+    double* bufs[2] = {gradients, other};
+    int cur = 0;                                   // bufs[cur] holds the latest sweep
+    for (int it = 1; it <= max_iterations; ++it) {
+        AMT_HIP(ctx, hipMemsetAsync(err, 0, 512 + 64, ctx->stream));              // err[64] and the ticket
+        A.y_old = bufs[cur], A.y_new = bufs[1 - cur], A.sweep = (unsigned int)it;
+        hipLaunchKernelGGL(k_cubic_gs, dim3((unsigned)n_rows), dim3(64), 0, ctx->stream, A);
+        AMT_LAUNCH_CHECK(ctx);
+        unsigned long long bits[64];
+        AMT_HIP(ctx, hipMemcpyAsync(bits, err, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
+        AMT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bool any = false, changed = false;
+        for (int c = 0; c < nchan; ++c) {
+            if (!host_active[c]) continue;
+            iterations[c] = it;
+            double worst;
+            std::memcpy(&worst, &bits[c], sizeof(worst));
+            if (worst < tolerance) {
+                host_active[c] = 0;                  // scipy returns after the sweep whose largest change is below the tolerance
+                changed = true;
+            } else {
+                any = true;
+            }
+        }
+        cur = 1 - cur;
+        if (!any) break;
+        if (changed) AMT_HIP(ctx, hipMemcpyAsync(active, host_active, 64, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (cur != 0) AMT_HIP(ctx, hipMemcpyAsync(gradients, other, grad_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return AMT_OK;
+}
+
+int amt_cubic_eval(amt_ctx* ctx, int64_t m, const double* targets, const int32_t* vertices, const double* centroids,
+                   const uint8_t* has_neighbour, const double* xy, const double* values, const double* gradients, int32_t nchan,
+                   double* out) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, m >= 0 && nchan >= 1, "bad size");
+    if (m == 0) return AMT_OK;
+    AMT_REQUIRE(ctx, targets && vertices && centroids && has_neighbour && xy && values && gradients && out, "NULL argument");
+    hipLaunchKernelGGL(k_cubic_eval, grid_for(m), dim3(kBlock), 0, ctx->stream, m, targets, vertices, centroids, has_neighbour, xy,
+                       values, gradients, nchan, out);
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }

@@ -352,8 +352,12 @@ def _check_method(method):
         raise NotImplementedError("method='%s' is not implemented (use 'mean', 'nearest', 'linear' or 'cubic')" % method)
 
 
-CUBIC_TOLERANCE = 1e-8      # largest relative change of a gradient in the last Jacobi sweep (scipy relaxes to 1e-6)
-CUBIC_MAX_SWEEPS = 800      # scipy: at most 400 point-after-point relaxations; a Jacobi sweep gains about half as much
+CUBIC_TOLERANCE = 1e-6      # scipy.interpolate.CloughTocher2DInterpolator(tol=1e-6, maxiter=400): griddata's defaults
+CUBIC_MAX_SWEEPS = 400
+# (the Jacobi sweeps on the pixel lattice of rounds 3-4, amt_cubic_gradients: an approximation that leaves Qhull's hull-closing
+# triangles out; kept as an entry point of the library, no longer what method='cubic' runs)
+CUBIC_LATTICE_TOLERANCE = 1e-8
+CUBIC_LATTICE_MAX_SWEEPS = 800
 
 
 def cubic_gradients(ctx, lat_c, lon_c, elev, center_mask, height, width, min_elevation, lon_wrap, data, dtype_code, nchan):
@@ -364,8 +368,74 @@ def cubic_gradients(ctx, lat_c, lon_c, elev, center_mask, height, width, min_ele
     sweeps = C.c_int32(0)
     min_el = float('-inf') if min_elevation is None else float(min_elevation)
     ctx.call('amt_cubic_gradients', ptr(lat_c), ptr(lon_c), ptr(elev), ptr(center_mask), height, width, min_el, lon_wrap,
-             ptr(data) if nchan else None, dtype_code, nchan, CUBIC_TOLERANCE, CUBIC_MAX_SWEEPS, ptr(grad), C.byref(sweeps))
+             ptr(data) if nchan else None, dtype_code, nchan, CUBIC_LATTICE_TOLERANCE, CUBIC_LATTICE_MAX_SWEEPS, ptr(grad),
+             C.byref(sweeps))
     return grad, sweeps.value
+
+
+def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask):
+    """
+    ``scipy.interpolate.griddata((lat, lon), values, grid centres, method='cubic')`` as the reference calls it (resample.py:
+    315-326) on its own triangulation and in its own order: the Delaunay triangulation of the valid pixel centres
+    (``amt_delaunay_create``, host: equal to Qhull's wherever that is unique), scipy's Gauss-Seidel gradient estimator over its
+    edges in the order of the points (``amt_cubic_gradients_csr``: tolerance 1e-6, at most 400 sweeps, every channel with its
+    own stopping sweep), the Clough-Tocher element in the triangle of every grid centre (``amt_delaunay_locate`` +
+    ``amt_cubic_eval``).
+
+    :param lat, lon: flat float64 device tensors (height * width) in the coordinates the grid is laid out in
+    :param valid: flat bool device tensor: the pixel is a data point
+    :param values: (height * width, channels) float64 device tensor
+    :param target_mask: (ny, nx) uint8 device tensor, non-zero = the grid centre is not wanted (outside the outline), or None
+    :return: ((ny * nx, channels) float64 device tensor, NaN outside the convex hull and where masked; sweeps per channel)
+    """
+    import torch
+    from ._native import lib
+    L = lib()
+    idx = torch.nonzero(valid.reshape(-1)).reshape(-1)               # row-major pixel order = the reference's point order
+    n, nchan = int(idx.numel()), int(values.shape[1])
+    out = torch.full((grid.ny * grid.nx, nchan), float('nan'), dtype=torch.float64, device=ctx.device)
+    if n < 3:
+        raise ValueError('method=\'cubic\' needs at least three valid pixels')
+    xy = torch.stack((lat.reshape(-1)[idx], lon.reshape(-1)[idx]), dim=1).contiguous()
+    xy_host = np.ascontiguousarray(to_host(xy))
+    handle = C.c_void_p()
+    rc = L.amt_delaunay_create(xy_host.ctypes.data_as(C.c_void_p), n, C.byref(handle))
+    if rc != 0:
+        raise ValueError('method=\'cubic\': the valid pixel centres cannot be triangulated (all collinear?)')
+    try:
+        nt, nn, nd = C.c_int64(), C.c_int64(), C.c_int64()
+        L.amt_delaunay_sizes(handle, C.byref(nt), C.byref(nn), C.byref(nd))
+        indptr, indices = np.empty(n + 1, dtype=np.int64), np.empty(nn.value, dtype=np.int32)
+        L.amt_delaunay_vertex_neighbours(handle, indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p))
+        rows = torch.div(idx, int(width), rounding_mode='floor')
+        row_start = torch.zeros(int(height) + 1, dtype=torch.int64, device=ctx.device)
+        row_start[1:] = torch.cumsum(torch.bincount(rows, minlength=int(height)), 0)
+        vals = values[idx].contiguous()
+        grad = ctx.empty((n, nchan, 2))
+        sweeps = (C.c_int32 * nchan)()
+        d_indptr, d_indices = ctx.to_device(indptr, np.int64), ctx.to_device(indices, np.int32)
+        ctx.call('amt_cubic_gradients_csr', ptr(xy), n, ptr(d_indptr), ptr(d_indices), ptr(row_start), int(height), ptr(vals),
+                 nchan, CUBIC_TOLERANCE, CUBIC_MAX_SWEEPS, ptr(grad), sweeps)
+        # the grid centres that are wanted, in row-major order (the walk from one to the next is a step or two)
+        wanted = np.ones((grid.ny, grid.nx), dtype=bool) if target_mask is None else ~to_host(target_mask).astype(bool)
+        sel = np.flatnonzero(wanted.ravel())
+        m = int(sel.size)
+        if m:
+            iy, ix = np.divmod(sel, grid.nx)
+            targets = np.ascontiguousarray(np.column_stack((np.asarray(grid.latCenters)[iy], np.asarray(grid.lonCenters)[ix])))
+            vertices = np.empty((m, 3), dtype=np.int32)
+            centroids = np.empty((m, 3, 2), dtype=np.float64)
+            has_nb = np.empty((m, 3), dtype=np.uint8)
+            rc = L.amt_delaunay_locate(handle, targets.ctypes.data_as(C.c_void_p), m, vertices.ctypes.data_as(C.c_void_p),
+                                       centroids.ctypes.data_as(C.c_void_p), has_nb.ctypes.data_as(C.c_void_p))
+            assert rc == 0
+            part = ctx.empty((m, nchan))
+            d_t, d_v, d_c, d_h = (ctx.to_device(a, a.dtype) for a in (targets, vertices, centroids, has_nb))
+            ctx.call('amt_cubic_eval', m, ptr(d_t), ptr(d_v), ptr(d_c), ptr(d_h), ptr(xy), ptr(vals), ptr(grad), nchan, ptr(part))
+            out[ctx.to_device(sel.astype(np.int64), np.int64)] = part
+    finally:
+        L.amt_delaunay_destroy(handle)
+    return out, [int(v) for v in sweeps]
 
 
 def outside_outline_mask(ctx, grid, outline):
@@ -488,16 +558,35 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
                          fd.img_dtype_code or 1, nch, ptr(mean), ptr(img) if nch else None, ptr(mask), ptr(alt), ptr(tri))
                 extra = dict(alt=alt, triangles=tri)
             else:
-                # scipy's Clough-Tocher element on the same triangles (griddata(method='cubic')): vertex gradients by
-                # Jacobi sweeps of its global estimator, then the element in the triangle of every grid centre
+                # scipy's griddata(method='cubic') on its own triangulation, in its own order (cubic_exact): image channels
+                # and elevation as float64 channels of the valid pixels, then numpy's rounding and cast of the image
                 assert fd.elev is not None, "method='cubic' on a frame needs the elevation"
-                grad, sweeps = cubic_gradients(ctx, lat_c, lon_c, fd.elev, fd.center_mask, fd.height, fd.width, min_elevation,
-                                               lon_wrap, fd.img, fd.img_dtype_code or 1, nch)
-                ctx.call('amt_cubic_gather', ptr(index), grid.ny, grid.nx, ptr(lat_c), ptr(lon_c), ptr(fd.elev),
-                         ptr(fd.center_mask), fd.height, fd.width, min_el, lon_wrap, ptr(tlat), ptr(tlon), ptr(fd.img),
-                         fd.img_dtype_code or 1, nch, ptr(grad), ptr(mean), ptr(img) if nch else None, ptr(mask), ptr(alt),
-                         ptr(tri))
-                extra = dict(alt=alt, triangles=tri, sweeps=sweeps)
+                la, lo = lat_c.reshape(-1), lon_c.reshape(-1)
+                if lon_wrap:
+                    lo = wrap_at_180_t(lo + 180)
+                valid = ~(torch.isnan(la) | torch.isnan(lo)) & (fd.elev.reshape(-1) >= min_el)
+                if fd.center_mask is not None:
+                    valid &= fd.center_mask.reshape(-1) == 0
+                chans = [fd.elev.reshape(-1, 1)]
+                if nch:
+                    pix = fd.img.reshape(-1, nch)
+                    if fd.img_dtype_code == 2:
+                        pix = pix.to(torch.int32) & 0xffff            # uint16 bits kept as int16
+                    chans.insert(0, pix.to(torch.float64))
+                vals, sweeps = cubic_exact(ctx, la, lo, valid, torch.cat(chans, dim=1), fd.height, fd.width, grid, target_mask)
+                mean.copy_(vals.reshape(grid.ny, grid.nx, nch + 1))
+                empty = torch.isnan(mean[..., 0])
+                mask.copy_(empty.to(torch.uint8))
+                if nch:
+                    # np.round + astype of the interpolated floats (reference resample.py:128-136); an overshoot wraps
+                    rounded = torch.round(torch.nan_to_num(mean[..., :nch], nan=0.0)).to(torch.int64)
+                    if fd.img_dtype_code == 2:
+                        img.copy_((rounded & 0xffff).to(torch.int32).to(torch.int16))
+                    else:
+                        img.copy_((rounded & 0xff).to(torch.uint8))
+                alt.fill_(float('nan'))
+                tri.fill_(-1)
+                extra = dict(alt=alt, triangles=tri, sweeps=max(sweeps))
         out = dict(has_elev=fd.elev is not None, grid=grid, contains_pole=bool(containsPole),
                    contains_discontinuity=bool(containsDiscontinuity), altitude=altitude)
         if keep_on_device:
@@ -606,19 +695,12 @@ def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingB
             picked = flat[index.clamp(min=0).reshape(-1)]
             picked[index.reshape(-1) < 0] = float('nan')
         elif method == 'cubic':
-            # arbitrary float channels go to the kernels as they are (img_dtype 3); at most 5 per call
-            tlat, tlon = grid.device_centers(ctx)
+            # scipy's griddata on its own triangulation, in its own order (cubic_exact); the data points are the pixels with
+            # a latitude (reference resample.py:315-321)
             la, lo = lat_c.reshape(-1).contiguous(), lon_c.reshape(-1).contiguous()
-            parts = []
-            for c0 in range(0, d.shape[2], 5):
-                chunk = flat[:, c0:c0 + 5].contiguous()
-                nchunk = chunk.shape[1]
-                grad, _ = cubic_gradients(ctx, la, lo, None, None, h, w, None, lon_wrap, chunk, 3, nchunk)
-                part = ctx.empty((grid.ny * grid.nx, nchunk))
-                ctx.call('amt_cubic_gather', ptr(index), grid.ny, grid.nx, ptr(la), ptr(lo), None, None, h, w, float('-inf'),
-                         lon_wrap, ptr(tlat), ptr(tlon), ptr(chunk), 3, nchunk, ptr(grad), ptr(part), None, None, None, None)
-                parts.append(part)
-            picked = torch.cat(parts, dim=1)
+            if lon_wrap:
+                lo = wrap_at_180_t(lo + 180)
+            picked, _ = cubic_exact(ctx, la, lo, ~torch.isnan(la), flat, h, w, grid, target_mask)
         else:
             # the triangle of every grid centre from the kernel, the barycentric sum of arbitrary float channels here
             tlat, tlon = grid.device_centers(ctx)

@@ -500,6 +500,38 @@ int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx,
                      int lon_wrap, const double* target_lat, const double* target_lon, const void* img, int32_t img_dtype,
                      int32_t nchan, const double* gradients, double* mean, void* out_img, uint8_t* out_mask, double* alt_mean,
                      int64_t* out_triangles);
+/* ---- method='cubic' on the exact triangulation (round 5) ----
+ * scipy.interpolate.griddata(method='cubic'), the reference's call (resample.py:323-326), is CloughTocher2DInterpolator on
+ * scipy.spatial.Delaunay(points): Qhull's Delaunay triangulation, gradients from a Gauss-Seidel relaxation over its edges in
+ * the order of the points, the Clough-Tocher element per triangle.
+ *   amt_delaunay_create   HOST: the Delaunay triangulation of n >= 3 points xy (n, 2) (host memory; unique unless four points
+ *                         are cocircular to the last bit: then Qhull's diagonal is not reproduced).  AMT_EINVAL when all
+ *                         points are collinear.  Points that coincide with an earlier one are left out (amt_delaunay_sizes).
+ *   amt_delaunay_triangles        simplices (nt, 3) counter-clockwise and neighbours (nt, 3): the triangle opposite vertex k
+ *                                 or -1 (scipy.spatial.Delaunay.simplices / .neighbors, in another order of triangles)
+ *   amt_delaunay_vertex_neighbours   CSR (indptr (n + 1) int64, indices int32): Delaunay.vertex_neighbor_vertices
+ *   amt_delaunay_locate   for m targets (m, 2): the vertices (m, 3) of the triangle that holds each (-1: outside the hull), the
+ *                         centroids (m, 3, 2) of the triangles across its three edges and has_neighbour (m, 3)
+ *   amt_cubic_gradients_csr   DEVICE: interpnd._estimate_gradients_2d_global in scipy's order — every channel relaxed until the
+ *                         largest relative change of a sweep is below `tolerance` (scipy: 1e-6) or max_iterations (400)
+ *                         sweeps; iterations[nchan] (host) receives the sweeps per channel.  xy (n, 2), values (n, nchan),
+ *                         gradients (n, nchan, 2) on the device; the points must be in row-major pixel order and
+ *                         row_start (n_rows + 1, device) give the first point of every pixel row (a wave walks a row).
+ *   amt_cubic_eval        DEVICE: the element at the m targets -> out (m, nchan); NaN outside the hull. */
+typedef struct amt_delaunay amt_delaunay;
+int amt_delaunay_create(const double* xy, int64_t n, amt_delaunay** out);
+int amt_delaunay_destroy(amt_delaunay* d);
+int amt_delaunay_sizes(const amt_delaunay* d, int64_t* n_triangles, int64_t* n_neighbours, int64_t* n_duplicates);
+int amt_delaunay_triangles(const amt_delaunay* d, int32_t* simplices, int32_t* neighbours);
+int amt_delaunay_vertex_neighbours(const amt_delaunay* d, int64_t* indptr, int32_t* indices);
+int amt_delaunay_locate(const amt_delaunay* d, const double* targets, int64_t m, int32_t* vertices, double* centroids,
+                        uint8_t* has_neighbour);
+int amt_cubic_gradients_csr(amt_ctx* ctx, const double* xy, int64_t n, const int64_t* indptr, const int32_t* indices,
+                            const int64_t* row_start, int32_t n_rows, const double* values, int32_t nchan, double tolerance,
+                            int32_t max_iterations, double* gradients, int32_t* iterations);
+int amt_cubic_eval(amt_ctx* ctx, int64_t m, const double* targets, const int32_t* vertices, const double* centroids,
+                   const uint8_t* has_neighbour, const double* xy, const double* values, const double* gradients, int32_t nchan,
+                   double* out);
 /* auromat/utils.py:58-74 pointsInsidePolygon = matplotlib.path.Path(polygon).contains_points(points): crossing test
  * with Agg's half-open edge rule; polygon: (n_vertices, 2) device doubles (x, y), closed implicitly. */
 int amt_points_in_polygon(amt_ctx* ctx, const double* px, const double* py, int64_t n, const double* polygon,
