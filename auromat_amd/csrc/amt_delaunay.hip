@@ -6,7 +6,9 @@
 // points are cocircular and no three collinear on the hull — so any exact algorithm reproduces it, triangle for triangle
 // (tests/test_delaunay_cpu.py: equal to scipy.spatial.Delaunay's simplices on every fixture of the reference's 'cubic' outputs).
 // Where four points ARE cocircular to the last bit (an undistorted lattice) Qhull's choice of diagonal follows from its facet
-// merging and is not reproduced.
+// merging, and where hull points are collinear up to rounding (straight rows of such a lattice) it keeps or merges slivers of
+// 1e-16 as its roundoff tolerances fall: neither is reproduced — this triangulation is the exact one of the doubles given.
+// Projected camera grids are curved by many orders of magnitude more than that.
 //
 // Algorithm: incremental Bowyer-Watson with ghost triangles for the hull (no super-triangle: the hull is exact), points inserted
 // along a Hilbert curve (the previous point is a neighbour: the walk to the new point takes a step or two), orientation and in-circle tests in double precision behind Shewchuk's static error bounds with a binary128 evaluation

@@ -766,12 +766,17 @@ __global__ __launch_bounds__(kBlock) void k_cubic_gather(lin_args A, const long 
 //     its filling of holes included — their long edges pull on the border pixels' gradients, and the pull decays by a factor
 //     of about three per ring of pixels, which is what kept the lattice-only estimate of rounds 3-4 from agreeing);
 //   * one WAVE per pixel row walks its row's points in order; lanes are channels (each channel is its own relaxation with its
-//     own stopping sweep, as scipy runs them one after the other).  A neighbour with a smaller index in ANOTHER row has been
-//     written by another wave: the walker waits for that point's stamp (= this sweep's number, stored with release order
-//     after the point's gradients) and reads the new array; neighbours with a larger index are read from the previous
-//     sweep's array — two arrays, so nobody can overtake.  Rows are handed out by a ticket in increasing order: a wave only
-//     ever waits for rows that were taken before its own, whose waves are running or done, so the lowest unfinished row
-//     always advances.
+//     own stopping sweep, as scipy runs them one after the other).  A neighbour with a smaller index in ANOTHER row is written
+//     by another wave: every gradient component is its own hand-over — the sweep's output array starts out filled with a
+//     marker (a NaN no computation produces), components are written and read with relaxed device-scope atomics (8 bytes:
+//     whole or not at all), and a reader that still finds the marker reads again.  No fences, no cache write-backs: a
+//     component is either the marker or final.  Neighbours with a larger index are read from the previous sweep's array —
+//     two arrays, so nobody can overtake.  Rows are handed out by a ticket in increasing order: a wave only ever waits for
+//     rows that were taken before its own, whose waves are running or done, so the lowest unfinished row always advances.
+//     (First version, with a stamp per point behind release / acquire fences: 1.35 s per sweep of 5.8 M points — every
+//     fence wrote back or invalidated a whole L2; this form: see tools/cubic_full_probe.py.)
+constexpr unsigned long long kGsMarker = 0x7ff8dead5eed0001ull;
+
 struct gs_args {
     const double* xy;                // (n, 2) points: lat, lon as the reference hands them to griddata
     const long long* indptr;         // (n + 1)
@@ -780,13 +785,24 @@ struct gs_args {
     int n_rows, nchan;
     const double* values;            // (n, nchan)
     const double* y_old;             // (n, nchan, 2)
-    double* y_new;
-    unsigned int* stamp;             // (n): number of the sweep that last wrote the point
-    unsigned int sweep;
+    unsigned long long* y_new;       // (n, nchan, 2) bit patterns, kGsMarker = not written yet
     unsigned int* ticket;
     unsigned long long* err;         // (nchan): largest relative change of the sweep (bits of a non-negative double)
     const unsigned char* active;     // (nchan): 0 = this channel has converged: its gradients are carried over
 };
+
+__global__ void k_fill_u64(unsigned long long* __restrict__ p, int64_t n, unsigned long long v) {
+    AMT_GRID_STRIDE(i, n) p[i] = v;
+}
+
+__device__ __forceinline__ double gs_read(const unsigned long long* p) {
+    unsigned long long b = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (b == kGsMarker) {
+        __builtin_amdgcn_s_sleep(1);
+        b = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return __longlong_as_double((long long)b);
+}
 
 __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
     const int lane = threadIdx.x;
@@ -798,46 +814,69 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
     const bool chan = lane < A.nchan;
     const bool live = chan && A.active[lane] != 0;
     double worst = 0;
+    double p0 = 0, p1 = 0;                        // this wave's previous point's new gradient
     for (long long v = v0; v < v1; ++v) {
+        if (!chan) break;
         const long long b = A.indptr[v], e = A.indptr[v + 1];
-        // neighbours of earlier rows must have been written in this sweep (those of this row were: by this wave)
-        for (long long k = b; k < e; ++k) {
-            const long long j = A.indices[k];
-            if (j < v0)
-                while (__hip_atomic_load(&A.stamp[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != A.sweep)
-                    __builtin_amdgcn_s_sleep(2);
-        }
-        if (chan) {
-            const long long o = (v * A.nchan + lane) * 2;
-            double g0 = A.y_old[o], g1 = A.y_old[o + 1];
-            if (live) {
-                const double xi = A.xy[2 * v], yi = A.xy[2 * v + 1], fi = A.values[v * A.nchan + lane];
-                double q0 = 0, q1 = 0, q3 = 0, s0 = 0, s1 = 0;
-                for (long long k = b; k < e; ++k) {
-                    const long long j = A.indices[k];
+        const long long o = (v * A.nchan + lane) * 2;
+        double g0 = A.y_old[o], g1 = A.y_old[o + 1];
+        if (live) {
+            const double xi = A.xy[2 * v], yi = A.xy[2 * v + 1], fi = A.values[v * A.nchan + lane];
+            double q0 = 0, q1 = 0, q3 = 0, s0 = 0, s1 = 0;
+            for (long long kb = b; kb < e; kb += 8) {
+                // the loads of up to eight neighbours are issued together, then waited for one by one
+                unsigned long long r0[8], r1[8];
+                const int cnt = (int)((e - kb) < 8 ? (e - kb) : 8);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    r0[t] = r1[t] = 0;
+                    if (t < cnt) {
+                        const long long j = A.indices[kb + t];
+                        if (j < v && j != v - 1) {
+                            const unsigned long long* q = A.y_new + (j * A.nchan + lane) * 2;
+                            r0[t] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            r1[t] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (t >= cnt) continue;
+                    const long long j = A.indices[kb + t];
+                    double y0, y1;
+                    if (j > v) {
+                        y0 = A.y_old[(j * A.nchan + lane) * 2], y1 = A.y_old[(j * A.nchan + lane) * 2 + 1];
+                    } else if (j == v - 1 && v > v0) {
+                        y0 = p0, y1 = p1;                         // written by this wave a moment ago
+                    } else if (j == v - 1) {
+                        // the last point of an earlier row
+                        y0 = gs_read(A.y_new + (j * A.nchan + lane) * 2), y1 = gs_read(A.y_new + (j * A.nchan + lane) * 2 + 1);
+                    } else {
+                        const unsigned long long* q = A.y_new + (j * A.nchan + lane) * 2;
+                        y0 = r0[t] == kGsMarker ? gs_read(q) : __longlong_as_double((long long)r0[t]);
+                        y1 = r1[t] == kGsMarker ? gs_read(q + 1) : __longlong_as_double((long long)r1[t]);
+                    }
                     const double ex = A.xy[2 * j] - xi, ey = A.xy[2 * j + 1] - yi;
                     const double l = sqrt(ex * ex + ey * ey), l3 = l * l * l;
-                    const double* yj = (j < v ? A.y_new : A.y_old) + (j * A.nchan + lane) * 2;
-                    const double df2 = -ex * yj[0] - ey * yj[1];
+                    const double df2 = -ex * y0 - ey * y1;
                     q0 += 4 * ex * ex / l3;
                     q1 += 4 * ex * ey / l3;
                     q3 += 4 * ey * ey / l3;
-                    const double t = (6 * (fi - A.values[j * A.nchan + lane]) - 2 * df2) / l3;
-                    s0 += t * ex;
-                    s1 += t * ey;
+                    const double tt = (6 * (fi - A.values[j * A.nchan + lane]) - 2 * df2) / l3;
+                    s0 += tt * ex;
+                    s1 += tt * ey;
                 }
-                const double det = q0 * q3 - q1 * q1;
-                const double r0 = (q3 * s0 - q1 * s1) / det, r1 = (-q1 * s0 + q0 * s1) / det;
-                double change = fmax(fabs(g0 + r0), fabs(g1 + r1));
-                change /= fmax(1.0, fmax(fabs(r0), fabs(r1)));
-                if (change == change) worst = fmax(worst, change);
-                g0 = -r0, g1 = -r1;
             }
-            A.y_new[o] = g0, A.y_new[o + 1] = g1;
+            const double det = q0 * q3 - q1 * q1;
+            const double r0_ = (q3 * s0 - q1 * s1) / det, r1_ = (-q1 * s0 + q0 * s1) / det;
+            double change = fmax(fabs(g0 + r0_), fabs(g1 + r1_));
+            change /= fmax(1.0, fmax(fabs(r0_), fabs(r1_)));
+            if (change == change) worst = fmax(worst, change);
+            g0 = -r0_, g1 = -r1_;
         }
-        // every lane's stores before the stamp (one wave: program order per lane, the release makes them visible)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) __hip_atomic_store(&A.stamp[v], A.sweep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        p0 = g0, p1 = g1;
+        __hip_atomic_store(A.y_new + o, (unsigned long long)__double_as_longlong(g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.y_new + o + 1, (unsigned long long)__double_as_longlong(g1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (live && worst > 0) atomicMax(&A.err[lane], (unsigned long long)__double_as_longlong(worst));
 }
@@ -1163,20 +1202,16 @@ int amt_cubic_gradients_csr(amt_ctx* ctx, const double* xy, int64_t n, const int
     AMT_REQUIRE(ctx, nchan >= 1 && nchan <= 64, "1..64 channels");
     AMT_REQUIRE(ctx, tolerance > 0 && max_iterations >= 1, "tolerance and max_iterations must be positive");
     const size_t grad_bytes = (size_t)n * nchan * 2 * sizeof(double);
-    const size_t stamp_bytes = ((size_t)n * sizeof(unsigned int) + 63) & ~(size_t)63;
-    char* ws = static_cast<char*>(amt_workspace(ctx, grad_bytes + stamp_bytes + 1024));
+    char* ws = static_cast<char*>(amt_workspace(ctx, grad_bytes + 1024));
     if (ws == nullptr) {
         ctx->last_error = "amt_cubic_gradients_csr: workspace allocation failed";
         return AMT_ENOMEM;
     }
     double* other = reinterpret_cast<double*>(ws);
-    unsigned int* stamp = reinterpret_cast<unsigned int*>(ws + grad_bytes);
-    unsigned long long* err = reinterpret_cast<unsigned long long*>(ws + grad_bytes + stamp_bytes);      // [64]
-    unsigned int* ticket = reinterpret_cast<unsigned int*>(ws + grad_bytes + stamp_bytes + 512);
-    unsigned char* active = reinterpret_cast<unsigned char*>(ws + grad_bytes + stamp_bytes + 576);      // [64]
+    unsigned long long* err = reinterpret_cast<unsigned long long*>(ws + grad_bytes);      // [64]
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(ws + grad_bytes + 512);
+    unsigned char* active = reinterpret_cast<unsigned char*>(ws + grad_bytes + 576);      // [64]
     AMT_HIP(ctx, hipMemsetAsync(gradients, 0, grad_bytes, ctx->stream));
-    AMT_HIP(ctx, hipMemsetAsync(other, 0, grad_bytes, ctx->stream));
-    AMT_HIP(ctx, hipMemsetAsync(stamp, 0, stamp_bytes, ctx->stream));
     unsigned char host_active[64];
     for (int c = 0; c < 64; ++c) host_active[c] = c < nchan ? 1 : 0;
     for (int c = 0; c < nchan; ++c) iterations[c] = 0;
@@ -1184,12 +1219,14 @@ int amt_cubic_gradients_csr(amt_ctx* ctx, const double* xy, int64_t n, const int
     gs_args A;
     A.xy = xy, A.indptr = reinterpret_cast<const long long*>(indptr), A.indices = indices;
     A.row_start = reinterpret_cast<const long long*>(row_start), A.n_rows = n_rows, A.nchan = nchan;
-    A.values = values, A.stamp = stamp, A.ticket = ticket, A.err = err, A.active = active;
+    A.values = values, A.ticket = ticket, A.err = err, A.active = active;
     double* bufs[2] = {gradients, other};
     int cur = 0;                                   // bufs[cur] holds the latest sweep
+    const int64_t n_comp = n * nchan * 2;
     for (int it = 1; it <= max_iterations; ++it) {
         AMT_HIP(ctx, hipMemsetAsync(err, 0, 512 + 64, ctx->stream));              // err[64] and the ticket
-        A.y_old = bufs[cur], A.y_new = bufs[1 - cur], A.sweep = (unsigned int)it;
+        A.y_old = bufs[cur], A.y_new = reinterpret_cast<unsigned long long*>(bufs[1 - cur]);
+        hipLaunchKernelGGL(k_fill_u64, grid_for(n_comp), dim3(kBlock), 0, ctx->stream, A.y_new, n_comp, kGsMarker);
         hipLaunchKernelGGL(k_cubic_gs, dim3((unsigned)n_rows), dim3(64), 0, ctx->stream, A);
         AMT_LAUNCH_CHECK(ctx);
         unsigned long long bits[64];

@@ -135,9 +135,11 @@ def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=No
                    plane) and 'linear' (barycentric interpolation in the triangle of pixel centres that holds the grid
                    centre; the triangulation is that of the pixel grid, which equals the reference's Qhull triangulation
                    up to the choice of diagonal in near-cocircular quads: values agree within the spread of the two
-                   diagonals) and 'cubic' (scipy's Clough-Tocher element with its globally estimated vertex gradients on
-                   the same triangles; an interpolant that overshoots, and an integer image wraps like numpy's cast), all
-                   masked outside the mapping's outline.
+                   diagonals) and 'cubic' (scipy's griddata: the Delaunay triangulation of the pixel centres — Qhull's,
+                   triangle for triangle, wherever it is unique —, scipy's gradient estimator in scipy's order with its
+                   stopping rule, the Clough-Tocher element; equal to the reference to rounding, ~1e-13 of a channel's span;
+                   an interpolant that overshoots, and an integer image wraps like numpy's cast), all masked outside the
+                   mapping's outline.
     :rtype: a subclass of BaseMapping or MappingCollection
     """
     _check_method(method)

@@ -1,7 +1,8 @@
-"""Differential fuzz of method='cubic' (amt_cubic_gradients + amt_cubic_gather through `_resample`) against scipy's
-CloughTocher2DInterpolator: random sheared / stretched / gently warped lattices (unambiguous Delaunay diagonals), smooth and noisy
-channels, optional holes in the footprint.  Away from the hull and from holes the two must agree to the solvers' tolerances; next
-to them scipy's triangles differ (Qhull spans holes) and only finiteness is asked for.
+"""Differential fuzz of method='cubic' (round 5: amt_delaunay_* + amt_cubic_gradients_csr + amt_cubic_eval through `_resample`)
+against scipy's CloughTocher2DInterpolator with griddata's defaults (tol 1e-6, maxiter 400): random sheared / stretched / gently
+warped lattices, smooth and noisy channels, optional holes in the footprint.  The triangulation is Qhull's and the relaxation
+runs in scipy's order with scipy's stopping rule, so EVERY filled cell — next to the hull and to holes as well — must agree to
+1e-9 of the channel's span.  (METHOD=linear still runs the lattice kernels: compared deep inside the footprint only.)
 usage: fuzz_cubic.py [rounds] [seed]      (METHOD=linear: the same against scipy's LinearNDInterpolator, to 1e-9)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +14,7 @@ from auromat_amd.resample import _resample
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 method = os.environ.get('METHOD', 'cubic')
-limit = 5e-5 if method == 'cubic' else 1e-9
+limit = 1e-9
 fails = 0
 worst = 0.0
 compared = cells = 0
@@ -25,6 +26,12 @@ for it in range(rounds):
     aspect = rng.uniform(0.5, 3.0)
     lat = 30.0 + step * (ii + shear * jj) + 0.3 * step * np.sin(ii / 9.0) * np.cos(jj / 11.0) * rng.uniform(0, 1)
     lon = -20.0 + step * aspect * (jj + 0.1 * ii) + 0.3 * step * np.cos(ii / 7.0) * rng.uniform(0, 1)
+    if method == 'cubic':
+        # every row and column gently curved, like a projected camera grid: rows that are straight up to rounding make the
+        # hull's triangles a matter of Qhull's roundoff handling (slivers of 1e-16 kept or merged), which nothing reproduces
+        bend = rng.uniform(1e-3, 1e-2) * step
+        lat = lat + bend * ((jj - w / 2.0) ** 2 / w + 0.5 * (ii - h / 2.0) ** 2 / h)
+        lon = lon + bend * aspect * ((ii - h / 2.0) ** 2 / h - 0.3 * (jj - w / 2.0) ** 2 / w)
     data = np.stack([np.sin(lat * rng.uniform(0.5, 3)) * np.cos(lon * rng.uniform(0.5, 3)) * 50,
                      rng.rand(h, w) * 20, 0.3 * lat * lat - lon + 0.1 * lat * lon], axis=2)
     hole = rng.rand() < 0.5
@@ -38,7 +45,7 @@ for it in range(rounds):
     d[~valid] = np.nan
     pts = np.column_stack((lat[valid], lon[valid]))
     tri_ = scipy.spatial.Delaunay(pts)
-    ref = scipy.interpolate.CloughTocher2DInterpolator(tri_, data[valid], tol=1e-10, maxiter=4000) if method == 'cubic' else \
+    ref = scipy.interpolate.CloughTocher2DInterpolator(tri_, data[valid]) if method == 'cubic' else \
         scipy.interpolate.LinearNDInterpolator(tri_, data[valid])
     # targets: a grid over the middle of the footprint
     m = 10
@@ -73,7 +80,11 @@ for it in range(rounds):
         if not got_ok[deep].all():
             print('round', it, 'NaN deep inside the footprint:', int((~got_ok[deep]).sum()), 'cells')
             bad = True
-        rel = (np.abs(out - want)[deep & got_ok] / span).max() if (deep & got_ok).any() else 0.0
+        where = got_ok if method == 'cubic' else (deep & got_ok)          # cubic: every filled cell
+        if method == 'cubic' and np.isnan(want[got_ok]).any():
+            print('round', it, 'cells filled outside scipy\'s convex hull:', int(np.isnan(want[got_ok][:, 0]).sum()))
+            bad = True
+        rel = (np.abs(out - want)[where] / span).max() if where.any() else 0.0
         worst = max(worst, rel)
         if rel > limit:
             print('round', it, 'h w', h, w, 'shear %.2f aspect %.2f hole %s: max relative difference %.2e' % (shear, aspect, hole, rel))
