@@ -1082,7 +1082,7 @@ def real_frame_south():
     fast centres -> maskedByElevation(10) -> _resample(pxPerDeg=10, 'mean') on the geographic grid; the same with exact
     centres; and the _resample call of resampleMLatMLT on the (MLat, SM longitude) grid, whose box straddles +-180 deg of SM
     longitude there or not as the reference's bounding-box rule decides (mapping.py:726-734, resample.py:203-218).  Copies
-    of the two data files: tests/golden/resources/."""
+    of the two data files: tests/golden/resources/south/."""
     from PIL import Image
     from auromat_amd.fits import readHeader
     from auromat_amd.mapping.spacecraft import getSpacecraftPosition

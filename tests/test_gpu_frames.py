@@ -891,12 +891,14 @@ def test_getMapping_with_a_non_tan_header():
     assert np.max(np.abs(m.lats.data[both] - tan.lats.data[both])) > 1e-3
     r = resample(m.maskedByElevation(10), pxPerDeg=10)
     r.checkGuarantees()
-    # a fresh mapping of this kind is masked at once (no camera model for the fused plan) and resamples to the same grid
+    # a fresh mapping of this kind only remembers the mask (round 5: the single-pass plan reads the direction array,
+    # amt_pipe_launch_dirs) and resamples to the same grid
     import auromat_amd.resample as R
     fresh = getMapping(img, hdr, cameraPosGCRS=cam, altitude=110, identifier='arc').maskedByElevation(10)
-    assert fresh._frame is not None
+    assert fresh._frame is None and fresh._lazy_elev == 10.0
     r2 = R.resample(fresh, pxPerDeg=10)
-    assert R.last_plan is None and np.array_equal(r2.img.filled(0), r.img.filled(0))
+    assert R.last_plan == 'single-pass' and fresh._frame is None
+    assert np.array_equal(ma.getmaskarray(r2.img), ma.getmaskarray(r.img)) and np.array_equal(r2.img.filled(0), r.img.filled(0))
 
 
 def test_single_pass_right_most_edge_rule():

@@ -6,7 +6,7 @@ The rest of the reference's own test data at full size:
   resampleMLatMLT (resample.py:203-218);
 * the header sequences test/resources/seq2/ (4 frames) and seq3/ (3 frames).
 
-Copies of the data files: tests/golden/resources/.  Expected values from the REAL reference (oracle/make_golden.py:
+Copies of the data files: tests/golden/resources/{south,seq2,seq3}/.  Expected values from the REAL reference (oracle/make_golden.py:
 real_frame_south, real_sequences_more): fast / exact centres -> maskedByElevation(10) -> _resample(pxPerDeg=10, 'mean').
 
 CPU: the oracle equals the reference cell for cell.  GPU: the reference's call sequence through the classes, both plans of
@@ -22,8 +22,8 @@ import pytest
 
 from conftest import GOLDEN, load_golden
 
-JPG = os.path.join(GOLDEN, 'resources', 'ISS029-E-8492.jpg')
-WCS = os.path.join(GOLDEN, 'resources', 'ISS029-E-8492.wcs')
+JPG = os.path.join(GOLDEN, 'resources', 'south', 'ISS029-E-8492.jpg')
+WCS = os.path.join(GOLDEN, 'resources', 'south', 'ISS029-E-8492.wcs')
 
 
 def check(res_img, res_mask, mean, z):
