@@ -106,7 +106,7 @@ class RunResult(C.Structure):
                 ('retried', C.c_int32), ('reserved2_', C.c_int32)]
 
 
-ABI_VERSION = 4          # include/auromat_hip.h AMT_ABI_VERSION
+ABI_VERSION = 5          # include/auromat_hip.h AMT_ABI_VERSION
 _I, _L, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p
 _SIGNATURES = {
     'amt_abi_version': ([], _I),

@@ -118,6 +118,7 @@ class FramePipeline(object):
         # corner directions of the last frame when they came from the caller ((h + 1, w + 1, 3) float64 device tensor, J2000;
         # the directions-in form of the pipeline, reference astrometry.py:49-64 with any camera model) instead of the TAN model
         self._dirs = None
+        self._img_rest = None       # (host image, r0, r1) of a partial set_image: rows outside [r0, r1) are not on the device
         self._out.bbox = fd.bbox.data_ptr()
 
     def _alloc_coords(self, full=False):
@@ -172,11 +173,14 @@ class FramePipeline(object):
             self._driver = None
 
     # -- inputs ---------------------------------------------------------------------------------
-    def set_image(self, img):
+    def set_image(self, img, rows=None):
         """Copy an (h, w, c) host image (or device tensor of the same bytes) into the frame buffer.  A pinned host
         tensor of the buffer's dtype (uint16 images as their int16 bits) is copied asynchronously on the current
-        stream."""
+        stream.  `rows` = (r0, r1), host arrays only: only that band of rows crosses the link now — the rows a camera frame's
+        kernels can read (outside them no ray reaches the shell: :meth:`earth_rows`) — and the rest when something asks for
+        the whole image (:meth:`complete_image`)."""
         import torch
+        self._img_rest = None
         if self.fd.img is not self._img_own or self._img_own is None:
             # the buffer aliased a caller's device image (use_image): copy into a buffer of our own
             if self._img_own is None:
@@ -192,7 +196,32 @@ class FramePipeline(object):
         a = np.ascontiguousarray(img, dtype=self.fd.img_dtype)
         assert a.size == self.fd.img.numel(), 'image of the wrong size'
         Context.current(self.ctx.device)
+        if rows is not None and 0 <= rows[0] < rows[1] <= self.height and (rows[1] - rows[0]) < 0.9 * self.height:
+            a = a.reshape(self._img_shape)
+            self.ctx.upload(a[rows[0]:rows[1]], self.fd.img[rows[0]:rows[1]])
+            self._img_rest = (a, rows[0], rows[1])
+            return
         self.ctx.upload(a, self.fd.img)          # through page-locked staging pieces (see Context.upload)
+
+    def complete_image(self):
+        """The rows a partial :meth:`set_image` left out (no pixel of them has coordinates; whoever wants the whole buffer —
+        a caller that keeps the frame's image, an exporter — gets it here)."""
+        if self._img_rest is not None:
+            a, r0, r1 = self._img_rest
+            self._img_rest = None
+            Context.current(self.ctx.device)
+            if r0 > 0:
+                self.ctx.upload(a[:r0], self.fd.img[:r0])
+            if r1 < self.height:
+                self.ctx.upload(a[r1:], self.fd.img[r1:])
+
+    def earth_rows(self, params):
+        """(r0, r1): the pixel rows of a camera frame outside of which no ray reaches the shell (amt_georef_sky_rows: the limb
+        is a conic section in the image; conservative), i.e. the only rows whose pixels any kernel reads."""
+        o = [C.c_int32(0) for _ in range(4)]
+        self.ctx._lib.amt_georef_sky_rows(C.byref(params), *[C.byref(v) for v in o])
+        rows, n, top, bottom = [v.value for v in o]
+        return max(0, top * rows), min(self.height, bottom * rows)
 
     def use_image(self, img):
         """Use a device-resident image of the buffer's layout ((h, w, c) uint8, or uint16 bits as int16) in place:
@@ -621,9 +650,20 @@ class FramePipeline(object):
         precedence over pxPerDeg, like the reference's resample()): the box-first plan — a box pass, px/deg from the frame's
         own bounding box, then the single-pass launch (``fuse``) or the two-pass plan; the px/deg pair used is in the
         result as 'pxPerDeg'."""
-        if img is not None:
-            self.set_image(img)
         coarse_started = False
+        if img is not None:
+            host_array = not hasattr(img, 'is_cuda')
+            if host_array and dirs is None and (params is not None or wcsHeader is not None):
+                # a host image of a camera frame: the estimate's pre-pass (or the box pass) runs while the image crosses the
+                # link, and only the rows a ray can hit cross it (43 % of the bench frame are sky)
+                if params is None:
+                    params = frame_params(wcsHeader, altitude, cameraPosGCRS, photoTime, fast, magnetic=self.with_mag)
+                if fuse and not arcsecPerPx and self.fd.nchan == 3 and (self.with_mag or not magnetic):
+                    self.start_coarse(params, min_elevation, bool(magnetic))
+                    coarse_started = True
+                self.set_image(img, rows=self.earth_rows(params))
+            else:
+                self.set_image(img)
         assert not (arcsecPerPx and dirs is not None), 'arcsecPerPx: the box-first plan is built on the camera model'
         if arcsecPerPx:
             if params is None:

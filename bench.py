@@ -647,13 +647,25 @@ def main(argv=None):
             assert gathered.n_frames == world * args.steps and len(gathered.unpack()) == world * args.steps
 
     upload = None
-    if not args.no_variants and not args.upload and shared is None and args.plan == 'fused' and not args.exact:
+    host_imgs = None
+    want_upload = not args.no_variants and not args.upload and shared is None and args.plan == 'fused' and not args.exact
+    if want_upload:
         # The PCIe-inclusive form of the same job (never the headline value): every rank streams its frames'
         # images from its OWN pinned host buffers (four distinct 72 MB images, cycled), uploaded on a copy stream beside the
         # previous frames' kernels, instead of finding them resident in HBM — what a real 256-frame run does, and what
         # eight ranks do to the host's memory system at once.  Same loop, gather included, barrier + max over the ranks.
         u_steps = min(args.steps, 96)
-        host_imgs = [torch.from_numpy(frame_image(WIDTH, HEIGHT, seed=100 + 4 * rank + i).view(np.int16)).pin_memory() for i in range(4)]
+        try:
+            host_imgs = [torch.from_numpy(frame_image(WIDTH, HEIGHT, seed=100 + 4 * rank + i).view(np.int16)).pin_memory() for i in range(4)]
+        except RuntimeError:
+            host_imgs = None                  # (page-locking 288 MB failed on this rank)
+        if use_dist:
+            # every rank or none: a rank that could not page-lock its images must not leave the others waiting in the gather
+            ok_all = torch.tensor([0 if host_imgs is None else 1], dtype=torch.int32, device=cdev)
+            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+            if int(ok_all.item()) == 0:
+                host_imgs = None
+    if want_upload and host_imgs is not None:
         u_frames = []
         for k in range(args.warmup + u_steps):
             hdr, cam, t, _ = sequence_frame(first + k, WIDTH, HEIGHT)

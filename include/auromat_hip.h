@@ -32,7 +32,9 @@ extern "C" {
 /* 2: amt_georef_out grew (bin_pole, altitude); amt_rotate_pole_deg, amt_pipe_finalize_stream, amt_seq_* added (round 2) */
 /* 4: amt_georef_last_variant; the MLat / MLT-only mode of the fused frame kernel (see amt_georef_out); the box-first plan
  *    (amt_pipe_launch_box[_many], amt_pipe_launch_many_res, amt_plate_carree_resolution) (round 4) */
-#define AMT_ABI_VERSION 4
+/* 5: the single-pass plan on caller-supplied corner directions (amt_georef_coarse_bbox_dirs, amt_pipe_coarse_dirs,
+ *    amt_pipe_launch_dirs); griddata(method='cubic') exactly: amt_delaunay_*, amt_cubic_gradients_csr, amt_cubic_eval (round 5) */
+#define AMT_ABI_VERSION 5
 
 #define AMT_OK 0
 #define AMT_EINVAL (-1)   /* bad argument (NULL pointer, negative size, unsupported dtype ...) */
