@@ -787,7 +787,8 @@ struct gs_args {
     const double* y_old;             // (n, nchan, 2)
     unsigned long long* y_new;       // (n, nchan, 2) bit patterns, kGsMarker = not written yet
     unsigned int* ticket;
-    unsigned long long* err;         // (nchan): largest relative change of the sweep (bits of a non-negative double)
+    unsigned long long* err;         // (nchan <= 63): largest relative change of the sweep (bits of a non-negative double);
+                                     // err[63]: set when a hand-over did not arrive (see gs_read)
     const unsigned char* active;     // (nchan): 0 = this channel has converged: its gradients are carried over
 };
 
@@ -795,13 +796,25 @@ __global__ void k_fill_u64(unsigned long long* __restrict__ p, int64_t n, unsign
     AMT_GRID_STRIDE(i, n) p[i] = v;
 }
 
-__device__ __forceinline__ double gs_read(const unsigned long long* p) {
+// (bounded: a hand-over that never comes — it cannot, by the ticket order, unless the device is being torn down — ends in a NaN
+// and a flag for the host after ~2 s instead of a wave that never finishes)
+constexpr int kGsMaxSpins = 1 << 26;
+__device__ __forceinline__ double gs_read(const unsigned long long* p, unsigned long long* stalled) {
     unsigned long long b = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (b == kGsMarker) {
+    for (int spins = 0; b == kGsMarker; ++spins) {
+        if (spins >= kGsMaxSpins) {
+            atomicMax(stalled, 1ull);
+            return NAN;
+        }
         __builtin_amdgcn_s_sleep(1);
         b = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return __longlong_as_double((long long)b);
+}
+
+// a gradient component as it is handed over: a NaN (from NaN data) in its canonical form, never the marker's bit pattern
+__device__ __forceinline__ unsigned long long gs_bits(double v) {
+    return v == v ? (unsigned long long)__double_as_longlong(v) : 0x7ff8000000000000ull;
 }
 
 __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
@@ -850,11 +863,11 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
                         y0 = p0, y1 = p1;                         // written by this wave a moment ago
                     } else if (j == v - 1) {
                         // the last point of an earlier row
-                        y0 = gs_read(A.y_new + (j * A.nchan + lane) * 2), y1 = gs_read(A.y_new + (j * A.nchan + lane) * 2 + 1);
+                        y0 = gs_read(A.y_new + (j * A.nchan + lane) * 2, A.err + 63), y1 = gs_read(A.y_new + (j * A.nchan + lane) * 2 + 1, A.err + 63);
                     } else {
                         const unsigned long long* q = A.y_new + (j * A.nchan + lane) * 2;
-                        y0 = r0[t] == kGsMarker ? gs_read(q) : __longlong_as_double((long long)r0[t]);
-                        y1 = r1[t] == kGsMarker ? gs_read(q + 1) : __longlong_as_double((long long)r1[t]);
+                        y0 = r0[t] == kGsMarker ? gs_read(q, A.err + 63) : __longlong_as_double((long long)r0[t]);
+                        y1 = r1[t] == kGsMarker ? gs_read(q + 1, A.err + 63) : __longlong_as_double((long long)r1[t]);
                     }
                     const double ex = A.xy[2 * j] - xi, ey = A.xy[2 * j + 1] - yi;
                     const double l = sqrt(ex * ex + ey * ey), l3 = l * l * l;
@@ -875,8 +888,8 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
             g0 = -r0_, g1 = -r1_;
         }
         p0 = g0, p1 = g1;
-        __hip_atomic_store(A.y_new + o, (unsigned long long)__double_as_longlong(g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(A.y_new + o + 1, (unsigned long long)__double_as_longlong(g1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.y_new + o, gs_bits(g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.y_new + o + 1, gs_bits(g1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (live && worst > 0) atomicMax(&A.err[lane], (unsigned long long)__double_as_longlong(worst));
 }
@@ -1199,7 +1212,7 @@ int amt_cubic_gradients_csr(amt_ctx* ctx, const double* xy, int64_t n, const int
     AMT_CHECK_CTX(ctx);
     AMT_REQUIRE(ctx, xy && indptr && indices && row_start && values && gradients && iterations, "NULL argument");
     AMT_REQUIRE(ctx, n >= 3 && n < 2147483647LL && n_rows >= 1, "bad size");
-    AMT_REQUIRE(ctx, nchan >= 1 && nchan <= 64, "1..64 channels");
+    AMT_REQUIRE(ctx, nchan >= 1 && nchan <= 63, "1..63 channels");
     AMT_REQUIRE(ctx, tolerance > 0 && max_iterations >= 1, "tolerance and max_iterations must be positive");
     const size_t grad_bytes = (size_t)n * nchan * 2 * sizeof(double);
     char* ws = static_cast<char*>(amt_workspace(ctx, grad_bytes + 1024));
@@ -1232,6 +1245,10 @@ int amt_cubic_gradients_csr(amt_ctx* ctx, const double* xy, int64_t n, const int
         unsigned long long bits[64];
         AMT_HIP(ctx, hipMemcpyAsync(bits, err, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
         AMT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (bits[63] != 0) {
+            ctx->last_error = "amt_cubic_gradients_csr: a sweep stalled (a point's gradient was never handed over)";
+            return AMT_EHIP;
+        }
         bool any = false, changed = false;
         for (int c = 0; c < nchan; ++c) {
             if (!host_active[c]) continue;

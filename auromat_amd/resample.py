@@ -412,12 +412,7 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask):
         rows = torch.div(idx, int(width), rounding_mode='floor')
         row_start = torch.zeros(int(height) + 1, dtype=torch.int64, device=ctx.device)
         row_start[1:] = torch.cumsum(torch.bincount(rows, minlength=int(height)), 0)
-        vals = values[idx].contiguous()
-        grad = ctx.empty((n, nchan, 2))
-        sweeps = (C.c_int32 * nchan)()
         d_indptr, d_indices = ctx.to_device(indptr, np.int64), ctx.to_device(indices, np.int32)
-        ctx.call('amt_cubic_gradients_csr', ptr(xy), n, ptr(d_indptr), ptr(d_indices), ptr(row_start), int(height), ptr(vals),
-                 nchan, CUBIC_TOLERANCE, CUBIC_MAX_SWEEPS, ptr(grad), sweeps)
         # the grid centres that are wanted, in row-major order (the walk from one to the next is a step or two)
         wanted = np.ones((grid.ny, grid.nx), dtype=bool) if target_mask is None else ~to_host(target_mask).astype(bool)
         sel = np.flatnonzero(wanted.ravel())
@@ -431,13 +426,24 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask):
             rc = L.amt_delaunay_locate(handle, targets.ctypes.data_as(C.c_void_p), m, vertices.ctypes.data_as(C.c_void_p),
                                        centroids.ctypes.data_as(C.c_void_p), has_nb.ctypes.data_as(C.c_void_p))
             assert rc == 0
-            part = ctx.empty((m, nchan))
             d_t, d_v, d_c, d_h = (ctx.to_device(a, a.dtype) for a in (targets, vertices, centroids, has_nb))
-            ctx.call('amt_cubic_eval', m, ptr(d_t), ptr(d_v), ptr(d_c), ptr(d_h), ptr(xy), ptr(vals), ptr(grad), nchan, ptr(part))
-            out[ctx.to_device(sel.astype(np.int64), np.int64)] = part
+            d_sel = ctx.to_device(sel.astype(np.int64), np.int64)
+        sweeps_all = []
+        for c0 in range(0, nchan, 32):                      # (the relaxation kernel takes up to 63 channels, one per lane)
+            vals = values[idx][:, c0:c0 + 32].contiguous()
+            k = int(vals.shape[1])
+            grad = ctx.empty((n, k, 2))
+            sweeps = (C.c_int32 * k)()
+            ctx.call('amt_cubic_gradients_csr', ptr(xy), n, ptr(d_indptr), ptr(d_indices), ptr(row_start), int(height), ptr(vals),
+                     k, CUBIC_TOLERANCE, CUBIC_MAX_SWEEPS, ptr(grad), sweeps)
+            sweeps_all.extend(int(v) for v in sweeps)
+            if m:
+                part = ctx.empty((m, k))
+                ctx.call('amt_cubic_eval', m, ptr(d_t), ptr(d_v), ptr(d_c), ptr(d_h), ptr(xy), ptr(vals), ptr(grad), k, ptr(part))
+                out[d_sel, c0:c0 + k] = part
     finally:
         L.amt_delaunay_destroy(handle)
-    return out, [int(v) for v in sweeps]
+    return out, sweeps_all
 
 
 def outside_outline_mask(ctx, grid, outline):

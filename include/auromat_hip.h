@@ -516,7 +516,7 @@ int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx,
  *                         centroids (m, 3, 2) of the triangles across its three edges and has_neighbour (m, 3)
  *   amt_cubic_gradients_csr   DEVICE: interpnd._estimate_gradients_2d_global in scipy's order — every channel relaxed until the
  *                         largest relative change of a sweep is below `tolerance` (scipy: 1e-6) or max_iterations (400)
- *                         sweeps; iterations[nchan] (host) receives the sweeps per channel.  xy (n, 2), values (n, nchan),
+ *                         sweeps; iterations[nchan] (host) receives the sweeps per channel (nchan <= 63).  xy (n, 2), values (n, nchan),
  *                         gradients (n, nchan, 2) on the device; the points must be in row-major pixel order and
  *                         row_start (n_rows + 1, device) give the first point of every pixel row (a wave walks a row).
  *   amt_cubic_eval        DEVICE: the element at the m targets -> out (m, nchan); NaN outside the hull. */
