@@ -132,14 +132,11 @@ def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=No
     :param None|number arcsecPerPx: spherical resolution, used to approximate pxPerDeg; has precedence
     :param None|bool containsPole: specify True|False to skip the pole check
     :param method: binning: 'mean'; interpolation: 'nearest' (value of the closest pixel centre in the lat/lon
-                   plane) and 'linear' (barycentric interpolation in the triangle of pixel centres that holds the grid
-                   centre; the triangulation is that of the pixel grid, which equals the reference's Qhull triangulation
-                   up to the choice of diagonal in near-cocircular quads: values agree within the spread of the two
-                   diagonals) and 'cubic' (scipy's griddata: the Delaunay triangulation of the pixel centres — Qhull's,
-                   triangle for triangle, wherever it is unique —, scipy's gradient estimator in scipy's order with its
-                   stopping rule, the Clough-Tocher element; equal to the reference to rounding, ~1e-13 of a channel's span;
-                   an interpolant that overshoots, and an integer image wraps like numpy's cast), all masked outside the
-                   mapping's outline.
+                   plane), 'linear' and 'cubic' (scipy's griddata: the Delaunay triangulation of the pixel centres — Qhull's,
+                   triangle for triangle, wherever it is unique —; 'linear': the barycentric sum in the grid centre's
+                   triangle; 'cubic': scipy's gradient estimator in scipy's order with its stopping rule and the Clough-Tocher
+                   element; both equal to the reference to rounding, ~1e-13 of a channel's span; a cubic overshoots, and an
+                   integer image wraps like numpy's cast), all masked outside the mapping's outline.
     :rtype: a subclass of BaseMapping or MappingCollection
     """
     _check_method(method)
@@ -375,14 +372,16 @@ def cubic_gradients(ctx, lat_c, lon_c, elev, center_mask, height, width, min_ele
     return grad, sweeps.value
 
 
-def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask):
+def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask, method='cubic', vertices_out=None):
     """
-    ``scipy.interpolate.griddata((lat, lon), values, grid centres, method='cubic')`` as the reference calls it (resample.py:
-    315-326) on its own triangulation and in its own order: the Delaunay triangulation of the valid pixel centres
-    (``amt_delaunay_create``, host: equal to Qhull's wherever that is unique), scipy's Gauss-Seidel gradient estimator over its
-    edges in the order of the points (``amt_cubic_gradients_csr``: tolerance 1e-6, at most 400 sweeps, every channel with its
-    own stopping sweep), the Clough-Tocher element in the triangle of every grid centre (``amt_delaunay_locate`` +
-    ``amt_cubic_eval``).
+    ``scipy.interpolate.griddata((lat, lon), values, grid centres, method='cubic' | 'linear')`` as the reference calls it
+    (resample.py:315-326) on its own triangulation and in its own order: the Delaunay triangulation of the valid pixel centres
+    (``amt_delaunay_create``, host: equal to Qhull's wherever that is unique); for 'cubic' scipy's Gauss-Seidel gradient
+    estimator over its edges in the order of the points (``amt_cubic_gradients_csr``: tolerance 1e-6, at most 400 sweeps, every
+    channel with its own stopping sweep) and the Clough-Tocher element in the triangle of every grid centre
+    (``amt_delaunay_locate`` + ``amt_cubic_eval``); for 'linear' the barycentric sum over that triangle's vertices.
+    `vertices_out`: a list that receives the (ny * nx, 3) int64 device tensor of each grid centre's triangle as flat pixel
+    indices (-1: none).
 
     :param lat, lon: flat float64 device tensors (height * width) in the coordinates the grid is laid out in
     :param valid: flat bool device tensor: the pixel is a data point
@@ -428,7 +427,28 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask):
             assert rc == 0
             d_t, d_v, d_c, d_h = (ctx.to_device(a, a.dtype) for a in (targets, vertices, centroids, has_nb))
             d_sel = ctx.to_device(sel.astype(np.int64), np.int64)
+        if vertices_out is not None:
+            tri_px = torch.full((grid.ny * grid.nx, 3), -1, dtype=torch.int64, device=ctx.device)
+            if m:
+                v64 = d_v.to(torch.int64)
+                tri_px[d_sel] = torch.where(v64 >= 0, idx[v64.clamp(min=0)], v64)
+            vertices_out.append(tri_px)
         sweeps_all = []
+        if method == 'linear':
+            if m:
+                # scipy's LinearNDInterpolator: the barycentric sum over the triangle's vertices
+                inside = d_v[:, 0] >= 0
+                v64 = d_v.to(torch.int64).clamp(min=0)
+                x, y = xy[:, 0][v64], xy[:, 1][v64]                       # (m, 3)
+                px, py = d_t[:, 0], d_t[:, 1]
+                det = (x[:, 1] - x[:, 0]) * (y[:, 2] - y[:, 0]) - (x[:, 2] - x[:, 0]) * (y[:, 1] - y[:, 0])
+                w1 = ((px - x[:, 0]) * (y[:, 2] - y[:, 0]) - (x[:, 2] - x[:, 0]) * (py - y[:, 0])) / det
+                w2 = ((x[:, 1] - x[:, 0]) * (py - y[:, 0]) - (px - x[:, 0]) * (y[:, 1] - y[:, 0])) / det
+                wts = torch.stack((1.0 - w1 - w2, w1, w2), dim=1)
+                part = (wts[:, :, None] * values[idx][v64]).sum(dim=1)
+                part[~inside] = float('nan')
+                out[d_sel] = part
+            return out, sweeps_all
         for c0 in range(0, nchan, 32):                      # (the relaxation kernel takes up to 63 channels, one per lane)
             vals = values[idx][:, c0:c0 + 32].contiguous()
             k = int(vals.shape[1])
@@ -560,15 +580,10 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
             alt = ctx.empty((grid.ny, grid.nx, nch + 1))
             tri = ctx.empty((grid.ny, grid.nx, 3), torch.int64)
             min_el = float('-inf') if min_elevation is None else float(min_elevation)
-            if method == 'linear':
-                ctx.call('amt_linear_gather', ptr(index), grid.ny, grid.nx, ptr(lat_c), ptr(lon_c), ptr(fd.elev),
-                         ptr(fd.center_mask), fd.height, fd.width, min_el, lon_wrap, ptr(tlat), ptr(tlon), ptr(fd.img),
-                         fd.img_dtype_code or 1, nch, ptr(mean), ptr(img) if nch else None, ptr(mask), ptr(alt), ptr(tri))
-                extra = dict(alt=alt, triangles=tri)
-            else:
-                # scipy's griddata(method='cubic') on its own triangulation, in its own order (cubic_exact): image channels
-                # and elevation as float64 channels of the valid pixels, then numpy's rounding and cast of the image
-                assert fd.elev is not None, "method='cubic' on a frame needs the elevation"
+            if method == 'linear' or method == 'cubic':
+                # scipy's griddata(method='linear' | 'cubic') on its own triangulation, in its own order (cubic_exact): image
+                # channels and elevation as float64 channels of the valid pixels, then numpy's rounding and cast of the image
+                assert fd.elev is not None, "method='%s' on a frame needs the elevation" % method
                 la, lo = lat_c.reshape(-1), lon_c.reshape(-1)
                 if lon_wrap:
                     lo = wrap_at_180_t(lo + 180)
@@ -581,7 +596,9 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
                     if fd.img_dtype_code == 2:
                         pix = pix.to(torch.int32) & 0xffff            # uint16 bits kept as int16
                     chans.insert(0, pix.to(torch.float64))
-                vals, sweeps = cubic_exact(ctx, la, lo, valid, torch.cat(chans, dim=1), fd.height, fd.width, grid, target_mask)
+                tri_out = []
+                vals, sweeps = cubic_exact(ctx, la, lo, valid, torch.cat(chans, dim=1), fd.height, fd.width, grid, target_mask,
+                                           method=method, vertices_out=tri_out)
                 mean.copy_(vals.reshape(grid.ny, grid.nx, nch + 1))
                 empty = torch.isnan(mean[..., 0])
                 mask.copy_(empty.to(torch.uint8))
@@ -592,9 +609,11 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
                         img.copy_((rounded & 0xffff).to(torch.int32).to(torch.int16))
                     else:
                         img.copy_((rounded & 0xff).to(torch.uint8))
-                alt.fill_(float('nan'))
-                tri.fill_(-1)
-                extra = dict(alt=alt, triangles=tri, sweeps=max(sweeps))
+                alt.copy_(mean)                    # (rounds 3-4: the value with the lattice cell's other diagonal)
+                tri.copy_(tri_out[0].reshape(grid.ny, grid.nx, 3))
+                extra = dict(alt=alt, triangles=tri)
+                if method == 'cubic':
+                    extra['sweeps'] = max(sweeps)
         out = dict(has_elev=fd.elev is not None, grid=grid, contains_pole=bool(containsPole),
                    contains_discontinuity=bool(containsDiscontinuity), altitude=altitude)
         if keep_on_device:
@@ -710,34 +729,15 @@ def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingB
                 lo = wrap_at_180_t(lo + 180)
             picked, _ = cubic_exact(ctx, la, lo, ~torch.isnan(la), flat, h, w, grid, target_mask)
         else:
-            # the triangle of every grid centre from the kernel, the barycentric sum of arbitrary float channels here
-            tlat, tlon = grid.device_centers(ctx)
-            tri = ctx.empty((grid.ny, grid.nx, 3), torch.int64)
+            # scipy's griddata(method='linear') on its own triangulation (cubic_exact): Qhull's triangle of every grid centre,
+            # the barycentric sum of the channels
             la, lo = lat_c.reshape(-1).contiguous(), lon_c.reshape(-1).contiguous()
-            ctx.call('amt_linear_gather', ptr(index), grid.ny, grid.nx, ptr(la), ptr(lo), None, None, h, w, float('-inf'),
-                     lon_wrap, ptr(tlat), ptr(tlon), None, 1, 0, None, None, None, None, ptr(tri))
-            tri = tri.reshape(-1, 3)
-            ok = tri[:, 0] >= 0
-            t = tri.clamp(min=0)
-            x, y = la[t], (wrap_at_180_t(lo + 180) if lon_wrap else lo)[t]
-            px = tlat[:, None].expand(grid.ny, grid.nx).reshape(-1)
-            py = tlon[None, :].expand(grid.ny, grid.nx).reshape(-1)
-            det = (x[:, 1] - x[:, 0]) * (y[:, 2] - y[:, 0]) - (x[:, 2] - x[:, 0]) * (y[:, 1] - y[:, 0])
-            w1 = ((px - x[:, 0]) * (y[:, 2] - y[:, 0]) - (x[:, 2] - x[:, 0]) * (py - y[:, 0])) / det
-            w2 = ((x[:, 1] - x[:, 0]) * (py - y[:, 0]) - (px - x[:, 0]) * (y[:, 1] - y[:, 0])) / det
-            wts = torch.stack((1.0 - w1 - w2, w1, w2), dim=1)
-            picked = (wts[:, :, None] * flat[t]).sum(dim=1)
-            picked[~ok] = float('nan')
+            if lon_wrap:
+                lo = wrap_at_180_t(lo + 180)
+            picked, _ = cubic_exact(ctx, la, lo, ~torch.isnan(la), flat, h, w, grid, target_mask, method='linear')
             if _alt_out is not None:
-                # channel by channel through the kernel's own interpolation (the channel in the place of the elevation)
-                alt = ctx.empty((grid.ny * grid.nx, d.shape[2]))
-                for c in range(d.shape[2]):
-                    chan = flat[:, c].contiguous()
-                    m1, a1 = ctx.empty((grid.ny * grid.nx,)), ctx.empty((grid.ny * grid.nx,))
-                    ctx.call('amt_linear_gather', ptr(index), grid.ny, grid.nx, ptr(la), ptr(lo), ptr(chan), None, h, w,
-                             float('-inf'), lon_wrap, ptr(tlat), ptr(tlon), None, 1, 0, ptr(m1), None, None, ptr(a1), None)
-                    alt[:, c] = a1
-                _alt_out.append(to_host(alt.reshape(grid.ny, grid.nx, d.shape[2])))
+                # (rounds 3-4 reported the value with the lattice cell's other diagonal here; the triangle is Qhull's now)
+                _alt_out.append(to_host(picked.reshape(grid.ny, grid.nx, d.shape[2])))
         mean = to_host(picked.reshape(grid.ny, grid.nx, d.shape[2]))
     lat, lon, lat_gc, lon_gc = grid.lat, grid.lon, grid.lat_c, grid.lon_c
     if containsPole:

@@ -2,7 +2,7 @@
 against scipy's CloughTocher2DInterpolator with griddata's defaults (tol 1e-6, maxiter 400): random sheared / stretched / gently
 warped lattices, smooth and noisy channels, optional holes in the footprint.  The triangulation is Qhull's and the relaxation
 runs in scipy's order with scipy's stopping rule, so EVERY filled cell — next to the hull and to holes as well — must agree to
-1e-9 of the channel's span.  (METHOD=linear still runs the lattice kernels: compared deep inside the footprint only.)
+1e-9 of the channel's span (METHOD=linear: the same against scipy's LinearNDInterpolator, on the same triangulation).
 usage: fuzz_cubic.py [rounds] [seed]      (METHOD=linear: the same against scipy's LinearNDInterpolator, to 1e-9)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,12 +26,11 @@ for it in range(rounds):
     aspect = rng.uniform(0.5, 3.0)
     lat = 30.0 + step * (ii + shear * jj) + 0.3 * step * np.sin(ii / 9.0) * np.cos(jj / 11.0) * rng.uniform(0, 1)
     lon = -20.0 + step * aspect * (jj + 0.1 * ii) + 0.3 * step * np.cos(ii / 7.0) * rng.uniform(0, 1)
-    if method == 'cubic':
-        # every row and column gently curved, like a projected camera grid: rows that are straight up to rounding make the
-        # hull's triangles a matter of Qhull's roundoff handling (slivers of 1e-16 kept or merged), which nothing reproduces
-        bend = rng.uniform(1e-3, 1e-2) * step
-        lat = lat + bend * ((jj - w / 2.0) ** 2 / w + 0.5 * (ii - h / 2.0) ** 2 / h)
-        lon = lon + bend * aspect * ((ii - h / 2.0) ** 2 / h - 0.3 * (jj - w / 2.0) ** 2 / w)
+    # every row and column gently curved, like a projected camera grid: rows that are straight up to rounding make the
+    # hull's triangles a matter of Qhull's roundoff handling (slivers of 1e-16 kept or merged), which nothing reproduces
+    bend = rng.uniform(1e-3, 1e-2) * step
+    lat = lat + bend * ((jj - w / 2.0) ** 2 / w + 0.5 * (ii - h / 2.0) ** 2 / h)
+    lon = lon + bend * aspect * ((ii - h / 2.0) ** 2 / h - 0.3 * (jj - w / 2.0) ** 2 / w)
     data = np.stack([np.sin(lat * rng.uniform(0.5, 3)) * np.cos(lon * rng.uniform(0.5, 3)) * 50,
                      rng.rand(h, w) * 20, 0.3 * lat * lat - lon + 0.1 * lat * lon], axis=2)
     hole = rng.rand() < 0.5
@@ -80,8 +79,8 @@ for it in range(rounds):
         if not got_ok[deep].all():
             print('round', it, 'NaN deep inside the footprint:', int((~got_ok[deep]).sum()), 'cells')
             bad = True
-        where = got_ok if method == 'cubic' else (deep & got_ok)          # cubic: every filled cell
-        if method == 'cubic' and np.isnan(want[got_ok]).any():
+        where = got_ok                                                    # every filled cell
+        if np.isnan(want[got_ok]).any():
             print('round', it, 'cells filled outside scipy\'s convex hull:', int(np.isnan(want[got_ok][:, 0]).sum()))
             bad = True
         rel = (np.abs(out - want)[where] / span).max() if where.any() else 0.0
