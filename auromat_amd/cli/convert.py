@@ -127,6 +127,10 @@ def parseargs(argv=None):
         parser.error('only one of --overwrite and --skip is allowed')
     if args.withoutGeo and args.format == Format.netcdf:
         parser.error('--without-geo is only usable with --format cdf')
+    if args.format == Format.cdf:
+        #  the version-3 container is laid out from the format description; no CDF library has opened such a file yet
+        sys.stderr.write('auromat-convert: note: CDF files are written without NASA\'s CDF library and have only been read back by this '
+                         'package\'s own reader; validate one with cdflib / pycdf before relying on them\n')
     return args
 
 

@@ -24,6 +24,13 @@
 
 namespace {
 
+// How often the predicates had to leave double precision, and how often the wider evaluation still could not tell (a tie: four
+// points cocircular, three collinear, as far as 113 bits can see).  Zero ties = the triangulation is the unique one.
+struct predicate_stats {
+    long long orient_wide, orient_zero, incircle_wide, incircle_zero;
+};
+thread_local predicate_stats* g_stats = nullptr;
+
 constexpr int kInf = -1;                // the vertex at infinity of a ghost triangle
 constexpr double kEps = 1.1102230246251565e-16;          // 2^-53
 
@@ -40,6 +47,10 @@ inline double orient2d(const pt& a, const pt& b, const pt& c) {
     // (differences of doubles of comparable size and their products fit 113 bits: exact)
     const __float128 L = ((__float128)a.x - c.x) * ((__float128)b.y - c.y), R = ((__float128)a.y - c.y) * ((__float128)b.x - c.x);
     const __float128 d = L - R;
+    if (g_stats) {
+        ++g_stats->orient_wide;
+        if (d == 0) ++g_stats->orient_zero;
+    }
     return d > 0 ? 1.0 : (d < 0 ? -1.0 : 0.0);
 }
 
@@ -62,8 +73,10 @@ inline double incircle(const pt& a, const pt& b, const pt& c, const pt& d) {
     auto ab = [](q v) { return v < 0 ? -v : v; };
     const q P = (ab(t1) + ab(t2)) * al + (ab(t3) + ab(t4)) * bl + (ab(t5) + ab(t6)) * cl;
     const q B = P * (q)1.6e-32;                       // ~ 16 x 2^-112 x the permanent
+    if (g_stats) ++g_stats->incircle_wide;
     if (D > B) return 1.0;
     if (-D > B) return -1.0;
+    if (g_stats) ++g_stats->incircle_zero;
     return 0.0;                                        // cocircular as far as 113 bits can tell
 }
 
@@ -81,6 +94,7 @@ struct amt_delaunay {
     std::vector<char> in_cavity;
     int last;                    // a live finite triangle near the latest point
     int n_dup;
+    predicate_stats stats;       // of build()
     // compacted result
     std::vector<int> tri;        // 3 per finite triangle
     std::vector<int> nbr;        // 3 per finite triangle: finite neighbour opposite vertex k or -1
@@ -368,7 +382,11 @@ int amt_delaunay_create(const double* xy, int64_t n, amt_delaunay** out) {
                 return AMT_EINVAL;
             }
         }
-        if (!d->build()) {
+        d->stats = predicate_stats{0, 0, 0, 0};
+        g_stats = &d->stats;
+        const bool built = d->build();
+        g_stats = nullptr;
+        if (!built) {
             delete d;
             return AMT_EINVAL;         // fewer than three points that are not collinear
         }
@@ -392,6 +410,13 @@ int amt_delaunay_sizes(const amt_delaunay* d, int64_t* n_triangles, int64_t* n_n
     if (n_triangles) *n_triangles = (int64_t)(d->tri.size() / 3);
     if (n_neighbours) *n_neighbours = (int64_t)d->indices.size();
     if (n_duplicates) *n_duplicates = d->n_dup;
+    return AMT_OK;
+}
+
+int amt_delaunay_stats(const amt_delaunay* d, int64_t* stats4) {
+    if (d == nullptr || stats4 == nullptr) return AMT_EINVAL;
+    stats4[0] = d->stats.orient_wide, stats4[1] = d->stats.orient_zero;
+    stats4[2] = d->stats.incircle_wide, stats4[3] = d->stats.incircle_zero;
     return AMT_OK;
 }
 

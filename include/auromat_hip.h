@@ -509,6 +509,10 @@ int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx,
  *   amt_delaunay_create   HOST: the Delaunay triangulation of n >= 3 points xy (n, 2) (host memory; unique unless four points
  *                         are cocircular to the last bit: then Qhull's diagonal is not reproduced).  AMT_EINVAL when all
  *                         points are collinear.  Points that coincide with an earlier one are left out (amt_delaunay_sizes).
+ *   amt_delaunay_stats    stats4[4]: orientation tests that left double precision, of those exact zeros (three points collinear),
+ *                         in-circle tests that left double precision, of those still undecided at 113 bits (four points
+ *                         cocircular).  [1] = [3] = 0: no tie was met — the triangulation is the unique Delaunay triangulation of
+ *                         the points, hence Qhull's.
  *   amt_delaunay_triangles        simplices (nt, 3) counter-clockwise and neighbours (nt, 3): the triangle opposite vertex k
  *                                 or -1 (scipy.spatial.Delaunay.simplices / .neighbors, in another order of triangles)
  *   amt_delaunay_vertex_neighbours   CSR (indptr (n + 1) int64, indices int32): Delaunay.vertex_neighbor_vertices
@@ -524,6 +528,7 @@ typedef struct amt_delaunay amt_delaunay;
 int amt_delaunay_create(const double* xy, int64_t n, amt_delaunay** out);
 int amt_delaunay_destroy(amt_delaunay* d);
 int amt_delaunay_sizes(const amt_delaunay* d, int64_t* n_triangles, int64_t* n_neighbours, int64_t* n_duplicates);
+int amt_delaunay_stats(const amt_delaunay* d, int64_t* stats4);
 int amt_delaunay_triangles(const amt_delaunay* d, int32_t* simplices, int32_t* neighbours);
 int amt_delaunay_vertex_neighbours(const amt_delaunay* d, int64_t* indptr, int32_t* indices);
 int amt_delaunay_locate(const amt_delaunay* d, const double* targets, int64_t m, int32_t* vertices, double* centroids,

@@ -28,7 +28,9 @@ def triangulate(pts):
     assert L.amt_delaunay_triangles(h, tri.ctypes.data_as(C.c_void_p), nbr.ctypes.data_as(C.c_void_p)) == 0
     indptr, ind = np.empty(len(pts) + 1, np.int64), np.empty(nn.value, np.int32)
     assert L.amt_delaunay_vertex_neighbours(h, indptr.ctypes.data_as(C.c_void_p), ind.ctypes.data_as(C.c_void_p)) == 0
-    return dict(handle=h, tri=tri, nbr=nbr, indptr=indptr, ind=ind, dup=nd.value, lib=L)
+    stats = (C.c_int64 * 4)()
+    assert L.amt_delaunay_stats(h, stats) == 0
+    return dict(handle=h, tri=tri, nbr=nbr, indptr=indptr, ind=ind, dup=nd.value, lib=L, stats=list(stats))
 
 
 def canon(t):
@@ -54,6 +56,10 @@ def test_triangulation_equals_qhulls_on_the_reference_fixtures(name):
     d = triangulate(pts)
     try:
         assert d['dup'] == 0 and len(ref.coplanar) == 0
+        # no tie was met while triangulating (no three points collinear, no four cocircular, even at 113 bits): this IS the
+        # unique Delaunay triangulation of the fixture's points — equal to Qhull's by uniqueness, not by luck
+        print(name, 'predicates beyond double precision: orientation %d (zeros %d), in-circle %d (undecided %d)' % tuple(d['stats']))
+        assert d['stats'][1] == 0 and d['stats'][3] == 0, d['stats']
         assert canon(d['tri']) == canon(ref.simplices)
         # counter-clockwise, and every neighbour relation mutual across the shared edge
         a, b, c = (pts[d['tri'][:, k]] for k in range(3))
@@ -121,6 +127,7 @@ def test_triangulation_of_a_jittered_lattice_with_holes_and_of_degenerate_inputs
     g = np.column_stack([a.ravel() for a in np.mgrid[0:12, 0:9].astype(np.float64)])
     h = triangulate(g)
     assert len(h['tri']) == 2 * 11 * 8 and h['dup'] == 0
+    assert h['stats'][3] > 0 and h['stats'][1] > 0                      # ... and the library says that it met ties
     a, b, c = (g[h['tri'][:, k]] for k in range(3))
     area = 0.5 * ((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0]))
     assert (area > 0).all() and abs(area.sum() - 11 * 8) < 1e-9
