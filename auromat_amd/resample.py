@@ -389,9 +389,19 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask, 
     :param target_mask: (ny, nx) uint8 device tensor, non-zero = the grid centre is not wanted (outside the outline), or None
     :return: ((ny * nx, channels) float64 device tensor, NaN outside the convex hull and where masked; sweeps per channel)
     """
+    import os
+    import time
     import torch
     from ._native import lib
     L = lib()
+    debug = bool(os.environ.get('AMT_CUBIC_DEBUG'))
+    marks = []
+
+    def mark(what):
+        if debug:
+            torch.cuda.synchronize()
+            marks.append((what, time.perf_counter()))
+    mark('start')
     idx = torch.nonzero(valid.reshape(-1)).reshape(-1)               # row-major pixel order = the reference's point order
     n, nchan = int(idx.numel()), int(values.shape[1])
     out = torch.full((grid.ny * grid.nx, nchan), float('nan'), dtype=torch.float64, device=ctx.device)
@@ -400,9 +410,11 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask, 
     xy = torch.stack((lat.reshape(-1)[idx], lon.reshape(-1)[idx]), dim=1).contiguous()
     xy_host = np.ascontiguousarray(to_host(xy))
     handle = C.c_void_p()
+    mark('points to the host')
     rc = L.amt_delaunay_create(xy_host.ctypes.data_as(C.c_void_p), n, C.byref(handle))
     if rc != 0:
         raise ValueError('method=\'cubic\': the valid pixel centres cannot be triangulated (all collinear?)')
+    mark('triangulation')
     try:
         nt, nn, nd = C.c_int64(), C.c_int64(), C.c_int64()
         L.amt_delaunay_sizes(handle, C.byref(nt), C.byref(nn), C.byref(nd))
@@ -412,6 +424,7 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask, 
         row_start = torch.zeros(int(height) + 1, dtype=torch.int64, device=ctx.device)
         row_start[1:] = torch.cumsum(torch.bincount(rows, minlength=int(height)), 0)
         d_indptr, d_indices = ctx.to_device(indptr, np.int64), ctx.to_device(indices, np.int32)
+        mark('neighbour lists to the device')
         # the grid centres that are wanted, in row-major order (the walk from one to the next is a step or two)
         wanted = np.ones((grid.ny, grid.nx), dtype=bool) if target_mask is None else ~to_host(target_mask).astype(bool)
         sel = np.flatnonzero(wanted.ravel())
@@ -427,6 +440,7 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask, 
             assert rc == 0
             d_t, d_v, d_c, d_h = (ctx.to_device(a, a.dtype) for a in (targets, vertices, centroids, has_nb))
             d_sel = ctx.to_device(sel.astype(np.int64), np.int64)
+        mark('point location')
         if vertices_out is not None:
             tri_px = torch.full((grid.ny * grid.nx, 3), -1, dtype=torch.int64, device=ctx.device)
             if m:
@@ -457,12 +471,16 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask, 
             ctx.call('amt_cubic_gradients_csr', ptr(xy), n, ptr(d_indptr), ptr(d_indices), ptr(row_start), int(height), ptr(vals),
                      k, CUBIC_TOLERANCE, CUBIC_MAX_SWEEPS, ptr(grad), sweeps)
             sweeps_all.extend(int(v) for v in sweeps)
+            mark('relaxation (%d sweeps)' % max(sweeps))
             if m:
                 part = ctx.empty((m, k))
                 ctx.call('amt_cubic_eval', m, ptr(d_t), ptr(d_v), ptr(d_c), ptr(d_h), ptr(xy), ptr(vals), ptr(grad), k, ptr(part))
                 out[d_sel, c0:c0 + k] = part
+        mark('element')
     finally:
         L.amt_delaunay_destroy(handle)
+    if debug:
+        print('cubic_exact: ' + ', '.join('%s %.3f s' % (b[0], b[1] - a[1]) for a, b in zip(marks, marks[1:])))
     return out, sweeps_all
 
 
