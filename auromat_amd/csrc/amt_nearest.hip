@@ -817,6 +817,46 @@ __device__ __forceinline__ unsigned long long gs_bits(double v) {
     return v == v ? (unsigned long long)__double_as_longlong(v) : 0x7ff8000000000000ull;
 }
 
+// Everything a point's update needs is fetched ONE POINT AHEAD, while the current point is being worked on: its neighbours'
+// indices, edge vectors, values, previous gradients — and this sweep's gradients of the neighbours in earlier rows (the
+// hand-overs).  A row runs a few points behind the row above it, so those are usually final by then; one that still shows the
+// marker is read again when its turn comes.  The sweep's critical path is (row length + lag x rows) steps long; with the
+// device-scope loads issued at the step itself a step took 10 us (their round trip), fetched ahead it is the arithmetic.
+constexpr int kGsPre = 8;           // neighbours fetched ahead (a lattice point has 6; hull points with more take the slow way)
+struct gs_point {
+    long long b, e;
+    int j[kGsPre];
+    double ex[kGsPre], ey[kGsPre], fj[kGsPre], y0[kGsPre], y1[kGsPre];
+    unsigned long long r0[kGsPre], r1[kGsPre];       // this sweep's components of neighbours in earlier rows, or the marker
+    double fi, g0, g1, xi, yi;
+};
+
+__device__ __forceinline__ void gs_fetch(const gs_args& A, long long v, long long v0, int lane, bool live, gs_point& P) {
+    P.b = A.indptr[v], P.e = A.indptr[v + 1];
+    const long long o = (v * A.nchan + lane) * 2;
+    P.g0 = A.y_old[o], P.g1 = A.y_old[o + 1];
+    if (!live) return;
+    P.xi = A.xy[2 * v], P.yi = A.xy[2 * v + 1], P.fi = A.values[v * A.nchan + lane];
+#pragma unroll
+    for (int t = 0; t < kGsPre; ++t) {
+        P.j[t] = -1;
+        P.r0[t] = P.r1[t] = kGsMarker;
+        if (P.b + t < P.e) {
+            const long long j = A.indices[P.b + t];
+            P.j[t] = (int)j;
+            P.ex[t] = A.xy[2 * j] - P.xi, P.ey[t] = A.xy[2 * j + 1] - P.yi;
+            P.fj[t] = A.values[j * A.nchan + lane];
+            if (j > v) {
+                P.y0[t] = A.y_old[(j * A.nchan + lane) * 2], P.y1[t] = A.y_old[(j * A.nchan + lane) * 2 + 1];
+            } else if (j < v0) {
+                const unsigned long long* q = A.y_new + (j * A.nchan + lane) * 2;
+                P.r0[t] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                P.r1[t] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
     const int lane = threadIdx.x;
     int row = 0;
@@ -826,59 +866,65 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
     const long long v0 = A.row_start[row], v1 = A.row_start[row + 1];
     const bool chan = lane < A.nchan;
     const bool live = chan && A.active[lane] != 0;
+    if (!chan || v0 >= v1) return;
     double worst = 0;
-    double p0 = 0, p1 = 0;                        // this wave's previous point's new gradient
+    // this wave's latest two points' new gradients (neighbours in the own row are the previous one or two points)
+    double p0 = 0, p1 = 0, pp0 = 0, pp1 = 0;
+    gs_point cur, nxt;
+    gs_fetch(A, v0, v0, lane, live, cur);
     for (long long v = v0; v < v1; ++v) {
-        if (!chan) break;
-        const long long b = A.indptr[v], e = A.indptr[v + 1];
+        if (v + 1 < v1) gs_fetch(A, v + 1, v0, lane, live, nxt);      // in flight while this point is worked on
         const long long o = (v * A.nchan + lane) * 2;
-        double g0 = A.y_old[o], g1 = A.y_old[o + 1];
+        double g0 = cur.g0, g1 = cur.g1;
         if (live) {
-            const double xi = A.xy[2 * v], yi = A.xy[2 * v + 1], fi = A.values[v * A.nchan + lane];
             double q0 = 0, q1 = 0, q3 = 0, s0 = 0, s1 = 0;
-            for (long long kb = b; kb < e; kb += 8) {
-                // the loads of up to eight neighbours are issued together, then waited for one by one
-                unsigned long long r0[8], r1[8];
-                const int cnt = (int)((e - kb) < 8 ? (e - kb) : 8);
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    r0[t] = r1[t] = 0;
-                    if (t < cnt) {
-                        const long long j = A.indices[kb + t];
-                        if (j < v && j != v - 1) {
-                            const unsigned long long* q = A.y_new + (j * A.nchan + lane) * 2;
-                            r0[t] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            r1[t] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
+            auto add = [&](double ex, double ey, double fj, double y0, double y1) {
+                const double l = sqrt(ex * ex + ey * ey), l3 = l * l * l;
+                const double df2 = -ex * y0 - ey * y1;
+                q0 += 4 * ex * ex / l3;
+                q1 += 4 * ex * ey / l3;
+                q3 += 4 * ey * ey / l3;
+                const double tt = (6 * (cur.fi - fj) - 2 * df2) / l3;
+                s0 += tt * ex;
+                s1 += tt * ey;
+            };
+            // a neighbour with a smaller index in this wave's own row: the previous point or the one before it come from
+            // registers, anything older from the array (written by this wave: visible to it)
+            auto own = [&](long long j, double& y0, double& y1) {
+                if (j == v - 1) {
+                    y0 = p0, y1 = p1;
+                } else if (j == v - 2) {
+                    y0 = pp0, y1 = pp1;
+                } else {
+                    y0 = gs_read(A.y_new + (j * A.nchan + lane) * 2, A.err + 63), y1 = gs_read(A.y_new + (j * A.nchan + lane) * 2 + 1, A.err + 63);
                 }
+            };
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    if (t >= cnt) continue;
-                    const long long j = A.indices[kb + t];
-                    double y0, y1;
-                    if (j > v) {
-                        y0 = A.y_old[(j * A.nchan + lane) * 2], y1 = A.y_old[(j * A.nchan + lane) * 2 + 1];
-                    } else if (j == v - 1 && v > v0) {
-                        y0 = p0, y1 = p1;                         // written by this wave a moment ago
-                    } else if (j == v - 1) {
-                        // the last point of an earlier row
-                        y0 = gs_read(A.y_new + (j * A.nchan + lane) * 2, A.err + 63), y1 = gs_read(A.y_new + (j * A.nchan + lane) * 2 + 1, A.err + 63);
-                    } else {
-                        const unsigned long long* q = A.y_new + (j * A.nchan + lane) * 2;
-                        y0 = r0[t] == kGsMarker ? gs_read(q, A.err + 63) : __longlong_as_double((long long)r0[t]);
-                        y1 = r1[t] == kGsMarker ? gs_read(q + 1, A.err + 63) : __longlong_as_double((long long)r1[t]);
-                    }
-                    const double ex = A.xy[2 * j] - xi, ey = A.xy[2 * j + 1] - yi;
-                    const double l = sqrt(ex * ex + ey * ey), l3 = l * l * l;
-                    const double df2 = -ex * y0 - ey * y1;
-                    q0 += 4 * ex * ex / l3;
-                    q1 += 4 * ex * ey / l3;
-                    q3 += 4 * ey * ey / l3;
-                    const double tt = (6 * (fi - A.values[j * A.nchan + lane]) - 2 * df2) / l3;
-                    s0 += tt * ex;
-                    s1 += tt * ey;
+            for (int t = 0; t < kGsPre; ++t) {
+                const long long j = cur.j[t];
+                if (j < 0) continue;
+                double y0 = cur.y0[t], y1 = cur.y1[t];                 // j > v: the previous sweep's
+                if (j < v0) {
+                    const unsigned long long* q = A.y_new + (j * A.nchan + lane) * 2;
+                    y0 = cur.r0[t] == kGsMarker ? gs_read(q, A.err + 63) : __longlong_as_double((long long)cur.r0[t]);
+                    y1 = cur.r1[t] == kGsMarker ? gs_read(q + 1, A.err + 63) : __longlong_as_double((long long)cur.r1[t]);
+                } else if (j < v) {
+                    own(j, y0, y1);
                 }
+                add(cur.ex[t], cur.ey[t], cur.fj[t], y0, y1);
+            }
+            // more neighbours than were fetched ahead (hull points): one by one
+            for (long long k = cur.b + kGsPre; k < cur.e; ++k) {
+                const long long j = A.indices[k];
+                double y0, y1;
+                if (j > v) {
+                    y0 = A.y_old[(j * A.nchan + lane) * 2], y1 = A.y_old[(j * A.nchan + lane) * 2 + 1];
+                } else if (j >= v0) {
+                    own(j, y0, y1);
+                } else {
+                    y0 = gs_read(A.y_new + (j * A.nchan + lane) * 2, A.err + 63), y1 = gs_read(A.y_new + (j * A.nchan + lane) * 2 + 1, A.err + 63);
+                }
+                add(A.xy[2 * j] - cur.xi, A.xy[2 * j + 1] - cur.yi, A.values[j * A.nchan + lane], y0, y1);
             }
             const double det = q0 * q3 - q1 * q1;
             const double r0_ = (q3 * s0 - q1 * s1) / det, r1_ = (-q1 * s0 + q0 * s1) / det;
@@ -887,9 +933,11 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
             if (change == change) worst = fmax(worst, change);
             g0 = -r0_, g1 = -r1_;
         }
+        pp0 = p0, pp1 = p1;
         p0 = g0, p1 = g1;
         __hip_atomic_store(A.y_new + o, gs_bits(g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(A.y_new + o + 1, gs_bits(g1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur = nxt;
     }
     if (live && worst > 0) atomicMax(&A.err[lane], (unsigned long long)__double_as_longlong(worst));
 }
