@@ -1,0 +1,138 @@
+// Store-pattern microbenchmark for the row kernel's outputs (round 5): the real launch shape (177 rows of work items x 68 strips of
+// 63 pixel columns, 16 pixel rows per item, 4 strips per workgroup, five arrays of doubles), a tunable amount of dependent FP64
+// work per row in place of the ray cast, and two ways of writing a row:
+//   A  every wave writes its own 63 x 8-byte run into each of the five arrays (what k_georef_rows does)
+//   B  the four waves of a workgroup stage their values in LDS; after a barrier wave w writes the workgroup's whole
+//      252-pixel run (2016 bytes) of array w (the fifth array is split over the four waves)
+// beside the work alone and the stores spread over a row's work, at full occupancy and at the real kernel's four waves per SIMD.
+// usage (GPU box): hipcc -O3 --offload-arch=gfx950 -o /tmp/store_pattern tools/store_pattern.hip && /tmp/store_pattern
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+constexpr int W = 4240, H = 2832, ROWS = 16, STRIPS = 68, CHUNKS = 177, NARR = 5;
+
+__device__ __forceinline__ double work(double x, int spin) {
+    // eight independent chains of FP64 multiply-adds: issue-bound at four waves per SIMD, as a row of the real kernel is
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = x + k;
+    for (int i = 0; i < spin; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = __builtin_fma(a[k], 0.9999999, 1e-7);
+    }
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+// MODE 0: A, stores at the end of a row   1: B, staged   2: no stores (the work alone)   3: A with the five stores spread over the row's work
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pattern(double* __restrict__ a0, double* __restrict__ a1, double* __restrict__ a2,
+                                                 double* __restrict__ a3, double* __restrict__ a4, int spin, int first_earth_chunk, int stride) {
+    __shared__ double stage[2][NARR][4 * 63 + 4];
+    extern __shared__ double occupancy_limiter[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    const int chunk_in_order = item / STRIPS, strip = item - chunk_in_order * STRIPS;
+    const int chunk = chunk_in_order * stride % CHUNKS;     // stride 1: sky first, then Earth; 76: the two kinds alternate
+    const int x0 = strip * 63, y0 = chunk * ROWS;
+    const int gx = x0 + lane;
+    const bool ok = lane < 63 && gx < W;
+    double* arr[NARR] = {a0, a1, a2, a3, a4};
+    if (spin < 0) occupancy_limiter[threadIdx.x] = 0.0;          // (keeps the dynamic allocation alive; never taken)
+    if (chunk < first_earth_chunk) {
+        // "sky": contiguous fill of the chunk's rows, 16 bytes per lane (as the real kernel's sky path)
+        const long long first = (long long)y0 * W, count = (long long)ROWS * W;
+        for (int k = 0; k < NARR; ++k) {
+            long long a = first + count * strip / STRIPS, b = first + count * (strip + 1) / STRIPS;
+            a &= ~1ll, b &= ~1ll;
+            const double2 two = {1.0, 2.0};
+            for (long long i = a + 2 * lane; i + 1 < b; i += 128) *reinterpret_cast<double2*>(arr[k] + i) = two;
+        }
+        return;
+    }
+    double v = (double)gx;
+    for (int r = 0; r < ROWS && y0 + r < H; ++r) {
+        const long long row = (long long)(y0 + r) * W;
+        if (MODE == 3) {
+            for (int k = 0; k < NARR; ++k) {
+                v = work(v, spin / NARR);
+                if (ok) arr[k][row + gx] = v + k;
+            }
+            continue;
+        }
+        v = work(v, spin);
+        if (MODE == 0) {
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < NARR; ++k) arr[k][row + gx] = v + k;
+            }
+        } else if (MODE == 2) {
+            if (ok && v == 12345.678) arr[0][row + gx] = v;      // never true: the work stays live, nothing is written
+        } else {
+            const int buf = r & 1;
+            if (lane < 63) {
+#pragma unroll
+                for (int k = 0; k < NARR; ++k) stage[buf][k][wave * 63 + lane] = v + k;
+            }
+            __syncthreads();
+            // the workgroup's run: pixels [gx0, gx0 + 252) of this row
+            const int gx0 = (blockIdx.x * 4 - chunk_in_order * STRIPS) * 63;
+            const int n = min(252, W - gx0);
+            auto put = [&](int k, int from, int to) {            // elements [from, to) of array k's run, 2 per lane per pass
+                for (int i = from + 2 * lane; i < to; i += 128) {
+                    arr[k][row + gx0 + i] = stage[buf][k][i];
+                    if (i + 1 < to) arr[k][row + gx0 + i + 1] = stage[buf][k][i + 1];
+                }
+            };
+            put(wave, 0, n);
+            put(4, wave * 63, min(n, wave * 63 + 63));
+        }
+    }
+}
+
+template <int MODE>
+static float run(double** a, int spin, int sky, unsigned lds, int stride) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const int blocks = CHUNKS * STRIPS / 4, reps = 12;
+    float sum = 0;
+    for (int rep = 0; rep < reps + 2; ++rep) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_pattern<MODE>, dim3(blocks), dim3(256), lds, 0, a[0], a[1], a[2], a[3], a[4], spin, sky, stride);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 2) sum += ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return sum / reps * 1e3f;
+}
+
+int main() {
+    const size_t n = (size_t)W * H;
+    double* a[NARR];
+    for (int k = 0; k < NARR; ++k) (void)hipMalloc(&a[k], n * sizeof(double));
+    const int sky = (int)(0.43 * CHUNKS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pattern<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pattern<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pattern<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pattern<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    std::printf("five arrays of %d x %d doubles = %.1f MB; %d of %d rows of work items are sky\n", W, H, NARR * n * 8 / 1e6, sky, CHUNKS);
+    std::printf("all sky (contiguous fill): %.1f us\n", run<0>(a, 0, CHUNKS + 1, 0, 1));
+    for (int stride : {1, 76})
+        for (unsigned lds : {0u, 28000u}) {                      // 28000 + 10 KB static: four workgroups = four waves per SIMD
+            std::printf("%s, dynamic LDS %u bytes per workgroup\n", stride == 1 ? "sky rows first" : "sky and Earth rows alternate", lds);
+            std::printf("  spin | work alone | A at row end | A spread | B staged  (us)\n");
+            for (int spin : {0, 10, 20, 25, 30, 35, 40, 50, 60}) {
+                const float w = run<2>(a, spin, sky, lds, stride), s0 = run<0>(a, spin, sky, lds, stride),
+                            s3 = run<3>(a, spin, sky, lds, stride), s1 = run<1>(a, spin, sky, lds, stride);
+                std::printf("  %4d | %10.1f | %12.1f | %8.1f | %8.1f\n", spin, w, s0, s3, s1);
+            }
+        }
+    return 0;
+}
