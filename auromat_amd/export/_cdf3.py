@@ -57,7 +57,9 @@ _LITTLE = (4, 6, 13, 16, 17, 19)                      # DECSTATION, IBMPC, ALPHA
 _BIG = (1, 2, 5, 7, 9, 11, 12, 18)                    # NETWORK, SUN, SGi, IBMRS, PPC, HP, NeXT, ARM_BIG
 GZIP_COMPRESSION = 5
 _VXR_ENTRIES = 7
-_GZIP_THREADS = max(1, min(16, int(os.environ.get('AMT_NC4_THREADS', '0')) or (os.cpu_count() or 1)))
+# native threads that deflate the blocks of one large record (AMT_IO_THREADS; AMT_NC4_THREADS, the netCDF-4 writer's switch, is
+# honoured too: both writers share the helper and its thread budget)
+_GZIP_THREADS = max(1, min(16, int(os.environ.get('AMT_IO_THREADS', os.environ.get('AMT_NC4_THREADS', '0'))) or (os.cpu_count() or 1)))
 _LEAP_TABLE_DATE = 20170101
 
 # TAI - UTC in whole seconds from the given day on (IERS Bulletin C; the table the CDF library carries for TT2000)
@@ -142,6 +144,8 @@ def infer(value, tt2000=True):
         t = _int_type(min(vals), max(vals))
         return t, len(vals), np.array(vals, '<' + _KIND[t]).tobytes()
     a = np.atleast_1d(np.asarray(value))
+    if a.size == 0:
+        raise ValueError('a CDF entry cannot be empty (%r)' % (value,))
     if a.dtype.kind == 'b':
         a = a.astype('u1')
     if a.dtype.kind in 'SU' or a.dtype.kind == 'O':
@@ -152,11 +156,47 @@ def infer(value, tt2000=True):
     return _OF_DTYPE[key], a.size, np.ascontiguousarray(a, dtype='<' + key).tobytes()
 
 
+def _entries_of(value, tt2000):
+    """one attribute value -> its entries [(type, n, bytes)] (a list of texts: one entry per text, as pycdf)"""
+    if isinstance(value, (list, tuple)) and value and all(isinstance(s, (str, bytes)) for s in value):
+        return [infer(s, tt2000) for s in value]
+    return [infer(value, tt2000)]
+
+
+class _Attrs(OrderedDict):
+    """Attributes of the file (scope 1) or of one variable (scope 2).  A value is checked when it is assigned — not in
+    ``write``, after every variable has been compressed —: its name's length, that the name is not in use in the other scope
+    (a CDF attribute is either global or of variable scope), that the value has a CDF type and is not empty, and, for a
+    variable, that it is ONE entry (a variable has one entry per attribute; a list of texts would need several)."""
+
+    def __init__(self, writer, scope):
+        OrderedDict.__init__(self)
+        self._writer, self._scope = writer, scope
+
+    def __setitem__(self, key, value):
+        w = self._writer
+        if len(key.encode('utf-8')) > 255:
+            raise ValueError('attribute names are at most 255 bytes long')
+        if self._scope == 1:
+            clash = any(key in v.attrs for v in w.vars.values())
+        else:
+            clash = key in w.attrs
+        if clash:
+            raise ValueError('an attribute name is either global or of variable scope: %s' % key)
+        entries = _entries_of(value, w.tt2000)
+        if self._scope == 2 and len(entries) != 1:
+            raise ValueError('a variable has ONE entry per attribute: %s = %r' % (key, value))
+        OrderedDict.__setitem__(self, key, value)
+
+    def __reduce__(self):                                   # (OrderedDict's would call __init__ without arguments)
+        return (OrderedDict, (list(self.items()),))
+
+
 class Var(object):
-    def __init__(self, name, cdf_type, n_elems, dims, rec_vary, records, compress):
+    def __init__(self, name, cdf_type, n_elems, dims, rec_vary, records, compress, writer=None):
         self.name, self.type, self.n_elems, self.dims = name, cdf_type, n_elems, tuple(int(d) for d in dims)
         self.rec_vary, self.records, self.compress = rec_vary, records, compress
-        self.attrs = OrderedDict()
+        self.attrs = _Attrs(writer, 2) if writer is not None else OrderedDict()
 
 
 class Writer(object):
@@ -167,17 +207,18 @@ class Writer(object):
     def __init__(self, tt2000=True, pool=None):
         """``pool``: a ``concurrent.futures`` executor; a large compressed variable then starts to compress when it is created
         (``new``), beside whatever the caller does to prepare the next one, and ``write`` collects the streams."""
-        self.attrs = OrderedDict()
         self.vars = OrderedDict()
         self.tt2000 = tt2000
         self.pool = pool
+        self.attrs = _Attrs(self, 1)
 
     def __getitem__(self, name):
         return self.vars[name]
 
     def new(self, name, data, type=None, recVary=True, compress=None, compress_param=5):
         """``data``: with ``recVary`` the first axis counts the records (as in pycdf), without it the whole array is the one
-        record.  ``compress``: None or GZIP_COMPRESSION with level ``compress_param`` (pycdf's default: 5)."""
+        record.  ``compress``: None or GZIP_COMPRESSION with level ``compress_param`` (pycdf's default: 5).  An array that
+        already has the variable's type and layout is NOT copied: it must not change until ``write`` has returned."""
         if name in self.vars:
             raise KeyError('variable %s exists' % name)
         if len(name.encode('utf-8')) > 255:
@@ -218,7 +259,7 @@ class Writer(object):
         if compress not in (None, 0, GZIP_COMPRESSION):
             raise ValueError('only GZIP compression is written')
         v = self.vars[name] = Var(name, type, 1, dims, bool(recVary), records,
-                                  int(compress_param) if compress == GZIP_COMPRESSION else None)
+                                  int(compress_param) if compress == GZIP_COMPRESSION else None, writer=self)
         v.blocks = None
         if self.pool is not None and v.compress is not None and records.nbytes >= (1 << 22):
             v.blocks = self.pool.submit(_blocks_of, v)           # (`data` must not change until write())
@@ -237,17 +278,10 @@ class Writer(object):
                 if k not in seen:
                     seen.add(k)
                     attr_names.append((k, 2))
-        for k, _ in attr_names:
-            if len(k.encode('utf-8')) > 255:
-                raise ValueError('attribute names are at most 255 bytes long')
-        if len(set(self.attrs) & seen):
-            raise ValueError('an attribute name is either global or of variable scope: %s' % sorted(set(self.attrs) & seen))
+        # (names, scopes and values were checked when they were assigned: _Attrs)
 
         def entries_of(value):
-            """one attribute value -> its entries [(type, n, bytes)] (a list of texts: one entry per text, as pycdf)"""
-            if isinstance(value, (list, tuple)) and value and all(isinstance(s, (str, bytes)) for s in value):
-                return [infer(s, self.tt2000) for s in value]
-            return [infer(value, self.tt2000)]
+            return _entries_of(value, self.tt2000)
 
         # variable data first (sizes of the compressed blocks are needed for the addresses)
         pool = pool or self.pool
@@ -266,7 +300,7 @@ class Writer(object):
                 ent = [(i, e) for i, e in enumerate(entries_of(self.attrs[k]))]
             else:
                 ent = [(vi, e) for vi, nm in enumerate(names) if k in self.vars[nm].attrs
-                       for e in entries_of(self.vars[nm].attrs[k])[:1]]
+                       for e in entries_of(self.vars[nm].attrs[k])]
             attr_entries.append(ent)
             for j, (_, (t, n, raw)) in enumerate(ent):
                 pieces.append(('aedr', num, j, 56 + len(raw)))
@@ -348,9 +382,8 @@ class Writer(object):
 
 def _blocks_of(v):
     """the records of a variable as the blocks its VXR lists: [(first record, last record, record type, bytes)]"""
-    raw = v.records.tobytes()
     if v.compress is None:
-        return [(0, v.records.shape[0] - 1, _VVR, raw)]
+        return [(0, v.records.shape[0] - 1, _VVR, v.records.tobytes())]
     per = v.records[0].nbytes
     out = []
     for r in range(v.records.shape[0]):                      # blocking factor 1: one gzip stream per record
@@ -361,7 +394,7 @@ def _blocks_of(v):
             z = _io.gzip_parallel(v.records[r], v.compress, _GZIP_THREADS)
         if z is None:
             c = _zlib.compressobj(v.compress, _zlib.DEFLATED, 31)
-            z = c.compress(raw[r * per:(r + 1) * per]) + c.flush()
+            z = c.compress(np.ascontiguousarray(v.records[r]).data) + c.flush()       # (no copy of the record)
         out.append((r, r, _CVVR, z))
     return out
 

@@ -7,6 +7,7 @@ they take when the helper cannot be built or loaded (``AMT_IO_HELPER=0`` forces 
 import ctypes as C
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -14,6 +15,27 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'amt_io.cpp')
 LIB_PATH = os.path.join(_PKG, 'lib', 'libauromat_io.so')
 _lib = []
+# native jobs running right now (several writer threads x several variables each can call in at once): every job gets its share
+# of the requested threads instead of all of them, so that a process stays near `threads` native threads in total
+_active = [0]
+_active_lock = threading.Lock()
+
+
+class _share(object):
+    """with _share(threads) as n: n = max(1, threads // jobs running, this one included)"""
+
+    def __init__(self, threads):
+        self.threads = int(threads)
+
+    def __enter__(self):
+        with _active_lock:
+            _active[0] += 1
+            return max(1, self.threads // _active[0])
+
+    def __exit__(self, *exc):
+        with _active_lock:
+            _active[0] -= 1
+        return False
 
 
 def build(force=False):
@@ -65,8 +87,9 @@ def deflate_rows(a, level, shuffle, threads):
     stride = int(h.amt_io_deflate_bound(chunk_bytes))
     out = np.empty((n, stride), np.uint8)
     sizes = np.empty(n, np.int64)
-    rc = h.amt_io_deflate_chunks(a.ctypes.data, n, chunk_bytes, a.dtype.itemsize, level, 1 if shuffle else 0, out.ctypes.data, stride,
-                                 sizes.ctypes.data, threads)
+    with _share(threads) as nt:
+        rc = h.amt_io_deflate_chunks(a.ctypes.data, n, chunk_bytes, a.dtype.itemsize, level, 1 if shuffle else 0, out.ctypes.data,
+                                     stride, sizes.ctypes.data, nt)
     if rc != 0:
         raise RuntimeError('zlib error %d' % rc)
     return [out[i, :sizes[i]].tobytes() for i in range(n)]
@@ -82,7 +105,8 @@ def gzip_parallel(a, level, threads, block_bytes=1 << 20):
     cap = int(h.amt_io_gzip_bound(n, block_bytes))
     out = np.empty(cap, np.uint8)
     out_len = C.c_int64(0)
-    rc = h.amt_io_gzip_parallel(a.ctypes.data, n, level, block_bytes, out.ctypes.data, cap, C.byref(out_len), threads)
+    with _share(threads) as nt:
+        rc = h.amt_io_gzip_parallel(a.ctypes.data, n, level, block_bytes, out.ctypes.data, cap, C.byref(out_len), nt)
     if rc != 0:
         raise RuntimeError('zlib error %d' % rc)
     return out[:out_len.value].tobytes()

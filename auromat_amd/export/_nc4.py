@@ -28,8 +28,10 @@ UNDEF = 0xFFFFFFFFFFFFFFFF
 _GROUP_K = 16            # group B-tree K (internal) — one node with one child is all this writer makes
 _CHUNK_K = 32            # chunk B-tree K: the library's default for superblock version 0 (which has no field for it)
 _DEFLATE_LEVEL = 4       # netCDF4-python's default complevel
-# threads that compress the chunks of a large array (deflate releases the interpreter lock); AMT_NC4_THREADS overrides
-_THREADS = max(1, min(16, int(os.environ.get('AMT_NC4_THREADS', '0')) or (os.cpu_count() or 1)))
+# threads that compress the chunks of a large array (deflate releases the interpreter lock); AMT_IO_THREADS / AMT_NC4_THREADS
+# override.  Native jobs that run at the same time share this number (_io._share): four writer threads with several variables
+# each stay near it instead of multiplying it.
+_THREADS = max(1, min(16, int(os.environ.get('AMT_IO_THREADS', os.environ.get('AMT_NC4_THREADS', '0'))) or (os.cpu_count() or 1)))
 _ROWS_PER_TASK = 32      # chunks of one row: rows a task shuffles at once (one NumPy copy) and then deflates one by one
 _POOL = []
 

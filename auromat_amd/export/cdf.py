@@ -33,6 +33,9 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
     :param bool includeGeoCoords: include geodetic coordinates
     :param bool compress: use (GZIP) compression for variables
     :param bool useTT2000: CDF_TIME_TT2000 for times (else CDF_EPOCH); needs CDF 3.4.0 or higher for reading
+
+    The mapping's arrays are read while this call runs, partly on other threads (large variables start to compress when they
+    are created): do not change them from another thread before it returns.
     """
     z = _cdf3.GZIP_COMPRESSION if compress else None
     root = _cdf3.Writer(tt2000=bool(useTT2000), pool=_pool() if compress else None)

@@ -45,6 +45,10 @@ def write(outputPath, mapping, metadata={}, includeBounds=True, includeMagCoords
                        per chunk —, written by :mod:`auromat_amd.export._nc4`) or 'NETCDF3_64BIT' (classic format with 64-bit
                        offsets, :mod:`auromat_amd.export._nc3`: no compression, no chunking; what
                        :class:`auromat_amd.mapping.netcdf.NetCDFMapping` reads)
+
+    The mapping's arrays are read while this call runs, partly on other threads (large arrays start to compress as soon as
+    they have been handed to the writer): do not change them from another thread before it returns.  ``AMT_IO_THREADS`` (or
+    ``AMT_NC4_THREADS``) bounds the native threads of a process, whatever the number of files being written at once.
     """
     if not includeGeoCoords:
         raise ValueError('Geodetic coordinates cannot be disabled for netCDF as they are essential to the format')

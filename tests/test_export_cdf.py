@@ -311,3 +311,94 @@ def test_large_records_are_one_gzip_member_made_in_blocks(tmp_path):
     for n in (0, 1, (1 << 16) + 3):
         b = rs.randint(0, 255, n).astype(np.uint8)
         assert gzip.decompress(_io.gzip_parallel(b, 5, 3, 1 << 16)) == b.tobytes()
+
+
+def test_attribute_values_are_checked_when_they_are_assigned():
+    """ a variable-scope attribute is ONE entry, an entry is never empty, a name lives in one scope — and all of it
+    is refused at the assignment, not after the variables have been compressed."""
+    from auromat_amd.export import _cdf3 as C
+    w = C.Writer()
+    v = w.new('a', np.arange(4.0))
+    w.attrs['Title'] = ['two', 'entries']                    # global: one entry per text, as pycdf
+    v.attrs['UNITS'] = 'deg'
+    with pytest.raises(ValueError):
+        v.attrs['Notes'] = ['first', 'second']               # (was: the second text dropped silently)
+    with pytest.raises(ValueError):
+        v.attrs['Empty'] = []
+    with pytest.raises(ValueError):
+        w.attrs['Empty'] = np.zeros(0)
+    with pytest.raises(ValueError):
+        w.attrs['UNITS'] = 'x'                               # already of variable scope
+    with pytest.raises(ValueError):
+        v.attrs['Title'] = 'x'                               # already global
+    with pytest.raises(ValueError):
+        v.attrs['n' * 256] = 1
+    with pytest.raises(TypeError):
+        v.attrs['Obj'] = object()
+    assert list(v.attrs) == ['UNITS'] and list(w.attrs) == ['Title']
+    assert C.infer([1, 2, 3])[1] == 3
+
+
+def test_large_variables_compress_early_to_the_same_bytes(tmp_path, monkeypatch):
+    """ Arrays of 4 MiB or more start to compress when they are handed over (`Writer.new` with a pool; `Variable.set`
+    of the netCDF-4 writer) — the files must be the bytes of the late path, with the native helper and without it."""
+    from concurrent.futures import ThreadPoolExecutor
+    from auromat_amd.export import _cdf3 as C, _io, _nc4
+    rs = np.random.RandomState(3)
+    big = np.cumsum(rs.rand(3, 420, 500), axis=2)                      # three records of 1.7 MB: 5 MB, early path, zlib per record
+    huge = np.cumsum(rs.rand(1, 800, 700), axis=2)                     # one record of 4.5 MB: the helper's blocks
+    small = big[:, :7]
+
+    def cdf(path, pool):
+        w = C.Writer(pool=pool)
+        w.attrs['Title'] = 'early / late'
+        for name, a in (('big', big), ('huge', huge), ('small', small)):
+            w.new(name, a, compress=C.GZIP_COMPRESSION).attrs['UNITS'] = 'deg'
+        assert (w['big'].blocks is not None) == (pool is not None) and w['small'].blocks is None
+        w.write(path)
+        return open(path, 'rb').read()
+
+    def nc(path):
+        w = _nc4.Writer()
+        w.create_dimension('y', 1300)
+        w.create_dimension('x', 500)
+        v = w.create_variable('a', 'f8', ('y', 'x'), zlib=True, chunksizes=(1, 500))
+        v.set(np.cumsum(rs.rand(1300, 500), axis=1))                     # 5.2 MB
+        early = v.early is not None
+        w.create_variable('b', 'i2', ('y', 'x'), zlib=True, chunksizes=(1, 500), fill_value=-1).set(rs.randint(0, 99, (1300, 500)))
+        w.write(path)
+        return early, open(path, 'rb').read()
+
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        with_pool = cdf(str(tmp_path / 'a.cdf'), pool)
+    without_pool = cdf(str(tmp_path / 'b.cdf'), None)
+    assert with_pool == without_pool
+    r = C.Reader(str(tmp_path / 'a.cdf'))
+    assert np.array_equal(r['big'].data, big) and np.array_equal(r['huge'].data, huge)
+    rs = np.random.RandomState(4)
+    early, nc_with = nc(str(tmp_path / 'a.nc'))
+    assert early
+    helper = _io.lib() is not None
+    monkeypatch.setattr(_io, '_lib', [None])                           # AMT_IO_HELPER=0
+    assert _io.lib() is None
+    python_only = cdf(str(tmp_path / 'c.cdf'), None)
+    # (the helper cuts a large record into blocks — another, equally valid gzip member; everything else is byte for byte)
+    r2 = C.Reader(str(tmp_path / 'c.cdf'))
+    assert np.array_equal(r2['huge'].data, huge) and np.array_equal(r2['big'].data, big)
+    assert helper or python_only == with_pool
+    rs = np.random.RandomState(4)
+    _, nc_without = nc(str(tmp_path / 'b.nc'))
+    assert nc_with == nc_without
+
+
+def test_native_jobs_share_the_thread_budget():
+    from auromat_amd.export import _io
+    with _io._share(16) as a:
+        assert a == 16
+        with _io._share(16) as b:
+            assert b == 8
+            with _io._share(3) as c:
+                assert c == 1
+        with _io._share(16) as d:
+            assert d == 8
+    assert _io._active[0] == 0
