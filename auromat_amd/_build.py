@@ -21,13 +21,35 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 
 
+def _deps():
+    return sources() + [os.path.join(CSRC, 'amt_common.h'), os.path.join(CSRC, 'amt_grid.h'), os.path.join(CSRC, 'amt_params.h'),
+                        os.path.join(os.path.dirname(PKG_DIR), 'include', 'auromat_hip.h')]
+
+
+def sources_hash():
+    """sha256 over the library's sources (names and contents) and the compiler flags"""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for d in _deps():
+        h.update(os.path.basename(d).encode() + b'\0')
+        with open(d, 'rb') as fp:
+            h.update(fp.read())
+    return h.hexdigest()
+
+
 def needs_build():
+    """The library is current when the hash recorded beside it at build time (``<library>.src``) is that of the sources — file
+    times do not survive a copy of the tree to another machine in any particular order.  A library without that record (built
+    by hand, ``tools/build_variant.sh``) falls back to the file times."""
     if not os.path.exists(LIB_PATH):
         return True
+    try:
+        with open(LIB_PATH + '.src') as fp:
+            return fp.read().strip() != sources_hash()
+    except OSError:
+        pass
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + [os.path.join(CSRC, 'amt_common.h'), os.path.join(CSRC, 'amt_grid.h'), os.path.join(CSRC, 'amt_params.h'),
-                        os.path.join(os.path.dirname(PKG_DIR), 'include', 'auromat_hip.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build(force=False, verbose=False):
@@ -35,6 +57,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    stamp = sources_hash()              # (of what is about to be compiled)
     tmp = LIB_PATH + '.tmp.%d' % os.getpid()
     # every source to an object of its own, a few at a time (the row kernel's file takes most of the time, the others
     # compile beside it), then one link
@@ -69,6 +92,9 @@ def build(force=False, verbose=False):
     finally:
         shutil.rmtree(objdir, ignore_errors=True)
     os.replace(tmp, LIB_PATH)
+    with open(LIB_PATH + '.src.tmp.%d' % os.getpid(), 'w') as fp:
+        fp.write(stamp + '\n')
+    os.replace(LIB_PATH + '.src.tmp.%d' % os.getpid(), LIB_PATH + '.src')
     return LIB_PATH
 
 
