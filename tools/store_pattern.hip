@@ -29,23 +29,25 @@ __device__ __forceinline__ double work(double x, int spin) {
 // MODE 0: A, stores at the end of a row   1: B, staged   2: no stores (the work alone)   3: A with the five stores spread over the row's work
 template <int MODE>
 __global__ __launch_bounds__(256) void k_pattern(double* __restrict__ a0, double* __restrict__ a1, double* __restrict__ a2,
-                                                 double* __restrict__ a3, double* __restrict__ a4, int spin, int first_earth_chunk, int stride) {
+                                                 double* __restrict__ a3, double* __restrict__ a4, int spin, int first_earth_chunk, int stride, int sw, int corner_pitch = W) {
     __shared__ double stage[2][NARR][4 * 63 + 4];
     extern __shared__ double occupancy_limiter[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wave;
-    const int chunk_in_order = item / STRIPS, strip = item - chunk_in_order * STRIPS;
+    const int strips = sw == 63 ? STRIPS : (W + sw - 1) / sw;
+    if (item >= CHUNKS * strips) return;
+    const int chunk_in_order = item / strips, strip = item - chunk_in_order * strips;
     const int chunk = chunk_in_order * stride % CHUNKS;     // stride 1: sky first, then Earth; 76: the two kinds alternate
-    const int x0 = strip * 63, y0 = chunk * ROWS;
+    const int x0 = strip * sw, y0 = chunk * ROWS;
     const int gx = x0 + lane;
-    const bool ok = lane < 63 && gx < W;
+    const bool ok = lane < sw && gx < W;
     double* arr[NARR] = {a0, a1, a2, a3, a4};
     if (spin < 0) occupancy_limiter[threadIdx.x] = 0.0;          // (keeps the dynamic allocation alive; never taken)
     if (chunk < first_earth_chunk) {
         // "sky": contiguous fill of the chunk's rows, 16 bytes per lane (as the real kernel's sky path)
         const long long first = (long long)y0 * W, count = (long long)ROWS * W;
         for (int k = 0; k < NARR; ++k) {
-            long long a = first + count * strip / STRIPS, b = first + count * (strip + 1) / STRIPS;
+            long long a = first + count * strip / strips, b = first + count * (strip + 1) / strips;
             a &= ~1ll, b &= ~1ll;
             const double2 two = {1.0, 2.0};
             for (long long i = a + 2 * lane; i + 1 < b; i += 128) *reinterpret_cast<double2*>(arr[k] + i) = two;
@@ -65,8 +67,10 @@ __global__ __launch_bounds__(256) void k_pattern(double* __restrict__ a0, double
         v = work(v, spin);
         if (MODE == 0) {
             if (ok) {
+                const long long crow = (long long)(y0 + r) * corner_pitch;
+                arr[0][crow + gx] = v, arr[1][crow + gx] = v + 1;
 #pragma unroll
-                for (int k = 0; k < NARR; ++k) arr[k][row + gx] = v + k;
+                for (int k = 2; k < NARR; ++k) arr[k][row + gx] = v + k;
             }
         } else if (MODE == 2) {
             if (ok && v == 12345.678) arr[0][row + gx] = v;      // never true: the work stays live, nothing is written
@@ -93,15 +97,15 @@ __global__ __launch_bounds__(256) void k_pattern(double* __restrict__ a0, double
 }
 
 template <int MODE>
-static float run(double** a, int spin, int sky, unsigned lds, int stride) {
+static float run(double** a, int spin, int sky, unsigned lds, int stride, int sw = 63, int corner_pitch = W) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    const int blocks = CHUNKS * STRIPS / 4, reps = 12;
+    const int blocks = (CHUNKS * (sw == 63 ? STRIPS : (W + sw - 1) / sw) + 3) / 4, reps = 12;
     float sum = 0;
     for (int rep = 0; rep < reps + 2; ++rep) {
         (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_pattern<MODE>, dim3(blocks), dim3(256), lds, 0, a[0], a[1], a[2], a[3], a[4], spin, sky, stride);
+        hipLaunchKernelGGL(k_pattern<MODE>, dim3(blocks), dim3(256), lds, 0, a[0], a[1], a[2], a[3], a[4], spin, sky, stride, sw, corner_pitch);
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
         float ms;
@@ -116,7 +120,7 @@ static float run(double** a, int spin, int sky, unsigned lds, int stride) {
 int main() {
     const size_t n = (size_t)W * H;
     double* a[NARR];
-    for (int k = 0; k < NARR; ++k) (void)hipMalloc(&a[k], n * sizeof(double));
+    for (int k = 0; k < NARR; ++k) (void)hipMalloc(&a[k], (n + (size_t)H + W + 64) * sizeof(double));
     const int sky = (int)(0.43 * CHUNKS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pattern<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pattern<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -133,6 +137,18 @@ int main() {
                             s3 = run<3>(a, spin, sky, lds, stride), s1 = run<1>(a, spin, sky, lds, stride);
                 std::printf("  %4d | %10.1f | %12.1f | %8.1f | %8.1f\n", spin, w, s0, s3, s1);
             }
+        }
+    // strips of 64 pixel columns: every run is 512 bytes and starts on a 512-byte boundary of a pixel array's row (4240 x 8 bytes
+    // per row = 66.25 runs: the rows themselves start on 64-byte boundaries only)
+    std::printf("sky and Earth rows alternate, four waves per SIMD: own runs of 63 columns (504 bytes) against 64 columns (512 bytes, aligned)\n");
+    std::printf("  spin | work alone 63 / 64 | A at row end 63 / 64  (us)\n");
+    for (int rep = 0; rep < 2; ++rep)
+        for (int spin : {0, 20, 30, 40}) {
+            const float w63 = run<2>(a, spin, sky, 28000u, 76, 63), w64 = run<2>(a, spin, sky, 28000u, 76, 64);
+            const float s63 = run<0>(a, spin, sky, 28000u, 76, 63), s64 = run<0>(a, spin, sky, 28000u, 76, 64);
+            const float c63 = run<0>(a, spin, sky, 28000u, 76, 63, W + 1), c64 = run<0>(a, spin, sky, 28000u, 76, 64, W + 1);
+            std::printf("  %4d | %8.1f / %8.1f | %8.1f / %8.1f | two of the five arrays at a pitch of W + 1 (corner arrays): %8.1f / %8.1f\n", spin,
+                        w63, w64, s63, s64, c63, c64);
         }
     return 0;
 }
