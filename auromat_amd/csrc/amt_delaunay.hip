@@ -13,11 +13,24 @@
 // Algorithm: incremental Bowyer-Watson with ghost triangles for the hull (no super-triangle: the hull is exact), points inserted
 // along a Hilbert curve (the previous point is a neighbour: the walk to the new point takes a step or two), orientation and in-circle tests in double precision behind Shewchuk's static error bounds with a binary128 evaluation
 // behind them (orientation: exact there; in-circle: to 1e-33 relative, and anything below ITS error bound counts as cocircular).
+//
+// Large point sets are built in parallel (build_parallel): the plane is cut into vertical strips of equal point counts, every strip
+// is triangulated by the algorithm above on a thread of its own, and neighbouring strips are joined the way divide-and-conquer
+// Delaunay algorithms join their halves — the lower and upper common tangents of the two hulls, the gap between the facing hull
+// chains filled by triangles that each take the next vertex of one chain, then Lawson's flips from the seam until every edge is
+// locally Delaunay again (a few per seam vertex).  The Delaunay triangulation is unique (see above), so the result is the
+// sequential one; the tests compare the two triangle for triangle.  AMT_DELAUNAY_THREADS (default: up to 8),
+// AMT_DELAUNAY_PARALLEL_MIN (points from which on the parallel build is used; default 200 000).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <exception>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/auromat_hip.h"
@@ -80,6 +93,30 @@ inline double incircle(const pt& a, const pt& b, const pt& c, const pt& d) {
     return 0.0;                                        // cocircular as far as 113 bits can tell
 }
 
+// f(j) for j = 0 .. parts - 1, each on a thread of its own (the calling thread takes part 0)
+// (an exception — std::bad_alloc — thrown on one of them is thrown again here, after all have ended)
+template <typename F>
+void on_threads(int parts, F f) {
+    std::vector<std::exception_ptr> failed((size_t)parts);
+    auto guarded = [&](int j) {
+        try {
+            f(j);
+        } catch (...) {
+            failed[(size_t)j] = std::current_exception();
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int j = 1; j < parts; ++j) pool.emplace_back(guarded, j);
+    } catch (...) {                                            // (no more threads to be had: the rest on this one)
+        for (int j = (int)pool.size() + 1; j < parts; ++j) guarded(j);
+    }
+    guarded(0);
+    for (auto& th : pool) th.join();
+    for (auto& e : failed)
+        if (e) std::rethrow_exception(e);
+}
+
 }  // namespace
 
 struct amt_delaunay {
@@ -94,6 +131,9 @@ struct amt_delaunay {
     std::vector<char> in_cavity;
     int last;                    // a live finite triangle near the latest point
     int n_dup;
+    int n_strips = 1;            // build_parallel: strips triangulated side by side, flips spent on joining them
+    int64_t n_flips = 0;
+    int n_threads = 1;           // threads compact() may use
     predicate_stats stats;       // of build()
     // compacted result
     std::vector<int> tri;        // 3 per finite triangle
@@ -247,6 +287,230 @@ struct amt_delaunay {
         return true;
     }
 
+    // ---- hull access through the ghosts: ghost (a, b, inf) is the hull edge a -> b with the outside on its left, i.e. the ring
+    // of ghosts runs CLOCKWISE round the hull
+    int inf_index(int t) const { return v[3 * t] == kInf ? 0 : (v[3 * t + 1] == kInf ? 1 : (v[3 * t + 2] == kInf ? 2 : -1)); }
+    int ghost_start(int g) const { return v[3 * g + (inf_index(g) + 1) % 3]; }
+    int ghost_end(int g) const { return v[3 * g + (inf_index(g) + 2) % 3]; }
+    int ghost_next(int g) const { return adj[3 * g + (inf_index(g) + 1) % 3]; }       // the ghost that starts where g ends
+    int ghost_prev(int g) const { return adj[3 * g + (inf_index(g) + 2) % 3]; }       // the ghost that ends where g starts
+    int ghost_inner(int g) const { return adj[3 * g + inf_index(g)]; }                // the finite triangle behind the hull edge
+    int slot_towards(int t, int n) const {                                            // k with adj[3t + k] == n
+        for (int k = 0; k < 3; ++k)
+            if (adj[3 * t + k] == n) return k;
+        return -1;
+    }
+    void kill(int t) {
+        dead[t] = 1;
+        free_list.push_back(t);
+    }
+
+    // flips the edge opposite vertex k of finite triangle t when the vertex across it lies inside t's circle; pushes the four
+    // outer edges of the quadrilateral.  Returns whether it flipped.
+    bool flip_if_needed(int t, int k, std::vector<int>& queue) {
+        if (dead[t] || inf_index(t) >= 0) return false;
+        const int n = adj[3 * t + k];
+        if (n < 0 || dead[n] || inf_index(n) >= 0) return false;
+        const int m = slot_towards(n, t);
+        if (m < 0) return false;
+        const int a = v[3 * t + k], b = v[3 * t + (k + 1) % 3], c = v[3 * t + (k + 2) % 3], d = v[3 * n + m];
+        if (!(incircle(p[a], p[b], p[c], p[d]) > 0)) return false;
+        // t = (a, b, c), n = (d, c, b) in some rotation: the shared edge is b - c.  After the flip: t = (a, b, d), n = (a, d, c)
+        const int t_ab = adj[3 * t + (k + 2) % 3];            // across a - b (opposite c)
+        const int t_ca = adj[3 * t + (k + 1) % 3];            // across c - a (opposite b)
+        const int n_bd = adj[3 * n + (m + 1) % 3];            // n = (d, c, b) from m: opposite c is the edge b - d
+        const int n_dc = adj[3 * n + (m + 2) % 3];            // opposite b: the edge d - c
+        v[3 * t] = a, v[3 * t + 1] = b, v[3 * t + 2] = d;
+        adj[3 * t] = n_bd, adj[3 * t + 1] = n, adj[3 * t + 2] = t_ab;          // opposite a: b - d; opposite b: d - a; opposite d: a - b
+        v[3 * n] = a, v[3 * n + 1] = d, v[3 * n + 2] = c;
+        adj[3 * n] = n_dc, adj[3 * n + 1] = t_ca, adj[3 * n + 2] = t;          // opposite a: d - c; opposite d: c - a; opposite c: a - d
+        if (n_bd >= 0) adj[3 * n_bd + slot_towards(n_bd, n)] = t;
+        if (t_ca >= 0) adj[3 * t_ca + slot_towards(t_ca, t)] = n;
+        vert_tri[a] = t, vert_tri[b] = t, vert_tri[d] = t, vert_tri[c] = n;
+        queue.push_back(t), queue.push_back(0);               // b - d
+        queue.push_back(t), queue.push_back(2);               // a - b
+        queue.push_back(n), queue.push_back(0);               // d - c
+        queue.push_back(n), queue.push_back(1);               // c - a
+        return true;
+    }
+
+    // Joins two components of the structure — A strictly to the left of B (every x of A below every x of B) —, each a complete
+    // triangulation with its ring of ghosts; ga / gb: any ghost of A / B.  Returns a ghost of the union, or -1 when the gap
+    // between the hulls cannot be filled without a degenerate triangle (collinear runs across the seam: the caller then builds
+    // sequentially).
+    int join(int ga, int gb) {
+        // the rightmost vertex of A and the leftmost of B (ties: the lower one), as ghosts that START there
+        auto extreme = [&](int g0, bool rightmost) {
+            int best = g0, g = g0;
+            do {
+                const pt &q = p[ghost_start(g)], &b = p[ghost_start(best)];
+                if (rightmost ? (q.x > b.x || (q.x == b.x && q.y < b.y)) : (q.x < b.x || (q.x == b.x && q.y < b.y))) best = g;
+                g = ghost_next(g);
+            } while (g != g0);
+            return best;
+        };
+        // Common tangents.  A vertex of A is held as the ghost that starts at it (ea), one of B as the ghost that ends at it (eb).
+        // Downwards on A's right side is clockwise (next), on B's left side counter-clockwise (prev); upwards the other way.
+        auto strictly_between = [&](const pt& x, const pt& a, const pt& b) {      // x on the line a b: closer to b than a is?
+            const double dx = b.x - a.x, dy = b.y - a.y;
+            const double s = (x.x - a.x) * dx + (x.y - a.y) * dy;
+            return s > 0 && s < dx * dx + dy * dy;
+        };
+        auto tangent = [&](bool lower, int& ea, int& eb, int& moves_a, int& moves_b) {
+            int64_t guard = (int64_t)dead.size() * 2 + 64;
+            for (;;) {
+                if (--guard < 0) return false;
+                const int a = ghost_start(ea), b = ghost_end(eb);
+                bool moved = false;
+                // A's candidate: the next vertex downwards (lower) / upwards (upper)
+                {
+                    const int cand_g = lower ? ghost_next(ea) : ghost_prev(ea);
+                    const int c = ghost_start(cand_g);
+                    if (c != a) {
+                        const double o = orient2d(p[a], p[b], p[c]);
+                        if (lower ? (o < 0) : (o > 0)) ea = cand_g, moved = true;
+                        else if (o == 0 && strictly_between(p[c], p[a], p[b])) ea = cand_g, moved = true;
+                    }
+                }
+                if (moved) {
+                    ++moves_a;
+                    continue;
+                }
+                {
+                    const int cand_g = lower ? ghost_prev(eb) : ghost_next(eb);
+                    const int c = ghost_end(cand_g);
+                    if (c != b) {
+                        const double o = orient2d(p[a], p[b], p[c]);
+                        if (lower ? (o < 0) : (o > 0)) eb = cand_g, moved = true;
+                        else if (o == 0 && strictly_between(p[c], p[b], p[a])) eb = cand_g, moved = true;
+                    }
+                }
+                if (!moved) return true;
+                ++moves_b;
+            }
+        };
+        auto ring_size = [&](int g0) {
+            int count = 0, g = g0;
+            do {
+                ++count;
+                g = ghost_next(g);
+            } while (g != g0);
+            return count;
+        };
+        const int ra = extreme(ga, true);
+        int lb = extreme(gb, false);
+        lb = ghost_prev(lb);                                   // ... as the ghost that ENDS at B's leftmost vertex
+        int lo_a = ra, lo_b = lb, up_a = ra, up_b = lb;
+        int moves_a = 0, moves_b = 0;
+        if (!tangent(true, lo_a, lo_b, moves_a, moves_b) || !tangent(false, up_a, up_b, moves_a, moves_b)) return -1;
+        const int a0 = ghost_start(lo_a), b0 = ghost_end(lo_b), a1 = ghost_start(up_a), b1 = ghost_end(up_b);
+        // The facing chains: A's hull edges from a1 clockwise down to a0, B's from b0 clockwise up to b1.  When both tangents touch
+        // a hull in ONE vertex the chain is empty if the walks never left the starting vertex — or the whole ring: that hull lies
+        // inside the wedge the two tangents make, only that vertex of it is on the union's hull.
+        int rem_a = 0, rem_b = 0;
+        if (a0 == a1) {
+            rem_a = moves_a > 0 ? ring_size(lo_a) : 0;
+        } else {
+            for (int g = up_a; ghost_start(g) != a0; g = ghost_next(g)) ++rem_a;
+        }
+        if (b0 == b1) {
+            rem_b = moves_b > 0 ? ring_size(lo_b) : 0;
+        } else {
+            for (int g = ghost_next(lo_b);; g = ghost_next(g)) {
+                ++rem_b;
+                if (g == up_b) break;
+            }
+        }
+        const bool whole_a = a0 == a1 && rem_a > 0, whole_b = b0 == b1 && rem_b > 0;
+        if (whole_a && whole_b) return -1;                     // (cannot be: two hulls apart)
+        // Dry run of the zip (no changes yet): every step needs a candidate strictly to the left of the base edge a -> b
+        {
+            int ga_cur = ghost_prev(lo_a), gb_cur = ghost_next(lo_b), ra_left = rem_a, rb_left = rem_b;
+            int a = a0, b = b0;
+            while (ra_left > 0 || rb_left > 0) {
+                const int a_up = ra_left > 0 ? ghost_start(ga_cur) : -1, b_up = rb_left > 0 ? ghost_end(gb_cur) : -1;
+                const bool va = ra_left > 0 && orient2d(p[a], p[b], p[a_up]) > 0, vb = rb_left > 0 && orient2d(p[a], p[b], p[b_up]) > 0;
+                if (!va && !vb) return -1;
+                bool take_b = vb;
+                if (va && vb) take_b = !(incircle(p[a], p[b], p[b_up], p[a_up]) > 0);
+                if (take_b) b = b_up, gb_cur = ghost_next(gb_cur), --rb_left; else a = a_up, ga_cur = ghost_prev(ga_cur), --ra_left;
+            }
+            if (a != a1 || b != b1) return -1;
+        }
+        // The ghosts outside the facing chains that the new hull edges link to (none on a side whose whole ring is consumed)
+        const int below_b = lo_b;                              // ends at b0
+        const int below_a = lo_a;                              // starts at a0 (lo_a runs on clockwise from a0, away from the gap)
+        const int above_a = ghost_prev(up_a);                  // ends at a1
+        const int above_b = ghost_next(up_b);                  // starts at b1
+        const int g_low = new_tri(b0, a0, kInf);               // hull edge b0 -> a0, outside (below) on its left
+        int prev_tri = g_low, prev_slot = 2;                   // the triangle below the current base and its slot for it
+        std::vector<int> queue;
+        int cur_a_ghost = ghost_prev(lo_a), cur_b_ghost = ghost_next(lo_b);        // the facing-chain ghosts next to be consumed
+        int a = a0, b = b0;
+        while (rem_a > 0 || rem_b > 0) {
+            const int a_up = rem_a > 0 ? ghost_start(cur_a_ghost) : -1, b_up = rem_b > 0 ? ghost_end(cur_b_ghost) : -1;
+            const bool va = rem_a > 0 && orient2d(p[a], p[b], p[a_up]) > 0, vb = rem_b > 0 && orient2d(p[a], p[b], p[b_up]) > 0;
+            bool take_b = vb;
+            if (va && vb) take_b = !(incircle(p[a], p[b], p[b_up], p[a_up]) > 0);
+            const int x = take_b ? b_up : a_up;
+            // (the ghost to be consumed is read BEFORE new_tri, which may hand out the slot of one consumed earlier)
+            const int g = take_b ? cur_b_ghost : cur_a_ghost, inner = ghost_inner(g);
+            if (take_b) cur_b_ghost = ghost_next(g), --rem_b; else cur_a_ghost = ghost_prev(g), --rem_a;
+            const int T = new_tri(a, b, x);
+            adj[3 * T + 2] = prev_tri;                         // opposite x: the base a - b
+            adj[3 * prev_tri + prev_slot] = T;
+            if (take_b) {
+                // edge b - x (opposite a) was B's hull edge b -> x: its ghost goes, the finite triangle behind it is T's neighbour
+                adj[3 * T] = inner;
+                adj[3 * inner + slot_towards(inner, g)] = T;
+                kill(g);
+                prev_tri = T, prev_slot = 1;                   // opposite b: the edge x - a = the next base (a, x)
+                b = x;
+            } else {
+                // edge x - a (opposite b) was A's hull edge x -> a
+                adj[3 * T + 1] = inner;
+                adj[3 * inner + slot_towards(inner, g)] = T;
+                kill(g);
+                prev_tri = T, prev_slot = 0;                   // opposite a: the edge b - x = the next base (x, b)
+                a = x;
+            }
+            vert_tri[v[3 * T]] = T, vert_tri[v[3 * T + 1]] = T, vert_tri[v[3 * T + 2]] = T;
+            for (int k = 0; k < 3; ++k) queue.push_back(T), queue.push_back(k);
+        }
+        const int g_up = new_tri(a1, b1, kInf);                // hull edge a1 -> b1, outside (above) on its left
+        adj[3 * g_up + 2] = prev_tri;
+        adj[3 * prev_tri + prev_slot] = g_up;
+        // ring: g_low = (b0, a0, inf): across (a0, inf) [slot 0] the ghost that starts at a0, across (inf, b0) [slot 1] the one that
+        // ends at b0; g_up = (a1, b1, inf): slot 0 the ghost that starts at b1, slot 1 the one that ends at a1
+        auto set_prev = [&](int g, int to) { adj[3 * g + (inf_index(g) + 2) % 3] = to; };
+        auto set_next = [&](int g, int to) { adj[3 * g + (inf_index(g) + 1) % 3] = to; };
+        if (whole_a) {
+            adj[3 * g_low] = g_up, adj[3 * g_up + 1] = g_low;           // a0 = a1 is A's only vertex on the hull
+        } else {
+            adj[3 * g_low] = below_a, set_prev(below_a, g_low);
+            adj[3 * g_up + 1] = above_a, set_next(above_a, g_up);
+        }
+        if (whole_b) {
+            adj[3 * g_up] = g_low, adj[3 * g_low + 1] = g_up;
+        } else {
+            adj[3 * g_low + 1] = below_b, set_next(below_b, g_low);
+            adj[3 * g_up] = above_b, set_prev(above_b, g_up);
+        }
+        // Lawson: flip until every edge near the seam is locally Delaunay (the guard only trips on a structure that is not a
+        // triangulation)
+        int64_t flips = 0;
+        const int64_t flip_limit = (int64_t)dead.size() * 16 + 1024;
+        while (!queue.empty()) {
+            const int k = queue.back();
+            queue.pop_back();
+            const int t = queue.back();
+            queue.pop_back();
+            if (flip_if_needed(t, k, queue) && ++flips > flip_limit) return -1;
+        }
+        n_flips += flips;
+        return g_up;
+    }
+
     // Insertion order: along a Hilbert curve through the points' bounding box.  In row-major order every new point of a
     // partly filled row destroys and rebuilds the fan of skinny triangles between that row's end and the rest of the row
     // above (O(width) per point, 36 us per point on a 1400 x 2000 lattice); along the curve the inserted set is a union of
@@ -326,53 +590,269 @@ struct amt_delaunay {
         return true;
     }
 
-    void compact() {
+    // (debugging aid, AMT_DELAUNAY_VALIDATE: every link of the structure is mutual and names the same edge from both sides)
+    bool validate(const char* when) const {
         const int nt = (int)dead.size();
-        slot_of.assign(nt, -1);
-        tri.clear();
         for (int t = 0; t < nt; ++t) {
-            if (dead[t] || v[3 * t] == kInf || v[3 * t + 1] == kInf || v[3 * t + 2] == kInf) continue;
-            slot_of[t] = (int)(tri.size() / 3);
-            tri.push_back(v[3 * t]), tri.push_back(v[3 * t + 1]), tri.push_back(v[3 * t + 2]);
-        }
-        nbr.assign(tri.size(), -1);
-        for (int t = 0; t < nt; ++t) {
-            if (slot_of[t] < 0) continue;
+            if (dead[t]) continue;
             for (int k = 0; k < 3; ++k) {
                 const int n = adj[3 * t + k];
-                nbr[3 * slot_of[t] + k] = n >= 0 ? slot_of[n] : -1;
+                const int x = v[3 * t + (k + 1) % 3], y = v[3 * t + (k + 2) % 3];
+                if (n < 0 || n >= nt || dead[n]) {
+                    std::fprintf(stderr, "[delaunay] %s: triangle %d (%d %d %d) slot %d -> %d (dead or none)\n", when, t, v[3 * t], v[3 * t + 1],
+                                 v[3 * t + 2], k, n);
+                    return false;
+                }
+                int m = -1;
+                for (int j = 0; j < 3; ++j)
+                    if (adj[3 * n + j] == t && v[3 * n + (j + 1) % 3] == y && v[3 * n + (j + 2) % 3] == x) m = j;
+                if (m < 0) {
+                    std::fprintf(stderr, "[delaunay] %s: triangle %d (%d %d %d) slot %d -> %d (%d %d %d | %d %d %d): not mutual\n", when, t, v[3 * t],
+                                 v[3 * t + 1], v[3 * t + 2], k, n, v[3 * n], v[3 * n + 1], v[3 * n + 2], adj[3 * n], adj[3 * n + 1], adj[3 * n + 2]);
+                    return false;
+                }
+            }
+            if (inf_index(t) < 0 && !(orient2d(p[v[3 * t]], p[v[3 * t + 1]], p[v[3 * t + 2]]) > 0)) {
+                std::fprintf(stderr, "[delaunay] %s: triangle %d (%d %d %d) is not counter-clockwise\n", when, t, v[3 * t], v[3 * t + 1], v[3 * t + 2]);
+                return false;
             }
         }
+        return true;
+    }
+
+    // Parallel build (see the head of the file).  false: not applicable / a degenerate seam — the caller builds sequentially.
+    bool build_parallel(int threads, int min_points) {
+        const int n = (int)p.size();
+        if (threads < 2 || n < min_points) return false;
+        static const bool debug = std::getenv("AMT_DELAUNAY_DEBUG") != nullptr;             // phase times on stderr
+        static const bool check = std::getenv("AMT_DELAUNAY_VALIDATE") != nullptr;       // every link checked after every join
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto t_begin = now();
+        auto lap = [&](const char* what) {
+            if (!debug) return;
+            const auto t = now();
+            std::fprintf(stderr, "[delaunay] %-12s %.3f s\n", what, std::chrono::duration<double>(t - t_begin).count());
+            t_begin = t;
+        };
+        int K = std::min(threads, n / std::max(256, min_points / 4));          // (a strip has a quarter of the threshold at least)
+        if (K < 2) return false;
+        // splitters: x values from a sorted sample; a point goes to the strip of the last splitter <= its x, so that equal x values
+        // never sit on both sides of a cut
+        std::vector<double> sample;
+        const int step = std::max(1, n / 65536);
+        for (int i = 0; i < n; i += step) sample.push_back(p[i].x);
+        std::sort(sample.begin(), sample.end());
+        std::vector<double> cut;
+        for (int j = 1; j < K; ++j) {
+            const double c = sample[(size_t)((int64_t)sample.size() * j / K)];
+            if (cut.empty() ? c > sample.front() : c > cut.back()) cut.push_back(c);
+        }
+        K = (int)cut.size() + 1;
+        if (K < 2) return false;
+        auto strip_of = [&](double x) { return (int)(std::upper_bound(cut.begin(), cut.end(), x) - cut.begin()); };
+        std::vector<std::vector<int>> members((size_t)K);
+        for (int j = 0; j < K; ++j) members[(size_t)j].reserve((size_t)n / K + 1024);
+        for (int i = 0; i < n; ++i) members[(size_t)strip_of(p[i].x)].push_back(i);
+        for (int j = 0; j < K; ++j)
+            if (members[(size_t)j].size() < 64) return false;
+        lap("partition");
+        // every strip on a thread of its own
+        std::vector<amt_delaunay> part((size_t)K);
+        std::vector<char> ok((size_t)K, 0);
+        std::vector<predicate_stats> part_stats((size_t)K, predicate_stats{0, 0, 0, 0});
+        auto work = [&](int j) {
+            amt_delaunay& d = part[(size_t)j];
+            const std::vector<int>& mine = members[(size_t)j];
+            d.p.resize(mine.size());
+            for (size_t i = 0; i < mine.size(); ++i) d.p[i] = p[(size_t)mine[i]];
+            g_stats = &part_stats[(size_t)j];
+            bool built = false;
+            try {
+                built = d.build();
+            } catch (const std::bad_alloc&) {
+                built = false;
+            }
+            g_stats = nullptr;
+            ok[(size_t)j] = built ? 1 : 0;
+        };
+        {
+            predicate_stats* mine = g_stats;
+            on_threads(K, work);
+            g_stats = mine;
+        }
+        for (int j = 0; j < K; ++j)
+            if (!ok[(size_t)j]) return false;
+        lap("strips");
+        // one structure: triangle ids shifted by the strips before, vertex ids back to the caller's (every strip copies itself)
+        std::vector<size_t> offs((size_t)K + 1, 0);
+        for (int j = 0; j < K; ++j) offs[(size_t)j + 1] = offs[(size_t)j] + part[(size_t)j].dead.size();
+        const size_t total = offs[(size_t)K];
+        v.resize(3 * total), adj.resize(3 * total), dead.resize(total), in_cavity.assign(total, 0);
+        free_list.clear();
+        vert_tri.assign((size_t)n, -1);
+        edge_from.assign((size_t)n + 1, -1);
+        edge_to.assign((size_t)n + 1, -1);
+        n_dup = 0;
+        std::vector<int> ghost_of((size_t)K, -1);
+        std::vector<std::vector<int>> freed((size_t)K);
+        on_threads(K, [&](int j) {
+            const amt_delaunay& d = part[(size_t)j];
+            const std::vector<int>& mine = members[(size_t)j];
+            const size_t nt = d.dead.size(), off = offs[(size_t)j];
+            int ghost = -1;
+            for (size_t t = 0; t < nt; ++t) {
+                dead[off + t] = d.dead[t];
+                if (d.dead[t]) {
+                    freed[(size_t)j].push_back((int)(off + t));
+                    v[3 * (off + t)] = v[3 * (off + t) + 1] = v[3 * (off + t) + 2] = -2;
+                    adj[3 * (off + t)] = adj[3 * (off + t) + 1] = adj[3 * (off + t) + 2] = -1;
+                    continue;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const int w = d.v[3 * t + k], a = d.adj[3 * t + k];
+                    v[3 * (off + t) + k] = w == kInf ? kInf : mine[(size_t)w];
+                    adj[3 * (off + t) + k] = a < 0 ? -1 : (int)(off + a);
+                    if (w == kInf) ghost = (int)(off + t);
+                }
+            }
+            ghost_of[(size_t)j] = ghost;
+            for (size_t i = 0; i < mine.size(); ++i)
+                if (d.vert_tri[i] >= 0) vert_tri[(size_t)mine[i]] = (int)(off + d.vert_tri[i]);
+        });
+        for (int j = 0; j < K; ++j) {
+            free_list.insert(free_list.end(), freed[(size_t)j].begin(), freed[(size_t)j].end());
+            n_dup += part[(size_t)j].n_dup;
+            stats.orient_wide += part_stats[(size_t)j].orient_wide, stats.orient_zero += part_stats[(size_t)j].orient_zero;
+            stats.incircle_wide += part_stats[(size_t)j].incircle_wide, stats.incircle_zero += part_stats[(size_t)j].incircle_zero;
+        }
+        part.clear();
+        lap("concatenate");
+        if (check && !validate("before the joins")) return false;
+        // join the strips, left to right
+        int g = ghost_of[0];
+        for (int j = 1; j < K; ++j) {
+            if (g < 0 || ghost_of[(size_t)j] < 0) return false;
+            g = join(g, ghost_of[(size_t)j]);
+            if (g < 0) return false;
+            if (check && !validate("after a join")) return false;
+        }
+        lap("join");
+        if (debug) std::fprintf(stderr, "[delaunay] %d strips, %lld flips\n", K, (long long)n_flips);
+        n_strips = K;
+        n_threads = threads;
+        last = ghost_inner(g);
+        return true;
+    }
+
+    void compact() {
+        static const bool debug = std::getenv("AMT_DELAUNAY_DEBUG") != nullptr;
+        auto t_begin = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!debug) return;
+            const auto t = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[delaunay] %-12s %.3f s\n", what, std::chrono::duration<double>(t - t_begin).count());
+            t_begin = t;
+        };
+        const int nt = (int)dead.size();
+        const int T = std::max(1, std::min(n_threads, nt / 65536));
+        auto chunk = [&](int64_t count, int j) { return std::pair<int64_t, int64_t>(count * j / T, count * (j + 1) / T); };
+        auto finite = [&](int t) { return !dead[t] && v[3 * t] != kInf && v[3 * t + 1] != kInf && v[3 * t + 2] != kInf; };
+        slot_of.resize((size_t)nt);
+        std::vector<int64_t> first((size_t)T + 1, 0);
+        on_threads(T, [&](int j) {
+            const auto r = chunk(nt, j);
+            int64_t c = 0;
+            for (int64_t t = r.first; t < r.second; ++t) c += finite((int)t) ? 1 : 0;
+            first[(size_t)j + 1] = c;
+        });
+        for (int j = 0; j < T; ++j) first[(size_t)j + 1] += first[(size_t)j];
+        tri.resize(3 * (size_t)first[(size_t)T]);
+        on_threads(T, [&](int j) {
+            const auto r = chunk(nt, j);
+            int64_t at = first[(size_t)j];
+            for (int64_t t = r.first; t < r.second; ++t) {
+                if (!finite((int)t)) {
+                    slot_of[(size_t)t] = -1;
+                    continue;
+                }
+                slot_of[(size_t)t] = (int)at;
+                tri[3 * (size_t)at] = v[3 * t], tri[3 * (size_t)at + 1] = v[3 * t + 1], tri[3 * (size_t)at + 2] = v[3 * t + 2];
+                ++at;
+            }
+        });
+        lap("triangles");
+        nbr.resize(tri.size());
+        on_threads(T, [&](int j) {
+            const auto r = chunk(nt, j);
+            for (int64_t t = r.first; t < r.second; ++t) {
+                const int s0 = slot_of[(size_t)t];
+                if (s0 < 0) continue;
+                for (int k = 0; k < 3; ++k) {
+                    const int n = adj[3 * t + k];
+                    nbr[3 * (size_t)s0 + k] = n >= 0 ? slot_of[(size_t)n] : -1;
+                }
+            }
+        });
         // vertex -> neighbouring vertices (scipy.spatial.Delaunay.vertex_neighbor_vertices; in no particular order).  Every
         // triangle lists its edges counter-clockwise, so an inner edge {x, y} comes up once as x -> y and once as y -> x (from
-        // the triangle on its other side); a hull edge comes up once and gets its reverse here: no sorting, no duplicates
+        // the triangle on its other side); a hull edge comes up once and gets its reverse here: no sorting, no duplicates.
+        // Threads own ranges of VERTICES and each walks all triangles: a vertex's list is in the order of the triangles whatever
+        // the number of threads.
+        lap("neighbours");
         const int n = (int)p.size();
         const size_t m = tri.size() / 3;
         indptr.assign((size_t)n + 1, 0);
-        for (size_t t = 0; t < m; ++t)
-            for (int k = 0; k < 3; ++k) {
-                ++indptr[(size_t)tri[3 * t + (k + 1) % 3] + 1];                       // edge opposite vertex k: v[k+1] -> v[k+2]
-                if (nbr[3 * t + k] < 0) ++indptr[(size_t)tri[3 * t + (k + 2) % 3] + 1];
-            }
+        on_threads(T, [&](int j) {
+            const auto r = chunk(n, j);
+            for (size_t t = 0; t < m; ++t)
+                for (int k = 0; k < 3; ++k) {
+                    const int x = tri[3 * t + (k + 1) % 3];                            // edge opposite vertex k: v[k+1] -> v[k+2]
+                    if (x >= r.first && x < r.second) ++indptr[(size_t)x + 1];
+                    if (nbr[3 * t + k] < 0) {
+                        const int y = tri[3 * t + (k + 2) % 3];
+                        if (y >= r.first && y < r.second) ++indptr[(size_t)y + 1];
+                    }
+                }
+        });
         for (int i = 0; i < n; ++i) indptr[(size_t)i + 1] += indptr[(size_t)i];
         indices.resize((size_t)indptr[(size_t)n]);
         std::vector<int64_t> fill(indptr.begin(), indptr.end() - 1);
-        for (size_t t = 0; t < m; ++t)
-            for (int k = 0; k < 3; ++k) {
-                const int x = tri[3 * t + (k + 1) % 3], y = tri[3 * t + (k + 2) % 3];
-                indices[(size_t)fill[(size_t)x]++] = y;
-                if (nbr[3 * t + k] < 0) indices[(size_t)fill[(size_t)y]++] = x;
-            }
+        on_threads(T, [&](int j) {
+            const auto r = chunk(n, j);
+            for (size_t t = 0; t < m; ++t)
+                for (int k = 0; k < 3; ++k) {
+                    const int x = tri[3 * t + (k + 1) % 3], y = tri[3 * t + (k + 2) % 3];
+                    if (x >= r.first && x < r.second) indices[(size_t)fill[(size_t)x]++] = y;
+                    if (nbr[3 * t + k] < 0 && y >= r.first && y < r.second) indices[(size_t)fill[(size_t)y]++] = x;
+                }
+        });
+        lap("vertex CSR");
     }
 };
 
 extern "C" {
 
-int amt_delaunay_create(const double* xy, int64_t n, amt_delaunay** out) {
+int amt_delaunay_create_threads(const double* xy, int64_t n, int32_t threads, int64_t parallel_min, amt_delaunay** out) {
     if (xy == nullptr || out == nullptr || n < 3 || n > 2000000000ll) return AMT_EINVAL;
     *out = nullptr;
     amt_delaunay* d = new (std::nothrow) amt_delaunay();
     if (d == nullptr) return AMT_ENOMEM;
+    if (threads <= 0) {
+        static const int env_threads = [] {
+            const char* e = std::getenv("AMT_DELAUNAY_THREADS");
+            const int v = e ? std::atoi(e) : 0;
+            return v > 0 ? v : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        }();
+        threads = env_threads;
+    }
+    if (parallel_min <= 0) {
+        static const int64_t env_min = [] {
+            const char* e = std::getenv("AMT_DELAUNAY_PARALLEL_MIN");
+            const long long v = e ? std::atoll(e) : 0;
+            return (int64_t)(v > 0 ? v : 200000);
+        }();
+        parallel_min = env_min;
+    }
     try {
         d->p.resize((size_t)n);
         for (int64_t i = 0; i < n; ++i) {
@@ -384,7 +864,22 @@ int amt_delaunay_create(const double* xy, int64_t n, amt_delaunay** out) {
         }
         d->stats = predicate_stats{0, 0, 0, 0};
         g_stats = &d->stats;
-        const bool built = d->build();
+        bool built = false;
+        try {
+            built = d->build_parallel(threads, (int)std::min<int64_t>(parallel_min, 2000000000ll));
+        } catch (const std::bad_alloc&) {
+            built = false;
+        }
+        if (!built) {
+            // (small inputs, one thread, a degenerate seam: the sequential build on a fresh structure)
+            std::vector<pt> pts;
+            pts.swap(d->p);
+            *d = amt_delaunay();
+            d->p.swap(pts);
+            d->stats = predicate_stats{0, 0, 0, 0};
+            g_stats = &d->stats;
+            built = d->build();
+        }
         g_stats = nullptr;
         if (!built) {
             delete d;
@@ -392,10 +887,19 @@ int amt_delaunay_create(const double* xy, int64_t n, amt_delaunay** out) {
         }
         d->compact();
     } catch (const std::bad_alloc&) {
+        g_stats = nullptr;
         delete d;
         return AMT_ENOMEM;
     }
     *out = d;
+    return AMT_OK;
+}
+
+int amt_delaunay_create(const double* xy, int64_t n, amt_delaunay** out) { return amt_delaunay_create_threads(xy, n, 0, 0, out); }
+
+int amt_delaunay_build_info(const amt_delaunay* d, int64_t* info2) {
+    if (d == nullptr || info2 == nullptr) return AMT_EINVAL;
+    info2[0] = d->n_strips, info2[1] = d->n_flips;
     return AMT_OK;
 }
 

@@ -509,6 +509,11 @@ int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx,
  *   amt_delaunay_create   HOST: the Delaunay triangulation of n >= 3 points xy (n, 2) (host memory; unique unless four points
  *                         are cocircular to the last bit: then Qhull's diagonal is not reproduced).  AMT_EINVAL when all
  *                         points are collinear.  Points that coincide with an earlier one are left out (amt_delaunay_sizes).
+ *   amt_delaunay_create_threads   the same with the number of threads (<= 0: AMT_DELAUNAY_THREADS, else up to 8) and the number of
+ *                         points from which on the build is parallel (<= 0: AMT_DELAUNAY_PARALLEL_MIN, else 200 000): vertical
+ *                         strips triangulated side by side and joined at their seams (common tangents, the gap filled, Lawson
+ *                         flips) — the same triangulation, the triangles in another order.
+ *   amt_delaunay_build_info   info2[2]: strips built side by side (1: the sequential build), edge flips spent on joining them
  *   amt_delaunay_stats    stats4[4]: orientation tests that left double precision, of those exact zeros (three points collinear),
  *                         in-circle tests that left double precision, of those still undecided at 113 bits (four points
  *                         cocircular).  [1] = [3] = 0: no tie was met — the triangulation is the unique Delaunay triangulation of
@@ -526,6 +531,8 @@ int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx,
  *   amt_cubic_eval        DEVICE: the element at the m targets -> out (m, nchan); NaN outside the hull. */
 typedef struct amt_delaunay amt_delaunay;
 int amt_delaunay_create(const double* xy, int64_t n, amt_delaunay** out);
+int amt_delaunay_create_threads(const double* xy, int64_t n, int32_t threads, int64_t parallel_min, amt_delaunay** out);
+int amt_delaunay_build_info(const amt_delaunay* d, int64_t* info2);
 int amt_delaunay_destroy(amt_delaunay* d);
 int amt_delaunay_sizes(const amt_delaunay* d, int64_t* n_triangles, int64_t* n_neighbours, int64_t* n_duplicates);
 int amt_delaunay_stats(const amt_delaunay* d, int64_t* stats4);

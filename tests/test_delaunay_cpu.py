@@ -14,12 +14,16 @@ import pytest
 from conftest import load_golden
 
 
-def triangulate(pts):
+def triangulate(pts, threads=None, parallel_min=1000):
+    """threads: None = the library's defaults (small inputs: the sequential build), else amt_delaunay_create_threads"""
     from auromat_amd._native import lib
     L = lib()
     pts = np.ascontiguousarray(pts, dtype=np.float64)
     h = C.c_void_p()
-    rc = L.amt_delaunay_create(pts.ctypes.data_as(C.c_void_p), len(pts), C.byref(h))
+    if threads is None:
+        rc = L.amt_delaunay_create(pts.ctypes.data_as(C.c_void_p), len(pts), C.byref(h))
+    else:
+        rc = L.amt_delaunay_create_threads(pts.ctypes.data_as(C.c_void_p), len(pts), threads, parallel_min, C.byref(h))
     if rc != 0:
         return rc
     nt, nn, nd = C.c_int64(), C.c_int64(), C.c_int64()
@@ -30,7 +34,9 @@ def triangulate(pts):
     assert L.amt_delaunay_vertex_neighbours(h, indptr.ctypes.data_as(C.c_void_p), ind.ctypes.data_as(C.c_void_p)) == 0
     stats = (C.c_int64 * 4)()
     assert L.amt_delaunay_stats(h, stats) == 0
-    return dict(handle=h, tri=tri, nbr=nbr, indptr=indptr, ind=ind, dup=nd.value, lib=L, stats=list(stats))
+    info = (C.c_int64 * 2)()
+    assert L.amt_delaunay_build_info(h, info) == 0
+    return dict(handle=h, tri=tri, nbr=nbr, indptr=indptr, ind=ind, dup=nd.value, lib=L, stats=list(stats), strips=info[0], flips=info[1])
 
 
 def canon(t):
@@ -132,3 +138,152 @@ def test_triangulation_of_a_jittered_lattice_with_holes_and_of_degenerate_inputs
     area = 0.5 * ((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0]))
     assert (area > 0).all() and abs(area.sum() - 11 * 8) < 1e-9
     h['lib'].amt_delaunay_destroy(h['handle'])
+
+
+def oriented(t):
+    """triangles as rotations that start at their smallest vertex: equal sets = the same triangles with the same orientation"""
+    t = np.asarray(t)
+    k = np.argmin(t, axis=1)
+    return set(map(tuple, np.stack([t[np.arange(len(t)), (k + i) % 3] for i in range(3)], axis=1)))
+
+
+def check_structure(pts, d, exact=False):
+    """counter-clockwise triangles, mutual neighbours across the shared edge, every inner edge locally Delaunay, the triangles
+    cover the convex hull once, the vertex lists are the edges.  exact: decided in exact arithmetic — Python integers for
+    integer coordinates, fractions for doubles (slivers of 1e-16 have no sign in floating point)."""
+    tri, nbr = d['tri'], d['nbr']
+    if exact and pts.dtype.kind == 'f':
+        from fractions import Fraction
+        P = np.array([[Fraction(float(x)), Fraction(float(y))] for x, y in pts], dtype=object)
+    else:
+        P = pts.astype(object) if exact else pts
+    src = P if exact else pts
+    a, b, c = (src[tri[:, k]] for k in range(3))
+    area2 = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])
+    assert (area2 > 0).all()
+    import scipy.spatial
+    total = float(area2.sum())
+    assert abs(total / 2 - scipy.spatial.ConvexHull(np.asarray(pts, dtype=np.float64)).volume) <= 1e-9 * abs(total)
+    edges = set()
+    for t in range(len(tri)):
+        for k in range(3):
+            x, y = int(tri[t, (k + 1) % 3]), int(tri[t, (k + 2) % 3])
+            edges.add((x, y))
+            n = nbr[t, k]
+            if n < 0:
+                edges.add((y, x))
+                continue
+            m = [j for j in range(3) if nbr[n, j] == t]
+            assert len(m) == 1 and {int(tri[n, (m[0] + 1) % 3]), int(tri[n, (m[0] + 2) % 3])} == {x, y}
+            # the vertex across the edge is not inside this triangle's circle
+            q = P[tri[n, m[0]]]
+            A, B, Cc = P[tri[t, 0]], P[tri[t, 1]], P[tri[t, 2]]
+            rows = [(u[0] - q[0], u[1] - q[1], (u[0] - q[0]) ** 2 + (u[1] - q[1]) ** 2) for u in (A, B, Cc)]
+            det = (rows[0][0] * (rows[1][1] * rows[2][2] - rows[1][2] * rows[2][1])
+                   - rows[0][1] * (rows[1][0] * rows[2][2] - rows[1][2] * rows[2][0])
+                   + rows[0][2] * (rows[1][0] * rows[2][1] - rows[1][1] * rows[2][0]))
+            if exact:
+                assert det <= 0, (t, k)
+            else:
+                scale = max(abs(v) for r in rows for v in r) ** 4
+                assert det <= 1e-9 * scale, (t, k, det)
+    got = set((v, int(w)) for v in range(len(pts)) for w in d['ind'][d['indptr'][v]:d['indptr'][v + 1]])
+    assert got == edges and len(d['ind']) == len(edges)
+
+
+def bent_lattice(h, w, seed=0):
+    rs = np.random.RandomState(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(float)
+    lon = x * 0.01 + 1e-6 * y * y + 3e-7 * x * y + rs.uniform(-2e-4, 2e-4, x.shape)
+    lat = y * 0.008 + 2e-6 * x * x - 1e-7 * x * y + rs.uniform(-2e-4, 2e-4, x.shape)
+    keep = rs.rand(h, w) > 0.03                                        # a few holes
+    return np.column_stack((lat[keep], lon[keep]))
+
+
+@pytest.mark.parametrize('kind,threads', [('lattice', 2), ('lattice', 3), ('lattice', 8), ('cloud', 5), ('cloud', 8), ('clusters', 4)])
+def test_parallel_build_gives_the_sequential_triangulation(kind, threads):
+    """Vertical strips triangulated side by side and joined at their seams (common tangents, the gap filled, Lawson flips):
+    the Delaunay triangulation is unique, so every triangle — and its orientation — must be the sequential build's."""
+    rs = np.random.RandomState(threads)
+    if kind == 'lattice':
+        pts = bent_lattice(150, 230, seed=threads)
+    elif kind == 'cloud':
+        pts = rs.rand(40000, 2) * [3.0, 1.0]
+    else:
+        centres = rs.rand(12, 2) * 10
+        pts = np.concatenate([c + rs.normal(size=(3000, 2)) * rs.uniform(0.05, 1.5) for c in centres])
+    seq = triangulate(pts, threads=1)
+    par = triangulate(pts, threads=threads, parallel_min=1000)
+    try:
+        assert seq['strips'] == 1 and par['strips'] >= 2 and par['flips'] > 0
+        assert seq['stats'][1] == 0 and seq['stats'][3] == 0 and par['stats'][1] == 0 and par['stats'][3] == 0      # no ties: unique
+        assert oriented(par['tri']) == oriented(seq['tri'])
+        for v in range(0, len(pts), 7):
+            assert set(par['ind'][par['indptr'][v]:par['indptr'][v + 1]]) == set(seq['ind'][seq['indptr'][v]:seq['indptr'][v + 1]])
+        if kind == 'lattice' and threads == 3:
+            check_structure(pts, par)
+    finally:
+        seq['lib'].amt_delaunay_destroy(seq['handle'])
+        par['lib'].amt_delaunay_destroy(par['handle'])
+
+
+@pytest.mark.parametrize('name', ['resample_nearest_iss030.npz', 'resample_nearest_iss029.npz', 'resample_nearest_synth_plain.npz',
+                                  'resample_nearest_synth_disc.npz', 'resample_nearest_synth_pole.npz'])
+def test_parallel_build_equals_qhull_on_the_reference_fixtures(name):
+    """(the curved outline of a camera frame makes strips whose hulls lie inside the wedge of their neighbours' tangents: only one
+    vertex of such a strip is on the joint hull and the whole ring of its hull edges faces the seam)"""
+    import scipy.spatial
+    pts = fixture_points(name)
+    want = canon(scipy.spatial.Delaunay(pts).simplices)
+    for threads in (2, 3, 5, 8):
+        d = triangulate(pts, threads=threads, parallel_min=300)
+        try:
+            assert d['strips'] >= 2, (name, threads, len(pts))
+            assert canon(d['tri']) == want, (name, threads)
+        finally:
+            d['lib'].amt_delaunay_destroy(d['handle'])
+
+
+@pytest.mark.parametrize('shape', ['arc', 'annulus', 'turned lattice', 'wedge'])
+def test_parallel_build_on_shapes_that_are_not_convex(shape):
+    rs = np.random.RandomState(11)
+    if shape == 'arc':
+        th, r = rs.uniform(0.2, 2.9, 30000), rs.uniform(9.0, 10.0, 30000)
+        pts = np.column_stack((r * np.cos(th), r * np.sin(th)))
+    elif shape == 'annulus':
+        th, r = rs.uniform(0, 2 * np.pi, 30000), rs.uniform(4.0, 5.0, 30000)
+        pts = np.column_stack((r * np.cos(th), r * np.sin(th)))
+    elif shape == 'turned lattice':
+        q = bent_lattice(120, 200, seed=5)
+        c, s_ = np.cos(0.7), np.sin(0.7)
+        pts = q.dot(np.array([[c, -s_], [s_, c]]))
+    else:
+        u = rs.rand(30000, 2)
+        pts = np.column_stack((u[:, 0] * 10, (u[:, 1] - 0.5) * u[:, 0] * 0.3))            # a thin wedge opening to the right
+    seq = triangulate(pts, threads=1)
+    try:
+        for threads in (2, 4, 7):
+            par = triangulate(pts, threads=threads, parallel_min=300)
+            try:
+                assert par['strips'] >= 2
+                assert oriented(par['tri']) == oriented(seq['tri']), (shape, threads)
+            finally:
+                par['lib'].amt_delaunay_destroy(par['handle'])
+    finally:
+        seq['lib'].amt_delaunay_destroy(seq['handle'])
+
+
+@pytest.mark.parametrize('threads', [1, 3])
+def test_exact_lattices_give_a_valid_delaunay_triangulation(threads):
+    """Integer lattices: every cell cocircular, every hull side and every seam between strips a run of collinear points.  No
+    unique answer exists (the header of csrc/amt_delaunay.hip) — but whatever comes out must be A Delaunay triangulation: checked
+    in exact integer arithmetic."""
+    y, x = np.mgrid[0:70, 0:190]
+    pts = np.column_stack((x.ravel(), y.ravel())).astype(np.float64)
+    d = triangulate(pts, threads=threads, parallel_min=1000)
+    try:
+        assert d['dup'] == 0 and len(d['tri']) == 2 * 69 * 189
+        assert (d['strips'] >= 2) == (threads > 1)
+        check_structure(pts.astype(np.int64), d, exact=True)
+    finally:
+        d['lib'].amt_delaunay_destroy(d['handle'])
