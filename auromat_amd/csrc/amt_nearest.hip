@@ -790,6 +790,7 @@ struct gs_args {
     unsigned long long* err;         // (nchan <= 63): largest relative change of the sweep (bits of a non-negative double);
                                      // err[63]: set when a hand-over did not arrive (see gs_read)
     const unsigned char* active;     // (nchan): 0 = this channel has converged: its gradients are carried over
+    const unsigned long long* rec;   // (n, 32) the points' geometry records (k_cubic_geometry)
 };
 
 __global__ void k_fill_u64(unsigned long long* __restrict__ p, int64_t n, unsigned long long v) {
@@ -817,46 +818,69 @@ __device__ __forceinline__ unsigned long long gs_bits(double v) {
     return v == v ? (unsigned long long)__double_as_longlong(v) : 0x7ff8000000000000ull;
 }
 
-// Everything a point's update needs is fetched ONE POINT AHEAD, while the current point is being worked on: its neighbours'
-// indices, edge vectors, values, previous gradients — and this sweep's gradients of the neighbours in earlier rows (the
-// hand-overs).  A row runs a few points behind the row above it, so those are usually final by then; one that still shows the
-// marker is read again when its turn comes.  The sweep's critical path is (row length + lag x rows) steps long; with the
-// device-scope loads issued at the step itself a step took 10 us (their round trip), fetched ahead it is the arithmetic.
-constexpr int kGsPre = 8;           // neighbours fetched ahead (a lattice point has 6; hull points with more take the slow way)
-struct gs_point {
-    long long b, e;
-    int j[kGsPre];
-    double ex[kGsPre], ey[kGsPre], fj[kGsPre], y0[kGsPre], y1[kGsPre];
-    unsigned long long r0[kGsPre], r1[kGsPre];       // this sweep's components of neighbours in earlier rows, or the marker
-    double fi, g0, g1, xi, yi;
-};
+// The geometry of a point's system does not change from sweep to sweep or from channel to channel: one 256-byte record per point,
+// made once per call (k_cubic_geometry) — the number of neighbours, the first eight neighbours' indices, edge vectors and l^3, and
+// the 2 x 2 matrix (q0, q1, q3) summed over ALL neighbours in their order, which is what scipy recomputes for every point of every
+// sweep of every channel (the same operations on the same numbers: the same bits).  A sweep then only gathers the right-hand side.
+constexpr int kGsPre = 8;           // neighbours held in the record (a lattice point has 6; hull points with more take the slow way)
+constexpr int kGsRecWords = 32;     // 8-byte words per record: [0] count, [1..4] indices, [5..12] ex, [13..20] ey, [21..28] l^3, [29..31] q0 q1 q3
 
-__device__ __forceinline__ void gs_fetch(const gs_args& A, long long v, long long v0, int lane, bool live, gs_point& P) {
-    P.b = A.indptr[v], P.e = A.indptr[v + 1];
-    const long long o = (v * A.nchan + lane) * 2;
-    P.g0 = A.y_old[o], P.g1 = A.y_old[o + 1];
-    if (!live) return;
-    P.xi = A.xy[2 * v], P.yi = A.xy[2 * v + 1], P.fi = A.values[v * A.nchan + lane];
-#pragma unroll
-    for (int t = 0; t < kGsPre; ++t) {
-        P.j[t] = -1;
-        P.r0[t] = P.r1[t] = kGsMarker;
-        if (P.b + t < P.e) {
-            const long long j = A.indices[P.b + t];
-            P.j[t] = (int)j;
-            P.ex[t] = A.xy[2 * j] - P.xi, P.ey[t] = A.xy[2 * j + 1] - P.yi;
-            P.fj[t] = A.values[j * A.nchan + lane];
-            if (j > v) {
-                P.y0[t] = A.y_old[(j * A.nchan + lane) * 2], P.y1[t] = A.y_old[(j * A.nchan + lane) * 2 + 1];
-            } else if (j < v0) {
-                const unsigned long long* q = A.y_new + (j * A.nchan + lane) * 2;
-                P.r0[t] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                P.r1[t] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__global__ __launch_bounds__(kBlock) void k_cubic_geometry(const double* __restrict__ xy, const long long* __restrict__ indptr,
+                                                            const int* __restrict__ indices, int64_t n,
+                                                            unsigned long long* __restrict__ rec) {
+    AMT_GRID_STRIDE(v, n) {
+        const long long b = indptr[v], e = indptr[v + 1];
+        const double xi = xy[2 * v], yi = xy[2 * v + 1];
+        unsigned long long* r = rec + v * kGsRecWords;
+        double q0 = 0, q1 = 0, q3 = 0;
+        int jj[kGsPre];
+        for (int t = 0; t < kGsPre; ++t) jj[t] = -1;
+        for (long long k = b; k < e; ++k) {
+            const long long j = indices[k];
+            const double ex = xy[2 * j] - xi, ey = xy[2 * j + 1] - yi;
+            const double l = sqrt(ex * ex + ey * ey), l3 = l * l * l;
+            q0 += 4 * ex * ex / l3;
+            q1 += 4 * ex * ey / l3;
+            q3 += 4 * ey * ey / l3;
+            const int t = (int)(k - b);
+            if (t < kGsPre) {
+                jj[t] = (int)j;
+                r[5 + t] = (unsigned long long)__double_as_longlong(ex);
+                r[13 + t] = (unsigned long long)__double_as_longlong(ey);
+                r[21 + t] = (unsigned long long)__double_as_longlong(l3);
             }
         }
+        for (int t = (int)(e - b); t < kGsPre; ++t) r[5 + t] = r[13 + t] = r[21 + t] = 0;
+        r[0] = (unsigned long long)(e - b);
+        for (int t = 0; t < kGsPre; t += 2) r[1 + t / 2] = (unsigned long long)(unsigned int)jj[t] | ((unsigned long long)(unsigned int)jj[t + 1] << 32);
+        r[29] = (unsigned long long)__double_as_longlong(q0);
+        r[30] = (unsigned long long)__double_as_longlong(q1);
+        r[31] = (unsigned long long)__double_as_longlong(q3);
     }
 }
 
+// word k of the record a wave holds one word per lane of (wave-uniform result)
+__device__ __forceinline__ unsigned long long gs_word(unsigned long long w, int k) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)w, k);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(w >> 32), k);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double gs_word_f64(unsigned long long w, int k) { return __longlong_as_double((long long)gs_word(w, k)); }
+
+// what a point's right-hand side needs from its (first eight) neighbours, per channel lane
+struct gs_data {
+    double fi, g0, g1;                                   // the point's own value and previous gradient
+    double fj[kGsPre], o0[kGsPre], o1[kGsPre];           // neighbours' values and previous-sweep gradients
+    unsigned long long n0[kGsPre], n1[kGsPre];           // ... and this sweep's (hand-overs: the marker where not written yet)
+};
+
+// Software pipeline of a row: while point v is worked on, the RECORD of point v + 2 and the DATA of point v + 1 (addressed through
+// the record of v + 1, which arrived a step ago) are in flight; every load is issued a whole step before its use.  The loads are
+// unconditional (both sweeps' gradients of every neighbour; an absent neighbour reads the point itself): no branch between a load
+// and its use.  A row runs a few points behind the row above it, so a hand-over is usually final when it is fetched; one that
+// still shows the marker is read again when its turn comes (gs_read).  The sweep's critical path is (row length + lag x rows)
+// steps long: with the loads of a step issued at the step itself a step took 10 us (three dependent round trips: CSR pointer,
+// indices, data), with everything one point ahead 9 (the same chain, merely started earlier), in this form the arithmetic.
 __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
     const int lane = threadIdx.x;
     int row = 0;
@@ -865,67 +889,93 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
     if (row >= A.n_rows) return;
     const long long v0 = A.row_start[row], v1 = A.row_start[row + 1];
     const bool chan = lane < A.nchan;
-    const bool live = chan && A.active[lane] != 0;
-    if (!chan || v0 >= v1) return;
+    if (v0 >= v1) return;
+    const int cl = chan ? lane : 0;                       // (lanes beyond the channels load channel 0's data and store nothing)
+    const bool live = chan && A.active[cl] != 0;
+    const long long last = v1 - 1;
+    auto load_rec = [&](long long v) {
+        v = v < last ? v : last;                          // (past the row's end: the last record again, never used)
+        return A.rec[v * kGsRecWords + (lane & (kGsRecWords - 1))];
+    };
+    auto neighbour = [&](unsigned long long rec, int t) {                 // index of neighbour t, -1 when absent (wave-uniform)
+        const unsigned long long w = gs_word(rec, 1 + t / 2);
+        return (int)(unsigned int)((t & 1) ? (w >> 32) : w);
+    };
+    auto load_data = [&](unsigned long long rec, long long v, gs_data& D) {
+        v = v < last ? v : last;
+        const long long o = (v * A.nchan + cl) * 2;
+        D.fi = A.values[v * A.nchan + cl];
+        D.g0 = A.y_old[o], D.g1 = A.y_old[o + 1];
+#pragma unroll
+        for (int t = 0; t < kGsPre; ++t) {
+            int j = neighbour(rec, t);
+            j = j < 0 ? (int)v : j;
+            const long long q = ((long long)j * A.nchan + cl) * 2;
+            D.fj[t] = A.values[(long long)j * A.nchan + cl];
+            D.o0[t] = A.y_old[q], D.o1[t] = A.y_old[q + 1];
+            D.n0[t] = __hip_atomic_load(A.y_new + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            D.n1[t] = __hip_atomic_load(A.y_new + q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     double worst = 0;
-    // this wave's latest two points' new gradients (neighbours in the own row are the previous one or two points)
+    // this wave's latest two points' new gradients (neighbours in the own row are mostly the previous one or two points)
     double p0 = 0, p1 = 0, pp0 = 0, pp1 = 0;
-    gs_point cur, nxt;
-    gs_fetch(A, v0, v0, lane, live, cur);
+    unsigned long long rec_a = load_rec(v0), rec_b = load_rec(v0 + 1);
+    gs_data cur, nxt;
+    load_data(rec_a, v0, cur);
     for (long long v = v0; v < v1; ++v) {
-        if (v + 1 < v1) gs_fetch(A, v + 1, v0, lane, live, nxt);      // in flight while this point is worked on
-        const long long o = (v * A.nchan + lane) * 2;
+        const unsigned long long rec_c = load_rec(v + 2);
+        load_data(rec_b, v + 1, nxt);                                     // (needs rec_b: issued a step ago)
+        const long long o = (v * A.nchan + cl) * 2;
         double g0 = cur.g0, g1 = cur.g1;
         if (live) {
-            double q0 = 0, q1 = 0, q3 = 0, s0 = 0, s1 = 0;
-            auto add = [&](double ex, double ey, double fj, double y0, double y1) {
-                const double l = sqrt(ex * ex + ey * ey), l3 = l * l * l;
+            const int m = (int)gs_word(rec_a, 0);
+            double s0 = 0, s1 = 0;
+            auto add = [&](double ex, double ey, double l3, double fj, double y0, double y1) {
                 const double df2 = -ex * y0 - ey * y1;
-                q0 += 4 * ex * ex / l3;
-                q1 += 4 * ex * ey / l3;
-                q3 += 4 * ey * ey / l3;
                 const double tt = (6 * (cur.fi - fj) - 2 * df2) / l3;
                 s0 += tt * ex;
                 s1 += tt * ey;
             };
-            // a neighbour with a smaller index in this wave's own row: the previous point or the one before it come from
-            // registers, anything older from the array (written by this wave: visible to it)
-            auto own = [&](long long j, double& y0, double& y1) {
-                if (j == v - 1) {
+            // this sweep's gradient of a neighbour with a smaller index: the previous point or the one before it come from
+            // registers, anything older — another row's or this row's — is a hand-over
+            auto earlier = [&](long long j, unsigned long long b0, unsigned long long b1, double& y0, double& y1) {
+                if (j == v - 1 && j >= v0) {
                     y0 = p0, y1 = p1;
-                } else if (j == v - 2) {
+                } else if (j == v - 2 && j >= v0) {
                     y0 = pp0, y1 = pp1;
                 } else {
-                    y0 = gs_read(A.y_new + (j * A.nchan + lane) * 2, A.err + 63), y1 = gs_read(A.y_new + (j * A.nchan + lane) * 2 + 1, A.err + 63);
+                    const unsigned long long* q = A.y_new + (j * A.nchan + cl) * 2;
+                    y0 = b0 == kGsMarker ? gs_read(q, A.err + 63) : __longlong_as_double((long long)b0);
+                    y1 = b1 == kGsMarker ? gs_read(q + 1, A.err + 63) : __longlong_as_double((long long)b1);
                 }
             };
 #pragma unroll
             for (int t = 0; t < kGsPre; ++t) {
-                const long long j = cur.j[t];
-                if (j < 0) continue;
-                double y0 = cur.y0[t], y1 = cur.y1[t];                 // j > v: the previous sweep's
-                if (j < v0) {
-                    const unsigned long long* q = A.y_new + (j * A.nchan + lane) * 2;
-                    y0 = cur.r0[t] == kGsMarker ? gs_read(q, A.err + 63) : __longlong_as_double((long long)cur.r0[t]);
-                    y1 = cur.r1[t] == kGsMarker ? gs_read(q + 1, A.err + 63) : __longlong_as_double((long long)cur.r1[t]);
-                } else if (j < v) {
-                    own(j, y0, y1);
-                }
-                add(cur.ex[t], cur.ey[t], cur.fj[t], y0, y1);
+                const long long j = neighbour(rec_a, t);
+                if (j < 0) continue;                                       // (wave-uniform)
+                double y0 = cur.o0[t], y1 = cur.o1[t];                     // j > v: the previous sweep's
+                if (j < v) earlier(j, cur.n0[t], cur.n1[t], y0, y1);
+                add(gs_word_f64(rec_a, 5 + t), gs_word_f64(rec_a, 13 + t), gs_word_f64(rec_a, 21 + t), cur.fj[t], y0, y1);
             }
-            // more neighbours than were fetched ahead (hull points): one by one
-            for (long long k = cur.b + kGsPre; k < cur.e; ++k) {
-                const long long j = A.indices[k];
-                double y0, y1;
-                if (j > v) {
-                    y0 = A.y_old[(j * A.nchan + lane) * 2], y1 = A.y_old[(j * A.nchan + lane) * 2 + 1];
-                } else if (j >= v0) {
-                    own(j, y0, y1);
-                } else {
-                    y0 = gs_read(A.y_new + (j * A.nchan + lane) * 2, A.err + 63), y1 = gs_read(A.y_new + (j * A.nchan + lane) * 2 + 1, A.err + 63);
+            if (m > kGsPre) {
+                // more neighbours than a record holds (hull points): one by one
+                const long long b = A.indptr[v], e = A.indptr[v + 1];
+                const double xi = A.xy[2 * v], yi = A.xy[2 * v + 1];
+                for (long long k = b + kGsPre; k < e; ++k) {
+                    const long long j = A.indices[k];
+                    double y0, y1;
+                    if (j > v) {
+                        y0 = A.y_old[(j * A.nchan + cl) * 2], y1 = A.y_old[(j * A.nchan + cl) * 2 + 1];
+                    } else {
+                        earlier(j, kGsMarker, kGsMarker, y0, y1);
+                    }
+                    const double ex = A.xy[2 * j] - xi, ey = A.xy[2 * j + 1] - yi;
+                    const double l = sqrt(ex * ex + ey * ey), l3 = l * l * l;
+                    add(ex, ey, l3, A.values[j * A.nchan + cl], y0, y1);
                 }
-                add(A.xy[2 * j] - cur.xi, A.xy[2 * j + 1] - cur.yi, A.values[j * A.nchan + lane], y0, y1);
             }
+            const double q0 = gs_word_f64(rec_a, 29), q1 = gs_word_f64(rec_a, 30), q3 = gs_word_f64(rec_a, 31);
             const double det = q0 * q3 - q1 * q1;
             const double r0_ = (q3 * s0 - q1 * s1) / det, r1_ = (-q1 * s0 + q0 * s1) / det;
             double change = fmax(fabs(g0 + r0_), fabs(g1 + r1_));
@@ -935,8 +985,11 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
         }
         pp0 = p0, pp1 = p1;
         p0 = g0, p1 = g1;
-        __hip_atomic_store(A.y_new + o, gs_bits(g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(A.y_new + o + 1, gs_bits(g1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (chan) {
+            __hip_atomic_store(A.y_new + o, gs_bits(g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.y_new + o + 1, gs_bits(g1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        rec_a = rec_b, rec_b = rec_c;
         cur = nxt;
     }
     if (live && worst > 0) atomicMax(&A.err[lane], (unsigned long long)__double_as_longlong(worst));
@@ -1262,8 +1315,9 @@ int amt_cubic_gradients_csr(amt_ctx* ctx, const double* xy, int64_t n, const int
     AMT_REQUIRE(ctx, n >= 3 && n < 2147483647LL && n_rows >= 1, "bad size");
     AMT_REQUIRE(ctx, nchan >= 1 && nchan <= 63, "1..63 channels");
     AMT_REQUIRE(ctx, tolerance > 0 && max_iterations >= 1, "tolerance and max_iterations must be positive");
-    const size_t grad_bytes = (size_t)n * nchan * 2 * sizeof(double);
-    char* ws = static_cast<char*>(amt_workspace(ctx, grad_bytes + 1024));
+    const size_t grad_bytes = ((size_t)n * nchan * 2 * sizeof(double) + 255) & ~(size_t)255;
+    const size_t rec_bytes = (size_t)n * kGsRecWords * sizeof(unsigned long long);
+    char* ws = static_cast<char*>(amt_workspace(ctx, grad_bytes + 1024 + rec_bytes));
     if (ws == nullptr) {
         ctx->last_error = "amt_cubic_gradients_csr: workspace allocation failed";
         return AMT_ENOMEM;
@@ -1272,7 +1326,11 @@ int amt_cubic_gradients_csr(amt_ctx* ctx, const double* xy, int64_t n, const int
     unsigned long long* err = reinterpret_cast<unsigned long long*>(ws + grad_bytes);      // [64]
     unsigned int* ticket = reinterpret_cast<unsigned int*>(ws + grad_bytes + 512);
     unsigned char* active = reinterpret_cast<unsigned char*>(ws + grad_bytes + 576);      // [64]
-    AMT_HIP(ctx, hipMemsetAsync(gradients, 0, grad_bytes, ctx->stream));
+    unsigned long long* rec = reinterpret_cast<unsigned long long*>(ws + grad_bytes + 1024);
+    AMT_HIP(ctx, hipMemsetAsync(gradients, 0, (size_t)n * nchan * 2 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_cubic_geometry, grid_for(n), dim3(kBlock), 0, ctx->stream, xy, reinterpret_cast<const long long*>(indptr), indices,
+                       n, rec);
+    AMT_LAUNCH_CHECK(ctx);
     unsigned char host_active[64];
     for (int c = 0; c < 64; ++c) host_active[c] = c < nchan ? 1 : 0;
     for (int c = 0; c < nchan; ++c) iterations[c] = 0;
@@ -1280,7 +1338,7 @@ int amt_cubic_gradients_csr(amt_ctx* ctx, const double* xy, int64_t n, const int
     gs_args A;
     A.xy = xy, A.indptr = reinterpret_cast<const long long*>(indptr), A.indices = indices;
     A.row_start = reinterpret_cast<const long long*>(row_start), A.n_rows = n_rows, A.nchan = nchan;
-    A.values = values, A.ticket = ticket, A.err = err, A.active = active;
+    A.values = values, A.ticket = ticket, A.err = err, A.active = active, A.rec = rec;
     double* bufs[2] = {gradients, other};
     int cur = 0;                                   // bufs[cur] holds the latest sweep
     const int64_t n_comp = n * nchan * 2;
@@ -1314,7 +1372,8 @@ int amt_cubic_gradients_csr(amt_ctx* ctx, const double* xy, int64_t n, const int
         if (!any) break;
         if (changed) AMT_HIP(ctx, hipMemcpyAsync(active, host_active, 64, hipMemcpyHostToDevice, ctx->stream));
     }
-    if (cur != 0) AMT_HIP(ctx, hipMemcpyAsync(gradients, other, grad_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (cur != 0)
+        AMT_HIP(ctx, hipMemcpyAsync(gradients, other, (size_t)n * nchan * 2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return AMT_OK;
 }
 
