@@ -870,17 +870,22 @@ __device__ __forceinline__ double gs_word_f64(unsigned long long w, int k) { ret
 // what a point's right-hand side needs from its (first eight) neighbours, per channel lane
 struct gs_data {
     double fi, g0, g1;                                   // the point's own value and previous gradient
-    double fj[kGsPre], o0[kGsPre], o1[kGsPre];           // neighbours' values and previous-sweep gradients
-    unsigned long long n0[kGsPre], n1[kGsPre];           // ... and this sweep's (hand-overs: the marker where not written yet)
+    double fj[kGsPre];                                   // neighbours' values
+    unsigned long long y0[kGsPre], y1[kGsPre];           // their gradients: the previous sweep's for neighbours with a larger index,
+                                                         // this sweep's for the others (hand-overs: the marker where not written yet)
 };
 
-// Software pipeline of a row: while point v is worked on, the RECORD of point v + 2 and the DATA of point v + 1 (addressed through
-// the record of v + 1, which arrived a step ago) are in flight; every load is issued a whole step before its use.  The loads are
-// unconditional (both sweeps' gradients of every neighbour; an absent neighbour reads the point itself): no branch between a load
-// and its use.  A row runs a few points behind the row above it, so a hand-over is usually final when it is fetched; one that
-// still shows the marker is read again when its turn comes (gs_read).  The sweep's critical path is (row length + lag x rows)
-// steps long: with the loads of a step issued at the step itself a step took 10 us (three dependent round trips: CSR pointer,
-// indices, data), with everything one point ahead 9 (the same chain, merely started earlier), in this form the arithmetic.
+// Software pipeline of a row, three points deep: when point v is done its registers take the DATA of point v + 3 (addressed through
+// the record of v + 3, which has had a step to arrive) and the RECORD of point v + 4 is requested: every load is issued two to
+// three steps before its use.  The loads are unconditional (an absent neighbour reads the point itself; which sweep's array a
+// neighbour's gradient comes from is a wave-uniform choice of the base pointer): no branch between a load and its use, the
+// compiler counts them (s_waitcnt vmcnt(n), n > 0: the step's own two stores are never waited for).  A row runs a few points
+// behind the row above it, so a hand-over is usually final when it is fetched; one that still shows the marker — another row's,
+// or this row's own point of three steps ago whose store the load overtook — is read again when its turn comes (gs_read): a
+// component is the marker or final, never anything else.  The sweep's critical path is (row length + lag x rows) steps long:
+// with the loads of a step issued at the step itself a step took 10 us (three dependent round trips: CSR pointer, indices,
+// data), with everything one point ahead 9 (the same chain, merely started earlier), with records and one point of look-ahead
+// 3.4, in this form see tools/cubic_full_probe.py.
 __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
     const int lane = threadIdx.x;
     int row = 0;
@@ -893,6 +898,7 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
     const int cl = chan ? lane : 0;                       // (lanes beyond the channels load channel 0's data and store nothing)
     const bool live = chan && A.active[cl] != 0;
     const long long last = v1 - 1;
+    const unsigned long long* const y_old = reinterpret_cast<const unsigned long long*>(A.y_old);
     auto load_rec = [&](long long v) {
         v = v < last ? v : last;                          // (past the row's end: the last record again, never used)
         return A.rec[v * kGsRecWords + (lane & (kGsRecWords - 1))];
@@ -911,25 +917,27 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
             int j = neighbour(rec, t);
             j = j < 0 ? (int)v : j;
             const long long q = ((long long)j * A.nchan + cl) * 2;
+            const unsigned long long* src = j > v ? y_old : A.y_new;       // (wave-uniform)
             D.fj[t] = A.values[(long long)j * A.nchan + cl];
-            D.o0[t] = A.y_old[q], D.o1[t] = A.y_old[q + 1];
-            D.n0[t] = __hip_atomic_load(A.y_new + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            D.n1[t] = __hip_atomic_load(A.y_new + q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            D.y0[t] = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            D.y1[t] = __hip_atomic_load(src + q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     double worst = 0;
     // this wave's latest two points' new gradients (neighbours in the own row are mostly the previous one or two points)
     double p0 = 0, p1 = 0, pp0 = 0, pp1 = 0;
-    unsigned long long rec_a = load_rec(v0), rec_b = load_rec(v0 + 1);
-    gs_data cur, nxt;
-    load_data(rec_a, v0, cur);
-    for (long long v = v0; v < v1; ++v) {
-        const unsigned long long rec_c = load_rec(v + 2);
-        load_data(rec_b, v + 1, nxt);                                     // (needs rec_b: issued a step ago)
+    // records of points v .. v + 4
+    unsigned long long r0 = load_rec(v0), r1 = load_rec(v0 + 1), r2 = load_rec(v0 + 2), r3 = load_rec(v0 + 3), r4 = 0;
+    gs_data d0, d1, d2;
+    load_data(r0, v0, d0);
+    load_data(r1, v0 + 1, d1);
+    load_data(r2, v0 + 2, d2);
+    auto step = [&](const long long v, gs_data& cur) {
+        r4 = load_rec(v + 4);
         const long long o = (v * A.nchan + cl) * 2;
         double g0 = cur.g0, g1 = cur.g1;
         if (live) {
-            const int m = (int)gs_word(rec_a, 0);
+            const int m = (int)gs_word(r0, 0);
             double s0 = 0, s1 = 0;
             auto add = [&](double ex, double ey, double l3, double fj, double y0, double y1) {
                 const double df2 = -ex * y0 - ey * y1;
@@ -952,11 +960,11 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
             };
 #pragma unroll
             for (int t = 0; t < kGsPre; ++t) {
-                const long long j = neighbour(rec_a, t);
+                const long long j = neighbour(r0, t);
                 if (j < 0) continue;                                       // (wave-uniform)
-                double y0 = cur.o0[t], y1 = cur.o1[t];                     // j > v: the previous sweep's
-                if (j < v) earlier(j, cur.n0[t], cur.n1[t], y0, y1);
-                add(gs_word_f64(rec_a, 5 + t), gs_word_f64(rec_a, 13 + t), gs_word_f64(rec_a, 21 + t), cur.fj[t], y0, y1);
+                double y0 = __longlong_as_double((long long)cur.y0[t]), y1 = __longlong_as_double((long long)cur.y1[t]);      // j > v
+                if (j < v) earlier(j, cur.y0[t], cur.y1[t], y0, y1);
+                add(gs_word_f64(r0, 5 + t), gs_word_f64(r0, 13 + t), gs_word_f64(r0, 21 + t), cur.fj[t], y0, y1);
             }
             if (m > kGsPre) {
                 // more neighbours than a record holds (hull points): one by one
@@ -975,7 +983,7 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
                     add(ex, ey, l3, A.values[j * A.nchan + cl], y0, y1);
                 }
             }
-            const double q0 = gs_word_f64(rec_a, 29), q1 = gs_word_f64(rec_a, 30), q3 = gs_word_f64(rec_a, 31);
+            const double q0 = gs_word_f64(r0, 29), q1 = gs_word_f64(r0, 30), q3 = gs_word_f64(r0, 31);
             const double det = q0 * q3 - q1 * q1;
             const double r0_ = (q3 * s0 - q1 * s1) / det, r1_ = (-q1 * s0 + q0 * s1) / det;
             double change = fmax(fabs(g0 + r0_), fabs(g1 + r1_));
@@ -989,8 +997,13 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
             __hip_atomic_store(A.y_new + o, gs_bits(g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(A.y_new + o + 1, gs_bits(g1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        rec_a = rec_b, rec_b = rec_c;
-        cur = nxt;
+        load_data(r3, v + 3, cur);                                        // this point's registers: the point three further on
+        r0 = r1, r1 = r2, r2 = r3, r3 = r4;
+    };
+    for (long long v = v0; v < v1; v += 3) {
+        step(v, d0);
+        if (v + 1 < v1) step(v + 1, d1);
+        if (v + 2 < v1) step(v + 2, d2);
     }
     if (live && worst > 0) atomicMax(&A.err[lane], (unsigned long long)__double_as_longlong(worst));
 }
