@@ -312,6 +312,40 @@ def test_bounding_box_center_and_size_reference_vectors():
     np.testing.assert_array_almost_equal(bb.center, m['center'])
 
 
+def test_angular_distance_on_parallel_against_vincenty():
+    """A second independent route to geographiclib's a12 (absent offline): Vincenty's inverse formulae (Survey Review 23, 1975 —
+    another published algorithm, a series to the third order in the flattening iterated on the longitude on the auxiliary
+    sphere), whose sigma IS the arc on the auxiliary sphere.  Good to ~1e-10 relative away from the antipode."""
+    import math
+    from auromat_amd.coordinates.geodesic import WGS84_f, angularDistanceOnParallel
+    f = WGS84_f
+
+    def vincenty_sigma(lat1, lat2, dlon):
+        u1, u2 = math.atan((1 - f) * math.tan(math.radians(lat1))), math.atan((1 - f) * math.tan(math.radians(lat2)))
+        L = math.radians(dlon)
+        lam = L
+        for _ in range(200):
+            sin_s = math.hypot(math.cos(u2) * math.sin(lam), math.cos(u1) * math.sin(u2) - math.sin(u1) * math.cos(u2) * math.cos(lam))
+            cos_s = math.sin(u1) * math.sin(u2) + math.cos(u1) * math.cos(u2) * math.cos(lam)
+            sigma = math.atan2(sin_s, cos_s)
+            sin_a = math.cos(u1) * math.cos(u2) * math.sin(lam) / sin_s
+            cos2_a = 1 - sin_a ** 2
+            cos_2sm = cos_s - 2 * math.sin(u1) * math.sin(u2) / cos2_a if cos2_a > 0 else 0.0
+            c = f / 16 * cos2_a * (4 + f * (4 - 3 * cos2_a))
+            new = L + (1 - c) * f * sin_a * (sigma + c * sin_s * (cos_2sm + c * cos_s * (-1 + 2 * cos_2sm ** 2)))
+            if abs(new - lam) < 1e-15:
+                break
+            lam = new
+        return math.degrees(sigma)
+
+    for lat, dlon in ((55.0, 25.0), (-57.5, 25.5), (80.0, 120.0), (30.0, 1.0), (10.0, 40.0), (51.05, 10.3), (-75.0, 90.0), (5.0, 0.02),
+                      (0.0, 17.0)):
+        got, want = angularDistanceOnParallel(lat, dlon), vincenty_sigma(lat, lat, dlon)
+        # (2e-10 relative; a few 1e-11 deg absolute where the arc itself is a fraction of a degree and both routes are at the
+        # resolution of their own arithmetic)
+        assert abs(got - want) < 2e-10 * want + 3e-11, (lat, dlon, got, want)
+
+
 def test_geodesic_direct_inverse_consistency():
     """destination / intermediate / line invert distance / course; the parallel arc of plateCarreeResolution equals
     the general inverse solution."""
