@@ -19,7 +19,7 @@
 // Delaunay algorithms join their halves — the lower and upper common tangents of the two hulls, the gap between the facing hull
 // chains filled by triangles that each take the next vertex of one chain, then Lawson's flips from the seam until every edge is
 // locally Delaunay again (a few per seam vertex).  The Delaunay triangulation is unique (see above), so the result is the
-// sequential one; the tests compare the two triangle for triangle.  AMT_DELAUNAY_THREADS (default: up to 8),
+// sequential one; the tests compare the two triangle for triangle.  AMT_DELAUNAY_THREADS (default: up to 16),
 // AMT_DELAUNAY_PARALLEL_MIN (points from which on the parallel build is used; default 200 000).
 #include <algorithm>
 #include <cmath>
@@ -841,7 +841,7 @@ int amt_delaunay_create_threads(const double* xy, int64_t n, int32_t threads, in
         static const int env_threads = [] {
             const char* e = std::getenv("AMT_DELAUNAY_THREADS");
             const int v = e ? std::atoi(e) : 0;
-            return v > 0 ? v : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+            return v > 0 ? v : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
         }();
         threads = env_threads;
     }

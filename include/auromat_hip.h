@@ -509,7 +509,7 @@ int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx,
  *   amt_delaunay_create   HOST: the Delaunay triangulation of n >= 3 points xy (n, 2) (host memory; unique unless four points
  *                         are cocircular to the last bit: then Qhull's diagonal is not reproduced).  AMT_EINVAL when all
  *                         points are collinear.  Points that coincide with an earlier one are left out (amt_delaunay_sizes).
- *   amt_delaunay_create_threads   the same with the number of threads (<= 0: AMT_DELAUNAY_THREADS, else up to 8) and the number of
+ *   amt_delaunay_create_threads   the same with the number of threads (<= 0: AMT_DELAUNAY_THREADS, else up to 16) and the number of
  *                         points from which on the build is parallel (<= 0: AMT_DELAUNAY_PARALLEL_MIN, else 200 000): vertical
  *                         strips triangulated side by side and joined at their seams (common tangents, the gap filled, Lawson
  *                         flips) — the same triangulation, the triangles in another order.
