@@ -859,92 +859,94 @@ __global__ __launch_bounds__(kBlock) void k_cubic_geometry(const double* __restr
     }
 }
 
-// word k of the record a wave holds one word per lane of (wave-uniform result)
-__device__ __forceinline__ unsigned long long gs_word(unsigned long long w, int k) {
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)w, k);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(w >> 32), k);
-    return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ double gs_word_f64(unsigned long long w, int k) { return __longlong_as_double((long long)gs_word(w, k)); }
+// Lanes of a wave are (neighbour, channel) pairs — eight neighbours x eight channels —: every lane gathers ONE term of a point's
+// right-hand side, and the eight terms of a channel are then added in the order of the neighbours (lane to lane, ds_bpermute), so
+// that the sum has scipy's rounding.  (With lanes as channels only — the first form — four of 64 lanes worked for an RGB image
+// and its elevation, and a step of the sweep's critical path was the ~1000 instructions of all eight terms one after the other.)
+constexpr int kGsChan = 8;          // channels per wave; more channels: more waves per row (blockIdx.y), each with its own ticket
 
-// what a point's right-hand side needs from its (first eight) neighbours, per channel lane
-struct gs_data {
-    double fi, g0, g1;                                   // the point's own value and previous gradient
-    double fj[kGsPre];                                   // neighbours' values
-    unsigned long long y0[kGsPre], y1[kGsPre];           // their gradients: the previous sweep's for neighbours with a larger index,
-                                                         // this sweep's for the others (hand-overs: the marker where not written yet)
+// what one lane needs for its term of point u: from the record (j, ex, ey, l3; count and matrix: the same in every lane) and,
+// addressed through j, the neighbour's value and gradient
+struct gs_term {
+    int j, m;
+    double ex, ey, l3, q0, q1, q3;
+    double fi, g0, g1;                                   // the point's own value and previous gradient (this lane's channel)
+    double fj;
+    unsigned long long y0, y1;                           // the neighbour's gradient: the previous sweep's (j > u) or this sweep's
+                                                         // (a hand-over: the marker where not written yet)
 };
 
-// Software pipeline of a row, three points deep: when point v is done its registers take the DATA of point v + 3 (addressed through
-// the record of v + 3, which has had a step to arrive) and the RECORD of point v + 4 is requested: every load is issued two to
-// three steps before its use.  The loads are unconditional (an absent neighbour reads the point itself; which sweep's array a
-// neighbour's gradient comes from is a wave-uniform choice of the base pointer): no branch between a load and its use, the
-// compiler counts them (s_waitcnt vmcnt(n), n > 0: the step's own two stores are never waited for).  A row runs a few points
-// behind the row above it, so a hand-over is usually final when it is fetched; one that still shows the marker — another row's,
-// or this row's own point of three steps ago whose store the load overtook — is read again when its turn comes (gs_read): a
-// component is the marker or final, never anything else.  The sweep's critical path is (row length + lag x rows) steps long:
-// with the loads of a step issued at the step itself a step took 10 us (three dependent round trips: CSR pointer, indices,
-// data), with everything one point ahead 9 (the same chain, merely started earlier), with records and one point of look-ahead
-// 3.4, in this form see tools/cubic_full_probe.py.
+// Software pipeline of a row: when point v is done, the lane's registers for it take the DATA of point v + 3, addressed through
+// the record fields of v + 3 (requested a step earlier), and the RECORD fields of point v + 4 are requested: every load is issued
+// two to three steps before its use, with no branch in between (an absent neighbour reads the point itself; which sweep's array
+// a gradient comes from is a select on the address).  A row runs a few points behind the row above it, so a hand-over is
+// usually final when it is fetched; one that still shows the marker — another row's, or this row's own point of three steps ago
+// whose store the load overtook — is read again when its turn comes (gs_read): a component is the marker or final, never
+// anything else.  The sweep's critical path is (row length + lag x rows) steps long: with the loads of a step issued at the step
+// itself a step took 10 us (three dependent round trips: CSR pointer, indices, data), with everything one point ahead 9 (the
+// same chain, merely started earlier), with records and the loads ahead 3.4 (lanes as channels: instruction latency), in this
+// form see tools/cubic_full_probe.py.
 __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
     const int lane = threadIdx.x;
+    const int t = lane >> 3, c = lane & 7;                // this lane's neighbour slot and channel within the group
+    const int group = blockIdx.y;
     int row = 0;
-    if (lane == 0) row = (int)atomicAdd(A.ticket, 1u);
+    if (lane == 0) row = (int)atomicAdd(A.ticket + group, 1u);
     row = __builtin_amdgcn_readfirstlane(row);
     if (row >= A.n_rows) return;
     const long long v0 = A.row_start[row], v1 = A.row_start[row + 1];
-    const bool chan = lane < A.nchan;
     if (v0 >= v1) return;
-    const int cl = chan ? lane : 0;                       // (lanes beyond the channels load channel 0's data and store nothing)
+    const int ch = group * kGsChan + c;
+    const bool chan = ch < A.nchan;
+    const int cl = chan ? ch : 0;                         // (lanes beyond the channels work on channel 0 and store nothing)
     const bool live = chan && A.active[cl] != 0;
     const long long last = v1 - 1;
     const unsigned long long* const y_old = reinterpret_cast<const unsigned long long*>(A.y_old);
-    auto load_rec = [&](long long v) {
-        v = v < last ? v : last;                          // (past the row's end: the last record again, never used)
-        return A.rec[v * kGsRecWords + (lane & (kGsRecWords - 1))];
+    struct rec_fields {
+        unsigned int j, m;
+        unsigned long long ex, ey, l3, q0, q1, q3;
     };
-    auto neighbour = [&](unsigned long long rec, int t) {                 // index of neighbour t, -1 when absent (wave-uniform)
-        const unsigned long long w = gs_word(rec, 1 + t / 2);
-        return (int)(unsigned int)((t & 1) ? (w >> 32) : w);
+    auto request_record = [&](long long u, rec_fields& R) {
+        u = u < last ? u : last;                          // (past the row's end: the last record again, never used)
+        const unsigned long long* r = A.rec + u * kGsRecWords;
+        R.j = reinterpret_cast<const unsigned int*>(r + 1)[t];
+        R.m = reinterpret_cast<const unsigned int*>(r)[0];
+        R.ex = r[5 + t], R.ey = r[13 + t], R.l3 = r[21 + t];
+        R.q0 = r[29], R.q1 = r[30], R.q3 = r[31];
     };
-    auto load_data = [&](unsigned long long rec, long long v, gs_data& D) {
-        v = v < last ? v : last;
-        const long long o = (v * A.nchan + cl) * 2;
-        D.fi = A.values[v * A.nchan + cl];
+    auto request_data = [&](const rec_fields& R, long long u, gs_term& D) {
+        u = u < last ? u : last;
+        D.j = (int)R.j, D.m = (int)R.m;
+        D.ex = __longlong_as_double((long long)R.ex), D.ey = __longlong_as_double((long long)R.ey);
+        D.l3 = __longlong_as_double((long long)R.l3);
+        D.q0 = __longlong_as_double((long long)R.q0), D.q1 = __longlong_as_double((long long)R.q1);
+        D.q3 = __longlong_as_double((long long)R.q3);
+        const long long o = (u * A.nchan + cl) * 2;
+        D.fi = A.values[u * A.nchan + cl];
         D.g0 = A.y_old[o], D.g1 = A.y_old[o + 1];
-#pragma unroll
-        for (int t = 0; t < kGsPre; ++t) {
-            int j = neighbour(rec, t);
-            j = j < 0 ? (int)v : j;
-            const long long q = ((long long)j * A.nchan + cl) * 2;
-            const unsigned long long* src = j > v ? y_old : A.y_new;       // (wave-uniform)
-            D.fj[t] = A.values[(long long)j * A.nchan + cl];
-            D.y0[t] = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            D.y1[t] = __hip_atomic_load(src + q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const long long j = D.j < 0 ? u : (long long)D.j;
+        const long long q = (j * A.nchan + cl) * 2;
+        const unsigned long long* src = j > u ? y_old : A.y_new;
+        D.fj = A.values[j * A.nchan + cl];
+        D.y0 = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        D.y1 = __hip_atomic_load(src + q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     double worst = 0;
-    // this wave's latest two points' new gradients (neighbours in the own row are mostly the previous one or two points)
+    // this row's latest two points' new gradients of this lane's channel (every lane of a channel computes them)
     double p0 = 0, p1 = 0, pp0 = 0, pp1 = 0;
-    // records of points v .. v + 4
-    unsigned long long r0 = load_rec(v0), r1 = load_rec(v0 + 1), r2 = load_rec(v0 + 2), r3 = load_rec(v0 + 3), r4 = 0;
-    gs_data d0, d1, d2;
-    load_data(r0, v0, d0);
-    load_data(r1, v0 + 1, d1);
-    load_data(r2, v0 + 2, d2);
-    auto step = [&](const long long v, gs_data& cur) {
-        r4 = load_rec(v + 4);
+    rec_fields pending;
+    gs_term d0, d1, d2;
+    request_record(v0, pending);
+    request_data(pending, v0, d0);
+    request_record(v0 + 1, pending);
+    request_data(pending, v0 + 1, d1);
+    request_record(v0 + 2, pending);
+    request_data(pending, v0 + 2, d2);
+    request_record(v0 + 3, pending);
+    auto step = [&](const long long v, gs_term& cur) {
         const long long o = (v * A.nchan + cl) * 2;
         double g0 = cur.g0, g1 = cur.g1;
-        if (live) {
-            const int m = (int)gs_word(r0, 0);
-            double s0 = 0, s1 = 0;
-            auto add = [&](double ex, double ey, double l3, double fj, double y0, double y1) {
-                const double df2 = -ex * y0 - ey * y1;
-                const double tt = (6 * (cur.fi - fj) - 2 * df2) / l3;
-                s0 += tt * ex;
-                s1 += tt * ey;
-            };
+        {
             // this sweep's gradient of a neighbour with a smaller index: the previous point or the one before it come from
             // registers, anything older — another row's or this row's — is a hand-over
             auto earlier = [&](long long j, unsigned long long b0, unsigned long long b1, double& y0, double& y1) {
@@ -958,54 +960,83 @@ __global__ __launch_bounds__(64) void k_cubic_gs(gs_args A) {
                     y1 = b1 == kGsMarker ? gs_read(q + 1, A.err + 63) : __longlong_as_double((long long)b1);
                 }
             };
-#pragma unroll
-            for (int t = 0; t < kGsPre; ++t) {
-                const long long j = neighbour(r0, t);
-                if (j < 0) continue;                                       // (wave-uniform)
-                double y0 = __longlong_as_double((long long)cur.y0[t]), y1 = __longlong_as_double((long long)cur.y1[t]);      // j > v
-                if (j < v) earlier(j, cur.y0[t], cur.y1[t], y0, y1);
-                add(gs_word_f64(r0, 5 + t), gs_word_f64(r0, 13 + t), gs_word_f64(r0, 21 + t), cur.fj[t], y0, y1);
+            auto term = [&](double ex, double ey, double l3, double fj, double y0, double y1, double& a, double& b) {
+                const double df2 = -ex * y0 - ey * y1;
+                const double tt = (6 * (cur.fi - fj) - 2 * df2) / l3;
+                a = tt * ex, b = tt * ey;
+            };
+            double a = 0, b = 0;
+            if (live && t < cur.m) {
+                const long long j = cur.j;
+                double y0 = __longlong_as_double((long long)cur.y0), y1 = __longlong_as_double((long long)cur.y1);          // j > v
+                if (j < v) earlier(j, cur.y0, cur.y1, y0, y1);
+                term(cur.ex, cur.ey, cur.l3, cur.fj, y0, y1, a, b);
             }
-            if (m > kGsPre) {
-                // more neighbours than a record holds (hull points): one by one
-                const long long b = A.indptr[v], e = A.indptr[v + 1];
+            // the channel's eight terms, added in the order of the neighbours (an absent neighbour adds + 0)
+            double s0 = 0, s1 = 0;
+#pragma unroll
+            for (int k = 0; k < kGsPre; ++k) {
+                s0 += __shfl(a, k * kGsChan + c);
+                s1 += __shfl(b, k * kGsChan + c);
+            }
+            if (cur.m > kGsPre) {
+                // More neighbours than a record holds: the vertices that close the hull round a concave outline have hundreds
+                // (one at a time — the first form — they were most of a sweep: ~1400 dependent round trips, each holding up
+                // every row behind).  Eight at a time, a lane per neighbour and channel like the record's eight; the next eight
+                // indices are on their way while these are worked on.
+                const long long kb = A.indptr[v], ke = kb + cur.m;
                 const double xi = A.xy[2 * v], yi = A.xy[2 * v + 1];
-                for (long long k = b + kGsPre; k < e; ++k) {
-                    const long long j = A.indices[k];
-                    double y0, y1;
-                    if (j > v) {
-                        y0 = A.y_old[(j * A.nchan + cl) * 2], y1 = A.y_old[(j * A.nchan + cl) * 2 + 1];
-                    } else {
-                        earlier(j, kGsMarker, kGsMarker, y0, y1);
-                    }
+                long long k = kb + kGsPre + t;
+                long long j_next = k < ke ? (long long)A.indices[k] : v;
+                for (long long k0 = kb + kGsPre; k0 < ke; k0 += kGsPre) {
+                    const bool present = k < ke;
+                    const long long j = j_next;
+                    k += kGsPre;
+                    j_next = k < ke ? (long long)A.indices[k] : v;
+                    double ea = 0, eb = 0;
                     const double ex = A.xy[2 * j] - xi, ey = A.xy[2 * j + 1] - yi;
-                    const double l = sqrt(ex * ex + ey * ey), l3 = l * l * l;
-                    add(ex, ey, l3, A.values[j * A.nchan + cl], y0, y1);
+                    const double fj = A.values[j * A.nchan + cl];
+                    const unsigned long long* src = j > v ? y_old : A.y_new;
+                    const unsigned long long b0 = __hip_atomic_load(src + (j * A.nchan + cl) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long b1 = __hip_atomic_load(src + (j * A.nchan + cl) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (live && present) {
+                        double y0 = __longlong_as_double((long long)b0), y1 = __longlong_as_double((long long)b1);
+                        if (j < v) earlier(j, b0, b1, y0, y1);
+                        const double l = sqrt(ex * ex + ey * ey), l3 = l * l * l;
+                        term(ex, ey, l3, fj, y0, y1, ea, eb);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < kGsPre; ++kk) {
+                        s0 += __shfl(ea, kk * kGsChan + c);
+                        s1 += __shfl(eb, kk * kGsChan + c);
+                    }
                 }
             }
-            const double q0 = gs_word_f64(r0, 29), q1 = gs_word_f64(r0, 30), q3 = gs_word_f64(r0, 31);
-            const double det = q0 * q3 - q1 * q1;
-            const double r0_ = (q3 * s0 - q1 * s1) / det, r1_ = (-q1 * s0 + q0 * s1) / det;
-            double change = fmax(fabs(g0 + r0_), fabs(g1 + r1_));
-            change /= fmax(1.0, fmax(fabs(r0_), fabs(r1_)));
-            if (change == change) worst = fmax(worst, change);
-            g0 = -r0_, g1 = -r1_;
+            if (live) {
+                const double q0 = cur.q0, q1 = cur.q1, q3 = cur.q3;
+                const double det = q0 * q3 - q1 * q1;
+                const double r0_ = (q3 * s0 - q1 * s1) / det, r1_ = (-q1 * s0 + q0 * s1) / det;
+                double change = fmax(fabs(g0 + r0_), fabs(g1 + r1_));
+                change /= fmax(1.0, fmax(fabs(r0_), fabs(r1_)));
+                if (change == change) worst = fmax(worst, change);
+                g0 = -r0_, g1 = -r1_;
+            }
         }
         pp0 = p0, pp1 = p1;
         p0 = g0, p1 = g1;
-        if (chan) {
+        if (chan && t == 0) {
             __hip_atomic_store(A.y_new + o, gs_bits(g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(A.y_new + o + 1, gs_bits(g1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        load_data(r3, v + 3, cur);                                        // this point's registers: the point three further on
-        r0 = r1, r1 = r2, r2 = r3, r3 = r4;
+        request_data(pending, v + 3, cur);                                // this point's registers: the point three further on
+        request_record(v + 4, pending);
     };
     for (long long v = v0; v < v1; v += 3) {
         step(v, d0);
         if (v + 1 < v1) step(v + 1, d1);
         if (v + 2 < v1) step(v + 2, d2);
     }
-    if (live && worst > 0) atomicMax(&A.err[lane], (unsigned long long)__double_as_longlong(worst));
+    if (live && t == 0 && worst > 0) atomicMax(&A.err[ch], (unsigned long long)__double_as_longlong(worst));
 }
 
 // The element in the triangle amt_delaunay_locate found for every target (vertices -1: outside the hull -> NaN)
@@ -1359,7 +1390,7 @@ int amt_cubic_gradients_csr(amt_ctx* ctx, const double* xy, int64_t n, const int
         AMT_HIP(ctx, hipMemsetAsync(err, 0, 512 + 64, ctx->stream));              // err[64] and the ticket
         A.y_old = bufs[cur], A.y_new = reinterpret_cast<unsigned long long*>(bufs[1 - cur]);
         hipLaunchKernelGGL(k_fill_u64, grid_for(n_comp), dim3(kBlock), 0, ctx->stream, A.y_new, n_comp, kGsMarker);
-        hipLaunchKernelGGL(k_cubic_gs, dim3((unsigned)n_rows), dim3(64), 0, ctx->stream, A);
+        hipLaunchKernelGGL(k_cubic_gs, dim3((unsigned)n_rows, (unsigned)((nchan + kGsChan - 1) / kGsChan)), dim3(64), 0, ctx->stream, A);
         AMT_LAUNCH_CHECK(ctx);
         unsigned long long bits[64];
         AMT_HIP(ctx, hipMemcpyAsync(bits, err, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
