@@ -944,8 +944,15 @@ int amt_delaunay_locate(const amt_delaunay* d, const double* targets, int64_t m,
         return AMT_EINVAL;
     const size_t nt = d->tri.size() / 3;
     if (nt == 0) return AMT_EINVAL;
+    // (targets in pieces on threads: every piece walks on from its own previous target; the answers do not depend on the pieces —
+    // a target on an edge or a vertex gets the triangle the walk from ITS predecessor reaches first, so pieces are cut at fixed
+    // multiples of 1024 targets whatever the number of threads)
+    const int64_t piece = 1024, pieces = (m + piece - 1) / piece;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(d->n_threads, pieces), 16));
+    on_threads(T, [&](int part) {
+    for (int64_t pc = part; pc < pieces; pc += T) {
     int t = 0;
-    for (int64_t i = 0; i < m; ++i) {
+    for (int64_t i = pc * piece; i < std::min(m, (pc + 1) * piece); ++i) {
         const pt q = {targets[2 * i], targets[2 * i + 1]};
         int32_t* vo = vertices + 3 * i;
         vo[0] = vo[1] = vo[2] = -1;
@@ -983,6 +990,8 @@ int amt_delaunay_locate(const amt_delaunay* d, const double* targets, int64_t m,
             }
         }
     }
+    }
+    });
     return AMT_OK;
 }
 
