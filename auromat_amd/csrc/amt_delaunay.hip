@@ -793,38 +793,39 @@ struct amt_delaunay {
                 }
             }
         });
-        // vertex -> neighbouring vertices (scipy.spatial.Delaunay.vertex_neighbor_vertices; in no particular order).  Every
-        // triangle lists its edges counter-clockwise, so an inner edge {x, y} comes up once as x -> y and once as y -> x (from
-        // the triangle on its other side); a hull edge comes up once and gets its reverse here: no sorting, no duplicates.
-        // Threads own ranges of VERTICES and each walks all triangles: a vertex's list is in the order of the triangles whatever
-        // the number of threads.
+        // vertex -> neighbouring vertices (scipy.spatial.Delaunay.vertex_neighbor_vertices).  Every triangle lists its edges
+        // counter-clockwise, so an inner edge {x, y} comes up once as x -> y and once as y -> x (from the triangle on its other
+        // side); a hull edge comes up once and gets its reverse here: no duplicates.  Threads take pieces of the triangles and
+        // count / place with atomic adds; every vertex's list is then sorted, so that the lists — and with them the order in
+        // which the relaxation sums a point's neighbours — do not depend on how the triangulation was built.
         lap("neighbours");
         const int n = (int)p.size();
         const size_t m = tri.size() / 3;
         indptr.assign((size_t)n + 1, 0);
+        auto tri_chunk = [&](int j) { return std::pair<size_t, size_t>(m * (size_t)j / (size_t)T, m * ((size_t)j + 1) / (size_t)T); };
         on_threads(T, [&](int j) {
-            const auto r = chunk(n, j);
-            for (size_t t = 0; t < m; ++t)
+            const auto r = tri_chunk(j);
+            for (size_t t = r.first; t < r.second; ++t)
                 for (int k = 0; k < 3; ++k) {
-                    const int x = tri[3 * t + (k + 1) % 3];                            // edge opposite vertex k: v[k+1] -> v[k+2]
-                    if (x >= r.first && x < r.second) ++indptr[(size_t)x + 1];
-                    if (nbr[3 * t + k] < 0) {
-                        const int y = tri[3 * t + (k + 2) % 3];
-                        if (y >= r.first && y < r.second) ++indptr[(size_t)y + 1];
-                    }
+                    __atomic_fetch_add(&indptr[(size_t)tri[3 * t + (k + 1) % 3] + 1], (int64_t)1, __ATOMIC_RELAXED);      // v[k+1] -> v[k+2]
+                    if (nbr[3 * t + k] < 0) __atomic_fetch_add(&indptr[(size_t)tri[3 * t + (k + 2) % 3] + 1], (int64_t)1, __ATOMIC_RELAXED);
                 }
         });
         for (int i = 0; i < n; ++i) indptr[(size_t)i + 1] += indptr[(size_t)i];
         indices.resize((size_t)indptr[(size_t)n]);
         std::vector<int64_t> fill(indptr.begin(), indptr.end() - 1);
         on_threads(T, [&](int j) {
-            const auto r = chunk(n, j);
-            for (size_t t = 0; t < m; ++t)
+            const auto r = tri_chunk(j);
+            for (size_t t = r.first; t < r.second; ++t)
                 for (int k = 0; k < 3; ++k) {
                     const int x = tri[3 * t + (k + 1) % 3], y = tri[3 * t + (k + 2) % 3];
-                    if (x >= r.first && x < r.second) indices[(size_t)fill[(size_t)x]++] = y;
-                    if (nbr[3 * t + k] < 0 && y >= r.first && y < r.second) indices[(size_t)fill[(size_t)y]++] = x;
+                    indices[(size_t)__atomic_fetch_add(&fill[(size_t)x], (int64_t)1, __ATOMIC_RELAXED)] = y;
+                    if (nbr[3 * t + k] < 0) indices[(size_t)__atomic_fetch_add(&fill[(size_t)y], (int64_t)1, __ATOMIC_RELAXED)] = x;
                 }
+        });
+        on_threads(T, [&](int j) {
+            const auto r = chunk(n, j);
+            for (int64_t i = r.first; i < r.second; ++i) std::sort(indices.begin() + indptr[(size_t)i], indices.begin() + indptr[(size_t)i + 1]);
         });
         lap("vertex CSR");
     }
