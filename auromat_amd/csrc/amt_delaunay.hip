@@ -29,6 +29,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -793,12 +794,28 @@ struct amt_delaunay {
                 }
             }
         });
+        lap("neighbours");
+    }
+
+    // vertex -> neighbouring vertices, made when somebody asks for them ('linear' never does)
+    bool lists_made = false;
+    void build_vertex_lists() {
+        static const bool debug = std::getenv("AMT_DELAUNAY_DEBUG") != nullptr;
+        auto t_begin = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!debug) return;
+            const auto t = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[delaunay] %-12s %.3f s\n", what, std::chrono::duration<double>(t - t_begin).count());
+            t_begin = t;
+        };
+        const int nt = (int)dead.size();
+        const int T = std::max(1, std::min(n_threads, nt / 65536));
+        auto chunk = [&](int64_t count, int j) { return std::pair<int64_t, int64_t>(count * j / T, count * (j + 1) / T); };
         // vertex -> neighbouring vertices (scipy.spatial.Delaunay.vertex_neighbor_vertices).  Every triangle lists its edges
         // counter-clockwise, so an inner edge {x, y} comes up once as x -> y and once as y -> x (from the triangle on its other
         // side); a hull edge comes up once and gets its reverse here: no duplicates.  Threads take pieces of the triangles and
         // count / place with atomic adds; every vertex's list is then sorted, so that the lists — and with them the order in
         // which the relaxation sums a point's neighbours — do not depend on how the triangulation was built.
-        lap("neighbours");
         const int n = (int)p.size();
         const size_t m = tri.size() / 3;
         indptr.assign((size_t)n + 1, 0);
@@ -830,6 +847,19 @@ struct amt_delaunay {
         lap("vertex CSR");
     }
 };
+
+namespace {
+// (a handle is const to its readers; the lists are its cache.  One lock for all handles: the build is what takes the time)
+void ensure_vertex_lists(const amt_delaunay* d) {
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
+    amt_delaunay* m = const_cast<amt_delaunay*>(d);
+    if (!m->lists_made) {
+        m->build_vertex_lists();
+        m->lists_made = true;
+    }
+}
+}  // namespace
 
 extern "C" {
 
@@ -913,7 +943,10 @@ int amt_delaunay_destroy(amt_delaunay* d) {
 int amt_delaunay_sizes(const amt_delaunay* d, int64_t* n_triangles, int64_t* n_neighbours, int64_t* n_duplicates) {
     if (d == nullptr) return AMT_EINVAL;
     if (n_triangles) *n_triangles = (int64_t)(d->tri.size() / 3);
-    if (n_neighbours) *n_neighbours = (int64_t)d->indices.size();
+    if (n_neighbours) {
+        ensure_vertex_lists(d);
+        *n_neighbours = (int64_t)d->indices.size();
+    }
     if (n_duplicates) *n_duplicates = d->n_dup;
     return AMT_OK;
 }
@@ -934,6 +967,7 @@ int amt_delaunay_triangles(const amt_delaunay* d, int32_t* simplices, int32_t* n
 
 int amt_delaunay_vertex_neighbours(const amt_delaunay* d, int64_t* indptr, int32_t* indices) {
     if (d == nullptr || indptr == nullptr || indices == nullptr) return AMT_EINVAL;
+    ensure_vertex_lists(d);
     std::memcpy(indptr, d->indptr.data(), d->indptr.size() * sizeof(int64_t));
     std::memcpy(indices, d->indices.data(), d->indices.size() * sizeof(int32_t));
     return AMT_OK;

@@ -416,15 +416,17 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask, 
         raise ValueError('method=\'cubic\': the valid pixel centres cannot be triangulated (all collinear?)')
     mark('triangulation')
     try:
-        nt, nn, nd = C.c_int64(), C.c_int64(), C.c_int64()
-        L.amt_delaunay_sizes(handle, C.byref(nt), C.byref(nn), C.byref(nd))
-        indptr, indices = np.empty(n + 1, dtype=np.int64), np.empty(nn.value, dtype=np.int32)
-        L.amt_delaunay_vertex_neighbours(handle, indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p))
-        rows = torch.div(idx, int(width), rounding_mode='floor')
-        row_start = torch.zeros(int(height) + 1, dtype=torch.int64, device=ctx.device)
-        row_start[1:] = torch.cumsum(torch.bincount(rows, minlength=int(height)), 0)
-        d_indptr, d_indices = ctx.to_device(indptr, np.int64), ctx.to_device(indices, np.int32)
-        mark('neighbour lists to the device')
+        if method != 'linear':
+            # the vertices' neighbour lists (the library makes them when they are first asked for: 'linear' never does)
+            nt, nn, nd = C.c_int64(), C.c_int64(), C.c_int64()
+            L.amt_delaunay_sizes(handle, C.byref(nt), C.byref(nn), C.byref(nd))
+            indptr, indices = np.empty(n + 1, dtype=np.int64), np.empty(nn.value, dtype=np.int32)
+            L.amt_delaunay_vertex_neighbours(handle, indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p))
+            rows = torch.div(idx, int(width), rounding_mode='floor')
+            row_start = torch.zeros(int(height) + 1, dtype=torch.int64, device=ctx.device)
+            row_start[1:] = torch.cumsum(torch.bincount(rows, minlength=int(height)), 0)
+            d_indptr, d_indices = ctx.to_device(indptr, np.int64), ctx.to_device(indices, np.int32)
+            mark('neighbour lists to the device')
         # the grid centres that are wanted, in row-major order (the walk from one to the next is a step or two)
         wanted = np.ones((grid.ny, grid.nx), dtype=bool) if target_mask is None else ~to_host(target_mask).astype(bool)
         sel = np.flatnonzero(wanted.ravel())

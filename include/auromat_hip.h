@@ -520,7 +520,8 @@ int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx,
  *                         the points, hence Qhull's.
  *   amt_delaunay_triangles        simplices (nt, 3) counter-clockwise and neighbours (nt, 3): the triangle opposite vertex k
  *                                 or -1 (scipy.spatial.Delaunay.simplices / .neighbors, in another order of triangles)
- *   amt_delaunay_vertex_neighbours   CSR (indptr (n + 1) int64, indices int32): Delaunay.vertex_neighbor_vertices
+ *   amt_delaunay_vertex_neighbours   CSR (indptr (n + 1) int64, indices int32): Delaunay.vertex_neighbor_vertices, every vertex's
+ *                                 list in increasing order (made on first request: this call or amt_delaunay_sizes' n_neighbours)
  *   amt_delaunay_locate   for m targets (m, 2): the vertices (m, 3) of the triangle that holds each (-1: outside the hull), the
  *                         centroids (m, 3, 2) of the triangles across its three edges and has_neighbour (m, 3)
  *   amt_cubic_gradients_csr   DEVICE: interpnd._estimate_gradients_2d_global in scipy's order — every channel relaxed until the
