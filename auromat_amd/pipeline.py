@@ -63,6 +63,23 @@ class _GridView(object):
         return getattr(self._full, name)
 
 
+def earth_rows_of(params, height):
+    """(r0, r1): the pixel rows of a camera frame outside of which no ray reaches the shell (amt_georef_sky_rows)"""
+    from . import _native
+    o = [C.c_int32(0) for _ in range(4)]
+    _native.lib().amt_georef_sky_rows(C.byref(params), *[C.byref(v) for v in o])
+    rows, n, top, bottom = [v.value for v in o]
+    return max(0, top * rows), min(int(height), bottom * rows)
+
+
+def uploaded_rows(rows, height):
+    """the rows of a host image :meth:`FramePipeline.set_image` sends for ``rows`` = (r0, r1): the band when it is worth
+    it (under nine tenths of the image), else everything"""
+    if rows is not None and 0 <= rows[0] < rows[1] <= height and (rows[1] - rows[0]) < 0.9 * height:
+        return rows[0], rows[1]
+    return 0, int(height)
+
+
 class FramePipeline(object):
     def __init__(self, width, height, nchan=3, img_dtype=np.uint16, device=None, with_mag=False, alloc_image=True,
                  alloc_coords=True, with_geo=True):
@@ -176,7 +193,7 @@ class FramePipeline(object):
     def set_image(self, img, rows=None):
         """Copy an (h, w, c) host image (or device tensor of the same bytes) into the frame buffer.  A pinned host
         tensor of the buffer's dtype (uint16 images as their int16 bits) is copied asynchronously on the current
-        stream.  `rows` = (r0, r1), host arrays only: only that band of rows crosses the link now — the rows a camera frame's
+        stream.  `rows` = (r0, r1), host images only: only that band of rows crosses the link now — the rows a camera frame's
         kernels can read (outside them no ray reaches the shell: :meth:`earth_rows`) — and the rest when something asks for
         the whole image (:meth:`complete_image`)."""
         import torch
@@ -186,8 +203,14 @@ class FramePipeline(object):
             if self._img_own is None:
                 self._img_own = self.ctx.empty(self._img_shape, self._img_torch_dtype)
             self.fd.img = self._img_own
+        band = uploaded_rows(rows, self.height) != (0, self.height)
         if isinstance(img, torch.Tensor) and not img.is_cuda and img.is_pinned() and img.dtype == self.fd.img.dtype:
-            self.fd.img.copy_(img.reshape(self.fd.img.shape), non_blocking=True)
+            src = img.reshape(self.fd.img.shape)
+            if band:
+                self.fd.img[rows[0]:rows[1]].copy_(src[rows[0]:rows[1]], non_blocking=True)
+                self._img_rest = (src, rows[0], rows[1])
+            else:
+                self.fd.img.copy_(src, non_blocking=True)
             return
         if isinstance(img, torch.Tensor):
             t = self.ctx.to_device(img, self.fd.img_dtype)
@@ -196,7 +219,7 @@ class FramePipeline(object):
         a = np.ascontiguousarray(img, dtype=self.fd.img_dtype)
         assert a.size == self.fd.img.numel(), 'image of the wrong size'
         Context.current(self.ctx.device)
-        if rows is not None and 0 <= rows[0] < rows[1] <= self.height and (rows[1] - rows[0]) < 0.9 * self.height:
+        if band:
             a = a.reshape(self._img_shape)
             self.ctx.upload(a[rows[0]:rows[1]], self.fd.img[rows[0]:rows[1]])
             self._img_rest = (a, rows[0], rows[1])
@@ -210,6 +233,12 @@ class FramePipeline(object):
             a, r0, r1 = self._img_rest
             self._img_rest = None
             Context.current(self.ctx.device)
+            if hasattr(a, 'is_pinned'):                   # a pinned host tensor
+                if r0 > 0:
+                    self.fd.img[:r0].copy_(a[:r0], non_blocking=True)
+                if r1 < self.height:
+                    self.fd.img[r1:].copy_(a[r1:], non_blocking=True)
+                return
             if r0 > 0:
                 self.ctx.upload(a[:r0], self.fd.img[:r0])
             if r1 < self.height:
@@ -218,10 +247,7 @@ class FramePipeline(object):
     def earth_rows(self, params):
         """(r0, r1): the pixel rows of a camera frame outside of which no ray reaches the shell (amt_georef_sky_rows: the limb
         is a conic section in the image; conservative), i.e. the only rows whose pixels any kernel reads."""
-        o = [C.c_int32(0) for _ in range(4)]
-        self.ctx._lib.amt_georef_sky_rows(C.byref(params), *[C.byref(v) for v in o])
-        rows, n, top, bottom = [v.value for v in o]
-        return max(0, top * rows), min(self.height, bottom * rows)
+        return earth_rows_of(params, self.height)
 
     def use_image(self, img):
         """Use a device-resident image of the buffer's layout ((h, w, c) uint8, or uint16 bits as int16) in place:
@@ -1073,7 +1099,9 @@ class SequencePipeline(object):
                     for busy in self._img_busy[slot]:
                         self.s_copy.wait_event(busy)                 # the buffer's previous image is still being read
                     self._img_busy[slot] = []
-                    q.set_image(img)
+                    # a host image: only the rows a ray of this frame can hit cross the link (no kernel reads the others)
+                    on_host = not getattr(img, 'is_cuda', False)
+                    q.set_image(img, rows=q.earth_rows(p) if (on_host and p is not None) else None)
                     uploaded = torch.cuda.Event()
                     uploaded.record(self.s_copy)
                 s_main.wait_event(uploaded)

@@ -679,7 +679,15 @@ def main(argv=None):
         args.steps = saved_steps
         u_own = u['elapsed']
         u_elapsed = u_own
-        u_rates = [u_steps * WIDTH * HEIGHT * 6 / u_own / 1e9]
+        # what crossed the link: only the rows a ray of the frame can hit (FramePipeline.set_image / earth_rows), not the 72 MB
+        from auromat_amd.mapping.astrometry import frame_params
+        from auromat_amd.pipeline import earth_rows_of, uploaded_rows
+        u_bytes = 0
+        for hdr, cam, t, _, alt in u_frames[args.warmup:]:
+            r0, r1 = uploaded_rows(earth_rows_of(frame_params(hdr, alt if alt is not None else ALTITUDE, cam, t, fast, magnetic=args.magnetic),
+                                                 HEIGHT), HEIGHT)
+            u_bytes += (r1 - r0) * WIDTH * 6
+        u_rates = [u_bytes / u_own / 1e9]
         if use_dist:
             tmax = torch.tensor([u_own], dtype=torch.float64, device=cdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -690,9 +698,11 @@ def main(argv=None):
         upload = {'Mpixels_per_s': world * u_steps * WIDTH * HEIGHT / 1e6 / u_elapsed, 'ms_per_frame': u_elapsed / u_steps * 1e3,
                   'frames_per_rank': u_steps, 'kernel_ms_per_frame': u['georef_ms'],
                   'single_pass_frames': sum(1 for q in u['plans'] if q == 'single-pass'),
-                  'image_bytes_per_frame': WIDTH * HEIGHT * 6, 'pcie_GBs_per_rank': u_rates, 'pcie_GBs_total': float(sum(u_rates)),
+                  'image_bytes_per_frame': WIDTH * HEIGHT * 6, 'uploaded_bytes_per_frame': u_bytes / u_steps,
+                  'pcie_GBs_per_rank': u_rates, 'pcie_GBs_total': float(sum(u_rates)),
                   'source': 'four distinct uint16 RGB images per rank in page-locked host memory, cycled; one upload per frame on a '
-                            'copy stream (SequencePipeline, Python loop), gather of the grids included'}
+                            'copy stream (SequencePipeline, Python loop) — the rows of the image a ray can hit, the only ones a '
+                            'kernel reads —, gather of the grids included'}
         del u, u_frames, host_imgs
         import gc
         gc.collect()
