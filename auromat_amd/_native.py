@@ -40,7 +40,7 @@ class GeorefOut(C.Structure):
                [(k, C.c_void_p) for k in ('bin_xaxis', 'bin_yaxis', 'bin_img', 'bin_acc')] + \
                [(k, C.c_int32) for k in ('bin_img_dtype', 'bin_lon_wrap', 'bin_magnetic', 'item_order')] + \
                [('bin_events', C.c_void_p), ('bin_event_count', C.c_void_p), ('bin_event_capacity', C.c_int64),
-                ('bin_pole', C.c_int32), ('reserved_pole', C.c_int32), ('altitude', C.c_double)]
+                ('bin_pole', C.c_int32), ('row_layout', C.c_int32), ('altitude', C.c_double)]
 
 
 SIP_MAX = 10
@@ -106,7 +106,7 @@ class RunResult(C.Structure):
                 ('retried', C.c_int32), ('reserved2_', C.c_int32)]
 
 
-ABI_VERSION = 5          # include/auromat_hip.h AMT_ABI_VERSION
+ABI_VERSION = 6          # include/auromat_hip.h AMT_ABI_VERSION
 _I, _L, _D, _P = C.c_int, C.c_int64, C.c_double, C.c_void_p
 _SIGNATURES = {
     'amt_abi_version': ([], _I),
@@ -133,6 +133,8 @@ _SIGNATURES = {
     'amt_pipe_launch_many_res': ([c_void_pp, C.c_int32, c_void_pp, c_void_pp, c_void_pp, C.c_int32, _D, c_double_p, c_double_p, _I, _I], _I),
     'amt_plate_carree_resolution': ([_D, _D, _D, _D, _D, c_double_p, c_double_p], _I),
     'amt_upload_staged': ([_P, _P, _P, C.c_size_t], _I),
+    'amt_padded_pitch': ([C.c_int32], C.c_int64),
+    'amt_unpad_rows': ([_P, _P, C.c_int32, C.c_int32, C.c_int32, _P], _I),
     'amt_download_staged': ([_P, _P, _P, C.c_size_t], _I),
     'amt_georef_last_variant': ([_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], _I),
     'amt_directions_tan': ([_P, C.POINTER(FrameParams), _I, _P], _I),

@@ -177,6 +177,23 @@ int copier_leave(amt_ctx* ctx, amt_copier* c) {
 
 }  // namespace
 
+
+// Strip-padded rows -> contiguous rows (amt_georef_out.row_layout): element x of a row comes from 64 (x / 63) + x % 63.  A thread
+// moves two consecutive elements of the destination row (rows of width + 1 doubles start at odd multiples of 8 bytes: the pair is
+// two 8-byte stores; the reads of a wave are two runs of 63 doubles).
+__global__ __launch_bounds__(256) void k_unpad_rows(const double* __restrict__ src, int64_t pitch, int cols, double* __restrict__ dst) {
+    const int x = 2 * (blockIdx.x * 256 + threadIdx.x);
+    if (x >= cols) return;
+    const double* s = src + (int64_t)blockIdx.y * pitch;
+    double* d = dst + (int64_t)blockIdx.y * cols;
+    const int q0 = x / 63;
+    d[x] = s[q0 * 64 + (x - q0 * 63)];
+    if (x + 1 < cols) {
+        const int q1 = (x + 1) / 63;
+        d[x + 1] = s[q1 * 64 + (x + 1 - q1 * 63)];
+    }
+}
+
 extern "C" {
 
 int amt_upload_staged(amt_ctx* ctx, void* dst_device, const void* src_host, size_t bytes) {
@@ -261,6 +278,20 @@ int amt_download_staged(amt_ctx* ctx, void* dst_host, const void* src_device, si
         ctx->last_error = "amt_download_staged: a transfer failed";
         return AMT_EHIP;
     }
+    return AMT_OK;
+}
+
+
+int amt_unpad_rows(amt_ctx* ctx, const double* src_padded, int32_t rows, int32_t cols, int32_t width, double* dst) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, src_padded && dst, "NULL argument");
+    AMT_REQUIRE(ctx, rows >= 0 && width > 0 && (cols == width || cols == width + 1), "cols must be width or width + 1");
+    if (rows == 0) return AMT_OK;
+    const int64_t pitch = amt_padded_pitch(width);
+    const int pairs = (cols + 1) / 2;
+    const dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)rows);
+    hipLaunchKernelGGL(k_unpad_rows, grid, dim3(256), 0, ctx->stream, src_padded, pitch, cols, dst);
+    AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;
 }
 

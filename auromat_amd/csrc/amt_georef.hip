@@ -124,7 +124,8 @@ struct georef_args {
     // rows of work items that cannot see the shell (sky_bands(): rows [0, sky_top_end) and [sky_bottom_begin, n)); their
     // waves write NaN and cast no ray
     int sky_top_end, sky_bottom_begin;
-    int bin_pole, pad_pole_;            // amt_georef_out.bin_pole: bin (and box) in the coordinates rotated by 90 deg about x
+    int bin_pole;                       // amt_georef_out.bin_pole: bin (and box) in the coordinates rotated by 90 deg about x
+    int row_layout;                     // amt_georef_out.row_layout: 0 = contiguous rows, 1 = strip-padded rows (k_georef_rows only)
     pole_consts pole;
     bin_event* bin_events;      // optional list for on-edge pixels (amt_georef_out.bin_events)
     unsigned int* bin_event_count;
@@ -610,8 +611,10 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
             if (((b - a) & 1) && lane == 0 && b > a) base[b - 1] = NAN;
         };
         const bool mag_out = MAG && !kPole;
-        const int64_t c0 = (int64_t)y0 * W1, cn = (int64_t)n_corner_rows * W1;
-        const int64_t p0 = (int64_t)y0 * A.width, pn = (int64_t)rows * A.width;
+        // (strip-padded rows: the pad columns are part of the contiguous range and become NaN too)
+        const int64_t cpitch = A.row_layout ? (int64_t)strips_x * 64 : W1, ppitch = A.row_layout ? (int64_t)strips_x * 64 : A.width;
+        const int64_t c0 = (int64_t)y0 * cpitch, cn = (int64_t)n_corner_rows * cpitch;
+        const int64_t p0 = (int64_t)y0 * ppitch, pn = (int64_t)rows * ppitch;
         fill_nan(A.lat, c0, cn);
         fill_nan(A.lon, c0, cn);
         fill_nan(A.lat_c, p0, pn);
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
     const int bx_n = pin2(A.bxl.nbin), by_n = pin2(A.byl.nbin);
     const bool lon_wrap = pin2(A.bin_lon_wrap) != 0;
     const double sm0 = pin2(B.math.small4[0]), sm1 = pin2(B.math.small4[1]), sm2 = pin2(B.math.small4[2]), sm3 = pin2(B.math.small4[3]);
-    const int frame_w = pin2(A.width), frame_h = pin2(A.height);
+    const int frame_h = pin2(A.height);
     // State of the previous corner row.  The row loop is unrolled by two with the roles of S0 / S1 swapped, so
     // that no prev <- cur register moves are needed.
     struct row_state {
@@ -751,9 +754,22 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
 
     // byte offsets of this lane's corner (row gy) and pixel (row gy-1) inside their arrays, advanced by one row per
     // step.  They fit 32 bits (the host checks), so every store is `base in SGPRs + 32-bit lane offset`.
-    unsigned int off_corner = (unsigned int)(y0 * W1 + gx) * 8u;
-    unsigned int off_pixel = (unsigned int)((y0 - 1) * A.width + gx) * 8u;      // row -1 wraps; used from row 0 on only
-    const unsigned int pitch_corner = (unsigned int)W1 * 8u, pitch_pixel = (unsigned int)A.width * 8u;
+    // Strip-padded rows (amt_georef_out.row_layout = AMT_ROWS_STRIP_PADDED; round 6): strip s of a row lies at doubles
+    // [64 s, 64 s + 64) of a row of 64 strips_x doubles and ALL 64 lanes store — a corner array's 64th value is the next strip's
+    // first corner (the same ray), a pixel array's a pad —, so that every run a wave writes is 512 bytes on a 512-byte
+    // boundary: whole 128-byte lines only.  With contiguous rows a run is 504 bytes from an odd multiple of 8 and its first and
+    // last line are shared with the neighbour strips' waves, which write their parts at another time: the memory system
+    // takes such partial lines at well under the rate of whole ones (tools/store_pattern.hip, profiles/r6/).
+    const bool padded = A.row_layout != 0;                                       // wave-uniform
+    const unsigned int pitch_corner = padded ? (unsigned int)strips_x * 512u : (unsigned int)W1 * 8u;
+    const unsigned int pitch_pixel = padded ? (unsigned int)strips_x * 512u : (unsigned int)A.width * 8u;
+    const unsigned int col_bytes = padded ? (unsigned int)(strip * 64 + lane) * 8u : (unsigned int)gx * 8u;
+    unsigned int off_corner = (unsigned int)y0 * pitch_corner + col_bytes;
+    unsigned int off_pixel = (unsigned int)(y0 - 1) * pitch_pixel + col_bytes;  // row -1 wraps; used from row 0 on only
+    // lanes that store: with contiguous rows the owners of a column (lane 63's corner column belongs to the next strip unless
+    // it is the last, its pixel column does not exist); with strip-padded rows every lane
+    const bool st_corner = padded || (col_ok && (lane < 63 || gx == A.width));
+    const bool st_pixel = padded || px_ok;
     auto at = [](double* base, unsigned int byte_offset) -> double& {
         return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_offset);
     };
@@ -989,7 +1005,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
         if (BIN) take_pixel(r, even, ch0, ch1, ch2);
         // the last corner row of a chunk is the first of the next one (which owns it) unless it is
         // the image's last; lane 63's column likewise belongs to the next strip unless it is the last
-        const bool owner = col_ok && (lane < 63 || gx == frame_w) && (r < rows || gy == frame_h);
+        const bool owner = st_corner && (r < rows || gy == frame_h);
         if (owner) {
             if (!kMagOnly) {
                 if (out_lat) at(out_lat, off_corner) = c.la;
@@ -1081,7 +1097,7 @@ __global__ __launch_bounds__(kRowsThreads, SECOND == 4 ? AMT_ROWS_MIN_WAVES_MAGO
                 const double n = opaque_nan();
                 lac = loc = el = ml = mt = slc = rlac = rloc = n;
             }
-            if (px_ok) {
+            if (st_pixel) {
                 if (!kMagOnly && out_lat_c) at(out_lat_c, off_pixel) = lac;
                 if (!kMagOnly && out_lon_c) at(out_lon_c, off_pixel) = loc;
                 if (out_elev) at(out_elev, off_pixel) = el;
@@ -1703,7 +1719,8 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
     int bin = 0;
     A.bin_img = nullptr;
     A.bin_acc = nullptr;
-    A.bin_lon_wrap = A.bin_magnetic = A.bin_pole = A.pad_pole_ = 0;
+    A.bin_lon_wrap = A.bin_magnetic = A.bin_pole = 0;
+    A.row_layout = out->row_layout == AMT_ROWS_STRIP_PADDED ? 1 : 0;
     A.pole = make_pole_consts(p->a0, p->b0, 0.0);
     A.bin_events = nullptr;
     A.bin_event_count = nullptr;
@@ -1802,6 +1819,10 @@ int prepare_georef(amt_ctx* ctx, const amt_frame_params* p, const double* dirs, 
         fold = A.bbox_partials + n_items * 8;
     }
     AMT_REQUIRE(ctx, !(bin && use_tiles), "fused binning is implemented by the row-marching kernel only");
+    AMT_REQUIRE(ctx, out->row_layout == AMT_ROWS_CONTIGUOUS || out->row_layout == AMT_ROWS_STRIP_PADDED, "unknown row_layout");
+    AMT_REQUIRE(ctx, !(A.row_layout && use_tiles), "strip-padded rows are written by the row-marching kernel only");
+    AMT_REQUIRE(ctx, !A.row_layout || ((int64_t)p->height + 1) * sh.strips_x * 512 < (1ll << 32),
+                "frame too large for strip-padded rows (32-bit byte offsets)");
     F->sh = sh;
     F->p = p;
     F->dirs = dirs;
@@ -2022,6 +2043,14 @@ int amt_georef_sky_rows(const amt_frame_params* p, int32_t* rows_per_item, int32
     *top_end = t;
     *bottom_begin = b;
     return AMT_OK;
+}
+
+int64_t amt_padded_pitch(int32_t width) {
+    if (width <= 0) return 0;
+    amt_frame_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.width = width, p.height = 1;
+    return (int64_t)shape_of(&p).strips_x * 64;
 }
 
 int amt_georef_frame_dirs(amt_ctx* ctx, const amt_frame_params* p, const double* corner_dirs,

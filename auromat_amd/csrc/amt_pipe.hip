@@ -45,6 +45,7 @@ struct amt_pipe {
     bool two_pass;                 // amt_pipe_set_plan: never fuse the binning into the big kernel
     bool general_ready;            // amt_pipe_general_layout has laid out the exact grid of the frame in flight
     const double* g_lat_c;
+    int g_row_layout;              // amt_georef_out.row_layout of the frame in flight (strip-padded arrays: no general path here)
     const double* g_lon_c;
     const double* g_elev;
     const void* g_img;
@@ -370,6 +371,7 @@ int pipe_prepare_rest(amt_pipe* pipe, const amt_frame_params* p, const amt_geore
     }
 
     pipe->g_lat_c = out->lat_c, pipe->g_lon_c = out->lon_c, pipe->g_elev = out->elev, pipe->g_img = img;
+    pipe->g_row_layout = out->row_layout;
     pipe->g_width = p->width, pipe->g_height = p->height, pipe->g_fast = p->fast_center, pipe->g_mode = mode;
     pipe->general_ready = false;
     // coarse [lat_min, lat_max, lon_min, lon_max, lon_min_positive, lon_max_nonpositive, n, hint]
@@ -708,8 +710,9 @@ int amt_pipe_general_layout(amt_pipe* pipe, amt_pipe_result* result) {
     pipe->general_ready = false;
     if (result->status != 1) return AMT_OK;
     // what the kernels of this path do not cover stays with the caller: a pole in view (binned in rotated coordinates),
-    // exact centres (their masks are reconciled first), MLat / MLT grids, frames whose coordinate arrays were not written
-    if (pipe->pole || !pipe->g_fast || pipe->g_mode != 0 || !pipe->g_lat_c || !pipe->g_lon_c || !pipe->g_elev) return AMT_OK;
+    // exact centres (their masks are reconciled first), MLat / MLT grids, frames whose coordinate arrays were not written or
+    // lie in strip-padded rows (amt_bin_frame reads contiguous rows: the caller compacts them first, amt_unpad_rows)
+    if (pipe->pole || !pipe->g_fast || pipe->g_mode != 0 || !pipe->g_lat_c || !pipe->g_lon_c || !pipe->g_elev || pipe->g_row_layout != 0) return AMT_OK;
     const double* b = result->bbox;
     if (!(b[6] > 0)) return AMT_OK;
     // BaseMapping.boundingBox + the date-line branch of _resample (reference mapping.py:711-741, resample.py:203-218)

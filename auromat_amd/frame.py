@@ -116,4 +116,83 @@ class FrameData(object):
         return None if self.bbox is None else to_host(self.bbox)
 
 
-__all__ = ['FrameData', 'ptr']
+_UNSET = object()
+
+
+def _coord_property(name):
+    def get(self):
+        v = self._plain.get(name, _UNSET)
+        return self._compacted(name) if v is _UNSET else v
+
+    def put(self, value):
+        # (shallow copies share the dictionaries: copy on write)
+        self._plain = dict(self._plain)
+        self._plain[name] = value
+
+    return property(get, put, doc='%s: contiguous rows, compacted from the strip-padded buffer when first asked for' % name)
+
+
+class PaddedFrameData(FrameData):
+    """
+    FrameData whose coordinate arrays live in STRIP-PADDED rows (include/auromat_hip.h amt_georef_out.row_layout): the layout the
+    row kernel writes fastest, for buffers a pipeline owns.  `fd.lat` & co. still are C-contiguous (rows, cols) tensors — what the
+    reference's properties return (astrometry.py:118-152) and every other kernel reads —: they are compacted from the padded
+    buffer (amt_unpad_rows, one pass over the array on the current stream) when somebody asks, and kept until the buffers are
+    written again (:meth:`touch`).  A pipeline that only bins (the single-pass plan) never asks.
+    """
+
+    def __init__(self, ctx, height, width):
+        self._plain = {}
+        FrameData.__init__(self, ctx, height, width)
+        self._plain = {}        # names assigned as ordinary tensors (a shallow copy's swapped arrays, None for "not kept")
+        self._padded = {}       # name -> (rows, pitch) float64 tensor
+        self._cache = {}        # name -> contiguous tensor compacted from _padded[name]
+        self.pitch = int(ctx._lib.amt_padded_pitch(self.width))
+
+    def alloc_padded(self, name):
+        """The padded buffer of array `name` (allocated on first use) -> tensor (rows, pitch)."""
+        t = self._padded.get(name)
+        if t is None:
+            rows = self.height + (1 if name in ('lat', 'lon', 'mlat', 'mlt') else 0)
+            t = self._padded[name] = self.ctx.empty((rows, self.pitch))
+            self._plain = {k: v for k, v in self._plain.items() if k != name}
+        return t
+
+    def padded(self, name):
+        return self._padded.get(name)
+
+    def has(self, name):
+        """Is array `name` kept (without compacting it)?"""
+        v = self._plain.get(name, _UNSET)
+        return (name in self._padded) if v is _UNSET else v is not None
+
+    def touch(self):
+        """The padded buffers have been (or are being) written again: compacted copies are stale."""
+        self._cache = {}
+
+    def _compacted(self, name):
+        src = self._padded.get(name)
+        if src is None:
+            return None
+        t = self._cache.get(name)
+        if t is None:
+            cols = self.width + (1 if name in ('lat', 'lon', 'mlat', 'mlt') else 0)
+            t = self.ctx.empty((src.shape[0], cols))
+            Context.current(self.ctx.device)
+            self.ctx.call('amt_unpad_rows', ptr(src), int(src.shape[0]), cols, self.width, ptr(t))
+            self._cache = dict(self._cache)
+            self._cache[name] = t
+        return t
+
+
+for _k in FrameData.COORDS:
+    setattr(PaddedFrameData, _k, _coord_property(_k))
+del _k
+
+
+def has_array(fd, name):
+    """Does the frame keep array `name`?  (Never compacts a padded buffer.)"""
+    return fd.has(name) if isinstance(fd, PaddedFrameData) else getattr(fd, name) is not None
+
+
+__all__ = ['FrameData', 'PaddedFrameData', 'has_array', 'ptr']

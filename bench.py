@@ -39,6 +39,8 @@ TIMING_EVERY = 1        # events ride on the dispatch packets (hipExtLaunchKerne
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 LAUNCH_STREAMS = 1      # --launch-streams
 MAX_RESIDENT_IMAGES = 128  # distinct images kept in HBM (72 MB each); longer runs cycle through them
+# the pipelines' own coordinate buffers in strip-padded rows (amt_georef_out.row_layout; AMT_PADDED_ROWS=0: contiguous, A/B runs)
+PADDED = os.environ.get('AMT_PADDED_ROWS', '1') != '0'
 
 
 def algorithmic_bytes(width, height, nchan=3, pix_bytes=2):
@@ -461,7 +463,7 @@ def directions_in_run(imgs, first, warmup, steps, fence, n_dirs=6, depth=3):
     from auromat_amd.mapping.astrometry import frame_params
     from auromat_amd.pipeline import FramePipeline
     from auromat_amd.synthetic import sequence_frame
-    pipes = [FramePipeline(WIDTH, HEIGHT, alloc_image=False) for _ in range(depth)]
+    pipes = [FramePipeline(WIDTH, HEIGHT, alloc_image=False, padded=PADDED) for _ in range(depth)]
     ctx = pipes[0].ctx
     for q in pipes:
         q.defer_join = True
@@ -771,7 +773,7 @@ def main(argv=None):
                                    ('; configs[4] when n_gpus = 8 and steps = 32: 256 frames sharded over 8 GPUs, grids '
                                     'gathered on rank 0' if world > 1 else ''),
                        'frame': [WIDTH, HEIGHT], 'px_per_deg': PPD, 'grid': list(res['mean'].shape),
-                       'plan': args.plan, 'frames_per_launch': seq.batch, 'frames_without_prepass': run['hinted'],
+                       'plan': args.plan, 'row_layout': 'strip-padded' if seq.padded else 'contiguous', 'frames_per_launch': seq.batch, 'frames_without_prepass': run['hinted'],
                        'single_pass_frames': sum(1 for q in plans if q == 'single-pass'),
                        'frames_total': world * args.steps,
                        # untimed frames run before the W warm-up steps to bring the chip to its sustained state
@@ -881,7 +883,7 @@ def main(argv=None):
             # georeferencing kernel without the fused binning, per-frame host set-up inside the timed region as above
             from auromat_amd.pipeline import FramePipeline
             nv_k = 96
-            gpipe = FramePipeline(WIDTH, HEIGHT, alloc_image=False)
+            gpipe = FramePipeline(WIDTH, HEIGHT, alloc_image=False, padded=PADDED)
             gframes = make_frames(nv_w + nv_k, False)
             for hdr, cam, t, _, _ in gframes[:nv_w]:
                 gpipe.georef(hdr, ALTITUDE, cam, t, True, MIN_ELEV)

@@ -34,7 +34,8 @@ extern "C" {
  *    (amt_pipe_launch_box[_many], amt_pipe_launch_many_res, amt_plate_carree_resolution) (round 4) */
 /* 5: the single-pass plan on caller-supplied corner directions (amt_georef_coarse_bbox_dirs, amt_pipe_coarse_dirs,
  *    amt_pipe_launch_dirs); griddata(method='cubic') exactly: amt_delaunay_*, amt_cubic_gradients_csr, amt_cubic_eval (round 5) */
-#define AMT_ABI_VERSION 5
+/* 6: amt_georef_out.row_layout (strip-padded rows for buffers a pipeline owns), amt_padded_pitch, amt_unpad_rows (round 6) */
+#define AMT_ABI_VERSION 6
 
 #define AMT_OK 0
 #define AMT_EINVAL (-1)   /* bad argument (NULL pointer, negative size, unsupported dtype ...) */
@@ -193,9 +194,29 @@ typedef struct amt_georef_out {
      * altitude the shell (a, b) = (a0, b0) + altitude was built from, as rotatePole takes it.  MLat / MLT outputs can be
      * combined with either grid. */
     int32_t bin_pole;
-    int32_t reserved_pole;
+    /* Row layout of the nine per-pixel output arrays (ABI v6; 0 in earlier callers' zero-initialised structs):
+     *   AMT_ROWS_CONTIGUOUS (0)    C-contiguous (height+1, width+1) / (height, width), what the reference's properties return
+     *                              (astrometry.py:118-152);
+     *   AMT_ROWS_STRIP_PADDED (1)  for buffers a pipeline OWNS and hands on only on request: every array has rows of
+     *                              P = amt_padded_pitch(width) doubles (corner arrays height+1 rows, pixel arrays height rows) and
+     *                              element (y, x) lies at y P + 64 (x / 63) + x % 63 — the kernel's work items are strips of 63
+     *                              columns, and with this layout each strip's run of a row is a whole number of 128-byte lines
+     *                              that no other wave writes (a measured 8-12 % of the kernel's time: DESIGN.md 4.1).  The 64th
+     *                              double of a strip (and columns beyond the frame in the last strip) is padding with
+     *                              unspecified content.  amt_unpad_rows compacts an array into contiguous rows, bit for bit the
+     *                              array the contiguous layout gives.  Row-marching kernel only (not AMT_GEOREF_KERNEL=tile);
+     *                              the two-pass binning (amt_bin_frame) and every other consumer read contiguous rows. */
+    int32_t row_layout;
     double altitude;
 } amt_georef_out;
+#define AMT_ROWS_CONTIGUOUS 0
+#define AMT_ROWS_STRIP_PADDED 1
+/* Doubles per row of a strip-padded array of a frame `width` pixels wide (64 per strip of 63 columns; 4352 for 4240). */
+int64_t amt_padded_pitch(int32_t width);
+/* Strip-padded rows -> contiguous rows (device to device, on the context's stream): `src` has `rows` rows of
+ * amt_padded_pitch(width) doubles, `dst` becomes a C-contiguous (rows, cols) array with cols = width (pixel arrays) or
+ * width + 1 (corner arrays) — what BaseAstrometryMapping.lats & co. hand out (astrometry.py:118-152). */
+int amt_unpad_rows(amt_ctx* ctx, const double* src_padded, int32_t rows, int32_t cols, int32_t width, double* dst);
 
 /* ---- building blocks (auromat.coordinates) ------------------------------------------- */
 

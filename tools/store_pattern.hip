@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 constexpr int W = 4240, H = 2832, ROWS = 16, STRIPS = 68, CHUNKS = 177, NARR = 5;
@@ -117,11 +118,109 @@ static float run(double** a, int spin, int sky, unsigned lds, int stride, int sw
     return sum / reps * 1e3f;
 }
 
+
+// Round 6: output layouts.  The same launch (items of 63 or 64 pixel columns x 16 rows, sky / Earth rows alternating, four waves per
+// SIMD), every array with its own pitch, a strip's columns at `slot` doubles per strip in memory:
+//   L0  the kernel of rounds 1-5: 63-column strips, contiguous rows (pitch W for the pixel arrays, W + 1 for the corner arrays)
+//   L1  VERDICT r5 item 1: 64-column strips, all five arrays at a pitch of 4288 doubles (every run 512 bytes on a 512-byte boundary)
+//   L2  strip-padded rows: 63-column strips (the kernel's own work items), strip s of a row at doubles [64 s, 64 s + 64) of a row of
+//       68 x 64 = 4352 doubles, all 64 lanes store (a corner array's 64th value is the next strip's first corner, a pixel array's
+//       a pad): every run 512 bytes on a 512-byte boundary with no change to the arithmetic
+//   L3  as L2, lane 63 does not store (504-byte runs on 512-byte boundaries)
+__global__ __launch_bounds__(256) void k_layout(double* __restrict__ a0, double* __restrict__ a1, double* __restrict__ a2,
+                                                double* __restrict__ a3, double* __restrict__ a4, int spin, int first_earth_chunk, int stride,
+                                                int sw, int slot, int pitch_corner, int pitch_pixel, int store_lanes, int with_stores) {
+    extern __shared__ double occupancy_limiter[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    const int strips = (W + sw - 1) / sw;
+    if (item >= CHUNKS * strips) return;
+    const int chunk_in_order = item / strips, strip = item - chunk_in_order * strips;
+    const int chunk = chunk_in_order * stride % CHUNKS;
+    const int y0 = chunk * ROWS;
+    const int col = strip * slot + lane;                           // column in memory
+    double* arr[NARR] = {a0, a1, a2, a3, a4};
+    const int pitch[NARR] = {pitch_corner, pitch_corner, pitch_pixel, pitch_pixel, pitch_pixel};
+    if (spin < 0) occupancy_limiter[threadIdx.x] = 0.0;
+    if (chunk < first_earth_chunk) {
+        for (int k = 0; k < NARR; ++k) {
+            const long long first = (long long)y0 * pitch[k], count = (long long)ROWS * pitch[k];
+            long long a = first + count * strip / strips, b = first + count * (strip + 1) / strips;
+            a &= ~1ll, b &= ~1ll;
+            const double2 two = {1.0, 2.0};
+            for (long long i = a + 2 * lane; i + 1 < b; i += 128) *reinterpret_cast<double2*>(arr[k] + i) = two;
+        }
+        return;
+    }
+    const bool ok = lane < store_lanes && col < pitch_pixel && strip * sw + lane < W + (store_lanes == 64 && slot == 64 && sw == 63 ? 1 : 0);
+    double v = (double)col;
+    for (int r = 0; r < ROWS && y0 + r < H; ++r) {
+        v = work(v, spin);
+        if (with_stores) {
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < NARR; ++k) arr[k][(long long)(y0 + r) * pitch[k] + col] = v + k;
+            }
+        } else if (ok && v == 12345.678) arr[0][col] = v;
+    }
+}
+
+struct layout { const char* name; int sw, slot, pitch_corner, pitch_pixel, store_lanes; };
+
+static float run_layout(double** a, const layout& L, int spin, int sky, int with_stores, int reps) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const int blocks = (CHUNKS * ((W + L.sw - 1) / L.sw) + 3) / 4;
+    std::vector<float> t;
+    for (int rep = 0; rep < reps + 2; ++rep) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_layout, dim3(blocks), dim3(256), 28000u, 0, a[0], a[1], a[2], a[3], a[4], spin, sky, 76, L.sw, L.slot,
+                           L.pitch_corner, L.pitch_pixel, L.store_lanes, with_stores);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 2) t.push_back(ms * 1e3f);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+}
+
+static void layouts(double** a, int sky) {
+    const layout Ls[] = {
+        {"L0 63-col strips, contiguous (W+1 / W)", 63, 63, W + 1, W, 63},
+        {"L1 64-col strips, pitch 4288", 64, 64, 4288, 4288, 64},
+        {"L2 63-col strips padded to 64, pitch 4352, 64 lanes store", 63, 64, 4352, 4352, 64},
+        {"L3 63-col strips padded to 64, pitch 4352, 63 lanes store", 63, 64, 4352, 4352, 63},
+        {"L4 63-col strips, contiguous, all at pitch W", 63, 63, W, W, 63},
+    };
+    const int nL = sizeof(Ls) / sizeof(Ls[0]);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_layout), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    std::printf("layouts (median of 5 passes x 9 launches, passes interleaved over the layouts; us)\n");
+    for (int k = 0; k < nL; ++k) std::printf("  %s\n", Ls[k].name);
+    std::printf("  spin | work alone L0 / L1 |   L0   |   L1   |   L2   |   L3   |   L4\n");
+    for (int spin : {0, 20, 25, 30, 35, 40}) {
+        std::vector<float> m[nL], w[2];
+        for (int pass = 0; pass < 5; ++pass) {
+            for (int k = 0; k < nL; ++k) m[k].push_back(run_layout(a, Ls[k], spin, sky, 1, 9));
+            for (int k = 0; k < 2; ++k) w[k].push_back(run_layout(a, Ls[k], spin, sky, 0, 9));
+        }
+        auto med = [](std::vector<float>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        std::printf("  %4d | %8.1f / %8.1f |", spin, med(w[0]), med(w[1]));
+        for (int k = 0; k < nL; ++k) std::printf(" %6.1f |", med(m[k]));
+        std::printf("\n");
+    }
+}
+
 int main() {
     const size_t n = (size_t)W * H;
     double* a[NARR];
-    for (int k = 0; k < NARR; ++k) (void)hipMalloc(&a[k], (n + (size_t)H + W + 64) * sizeof(double));
+    for (int k = 0; k < NARR; ++k) (void)hipMalloc(&a[k], ((size_t)4352 * (H + 2) + 64) * sizeof(double));
     const int sky = (int)(0.43 * CHUNKS);
+    if (std::getenv("LAYOUTS_ONLY")) { layouts(a, sky); return 0; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pattern<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pattern<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pattern<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -150,5 +249,6 @@ int main() {
             std::printf("  %4d | %8.1f / %8.1f | %8.1f / %8.1f | two of the five arrays at a pitch of W + 1 (corner arrays): %8.1f / %8.1f\n", spin,
                         w63, w64, s63, s64, c63, c64);
         }
+    layouts(a, sky);
     return 0;
 }
