@@ -94,7 +94,8 @@ class RunConfig(C.Structure):
 class RunFrame(C.Structure):
     """amt_run_frame"""
     _fields_ = [('crval', C.c_double * 2), ('crpix', C.c_double * 2), ('cd', C.c_double * 4), ('lonpole', C.c_double),
-                ('cam', C.c_double * 3), ('jd', C.c_double), ('altitude', C.c_double), ('img', C.c_void_p)]
+                ('cam', C.c_double * 3), ('jd', C.c_double), ('altitude', C.c_double), ('img', C.c_void_p),
+                ('img_host', C.c_void_p)]
 
 
 class RunResult(C.Structure):
@@ -103,7 +104,7 @@ class RunResult(C.Structure):
                                          'edge_pixels', 'two_pass', 'reserved_')] + \
                [('grid_offset', C.c_int64), ('image_offset', C.c_int64), ('bbox', C.c_double * 8), ('altitude', C.c_double),
                 ('grid', Grid), ('params', FrameParams), ('lat_px_per_deg', C.c_double), ('lon_px_per_deg', C.c_double),
-                ('retried', C.c_int32), ('reserved2_', C.c_int32)]
+                ('retried', C.c_int32), ('reserved2_', C.c_int32), ('uploaded_bytes', C.c_int64)]
 
 
 ABI_VERSION = 6          # include/auromat_hip.h AMT_ABI_VERSION
@@ -119,6 +120,8 @@ _SIGNATURES = {
     'amt_device_info': ([_P, C.c_char_p, C.c_size_t, C.POINTER(_I), C.POINTER(_I), C.POINTER(C.c_size_t)], _I),
     'amt_malloc': ([_P, C.c_size_t, c_void_pp], _I),
     'amt_free': ([_P, _P], _I),
+    'amt_malloc_host': ([_P, C.c_size_t, c_void_pp], _I),
+    'amt_free_host': ([_P, _P], _I),
     'amt_memcpy_h2d': ([_P, _P, _P, C.c_size_t], _I),
     'amt_memcpy_d2h': ([_P, _P, _P, C.c_size_t], _I),
     'amt_memset': ([_P, _P, _I, C.c_size_t], _I),
@@ -174,6 +177,7 @@ _SIGNATURES = {
     'amt_pipe_coarse_dirs': ([_P, C.POINTER(FrameParams), _P, _D, _I], _I),
     'amt_pipe_launch_dirs': ([_P, C.POINTER(FrameParams), _P, C.POINTER(GeorefOut), _P, C.c_int32, _D, _D, _D, _I, _I], _I),
     'amt_georef_sky_rows': ([C.POINTER(FrameParams)] + [C.POINTER(C.c_int32)] * 4, _I),
+    'amt_georef_image_rows': ([C.POINTER(FrameParams), _D] + [C.POINTER(C.c_int32)] * 2, _I),
     'amt_mask_by_elevation': ([_P, _P, _P, C.c_int32, C.c_int32, _D, _P, _P, _P], _I),
     'amt_sanitize_masks': ([_P, _P, _P, _P, C.c_int32, C.c_int32, _I], _I),
     'amt_bbox_corners': ([_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P], _I),

@@ -124,6 +124,28 @@ int amt_free(amt_ctx* ctx, void* dptr) {
     return AMT_OK;
 }
 
+int amt_malloc_host(amt_ctx* ctx, size_t bytes, void** out_hptr) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, out_hptr != nullptr, "out_hptr is NULL");
+    if (amt_set_device(ctx)) return AMT_EHIP;
+    hipError_t e = hipHostMalloc(out_hptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out_hptr = nullptr;
+        ctx->last_error = std::string("amt_malloc_host: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? AMT_ENOMEM : AMT_EHIP;
+    }
+    return AMT_OK;
+}
+
+int amt_free_host(amt_ctx* ctx, void* hptr) {
+    AMT_CHECK_CTX(ctx);
+    if (hptr == nullptr) return AMT_OK;
+    if (amt_set_device(ctx)) return AMT_EHIP;
+    AMT_HIP(ctx, hipHostFree(hptr));
+    return AMT_OK;
+}
+
 int amt_memcpy_h2d(amt_ctx* ctx, void* dst, const void* src, size_t bytes) {
     AMT_CHECK_CTX(ctx);
     AMT_REQUIRE(ctx, dst && src, "NULL pointer");

@@ -1519,32 +1519,11 @@ bool ray_hits_host(const affine_cam& c, const shell_ray& e, double x, double y) 
 // in y fitted through three rows; per line of corners that costs three evaluations.  The bands are taken a pixel wider
 // than the rows of an item (exact centre rays lie between the corners) and a line only counts as free of hits when
 // max disc < -1e-9 of its scale or max nb < 0: anything nearer to the limb than that goes the ordinary way.
-void sky_bands(const georef_args& A, const launch_shape& sh, int* top_end, int* bottom_begin) {
-    const int n = sh.chunks_y;
+// The machinery: bands of rows_per_chunk rows (n of them) of a W x H frame in which a convex region {quadratic >= 0, linear >= 0}
+// of the image plane has no point; eval(x, y, &linear) -> quadratic.  [0, *top_end) and [*bottom_begin, n) are free of it.
+template <class Eval>
+void conic_bands(double W, double H, int n, int rows_per_chunk, Eval eval, int* top_end, int* bottom_begin) {
     *top_end = 0, *bottom_begin = n;
-    const shell_ray& e = A.sray;
-    if (!(e.root_sign < 0)) return;                       // camera inside the shell: every ray hits
-    const double W = A.width, H = A.height;
-    auto eval = [&](double x, double y, double* nb_out) {
-        const affine_cam& c = A.cam;
-        const double px = x + c.cx, py = y + c.cy;
-        const double ux = c.u0[0] + px * c.ux[0] + py * c.uy[0], uy = c.u0[1] + px * c.ux[1] + py * c.uy[1],
-                     uz = c.u0[2] + px * c.ux[2] + py * c.uy[2];
-        const double uu = ux * ux + uy * uy + uz * uz;
-        const double ku = ux * e.kx + uy * e.ky + uz * e.kz, uo = ux * e.ox + uy * e.oy + uz * e.oz;
-        const double a2 = e.qd * ku * ku + e.qa * uu, nb = -(e.qa * uo + e.qd_ko * ku);
-        *nb_out = nb;
-        return nb * nb - a2 * e.c0;
-    };
-    // the Earth must be far larger in the image than a band is tall (see above): apparent radius of the shell against
-    // the angle a band spans
-    {
-        const double oo = std::sqrt(e.ox * e.ox + e.oy * e.oy + e.oz * e.oz);
-        const double sin_rho = std::min(1.0, 1.0 / (std::sqrt(e.qa) * oo));             // ~ a / |camera|
-        const double px_scale = std::sqrt(std::max(A.cam.uy[0] * A.cam.uy[0] + A.cam.uy[1] * A.cam.uy[1] + A.cam.uy[2] * A.cam.uy[2],
-                                                   A.cam.ux[0] * A.cam.ux[0] + A.cam.ux[1] * A.cam.ux[1] + A.cam.ux[2] * A.cam.ux[2])) / kRad2Deg;
-        if (!(std::asin(sin_rho) > 8.0 * (sh.rows_per_chunk + 2) * px_scale)) return;
-    }
     // quadratic through (t0, f0), (t1, f1), (t2, f2) with t1 the midpoint: coefficients of f(t0 + s), s in [0, L]
     struct quad {
         double a, b, c, L;
@@ -1607,16 +1586,85 @@ void sky_bands(const georef_args& A, const launch_shape& sh, int* top_end, int* 
     };
     auto band_free = [&](int c) {
         // corner rows c R ... min((c + 1) R, H), a pixel more on both sides; s counts from y0 = -1
-        const double s0 = (double)c * sh.rows_per_chunk, s1 = std::min((double)(c + 1) * sh.rows_per_chunk, H) + 2.0;
+        const double s0 = (double)c * rows_per_chunk, s1 = std::min((double)(c + 1) * rows_per_chunk, H) + 2.0;
         return line_free(s0) && line_free(s1) && side_free(0, s0, s1) && side_free(2, s0, s1);
     };
     int t = 0;
     while (t < n && band_free(t)) ++t;
     *top_end = t;
-    if (t == n) return;                                   // a frame of sky: everything is in the first range
+    if (t == n) return;                                   // nothing of the region in the frame: everything is in the first range
     int b = n;
     while (b > t && band_free(b - 1)) --b;
     *bottom_begin = b;
+}
+
+// angle one pixel spans (radians, the larger of the two axes) in the affine camera model
+double pixel_angle(const affine_cam& c) {
+    return std::sqrt(std::max(c.uy[0] * c.uy[0] + c.uy[1] * c.uy[1] + c.uy[2] * c.uy[2],
+                              c.ux[0] * c.ux[0] + c.ux[1] * c.ux[1] + c.ux[2] * c.ux[2])) / kRad2Deg;
+}
+
+void sky_bands(const georef_args& A, const launch_shape& sh, int* top_end, int* bottom_begin) {
+    const int n = sh.chunks_y;
+    *top_end = 0, *bottom_begin = n;
+    const shell_ray& e = A.sray;
+    if (!(e.root_sign < 0)) return;                       // camera inside the shell: every ray hits
+    auto eval = [&](double x, double y, double* nb_out) {
+        const affine_cam& c = A.cam;
+        const double px = x + c.cx, py = y + c.cy;
+        const double ux = c.u0[0] + px * c.ux[0] + py * c.uy[0], uy = c.u0[1] + px * c.ux[1] + py * c.uy[1],
+                     uz = c.u0[2] + px * c.ux[2] + py * c.uy[2];
+        const double uu = ux * ux + uy * uy + uz * uz;
+        const double ku = ux * e.kx + uy * e.ky + uz * e.kz, uo = ux * e.ox + uy * e.oy + uz * e.oz;
+        const double a2 = e.qd * ku * ku + e.qa * uu, nb = -(e.qa * uo + e.qd_ko * ku);
+        *nb_out = nb;
+        return nb * nb - a2 * e.c0;
+    };
+    // the Earth must be far larger in the image than a band is tall (see above): apparent radius of the shell against
+    // the angle a band spans
+    {
+        const double oo = std::sqrt(e.ox * e.ox + e.oy * e.oy + e.oz * e.oz);
+        const double sin_rho = std::min(1.0, 1.0 / (std::sqrt(e.qa) * oo));             // ~ a / |camera|
+        if (!(std::asin(sin_rho) > 8.0 * (sh.rows_per_chunk + 2) * pixel_angle(A.cam))) return;
+    }
+    conic_bands((double)A.width, (double)A.height, n, sh.rows_per_chunk, eval, top_end, bottom_begin);
+}
+
+// Which rows of work items can hold a pixel that survives maskedByElevation(min_elev)?  (The rows of a host image that have to
+// cross the link: the fused binning reads a pixel's colours only to bin it, and only pixels with elevation >= min_elev are
+// binned, reference mapping.py:845-864, resample.py:119-120,315-321.)  The elevation is measured against the geocentric radial
+// of the hit point P (astrometry.py:200-212): in the triangle (Earth's centre, camera C, P) the law of sines gives
+//     sin(nadir angle of the ray) = |P| / |C| * cos(elevation),
+// and |P| <= the shell's larger semi-axis, so every pixel with elevation >= e0 > 0 lies inside the cone of half-angle
+// asin(a_max / |C| * cos e0) about the nadir — in the image of the affine camera model a conic section again, bounded per band
+// of rows exactly like the limb.  Conservative by construction (|P| bounded from above, a band a pixel wider than its rows and one
+// more band on either side); outside [*top_end, *bottom_begin) no pixel is binned.
+void elevation_bands(const georef_args& A, const launch_shape& sh, double min_elev_deg, int* top_end, int* bottom_begin) {
+    const int n = sh.chunks_y;
+    *top_end = 0, *bottom_begin = n;
+    const shell_ray& e = A.sray;
+    if (!(e.root_sign < 0) || !(min_elev_deg > 0) || !(min_elev_deg < 90)) return;
+    const double oo = e.ox * e.ox + e.oy * e.oy + e.oz * e.oz;
+    const double r_max = 1.0 / std::sqrt(std::min(e.qa, e.qa + e.qd));                // max(a, b) of the shell
+    const double k = r_max / std::sqrt(oo) * std::cos(min_elev_deg * kDeg2Rad);      // sin of the cone's half-angle
+    if (!(k < 1.0)) return;
+    const double cos2 = 1.0 - k * k;
+    if (!(std::asin(k) > 8.0 * (sh.rows_per_chunk + 2) * pixel_angle(A.cam))) return;
+    auto eval = [&](double x, double y, double* lin_out) {
+        const affine_cam& c = A.cam;
+        const double px = x + c.cx, py = y + c.cy;
+        const double ux = c.u0[0] + px * c.ux[0] + py * c.uy[0], uy = c.u0[1] + px * c.ux[1] + py * c.uy[1],
+                     uz = c.u0[2] + px * c.ux[2] + py * c.uy[2];
+        const double uu = ux * ux + uy * uy + uz * uz;
+        const double uo = ux * e.ox + uy * e.oy + uz * e.oz;
+        *lin_out = -uo;                                   // > 0: the ray points to the Earth's side
+        return uo * uo - cos2 * oo * uu;                  // >= 0: inside the cone (or its mirror image, which `lin` excludes)
+    };
+    int t = 0, b = n;
+    conic_bands((double)A.width, (double)A.height, n, sh.rows_per_chunk, eval, &t, &b);
+    // one more band on either side: a fast centre is the mean of four corner hits, not a ray of its own
+    *top_end = std::max(0, t - 1), *bottom_begin = std::min(n, b + 1);
+    if (t == n) *top_end = n, *bottom_begin = n;          // nothing above the threshold in the frame
 }
 
 // item_order 4: where the limb cuts the frame's rows of work items.  The middle row of every chunk is probed in three
@@ -2051,6 +2099,34 @@ int64_t amt_padded_pitch(int32_t width) {
     std::memset(&p, 0, sizeof(p));
     p.width = width, p.height = 1;
     return (int64_t)shape_of(&p).strips_x * 64;
+}
+
+int amt_georef_image_rows(const amt_frame_params* p, double min_elevation, int32_t* row_begin, int32_t* row_end) {
+    if (p == nullptr || row_begin == nullptr || row_end == nullptr) return AMT_EINVAL;
+    if (p->width <= 0 || p->height <= 0) return AMT_EINVAL;
+    georef_args A;
+    std::memset(&A, 0, sizeof(A));
+    A.wcs = make_tan_wcs(p);
+    double rot_geo[9];
+    mat_mul3(p->m_geo, p->rot, rot_geo);
+    tan_wcs wcs_geo = A.wcs;
+    wcs_geo.rot = make_mat3(rot_geo);
+    A.cam = make_affine_cam(wcs_geo);
+    A.sray = make_shell_ray(p->a, p->b, p->cam, p->m_geo);
+    A.width = p->width;
+    A.height = p->height;
+    const launch_shape sh = shape_of(p);
+    int t = 0, b = sh.chunks_y, te = 0, be = sh.chunks_y;
+    sky_bands(A, sh, &t, &b);
+    if (min_elevation > 0) elevation_bands(A, sh, min_elevation, &te, &be);
+    t = std::max(t, te), b = std::min(b, be);
+    if (t >= b) {
+        *row_begin = *row_end = 0;                         // no pixel of the frame can be binned
+        return AMT_OK;
+    }
+    *row_begin = std::max(0, t * sh.rows_per_chunk);
+    *row_end = std::min(p->height, b * sh.rows_per_chunk);
+    return AMT_OK;
 }
 
 int amt_georef_frame_dirs(amt_ctx* ctx, const amt_frame_params* p, const double* corner_dirs,

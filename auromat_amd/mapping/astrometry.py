@@ -22,7 +22,7 @@ from .._native import Context, FrameParams, GeorefOut, RunFrame, ptr
 from .mapping import BaseMapping, GenericMapping, inflatedEarthIntersection
 
 
-def run_frame(wcsHeader, cameraPosGCRS, photoTime, altitude=0.0, img_ptr=None, out=None):
+def run_frame(wcsHeader, cameraPosGCRS, photoTime, altitude=0.0, img_ptr=None, out=None, img_host_ptr=None):
     """The amt_run_frame of one frame: the WCS cards, the camera and the photo time as the native side takes them."""
     from ..coordinates.transform import julian_date
     check_tan_header(wcsHeader)
@@ -35,6 +35,7 @@ def run_frame(wcsHeader, cameraPosGCRS, photoTime, altitude=0.0, img_ptr=None, o
     f.jd = julian_date(photoTime)
     f.altitude = float(altitude)
     f.img = img_ptr
+    f.img_host = img_host_ptr
     return f
 
 
@@ -386,6 +387,7 @@ class DirectionArrayMapping(BaseAstrometryMapping):
                        min_elevation=self._lazy_elev, pxPerDeg=pxPerDeg, containsPole=containsPole, magnetic=magnetic, fuse=True,
                        params=self._params(), dirs=self._dirs_tensor(pipe.ctx))
         res['plan'] = pipe.last_plan
+        pipe.forget_inputs()          # (the cached pipeline must not keep this mapping's direction array alive)
         return res
 
     def _dirs_tensor(self, ctx):

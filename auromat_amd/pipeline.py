@@ -63,13 +63,15 @@ class _GridView(object):
         return getattr(self._full, name)
 
 
-def earth_rows_of(params, height):
-    """(r0, r1): the pixel rows of a camera frame outside of which no ray reaches the shell (amt_georef_sky_rows)"""
+def earth_rows_of(params, height, min_elevation=None):
+    """(r0, r1): the pixel rows of a camera frame's image that a kernel can need (amt_georef_image_rows): outside of them no ray
+    reaches the shell or — with `min_elevation` > 0 — no pixel reaches that elevation, and only pixels that survive
+    maskedByElevation are ever binned (reference mapping.py:845-864, resample.py:315-321).  Conservative."""
     from . import _native
-    o = [C.c_int32(0) for _ in range(4)]
-    _native.lib().amt_georef_sky_rows(C.byref(params), *[C.byref(v) for v in o])
-    rows, n, top, bottom = [v.value for v in o]
-    return max(0, top * rows), min(int(height), bottom * rows)
+    r0, r1 = C.c_int32(0), C.c_int32(0)
+    me = NEG_INF if min_elevation is None else float(min_elevation)
+    _native.lib().amt_georef_image_rows(C.byref(params), me, C.byref(r0), C.byref(r1))
+    return max(0, r0.value), min(int(height), r1.value)
 
 
 def uploaded_rows(rows, height):
@@ -139,7 +141,6 @@ class FramePipeline(object):
         # corner directions of the last frame when they came from the caller ((h + 1, w + 1, 3) float64 device tensor, J2000;
         # the directions-in form of the pipeline, reference astrometry.py:49-64 with any camera model) instead of the TAN model
         self._dirs = None
-        self._img_rest = None       # (host image, r0, r1) of a partial set_image: rows outside [r0, r1) are not on the device
         self._out.bbox = fd.bbox.data_ptr()
 
     def _alloc_coords(self, full=False):
@@ -210,11 +211,10 @@ class FramePipeline(object):
     def set_image(self, img, rows=None):
         """Copy an (h, w, c) host image (or device tensor of the same bytes) into the frame buffer.  A pinned host
         tensor of the buffer's dtype (uint16 images as their int16 bits) is copied asynchronously on the current
-        stream.  `rows` = (r0, r1), host images only: only that band of rows crosses the link now — the rows a camera frame's
-        kernels can read (outside them no ray reaches the shell: :meth:`earth_rows`) — and the rest when something asks for
-        the whole image (:meth:`complete_image`)."""
+        stream.  `rows` = (r0, r1), host images only: only that band of rows crosses the link — the rows a camera frame's
+        kernels can need (:meth:`earth_rows`); the buffer's other rows are UNDEFINED afterwards (they keep whatever an earlier
+        frame left there): the buffer is the binning kernel's input, not a copy of the image for anybody else."""
         import torch
-        self._img_rest = None
         if self.fd.img is not self._img_own or self._img_own is None:
             # the buffer aliased a caller's device image (use_image): copy into a buffer of our own
             if self._img_own is None:
@@ -225,7 +225,6 @@ class FramePipeline(object):
             src = img.reshape(self.fd.img.shape)
             if band:
                 self.fd.img[rows[0]:rows[1]].copy_(src[rows[0]:rows[1]], non_blocking=True)
-                self._img_rest = (src, rows[0], rows[1])
             else:
                 self.fd.img.copy_(src, non_blocking=True)
             return
@@ -239,32 +238,18 @@ class FramePipeline(object):
         if band:
             a = a.reshape(self._img_shape)
             self.ctx.upload(a[rows[0]:rows[1]], self.fd.img[rows[0]:rows[1]])
-            self._img_rest = (a, rows[0], rows[1])
             return
         self.ctx.upload(a, self.fd.img)          # through page-locked staging pieces (see Context.upload)
 
-    def complete_image(self):
-        """The rows a partial :meth:`set_image` left out (no pixel of them has coordinates; whoever wants the whole buffer —
-        a caller that keeps the frame's image, an exporter — gets it here)."""
-        if self._img_rest is not None:
-            a, r0, r1 = self._img_rest
-            self._img_rest = None
-            Context.current(self.ctx.device)
-            if hasattr(a, 'is_pinned'):                   # a pinned host tensor
-                if r0 > 0:
-                    self.fd.img[:r0].copy_(a[:r0], non_blocking=True)
-                if r1 < self.height:
-                    self.fd.img[r1:].copy_(a[r1:], non_blocking=True)
-                return
-            if r0 > 0:
-                self.ctx.upload(a[:r0], self.fd.img[:r0])
-            if r1 < self.height:
-                self.ctx.upload(a[r1:], self.fd.img[r1:])
+    def earth_rows(self, params, min_elevation=None):
+        """(r0, r1): the pixel rows of a camera frame's image a kernel can need (:func:`earth_rows_of`)."""
+        return earth_rows_of(params, self.height, min_elevation)
 
-    def earth_rows(self, params):
-        """(r0, r1): the pixel rows of a camera frame outside of which no ray reaches the shell (amt_georef_sky_rows: the limb
-        is a conic section in the image; conservative), i.e. the only rows whose pixels any kernel reads."""
-        return earth_rows_of(params, self.height)
+    def forget_inputs(self):
+        """Drop what the pipeline holds of its caller's last frame (a 288 MB direction array of a DirectionArrayMapping, the
+        parameters): a cached pipeline must not keep them alive.  The frame's arrays can then no longer be computed on demand."""
+        self._dirs = None
+        self._coords_valid = self._kept_valid = False
 
     def use_image(self, img):
         """Use a device-resident image of the buffer's layout ((h, w, c) uint8, or uint16 bits as int16) in place:
@@ -706,7 +691,7 @@ class FramePipeline(object):
                 if fuse and not arcsecPerPx and self.fd.nchan == 3 and (self.with_mag or not magnetic):
                     self.start_coarse(params, min_elevation, bool(magnetic))
                     coarse_started = True
-                self.set_image(img, rows=self.earth_rows(params))
+                self.set_image(img, rows=self.earth_rows(params, min_elevation))
             else:
                 self.set_image(img)
         assert not (arcsecPerPx and dirs is not None), 'arcsecPerPx: the box-first plan is built on the camera model'
@@ -1050,6 +1035,7 @@ class SequencePipeline(object):
         self._hint_prev = None              # ... and of the one finished before it (for the extrapolation, see _box_hint)
         self._frames_done = 0               # frames of earlier process() calls (hints count frames across calls)
         self.hinted = 0                     # frames of the last process() call that needed no pre-pass
+        self.uploaded_bytes = 0             # image bytes the last process() call sent over the link (host images)
         # the frame loop in the library (amt_run_process) where it applies: device-resident images, no on_batch hook;
         # AMT_SEQ_NATIVE=0 keeps the Python loop (A/B runs)
         self.native = os.environ.get('AMT_SEQ_NATIVE', '1') != '0'
@@ -1128,7 +1114,11 @@ class SequencePipeline(object):
                     self._img_busy[slot] = []
                     # a host image: only the rows a ray of this frame can hit cross the link (no kernel reads the others)
                     on_host = not getattr(img, 'is_cuda', False)
-                    q.set_image(img, rows=q.earth_rows(p) if (on_host and p is not None) else None)
+                    rows = q.earth_rows(p, self.min_elevation) if (on_host and p is not None) else None
+                    q.set_image(img, rows=rows)
+                    if on_host:
+                        r0, r1 = uploaded_rows(rows, q.height)
+                        self.uploaded_bytes += (r1 - r0) * q.width * q.fd.nchan * q.fd.img_dtype.itemsize
                     uploaded = torch.cuda.Event()
                     uploaded.record(self.s_copy)
                 s_main.wait_event(uploaded)
@@ -1227,8 +1217,10 @@ class SequencePipeline(object):
         dt, numel = q._img_torch_dtype, int(np.prod(q._img_shape))
         for f in frames:
             img = f[3]
-            if not (type(f[0]) is dict and getattr(img, 'is_cuda', False) and img.dtype == dt and img.numel() == numel and
-                    img.is_contiguous()):
+            # a device-resident image, or one in page-locked host memory (a pinned torch tensor: amt_run_frame.img_host — the
+            # runner uploads the rows of it that can be binned, one batch ahead of the frame's launch)
+            if not (type(f[0]) is dict and hasattr(img, 'is_cuda') and img.dtype == dt and img.numel() == numel and
+                    img.is_contiguous() and (img.is_cuda or img.is_pinned())):
                 return False
         return True
 
@@ -1300,7 +1292,12 @@ class SequencePipeline(object):
                     # frame by frame: the library launches as soon as a batch is complete, the first after one frame
                     for f in frames[done_total:]:
                         alt = f[4] if len(f) > 4 and f[4] is not None else 0.0
-                        ctx.check(lib.amt_run_push(run, C.byref(run_frame(f[0], f[1], f[2], alt, f[3].data_ptr(), out=one))))
+                        im_f = f[3]
+                        if im_f.is_cuda:
+                            run_frame(f[0], f[1], f[2], alt, im_f.data_ptr(), out=one)
+                        else:
+                            run_frame(f[0], f[1], f[2], alt, None, out=one, img_host_ptr=im_f.data_ptr())
+                        ctx.check(lib.amt_run_push(run, C.byref(one)))
                 except Exception:
                     #  a call that failed leaves the runner in no state to go on from: the next call makes a new one
                     lib.amt_run_end(run, None)
@@ -1343,6 +1340,7 @@ class SequencePipeline(object):
         table = np.frombuffer(rec, dtype=_run_result_dtype())
         status = table['status']
         self.hinted += int(table['hinted'].sum())
+        self.uploaded_bytes += int(table['uploaded_bytes'].sum())
         fallbacks = {}
         max_cells = int((table['ny'].astype(np.int64) * table['nx']).max()) if n else 1
         names = {0: 'single-pass', 2: 'empty', 4: 'pole-without-resolution'}
@@ -1356,7 +1354,10 @@ class SequencePipeline(object):
                     continue
                 f = frames[k]
                 q = self.pipes[0]
-                q.use_image(f[3])
+                if f[3].is_cuda:
+                    q.use_image(f[3])
+                else:
+                    q.set_image(f[3])
                 alt = f[4] if len(f) > 4 and f[4] is not None else self.altitude
                 try:
                     ppd = (table['lat_px_per_deg'][k], table['lon_px_per_deg'][k]) if self.arcsecPerPx else self.pxPerDeg
@@ -1522,6 +1523,7 @@ class SequencePipeline(object):
         import torch
         del self.plans[:]
         self.hinted = 0
+        self.uploaded_bytes = 0
         if on_batch is None and self.native and isinstance(frames, (list, tuple)):
             # (an iterator — the convert driver's read-ahead generator of decoded host images — is consumed frame by frame
             # below: its images are not device-resident anyway, and materialising it would hold every decoded image of the

@@ -402,7 +402,7 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
     hinted, seq, results, extra) — georef_ms / bin_ms are per FRAME, from HIP events on the dispatch packets.
     `after(results)` runs inside the timed region (the gather of the N > 1 runs).
     """
-    from auromat_amd.pipeline import SequencePipeline
+    from auromat_amd.pipeline import NativeResults, SequencePipeline
     seq = SequencePipeline(WIDTH, HEIGHT, altitude=ALTITUDE, fast=fast, min_elevation=MIN_ELEV, pxPerDeg=PPD,
                            plan='single-pass' if plan == 'fused' else 'two-pass', bin_stream=streams == 2,
                            shared_image=shared_image, magnetic=magnetic, batch=batch, own_image_buffers=own_buffers,
@@ -444,7 +444,8 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
     n_timed = (steps + TIMING_EVERY - 1) // TIMING_EVERY
     assert g_n == n_timed and b_n in (0, n_timed), (g_n, b_n)
     return dict(elapsed=elapsed, georef_ms=g_total / g_n, bin_ms=(b_total / b_n if b_n else 0.0), plans=plans,
-                hinted=hinted, seq=seq, results=results, extra=extra, spinup_frames=spun,
+                hinted=hinted, seq=seq, results=results, extra=extra, spinup_frames=spun, uploaded_bytes=seq.uploaded_bytes,
+                native_loop=isinstance(results, NativeResults),
                 process_ms=(t_proc - t0) * 1e3, after_ms=(t_after - t_proc) * 1e3, fence_ms=(t0 + elapsed - t_after) * 1e3,
                 variant=ctx.last_variant())
 
@@ -681,14 +682,9 @@ def main(argv=None):
         args.steps = saved_steps
         u_own = u['elapsed']
         u_elapsed = u_own
-        # what crossed the link: only the rows a ray of the frame can hit (FramePipeline.set_image / earth_rows), not the 72 MB
-        from auromat_amd.mapping.astrometry import frame_params
-        from auromat_amd.pipeline import earth_rows_of, uploaded_rows
-        u_bytes = 0
-        for hdr, cam, t, _, alt in u_frames[args.warmup:]:
-            r0, r1 = uploaded_rows(earth_rows_of(frame_params(hdr, alt if alt is not None else ALTITUDE, cam, t, fast, magnetic=args.magnetic),
-                                                 HEIGHT), HEIGHT)
-            u_bytes += (r1 - r0) * WIDTH * 6
+        # what crossed the link, as the loop that sent it counted it: only the rows of each image that can be binned (inside the
+        # limb and above min_elevation: amt_georef_image_rows / amt_run_result.uploaded_bytes), not the 72 MB
+        u_bytes = u['uploaded_bytes']
         u_rates = [u_bytes / u_own / 1e9]
         if use_dist:
             tmax = torch.tensor([u_own], dtype=torch.float64, device=cdev)
@@ -702,9 +698,11 @@ def main(argv=None):
                   'single_pass_frames': sum(1 for q in u['plans'] if q == 'single-pass'),
                   'image_bytes_per_frame': WIDTH * HEIGHT * 6, 'uploaded_bytes_per_frame': u_bytes / u_steps,
                   'pcie_GBs_per_rank': u_rates, 'pcie_GBs_total': float(sum(u_rates)),
-                  'source': 'four distinct uint16 RGB images per rank in page-locked host memory, cycled; one upload per frame on a '
-                            'copy stream (SequencePipeline, Python loop) — the rows of the image a ray can hit, the only ones a '
-                            'kernel reads —, gather of the grids included'}
+                  'frame_loop': 'library (amt_run_push with amt_run_frame.img_host)' if u['native_loop'] else 'python',
+                  'source': 'four distinct uint16 RGB images per rank in page-locked host memory, cycled; one upload per frame on the '
+                            "runner's copy stream, one batch ahead of the frame's launch — the rows of the image that can be binned "
+                            '(a ray hits the shell at an elevation >= min_elevation), the only ones a kernel needs —, gather of the '
+                            'grids included'}
         del u, u_frames, host_imgs
         import gc
         gc.collect()
@@ -779,8 +777,7 @@ def main(argv=None):
                        # untimed frames run before the W warm-up steps to bring the chip to its sustained state
                        'spinup_frames_untimed': run['spinup_frames'], 'spinup_ms': args.spinup_ms,
                        'parallelism': 'frames sharded over %d GPU(s), %s gather of grids' % (world, 'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'),
-                       'frame_loop': 'library (amt_run_*)' if getattr(seq, 'native', False) and not args.upload and
-                       (args.plan == 'fused' or (fast and not args.magnetic)) else 'python',
+                       'frame_loop': 'library (amt_run_*)' if run['native_loop'] else 'python',
                        # transparency: rows of work items whose waves write NaN without casting rays, because the host has
                        # bounded the limb (a conic section in the image) and no ray of them can hit the shell; every
                        # output array is still written in full and is identical to the ray-cast result

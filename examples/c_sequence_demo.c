@@ -11,6 +11,9 @@
  * A NEGATIVE px_per_deg is a resolution in arcsec per pixel — `auromat-convert --resolution R`, the reference's own call form
  * `resample(mapping, arcsecPerPx=R)` (cli/convert.py:176-185): every frame's px/deg then follows from its own bounding box
  * (amt_run_config.arcsec_per_px: the box-first plan; the pair a frame was binned at is in its result record).
+ * An eighth argument `host`: the images stay in page-locked HOST memory (amt_malloc_host) and every frame names its image there
+ * (amt_run_frame.img_host) — the runner sends the rows of each that can be binned, on a copy stream of its own, one batch ahead
+ * of the frame's launch: what a real sequence does with the image it has just read (reference cli/convert.py:178-216).
  */
 #include <math.h>
 #include <stdio.h>
@@ -41,10 +44,11 @@ static void* read_file(const char* path, size_t bytes) {
 
 int main(int argc, char** argv) {
     amt_ctx* ctx = NULL;
-    if (argc != 8) {
-        fprintf(stderr, "usage: %s frames.bin images_u16.bin n width height px_per_deg out.bin\n", argv[0]);
+    if (argc != 8 && !(argc == 9 && strcmp(argv[8], "host") == 0)) {
+        fprintf(stderr, "usage: %s frames.bin images_u16.bin n width height px_per_deg out.bin [host]\n", argv[0]);
         return 2;
     }
+    const int host_images = argc == 9;
     const int n = atoi(argv[3]), width = atoi(argv[4]), height = atoi(argv[5]);
     const double ppd = atof(argv[6]);
     const size_t img_bytes = (size_t)width * height * 6;
@@ -52,10 +56,18 @@ int main(int argc, char** argv) {
     unsigned char* images = (unsigned char*)read_file(argv[2], (size_t)n * img_bytes);
 
     CHECK(amt_ctx_create(0, NULL, 1, &ctx));                       /* device 0, a stream owned by the library */
-    void* d_images;
-    CHECK(amt_malloc(ctx, (size_t)n * img_bytes, &d_images));
-    CHECK(amt_upload_staged(ctx, d_images, images, (size_t)n * img_bytes));      /* pageable memory at the link's rate */
-    for (int k = 0; k < n; ++k) frames[k].img = (const char*)d_images + (size_t)k * img_bytes;
+    void* d_images = NULL;
+    void* h_images = NULL;
+    if (host_images) {
+        /* (a reader would fill the page-locked buffer directly) */
+        CHECK(amt_malloc_host(ctx, (size_t)n * img_bytes, &h_images));
+        memcpy(h_images, images, (size_t)n * img_bytes);
+        for (int k = 0; k < n; ++k) frames[k].img = NULL, frames[k].img_host = (const char*)h_images + (size_t)k * img_bytes;
+    } else {
+        CHECK(amt_malloc(ctx, (size_t)n * img_bytes, &d_images));
+        CHECK(amt_upload_staged(ctx, d_images, images, (size_t)n * img_bytes));      /* pageable memory at the link's rate */
+        for (int k = 0; k < n; ++k) frames[k].img = (const char*)d_images + (size_t)k * img_bytes, frames[k].img_host = NULL;
+    }
 
     /* grids only: no per-pixel array is written (NULL pointers in every slot) */
     enum { BATCH = 3, SLOTS = 3 * BATCH };      /* 2 x BATCH for a fixed px/deg, 3 x BATCH for the box-first plan */
@@ -85,11 +97,12 @@ int main(int argc, char** argv) {
         fprintf(stderr, "the arenas were too small: %d of %d frames\n", (int)done, n);
         return 3;
     }
-    int64_t used = 0;
+    int64_t used = 0, uploaded = 0;
     int hinted = 0;
     for (int k = 0; k < n; ++k) {
         if (res[k].status == 0) used = res[k].grid_offset + 5 * (int64_t)res[k].ny * res[k].nx;
         hinted += res[k].hinted;
+        uploaded += res[k].uploaded_bytes;
     }
     double* host = (double*)malloc((size_t)(used > 0 ? used : 1) * 8);
     CHECK(amt_memcpy_d2h(ctx, host, grids, (size_t)used * 8));
@@ -102,8 +115,10 @@ int main(int argc, char** argv) {
     CHECK(amt_free(ctx, grids));
     CHECK(amt_free(ctx, imgs));
     CHECK(amt_free(ctx, d_images));
+    CHECK(amt_free_host(ctx, h_images));
     CHECK(amt_ctx_destroy(ctx));
-    printf("ok %d frames of %d x %d, %d without a pre-pass, %lld doubles of grids\n", n, width, height, hinted, (long long)used);
+    printf("ok %d frames of %d x %d, %d without a pre-pass, %lld doubles of grids, %lld of %lld image bytes sent by the runner\n", n, width,
+           height, hinted, (long long)used, (long long)uploaded, (long long)(host_images ? (int64_t)n * (int64_t)img_bytes : 0));
     free(host), free(res), free(images), free(frames);
     return 0;
 }

@@ -34,7 +34,9 @@ extern "C" {
  *    (amt_pipe_launch_box[_many], amt_pipe_launch_many_res, amt_plate_carree_resolution) (round 4) */
 /* 5: the single-pass plan on caller-supplied corner directions (amt_georef_coarse_bbox_dirs, amt_pipe_coarse_dirs,
  *    amt_pipe_launch_dirs); griddata(method='cubic') exactly: amt_delaunay_*, amt_cubic_gradients_csr, amt_cubic_eval (round 5) */
-/* 6: amt_georef_out.row_layout (strip-padded rows for buffers a pipeline owns), amt_padded_pitch, amt_unpad_rows (round 6) */
+/* 6: amt_georef_out.row_layout (strip-padded rows for buffers a pipeline owns), amt_padded_pitch, amt_unpad_rows; host images in the
+ *    sequence runner (amt_run_frame.img_host, amt_run_result.uploaded_bytes, amt_georef_image_rows, amt_malloc_host / amt_free_host)
+ *    (round 6) */
 #define AMT_ABI_VERSION 6
 
 #define AMT_OK 0
@@ -68,6 +70,10 @@ int amt_device_info(amt_ctx* ctx, char* name, size_t name_len, int* compute_unit
 /* Plain device-memory helpers so that a host without torch can drive the library. */
 int amt_malloc(amt_ctx* ctx, size_t bytes, void** out_dptr);
 int amt_free(amt_ctx* ctx, void* dptr);
+/* Page-locked host memory (what amt_run_frame.img_host points into: the DMA engine reads it at the link's rate while the host
+ * goes on); ABI v6. */
+int amt_malloc_host(amt_ctx* ctx, size_t bytes, void** out_hptr);
+int amt_free_host(amt_ctx* ctx, void* hptr);
 int amt_memcpy_h2d(amt_ctx* ctx, void* dst, const void* src, size_t bytes);   /* async on the stream */
 int amt_memcpy_d2h(amt_ctx* ctx, void* dst, const void* src, size_t bytes);   /* synchronises */
 int amt_memset(amt_ctx* ctx, void* dst, int value, size_t bytes);
@@ -364,6 +370,14 @@ int amt_georef_coarse_bbox_dirs(amt_ctx* ctx, const amt_frame_params* p, const d
  * intersection.py:58-104) — and changes no result. */
 int amt_georef_sky_rows(const amt_frame_params* p, int32_t* rows_per_item, int32_t* n_item_rows, int32_t* top_end,
                         int32_t* bottom_begin);
+/* Host function (no GPU call): the pixel rows [*row_begin, *row_end) of a camera frame's IMAGE that the fused binning can need
+ * — a pixel's colours are read only to bin it, and only pixels whose ray hits the shell with an elevation >= min_elevation are
+ * binned (reference mapping.py:845-864 maskedByElevation, resample.py:119-120,315-321).  Bounded from the camera model alone: the
+ * limb as above, and the cone about the nadir inside which the elevation can reach min_elevation (law of sines in the triangle
+ * Earth's centre / camera / hit point: sin(nadir angle) = |P| / |C| cos(elevation), |P| <= the shell's larger semi-axis).
+ * Conservative, at the granularity of the work items' rows; min_elevation <= 0 or -inf: the rows a ray can hit.  What a host
+ * that holds the image in page-locked memory has to send (amt_run_frame.img_host does exactly that). */
+int amt_georef_image_rows(const amt_frame_params* p, double min_elevation, int32_t* row_begin, int32_t* row_end);
 
 /* ---- mask rules ---------------------------------------------------------------------- */
 
@@ -764,6 +778,12 @@ typedef struct amt_run_frame {
     double jd;                    /* photo time, UTC Julian date as ONE double (astropy Time(...).jd, transform.py:529) */
     double altitude;              /* mapping shell [km]; <= 0: the config's */
     const void* img;              /* device, (height, width, 3) of img_dtype; read until the call returns */
+    /* ABI v6: with img == NULL, the image in PAGE-LOCKED host memory (hipHostMalloc / hipHostRegister / torch pin_memory; same
+     * layout; read until amt_run_end returns).  The runner sends the rows that can be binned (amt_georef_image_rows) to a device
+     * buffer of its own per slot on a copy stream of its own at once — the frame's launch comes one batch later and waits for
+     * them —; amt_run_result.uploaded_bytes says how many bytes that were.  What the reference's loop does with the image it
+     * has just read from disk (cli/convert.py:178-216, mapping/spacecraft.py:326-332). */
+    const void* img_host;
 } amt_run_frame;
 typedef struct amt_run_result {
     int32_t status, slot;
@@ -782,6 +802,7 @@ typedef struct amt_run_result {
     amt_frame_params params;      /* what the frame was computed with */
     double lat_px_per_deg, lon_px_per_deg;   /* the resolution the frame was binned at */
     int32_t retried, reserved2_;  /* retried = 1: launched a second time with its exact box as the estimate */
+    int64_t uploaded_bytes;       /* amt_run_frame.img_host: bytes of the image that crossed the link (0 for a device image) */
 } amt_run_result;
 /* The host scalars of one frame (no GPU call).  AMT_EINVAL: date outside the IGRF table with want_sm. */
 int amt_frame_params_from_wcs(const amt_run_frame* frame, int32_t width, int32_t height, int32_t fast_center,

@@ -1043,27 +1043,79 @@ def test_degenerate_frame_sizes(width, height):
 
 
 def test_sequence_with_uploaded_images_from_pinned_memory():
-    """Per-frame images from pinned host memory (asynchronous upload on the copy stream, buffers re-used while older
-    frames are still in flight) give the same grids as one frame at a time."""
+    """Per-frame images from page-locked host memory give the same grids as one frame at a time with the WHOLE image resident on
+    the device — although only the rows that can be binned cross the link (amt_georef_image_rows: inside the limb, above
+    min_elevation), in the library's frame loop (amt_run_frame.img_host: the runner's copy stream, one batch ahead of the launch)
+    as in the Python loop; frames that leave the single-pass plan (pole, empty sky) and buffers re-used while older frames are
+    still in flight included."""
     import torch
-    from auromat_amd.pipeline import FramePipeline, SequencePipeline
-    from auromat_amd.synthetic import frame_image, sequence_frame
-    w, h, n = 530, 354, 14
+    from auromat_amd.pipeline import FramePipeline, NativeResults, SequencePipeline
+    from auromat_amd.synthetic import frame_image, pole_frame, sequence_frame
+    w, h, n = 530, 354, 17
     frames, imgs = [], []
     for k in range(n):
         hdr, cam, t, seed = sequence_frame(k, w, h)
+        if k == 6:
+            hdr, cam, t = pole_frame(w, h)
+        if k == 11:
+            hdr = dict(hdr, CRVAL2=hdr['CRVAL2'] + 70.0)           # off the limb: no valid pixel
         img = frame_image(w, h, seed=seed)
         imgs.append(img)
         frames.append((hdr, cam, t, torch.from_numpy(img.view(np.int16)).pin_memory()))
     single = FramePipeline(w, h)
-    want = [single.run(hdr, 110, cam, t, img=imgs[k], pxPerDeg=10) for k, (hdr, cam, t, _) in enumerate(frames)]
-    for plan in ('single-pass', 'two-pass'):
+    want = []
+    for k, (hdr, cam, t, _) in enumerate(frames):
+        try:
+            want.append(single.run(hdr, 110, cam, t, img=torch.from_numpy(imgs[k].view(np.int16)).cuda(), pxPerDeg=10))
+        except ValueError:
+            want.append(None)
+    assert want[11] is None and want[6]['contains_pole']
+    sent = {}
+    for plan, native in (('single-pass', True), ('single-pass', False), ('two-pass', False)):
         seq = SequencePipeline(w, h, pxPerDeg=10, plan=plan)
-        got = seq.process(frames, keep_on_device=False)
-        assert len(got) == n and seq.s_copy is not None
-        for k in range(n):
-            for key in ('mean', 'count', 'img', 'mask'):
-                assert np.array_equal(got[k][key], want[k][key], equal_nan=True), (plan, k, key)
+        seq.native = native
+        for rep in range(2):
+            got = seq.process(frames, keep_on_device=False)
+            assert len(got) == n and isinstance(got, NativeResults) == native
+            assert native or seq.s_copy is not None
+            assert 0 < seq.uploaded_bytes < 0.8 * n * w * h * 6, seq.uploaded_bytes
+            sent[(plan, native)] = seq.uploaded_bytes
+            for k in range(n):
+                assert (got[k] is None) == (want[k] is None), (plan, native, k)
+                if want[k] is None:
+                    continue
+                for key in ('mean', 'count', 'img', 'mask'):
+                    assert np.array_equal(got[k][key], want[k][key], equal_nan=True), (plan, native, rep, k, key)
+    # the library's loop sends what the Python loop sends, except that the Python loop sends a band of 90 % or more whole
+    assert sent[('single-pass', True)] <= sent[('single-pass', False)] == sent[('two-pass', False)]
+
+
+def test_uploaded_rows_really_are_all_that_is_read():
+    """The device image buffer of a slot holds GARBAGE outside the uploaded band (here: the previous frame's pixels, inverted):
+    the grids do not change — full-size frame, the fused kernel and the separate binning pass."""
+    import torch
+    from auromat_amd.pipeline import FramePipeline, earth_rows_of
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    w, h = 1060, 708
+    hdr, cam, t, seed = sequence_frame(5, w, h)
+    img = frame_image(w, h, seed=seed)
+    p = frame_params(hdr, 110, cam, t, True)
+    r0, r1 = earth_rows_of(p, h, 10.0)
+    assert 0 < r0 < r1 == h
+    bad = (~img).copy()
+    bad[r0:r1] = img[r0:r1]
+    for fuse in (True, False):
+        q = FramePipeline(w, h)
+        a = q.run(hdr, 110, cam, t, img=torch.from_numpy(img.view(np.int16)).cuda(), pxPerDeg=10, fuse=fuse)
+        b = q.run(hdr, 110, cam, t, img=torch.from_numpy(bad.view(np.int16)).cuda(), pxPerDeg=10, fuse=fuse)
+        for key in ('mean', 'count', 'img', 'mask'):
+            assert np.array_equal(a[key], b[key], equal_nan=True), (fuse, key)
+    # ... and one row more would be missed: the band is not loose by accident (a pixel of row r0 + 32 is binned)
+    bad[r0:r0 + 48] = ~img[r0:r0 + 48]
+    q = FramePipeline(w, h)
+    c = q.run(hdr, 110, cam, t, img=torch.from_numpy(bad.view(np.int16)).cuda(), pxPerDeg=10, fuse=True)
+    assert not np.array_equal(a['mean'], c['mean'], equal_nan=True)
 
 
 def test_plain_c_client_of_the_abi(tmp_path):

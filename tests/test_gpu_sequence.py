@@ -388,14 +388,20 @@ def test_plain_c_host_runs_a_sequence(tmp_path):
         run_frame(hdr, cam, t, 0.0, None, out=arr[k])
     (tmp_path / 'frames.bin').write_bytes(bytes(C.string_at(C.byref(arr), C.sizeof(arr))))
     (tmp_path / 'images.bin').write_bytes(b''.join(img.tobytes() for _, _, _, img in frames))
-    for resolution, kw in (('6', dict(pxPerDeg=6)), ('-600', dict(arcsecPerPx=600))):
-        # (a negative "px per degree" is arcsec per pixel: the reference's own call form, every frame at the px/deg of its box)
+    for resolution, kw, where in (('6', dict(pxPerDeg=6), []), ('-600', dict(arcsecPerPx=600), []),
+                                  ('6', dict(pxPerDeg=6), ['host']), ('-600', dict(arcsecPerPx=600), ['host'])):
+        # (a negative "px per degree" is arcsec per pixel: the reference's own call form, every frame at the px/deg of its box;
+        # `host`: the images stay in page-locked host memory and the runner sends the rows of each that can be binned)
         run = subprocess.run([exe, str(tmp_path / 'frames.bin'), str(tmp_path / 'images.bin'), str(n), str(w), str(h), resolution,
-                              str(tmp_path / 'out.bin')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True,
-                             timeout=120)
+                              str(tmp_path / 'out.bin')] + where, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                             universal_newlines=True, timeout=120)
         assert run.returncode == 0 and run.stdout.startswith('ok %d frames' % n), run.stdout
         raw = (tmp_path / 'out.bin').read_bytes()
         rec = np.frombuffer(raw[:n * C.sizeof(RunResult)], dtype=np.dtype(RunResult))
+        if where:
+            assert 0 < rec['uploaded_bytes'].sum() < 0.8 * n * w * h * 6 and (rec['uploaded_bytes'][[7]] == 0).all(), rec['uploaded_bytes']
+        else:
+            assert not rec['uploaded_bytes'].any()
         grids = np.frombuffer(raw[n * C.sizeof(RunResult):], dtype=np.float64)
         seq = SequencePipeline(w, h, **kw)
         want = seq.process(frames, keep_on_device=False)

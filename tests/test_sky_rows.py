@@ -82,3 +82,53 @@ def test_sky_rows_of_the_bench_frame():
     rows, n, top, bottom = sky_rows(hdr, cam, t)
     # the limb crosses the bench frame between rows 1140 and 1300 (43 % of the frame is sky)
     assert (rows, n, bottom) == (16, 177, 177) and 60 <= top <= 72, (top, bottom)
+
+
+# ---- amt_georef_image_rows (round 6): the rows of a host image that have to cross the link --------------------------------------
+def image_rows(hdr, cam, t, min_elev, altitude=110, fast=True):
+    from auromat_amd import _native
+    from auromat_amd.mapping.astrometry import frame_params
+    p = frame_params(hdr, altitude, cam, t, fast)
+    r0, r1 = C.c_int32(-1), C.c_int32(-1)
+    assert _native.lib().amt_georef_image_rows(C.byref(p), float(min_elev), C.byref(r0), C.byref(r1)) == 0
+    return r0.value, r1.value
+
+
+def binned_pixel_rows(hdr, cam, t, min_elev, altitude=110, fast=True):
+    """Pixel rows that hold a pixel the binning reads: centre on the shell and elevation >= min_elev (the oracle's, every pixel)."""
+    from oracle import ref_numpy as O
+    from auromat_amd.coordinates import transform as T
+    g = O.georef_frame(hdr, altitude, cam, O.mat_j2000_to_geo(T.date2es(t)), None, fast=fast)
+    with np.errstate(invalid='ignore'):
+        ok = ~np.isnan(g['lat_c']) & (g['elev'] >= min_elev)
+    return ok.any(axis=1)
+
+
+@pytest.mark.parametrize('case', cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize('min_elev', [-np.inf, 0.0, 3.0, 10.0, 25.0, 60.0])
+def test_image_rows_are_sound_and_tight(case, min_elev):
+    name, hdr, cam, t = case
+    h = hdr['IMAGEH']
+    for altitude, fast in ((110, True), (300, False)):
+        r0, r1 = image_rows(hdr, cam, t, min_elev, altitude, fast)
+        assert 0 <= r0 <= r1 <= h
+        need = binned_pixel_rows(hdr, cam, t, min_elev, altitude, fast)
+        assert not need[:r0].any() and not need[r1:].any(), (name, min_elev, altitude, r0, r1, np.flatnonzero(need)[[0, -1]])
+        if not need.any():
+            continue
+        first, last = np.flatnonzero(need)[[0, -1]]
+        # at most three bands of 16 rows more than needed on either side (one for the limb's tolerance, one for the pixel the bands
+        # are widened by, one the elevation bound adds)
+        assert r0 >= (first // 16 - 3) * 16 and r1 <= (last // 16 + 4) * 16, (name, min_elev, altitude, r0, r1, first, last)
+        if not min_elev > 0:
+            rows, n, top, bottom = sky_rows(hdr, cam, t, altitude)
+            assert (r0, r1) == (top * rows, min(h, bottom * rows))
+
+
+def test_image_rows_of_the_bench_frame():
+    from auromat_amd.synthetic import sequence_frame
+    hdr, cam, t, _ = sequence_frame(0, 4240, 2832)
+    e0, e1 = image_rows(hdr, cam, t, -np.inf)
+    r0, r1 = image_rows(hdr, cam, t, 10.0)
+    # the rows a ray can hit: 62 % of the frame; those with a pixel above 10 deg of elevation: fewer
+    assert e1 == r1 == 2832 and 0.55 < (e1 - e0) / 2832.0 < 0.66 and r0 > e0 + 200, (e0, e1, r0, r1)
