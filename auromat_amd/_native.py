@@ -207,6 +207,7 @@ _SIGNATURES = {
     'amt_pipe_coarse_hint': ([_P, c_double_p, _I], _I),
     'amt_pipe_launch': ([_P, C.POINTER(FrameParams), C.POINTER(GeorefOut), _P, C.c_int32, _D, _D, _D, _I, _I], _I),
     'amt_pipe_launch_many': ([c_void_pp, C.c_int32, c_void_pp, c_void_pp, c_void_pp, C.c_int32, _D, _D, _D, _I, _I], _I),
+    'amt_pipe_launch_dirs_many': ([c_void_pp, C.c_int32, c_void_pp, c_void_pp, c_void_pp, c_void_pp, C.c_int32, _D, _D, _D, _I, _I], _I),
     'amt_pipe_wait': ([_P, C.POINTER(PipeResult)], _I),
     'amt_pipe_finalize': ([_P, _P, _P, _P, _P], _I),
     'amt_pipe_finalize_stream': ([_P, _P], _I),

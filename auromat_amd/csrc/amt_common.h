@@ -83,6 +83,9 @@ int amt_georef_launch(amt_ctx* ctx, const amt_frame_params* p, const double* dir
 #define AMT_MAX_BATCH 3
 int amt_georef_launch_many(amt_ctx* ctx, int n, const amt_frame_params* const* p, const amt_georef_out* const* out,
                            const amt_georef_tail* const* tail);
+// the same with caller-supplied corner directions, one array per frame (all frames or none)
+int amt_georef_launch_many_dirs(amt_ctx* ctx, int n, const amt_frame_params* const* p, const double* const* dirs,
+                                const amt_georef_out* const* out, const amt_georef_tail* const* tail);
 // k_apply_bin_events on `stream` (before the finalise kernel): see bin_event
 int amt_bin_apply_events_on(amt_ctx* ctx, hipStream_t stream, const void* events, uint32_t* count, uint64_t* acc,
                             int32_t acc_nx, int32_t acc_ny, int32_t off_x, int32_t off_y, int32_t nx, int32_t ny);

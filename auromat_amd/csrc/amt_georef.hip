@@ -1903,7 +1903,7 @@ int launch_prepared(amt_ctx* ctx, int n, prepared_frame* F) {
     for (int i = 1; i < n && together; ++i)
         together = !F[0].sh.use_tiles && F[i].p->width == F[0].p->width && F[i].p->height == F[0].p->height &&
                    F[i].p->fast_center == F[0].p->fast_center && F[i].second == F[0].second && F[i].bin == F[0].bin &&
-                   F[i].dirs == nullptr && F[0].dirs == nullptr;
+                   (F[i].dirs != nullptr) == (F[0].dirs != nullptr);
     if (n > 1 && !together) {
         for (int i = 0; i < n; ++i)
             if (int rc = launch_prepared(ctx, 1, F + i)) return rc;
@@ -1998,6 +1998,18 @@ int amt_georef_launch_many(amt_ctx* ctx, int n, const amt_frame_params* const* p
     prepared_frame F[kMaxBatch];
     for (int i = 0; i < n; ++i)
         if (int rc = prepare_georef(ctx, p[i], nullptr, out[i], tail[i], &F[i])) return rc;
+    return launch_prepared(ctx, n, F);
+}
+
+int amt_georef_launch_many_dirs(amt_ctx* ctx, int n, const amt_frame_params* const* p, const double* const* dirs,
+                                const amt_georef_out* const* out, const amt_georef_tail* const* tail) {
+    AMT_CHECK_CTX(ctx);
+    AMT_REQUIRE(ctx, n >= 1 && n <= kMaxBatch && p && dirs && out && tail, "bad batch");
+    prepared_frame F[kMaxBatch];
+    for (int i = 0; i < n; ++i) {
+        AMT_REQUIRE(ctx, dirs[i] != nullptr, "corner_dirs is NULL");
+        if (int rc = prepare_georef(ctx, p[i], dirs[i], out[i], tail[i], &F[i])) return rc;
+    }
     return launch_prepared(ctx, n, F);
 }
 

@@ -514,6 +514,35 @@ int amt_pipe_launch_dirs(amt_pipe* pipe, const amt_frame_params* p, const double
     return pipe_after_launch(pipe);
 }
 
+int amt_pipe_launch_dirs_many(amt_pipe* const* pipes, int32_t n, const amt_frame_params* const* p, const double* const* corner_dirs,
+                              const amt_georef_out* const* out, const void* const* img, int32_t img_dtype, double min_elevation,
+                              double lat_px_per_deg, double lon_px_per_deg, int pole_in_view, int magnetic) {
+    if (pipes == nullptr || n < 1 || pipes[0] == nullptr) return AMT_EINVAL;
+    amt_ctx* ctx = pipes[0]->ctx;
+    AMT_REQUIRE(ctx, n <= AMT_MAX_BATCH, "at most AMT_PIPE_MAX_BATCH frames per launch");
+    AMT_REQUIRE(ctx, p && corner_dirs && out && img, "NULL argument");
+    amt_georef_out o[AMT_MAX_BATCH];
+    amt_georef_tail tails[AMT_MAX_BATCH];
+    const amt_georef_out* op[AMT_MAX_BATCH];
+    const amt_georef_tail* tp[AMT_MAX_BATCH];
+    for (int i = 0; i < n; ++i) {
+        AMT_REQUIRE(ctx, pipes[i] != nullptr && pipes[i]->ctx == ctx, "drivers of one launch must share the context");
+        for (int k = 0; k < i; ++k) AMT_REQUIRE(ctx, pipes[k] != pipes[i], "a driver can hold one frame of a launch");
+        AMT_REQUIRE(ctx, p[i] && corner_dirs[i] && out[i] && img[i], "NULL argument");
+        AMT_REQUIRE(ctx, p[i]->fast_center, "caller-supplied directions need fast_center");
+        if (int rc = pipe_prepare(pipes[i], p[i], out[i], img[i], img_dtype, min_elevation, lat_px_per_deg, lon_px_per_deg,
+                                  pole_in_view, magnetic, &o[i], &tails[i], corner_dirs[i]))
+            return rc;
+        pipes[i]->g_mode = -1;
+        op[i] = &o[i];
+        tp[i] = &tails[i];
+    }
+    if (int rc = amt_georef_launch_many_dirs(ctx, n, p, corner_dirs, op, tp)) return rc;
+    for (int i = 0; i < n; ++i)
+        if (int rc = pipe_after_launch(pipes[i])) return rc;
+    return AMT_OK;
+}
+
 int amt_pipe_launch_box_many(amt_pipe* const* pipes, int32_t n, const amt_frame_params* const* p, double min_elevation,
                              int magnetic) {
     if (pipes == nullptr || n < 1 || pipes[0] == nullptr) return AMT_EINVAL;

@@ -402,10 +402,11 @@ class FramePipeline(object):
         return fd
 
     @staticmethod
-    def georef_many(pipes, params, altitudes, min_elevation, fuse_pxPerDeg, fuse_magnetic=False):
+    def georef_many(pipes, params, altitudes, min_elevation, fuse_pxPerDeg, fuse_magnetic=False, dirs=None, pole_in_view=-1):
         """
         The single-pass launch of :meth:`georef` for up to AMT_PIPE_MAX_BATCH pipelines at once (one frame each, coarse
-        pre-pass already started): ONE launch of the big kernel covers all frames (amt_pipe_launch_many).
+        pre-pass already started): ONE launch of the big kernel covers all frames (amt_pipe_launch_many).  `dirs`: one
+        (h + 1, w + 1, 3) direction tensor per frame instead of the camera model (amt_pipe_launch_dirs_many).
         """
         n = len(pipes)
         ctx = pipes[0].ctx
@@ -425,16 +426,23 @@ class FramePipeline(object):
         # px/deg follows from its own bounding box)
         per_frame = isinstance(fuse_pxPerDeg, list)
         ppd = [tuple(v) for v in fuse_pxPerDeg] if per_frame else [tuple(fuse_pxPerDeg)] * n
-        if per_frame:
+        if dirs is not None:
+            assert not per_frame and len(dirs) == n
+            for d, q in zip(dirs, pipes):
+                assert d.is_cuda and d.is_contiguous() and tuple(d.shape) == (q.height + 1, q.width + 1, 3)
+            dd = (C.c_void_p * n)(*[d.data_ptr() for d in dirs])
+            ctx.check(ctx._lib.amt_pipe_launch_dirs_many(handles, n, pp, dd, oo, ii, pipes[0].fd.img_dtype_code, min_elev,
+                                                         float(ppd[0][0]), float(ppd[0][1]), int(pole_in_view), mag))
+        elif per_frame:
             la, lo = (C.c_double * n)(*[float(v[0]) for v in ppd]), (C.c_double * n)(*[float(v[1]) for v in ppd])
             ctx.check(ctx._lib.amt_pipe_launch_many_res(handles, n, pp, oo, ii, pipes[0].fd.img_dtype_code, min_elev, la, lo, -1, mag))
         else:
             ctx.check(ctx._lib.amt_pipe_launch_many(handles, n, pp, oo, ii, pipes[0].fd.img_dtype_code, min_elev,
                                                     float(ppd[0][0]), float(ppd[0][1]), -1, mag))
-        for q, p, altitude, v in zip(pipes, params, altitudes, ppd):
+        for i, (q, p, altitude, v) in enumerate(zip(pipes, params, altitudes, ppd)):
             q.params, q.altitude, q.min_elevation = p, altitude, min_elevation
-            q._dirs = None
-            q._fused = dict(pxPerDeg=v, magnetic=bool(mag), result=None)
+            q._dirs = None if dirs is None else dirs[i]
+            q._fused = dict(pxPerDeg=v, magnetic=bool(mag), result=None, pole_in_view=int(pole_in_view))
             q.fd.corner_mask = q.fd.center_mask = None
             q._coords_valid = has_array(q.fd, 'lat') and q.with_geo
             q._kept_valid = has_array(q.fd, 'elev')

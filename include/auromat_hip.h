@@ -665,6 +665,11 @@ int amt_pipe_coarse_dirs(amt_pipe* pipe, const amt_frame_params* p, const double
 int amt_pipe_launch_dirs(amt_pipe* pipe, const amt_frame_params* p, const double* corner_dirs, const amt_georef_out* out,
                          const void* img, int32_t img_dtype, double min_elevation, double lat_px_per_deg,
                          double lon_px_per_deg, int pole_in_view, int magnetic);
+/* amt_pipe_launch_dirs for n <= AMT_PIPE_MAX_BATCH frames, one per driver, each with its own direction array, in ONE launch of
+ * the big kernel (ABI v6; see amt_pipe_launch_many below). */
+int amt_pipe_launch_dirs_many(amt_pipe* const* pipes, int32_t n, const amt_frame_params* const* p, const double* const* corner_dirs,
+                              const amt_georef_out* const* out, const void* const* img, int32_t img_dtype, double min_elevation,
+                              double lat_px_per_deg, double lon_px_per_deg, int pole_in_view, int magnetic);
 /* The same for n <= AMT_PIPE_MAX_BATCH frames, one per driver (all on one context), with ONE launch of the big
  * kernel when the frames are equally sized and take the same kernel variant (their constants sit side by side in
  * the kernel-argument segment; otherwise one launch each): the 14-17 us between two big kernels on a stream are

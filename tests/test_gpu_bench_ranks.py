@@ -35,6 +35,11 @@ def test_bench_with_several_ranks_on_one_gpu(world, steps):
     assert abs(out['value'] - world * steps * npx / 1e6 / (out['ms_per_step'] * steps * 1e-3)) < 1e-6 * out['value']
     assert out['config']['workload'].startswith('configs[')
     assert out['roofline']['frac'] > 0 and out['roofline']['bound'] == 'hbm'
+    # the value is that of the median of seven timed regions (each: barrier, K steps, gather, barrier; maximum over the ranks)
+    assert out['repeats'] == 7 and len(out['regions_ms']) == 7
+    assert out['ms_per_step_min'] <= out['ms_per_step'] <= out['ms_per_step_max']
+    assert sorted(out['regions_ms'])[3] == pytest.approx(out['ms_per_step'] * steps, rel=1e-9)
+    assert out['config']['frame_loop'].startswith('library')
     assert out['config']['frames_total'] == world * steps and out['config']['single_pass_frames'] == steps
     # the line describes its ranks: N of them reported, each with its device, its own times and what it sent
     assert out['ranks'] == world and out['backend'] == 'gloo'
@@ -75,3 +80,6 @@ def test_n_rank_line_carries_the_upload_variant():
     assert abs(up['Mpixels_per_s'] - world * steps * npx / 1e6 / (up['ms_per_frame'] * steps * 1e-3)) < 1e-6 * up['Mpixels_per_s']
     # PCIe-inclusive: slower than the HBM-resident figure of the same line
     assert up['Mpixels_per_s'] < out['value']
+    # through the library's frame loop, and only the rows of an image that can be binned cross the link
+    assert up['frame_loop'].startswith('library') and up['repeats'] == 7
+    assert 0 < up['uploaded_bytes_per_frame'] < 0.8 * up['image_bytes_per_frame']
