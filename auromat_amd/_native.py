@@ -120,6 +120,7 @@ _SIGNATURES = {
     'amt_device_info': ([_P, C.c_char_p, C.c_size_t, C.POINTER(_I), C.POINTER(_I), C.POINTER(C.c_size_t)], _I),
     'amt_malloc': ([_P, C.c_size_t, c_void_pp], _I),
     'amt_free': ([_P, _P], _I),
+    'amt_host_threads': ([_I, C.POINTER(_I), C.POINTER(_I)], _I),
     'amt_malloc_host': ([_P, C.c_size_t, c_void_pp], _I),
     'amt_free_host': ([_P, _P], _I),
     'amt_memcpy_h2d': ([_P, _P, _P, C.c_size_t], _I),
@@ -236,6 +237,38 @@ _lib_lock = threading.Lock()
 
 class NativeError(RuntimeError):
     pass
+
+
+def host_threads(wanted):
+    """Threads a host-side pool of this process may use when it would like `wanted`: the cores the process may run on divided by
+    the ranks that share the node (LOCAL_WORLD_SIZE of torch.distributed.run, or AMT_LOCAL_RANKS), at least 1 — the rule of the
+    library's own pools (include/auromat_hip.h amt_host_threads; the same arithmetic here, so that modules which never load the
+    GPU library can size their pools).  Eight ranks on one host each start a copy pool, a triangulator and writer threads."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    ranks = 1
+    for name in ('AMT_LOCAL_RANKS', 'LOCAL_WORLD_SIZE'):
+        try:
+            v = int(os.environ.get(name, '0'))
+        except ValueError:
+            v = 0
+        if v > 0:
+            ranks = v
+            break
+    return max(1, min(int(wanted), max(1, cores // ranks)))
+
+
+def host_threads_report():
+    """What the pools of this process were sized from and to (bench.py's per_rank records carry it)."""
+    cores, ranks = C.c_int(0), C.c_int(0)
+    share = lib().amt_host_threads(1 << 20, C.byref(cores), C.byref(ranks))
+    copy = int(os.environ.get('AMT_COPY_THREADS', '8'))
+    return dict(cores_available=cores.value, local_ranks=ranks.value, share=share,
+                copy_threads=max(1, min(copy, (share + 1) // 2, 16)),
+                triangulator_threads=int(os.environ.get('AMT_DELAUNAY_THREADS', '0')) or lib().amt_host_threads(16, None, None),
+                io_threads=host_threads(16), omp_num_threads=os.environ.get('OMP_NUM_THREADS'))
 
 
 def lib():

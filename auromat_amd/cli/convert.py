@@ -310,7 +310,8 @@ def convert_with_pipeline(args, frames, export):
             from collections import deque
             from concurrent.futures import ThreadPoolExecutor
             ahead = max(1, int(os.environ.get('AMT_CONVERT_READ_AHEAD', '8')))
-            with ThreadPoolExecutor(max_workers=min(ahead, 8)) as pool:
+            from .._native import host_threads
+            with ThreadPoolExecutor(max_workers=host_threads(min(ahead, 8))) as pool:
                 pending = deque()
                 it = iter(todo)
                 for item in it:
@@ -331,7 +332,9 @@ def convert_with_pipeline(args, frames, export):
         # resampled grid takes 6 ms to compute and 20-odd to compress and lay out
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
+        from .._native import host_threads
         n_writers = max(0, int(os.environ.get('AMT_CONVERT_WRITERS', '4')))
+        n_writers = host_threads(n_writers) if n_writers else 0          # (several ranks on one host share its cores)
         writers = ThreadPoolExecutor(max_workers=n_writers) if n_writers else None
         written = deque()
         try:

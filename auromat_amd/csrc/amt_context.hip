@@ -1,4 +1,9 @@
 // Context, stream, memory and event helpers of the C ABI (include/auromat_hip.h).
+#include <sched.h>
+
+#include <cstdlib>
+#include <thread>
+
 #include "amt_common.h"
 
 extern "C" {
@@ -122,6 +127,30 @@ int amt_free(amt_ctx* ctx, void* dptr) {
     if (amt_set_device(ctx)) return AMT_EHIP;
     AMT_HIP(ctx, hipFree(dptr));
     return AMT_OK;
+}
+
+int amt_host_threads(int wanted, int* cores, int* local_ranks) {
+    int n_cores = 0;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n_cores = CPU_COUNT(&set);
+    if (n_cores <= 0) n_cores = (int)std::thread::hardware_concurrency();
+    if (n_cores <= 0) n_cores = 1;
+    int ranks = 1;
+    for (const char* name : {"AMT_LOCAL_RANKS", "LOCAL_WORLD_SIZE"}) {
+        const char* e = std::getenv(name);
+        const int v = e ? std::atoi(e) : 0;
+        if (v > 0) {
+            ranks = v;
+            break;
+        }
+    }
+    if (cores) *cores = n_cores;
+    if (local_ranks) *local_ranks = ranks;
+    int share = n_cores / ranks;
+    if (share < 1) share = 1;
+    if (wanted < 1) wanted = 1;
+    return wanted < share ? wanted : share;
 }
 
 int amt_malloc_host(amt_ctx* ctx, size_t bytes, void** out_hptr) {

@@ -100,11 +100,12 @@ amt_copier* copier_of(amt_ctx* ctx) {
     if (ctx->copier != nullptr) return ctx->copier;
     amt_copier* c = new (std::nothrow) amt_copier();
     if (c == nullptr) return nullptr;
-    // AMT_COPY_THREADS: host threads that copy (default 8, at most half the host's cores and 16: 43 GB/s with 4, 50 with 8)
+    // AMT_COPY_THREADS: host threads that copy (default 8, at most 16 and half of this rank's share of the host's cores —
+    // amt_host_threads: the cores this process may run on divided by the ranks on the node —: 43 GB/s with 4, 50 with 8)
     const char* e = std::getenv("AMT_COPY_THREADS");
     int n = e ? std::atoi(e) : 8;
-    const unsigned hw = std::thread::hardware_concurrency();
-    if (hw > 0 && n > (int)((hw + 1) / 2)) n = (int)((hw + 1) / 2);
+    const int share = amt_host_threads(1 << 20, nullptr, nullptr);
+    if (n > (share + 1) / 2) n = (share + 1) / 2;
     c->n_workers = n < 1 ? 1 : (n > amt_copier::kMaxWorkers ? amt_copier::kMaxWorkers : n);
     c->generation = 0, c->remaining = 0, c->quit = false;
     c->failed = 0;

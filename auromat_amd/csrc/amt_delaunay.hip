@@ -872,7 +872,7 @@ int amt_delaunay_create_threads(const double* xy, int64_t n, int32_t threads, in
         static const int env_threads = [] {
             const char* e = std::getenv("AMT_DELAUNAY_THREADS");
             const int v = e ? std::atoi(e) : 0;
-            return v > 0 ? v : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+            return v > 0 ? v : amt_host_threads(16, nullptr, nullptr);      // (this rank's share of the host's cores)
         }();
         threads = env_threads;
     }

@@ -59,7 +59,12 @@ GZIP_COMPRESSION = 5
 _VXR_ENTRIES = 7
 # native threads that deflate the blocks of one large record (AMT_IO_THREADS; AMT_NC4_THREADS, the netCDF-4 writer's switch, is
 # honoured too: both writers share the helper and its thread budget)
-_GZIP_THREADS = max(1, min(16, int(os.environ.get('AMT_IO_THREADS', os.environ.get('AMT_NC4_THREADS', '0'))) or (os.cpu_count() or 1)))
+def _io_threads():
+    from .._native import host_threads
+    return int(os.environ.get('AMT_IO_THREADS', os.environ.get('AMT_NC4_THREADS', '0'))) or host_threads(16)
+
+
+_GZIP_THREADS = max(1, min(16, _io_threads()))          # (this rank's share of the host's cores: _native.host_threads)
 _LEAP_TABLE_DATE = 20170101
 
 # TAI - UTC in whole seconds from the given day on (IERS Bulletin C; the table the CDF library carries for TT2000)

@@ -31,7 +31,12 @@ _DEFLATE_LEVEL = 4       # netCDF4-python's default complevel
 # threads that compress the chunks of a large array (deflate releases the interpreter lock); AMT_IO_THREADS / AMT_NC4_THREADS
 # override.  Native jobs that run at the same time share this number (_io._share): four writer threads with several variables
 # each stay near it instead of multiplying it.
-_THREADS = max(1, min(16, int(os.environ.get('AMT_IO_THREADS', os.environ.get('AMT_NC4_THREADS', '0'))) or (os.cpu_count() or 1)))
+def _io_threads():
+    from .._native import host_threads
+    return int(os.environ.get('AMT_IO_THREADS', os.environ.get('AMT_NC4_THREADS', '0'))) or host_threads(16)
+
+
+_THREADS = max(1, min(16, _io_threads()))               # (this rank's share of the host's cores: _native.host_threads)
 _ROWS_PER_TASK = 32      # chunks of one row: rows a task shuffles at once (one NumPy copy) and then deflates one by one
 _POOL = []
 

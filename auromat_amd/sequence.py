@@ -12,6 +12,38 @@ this size).
 import numpy as np
 
 
+class SequenceError(RuntimeError):
+    """A rank of a distributed sequence failed (its pipeline raised, or its grids did not fit the agreed gather capacity).
+    Raised on EVERY rank by :func:`agree_ok`, so that the whole job ends with a non-zero code instead of some ranks returning
+    while others wait in a collective.  `ranks`: the ranks that reported a failure, `messages`: what they said."""
+
+    def __init__(self, ranks, messages):
+        RuntimeError.__init__(self, 'rank(s) %s of the sequence failed: %s' % (ranks, '; '.join(messages)))
+        self.ranks, self.messages = ranks, messages
+
+
+def agree_ok(error, device, group=None):
+    """
+    Every rank calls this at the same point of the program with its own failure — an exception, a message, or None.  When any
+    rank reports one, EVERY rank raises :class:`SequenceError` naming those ranks (one all_gather of a flag, and of the
+    messages only when something failed); otherwise returns.  The reference has no counterpart: its frames are a ``map`` in one
+    process (mapping/spacecraft.py:326-332) and an exception simply ends it.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    flag = torch.tensor([0 if error is None else 1], dtype=torch.int32, device=device)
+    flags = [torch.zeros_like(flag) for _ in range(world)]
+    dist.all_gather(flags, flag, group=group)
+    failed = [r for r, f in enumerate(flags) if int(f.item()) != 0]
+    if not failed:
+        return
+    messages = [None] * world
+    dist.all_gather_object(messages, None if error is None else '%s: %s' % (type(error).__name__, error) if isinstance(error, BaseException)
+                           else str(error), group=group)
+    raise SequenceError(failed, ['rank %d: %s' % (r, messages[r]) for r in failed])
+
+
 def shard(n_frames, rank, world_size):
     """Contiguous block of frame indices for `rank` (sizes differ by at most one)."""
     base, extra = divmod(n_frames, world_size)
@@ -139,6 +171,9 @@ class Gathered(object):
             # gathered with an agreed capacity: every buffer ends with its own (frames, payload length)
             import torch
             tail = torch.stack([b[-2:] for b in self.bufs]).cpu().numpy()
+            if (tail[:, 0] == -2).any():
+                raise ValueError('gather_device: rank(s) %s failed before the gather and sent nothing'
+                                 % np.nonzero(tail[:, 0] == -2)[0].tolist())
             if (tail[:, 0] < 0).any():
                 raise ValueError('gather_device: the grids of rank(s) %s did not fit the agreed capacity'
                                  % np.nonzero(tail[:, 0] < 0)[0].tolist())
@@ -286,6 +321,36 @@ def agree_capacity(results, indices, device, margin=1.25, group=None):
     return int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max() * margin) + 1
 
 
+def gather_checked(results, indices, device, dst=0, group=None, capacity=None, packer=None, error=None):
+    """
+    :func:`gather_device` for a job in which a rank may have FAILED before the gather (`error`: its exception; `results` is
+    then ignored) or may find that its grids do not fit the agreed capacity: the failed rank still takes part in the
+    collective (it sends a buffer that says so: nobody waits for it), the destination reads the sizes, and then all ranks
+    agree (:func:`agree_ok`) — every rank raises :class:`SequenceError` when something went wrong anywhere, the destination's
+    knowledge of an overflow included.  Two small collectives more than gather_device (outside of a benchmark's timed region
+    only when the caller puts them there).
+    """
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    problem = error
+    if error is not None:
+        results, indices, packer = _FailedRank(), [], None
+    g = None
+    try:
+        g = gather_device(results, indices, device, dst, group, capacity, packer)
+        if g is not None and rank == dst:
+            g.sizes                              # (reads the trailers: an overflow or a failed rank shows here)
+    except ValueError as e:
+        problem = problem or e
+    agree_ok(problem, device, group)
+    return g
+
+
+class _FailedRank(list):
+    """The results of a rank that failed: no frames; with an agreed capacity its buffer's trailer says (-2, 0)."""
+    failed = True
+
+
 def gather_device(results, indices, device, dst=0, group=None, capacity=None, packer=None):
     """
     Gather every rank's per-frame grids on rank `dst`, device to device.  Two collectives: an all_gather of the
@@ -315,7 +380,10 @@ def gather_device(results, indices, device, dst=0, group=None, capacity=None, pa
         max_frames, max_payload = capacity
         parts, total = payload_parts(results, device)
         head = np.zeros(max_frames * DESC_LEN + 2, dtype=np.float64)
-        if len(results) <= max_frames and total <= max_payload:
+        if getattr(results, 'failed', False):
+            head[-2:] = (-2.0, 0.0)              # this rank failed before the gather (gather_checked)
+            parts, total = [], 0
+        elif len(results) <= max_frames and total <= max_payload:
             head[:len(results) * DESC_LEN] = describe_results(results, indices).reshape(-1)
             head[-2:] = (len(results), total)
         else:
@@ -381,16 +449,27 @@ def run_sequence(frames, width, height, altitude=110, fast=True, min_elevation=1
                            img_dtype=first.dtype if first is not None else np.uint16, device=device,
                            altitude=altitude, fast=fast, min_elevation=min_elevation, pxPerDeg=pxPerDeg,
                            magnetic=magnetic)
-    results = seq.process([frames[k] for k in mine])
-    dev = collective_device(seq.ctx.device) if distributed else seq.ctx.device
     # every rank takes part in the collectives whatever its frames did: a frame without a valid pixel travels as
-    # an empty descriptor and is reported in `failed`, it does not raise on one rank while the others wait
+    # an empty descriptor and is reported in `failed`; a rank whose pipeline RAISES (a date outside the IGRF table, a HIP
+    # error, no memory) takes part too and says so — then every rank raises SequenceError (gather_checked / agree_ok)
+    error = None
+    try:
+        results = seq.process([frames[k] for k in mine])
+    except Exception as e:
+        if not distributed:
+            raise
+        error, results = e, []
+    dev = collective_device(seq.ctx.device) if distributed else seq.ctx.device
     failed = []
-    if not distributed or not gather:
+    if not distributed:
+        descs, payload = pack_results(results, mine, dev)
+        out = unpack_results(descs, payload, failed)
+    elif not gather:
+        agree_ok(error, dev)
         descs, payload = pack_results(results, mine, dev)
         out = unpack_results(descs, payload, failed)
     else:
-        g = gather_device(results, mine, dev)
+        g = gather_checked(results, mine, dev, error=error)
         out = g.unpack() if g is not None else None
         failed = g.failed if g is not None else failed
     if return_failed:

@@ -70,6 +70,12 @@ int amt_device_info(amt_ctx* ctx, char* name, size_t name_len, int* compute_unit
 /* Plain device-memory helpers so that a host without torch can drive the library. */
 int amt_malloc(amt_ctx* ctx, size_t bytes, void** out_dptr);
 int amt_free(amt_ctx* ctx, void* dptr);
+/* Host threads a pool of this process may use when it would like `wanted` (no GPU call; ABI v6): the cores the process may run on
+ * (sched_getaffinity) divided by the ranks that share the node (LOCAL_WORLD_SIZE of torch.distributed.run, or AMT_LOCAL_RANKS),
+ * at least 1, at most `wanted`.  The library's own pools (amt_upload_staged's copy threads, the triangulator's strips) are
+ * sized by it, so that eight ranks on one host do not start 8 x (8 + 16) threads on its cores.  *cores / *local_ranks (each
+ * optional) report what it saw.  The reference is single-threaded per process (mapping/spacecraft.py:326-332). */
+int amt_host_threads(int wanted, int* cores, int* local_ranks);
 /* Page-locked host memory (what amt_run_frame.img_host points into: the DMA engine reads it at the link's rate while the host
  * goes on); ABI v6. */
 int amt_malloc_host(amt_ctx* ctx, size_t bytes, void** out_hptr);
