@@ -425,7 +425,7 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
         # the first gather (RCCL channels, its buffers at full size) comes BEFORE the spin-up: its host synchronisations
         # leave the GPU idle, and a short timed region right behind it runs its first launches 10 % slower
         first = seq.process(frames[:max(warmup, 1)])
-        after(first, True)
+        after(first, True, None)
         del first
     if spinup_ms > 0 and warmup + steps > 0:
         import torch
@@ -444,12 +444,28 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
         ctx.timing_enable(TIMING_EVERY)
         fence()
         t0 = time.perf_counter()
-        results = seq.process(frames[warmup:warmup + steps])
+        error = None
+        try:
+            timed = frames[warmup:warmup + steps]
+            if os.environ.get('AMT_BENCH_FAIL_RANK') == os.environ.get('RANK', '0') and len(regions) == 1:
+                # (tests: this rank's pipeline fails in the middle of its second timed region — a frame dated beyond the IGRF
+                # table, which the library's frame loop refuses — while the other ranks go on to the gather)
+                from datetime import datetime
+                bad = list(timed[len(timed) // 2])
+                bad[2] = datetime(2031, 1, 1)
+                timed = timed[:len(timed) // 2] + [tuple(bad)] + timed[len(timed) // 2 + 1:]
+            results = seq.process(timed)
+        except Exception as e:              # (a HIP error, no memory, a date outside the IGRF table ...)
+            if after is None:
+                raise
+            error, results = e, None
         t_proc = time.perf_counter()
         plans, hinted = list(seq.plans), seq.hinted
-        extra = after(results, False) if after is not None else None
+        # a rank that failed still takes part in the gather (it sends a buffer that says so) and in the closing fence, where
+        # every rank learns of it and raises: the job ends with a non-zero code, nobody waits in a collective
+        extra = after(results, False, error) if after is not None else None
         t_after = time.perf_counter()
-        fence()
+        fence(error)
         elapsed = time.perf_counter() - t0
         if os.environ.get('AMT_BENCH_DEBUG'):
             sys.stderr.write('timed region: process %.3f ms, after %.3f ms, fence %.3f ms\n' % (
@@ -611,16 +627,20 @@ def main(argv=None):
     def init_dist():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29541')
+        # (a rank that dies without a word — killed, a fault — leaves the others in a collective: they give up after this long
+        # and the launcher, which tears the job down at the first rank that exits with an error, ends it sooner)
+        from datetime import timedelta
+        limit = timedelta(seconds=int(os.environ.get('AMT_DIST_TIMEOUT_S', '600')))
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank), timeout=limit)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
 
     if use_dist:
         init_dist()
 
-    from auromat_amd._native import Context
-    from auromat_amd.sequence import agree_capacity, collective_device, gather_device
+    from auromat_amd._native import Context, host_threads_report
+    from auromat_amd.sequence import agree_capacity, agree_ok, collective_device, gather_device
     from auromat_amd.synthetic import sequence_frame, frame_image
 
     ctx = Context.current()
@@ -647,19 +667,33 @@ def main(argv=None):
             fr.append((hdr, cam, t, imgs[k % len(imgs)], SHELLS[k % 3] if magnetic else None))
         return fr
 
-    def fence():
+    def fence(error=None):
+        """synchronize + barrier + synchronize.  With a process group the barrier is an all_reduce(MAX) of one flag — what a
+        barrier is made of anyway — that carries this rank's failure: when any rank failed, every rank raises here."""
         torch.cuda.synchronize()
         if use_dist and dist.is_initialized():
-            dist.barrier()
+            flag = torch.tensor([0 if error is None else 1], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            torch.cuda.synchronize()
+            if error is not None:
+                raise error
+            if int(flag.item()):
+                from auromat_amd.sequence import SequenceError
+                raise SequenceError(['?'], ['another rank failed inside the timed region (its own message is on its stderr)'])
+        elif error is not None:
+            raise error
         torch.cuda.synchronize()
 
     gather_state = {}
 
-    def gather(results, warm):
+    def gather(results, warm, error=None):
         # device-to-device over xGMI; rank 0 unpacks to the host after the timed region.  The first call's costs
         # (RCCL channels, allocations) belong to the warm-up.
         if not use_dist:
             return None
+        if error is not None:
+            from auromat_amd.sequence import _FailedRank
+            return gather_device(_FailedRank(), [], cdev, capacity=gather_state.get('capacity'))
         base = first + (0 if warm else args.warmup)
         if warm:
             # as many frames as the timed gather will carry, so that its buffers (payload, padded send and receive
@@ -693,6 +727,16 @@ def main(argv=None):
                     single_pass_frames=sum(1 for q in reg['plans'] if q == 'single-pass'),
                     payload_bytes=None if whole is None else int(whole[1]) * 8,
                     gather_bytes=None if cap is None else (cap[0] * DESC_LEN + cap[1] + 2) * 8)
+        mine['host_threads'] = host_threads_report()
+        # a rank whose grids did not fit the capacity agreed in the warm-up said so in its buffer: the destination reads that
+        # now, and every rank ends with it (agree_ok raises SequenceError on all of them)
+        problem = None
+        if rank == 0:
+            try:
+                run['extra'].sizes
+            except ValueError as e:
+                problem = e
+        agree_ok(problem, cdev)
         rank_records = [None] * world
         dist.all_gather_object(rank_records, mine)
         if rank == 0:
@@ -837,7 +881,7 @@ def main(argv=None):
                        # output array is still written in full and is identical to the ray-cast result
                        'sky_item_rows': sky_rows_note(),
                        'kernel_variant': dict(zip(('second', 'bin', 'frames_in_last_launch'), run['variant'])),
-                       'device': info['name']},
+                       'host_threads': host_threads_report(), 'device': info['name']},
             # dominant kernel.  What bounds it is the rate at which the memory system takes its stores (every
             # variant moves its bytes at about the same rate whatever it computes; the strip-padded rows of round 6 raised that
             # rate by a tenth); `frac` prices SURVEY 8d's contract bytes, `frac_bytes_moved_min` the bytes the kernel has to move.

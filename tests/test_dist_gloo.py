@@ -269,3 +269,62 @@ def test_config5_sharding_and_gather_world8(tmp_path):
     mp.spawn(_config5_worker, args=(world, _free_port(), 256, str(tmp_path)), nprocs=world, join=True)
     total = int((tmp_path / 'ok').read_text())
     assert 8e6 < total < 1e8, total
+
+
+# ---- a rank that fails must end the whole job --------------------------------------------------------------
+
+@pytest.mark.parametrize('mode,culprit', [('ok', None), ('raise', 2), ('overflow', 1)])
+def test_a_failing_rank_ends_every_rank(mode, culprit):
+    """World 4 over gloo, one process per rank, started and watched one by one (as the launcher does): a rank whose pipeline
+    raises NativeError in the middle of its frames ('raise'), or whose grids do not fit the capacity the ranks agreed on in the
+    warm-up ('overflow'), still takes part in the gather and says so; every rank then raises SequenceError naming it and exits
+    with a non-zero code within the timeout — nobody returns normally, nobody waits in a collective (before round 6 only
+    rank 0 noticed an overflow, and a raising rank left the others in the gather until the backend's timeout)."""
+    import subprocess
+    import time
+    world, port = 4, _free_port()
+    worker = os.path.join(ROOT, 'tests', '_failing_rank_worker.py')
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, worker, mode, str(r), str(world), str(port)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, universal_newlines=True, env=env) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=max(5.0, 150.0 - (time.time() - t0))))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    codes = [p.returncode for p in procs]
+    if culprit is None:
+        assert codes == [0] * world, (codes, [o[1][-500:] for o in outs])
+        return
+    assert codes == [3] * world, (codes, [o[1][-500:] for o in outs])
+    for r, (_, err) in enumerate(outs):
+        assert 'SequenceError' in err and 'rank(s) [%d]' % culprit in err, (r, err[-500:])
+    if mode == 'raise':
+        assert all('NativeError' in err and 'injected' in err for _, err in outs)
+    else:
+        assert all('did not fit' in err for _, err in outs)
+
+
+def test_host_thread_share_follows_the_ranks_on_the_node():
+    """_native.host_threads (pure Python) and amt_host_threads (the library's pools) apply the same rule: the cores this process
+    may run on divided by LOCAL_WORLD_SIZE, at least one, never more than asked for."""
+    import ctypes as C
+    import subprocess
+    code = ("import ctypes as C, json, os, sys; sys.path.insert(0, %r); from auromat_amd import _native as N; "
+            "c, r = C.c_int(), C.c_int(); n = N.lib().amt_host_threads(16, C.byref(c), C.byref(r)); "
+            "print(json.dumps([n, c.value, r.value, N.host_threads(16), N.host_threads_report()]))" % ROOT)
+    import json
+    cores = len(os.sched_getaffinity(0))
+    for ranks in (None, 2, 8, 1000):
+        env = {k: v for k, v in os.environ.items() if k not in ('LOCAL_WORLD_SIZE', 'AMT_LOCAL_RANKS')}
+        if ranks:
+            env['LOCAL_WORLD_SIZE'] = str(ranks)
+        out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, env=env, universal_newlines=True, check=True).stdout
+        n, c, r, py, rep = json.loads(out.strip().splitlines()[-1])
+        want = max(1, min(16, cores // (ranks or 1)))
+        assert (n, c, r, py) == (want, cores, ranks or 1, want), (ranks, n, c, r, py)
+        assert rep['copy_threads'] <= max(1, (rep['share'] + 1) // 2) and rep['triangulator_threads'] == want

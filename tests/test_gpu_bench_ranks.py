@@ -83,3 +83,20 @@ def test_n_rank_line_carries_the_upload_variant():
     # through the library's frame loop, and only the rows of an image that can be binned cross the link
     assert up['frame_loop'].startswith('library') and up['repeats'] == 7
     assert 0 < up['uploaded_bytes_per_frame'] < 0.8 * up['image_bytes_per_frame']
+
+
+def test_a_rank_that_fails_in_the_timed_region_ends_the_run():
+    """One of two ranks' pipelines raises in the middle of a timed region (AMT_BENCH_FAIL_RANK: a frame dated beyond the IGRF table,
+    refused by the library's frame loop).  The rank still takes part in the gather and in the closing fence; there every rank
+    learns of it: the run ends with a non-zero code and no result line, well inside the collectives' timeout."""
+    import time
+    world, steps = 2, 6
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(AMT_BENCH_BACKEND='gloo', AMT_BENCH_ONE_GPU='1', AMT_BENCH_FAIL_RANK='1', AMT_DIST_TIMEOUT_S='120')
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', str(steps), '--warmup', '2',
+                          '--cpu-rows', '0', '--no-variants'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True, timeout=300)
+    assert res.returncode != 0 and time.time() - t0 < 110
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert 'IGRF' in res.stderr and 'SequenceError' in res.stderr, res.stderr[-3000:]
