@@ -170,8 +170,9 @@ int amt_grid_layout(double lat_px_per_deg, double lon_px_per_deg, double lat_min
 int amt_plate_carree_resolution(double lat_south, double lon_west, double lat_north, double lon_east, double arcsec_per_px,
                                 double* lat_px_per_deg, double* lon_px_per_deg) {
     if (lat_px_per_deg == nullptr || lon_px_per_deg == nullptr) return AMT_EINVAL;
-    return amt_gl::plate_carree_resolution(lat_south, lon_west, lat_north, lon_east, arcsec_per_px, lat_px_per_deg,
-                                           lon_px_per_deg) ? AMT_OK : AMT_EINVAL;
+    if (!amt_gl::plate_carree_resolution(lat_south, lon_west, lat_north, lon_east, arcsec_per_px, lat_px_per_deg, lon_px_per_deg))
+        return AMT_EINVAL;
+    return *lon_px_per_deg > 0 ? AMT_OK : AMT_EDOMAIN;
 }
 
 int amt_pipe_create(amt_ctx* ctx, amt_pipe** out_pipe) {

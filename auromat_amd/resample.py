@@ -50,8 +50,10 @@ def plateCarreeResolution(boundingBox, arcsecPerPx):
     lat_ppd, lon_ppd = C.c_double(), C.c_double()
     rc = lib().amt_plate_carree_resolution(float(boundingBox.latSouth), float(boundingBox.lonWest), float(boundingBox.latNorth),
                                            float(boundingBox.lonEast), float(arcsecPerPx), C.byref(lat_ppd), C.byref(lon_ppd))
-    if rc != 0:
+    if rc != 0 and rc != -5:
         return plateCarreeResolution_py(boundingBox, arcsecPerPx)      # (raises what the Python restatement raises)
+    # (-5 = AMT_EDOMAIN: a box that goes all the way round — the reference's function returns (latPxPerDeg, 0) for it and fails
+    # later, resample.py:226-227; the callers here check the longitude resolution before they lay out a grid)
     return lat_ppd.value, lon_ppd.value
 
 

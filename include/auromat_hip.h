@@ -44,6 +44,8 @@ extern "C" {
 #define AMT_EHIP (-2)     /* a HIP runtime call failed; see amt_last_error */
 #define AMT_ENOMEM (-3)
 #define AMT_EEMPTY (-4)   /* operation would leave no valid pixel (mapping.py:858-859 -> ValueError) */
+#define AMT_EDOMAIN (-5)  /* the result exists but nothing can be built on it (amt_plate_carree_resolution: no longitude resolution
+                           * for a box that goes all the way round; ABI v6) */
 
 typedef struct amt_ctx amt_ctx;
 
@@ -707,9 +709,10 @@ int amt_pipe_launch_box_many(amt_pipe* const* pipes, int32_t n, const amt_frame_
  * (latPxPerDeg, lonPxPerDeg); geodesic.angularDistance (geographiclib's a12 in the reference) restated from Karney's
  * integral formulation for two points on one parallel.  Host arithmetic, no GPU.  A box wider than 180 deg is measured the
  * shorter way round, as the reference does (min(lons, 360 - lons)); for a box that goes all the way around (a pole in view)
- * that gives AMT_OK with *lon_px_per_deg = 0, which no grid can be laid out for — the caller checks (the reference fails
- * downstream on `assert nLon > 1`, resample.py:226-227).  AMT_EINVAL when the resolution is not positive or the box has no
- * width. */
+ * that gives *lon_px_per_deg = 0, which no grid can be laid out for: the outputs are filled as the reference's function
+ * returns them — (3600 / arcsec_per_px, 0) — and the status is AMT_EDOMAIN (ABI v6; AMT_OK before), so that a host that checks
+ * the status cannot lay out a grid without columns (the reference fails downstream on `assert nLon > 1`,
+ * resample.py:226-227).  AMT_EINVAL when the resolution is not positive or the box has no width. */
 int amt_plate_carree_resolution(double lat_south, double lon_west, double lat_north, double lon_east, double arcsec_per_px,
                                 double* lat_px_per_deg, double* lon_px_per_deg);
 int amt_pipe_wait(amt_pipe* pipe, amt_pipe_result* result);

@@ -29,6 +29,8 @@ Fixtures
   real_sequence_iss029.npz  the ten consecutive real headers seq/ISS029-E-8493..8502.wcs with synthetic images at full
                         size -> the same flow, per-frame output grids (headers: tests/golden/resources/seq/)
   real_frame_iss030_{exact,sm}.npz  the same frame with exact centres / on the MLat-MLT grid
+  real_frame_*_arcsec100.npz  both of the reference's test frames, geographic and MLat/MLT grid, through the real _resample at
+                        the px/deg pair this repository's plateCarreeResolution gives for arcsecPerPx=100 (real_frame_arcsec)
   real_frame_iss030.npz the reference's own ISS030-E-102170_dc.jpg + .wcs at full size -> maskedByElevation(10) ->
                         _resample(pxPerDeg=10): complete output (the two data files: tests/golden/resources/)
 """
@@ -1108,6 +1110,66 @@ def real_frame_south():
                          110, merged, (10, 10))
     print('sm', case['bbox'], bool(case['contains_discontinuity']), case['out_data'].shape, flush=True)
     _finish_real(case, 'real_frame_iss029_sm.npz', mm, t, cam)
+
+
+def real_frame_arcsec():
+    """real_frame_{iss030,iss029}{,_sm}_arcsec100.npz: the reference's OWN call form, `resample(mapping, arcsecPerPx=100)`
+    (test/mapping_test.py:24-42; `auromat-convert --resolution 100`, cli/convert.py:176-185), on the two frames its mapping test
+    runs, on the geographic and on the (MLat, SM longitude) grid — as far as the real reference can run here: its
+    plateCarreeResolution (resample.py:36-61) calls geographiclib's a12, which is absent, so the (latPxPerDeg, lonPxPerDeg) pair
+    is the one THIS repository's restatement yields for the mapping's bounding box (auromat_amd.resample.plateCarreeResolution_py:
+    Karney's integrals; the a12 it computed is stored beside Vincenty's value for the same two points), and with that pair the
+    REAL `_resample` lays out the grid and bins.  What the fixtures pin: the grid layout and the binned means at a resolution
+    that is NOT a whole number of pixels per degree and differs between the two axes — the box-first plan's whole path behind
+    the a12 value."""
+    from PIL import Image
+    from auromat_amd.coordinates import geodesic as G
+    from auromat_amd.fits import readHeader
+    from auromat_amd.mapping.spacecraft import getShiftedSpacecraftPosition, getSpacecraftPosition
+    from auromat_amd.resample import plateCarreeResolution_py
+    for tag, stem in (('iss030', 'ISS030-E-102170_dc'), ('iss029', 'ISS029-E-8492')):
+        hdr = readHeader(RES + stem + '.wcs')
+        img = np.asarray(Image.open(RES + stem + '.jpg'))
+        if tag == 'iss030':
+            cam, t, _ = getShiftedSpacecraftPosition(hdr)
+        else:
+            cam, t = getSpacecraftPosition(hdr)
+        m = ArraySpacecraftMapping(hdr, 110, img, cam, t, stem, fastCenterCalculation=True)
+        mm = m.maskedByElevation(10)
+        merged = np.dstack((mm.img.astype(np.float64).filled(np.nan), mm.elevation.filled(np.nan)))
+        mask, cmask = ma.getmaskarray(mm.lats), ma.getmaskarray(mm.latsCenter)
+        mlat, mlt = mm.mLatMlt
+        mlat_c, mlt_c = mm.mLatMltCenter
+        for grid in ('geo', 'sm'):
+            if grid == 'geo':
+                la, lo = mm.lats, mm.lons
+                lac, loc = mm.latsCenter.filled(np.nan), mm.lonsCenter.filled(np.nan)
+            else:
+                la, lo = ma.masked_array(mlat.data, mask), ma.masked_array(T.mltToSmLon(mlt.data), mask)
+                lac, loc = np.where(cmask, np.nan, mlat_c.data), np.where(cmask, np.nan, T.mltToSmLon(mlt_c.data))
+            bb = _bbox_from(la, lo)
+            ppd = plateCarreeResolution_py(bb, 100.0)
+            lons = bb.lonEast + 360 - bb.lonWest if bb.lonWest > bb.lonEast else bb.lonEast - bb.lonWest
+            lat_mid = (bb.latNorth + bb.latSouth) / 2
+            a12 = G.angularDistanceOnParallel(lat_mid, min(lons, 360 - lons))
+            a12_v = G._inverse(lat_mid, 0.0, lat_mid, min(lons, 360 - lons))[3]
+            assert abs(a12 - a12_v) < 3e-10 * a12, (a12, a12_v)
+            case = _run_resample(la, lo, lac, loc, 110, merged, ppd)
+            name = 'real_frame_%s%s_arcsec100.npz' % (tag, '' if grid == 'geo' else '_sm')
+            print(name, case['bbox'], bool(case['contains_discontinuity']), ppd, case['out_data'].shape, flush=True)
+            rimg, relev = np.dsplit(case['out_data'], [-1])
+            with np.errstate(invalid='ignore'):
+                rimg = np.round(rimg)
+            rimg = np.require(ma.masked_invalid(rimg, copy=False), np.uint8)
+            del case['outline']
+            out = dict(case)
+            out.update(out_img=rimg.data, out_img_mask=ma.getmaskarray(rimg))
+            out.update(time_arrays(t))
+            out.update(cam=cam, altitude=np.float64(110), min_elev=np.float64(10), ppd=np.array(ppd, dtype=np.float64),
+                       arcsec_per_px=np.float64(100), a12_karney_integrals=np.float64(a12), a12_vincenty=np.float64(a12_v),
+                       a12_lat=np.float64(lat_mid), a12_dlon=np.float64(min(lons, 360 - lons)),
+                       n_valid=np.int64((~cmask).sum()))
+            save(name, **out)
 
 
 def real_sequences_more():

@@ -4,8 +4,7 @@ TEST INFRASTRUCTURE — container-only loader for the *real* reference.
 Imports esa/auromat from /root/reference (read-only, never copied) on top of a
 few in-memory stand-ins for third-party packages that are absent from this
 image (astropy, geographiclib, scikit-image, numpy.core.umath_tests, ...).
-Only ``oracle/make_golden.py`` and ``oracle/check_oracle_vs_reference.py`` use
-it, and only in the build container: /root/reference does not exist on the GPU
+Only ``oracle/make_golden.py`` uses it, and only in the build container: /root/reference does not exist on the GPU
 box, so nothing under tests/, bench.py or the product may import this file.
 
 What the stand-ins replace and why the arithmetic is unaffected:

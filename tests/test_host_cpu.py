@@ -251,6 +251,15 @@ def test_native_plate_carree_resolution_equals_the_python_restatement(lib):
         assert round(got[1] * 360 + 1) == round(want[1] * 360 + 1)
     assert plateCarreeResolution(BoundingBox(-5, 170, 5, -170), 200) == plateCarreeResolution(BoundingBox(-5, -10, 5, 10), 200)
     assert plateCarreeResolution(BoundingBox(60, -180, 90, 180), 100) == plateCarreeResolution_py(BoundingBox(60, -180, 90, 180), 100) == (36.0, 0.0)
+    # the C ABI's error behaviour: a distinct status for the all-round box (a host that checks it cannot lay out a grid without
+    # columns), the reference's values in the outputs; AMT_EINVAL for a resolution that is not positive and for NULL outputs
+    import ctypes as C
+    la, lo = C.c_double(-1), C.c_double(-1)
+    assert lib.amt_plate_carree_resolution(60.0, -180.0, 90.0, 180.0, 100.0, C.byref(la), C.byref(lo)) == -5      # AMT_EDOMAIN
+    assert (la.value, lo.value) == (36.0, 0.0)
+    assert lib.amt_plate_carree_resolution(40.0, -10.0, 50.0, 10.0, 100.0, C.byref(la), C.byref(lo)) == 0 and lo.value > 0
+    assert lib.amt_plate_carree_resolution(40.0, -10.0, 50.0, 10.0, 0.0, C.byref(la), C.byref(lo)) == -1
+    assert lib.amt_plate_carree_resolution(40.0, -10.0, 50.0, 10.0, 100.0, None, C.byref(lo)) == -1
 
 
 def test_public_header_is_plain_c():
