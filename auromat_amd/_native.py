@@ -194,12 +194,6 @@ _SIGNATURES = {
     'amt_nearest_frame': ([_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _D, C.POINTER(Axis), C.POINTER(Axis), _I, _P, _P, _P,
                            _P], _I),
     'amt_nearest_gather': ([_P, _P, _L, _P, C.c_int32, C.c_int32, _P, _P, _P, _P], _I),
-    'amt_linear_gather': ([_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _D, _I, _P, _P, _P, C.c_int32,
-                           C.c_int32, _P, _P, _P, _P, _P], _I),
-    'amt_cubic_gradients': ([_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _D, _I, _P, C.c_int32, C.c_int32, _D, C.c_int32, _P,
-                             C.POINTER(C.c_int32)], _I),
-    'amt_cubic_gather': ([_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _D, _I, _P, _P, _P, C.c_int32,
-                          C.c_int32, _P, _P, _P, _P, _P, _P], _I),
     'amt_points_in_polygon': ([_P, _P, _P, _L, _P, C.c_int32, _P], _I),
     'amt_grid_layout': ([_D, _D, _D, _D, _D, _D, C.POINTER(Grid)], _I),
     'amt_pipe_create': ([_P, c_void_pp], _I),

@@ -850,14 +850,24 @@ struct amt_delaunay {
 
 namespace {
 // (a handle is const to its readers; the lists are its cache.  One lock for all handles: the build is what takes the time)
-void ensure_vertex_lists(const amt_delaunay* d) {
+// -> AMT_OK, or AMT_ENOMEM / AMT_EHIP when the lists could not be made (no memory for ~140 MB of lists at full frame size, no
+// thread to be had): nothing escapes into the C ABI, and `lists_made` stays false so that a later call tries again
+int ensure_vertex_lists(const amt_delaunay* d) {
     static std::mutex lock;
     std::lock_guard<std::mutex> guard(lock);
     amt_delaunay* m = const_cast<amt_delaunay*>(d);
-    if (!m->lists_made) {
+    if (m->lists_made) return AMT_OK;
+    try {
         m->build_vertex_lists();
         m->lists_made = true;
+    } catch (const std::bad_alloc&) {
+        m->indptr.clear(), m->indices.clear();
+        return AMT_ENOMEM;
+    } catch (...) {
+        m->indptr.clear(), m->indices.clear();
+        return AMT_EHIP;
     }
+    return AMT_OK;
 }
 }  // namespace
 
@@ -944,7 +954,7 @@ int amt_delaunay_sizes(const amt_delaunay* d, int64_t* n_triangles, int64_t* n_n
     if (d == nullptr) return AMT_EINVAL;
     if (n_triangles) *n_triangles = (int64_t)(d->tri.size() / 3);
     if (n_neighbours) {
-        ensure_vertex_lists(d);
+        if (int rc = ensure_vertex_lists(d)) return rc;
         *n_neighbours = (int64_t)d->indices.size();
     }
     if (n_duplicates) *n_duplicates = d->n_dup;
@@ -967,7 +977,7 @@ int amt_delaunay_triangles(const amt_delaunay* d, int32_t* simplices, int32_t* n
 
 int amt_delaunay_vertex_neighbours(const amt_delaunay* d, int64_t* indptr, int32_t* indices) {
     if (d == nullptr || indptr == nullptr || indices == nullptr) return AMT_EINVAL;
-    ensure_vertex_lists(d);
+    if (int rc = ensure_vertex_lists(d)) return rc;
     std::memcpy(indptr, d->indptr.data(), d->indptr.size() * sizeof(int64_t));
     std::memcpy(indices, d->indices.data(), d->indices.size() * sizeof(int32_t));
     return AMT_OK;
@@ -984,6 +994,7 @@ int amt_delaunay_locate(const amt_delaunay* d, const double* targets, int64_t m,
     // multiples of 1024 targets whatever the number of threads)
     const int64_t piece = 1024, pieces = (m + piece - 1) / piece;
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(d->n_threads, pieces), 16));
+    try {
     on_threads(T, [&](int part) {
     for (int64_t pc = part; pc < pieces; pc += T) {
     int t = 0;
@@ -1027,6 +1038,11 @@ int amt_delaunay_locate(const amt_delaunay* d, const double* targets, int64_t m,
     }
     }
     });
+    } catch (const std::bad_alloc&) {
+        return AMT_ENOMEM;          // (nothing of it may leave through the C ABI)
+    } catch (...) {
+        return AMT_EHIP;
+    }
     return AMT_OK;
 }
 

@@ -227,362 +227,13 @@ __global__ void k_nn_gather(const long long* __restrict__ index, int64_t total, 
     }
 }
 
-// ---- method='linear' (reference resample.py:323-326: scipy.interpolate.griddata(method='linear'), i.e. barycentric
-// interpolation on a Delaunay triangulation of the valid pixel centres in the (lat, lon) plane) ----------------------
-// The pixel centres are a smoothly mapped regular grid, so their Delaunay triangulation is, locally, that of a lattice:
-// the cells of the REDUCED basis (Gauss reduction of the two grid steps at the pixel centre nearest to the grid centre,
-// amt_nearest_frame) cut along the diagonal the empty-circle criterion picks; a cell with three valid centres is that
-// triangle.  Where a cell is close to cocircular Qhull's triangulation takes either diagonal: values then differ
-// from scipy's within the spread of the two diagonal interpolants of the cell, which the kernel reports beside the
-// value (`alt`); tests/test_gpu_nearest.py pins the rule.
-struct lin_args {
-    const double* lat_c;
-    const double* lon_c;
-    const double* elev;
-    const uint8_t* center_mask;
-    int height, width;
-    double min_elev;
-    int lon_wrap, nchan;
-};
-
-__device__ __forceinline__ bool lin_valid(const lin_args& A, int i, int j, double* x, double* y) {
-    if (i < 0 || j < 0 || i >= A.height || j >= A.width) return false;
-    const int64_t p = (int64_t)i * A.width + j;
-    const double la = A.lat_c[p];
-    double lo = A.lon_c[p];
-    if (!(la == la) || !(lo == lo)) return false;
-    if (A.center_mask != nullptr && A.center_mask[p]) return false;
-    if (A.elev != nullptr && !(A.elev[p] >= A.min_elev)) return false;
-    if (A.lon_wrap) lo = wrap180_shifted(lo);
-    *x = la, *y = lo;
-    return true;
-}
-
-// barycentric coordinates of (px, py) in triangle (x0,y0),(x1,y1),(x2,y2); false for a degenerate triangle
-__device__ __forceinline__ bool lin_bary(double x0, double y0, double x1, double y1, double x2, double y2, double px, double py,
-                                         double* w) {
-    const double d = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
-    if (!(fabs(d) > 0)) return false;
-    w[1] = ((px - x0) * (y2 - y0) - (x2 - x0) * (py - y0)) / d;
-    w[2] = ((x1 - x0) * (py - y0) - (px - x0) * (y1 - y0)) / d;
-    w[0] = 1.0 - w[1] - w[2];
-    return true;
-}
-
-__device__ __forceinline__ bool lin_inside(const double* w) {
-    constexpr double eps = 1e-12;
-    return w[0] >= -eps && w[1] >= -eps && w[2] >= -eps;
-}
-
-// is D strictly inside the circumcircle of A, B, C (any orientation)?
-__device__ __forceinline__ bool lin_incircle(double ax, double ay, double bx, double by, double cx, double cy, double dx, double dy) {
-    const double adx = ax - dx, ady = ay - dy, bdx = bx - dx, bdy = by - dy, cdx = cx - dx, cdy = cy - dy;
-    const double ad = adx * adx + ady * ady, bd = bdx * bdx + bdy * bdy, cd = cdx * cdx + cdy * cdy;
-    const double det = adx * (bdy * cd - bd * cdy) - ady * (bdx * cd - bd * cdx) + ad * (bdx * cdy - bdy * cdx);
-    const double orient = (bx - ax) * (cy - ay) - (cx - ax) * (by - ay);
-    return orient > 0 ? det > 0 : det < 0;
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_linear_gather(lin_args A, const long long* __restrict__ index, int ny, int nx,
-                                                          const double* __restrict__ tlat, const double* __restrict__ tlon,
-                                                          const T* __restrict__ img, double* __restrict__ mean,
-                                                          T* __restrict__ out_img, uint8_t* __restrict__ out_mask,
-                                                          double* __restrict__ alt, long long* __restrict__ out_tri) {
-    constexpr double kNaN = __builtin_nan("");
-    const int nch = A.nchan;
-    AMT_GRID_STRIDE(t, (int64_t)ny * nx) {
-        const long long near = index[t];
-        const int ty = (int)(t / nx), tx = (int)(t - (int64_t)ty * nx);
-        const double px = tlat[ty], py = tlon[tx];
-        long long tri[3] = {-1, -1, -1}, tri2[3] = {-1, -1, -1};
-        double w[3] = {0, 0, 0}, w2[3] = {0, 0, 0};
-        bool found = false, found2 = false;
-        if (near >= 0) {
-            const int pi = (int)(near / A.width), pj = (int)(near - (long long)pi * A.width);
-            // The Delaunay triangulation of a smoothly mapped pixel grid joins neighbours of the REDUCED lattice basis, not
-            // of the index grid: seen obliquely, a pixel's footprint is several times longer than wide in the (lat, lon)
-            // plane, and the compact triangles join pixels like (i, j) and (i + 1, j + 3).  So: the local basis (one step
-            // in j, one step in i) at the nearest centre, Gauss-reduced (integer combinations with the shortest vectors),
-            // and the cells of THAT lattice around the grid centre, each cut along the diagonal the empty-circle test picks.
-            double x0, y0, xa, ya, xb, yb;
-            int uj = 1, ui = 0, vj = 0, vi = 1;                 // index steps of the two basis vectors
-            bool have = lin_valid(A, pi, pj, &x0, &y0);
-            double ux = 0, uy = 0, vx = 0, vy = 0;
-            if (have) {
-                if (lin_valid(A, pi, pj + 1, &xa, &ya)) ux = xa - x0, uy = ya - y0;
-                else if (lin_valid(A, pi, pj - 1, &xa, &ya)) ux = x0 - xa, uy = y0 - ya;
-                else have = false;
-                if (lin_valid(A, pi + 1, pj, &xb, &yb)) vx = xb - x0, vy = yb - y0;
-                else if (lin_valid(A, pi - 1, pj, &xb, &yb)) vx = x0 - xb, vy = y0 - yb;
-                else have = false;
-            }
-            if (have) {
-                for (int it = 0; it < 16; ++it) {
-                    double uu = ux * ux + uy * uy, vv = vx * vx + vy * vy;
-                    if (uu > vv) {
-                        double tx_ = ux; ux = vx; vx = tx_;
-                        double ty_ = uy; uy = vy; vy = ty_;
-                        int tj = uj; uj = vj; vj = tj;
-                        int ti = ui; ui = vi; vi = ti;
-                        uu = vv;
-                    }
-                    if (!(uu > 0)) break;
-                    const double m = rint((ux * vx + uy * vy) / uu);
-                    if (m == 0) break;
-                    vx -= m * ux, vy -= m * uy;
-                    vj -= (int)m * uj, vi -= (int)m * ui;
-                }
-                const double det = ux * vy - uy * vx;
-                have = fabs(det) > 0;
-                if (have) {
-                    // lattice coordinates of the grid centre relative to the nearest pixel centre
-                    const double al = ((px - x0) * vy - (py - y0) * vx) / det, be = (ux * (py - y0) - uy * (px - x0)) / det;
-                    const int a0 = (int)floor(al), b0 = (int)floor(be);
-                    for (int ring = 0; ring < 2 && !found; ++ring)
-                        for (int da = -ring; da <= ring && !found; ++da)
-                            for (int db = -ring; db <= ring && !found; ++db) {
-                                if (ring == 1 && da == 0 && db == 0) continue;
-                                const int a = a0 + da, b = b0 + db;
-                                double x[4], y[4];
-                                // corners in cyclic order: (a, b), (a+1, b), (a+1, b+1), (a, b+1) of the reduced lattice
-                                const int ca[4] = {a, a + 1, a + 1, a}, cb[4] = {b, b, b + 1, b + 1};
-                                int ci[4], cj[4];
-                                bool v[4];
-                                int nv = 0;
-                                for (int k = 0; k < 4; ++k) {
-                                    ci[k] = pi + ca[k] * ui + cb[k] * vi;
-                                    cj[k] = pj + ca[k] * uj + cb[k] * vj;
-                                    v[k] = lin_valid(A, ci[k], cj[k], &x[k], &y[k]);
-                                    nv += v[k] ? 1 : 0;
-                                }
-                                if (nv < 3) continue;
-                                auto id = [&](int k) { return (long long)ci[k] * A.width + cj[k]; };
-                                auto try_tri = [&](int k0, int k1, int k2, double* ww, long long* tt) {
-                                    if (!lin_bary(x[k0], y[k0], x[k1], y[k1], x[k2], y[k2], px, py, ww) || !lin_inside(ww)) return false;
-                                    tt[0] = id(k0), tt[1] = id(k1), tt[2] = id(k2);
-                                    return true;
-                                };
-                                if (nv == 3) {
-                                    int k[3], m = 0;
-                                    for (int q = 0; q < 4; ++q)
-                                        if (v[q]) k[m++] = q;
-                                    found = try_tri(k[0], k[1], k[2], w, tri);
-                                    continue;
-                                }
-                                // diagonal 0-2 unless corner 3 lies inside the circle through 0, 1, 2 (then 1-3)
-                                const bool flip = lin_incircle(x[0], y[0], x[1], y[1], x[2], y[2], x[3], y[3]);
-                                if (!flip) {
-                                    found = try_tri(0, 1, 2, w, tri) || try_tri(0, 2, 3, w, tri);
-                                    if (found) found2 = try_tri(0, 1, 3, w2, tri2) || try_tri(1, 2, 3, w2, tri2);
-                                } else {
-                                    found = try_tri(0, 1, 3, w, tri) || try_tri(1, 2, 3, w, tri);
-                                    if (found) found2 = try_tri(0, 1, 2, w2, tri2) || try_tri(0, 2, 3, w2, tri2);
-                                }
-                            }
-                }
-            }
-        }
-        for (int c = 0; c <= nch; ++c) {
-            double val = kNaN, val2 = kNaN;
-            if (found) {
-                val = 0;
-                for (int k = 0; k < 3; ++k)
-                    val += w[k] * (c < nch ? (double)img[tri[k] * nch + c] : (A.elev ? A.elev[tri[k]] : kNaN));
-                val2 = val;
-                if (found2) {
-                    val2 = 0;
-                    for (int k = 0; k < 3; ++k)
-                        val2 += w2[k] * (c < nch ? (double)img[tri2[k] * nch + c] : (A.elev ? A.elev[tri2[k]] : kNaN));
-                }
-            }
-            if (mean) mean[t * (nch + 1) + c] = val;
-            if (alt) alt[t * (nch + 1) + c] = val2;
-            if (c < nch && out_img) out_img[t * nch + c] = found ? (T)rint(val) : (T)0;      // np.round: half to even
-        }
-        if (out_mask) out_mask[t] = found ? 0 : 1;
-        if (out_tri)
-            for (int k = 0; k < 3; ++k) out_tri[t * 3 + k] = tri[k];
-    }
-}
-
-// ---- method='cubic' (reference resample.py:323-326: scipy griddata(method='cubic') = CloughTocher2DInterpolator) --------
-// The piecewise cubic, C1 Clough-Tocher interpolant on the same triangulation as 'linear', with the vertex gradients of
-// scipy's global estimator: the gradient at every data point minimises the curvature energy of the cubic Hermite curves
-// along its triangulation edges (Nielson 1983; Renka & Cline 1984), a 2 x 2 system per point coupled to the neighbours'
-// gradients, which scipy relaxes point after point until the largest relative change drops below 1e-6.  Here: one Jacobi
-// sweep per launch over all valid pixels (the 2 x 2 blocks dominate the coupling 2 : 1, so Jacobi converges too), the
-// neighbours of a pixel taken from the reduced lattice around it — the four axis neighbours and, for each of the four
-// cells that meet at the pixel, the partner on the cell's Delaunay diagonal when that diagonal passes through the pixel.
-// The element itself (12 boundary + 7 interior Bezier ordinates per triangle; the three free parameters fixed by making the
-// derivative towards the neighbouring triangle's centroid linear along each edge, which is what makes scipy's element
-// affine invariant) is restated from scipy 1.15's interpnd module and checked against it to rounding on scipy's own
-// triangulation (oracle/ref_numpy.py: clough_tocher_*, tests/test_oracle_golden.py).
-
-struct lat_basis {
-    double x0, y0, ux, uy, vx, vy;
-    int uj, ui, vj, vi;          // index steps of the two reduced basis vectors
-};
-
-// the local lattice basis at pixel (pi, pj) — one step in j, one step in i —, Gauss-reduced (see k_linear_gather)
-__device__ bool lattice_basis(const lin_args& A, int pi, int pj, lat_basis* B) {
-    double xa, ya, xb, yb;
-    if (!lin_valid(A, pi, pj, &B->x0, &B->y0)) return false;
-    double ux, uy, vx, vy;
-    if (lin_valid(A, pi, pj + 1, &xa, &ya)) ux = xa - B->x0, uy = ya - B->y0;
-    else if (lin_valid(A, pi, pj - 1, &xa, &ya)) ux = B->x0 - xa, uy = B->y0 - ya;
-    else return false;
-    if (lin_valid(A, pi + 1, pj, &xb, &yb)) vx = xb - B->x0, vy = yb - B->y0;
-    else if (lin_valid(A, pi - 1, pj, &xb, &yb)) vx = B->x0 - xb, vy = B->y0 - yb;
-    else return false;
-    int uj = 1, ui = 0, vj = 0, vi = 1;
-    for (int it = 0; it < 16; ++it) {
-        double uu = ux * ux + uy * uy, vv = vx * vx + vy * vy;
-        if (uu > vv) {
-            double t = ux; ux = vx; vx = t;
-            t = uy; uy = vy; vy = t;
-            int k = uj; uj = vj; vj = k;
-            k = ui; ui = vi; vi = k;
-            uu = vv;
-        }
-        if (!(uu > 0)) break;
-        const double m = rint((ux * vx + uy * vy) / uu);
-        if (m == 0) break;
-        vx -= m * ux, vy -= m * uy;
-        vj -= (int)m * uj, vi -= (int)m * ui;
-    }
-    if (!(fabs(ux * vy - uy * vx) > 0)) return false;
-    B->ux = ux, B->uy = uy, B->vx = vx, B->vy = vy;
-    B->uj = uj, B->ui = ui, B->vj = vj, B->vi = vi;
-    return true;
-}
-
-// cell (a, b) of the reduced lattice around pixel (pi, pj): corners in cyclic order (a, b), (a+1, b), (a+1, b+1), (a, b+1);
-// flip: cut along 1-3 instead of 0-2 (corner 3 inside the circle through 0, 1, 2), defined for 4 valid corners
-struct lat_cell {
-    int ci[4], cj[4];
-    double x[4], y[4];
-    bool v[4];
-    int nv;
-    bool flip;
-};
-
-__device__ void lattice_cell(const lin_args& A, int pi, int pj, const lat_basis& B, int a, int b, lat_cell* c) {
-    const int ca[4] = {a, a + 1, a + 1, a}, cb[4] = {b, b, b + 1, b + 1};
-    c->nv = 0;
-    for (int k = 0; k < 4; ++k) {
-        c->ci[k] = pi + ca[k] * B.ui + cb[k] * B.vi;
-        c->cj[k] = pj + ca[k] * B.uj + cb[k] * B.vj;
-        c->x[k] = c->y[k] = 0;
-        c->v[k] = lin_valid(A, c->ci[k], c->cj[k], &c->x[k], &c->y[k]);
-        c->nv += c->v[k] ? 1 : 0;
-    }
-    c->flip = c->nv == 4 && lin_incircle(c->x[0], c->y[0], c->x[1], c->y[1], c->x[2], c->y[2], c->x[3], c->y[3]);
-}
-
-// the corner of cell c that completes the triangle on the cell's side s (corners s, s+1); -1: the cell has no such triangle
-__device__ int lattice_third(const lat_cell& c, int s) {
-    if (c.nv == 4) {
-        const int plain[4] = {2, 0, 0, 2}, flipped[4] = {3, 3, 1, 1};
-        return c.flip ? flipped[s] : plain[s];
-    }
-    if (c.nv == 3 && c.v[s] && c.v[(s + 1) & 3]) return c.v[(s + 2) & 3] ? (s + 2) & 3 : (s + 3) & 3;
-    return -1;
-}
-
-constexpr int kCubicNb = 8;
-
-// neighbours of every pixel in the triangulation: flat pixel indices, -1 = none.  Slots: +u, -u, +v, -v, +u+v, -u-v, -u+v, +u-v
-__global__ __launch_bounds__(kBlock) void k_cubic_neighbours(lin_args A, int* __restrict__ nb) {
-    AMT_GRID_STRIDE(p, (int64_t)A.height * A.width) {
-        int out[kCubicNb];
-        for (int k = 0; k < kCubicNb; ++k) out[k] = -1;
-        const int i = (int)(p / A.width), j = (int)(p - (int64_t)i * A.width);
-        lat_basis B;
-        if (lattice_basis(A, i, j, &B)) {
-            lat_cell c00, cm0, cmm, c0m;
-            lattice_cell(A, i, j, B, 0, 0, &c00);        // the pixel is its corner 0
-            lattice_cell(A, i, j, B, -1, 0, &cm0);       // corner 1
-            lattice_cell(A, i, j, B, -1, -1, &cmm);      // corner 2
-            lattice_cell(A, i, j, B, 0, -1, &c0m);       // corner 3
-            auto id = [&](const lat_cell& c, int k) { return c.ci[k] * A.width + c.cj[k]; };
-            if (c00.v[1] && (c00.nv >= 3 || c0m.nv >= 3)) out[0] = id(c00, 1);
-            if (cm0.v[0] && (cm0.nv >= 3 || cmm.nv >= 3)) out[1] = id(cm0, 0);
-            if (c00.v[3] && (c00.nv >= 3 || cm0.nv >= 3)) out[2] = id(c00, 3);
-            if (c0m.v[0] && (c0m.nv >= 3 || cmm.nv >= 3)) out[3] = id(c0m, 0);
-            if (c00.v[2] && ((c00.nv == 4 && !c00.flip) || c00.nv == 3)) out[4] = id(c00, 2);
-            if (cmm.v[0] && ((cmm.nv == 4 && !cmm.flip) || cmm.nv == 3)) out[5] = id(cmm, 0);
-            if (cm0.v[3] && ((cm0.nv == 4 && cm0.flip) || cm0.nv == 3)) out[6] = id(cm0, 3);
-            if (c0m.v[1] && ((c0m.nv == 4 && c0m.flip) || c0m.nv == 3)) out[7] = id(c0m, 1);
-        }
-        for (int k = 0; k < kCubicNb; ++k) nb[p * kCubicNb + k] = out[k];
-    }
-}
-
-constexpr int kCubicMaxChan = 5;      // image channels + elevation
-
-template <typename T>
-__device__ __forceinline__ double cubic_value(const lin_args& A, const T* img, int64_t p, int c) {
-    return c < A.nchan ? (double)img[p * A.nchan + c] : A.elev[p];
-}
-
-// one Jacobi sweep of the gradient estimator (scipy interpnd: _estimate_gradients_2d_global): y_out from y_in; the largest
-// change, relative as scipy measures it, goes to *err (bit pattern of a non-negative double: ordered like an integer)
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_cubic_sweep(lin_args A, const int* __restrict__ nb, const T* __restrict__ img,
-                                                        const double* __restrict__ y_in, double* __restrict__ y_out,
-                                                        unsigned long long* __restrict__ err) {
-    const int nc = A.nchan + (A.elev != nullptr ? 1 : 0);
-    double worst = 0;
-    AMT_GRID_STRIDE(p, (int64_t)A.height * A.width) {
-        const int i = (int)(p / A.width), j = (int)(p - (int64_t)i * A.width);
-        double x1, y1;
-        double s0[kCubicMaxChan], s1[kCubicMaxChan], f1[kCubicMaxChan];
-        double q0 = 0, q1 = 0, q3 = 0;
-        for (int c = 0; c < nc; ++c) s0[c] = s1[c] = 0;
-        int used = 0;
-        if (lin_valid(A, i, j, &x1, &y1)) {
-            for (int c = 0; c < nc; ++c) f1[c] = cubic_value(A, img, p, c);
-            for (int k = 0; k < kCubicNb; ++k) {
-                const int q = nb[p * kCubicNb + k];
-                if (q < 0) continue;
-                double x2, y2;
-                const int qi = q / A.width, qj = q - qi * A.width;
-                if (!lin_valid(A, qi, qj, &x2, &y2)) continue;
-                ++used;
-                const double ex = x2 - x1, ey = y2 - y1;
-                const double l2 = ex * ex + ey * ey, l3 = l2 * sqrt(l2);
-                q0 += 4 * ex * ex / l3;
-                q1 += 4 * ex * ey / l3;
-                q3 += 4 * ey * ey / l3;
-                for (int c = 0; c < nc; ++c) {
-                    const double f2 = cubic_value(A, img, (int64_t)q, c);
-                    const double* g2 = y_in + ((int64_t)q * nc + c) * 2;
-                    const double df2 = -ex * g2[0] - ey * g2[1];
-                    const double t = (6 * (f1[c] - f2) - 2 * df2) / l3;
-                    s0[c] += t * ex;
-                    s1[c] += t * ey;
-                }
-            }
-        }
-        const double det = q0 * q3 - q1 * q1;
-        for (int c = 0; c < nc; ++c) {
-            double* g = y_out + (p * nc + c) * 2;
-            if (used < 2 || !(fabs(det) > 0)) {
-                g[0] = g[1] = 0;
-                continue;
-            }
-            const double r0 = (q3 * s0[c] - q1 * s1[c]) / det, r1 = (-q1 * s0[c] + q0 * s1[c]) / det;
-            const double* old = y_in + (p * nc + c) * 2;
-            double change = fmax(fabs(old[0] + r0), fabs(old[1] + r1));
-            change /= fmax(1.0, fmax(fabs(r0), fabs(r1)));
-            if (change == change) worst = fmax(worst, change);
-            g[0] = -r0, g[1] = -r1;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));
-    if ((threadIdx.x & 63) == 0 && worst > 0) atomicMax(err, (unsigned long long)__double_as_longlong(worst));
-}
+// ---- method='cubic' (reference resample.py:323-326: scipy griddata(method='cubic') = CloughTocher2DInterpolator): the element ----
+// (12 boundary + 7 interior Bezier ordinates per triangle; the three free parameters fixed by making the derivative towards the
+// neighbouring triangle's centroid linear along each edge, which is what makes scipy's element affine invariant; restated from
+// scipy 1.15's interpnd module and checked against it to rounding on scipy's own triangulation: oracle/ref_numpy.py
+// clough_tocher_*, tests/test_oracle_golden.py).  The lattice approximations of rounds 3-4 (k_linear_gather, k_cubic_sweep,
+// k_cubic_gather: the Gauss-reduced local lattice of the pixel grid instead of the triangulation) were retired in round 6: 'linear'
+// and 'cubic' run on the exact triangulation only (amt_delaunay_*, amt_cubic_gradients_csr, amt_cubic_eval below).
 
 // value of the Clough-Tocher element of the triangle (x, y)[0..2] at barycentric coordinates b; f: vertex values, d: vertex
 // gradients (dx, dy), n: whether edge k (opposite vertex k) has a neighbouring triangle, (cx, cy)[k] its centroid
@@ -623,138 +274,6 @@ __device__ double clough_tocher(const double* x, const double* y, const double* 
            3 * b1 * b4 * b4 * c1002 + b2 * b2 * b2 * c0300 + 3 * b2 * b2 * b3 * c0210 + 3 * b2 * b2 * b4 * c0201 +
            3 * b2 * b3 * b3 * c0120 + 6 * b2 * b3 * b4 * c0111 + 3 * b2 * b4 * b4 * c0102 + b3 * b3 * b3 * c0030 +
            3 * b3 * b3 * b4 * c0021 + 3 * b3 * b4 * b4 * c0012 + b4 * b4 * b4 * c0003;
-}
-
-// The triangle (corners k[0..2] of the cell `c` at lattice position (a, b) around pixel (pi, pj)) with everything the element
-// needs: for each edge the neighbouring triangle's centroid — across the cell's diagonal the cell's other triangle, across
-// a side the triangle of the adjacent cell on that side
-template <typename T>
-__device__ void cubic_in_triangle(const lin_args& A, int pi, int pj, const lat_basis& B, int a, int b, const lat_cell& c,
-                                  const int* k, const double* w, const T* img, const double* grad, double* out) {
-    double x[3], y[3], cx[3] = {0, 0, 0}, cy[3] = {0, 0, 0};
-    bool has[3];
-    int64_t pix[3];
-    for (int m = 0; m < 3; ++m) {
-        x[m] = c.x[k[m]], y[m] = c.y[k[m]];
-        pix[m] = (int64_t)c.ci[k[m]] * A.width + c.cj[k[m]];
-    }
-    for (int m = 0; m < 3; ++m) {
-        // edge opposite vertex m: corners p, q
-        const int p = k[(m + 1) % 3], q = k[(m + 2) % 3];
-        has[m] = false;
-        double tx = 0, ty = 0;
-        if (((p - q) & 3) == 2) {
-            // the cell's diagonal: the other triangle is the remaining corner's
-            if (c.nv == 4) {
-                const int r = 6 - k[0] - k[1] - k[2];
-                tx = c.x[r], ty = c.y[r];
-                has[m] = true;
-            }
-        } else {
-            const int s = ((p + 1) & 3) == q ? p : q;                 // side s: corners s, s+1
-            const int da[4] = {0, 1, 0, -1}, db[4] = {-1, 0, 1, 0};
-            lat_cell nbc;
-            lattice_cell(A, pi, pj, B, a + da[s], b + db[s], &nbc);
-            const int r = lattice_third(nbc, (s + 2) & 3);
-            if (r >= 0) {
-                tx = nbc.x[r], ty = nbc.y[r];
-                has[m] = true;
-            }
-        }
-        if (has[m]) {
-            cx[m] = (c.x[p] + c.x[q] + tx) / 3;
-            cy[m] = (c.y[p] + c.y[q] + ty) / 3;
-        }
-    }
-    const int nc = A.nchan + (A.elev != nullptr ? 1 : 0);
-    for (int ch = 0; ch < nc; ++ch) {
-        double f[3], d[3][2];
-        for (int m = 0; m < 3; ++m) {
-            f[m] = cubic_value(A, img, pix[m], ch);
-            d[m][0] = grad[(pix[m] * nc + ch) * 2];
-            d[m][1] = grad[(pix[m] * nc + ch) * 2 + 1];
-        }
-        out[ch] = clough_tocher(x, y, w, f, d, has, cx, cy);
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_cubic_gather(lin_args A, const long long* __restrict__ index, int ny, int nx,
-                                                         const double* __restrict__ tlat, const double* __restrict__ tlon,
-                                                         const T* __restrict__ img, const double* __restrict__ grad,
-                                                         double* __restrict__ mean, T* __restrict__ out_img,
-                                                         uint8_t* __restrict__ out_mask, double* __restrict__ alt,
-                                                         long long* __restrict__ out_tri) {
-    constexpr double kNaN = __builtin_nan("");
-    const int nch = A.nchan, nc = nch + (A.elev != nullptr ? 1 : 0);
-    AMT_GRID_STRIDE(t, (int64_t)ny * nx) {
-        const long long near = index[t];
-        const int ty = (int)(t / nx), tx = (int)(t - (int64_t)ty * nx);
-        const double px = tlat[ty], py = tlon[tx];
-        double val[kCubicMaxChan], val2[kCubicMaxChan];
-        long long tri[3] = {-1, -1, -1};
-        bool found = false, found2 = false;
-        if (near >= 0) {
-            const int pi = (int)(near / A.width), pj = (int)(near - (long long)pi * A.width);
-            lat_basis B;
-            if (lattice_basis(A, pi, pj, &B)) {
-                const double det = B.ux * B.vy - B.uy * B.vx;
-                const double al = ((px - B.x0) * B.vy - (py - B.y0) * B.vx) / det, be = (B.ux * (py - B.y0) - B.uy * (px - B.x0)) / det;
-                const int a0 = (int)floor(al), b0 = (int)floor(be);
-                for (int ring = 0; ring < 2 && !found; ++ring)
-                    for (int da = -ring; da <= ring && !found; ++da)
-                        for (int db = -ring; db <= ring && !found; ++db) {
-                            if (ring == 1 && da == 0 && db == 0) continue;
-                            const int a = a0 + da, b = b0 + db;
-                            lat_cell c;
-                            lattice_cell(A, pi, pj, B, a, b, &c);
-                            if (c.nv < 3) continue;
-                            int k[3], k2[3];
-                            double w[3], w2[3];
-                            auto try_tri = [&](int k0, int k1, int k2_, int* kk, double* ww) {
-                                if (!lin_bary(c.x[k0], c.y[k0], c.x[k1], c.y[k1], c.x[k2_], c.y[k2_], px, py, ww) || !lin_inside(ww)) return false;
-                                kk[0] = k0, kk[1] = k1, kk[2] = k2_;
-                                return true;
-                            };
-                            if (c.nv == 3) {
-                                int q[3], m = 0;
-                                for (int r = 0; r < 4; ++r)
-                                    if (c.v[r]) q[m++] = r;
-                                found = try_tri(q[0], q[1], q[2], k, w);
-                            } else if (!c.flip) {
-                                found = try_tri(0, 1, 2, k, w) || try_tri(0, 2, 3, k, w);
-                                if (found) found2 = try_tri(0, 1, 3, k2, w2) || try_tri(1, 2, 3, k2, w2);
-                            } else {
-                                found = try_tri(0, 1, 3, k, w) || try_tri(1, 2, 3, k, w);
-                                if (found) found2 = try_tri(0, 1, 2, k2, w2) || try_tri(0, 2, 3, k2, w2);
-                            }
-                            if (!found) continue;
-                            for (int m = 0; m < 3; ++m) tri[m] = (long long)c.ci[k[m]] * A.width + c.cj[k[m]];
-                            cubic_in_triangle(A, pi, pj, B, a, b, c, k, w, img, grad, val);
-                            if (found2 && alt != nullptr) {
-                                // the cell cut along its other diagonal (what Qhull may have chosen for a near-cocircular quad)
-                                lat_cell c2 = c;
-                                c2.flip = !c.flip;
-                                cubic_in_triangle(A, pi, pj, B, a, b, c2, k2, w2, img, grad, val2);
-                            }
-                        }
-            }
-        }
-        for (int ch = 0; ch < nc; ++ch) {
-            const double v = found ? val[ch] : kNaN;
-            if (mean) mean[t * nc + ch] = v;
-            if (alt) alt[t * nc + ch] = found ? (found2 ? val2[ch] : val[ch]) : kNaN;
-            if (sizeof(T) < 8 && ch < nch && out_img) {
-                // np.round (half to even), then the cast of the reference (resample.py:129-132); a cubic overshoots, and
-                // numpy's cast of an out-of-range float wraps modulo the type's range on x86-64: the same here
-                const double r = found ? rint(v) : 0.0;
-                out_img[t * nch + ch] = (T)(unsigned long long)(long long)r;
-            }
-        }
-        if (out_mask) out_mask[t] = found ? 0 : 1;
-        if (out_tri)
-            for (int m = 0; m < 3; ++m) out_tri[t * 3 + m] = tri[m];
-    }
 }
 
 // ---- method='cubic' on the EXACT triangulation (round 5) ---------------------------------------------------------------------
@@ -860,8 +379,13 @@ __global__ __launch_bounds__(kBlock) void k_cubic_geometry(const double* __restr
 }
 
 // Lanes of a wave are (neighbour, channel) pairs — eight neighbours x eight channels —: every lane gathers ONE term of a point's
-// right-hand side, and the eight terms of a channel are then added in the order of the neighbours (lane to lane, ds_bpermute), so
-// that the sum has scipy's rounding.  (With lanes as channels only — the first form — four of 64 lanes worked for an RGB image
+// right-hand side, and the eight terms of a channel are then added in the order of this library's neighbour lists (ascending
+// vertex index, build_vertex_lists; lane to lane, ds_bpermute): a fixed order, so the result does not depend on the schedule.  It is
+// NOT scipy's rounding to the bit — scipy lists a vertex's neighbours in the order Qhull's simplices first mention them and
+// evaluates a term as (..) * ex / l3 where this code multiplies by a stored 1 / l3 —: equal to scipy up to summation order (1e-13
+// of a channel's span on every fixture), and, because the stopping rule `error < tol` is a yes / no decision per sweep, a channel
+// whose sweep error lands within rounding of the tolerance could stop one sweep apart from scipy (a difference of ~1e-6 relative;
+// not observed: amt_cubic_gradients_csr returns the sweep count per channel for exactly that check).  (With lanes as channels only — the first form — four of 64 lanes worked for an RGB image
 // and its elevation, and a step of the sweep's critical path was the ~1000 instructions of all eight terms one after the other.)
 constexpr int kGsChan = 8;          // channels per wave; more channels: more waves per row (blockIdx.y), each with its own ticket
 
@@ -1207,145 +731,6 @@ int amt_nearest_gather(amt_ctx* ctx, const int64_t* index, int64_t n_targets, co
         hipLaunchKernelGGL(k_nn_gather<uint8_t>, grid_for(n_targets), dim3(kBlock), 0, ctx->stream, idx, n_targets,
                            static_cast<const uint8_t*>(img), nchan, elev, mean, static_cast<uint8_t*>(out_img),
                            out_mask);
-    }
-    AMT_LAUNCH_CHECK(ctx);
-    return AMT_OK;
-}
-
-int amt_linear_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx, const double* lat_c, const double* lon_c,
-                      const double* elev, const uint8_t* center_mask, int32_t height, int32_t width, double min_elevation,
-                      int lon_wrap, const double* target_lat, const double* target_lon, const void* img, int32_t img_dtype,
-                      int32_t nchan, double* mean, void* out_img, uint8_t* out_mask, double* alt_mean, int64_t* out_triangles) {
-    AMT_CHECK_CTX(ctx);
-    AMT_REQUIRE(ctx, index && lat_c && lon_c && target_lat && target_lon, "NULL argument");
-    AMT_REQUIRE(ctx, ny >= 0 && nx >= 0 && height > 0 && width > 0, "bad size");
-    AMT_REQUIRE(ctx, nchan >= 0 && nchan <= 4, "nchan must be 0..4");
-    AMT_REQUIRE(ctx, nchan == 0 || (img && (img_dtype == 1 || img_dtype == 2)), "img must be uint8 (1) or uint16 (2)");
-    const int64_t total = (int64_t)ny * nx;
-    if (total == 0) return AMT_OK;
-    lin_args A;
-    A.lat_c = lat_c, A.lon_c = lon_c, A.elev = elev, A.center_mask = center_mask;
-    A.height = height, A.width = width;
-    A.min_elev = min_elevation;
-    A.lon_wrap = lon_wrap ? 1 : 0;
-    A.nchan = nchan;
-    const long long* idx = reinterpret_cast<const long long*>(index);
-    long long* tri = reinterpret_cast<long long*>(out_triangles);
-    if (img_dtype == 2) {
-        hipLaunchKernelGGL(k_linear_gather<uint16_t>, grid_for(total), dim3(kBlock), 0, ctx->stream, A, idx, ny, nx, target_lat,
-                           target_lon, static_cast<const uint16_t*>(img), mean, static_cast<uint16_t*>(out_img), out_mask,
-                           alt_mean, tri);
-    } else {
-        hipLaunchKernelGGL(k_linear_gather<uint8_t>, grid_for(total), dim3(kBlock), 0, ctx->stream, A, idx, ny, nx, target_lat,
-                           target_lon, static_cast<const uint8_t*>(img), mean, static_cast<uint8_t*>(out_img), out_mask,
-                           alt_mean, tri);
-    }
-    AMT_LAUNCH_CHECK(ctx);
-    return AMT_OK;
-}
-
-int amt_cubic_gradients(amt_ctx* ctx, const double* lat_c, const double* lon_c, const double* elev, const uint8_t* center_mask,
-                        int32_t height, int32_t width, double min_elevation, int lon_wrap, const void* img, int32_t img_dtype,
-                        int32_t nchan, double tolerance, int32_t max_iterations, double* gradients, int32_t* iterations) {
-    AMT_CHECK_CTX(ctx);
-    AMT_REQUIRE(ctx, lat_c && lon_c && gradients, "NULL argument");
-    AMT_REQUIRE(ctx, height > 0 && width > 0 && (int64_t)height * width < 2147483647LL, "bad size");
-    AMT_REQUIRE(ctx, nchan >= 0 && nchan + (elev ? 1 : 0) <= kCubicMaxChan && nchan + (elev ? 1 : 0) >= 1,
-                "1..5 channels (image channels + elevation)");
-    AMT_REQUIRE(ctx, nchan == 0 || (img && img_dtype >= 1 && img_dtype <= 3), "img must be uint8 (1), uint16 (2) or float64 (3)");
-    AMT_REQUIRE(ctx, tolerance > 0 && max_iterations >= 1, "tolerance and max_iterations must be positive");
-    lin_args A;
-    A.lat_c = lat_c, A.lon_c = lon_c, A.elev = elev, A.center_mask = center_mask;
-    A.height = height, A.width = width;
-    A.min_elev = min_elevation;
-    A.lon_wrap = lon_wrap ? 1 : 0;
-    A.nchan = nchan;
-    const int64_t n = (int64_t)height * width;
-    const size_t grad_bytes = (size_t)n * (nchan + (elev ? 1 : 0)) * 2 * sizeof(double);
-    const size_t nb_bytes = (size_t)n * kCubicNb * sizeof(int);
-    char* ws = static_cast<char*>(amt_workspace(ctx, grad_bytes + nb_bytes + 64));
-    if (ws == nullptr) {
-        ctx->last_error = "amt_cubic_gradients: workspace allocation failed";
-        return AMT_ENOMEM;
-    }
-    double* other = reinterpret_cast<double*>(ws);
-    int* nb = reinterpret_cast<int*>(ws + grad_bytes);
-    unsigned long long* err = reinterpret_cast<unsigned long long*>(ws + grad_bytes + nb_bytes);
-    if (hipMemsetAsync(gradients, 0, grad_bytes, ctx->stream) != hipSuccess) {
-        ctx->last_error = "amt_cubic_gradients: memset failed";
-        return AMT_EHIP;
-    }
-    hipLaunchKernelGGL(k_cubic_neighbours, grid_for(n), dim3(kBlock), 0, ctx->stream, A, nb);
-    auto sweep = [&](const double* from, double* to) {
-        if (img_dtype == 3)
-            hipLaunchKernelGGL(k_cubic_sweep<double>, grid_for(n), dim3(kBlock), 0, ctx->stream, A, nb,
-                               static_cast<const double*>(img), from, to, err);
-        else if (img_dtype == 2)
-            hipLaunchKernelGGL(k_cubic_sweep<uint16_t>, grid_for(n), dim3(kBlock), 0, ctx->stream, A, nb,
-                               static_cast<const uint16_t*>(img), from, to, err);
-        else
-            hipLaunchKernelGGL(k_cubic_sweep<uint8_t>, grid_for(n), dim3(kBlock), 0, ctx->stream, A, nb,
-                               static_cast<const uint8_t*>(img), from, to, err);
-    };
-    // sweeps in pairs (the result of a pair is in `gradients` again); the second one's largest change decides
-    int done = 0;
-    double worst = 0;
-    while (done < max_iterations) {
-        sweep(gradients, other);
-        if (hipMemsetAsync(err, 0, sizeof(*err), ctx->stream) != hipSuccess) {
-            ctx->last_error = "amt_cubic_gradients: memset failed";
-            return AMT_EHIP;
-        }
-        sweep(other, gradients);
-        done += 2;
-        unsigned long long bits = 0;
-        if (hipMemcpyAsync(&bits, err, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            ctx->last_error = "amt_cubic_gradients: reading the convergence flag failed";
-            return AMT_EHIP;
-        }
-        std::memcpy(&worst, &bits, sizeof(worst));
-        if (worst < tolerance) break;
-    }
-    if (iterations) *iterations = done;
-    AMT_LAUNCH_CHECK(ctx);
-    return AMT_OK;
-}
-
-int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx, const double* lat_c, const double* lon_c,
-                     const double* elev, const uint8_t* center_mask, int32_t height, int32_t width, double min_elevation,
-                     int lon_wrap, const double* target_lat, const double* target_lon, const void* img, int32_t img_dtype,
-                     int32_t nchan, const double* gradients, double* mean, void* out_img, uint8_t* out_mask, double* alt_mean,
-                     int64_t* out_triangles) {
-    AMT_CHECK_CTX(ctx);
-    AMT_REQUIRE(ctx, index && lat_c && lon_c && target_lat && target_lon && gradients, "NULL argument");
-    AMT_REQUIRE(ctx, ny >= 0 && nx >= 0 && height > 0 && width > 0, "bad size");
-    AMT_REQUIRE(ctx, nchan >= 0 && nchan + (elev ? 1 : 0) <= kCubicMaxChan && nchan + (elev ? 1 : 0) >= 1,
-                "1..5 channels (image channels + elevation)");
-    AMT_REQUIRE(ctx, nchan == 0 || (img && img_dtype >= 1 && img_dtype <= 3), "img must be uint8 (1), uint16 (2) or float64 (3)");
-    AMT_REQUIRE(ctx, img_dtype != 3 || out_img == nullptr, "out_img needs an integer image");
-    const int64_t total = (int64_t)ny * nx;
-    if (total == 0) return AMT_OK;
-    lin_args A;
-    A.lat_c = lat_c, A.lon_c = lon_c, A.elev = elev, A.center_mask = center_mask;
-    A.height = height, A.width = width;
-    A.min_elev = min_elevation;
-    A.lon_wrap = lon_wrap ? 1 : 0;
-    A.nchan = nchan;
-    const long long* idx = reinterpret_cast<const long long*>(index);
-    long long* tri = reinterpret_cast<long long*>(out_triangles);
-    if (img_dtype == 3) {
-        hipLaunchKernelGGL(k_cubic_gather<double>, grid_for(total), dim3(kBlock), 0, ctx->stream, A, idx, ny, nx, target_lat,
-                           target_lon, static_cast<const double*>(img), gradients, mean, static_cast<double*>(nullptr), out_mask,
-                           alt_mean, tri);
-    } else if (img_dtype == 2) {
-        hipLaunchKernelGGL(k_cubic_gather<uint16_t>, grid_for(total), dim3(kBlock), 0, ctx->stream, A, idx, ny, nx, target_lat,
-                           target_lon, static_cast<const uint16_t*>(img), gradients, mean, static_cast<uint16_t*>(out_img),
-                           out_mask, alt_mean, tri);
-    } else {
-        hipLaunchKernelGGL(k_cubic_gather<uint8_t>, grid_for(total), dim3(kBlock), 0, ctx->stream, A, idx, ny, nx, target_lat,
-                           target_lon, static_cast<const uint8_t*>(img), gradients, mean, static_cast<uint8_t*>(out_img),
-                           out_mask, alt_mean, tri);
     }
     AMT_LAUNCH_CHECK(ctx);
     return AMT_OK;

@@ -13,6 +13,7 @@ import numpy as np
 import numpy.ma as ma
 
 from ..export import _cdf3
+from ._catalogue import DateCatalogue, unsigned_pixels
 from .mapping import BaseMappingProvider, GenericMapping
 
 
@@ -25,10 +26,10 @@ def read_arrays(path, i=0):
     cameraPosGCRS = np.array(var['camera_pos'][i])
     photoTime = root.times('Epoch')[i]
     if 'img' in var:
-        img = _convertImgDtype(var['img'][i], var['img'].attrs.get('FILLVAL'))
+        img = unsigned_pixels(var['img'][i], var['img'].attrs.get('FILLVAL'))
         img = img[:, :, None] if img.ndim == 2 else img
     else:
-        bands = [_convertImgDtype(var[k][i], var[k].attrs.get('FILLVAL')) for k in ('img_red', 'img_green', 'img_blue')]
+        bands = [unsigned_pixels(var[k][i], var[k].attrs.get('FILLVAL')) for k in ('img_red', 'img_green', 'img_blue')]
         img = ma.dstack(bands)
     latsCenter, lonsCenter = var['lat'][i], var['lon'][i]
     lats = var[var['lat'].attrs['bounds']][i]
@@ -51,62 +52,31 @@ class CDFMapping(GenericMapping):
 
 
 class CDFMappingProvider(BaseMappingProvider):
-    """Mappings from a list of exported files, looked up by date: (file, record) per date (reference mapping/cdf.py:19-77)."""
+    """Mappings from a list of exported CDF files, looked up by date; a file may hold several records (reference
+    mapping/cdf.py:19-77)."""
 
     def __init__(self, cdfPaths, maxTimeOffset=3):
         BaseMappingProvider.__init__(self, maxTimeOffset=maxTimeOffset)
-        self.cdfPaths = cdfPaths
-        datemap = {}
-        for path_idx, path in enumerate(cdfPaths):
-            for cdf_idx, date in enumerate(_cdf3.Reader(path).times('Epoch')):
-                if date in datemap:
-                    raise ValueError('The date ' + str(date) + ' is appearing twice in the CDF files ' + path + ' and ' +
-                                     cdfPaths[datemap[date][0]])
-                datemap[date] = (path_idx, cdf_idx)
-        self.datemap = collections.OrderedDict(sorted(datemap.items()))
+        self.cdfPaths = list(cdfPaths)
+        self.catalogue = DateCatalogue(((date, (path, record), path) for path in self.cdfPaths
+                                        for record, date in enumerate(_cdf3.Reader(path).times('Epoch'))), 'the list of CDF files')
 
     def __len__(self):
-        return len(self.datemap)
+        return len(self.catalogue)
 
     @property
     def range(self):
-        return list(self.datemap.keys())[0], list(self.datemap.keys())[-1]
-
-    def _nearest(self, date):
-        dates = list(self.datemap.keys())
-        idx = int(np.argmin([abs((d - date).total_seconds()) for d in dates]))
-        return dates[idx], abs((dates[idx] - date).total_seconds())
+        return self.catalogue.span
 
     def contains(self, date):
-        return self._nearest(date)[1] <= self.maxTimeOffset
+        return self.catalogue.within(date, self.maxTimeOffset)
 
     def get(self, date):
-        found, offset = self._nearest(date)
-        if offset > self.maxTimeOffset:
-            raise ValueError('Closest mapping found at ' + str(found) + ' but offset > ' + str(self.maxTimeOffset) +
-                             ' seconds, requested: ' + str(date))
-        path_idx, cdf_idx = self.datemap[found]
-        return CDFMapping(self.cdfPaths[path_idx], cdf_idx)
+        return CDFMapping(*self.catalogue.pick(date, self.maxTimeOffset))
 
     def getById(self, identifier):
         raise NotImplementedError
 
     def getSequence(self, dateBegin=None, dateEnd=None):
-        if not dateBegin:
-            dateBegin = self.range[0]
-        if not dateEnd:
-            dateEnd = self.range[1]
-        for date in [d for d in self.datemap if dateBegin <= d <= dateEnd]:
-            path_idx, cdf_idx = self.datemap[date]
-            yield CDFMapping(self.cdfPaths[path_idx], cdf_idx)
-
-
-def _convertImgDtype(arr, fillval):
-    if arr.dtype in [np.uint8, np.uint16, np.uint32]:
-        return ma.masked_array(arr)
-    arr = ma.masked_equal(arr, fillval, copy=False) if fillval is not None else ma.masked_array(arr)
-    for signed, unsigned in ((np.int16, np.uint8), (np.int32, np.uint16), (np.int64, np.uint32)):
-        if arr.dtype == signed:
-            assert 0 <= np.min(arr) <= np.max(arr) <= np.iinfo(unsigned).max
-            return arr.astype(unsigned)
-    raise NotImplementedError('Data type not supported: ' + str(arr.dtype))
+        for path, record in self.catalogue.between(dateBegin, dateEnd):
+            yield CDFMapping(path, record)

@@ -13,52 +13,65 @@ import numpy as np
 import numpy.ma as ma
 
 from ..export import _nc4
+from ._catalogue import DateCatalogue, unsigned_pixels
 from .mapping import BaseMappingProvider, GenericMapping
+
+
+def _edges_from_intervals(bounds, name):
+    """(n, 2) cell intervals of a rectilinear axis -> the n + 1 edges; neighbouring cells must share their edge."""
+    if not np.array_equal(bounds[1:, 0], bounds[:-1, 1]):
+        raise ValueError('the %s bounds are not contiguous' % name)
+    return np.append(bounds[:, 0], bounds[-1, 1])
+
+
+def _corner_grid(bounds, name):
+    """(ny, nx, 4) cell vertices — upper left, upper right, lower right, lower left, the order the exporter writes — -> the
+    (ny + 1, nx + 1) grid of corners, after checking that the four cells around every corner agree on it (NaN = missing corner)."""
+    ny, nx = bounds.shape[:2]
+    grid = np.empty((ny + 1, nx + 1), bounds.dtype)
+    grid[:ny, :nx] = bounds[..., 0]
+    grid[:ny, nx] = bounds[:, -1, 1]
+    grid[ny, :nx] = bounds[-1, :, 3]
+    grid[ny, nx] = bounds[-1, -1, 2]
+    views = {1: grid[:ny, 1:], 2: grid[1:, 1:], 3: grid[1:, :nx]}
+    for vertex, view in views.items():
+        if not np.array_equal(view, bounds[..., vertex], equal_nan=True):
+            raise ValueError('the %s bounds of neighbouring cells disagree about their common corners' % name)
+    return grid
 
 
 def read_arrays(path):
     """
-    -> dict(lats, lons, latsCenter, lonsCenter, elevation, img, altitude, cameraPosGCRS, photoTime, metadata) of one
-    exported mapping, as the reference's ``NetCDFMapping.__init__`` assembles them (mapping/netcdf.py:96-157): corner
-    grids rebuilt from the cell bounds, images back to their unsigned type, elevation = 90 - zenith angle.
+    -> dict(lats, lons, latsCenter, lonsCenter, elevation, img, altitude, cameraPosGCRS, photoTime, metadata) of one exported
+    mapping (what the reference's ``NetCDFMapping`` holds, mapping/netcdf.py:96-157): corner grids rebuilt from the CF cell
+    bounds — intervals per axis for a plate carree mapping, four vertices per cell otherwise —, images back to their unsigned
+    pixel type, elevation = 90 - zenith angle, altitude in km.
     """
     f = _nc4.open_file(path)
     var = f.vars
-    altitude = var['altitude'].data / 1000
-    cameraPosGCRS = np.array(var['camera_pos'].data)
-    photoTime = _readDate(var['time'])
+    for name, unit in (('altitude', 'meters'), ('camera_pos', 'kilometers')):
+        if var[name].attrs['units'] != unit:
+            raise ValueError('%s in %s, expected %s' % (name, var[name].attrs['units'], unit))
+    pixels = lambda v: unsigned_pixels(v.data, v.attrs.get('_FillValue'))
     if 'img' in var:
-        img = _convertImgDtype(_masked_fill(var['img']))[:, :, None]
+        img = pixels(var['img'])[:, :, None]
     else:
-        img = ma.dstack([_convertImgDtype(_masked_fill(var[k])) for k in ('img_red', 'img_green', 'img_blue')])
-    latsCenter, lonsCenter = var['lat'].data, var['lon'].data
-    latBounds = var[var['lat'].attrs['bounds']].data
-    lonBounds = var[var['lon'].attrs['bounds']].data
-    if latsCenter.ndim == 1:
-        latsCenter, lonsCenter = np.dstack(np.meshgrid(latsCenter, lonsCenter)).T
-        assert np.all(latBounds[:-1, 1] == latBounds[1:, 0])
-        assert np.all(lonBounds[:-1, 1] == lonBounds[1:, 0])
-        latBounds = np.concatenate((latBounds[:, 0], [latBounds[-1, 1]]))
-        lonBounds = np.concatenate((lonBounds[:, 0], [lonBounds[-1, 1]]))
-        lats, lons = np.dstack(np.meshgrid(latBounds, lonBounds)).T
+        img = ma.dstack([pixels(var[k]) for k in ('img_red', 'img_green', 'img_blue')])
+    centres = {k: var[k].data for k in ('lat', 'lon')}
+    bounds = {k: var[var[k].attrs['bounds']].data for k in ('lat', 'lon')}
+    if centres['lat'].ndim == 1:
+        # plate carree: one axis each; every array is (n_lat, n_lon)
+        latsCenter, lonsCenter = np.meshgrid(centres['lat'], centres['lon'], indexing='ij')
+        lats, lons = np.meshgrid(_edges_from_intervals(bounds['lat'], 'latitude'), _edges_from_intervals(bounds['lon'], 'longitude'),
+                                 indexing='ij')
     else:
-        lats = np.empty((latsCenter.shape[0] + 1, latsCenter.shape[1] + 1), latBounds.dtype)
-        lons = np.empty_like(lats)
-        for grid, bounds in [(lats, latBounds), (lons, lonBounds)]:
-            np.testing.assert_array_equal(bounds[:-1, :-1, 2], bounds[:-1, 1:, 3])
-            np.testing.assert_array_equal(bounds[:-1, :-1, 2], bounds[1:, 1:, 0])
-            np.testing.assert_array_equal(bounds[:-1, :-1, 2], bounds[1:, :-1, 1])
-            grid[:-1, :-1] = bounds[:, :, 0]
-            grid[-1, :-1] = bounds[-1, :, 3]
-            grid[:-1, -1] = bounds[:, -1, 1]
-            grid[-1, -1] = bounds[-1, -1, 2]
-    assert var['altitude'].attrs['units'] == 'meters'
-    assert var['camera_pos'].attrs['units'] == 'kilometers'
+        latsCenter, lonsCenter = centres['lat'], centres['lon']
+        lats, lons = _corner_grid(bounds['lat'], 'latitude'), _corner_grid(bounds['lon'], 'longitude')
     return dict(lats=ma.masked_invalid(lats), lons=ma.masked_invalid(lons), latsCenter=ma.masked_invalid(latsCenter),
                 lonsCenter=ma.masked_invalid(lonsCenter),
                 elevation=ma.masked_invalid(90 - var['zenith_angle'].data.astype(np.float64)), img=img,
-                altitude=float(altitude), cameraPosGCRS=cameraPosGCRS, photoTime=photoTime,
-                metadata=collections.OrderedDict(f.attrs))
+                altitude=float(var['altitude'].data) / 1000, cameraPosGCRS=np.array(var['camera_pos'].data),
+                photoTime=_readDate(var['time']), metadata=collections.OrderedDict(f.attrs))
 
 
 class NetCDFMapping(GenericMapping):
@@ -70,69 +83,33 @@ class NetCDFMapping(GenericMapping):
 
 
 class NetCDFMappingProvider(BaseMappingProvider):
-    """Mappings from a list of exported files, looked up by date (reference mapping/netcdf.py:20-76)."""
+    """Mappings from a list of exported netCDF files (one mapping each), looked up by date (reference mapping/netcdf.py:20-76)."""
 
     def __init__(self, cdfPaths, maxTimeOffset=3):
         BaseMappingProvider.__init__(self, maxTimeOffset=maxTimeOffset)
-        self.cdfPaths = cdfPaths
-        datemap = {}
-        for path_idx, path in enumerate(cdfPaths):
-            date = _readDate(_nc3.File(path).vars['time'])
-            if date in datemap:
-                raise ValueError('The date ' + str(date) + ' is appearing twice in the NetCDF files ' + path + ' and ' +
-                                 cdfPaths[datemap[date]])
-            datemap[date] = path_idx
-        self.datemap = collections.OrderedDict(sorted(datemap.items()))
+        self.cdfPaths = list(cdfPaths)
+        self.catalogue = DateCatalogue(((_readDate(_nc4.open_file(path).vars['time']), path, path) for path in self.cdfPaths),
+                                       'the list of netCDF files')
 
     def __len__(self):
-        return len(self.datemap)
+        return len(self.catalogue)
 
     @property
     def range(self):
-        return list(self.datemap.keys())[0], list(self.datemap.keys())[-1]
-
-    def _nearest(self, date):
-        dates = list(self.datemap.keys())
-        idx = int(np.argmin([abs((d - date).total_seconds()) for d in dates]))
-        return dates[idx], abs((dates[idx] - date).total_seconds())
+        return self.catalogue.span
 
     def contains(self, date):
-        return self._nearest(date)[1] <= self.maxTimeOffset
+        return self.catalogue.within(date, self.maxTimeOffset)
 
     def get(self, date):
-        found, offset = self._nearest(date)
-        if offset > self.maxTimeOffset:
-            raise ValueError('Closest mapping found at ' + str(found) + ' but offset > ' + str(self.maxTimeOffset) +
-                             ' seconds, requested: ' + str(date))
-        return NetCDFMapping(self.cdfPaths[self.datemap[found]])
+        return NetCDFMapping(self.catalogue.pick(date, self.maxTimeOffset))
 
     def getById(self, identifier):
         raise NotImplementedError
 
     def getSequence(self, dateBegin=None, dateEnd=None):
-        if not dateBegin:
-            dateBegin = self.range[0]
-        if not dateEnd:
-            dateEnd = self.range[1]
-        for date in [d for d in self.datemap if dateBegin <= d <= dateEnd]:
-            yield NetCDFMapping(self.cdfPaths[self.datemap[date]])
-
-
-def _masked_fill(v):
-    fill = v.attrs.get('_FillValue')
-    return ma.masked_equal(v.data, fill) if fill is not None else ma.masked_array(v.data)
-
-
-def _convertImgDtype(arr):
-    if arr.dtype in [np.uint8, np.uint16]:
-        return arr
-    elif arr.dtype == np.int16:
-        assert 0 <= np.min(arr) <= np.max(arr) <= np.iinfo(np.uint8).max
-        return arr.astype(np.uint8)
-    elif arr.dtype == np.int32:
-        assert 0 <= np.min(arr) <= np.max(arr) <= np.iinfo(np.uint16).max
-        return arr.astype(np.uint16)
-    raise NotImplementedError('Data type not supported: ' + str(arr.dtype))
+        for path in self.catalogue.between(dateBegin, dateEnd):
+            yield NetCDFMapping(path)
 
 
 def _readDate(date_var):

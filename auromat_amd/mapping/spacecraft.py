@@ -221,17 +221,37 @@ def _load_metadata(path):
 
 
 def _metadata_of(metadata, identifier):
+    """What metadata.json says about one image: the sequence's entries, overridden by the image's own."""
     if not metadata:
         return None
-    return dict(list(metadata['sequence_metadata'].items()) + list(metadata['image_metadata'][identifier].items()))
+    merged = dict(metadata['sequence_metadata'])
+    merged.update(metadata['image_metadata'][identifier])
+    return merged
+
+
+def _stem(path):
+    return os.path.splitext(os.path.basename(path))[0]
+
+
+def _solved_frames(image_paths, wcs_paths, time_of):
+    """DateCatalogue of the frames that have a solution: per ``.wcs`` file its image (same file name without the extension),
+    ordered by `time_of(header)`; payload (identifier, image path, wcs path).  A solution without an image is an error."""
+    from ..fits import readHeader
+    from ._catalogue import DateCatalogue
+    image_of = {_stem(p): p for p in image_paths}
+    orphans = [_stem(w) for w in wcs_paths if _stem(w) not in image_of]
+    if orphans:
+        raise ValueError('no image file for the solutions ' + ', '.join(orphans))
+    return DateCatalogue(((time_of(readHeader(w)), (_stem(w), image_of[_stem(w)], w), w) for w in wcs_paths), 'the set of .wcs files'), image_of
 
 
 class SpacecraftMappingProvider(BaseMappingProvider):
     """
-    Mappings of a folder (or of two path lists) of image files and their astrometry.net ``.wcs`` solutions, by date,
-    identifier or as a sequence — the reference's provider (spacecraft.py:40-248) on
-    :func:`auromat_amd.fits.readHeader` / :func:`getMapping`.  A ``metadata.json`` next to the images
-    (``sequence_metadata`` + per-image ``image_metadata``) is attached to the mappings.
+    The frames of a folder — image files and, next to them or in a folder of their own, their astrometry.net ``.wcs`` solutions
+    — or of two explicit path lists, as mappings by date, by identifier or as a sequence in time order (the reference's provider,
+    spacecraft.py:40-248, on :func:`auromat_amd.fits.readHeader` / :func:`getMapping`).  A ``metadata.json`` beside the images
+    (``sequence_metadata`` for all, ``image_metadata`` per identifier) is merged into each mapping's metadata.  The camera
+    position comes from the header cards (TLE look-up is not part of this package; the parameters are accepted and passed on).
     """
 
     def __init__(self, imageSequenceFolder, wcsFolder=None, imageFileExtension=None, timeshift=None, noradId=None,
@@ -239,134 +259,118 @@ class SpacecraftMappingProvider(BaseMappingProvider):
                  fastCenterCalculation=False):
         """
         :param imageSequenceFolder: folder path or a list of image file paths
-        :param wcsFolder: folder path or a list of wcs file paths; optional if imageSequenceFolder is a folder that
-                          contains the wcs files as well
+        :param wcsFolder: folder path or a list of wcs file paths; may be left out when the image folder holds the wcs files too
         """
         BaseMappingProvider.__init__(self, maxTimeOffset=maxTimeOffset)
+        lists = isinstance(imageSequenceFolder, list), isinstance(wcsFolder, list)
         if wcsFolder is None:
-            assert not isinstance(imageSequenceFolder, list), \
-                'The wcsFolder parameter is required if imageSequenceFolder is a list'
-            wcsFolder = imageSequenceFolder
-        if isinstance(imageSequenceFolder, list) and isinstance(wcsFolder, list):
-            self.imageSequenceFolder = self.wcsFolder = None
-            self.imagePaths, self.wcsPaths = list(imageSequenceFolder), list(wcsFolder)
-            self._imageFileExtension = os.path.splitext(self.imagePaths[0])[1][1:]
-            self._match()
-        elif not isinstance(imageSequenceFolder, list) and not isinstance(wcsFolder, list):
-            self.imageSequenceFolder, self.wcsFolder = imageSequenceFolder, wcsFolder
-            self._imageFileExtension = imageFileExtension
-            self.reload()
-        else:
+            if lists[0]:
+                raise ValueError('wcsFolder is needed when imageSequenceFolder is a list of paths')
+            wcsFolder, lists = imageSequenceFolder, (False, False)
+        if lists[0] != lists[1]:
             raise ValueError('imageSequenceFolder and wcsFolder must be both path lists or folder paths')
+        self._from_lists = lists[0]
+        self.imageSequenceFolder, self.wcsFolder = (None, None) if self._from_lists else (imageSequenceFolder, wcsFolder)
+        self._given = (list(imageSequenceFolder), list(wcsFolder)) if self._from_lists else None
+        self._imageFileExtension = os.path.splitext(self._given[0][0])[1][1:] if self._from_lists else imageFileExtension
         self.timeshift, self.noradId, self.tleFolder, self.spacetrack = timeshift, noradId, tleFolder, spacetrack
         self.altitude, self.fastCenterCalculation = altitude, fastCenterCalculation
-        self.metadata = _load_metadata(os.path.join(os.path.dirname(self.imagePaths[0]), 'metadata.json')) \
-            if self.imagePaths else None
         self._sequenceInParallel = sequenceInParallel
-
-    def __len__(self):
-        return len(self.wcsPaths)
+        self.reload()
+        self.metadata = _load_metadata(os.path.join(os.path.dirname(self.imagePaths[0]), 'metadata.json')) if self.imagePaths else None
 
     def reload(self):
-        """Refresh to the current state of the folders (no-op for path lists)."""
-        if self.wcsFolder is None:
-            return
-        self.wcsPaths = sorted(os.path.join(self.wcsFolder, f) for f in os.listdir(self.wcsFolder) if f.endswith('.wcs'))
-        try:
-            ext = '.' + self.imageFileExtension
-            self.imagePaths = sorted(os.path.join(self.imageSequenceFolder, f)
-                                     for f in os.listdir(self.imageSequenceFolder) if f.endswith(ext))
-        except ValueError:
-            self.imagePaths, self.wcsPaths = [], []
-        self._match()
+        """Look at the folders again (path lists: at the lists as given)."""
+        if self._from_lists:
+            images, solutions = self._given
+        else:
+            solutions = sorted(os.path.join(self.wcsFolder, f) for f in os.listdir(self.wcsFolder) if f.endswith('.wcs'))
+            try:
+                suffix = '.' + self.imageFileExtension
+                images = sorted(os.path.join(self.imageSequenceFolder, f) for f in os.listdir(self.imageSequenceFolder) if f.endswith(suffix))
+            except ValueError:
+                images, solutions = [], []            # nothing solved yet: no extension to go by
+        self._frames, self._imageOf = _solved_frames(images, solutions, getShiftedPhotoTime)
+        self.imagePaths = images
+        self.dates = list(self._frames.dates)
+        self.ids = [f[0] for f in self._frames.payloads]
+        self.wcsPaths = [f[2] for f in self._frames.payloads]
 
-    def _match(self):
-        """Every solution needs its image; solutions sorted by (shifted) photo time."""
-        images = {os.path.splitext(os.path.basename(p))[0]: p for p in self.imagePaths}
-        ids = [os.path.splitext(os.path.basename(p))[0] for p in self.wcsPaths]
-        missing = [i for i in ids if i not in images]
-        assert not missing, 'no image for the solutions ' + str(missing)
-        from ..fits import readHeader
-        dated = sorted((getShiftedPhotoTime(readHeader(p)), p, i) for p, i in zip(self.wcsPaths, ids))
-        self.dates = [d for d, _, _ in dated]
-        self.wcsPaths = [p for _, p, _ in dated]
-        self.ids = [i for _, _, i in dated]
-        self._imageOf = images
+    def __len__(self):
+        return len(self._frames)
 
     @property
     def imageFileExtension(self):
-        """e.g. 'jpg'; found from the files when not given."""
+        """e.g. 'jpg'.  When not given: the extension of the one file that shares its name with a ``.wcs`` file."""
         if self._imageFileExtension is None:
-            names = os.listdir(self.imageSequenceFolder)
-            solved = [f for f in os.listdir(self.wcsFolder) if f.endswith('.wcs')]
-            if self.imageSequenceFolder == self.wcsFolder:
-                names = [f for f in names if f not in solved]
-            for wcs in solved:
-                base = os.path.splitext(wcs)[0]
-                matches = [f for f in names if os.path.splitext(f)[0] == base]
-                if len(matches) == 1:
-                    self._imageFileExtension = os.path.splitext(matches[0])[1][1:]
-                    break
-                elif len(matches) > 1:
-                    raise ValueError('Image file extension not given but multiple candidates exist: ' + str(matches))
-            if self._imageFileExtension is None:
-                raise ValueError('Image file extension could not be determined. Make sure that there exists at least '
-                                 'one .wcs file and a corresponding image with the same filename base.')
+            solved = set(_stem(f) for f in os.listdir(self.wcsFolder) if f.endswith('.wcs'))
+            partners = {}
+            for f in os.listdir(self.imageSequenceFolder):
+                base, ext = os.path.splitext(f)
+                if base in solved and ext != '.wcs':
+                    partners.setdefault(base, []).append(ext[1:])
+            for base in sorted(partners):
+                if len(partners[base]) > 1:
+                    raise ValueError('no image file extension given and %s.* is ambiguous: %s' % (base, sorted(partners[base])))
+                self._imageFileExtension = partners[base][0]
+                break
+            else:
+                raise ValueError('no image file extension given and none can be found: there is no .wcs file with an image file '
+                                 'of the same name')
         return self._imageFileExtension
 
     @property
     def range(self):
-        return self.dates[0], self.dates[-1]
+        return self._frames.span
 
     @property
     def unsolvedIds(self):
-        solved = set(self.ids)
-        return sorted(i for i in self._imageOf if i not in solved)
-
-    def _nearest(self, date):
-        from ..utils import findNearest
-        idx = findNearest(self.dates, date)
-        return idx, abs(self.dates[idx] - date).total_seconds()
+        """Identifiers of the images that have no ``.wcs`` file (yet)."""
+        return sorted(set(self._imageOf) - set(self.ids))
 
     def contains(self, date):
-        return bool(self.dates) and self._nearest(date)[1] <= self.maxTimeOffset
+        return self._frames.within(date, self.maxTimeOffset)
+
+    def _mapping(self, frame):
+        identifier, image, solution = frame
+        return getMapping(image, solution, self.timeshift, self.noradId, self.tleFolder, self.spacetrack, altitude=self.altitude,
+                          fastCenterCalculation=self.fastCenterCalculation, metadata=_metadata_of(self.metadata, identifier))
 
     def get(self, date):
-        if not self.dates:
-            raise ValueError('No image found')
-        idx, offset = self._nearest(date)
-        if offset > self.maxTimeOffset:
-            raise ValueError('No image found')
-        identifier = self.ids[idx]
-        return getMapping(self._imageOf[identifier], self.wcsPaths[idx], self.timeshift, self.noradId, self.tleFolder,
-                          self.spacetrack, altitude=self.altitude, fastCenterCalculation=self.fastCenterCalculation,
-                          metadata=_metadata_of(self.metadata, identifier))
+        if not len(self._frames):
+            raise ValueError('the provider holds no solved frame')
+        return self._mapping(self._frames.pick(date, self.maxTimeOffset))
 
     def getById(self, identifier):
-        matched = [i for i in self.ids if identifier in i]
-        if len(matched) != 1:
-            raise ValueError('Ambiguous or unknown identifier: ' + str(matched))
-        return self.get(self.dates[self.ids.index(matched[0])])
+        """The frame whose identifier contains `identifier`; ValueError unless exactly one does."""
+        hits = [f for f in self._frames.payloads if identifier in f[0]]
+        if len(hits) != 1:
+            raise ValueError('%r names %d frames: %s' % (identifier, len(hits), [f[0] for f in hits][:5]))
+        return self._mapping(hits[0])
 
     def getSequence(self, dateBegin=None, dateEnd=None):
-        assert dateBegin is None and dateEnd is None, 'Date ranges not supported'
-        metadatas = [_metadata_of(self.metadata, i) for i in self.ids] if self.metadata else None
-        return getMappingSequence([self._imageOf[i] for i in self.ids], self.wcsPaths, metadatas, self.timeshift,
-                                  self.noradId, self.tleFolder, self.spacetrack, altitude=self.altitude,
-                                  parallel=self._sequenceInParallel, fastCenterCalculation=self.fastCenterCalculation)
+        if dateBegin is not None or dateEnd is not None:
+            raise NotImplementedError('sequences of a date range (the reference does not support them either, spacecraft.py:226-228)')
+        frames = self._frames.payloads
+        metadatas = [_metadata_of(self.metadata, f[0]) for f in frames] if self.metadata else None
+        return getMappingSequence([f[1] for f in frames], [f[2] for f in frames], metadatas, self.timeshift, self.noradId,
+                                  self.tleFolder, self.spacetrack, altitude=self.altitude, parallel=self._sequenceInParallel,
+                                  fastCenterCalculation=self.fastCenterCalculation)
 
 
 class SpacecraftMappingPathProvider(BaseMappingProvider):
-    """The same for explicit path lists, sequence access only (reference spacecraft.py:250-300)."""
+    """Explicit lists of image and ``.wcs`` paths (pairs by position), as a sequence in the order of the ORIGINAL photo times
+    only; look-up by date or identifier is not offered (reference spacecraft.py:250-300)."""
 
     def __init__(self, imagePaths, wcsPaths, metadataPath=None, timeshift=None, noradId=None, tleFolder=None,
                  spacetrack=None, altitude=110, maxTimeOffset=3, sequenceInParallel=False, fastCenterCalculation=False):
         BaseMappingProvider.__init__(self, maxTimeOffset=maxTimeOffset)
-        assert len(imagePaths) == len(wcsPaths)
+        if len(imagePaths) != len(wcsPaths):
+            raise ValueError('%d images for %d solutions' % (len(imagePaths), len(wcsPaths)))
         from ..fits import readHeader
-        pairs = sorted(zip(wcsPaths, imagePaths), key=lambda wi: getPhotoTime(readHeader(wi[0])))
-        self.wcsPaths = [w for w, _ in pairs]
-        self.imagePaths = [i for _, i in pairs]
+        order = sorted(range(len(wcsPaths)), key=lambda k: getPhotoTime(readHeader(wcsPaths[k])))
+        self.wcsPaths = [wcsPaths[k] for k in order]
+        self.imagePaths = [imagePaths[k] for k in order]
         self.timeshift, self.noradId, self.tleFolder, self.spacetrack = timeshift, noradId, tleFolder, spacetrack
         self.altitude, self.sequenceInParallel, self.fastCenterCalculation = altitude, sequenceInParallel, fastCenterCalculation
         self.metadata = _load_metadata(metadataPath)
@@ -378,11 +382,14 @@ class SpacecraftMappingPathProvider(BaseMappingProvider):
     def imageFileExtension(self):
         return os.path.splitext(self.imagePaths[0])[1][1:]
 
+    def _time_of(self, wcs_path):
+        from ..fits import readHeader
+        header = readHeader(wcs_path)
+        return getShiftedPhotoTime(header) if self.timeshift is None else getPhotoTime(header) + self.timeshift
+
     @property
     def range(self):
-        from ..fits import readHeader
-        return tuple(getShiftedPhotoTime(readHeader(p)) if self.timeshift is None else
-                     getPhotoTime(readHeader(p)) + self.timeshift for p in (self.wcsPaths[0], self.wcsPaths[-1]))
+        return self._time_of(self.wcsPaths[0]), self._time_of(self.wcsPaths[-1])
 
     def contains(self, date):
         raise NotImplementedError
@@ -394,10 +401,9 @@ class SpacecraftMappingPathProvider(BaseMappingProvider):
         raise NotImplementedError
 
     def getSequence(self, dateBegin=None, dateEnd=None):
-        assert dateBegin is None and dateEnd is None, 'Date ranges not supported'
-        metadatas = None
-        if self.metadata:
-            metadatas = [_metadata_of(self.metadata, os.path.splitext(os.path.basename(p))[0]) for p in self.imagePaths]
+        if dateBegin is not None or dateEnd is not None:
+            raise NotImplementedError('sequences of a date range')
+        metadatas = [_metadata_of(self.metadata, _stem(p)) for p in self.imagePaths] if self.metadata else None
         return getMappingSequence(self.imagePaths, self.wcsPaths, metadatas, self.timeshift, self.noradId, self.tleFolder,
                                   self.spacetrack, altitude=self.altitude, parallel=self.sequenceInParallel,
                                   fastCenterCalculation=self.fastCenterCalculation)

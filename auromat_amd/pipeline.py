@@ -634,8 +634,13 @@ class FramePipeline(object):
         if self._fused is not None and self._fused['pxPerDeg'] == tuple(pxPerDeg) and \
                 self._fused['magnetic'] == bool(magnetic):
             res = self._wait_fused()
+            # (a direction-array frame whose caller left the pole open and whose box reaches within 5 deg of a pole was handed
+            # back by the pole guard of amt_pipe_wait, not for a poor estimate: launching it again cannot help — the driver
+            # refuses to fuse that box again —, its corner quads decide, below)
+            pole_guard = self._dirs is not None and self._fused.get('pole_in_view', -1) < 0 and \
+                (res.bbox[0] <= -85.0 or res.bbox[1] >= 85.0)
             if res.status == 1 and res.fused and res.bbox[6] > 0 and res.edge_pixels <= 16384 and not self._fused.get('retried') \
-                    and self.shard is None:
+                    and self.shard is None and not pole_guard:
                 # handed back although the launch was fused (the exact box does not fit the superset grid of a poor estimate,
                 # the date line judged differently by the pre-pass): once more with the exact box — in the coordinates of
                 # the plan, res.bbox[7] — as the estimate, instead of five per-pixel arrays and a separate binning pass

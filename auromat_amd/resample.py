@@ -137,7 +137,8 @@ def resample(mappingOrCollection, pxPerDeg=25, arcsecPerPx=None, containsPole=No
                    plane), 'linear' and 'cubic' (scipy's griddata: the Delaunay triangulation of the pixel centres — Qhull's,
                    triangle for triangle, wherever it is unique —; 'linear': the barycentric sum in the grid centre's
                    triangle; 'cubic': scipy's gradient estimator in scipy's order with its stopping rule and the Clough-Tocher
-                   element; both equal to the reference to rounding, ~1e-13 of a channel's span; a cubic overshoots, and an
+                   element; both equal to the reference up to summation order, ~1e-13 of a channel's span (and up to the per-channel sweep count of
+                   the relaxation, a yes / no decision at scipy's tolerance: see csrc/amt_nearest.hip k_cubic_gs); a cubic overshoots, and an
                    integer image wraps like numpy's cast), all masked outside the mapping's outline.
     :rtype: a subclass of BaseMapping or MappingCollection
     """
@@ -355,24 +356,6 @@ def _check_method(method):
 
 CUBIC_TOLERANCE = 1e-6      # scipy.interpolate.CloughTocher2DInterpolator(tol=1e-6, maxiter=400): griddata's defaults
 CUBIC_MAX_SWEEPS = 400
-# (the Jacobi sweeps on the pixel lattice of rounds 3-4, amt_cubic_gradients: an approximation that leaves Qhull's hull-closing
-# triangles out; kept as an entry point of the library, no longer what method='cubic' runs)
-CUBIC_LATTICE_TOLERANCE = 1e-8
-CUBIC_LATTICE_MAX_SWEEPS = 800
-
-
-def cubic_gradients(ctx, lat_c, lon_c, elev, center_mask, height, width, min_elevation, lon_wrap, data, dtype_code, nchan):
-    """Vertex gradients of scipy's Clough-Tocher interpolant (amt_cubic_gradients) -> (tensor (h * w, channels, 2), sweeps)."""
-    import torch
-    nc = nchan + (1 if elev is not None else 0)
-    grad = ctx.empty((height * width, nc, 2))
-    sweeps = C.c_int32(0)
-    min_el = float('-inf') if min_elevation is None else float(min_elevation)
-    ctx.call('amt_cubic_gradients', ptr(lat_c), ptr(lon_c), ptr(elev), ptr(center_mask), height, width, min_el, lon_wrap,
-             ptr(data) if nchan else None, dtype_code, nchan, CUBIC_LATTICE_TOLERANCE, CUBIC_LATTICE_MAX_SWEEPS, ptr(grad),
-             C.byref(sweeps))
-    return grad, sweeps.value
-
 
 def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask, method='cubic', vertices_out=None):
     """
@@ -408,22 +391,28 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask, 
     n, nchan = int(idx.numel()), int(values.shape[1])
     out = torch.full((grid.ny * grid.nx, nchan), float('nan'), dtype=torch.float64, device=ctx.device)
     if n < 3:
-        raise ValueError('method=\'cubic\' needs at least three valid pixels')
+        raise ValueError("method='%s' needs at least three valid pixels" % method)
     xy = torch.stack((lat.reshape(-1)[idx], lon.reshape(-1)[idx]), dim=1).contiguous()
     xy_host = np.ascontiguousarray(to_host(xy))
     handle = C.c_void_p()
     mark('points to the host')
     rc = L.amt_delaunay_create(xy_host.ctypes.data_as(C.c_void_p), n, C.byref(handle))
+    if rc == -3:                                                     # AMT_ENOMEM
+        raise MemoryError("method='%s': no memory for the triangulation of %d pixel centres" % (method, n))
     if rc != 0:
-        raise ValueError('method=\'cubic\': the valid pixel centres cannot be triangulated (all collinear?)')
+        raise ValueError("method='%s': the valid pixel centres cannot be triangulated (all collinear, or a coordinate that is "
+                         "not finite)" % method)
     mark('triangulation')
     try:
         if method != 'linear':
             # the vertices' neighbour lists (the library makes them when they are first asked for: 'linear' never does)
             nt, nn, nd = C.c_int64(), C.c_int64(), C.c_int64()
-            L.amt_delaunay_sizes(handle, C.byref(nt), C.byref(nn), C.byref(nd))
+            rc = L.amt_delaunay_sizes(handle, C.byref(nt), C.byref(nn), C.byref(nd))
+            if rc != 0:
+                raise MemoryError("method='cubic': the vertex lists of the triangulation could not be made (status %d)" % rc)
             indptr, indices = np.empty(n + 1, dtype=np.int64), np.empty(nn.value, dtype=np.int32)
-            L.amt_delaunay_vertex_neighbours(handle, indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p))
+            rc = L.amt_delaunay_vertex_neighbours(handle, indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p))
+            assert rc == 0, rc
             rows = torch.div(idx, int(width), rounding_mode='floor')
             row_start = torch.zeros(int(height) + 1, dtype=torch.int64, device=ctx.device)
             row_start[1:] = torch.cumsum(torch.bincount(rows, minlength=int(height)), 0)
@@ -586,66 +575,65 @@ def resample_frame(fd, altitude, boundingBox, pxPerDeg, containsDiscontinuity=Fa
         elif containsDiscontinuity:
             outline[:, 1] = wrap_at_180(outline[:, 1] + 180)
         target_mask = outside_outline_mask(ctx, grid, outline)
-        index = nearest_indices(ctx, lat_c, lon_c, fd.elev, fd.center_mask, fd.height, fd.width, min_elevation, grid,
-                                lon_wrap, target_mask)
         mean = ctx.empty((grid.ny, grid.nx, nch + 1))
         img = ctx.empty((grid.ny, grid.nx, max(nch, 1)), torch.uint8 if fd.img_dtype_code != 2 else torch.int16)
         mask = ctx.empty((grid.ny, grid.nx), torch.uint8)
         extra = {}
+        index = None
         if method == 'nearest':
+            index = nearest_indices(ctx, lat_c, lon_c, fd.elev, fd.center_mask, fd.height, fd.width, min_elevation, grid,
+                                    lon_wrap, target_mask)
             ctx.call('amt_nearest_gather', ptr(index), grid.nx * grid.ny, ptr(fd.img), fd.img_dtype_code or 1, nch,
                      ptr(fd.elev), ptr(mean), ptr(img) if nch else None, ptr(mask))
         else:
-            # barycentric interpolation in the triangle of the pixel grid that holds the grid centre (reference
-            # resample.py:323-326: scipy griddata(method='linear')); `alt`: the value with the quad's other diagonal
-            tlat, tlon = grid.device_centers(ctx)
-            alt = ctx.empty((grid.ny, grid.nx, nch + 1))
             tri = ctx.empty((grid.ny, grid.nx, 3), torch.int64)
             min_el = float('-inf') if min_elevation is None else float(min_elevation)
-            if method == 'linear' or method == 'cubic':
-                # scipy's griddata(method='linear' | 'cubic') on its own triangulation, in its own order (cubic_exact): image
-                # channels and elevation as float64 channels of the valid pixels, then numpy's rounding and cast of the image
-                assert fd.elev is not None, "method='%s' on a frame needs the elevation" % method
-                la, lo = lat_c.reshape(-1), lon_c.reshape(-1)
-                if lon_wrap:
-                    lo = wrap_at_180_t(lo + 180)
-                valid = ~(torch.isnan(la) | torch.isnan(lo)) & (fd.elev.reshape(-1) >= min_el)
-                if fd.center_mask is not None:
-                    valid &= fd.center_mask.reshape(-1) == 0
-                chans = [fd.elev.reshape(-1, 1)]
-                if nch:
-                    pix = fd.img.reshape(-1, nch)
-                    if fd.img_dtype_code == 2:
-                        pix = pix.to(torch.int32) & 0xffff            # uint16 bits kept as int16
-                    chans.insert(0, pix.to(torch.float64))
-                tri_out = []
-                vals, sweeps = cubic_exact(ctx, la, lo, valid, torch.cat(chans, dim=1), fd.height, fd.width, grid, target_mask,
-                                           method=method, vertices_out=tri_out)
-                mean.copy_(vals.reshape(grid.ny, grid.nx, nch + 1))
-                empty = torch.isnan(mean[..., 0])
-                mask.copy_(empty.to(torch.uint8))
-                if nch:
-                    # np.round + astype of the interpolated floats (reference resample.py:128-136); an overshoot wraps
-                    rounded = torch.round(torch.nan_to_num(mean[..., :nch], nan=0.0)).to(torch.int64)
-                    if fd.img_dtype_code == 2:
-                        img.copy_((rounded & 0xffff).to(torch.int32).to(torch.int16))
-                    else:
-                        img.copy_((rounded & 0xff).to(torch.uint8))
-                alt.copy_(mean)                    # (rounds 3-4: the value with the lattice cell's other diagonal)
-                tri.copy_(tri_out[0].reshape(grid.ny, grid.nx, 3))
-                extra = dict(alt=alt, triangles=tri)
-                if method == 'cubic':
-                    extra['sweeps'] = max(sweeps)
+            # scipy's griddata(method='linear' | 'cubic') on its own triangulation, in its own order (cubic_exact): image
+            # channels and elevation as float64 channels of the valid pixels, then numpy's rounding and cast of the image
+            assert fd.elev is not None, "method='%s' on a frame needs the elevation" % method
+            la, lo = lat_c.reshape(-1), lon_c.reshape(-1)
+            if lon_wrap:
+                lo = wrap_at_180_t(lo + 180)
+            valid = ~(torch.isnan(la) | torch.isnan(lo)) & (fd.elev.reshape(-1) >= min_el)
+            if fd.center_mask is not None:
+                valid &= fd.center_mask.reshape(-1) == 0
+            chans = [fd.elev.reshape(-1, 1)]
+            if nch:
+                pix = fd.img.reshape(-1, nch)
+                if fd.img_dtype_code == 2:
+                    pix = pix.to(torch.int32) & 0xffff            # uint16 bits kept as int16
+                chans.insert(0, pix.to(torch.float64))
+            tri_out = []
+            vals, sweeps = cubic_exact(ctx, la, lo, valid, torch.cat(chans, dim=1), fd.height, fd.width, grid, target_mask,
+                                       method=method, vertices_out=tri_out)
+            mean.copy_(vals.reshape(grid.ny, grid.nx, nch + 1))
+            empty = torch.isnan(mean[..., 0])
+            mask.copy_(empty.to(torch.uint8))
+            if nch:
+                # np.round + astype of the interpolated floats (reference resample.py:128-136); an overshoot wraps
+                rounded = torch.round(torch.nan_to_num(mean[..., :nch], nan=0.0)).to(torch.int64)
+                if fd.img_dtype_code == 2:
+                    img.copy_((rounded & 0xffff).to(torch.int32).to(torch.int16))
+                else:
+                    img.copy_((rounded & 0xff).to(torch.uint8))
+            tri.copy_(tri_out[0].reshape(grid.ny, grid.nx, 3))
+            extra = dict(triangles=tri)
+            if method == 'cubic':
+                extra['sweeps'] = max(sweeps)
         out = dict(has_elev=fd.elev is not None, grid=grid, contains_pole=bool(containsPole),
                    contains_discontinuity=bool(containsDiscontinuity), altitude=altitude)
         if keep_on_device:
-            out.update(mean=mean, img=img, mask=mask, index=index, **extra)
+            out.update(mean=mean, img=img, mask=mask, **extra)
+            if index is not None:
+                out['index'] = index
             return out
         out.update(grid_coordinates(out))
         out.update(mean=to_host(mean), img=to_host(img, dtype=fd.img_dtype if nch else np.uint8),
-                   mask=to_host(mask).astype(bool), index=to_host(index, dtype=np.int64))
+                   mask=to_host(mask).astype(bool))
+        if index is not None:
+            out['index'] = to_host(index, dtype=np.int64)
         if extra:
-            out.update(alt=to_host(extra['alt']), triangles=to_host(extra['triangles'], dtype=np.int64))
+            out.update(triangles=to_host(extra['triangles'], dtype=np.int64))
             if 'sweeps' in extra:
                 out['sweeps'] = extra['sweeps']
         return out
@@ -688,7 +676,7 @@ def grid_coordinates(res):
 
 
 def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingBox, pxPerDeg,
-              containsDiscontinuity=False, containsPole=False, method='mean', _alt_out=None):
+              containsDiscontinuity=False, containsPole=False, method='mean'):
     """
     Array-level resampling with the reference's signature (resample.py:159-279): every channel of
     `data` (float, NaN = missing) is binned on its own.
@@ -698,9 +686,6 @@ def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingB
     :param outlineLatLonFn: callable returning (n,2) [lat,lon] points whose min/max bound the data
                             (only used in the pole / discontinuity branches)
     :param pxPerDeg: tuple (latPxPerDeg, lonPxPerDeg)
-    :param _alt_out: (not in the reference; method='linear' only) a list that receives the (ny, nx, n) array of the values
-                     with the OTHER diagonal of every grid centre's lattice cell (see amt_linear_gather: Qhull takes either
-                     diagonal of a near-cocircular cell; the tests bound the reference's values by the two)
     :rtype: tuple (lat, lon, latCenter, lonCenter, data)
     """
     _check_method(method)
@@ -737,10 +722,10 @@ def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingB
             outline = np.array(outlineLatLonFn(), dtype=np.float64)
         target_mask = outside_outline_mask(ctx, grid, outline)
         h, w = d.shape[:2]
-        index = nearest_indices(ctx, lat_c.reshape(-1), lon_c.reshape(-1), None, None, h, w, None, grid, lon_wrap,
-                                target_mask)
         flat = ctx.to_device(np.ascontiguousarray(d.reshape(h * w, d.shape[2])))
         if method == 'nearest':
+            index = nearest_indices(ctx, lat_c.reshape(-1), lon_c.reshape(-1), None, None, h, w, None, grid, lon_wrap,
+                                    target_mask)
             picked = flat[index.clamp(min=0).reshape(-1)]
             picked[index.reshape(-1) < 0] = float('nan')
         elif method == 'cubic':
@@ -749,17 +734,14 @@ def _resample(latsCenter, lonsCenter, altitude, data, outlineLatLonFn, boundingB
             la, lo = lat_c.reshape(-1).contiguous(), lon_c.reshape(-1).contiguous()
             if lon_wrap:
                 lo = wrap_at_180_t(lo + 180)
-            picked, _ = cubic_exact(ctx, la, lo, ~torch.isnan(la), flat, h, w, grid, target_mask)
+            picked, _ = cubic_exact(ctx, la, lo, ~(torch.isnan(la) | torch.isnan(lo)), flat, h, w, grid, target_mask)
         else:
             # scipy's griddata(method='linear') on its own triangulation (cubic_exact): Qhull's triangle of every grid centre,
             # the barycentric sum of the channels
             la, lo = lat_c.reshape(-1).contiguous(), lon_c.reshape(-1).contiguous()
             if lon_wrap:
                 lo = wrap_at_180_t(lo + 180)
-            picked, _ = cubic_exact(ctx, la, lo, ~torch.isnan(la), flat, h, w, grid, target_mask, method='linear')
-            if _alt_out is not None:
-                # (rounds 3-4 reported the value with the lattice cell's other diagonal here; the triangle is Qhull's now)
-                _alt_out.append(to_host(picked.reshape(grid.ny, grid.nx, d.shape[2])))
+            picked, _ = cubic_exact(ctx, la, lo, ~(torch.isnan(la) | torch.isnan(lo)), flat, h, w, grid, target_mask, method='linear')
         mean = to_host(picked.reshape(grid.ny, grid.nx, d.shape[2]))
     lat, lon, lat_gc, lon_gc = grid.lat, grid.lon, grid.lat_c, grid.lon_c
     if containsPole:

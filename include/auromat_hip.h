@@ -36,6 +36,7 @@ extern "C" {
  *    amt_pipe_launch_dirs); griddata(method='cubic') exactly: amt_delaunay_*, amt_cubic_gradients_csr, amt_cubic_eval (round 5) */
 /* 6: amt_georef_out.row_layout (strip-padded rows for buffers a pipeline owns), amt_padded_pitch, amt_unpad_rows; host images in the
  *    sequence runner (amt_run_frame.img_host, amt_run_result.uploaded_bytes, amt_georef_image_rows, amt_malloc_host / amt_free_host)
+ *    amt_pipe_launch_dirs_many, amt_host_threads, AMT_EDOMAIN; retired: amt_linear_gather, amt_cubic_gradients, amt_cubic_gather
  *    (round 6) */
 #define AMT_ABI_VERSION 6
 
@@ -511,40 +512,10 @@ int amt_nearest_frame(amt_ctx* ctx, const double* lat_c, const double* lon_c, co
  * out_img (optional): (n_targets, nchan) of img_dtype (0 where index < 0); out_mask (optional): 1 where index < 0. */
 int amt_nearest_gather(amt_ctx* ctx, const int64_t* index, int64_t n_targets, const void* img, int32_t img_dtype,
                        int32_t nchan, const double* elev, double* mean, void* out_img, uint8_t* out_mask);
-/* method='linear' (reference resample.py:323-326: scipy.interpolate.griddata(method='linear') = barycentric
- * interpolation on a Delaunay triangulation of the valid pixel centres in the (lat, lon) plane).  The triangulation is
- * taken from the pixel grid: a quad of four neighbouring valid centres is cut along the diagonal the empty-circle
- * criterion picks, a quad with three valid centres is that triangle; the triangle of a grid centre is searched among the
- * quads within two rings of the pixel centre nearest to it (index = the output of amt_nearest_frame for the same arrays,
- * masks, threshold and lon_wrap).  mean (ny, nx, nchan+1): interpolated channels + elevation, NaN where no triangle holds
- * the centre; out_img rounded half to even like np.round; out_mask 1 where NaN; alt_mean (optional): the value with the
- * quad's OTHER diagonal (= mean where the quad has one triangle) — Qhull takes either diagonal of the near-cocircular
- * quads of a smoothly mapped grid, so scipy's value lies between the two; out_triangles (optional, (ny, nx, 3)): the flat
- * pixel indices of the triangle used, -1 where none. */
-int amt_linear_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx, const double* lat_c, const double* lon_c,
-                      const double* elev, const uint8_t* center_mask, int32_t height, int32_t width, double min_elevation,
-                      int lon_wrap, const double* target_lat, const double* target_lon, const void* img, int32_t img_dtype,
-                      int32_t nchan, double* mean, void* out_img, uint8_t* out_mask, double* alt_mean, int64_t* out_triangles);
-
-/* method='cubic' (reference resample.py:323-326: scipy.interpolate.griddata(method='cubic') = CloughTocher2DInterpolator:
- * a C1 piecewise cubic on the Delaunay triangulation with globally estimated vertex gradients).  Two calls on the
- * triangulation of amt_linear_gather:
- * amt_cubic_gradients: the gradient (d/dlat, d/dlon) of every channel and of the elevation at every valid pixel centre,
- *   gradients (height * width, channels, 2), by Jacobi sweeps of scipy's estimator until the largest change (relative,
- *   as scipy measures it) is below `tolerance` (scipy: 1e-6 with its point-after-point relaxation; pass 1e-8 to be inside
- *   its noise) or max_iterations (scipy: 400) sweeps are done; *iterations (optional) = sweeps done.  Synchronises the
- *   context's stream (the convergence flag is read back every second sweep).  img_dtype 3 = float64 channels (arbitrary
- *   data, as `_resample` takes it); elev may be NULL (then no elevation channel and no threshold): 1..5 channels in all.
- * amt_cubic_gather: like amt_linear_gather with the Clough-Tocher element instead of the plane; out_img is np.round of the
- *   value cast like numpy casts (a cubic overshoots: out-of-range values wrap modulo the type's range). */
-int amt_cubic_gradients(amt_ctx* ctx, const double* lat_c, const double* lon_c, const double* elev, const uint8_t* center_mask,
-                        int32_t height, int32_t width, double min_elevation, int lon_wrap, const void* img, int32_t img_dtype,
-                        int32_t nchan, double tolerance, int32_t max_iterations, double* gradients, int32_t* iterations);
-int amt_cubic_gather(amt_ctx* ctx, const int64_t* index, int32_t ny, int32_t nx, const double* lat_c, const double* lon_c,
-                     const double* elev, const uint8_t* center_mask, int32_t height, int32_t width, double min_elevation,
-                     int lon_wrap, const double* target_lat, const double* target_lon, const void* img, int32_t img_dtype,
-                     int32_t nchan, const double* gradients, double* mean, void* out_img, uint8_t* out_mask, double* alt_mean,
-                     int64_t* out_triangles);
+/* method='linear' and 'cubic' (reference resample.py:323-326: scipy.interpolate.griddata on a Delaunay triangulation of the valid
+ * pixel centres) run on the exact triangulation below (amt_delaunay_*).  The lattice approximations of rounds 3-4
+ * (amt_linear_gather, amt_cubic_gradients, amt_cubic_gather: the Gauss-reduced local lattice of the pixel grid in place of
+ * Qhull's triangulation) were retired with ABI v6. */
 /* ---- method='cubic' on the exact triangulation (round 5) ----
  * scipy.interpolate.griddata(method='cubic'), the reference's call (resample.py:323-326), is CloughTocher2DInterpolator on
  * scipy.spatial.Delaunay(points): Qhull's Delaunay triangulation, gradients from a Gauss-Seidel relaxation over its edges in

@@ -232,8 +232,10 @@ def test_arc_sec_per_px():
 
 @pytest.mark.parametrize('dtype', [np.uint8, np.uint16])
 def test_pixel_polygons_for_drawing(dtype):
-    """draw_helpers.generatePolygonsFromMapping (draw_helpers.py:34-94, the call of mapping_test.py:16-23): the device
-    gather equals the reference's array expressions evaluated on the mapping's host arrays."""
+    """draw_helpers.generatePolygonsFromMapping (reference draw_helpers.py:34-94, the call of mapping_test.py:16-23), and
+    createPolygonsAndColors + filterNanPolygons on the mapping's arrays: every unmasked pixel in row-major order, its four
+    corners clockwise from the upper left as (lat, lon), its colour as the mapping's `rgb` gives it — written out here from
+    that definition, pixel by pixel."""
     from auromat_amd.draw_helpers import (ColorMode, createPolygonsAndColors, filterNanPolygons,
                                           generatePolygonsFromMapping)
     from auromat_amd.mapping.spacecraft import ArraySpacecraftMapping
@@ -242,15 +244,36 @@ def test_pixel_polygons_for_drawing(dtype):
     hdr, cam, t = frame_header(w, h, 'iss030')
     m = ArraySpacecraftMapping(hdr, 110, frame_image(w, h, seed=8, dtype=dtype), cam, t, 'd',
                                fastCenterCalculation=True).maskedByElevation(10)
+
+    def expected(lats, lons, as_float):
+        la, lo = ma.filled(lats, np.nan), ma.filled(lons, np.nan)
+        r, c = np.nonzero(~ma.getmaskarray(m.latsCenter))
+        verts = np.empty((len(r), 4, 2))
+        for k, (dr, dc) in enumerate(((0, 0), (0, 1), (1, 1), (1, 0))):
+            verts[:, k, 0], verts[:, k, 1] = la[r + dr, c + dc], lo[r + dr, c + dc]
+        rgb = ma.getdata(m.rgb)[r, c]
+        assert rgb.dtype == np.uint8
+        return verts, (rgb / 255.0 if as_float else rgb)
+
     for mode in (None, ColorMode.matplotlib):
+        wv, wc = expected(m.lats, m.lons, mode is not None)
         verts, colors = generatePolygonsFromMapping(m, mode)
-        wv, wc = filterNanPolygons(*createPolygonsAndColors(m.lats, m.lons, m.rgb, mode))
         assert verts.shape == wv.shape == (int((~ma.getmaskarray(m.latsCenter)).sum()), 4, 2)
         assert np.array_equal(verts, wv) and not np.isnan(verts).any()
         assert colors.dtype == wc.dtype and np.array_equal(colors, wc)
-    # other coordinates (MLat / MLT corners): the host path
+        # the two-step form on arrays: a polygon for every pixel, then those with a colour
+        av, ac = createPolygonsAndColors(m.lats, m.lons, m.rgb, mode)
+        assert av.shape == (w * h, 4, 2) and ac.shape == (w * h, 3) and ma.isMaskedArray(ac)
+        fv, fc = filterNanPolygons(av, ac)
+        assert np.array_equal(fv, wv) and fc.dtype == wc.dtype and np.array_equal(fc, wc)
+    # NaN colours (a float image with holes) are dropped like masked ones
+    fv, fc = filterNanPolygons(np.zeros((3, 4, 2)), np.array([[1.0, 1, 1], [np.nan, np.nan, np.nan], [0.5, 0, 0]]))
+    assert fv.shape == (2, 4, 2) and np.array_equal(fc, [[1.0, 1, 1], [0.5, 0, 0]])
+    # other coordinates (MLat / MLT corners) through coordsFn
+    mlat, mlt = m.mLatMlt
     v2, c2 = generatePolygonsFromMapping(m, None, coordsFn=lambda mp: mp.mLatMlt)
-    assert v2.shape == verts.shape and np.array_equal(c2, generatePolygonsFromMapping(m)[1])
+    wv, wc = expected(mlat, mlt, False)
+    assert np.array_equal(v2, wv) and np.array_equal(c2, wc)
 
 
 def test_pole_inside_a_hole_of_the_mapping():
