@@ -6,11 +6,14 @@ rc=0
 run() { echo "== $*"; timeout 600 "$@" < /dev/null 2>&1 | tail -1; [ ${PIPESTATUS[0]} -eq 0 ] || rc=1; }
 run python tools/fuzz_frames.py 800 $S
 run python tools/fuzz_dirs.py 400 $S
+PADDED=1 run python tools/fuzz_frames.py 400 $S
+PADDED=1 run python tools/fuzz_dirs.py 200 $S
 BIG=5 run python tools/fuzz_dirs.py 60 $S
 run python tools/fuzz_widened.py 800 $S
 run python tools/fuzz_ops.py 800 $S
 run python tools/fuzz_sequence.py 80 $S
 RESIDENT=1 run python tools/fuzz_sequence.py 80 $S
+PINNED=1 run python tools/fuzz_sequence.py 80 $S
 run python tools/fuzz_mapping.py 800 $S
 run python tools/fuzz_cubic.py 100 $S
 METHOD=linear run python tools/fuzz_cubic.py 100 $S

@@ -7,6 +7,7 @@ import os, sys
 from datetime import timedelta
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+PADDED = bool(os.environ.get('PADDED'))      # PADDED=1: the pipelines' buffers in strip-padded rows (round 6)
 from auromat_amd.mapping.astrometry import frame_params, pixelDirection
 from auromat_amd.pipeline import FramePipeline
 from auromat_amd.synthetic import frame_header, frame_image, pole_frame
@@ -81,7 +82,7 @@ for case in range(cases):
     dirs = np.ascontiguousarray(bend(pixelDirection(hdr, corner=True), k, roll))
     tag = '%d: %dx%d %s -%gmin alt %g ppd %s thr %s %s k %.2f roll %g%s' % (case, w, h, pointing, shift, alt, ppd, thr, dtype.__name__,
                                                                         k, roll, ' magnetic' if magnetic else '')
-    pipe = FramePipeline(w, h, img_dtype=dtype, with_mag=magnetic)
+    pipe = FramePipeline(w, h, img_dtype=dtype, with_mag=magnetic, padded=PADDED)
     dev = pipe.ctx.to_device(dirs)
     p = frame_params(hdr, alt, cam, t, True, magnetic=magnetic)
     try:

@@ -5,6 +5,7 @@ import os, sys
 from datetime import timedelta
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+PADDED = bool(os.environ.get('PADDED'))      # PADDED=1: the pipelines' buffers in strip-padded rows (round 6)
 from auromat_amd.pipeline import FramePipeline
 from auromat_amd.synthetic import frame_header, frame_image, pole_frame
 from oracle import ref_numpy as O
@@ -33,7 +34,7 @@ for case in range(cases):
     tag = '%d: %dx%d %s -%gmin alt %g ppd %s %s thr %s %s%s' % (case, w, h, pointing, shift, alt, ppd,
                                                                  'fast' if fast else 'exact', thr, dtype.__name__,
                                                                  ' magnetic' if magnetic else (' with_mag' if with_mag else ''))
-    pipe = FramePipeline(w, h, img_dtype=dtype, with_mag=with_mag)
+    pipe = FramePipeline(w, h, img_dtype=dtype, with_mag=with_mag, padded=PADDED)
     try:
         two = pipe.run(hdr, alt, cam, t, img=img, fast=fast, min_elevation=thr, pxPerDeg=ppd, fuse=False,
                        magnetic=magnetic)
@@ -57,7 +58,7 @@ for case in range(cases):
                 break
     if magnetic:
         # round 4, MLat / MLT-only mode (k_georef_rows<SECOND = 4>): the same grid, and the five arrays it keeps, bit for bit
-        lean = FramePipeline(w, h, img_dtype=dtype, with_mag=True, with_geo=False)
+        lean = FramePipeline(w, h, img_dtype=dtype, with_mag=True, with_geo=False, padded=PADDED)
         five = lean.run(hdr, alt, cam, t, img=img, fast=fast, min_elevation=thr, pxPerDeg=ppd, fuse=True, magnetic=True)
         for k in ('mean', 'count', 'img', 'mask'):
             if not np.array_equal(five[k], two[k], equal_nan=True):

@@ -1,6 +1,7 @@
 """Sequence fuzz: frames that do NOT follow each other smoothly (random pointings, times up to 95 min apart — date-line
 and pole frames included —, jumps back and forth, repeated frames) through SequencePipeline with every plan / batch
 size and hints on, against one frame at a time.  usage: fuzz_sequence.py [sequences] [seed]
+PINNED=1: the images are pinned host tensors (the library's loop uploads the rows that can be binned: amt_run_frame.img_host).
 RESIDENT=1: the images are device tensors, which sends the sequence through the frame loop in the library (amt_run_*: the
 single-pass plan, its hand-backs and the two-pass plan natively) instead of the Python loop."""
 import os, sys
@@ -31,6 +32,10 @@ for s in range(nseq):
         import torch
         from auromat_amd.resample import grid_coordinates
         feed = frames
+        if os.environ.get('PINNED'):
+            # (round 6) images in page-locked host memory: the library's loop uploads the rows that can be binned (img_host)
+            feed = [(hd, cam, t, torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img).pin_memory(), alt)
+                    for hd, cam, t, img, alt in frames]
         if os.environ.get('RESIDENT'):
             feed = [(hd, cam, t, torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img).cuda()) for hd, cam, t, img, alt in frames]
             feed = [f + (alt,) for f, alt in zip(feed, alts)]
@@ -63,6 +68,9 @@ for s in range(nseq):
     for batch in (1, 3):
         feed = frames
         kw = {}
+        if os.environ.get('PINNED'):
+            feed = [(hd, cam, t, torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img).pin_memory(), alt)
+                    for hd, cam, t, img, alt in frames]
         if os.environ.get('RESIDENT'):
             feed = [(hd, cam, t, torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img).cuda(), alt)
                     for hd, cam, t, img, alt in frames]
