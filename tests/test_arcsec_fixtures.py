@@ -134,7 +134,7 @@ def test_box_first_plan_equals_the_references_grids(tag, magnetic):
     seq = SequencePipeline(4256, 2832, img_dtype=np.uint8, altitude=110, fast=True, min_elevation=10, arcsecPerPx=100,
                            magnetic=magnetic, keep_coordinates=False)
     import torch
-    dev_img = torch.from_numpy(img).to(seq.ctx.device)
+    dev_img = torch.from_numpy(np.array(img)).to(seq.ctx.device)
     out = seq.process([(hdr, cam, t, dev_img)] * 4, keep_on_device=False)
     assert seq.plans == ['single-pass'] * 4
     for q in out:
