@@ -36,6 +36,16 @@
 
 #include "../../include/auromat_hip.h"
 
+#ifdef AMT_DELAUNAY_STANDALONE
+// (this file alone as a host library — tools/asan_delaunay.py builds it with g++ under the sanitizers —: the one function it takes
+// from the rest of the library)
+extern "C" int amt_host_threads(int wanted, int* cores, int* local_ranks) {
+    if (cores) *cores = (int)std::thread::hardware_concurrency();
+    if (local_ranks) *local_ranks = 1;
+    return wanted < 1 ? 1 : wanted;
+}
+#endif
+
 namespace {
 
 // How often the predicates had to leave double precision, and how often the wider evaluation still could not tell (a tie: four
@@ -797,6 +807,10 @@ struct amt_delaunay {
         lap("neighbours");
     }
 
+    // `tri` / `nbr` (the finite triangles, renumbered) are made when somebody asks for them — amt_delaunay_triangles, the vertex
+    // lists —; point location alone ('linear') walks the build's own structure (v / adj: ghosts and dead slots skipped)
+    bool compacted = false;
+    int first_finite = -1;          // the finite triangle with the lowest slot: where every piece of targets starts its walk
     // vertex -> neighbouring vertices, made when somebody asks for them ('linear' never does)
     bool lists_made = false;
     void build_vertex_lists() {
@@ -852,7 +866,26 @@ namespace {
 // (a handle is const to its readers; the lists are its cache.  One lock for all handles: the build is what takes the time)
 // -> AMT_OK, or AMT_ENOMEM / AMT_EHIP when the lists could not be made (no memory for ~140 MB of lists at full frame size, no
 // thread to be had): nothing escapes into the C ABI, and `lists_made` stays false so that a later call tries again
+int ensure_compact(const amt_delaunay* d) {
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
+    amt_delaunay* m = const_cast<amt_delaunay*>(d);
+    if (m->compacted) return AMT_OK;
+    try {
+        m->compact();
+        m->compacted = true;
+    } catch (const std::bad_alloc&) {
+        m->tri.clear(), m->nbr.clear();
+        return AMT_ENOMEM;
+    } catch (...) {
+        m->tri.clear(), m->nbr.clear();
+        return AMT_EHIP;
+    }
+    return AMT_OK;
+}
+
 int ensure_vertex_lists(const amt_delaunay* d) {
+    if (int rc = ensure_compact(d)) return rc;
     static std::mutex lock;
     std::lock_guard<std::mutex> guard(lock);
     amt_delaunay* m = const_cast<amt_delaunay*>(d);
@@ -926,7 +959,14 @@ int amt_delaunay_create_threads(const double* xy, int64_t n, int32_t threads, in
             delete d;
             return AMT_EINVAL;         // fewer than three points that are not collinear
         }
-        d->compact();
+        // (no compaction here: see `compacted`)
+        const int slots = (int)d->dead.size();
+        for (int t = 0; t < slots && d->first_finite < 0; ++t)
+            if (!d->dead[t] && d->v[3 * t] != kInf && d->v[3 * t + 1] != kInf && d->v[3 * t + 2] != kInf) d->first_finite = t;
+        if (d->first_finite < 0) {
+            delete d;
+            return AMT_EINVAL;
+        }
     } catch (const std::bad_alloc&) {
         g_stats = nullptr;
         delete d;
@@ -952,7 +992,10 @@ int amt_delaunay_destroy(amt_delaunay* d) {
 
 int amt_delaunay_sizes(const amt_delaunay* d, int64_t* n_triangles, int64_t* n_neighbours, int64_t* n_duplicates) {
     if (d == nullptr) return AMT_EINVAL;
-    if (n_triangles) *n_triangles = (int64_t)(d->tri.size() / 3);
+    if (n_triangles) {
+        if (int rc = ensure_compact(d)) return rc;
+        *n_triangles = (int64_t)(d->tri.size() / 3);
+    }
     if (n_neighbours) {
         if (int rc = ensure_vertex_lists(d)) return rc;
         *n_neighbours = (int64_t)d->indices.size();
@@ -970,6 +1013,7 @@ int amt_delaunay_stats(const amt_delaunay* d, int64_t* stats4) {
 
 int amt_delaunay_triangles(const amt_delaunay* d, int32_t* simplices, int32_t* neighbours) {
     if (d == nullptr) return AMT_EINVAL;
+    if (int rc = ensure_compact(d)) return rc;
     if (simplices) std::memcpy(simplices, d->tri.data(), d->tri.size() * sizeof(int32_t));
     if (neighbours) std::memcpy(neighbours, d->nbr.data(), d->nbr.size() * sizeof(int32_t));
     return AMT_OK;
@@ -987,8 +1031,14 @@ int amt_delaunay_locate(const amt_delaunay* d, const double* targets, int64_t m,
                         uint8_t* has_neighbour) {
     if (d == nullptr || targets == nullptr || vertices == nullptr || centroids == nullptr || has_neighbour == nullptr || m < 0)
         return AMT_EINVAL;
-    const size_t nt = d->tri.size() / 3;
-    if (nt == 0) return AMT_EINVAL;
+    // The walk runs on the build's own structure (slots of v / adj: ghost triangles carry kInf, dead slots are never reached from a
+    // live one) — the same triangles in the same order with the same corner order as the compacted lists, so the answers are those
+    // a walk over `tri` / `nbr` gives (every piece starts at the finite triangle with the lowest slot = compacted triangle 0).
+    const size_t nt = d->dead.size();
+    if (nt == 0 || d->first_finite < 0) return AMT_EINVAL;
+    const int* V = d->v.data();
+    const int* A = d->adj.data();
+    auto ghost = [&](int t) { return V[3 * (size_t)t] == kInf || V[3 * (size_t)t + 1] == kInf || V[3 * (size_t)t + 2] == kInf; };
     // (targets in pieces on threads: every piece walks on from its own previous target; the answers do not depend on the pieces —
     // a target on an edge or a vertex gets the triangle the walk from ITS predecessor reaches first, so pieces are cut at fixed
     // multiples of 1024 targets whatever the number of threads)
@@ -997,7 +1047,7 @@ int amt_delaunay_locate(const amt_delaunay* d, const double* targets, int64_t m,
     try {
     on_threads(T, [&](int part) {
     for (int64_t pc = part; pc < pieces; pc += T) {
-    int t = 0;
+    int t = d->first_finite;
     for (int64_t i = pc * piece; i < std::min(m, (pc + 1) * piece); ++i) {
         const pt q = {targets[2 * i], targets[2 * i + 1]};
         int32_t* vo = vertices + 3 * i;
@@ -1011,7 +1061,7 @@ int amt_delaunay_locate(const amt_delaunay* d, const double* targets, int64_t m,
         bool inside = false;
         for (;;) {
             if (--guard < 0) break;
-            const int* w = &d->tri[3 * (size_t)t];
+            const int* w = &V[3 * (size_t)t];
             int k;
             for (k = 0; k < 3; ++k)
                 if (orient2d(d->p[w[(k + 1) % 3]], d->p[w[(k + 2) % 3]], q) < 0) break;
@@ -1019,17 +1069,17 @@ int amt_delaunay_locate(const amt_delaunay* d, const double* targets, int64_t m,
                 inside = true;
                 break;
             }
-            const int n = d->nbr[3 * (size_t)t + k];
-            if (n < 0) break;
+            const int n = A[3 * (size_t)t + k];
+            if (n < 0 || ghost(n)) break;
             t = n;
         }
         if (!inside) continue;
-        const int* w = &d->tri[3 * (size_t)t];
+        const int* w = &V[3 * (size_t)t];
         for (int k = 0; k < 3; ++k) {
             vo[k] = w[k];
-            const int n = d->nbr[3 * (size_t)t + k];
-            if (n >= 0) {
-                const int* u = &d->tri[3 * (size_t)n];
+            const int n = A[3 * (size_t)t + k];
+            if (n >= 0 && !ghost(n)) {
+                const int* u = &V[3 * (size_t)n];
                 has_neighbour[3 * i + k] = 1;
                 centroids[6 * i + 2 * k] = (d->p[u[0]].x + d->p[u[1]].x + d->p[u[2]].x) / 3;
                 centroids[6 * i + 2 * k + 1] = (d->p[u[0]].y + d->p[u[1]].y + d->p[u[2]].y) / 3;

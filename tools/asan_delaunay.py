@@ -2,10 +2,10 @@
 allows no sanitizer runs): the reference's fixtures, an exact lattice (ties everywhere), duplicates, collinear and tiny inputs, NaN
 targets, random clouds at several scales — through the sequential build and through the parallel one (strips on threads, joined
 at their seams).  usage (build container):
-  g++ -O1 -g -std=c++17 -pthread -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -x c++ -o /tmp/libdel_asan.so auromat_amd/csrc/amt_delaunay.hip
+  g++ -O1 -g -std=c++17 -pthread -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -DAMT_DELAUNAY_STANDALONE -x c++ -o /tmp/libdel_asan.so auromat_amd/csrc/amt_delaunay.hip
   LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python tools/asan_delaunay.py
 and under ThreadSanitizer (the strips, the copy into one structure and the compaction run on threads):
-  g++ -O1 -g -std=c++17 -pthread -fPIC -shared -fsanitize=thread -x c++ -o /tmp/libdel_asan.so auromat_amd/csrc/amt_delaunay.hip
+  g++ -O1 -g -std=c++17 -pthread -fPIC -shared -fsanitize=thread -DAMT_DELAUNAY_STANDALONE -x c++ -o /tmp/libdel_asan.so auromat_amd/csrc/amt_delaunay.hip
   LD_PRELOAD=$(g++ -print-file-name=libtsan.so) python tools/asan_delaunay.py"""
 import ctypes as C, numpy as np, sys
 lib=C.CDLL('/tmp/libdel_asan.so')
