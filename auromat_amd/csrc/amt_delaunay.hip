@@ -661,9 +661,26 @@ struct amt_delaunay {
         K = (int)cut.size() + 1;
         if (K < 2) return false;
         auto strip_of = [&](double x) { return (int)(std::upper_bound(cut.begin(), cut.end(), x) - cut.begin()); };
+        // (every thread sorts a contiguous piece of the points into strips; a strip's members are the pieces' lists one after the
+        // other, i.e. in increasing order of the point index, as one pass over all points would leave them)
         std::vector<std::vector<int>> members((size_t)K);
-        for (int j = 0; j < K; ++j) members[(size_t)j].reserve((size_t)n / K + 1024);
-        for (int i = 0; i < n; ++i) members[(size_t)strip_of(p[i].x)].push_back(i);
+        {
+            const int P = std::max(1, std::min(threads, n / 262144));
+            std::vector<std::vector<std::vector<int>>> mine((size_t)P, std::vector<std::vector<int>>((size_t)K));
+            on_threads(P, [&](int q) {
+                const int a = (int)((int64_t)n * q / P), b = (int)((int64_t)n * (q + 1) / P);
+                for (int j = 0; j < K; ++j) mine[(size_t)q][(size_t)j].reserve((size_t)(b - a) / K + 1024);
+                for (int i = a; i < b; ++i) mine[(size_t)q][(size_t)strip_of(p[i].x)].push_back(i);
+            });
+            on_threads(std::min(K, threads), [&](int t) {
+                for (int j = t; j < K; j += std::min(K, threads)) {
+                    size_t total = 0;
+                    for (int q = 0; q < P; ++q) total += mine[(size_t)q][(size_t)j].size();
+                    members[(size_t)j].reserve(total);
+                    for (int q = 0; q < P; ++q) members[(size_t)j].insert(members[(size_t)j].end(), mine[(size_t)q][(size_t)j].begin(), mine[(size_t)q][(size_t)j].end());
+                }
+            });
+        }
         for (int j = 0; j < K; ++j)
             if (members[(size_t)j].size() < 64) return false;
         lap("partition");
