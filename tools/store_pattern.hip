@@ -129,7 +129,8 @@ static float run(double** a, int spin, int sky, unsigned lds, int stride, int sw
 //   L3  as L2, lane 63 does not store (504-byte runs on 512-byte boundaries)
 __global__ __launch_bounds__(256) void k_layout(double* __restrict__ a0, double* __restrict__ a1, double* __restrict__ a2,
                                                 double* __restrict__ a3, double* __restrict__ a4, int spin, int first_earth_chunk, int stride,
-                                                int sw, int slot, int pitch_corner, int pitch_pixel, int store_lanes, int with_stores) {
+                                                int sw, int slot, int pitch_corner, int pitch_pixel, int store_lanes, int with_stores,
+                                                int dist_fill = 0) {
     extern __shared__ double occupancy_limiter[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wave;
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256) void k_layout(double* __restrict__ a0, double*
     const int pitch[NARR] = {pitch_corner, pitch_corner, pitch_pixel, pitch_pixel, pitch_pixel};
     if (spin < 0) occupancy_limiter[threadIdx.x] = 0.0;
     if (chunk < first_earth_chunk) {
+        if (dist_fill) return;            // (the Earth items write the sky rows, a slice after each of their own rows)
         for (int k = 0; k < NARR; ++k) {
             const long long first = (long long)y0 * pitch[k], count = (long long)ROWS * pitch[k];
             long long a = first + count * strip / strips, b = first + count * (strip + 1) / strips;
@@ -154,6 +156,16 @@ __global__ __launch_bounds__(256) void k_layout(double* __restrict__ a0, double*
     }
     const bool ok = lane < store_lanes && col < pitch_pixel && strip * sw + lane < W + (store_lanes == 64 && slot == 64 && sw == 63 ? 1 : 0);
     double v = (double)col;
+    const long long n_e = (long long)(CHUNKS - first_earth_chunk) * strips, e = (long long)(chunk - first_earth_chunk) * strips + strip;
+    // (this wave's share of the sky rows of every array, in units of 128-byte lines; computed once: 64-bit divisions are slow)
+    unsigned int l0[NARR], ln[NARR];
+    if (dist_fill) {
+        for (int k = 0; k < NARR; ++k) {
+            const long long lines = (long long)first_earth_chunk * ROWS * pitch[k] / 16;
+            const long long a = lines * e / n_e, b = lines * (e + 1) / n_e;
+            l0[k] = (unsigned int)a, ln[k] = (unsigned int)(b - a);
+        }
+    }
     for (int r = 0; r < ROWS && y0 + r < H; ++r) {
         v = work(v, spin);
         if (with_stores) {
@@ -161,13 +173,23 @@ __global__ __launch_bounds__(256) void k_layout(double* __restrict__ a0, double*
 #pragma unroll
                 for (int k = 0; k < NARR; ++k) arr[k][(long long)(y0 + r) * pitch[k] + col] = v + k;
             }
+            if (dist_fill) {
+                // this wave's share of the sky rows of every array, one sixteenth of it per row step, whole lines
+                for (int k = 0; k < NARR; ++k) {
+                    const unsigned int a = l0[k] + ((ln[k] * (unsigned int)r) >> 4), b = l0[k] + ((ln[k] * (unsigned int)(r + 1)) >> 4);
+                    const double2 two = {1.0, 2.0};
+                    // a line is 8 lanes x 16 bytes: the wave writes 8 lines per pass
+                    for (unsigned int line = a + (lane >> 3); line < b; line += 8)
+                        *reinterpret_cast<double2*>(arr[k] + (size_t)line * 16 + 2 * (lane & 7)) = two;
+                }
+            }
         } else if (ok && v == 12345.678) arr[0][col] = v;
     }
 }
 
 struct layout { const char* name; int sw, slot, pitch_corner, pitch_pixel, store_lanes; };
 
-static float run_layout(double** a, const layout& L, int spin, int sky, int with_stores, int reps) {
+static float run_layout(double** a, const layout& L, int spin, int sky, int with_stores, int reps, int dist_fill = 0, int stride = 76) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
@@ -175,8 +197,8 @@ static float run_layout(double** a, const layout& L, int spin, int sky, int with
     std::vector<float> t;
     for (int rep = 0; rep < reps + 2; ++rep) {
         (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_layout, dim3(blocks), dim3(256), 28000u, 0, a[0], a[1], a[2], a[3], a[4], spin, sky, 76, L.sw, L.slot,
-                           L.pitch_corner, L.pitch_pixel, L.store_lanes, with_stores);
+        hipLaunchKernelGGL(k_layout, dim3(blocks), dim3(256), 28000u, 0, a[0], a[1], a[2], a[3], a[4], spin, sky, stride, L.sw, L.slot,
+                           L.pitch_corner, L.pitch_pixel, L.store_lanes, with_stores, dist_fill);
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
         float ms;
@@ -187,6 +209,26 @@ static float run_layout(double** a, const layout& L, int spin, int sky, int with
     (void)hipEventDestroy(e1);
     std::sort(t.begin(), t.end());
     return t[t.size() / 2];
+}
+
+// Round 6, second question: WHEN the sky rows are written.  Padded layout L2 throughout; (a) sky rows of items first, then the Earth's
+// (the kernel's order), (b) the two kinds alternating, (c) no sky items at all: every Earth wave writes a sixteenth of its share of the
+// sky after each of its own rows (the fill's traffic spread evenly over the launch).
+static void fill_schedules(double** a, int sky) {
+    const layout L2 = {"L2", 63, 64, 4352, 4352, 64};
+    std::printf("when the sky is written (padded rows; median of 5 passes x 9 launches; us)\n");
+    std::printf("  spin | work alone | sky first | alternating | spread over the Earth waves\n");
+    for (int spin : {0, 20, 25, 30, 35, 40}) {
+        std::vector<float> m[4];
+        for (int pass = 0; pass < 5; ++pass) {
+            m[0].push_back(run_layout(a, L2, spin, sky, 0, 9));
+            m[1].push_back(run_layout(a, L2, spin, sky, 1, 9, 0, 1));
+            m[2].push_back(run_layout(a, L2, spin, sky, 1, 9, 0, 76));
+            m[3].push_back(run_layout(a, L2, spin, sky, 1, 9, 1, 1));
+        }
+        auto med = [](std::vector<float>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        std::printf("  %4d | %10.1f | %9.1f | %11.1f | %9.1f\n", spin, med(m[0]), med(m[1]), med(m[2]), med(m[3]));
+    }
 }
 
 static void layouts(double** a, int sky) {
@@ -220,6 +262,7 @@ int main() {
     double* a[NARR];
     for (int k = 0; k < NARR; ++k) (void)hipMalloc(&a[k], ((size_t)4352 * (H + 2) + 64) * sizeof(double));
     const int sky = (int)(0.43 * CHUNKS);
+    if (std::getenv("FILL_ONLY")) { fill_schedules(a, sky); return 0; }
     if (std::getenv("LAYOUTS_ONLY")) { layouts(a, sky); return 0; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pattern<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pattern<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
