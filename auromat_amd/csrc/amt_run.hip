@@ -1,6 +1,7 @@
 // Native sequence runner (include/auromat_hip.h, "native sequence runner"): the per-frame host loop of a sequence —
 // host scalars, box hints, launches, waits, grid layouts, finalise kernels — in one C call.  Host orchestration only;
 // it drives the single-pass frame drivers of amt_pipe.hip through their public entry points.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -625,6 +626,14 @@ int amt_run_end(amt_run* run, int32_t* frames_done) {
         if (rc_all == AMT_OK) rc_all = rc;
     }
     run->n_launched = run->n_boxed = 0;
+    // host images are read "until amt_run_end returns": the upload of a frame that was pushed but never launched (arenas full, a
+    // failed call) may still be in flight
+    if (run->copy_stream != nullptr && hipStreamSynchronize(run->copy_stream) != hipSuccess && rc_all == AMT_OK) {
+        (void)hipGetLastError();
+        ctx->last_error = "amt_run_end: the copy stream failed";
+        rc_all = AMT_EHIP;
+    }
+    std::fill(run->upload_pending.begin(), run->upload_pending.end(), 0);
     // order the context's stream behind every finalise kernel of this call
     for (amt_pipe* p : run->pipes) {
         const int rc = amt_pipe_join(p);
