@@ -167,6 +167,7 @@ _SIGNATURES = {
     'amt_delaunay_destroy': ([_P], _I),
     'amt_delaunay_sizes': ([_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], _I),
     'amt_delaunay_stats': ([_P, _P], _I),
+    'amt_delaunay_slots': ([_P, c_void_pp, c_void_pp, C.POINTER(C.c_int64)], _I),
     'amt_delaunay_create_threads': ([_P, C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)], _I),
     'amt_delaunay_build_info': ([_P, _P], _I),
     'amt_delaunay_triangles': ([_P, _P, _P], _I),

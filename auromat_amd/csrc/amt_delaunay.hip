@@ -1021,6 +1021,15 @@ int amt_delaunay_sizes(const amt_delaunay* d, int64_t* n_triangles, int64_t* n_n
     return AMT_OK;
 }
 
+int amt_delaunay_slots(const amt_delaunay* d, const int32_t** vertices, const uint8_t** dead, int64_t* n_slots) {
+    if (d == nullptr || vertices == nullptr || dead == nullptr || n_slots == nullptr) return AMT_EINVAL;
+    static_assert(sizeof(int) == sizeof(int32_t) && sizeof(char) == sizeof(uint8_t), "the structure's arrays as the ABI names them");
+    *vertices = reinterpret_cast<const int32_t*>(d->v.data());
+    *dead = reinterpret_cast<const uint8_t*>(d->dead.data());
+    *n_slots = (int64_t)d->dead.size();
+    return AMT_OK;
+}
+
 int amt_delaunay_stats(const amt_delaunay* d, int64_t* stats4) {
     if (d == nullptr || stats4 == nullptr) return AMT_EINVAL;
     stats4[0] = d->stats.orient_wide, stats4[1] = d->stats.orient_zero;

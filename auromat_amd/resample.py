@@ -405,19 +405,16 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask, 
     mark('triangulation')
     try:
         if method != 'linear':
-            # the vertices' neighbour lists (the library makes them when they are first asked for: 'linear' never does)
-            nt, nn, nd = C.c_int64(), C.c_int64(), C.c_int64()
-            rc = L.amt_delaunay_sizes(handle, C.byref(nt), C.byref(nn), C.byref(nd))
-            if rc != 0:
-                raise MemoryError("method='cubic': the vertex lists of the triangulation could not be made (status %d)" % rc)
-            indptr, indices = np.empty(n + 1, dtype=np.int64), np.empty(nn.value, dtype=np.int32)
-            rc = L.amt_delaunay_vertex_neighbours(handle, indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p))
-            assert rc == 0, rc
+            # the vertices' neighbour lists (scipy.spatial.Delaunay.vertex_neighbor_vertices, every list in increasing order), made
+            # ON THE DEVICE from the build's own triangle slots (amt_delaunay_slots: no compaction, no list building, no 190 MB of
+            # lists over the link — the host spent 0.2 s on those): every finite triangle gives the directed edges v1 -> v2,
+            # v2 -> v0, v0 -> v1; an inner edge comes up once in each direction (from its two triangles), a hull edge once and
+            # gets its reverse here; sorted by (source, target) they are the CSR the relaxation walks
+            d_indptr, d_indices = device_vertex_lists(ctx, L, handle, n)
             rows = torch.div(idx, int(width), rounding_mode='floor')
             row_start = torch.zeros(int(height) + 1, dtype=torch.int64, device=ctx.device)
             row_start[1:] = torch.cumsum(torch.bincount(rows, minlength=int(height)), 0)
-            d_indptr, d_indices = ctx.to_device(indptr, np.int64), ctx.to_device(indices, np.int32)
-            mark('neighbour lists to the device')
+            mark('neighbour lists on the device')
         # the grid centres that are wanted, in row-major order (the walk from one to the next is a step or two)
         wanted = np.ones((grid.ny, grid.nx), dtype=bool) if target_mask is None else ~to_host(target_mask).astype(bool)
         sel = np.flatnonzero(wanted.ravel())
@@ -480,6 +477,38 @@ def cubic_exact(ctx, lat, lon, valid, values, height, width, grid, target_mask, 
         if debug:
             print('cubic_exact: ' + ', '.join('%s %.3f s' % (b[0], b[1] - a[1]) for a, b in zip(marks, marks[1:])))
     return out, sweeps_all
+
+
+def device_vertex_lists(ctx, L, handle, n):
+    """(indptr (n + 1) int64, indices int32) on the device: the vertex neighbour lists of a triangulation made by
+    amt_delaunay_create*, equal to amt_delaunay_vertex_neighbours' (tests/test_gpu_nearest.py)."""
+    import torch
+    pv, pd, ns = C.c_void_p(), C.c_void_p(), C.c_int64()
+    rc = L.amt_delaunay_slots(handle, C.byref(pv), C.byref(pd), C.byref(ns))
+    assert rc == 0 and ns.value > 0, rc
+    slots = int(ns.value)
+    v_host = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_int32)), shape=(slots, 3))
+    dead_host = np.ctypeslib.as_array(C.cast(pd, C.POINTER(C.c_uint8)), shape=(slots,))
+    v = ctx.to_device(v_host, np.int32)
+    dead = ctx.to_device(dead_host, np.uint8)
+    tri = v[(dead == 0) & (v >= 0).all(dim=1)].to(torch.int64)            # finite triangles (a ghost carries -1)
+    del v, dead
+    src = torch.cat((tri[:, 1], tri[:, 2], tri[:, 0]))
+    dst = torch.cat((tri[:, 2], tri[:, 0], tri[:, 1]))
+    del tri
+    key = torch.sort((src << 32) | dst).values
+    rev = (dst << 32) | src
+    del src, dst
+    at = torch.searchsorted(key, rev).clamp(max=key.numel() - 1)
+    hull = rev[key[at] != rev]                                             # reverses that no triangle supplies: hull edges
+    del at, rev
+    if hull.numel():
+        key = torch.sort(torch.cat((key, hull))).values
+    source = key >> 32
+    indices = (key & 0xffffffff).to(torch.int32)
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=ctx.device)
+    indptr[1:] = torch.cumsum(torch.bincount(source, minlength=n), 0)
+    return indptr, indices.contiguous()
 
 
 def outside_outline_mask(ctx, grid, outline):

@@ -536,6 +536,13 @@ int amt_nearest_gather(amt_ctx* ctx, const int64_t* index, int64_t n_targets, co
  *                                 or -1 (scipy.spatial.Delaunay.simplices / .neighbors, in another order of triangles)
  *   amt_delaunay_vertex_neighbours   CSR (indptr (n + 1) int64, indices int32): Delaunay.vertex_neighbor_vertices, every vertex's
  *                                 list in increasing order (made on first request: this call or amt_delaunay_sizes' n_neighbours)
+ *   amt_delaunay_slots    (ABI v6) the build's own triangle slots without a copy: *vertices (n_slots, 3) int32, counter-clockwise,
+ *                         -1 = the vertex at infinity of a ghost triangle (one per hull edge), and *dead (n_slots) uint8, 1 = a
+ *                         slot that holds no triangle; host pointers into the handle, valid until amt_delaunay_destroy.  A caller
+ *                         that wants the vertex lists ON THE DEVICE uploads these two arrays and builds the lists there (every
+ *                         finite triangle gives the directed edges v1 -> v2, v2 -> v0, v0 -> v1; an edge without its reverse is a
+ *                         hull edge and gets it; sorted by (source, target) they are the CSR above) instead of waiting for the
+ *                         host to make and copy them: auromat_amd.resample.cubic_exact
  *   amt_delaunay_locate   for m targets (m, 2): the vertices (m, 3) of the triangle that holds each (-1: outside the hull), the
  *                         centroids (m, 3, 2) of the triangles across its three edges and has_neighbour (m, 3)
  *   amt_cubic_gradients_csr   DEVICE: interpnd._estimate_gradients_2d_global in scipy's order — every channel relaxed until the
@@ -552,6 +559,7 @@ int amt_delaunay_destroy(amt_delaunay* d);
 int amt_delaunay_sizes(const amt_delaunay* d, int64_t* n_triangles, int64_t* n_neighbours, int64_t* n_duplicates);
 int amt_delaunay_stats(const amt_delaunay* d, int64_t* stats4);
 int amt_delaunay_triangles(const amt_delaunay* d, int32_t* simplices, int32_t* neighbours);
+int amt_delaunay_slots(const amt_delaunay* d, const int32_t** vertices, const uint8_t** dead, int64_t* n_slots);
 int amt_delaunay_vertex_neighbours(const amt_delaunay* d, int64_t* indptr, int32_t* indices);
 int amt_delaunay_locate(const amt_delaunay* d, const double* targets, int64_t m, int32_t* vertices, double* centroids,
                         uint8_t* has_neighbour);

@@ -553,3 +553,35 @@ def test_cubic_full_size_reproduces_a_plane():
     both = keep & ~np.isnan(lin)
     assert both.sum() == keep.sum()
     assert np.abs(lin - out[..., 2])[both].max() < 1e-3
+
+
+def test_vertex_lists_built_on_the_device_equal_the_hosts():
+    """resample.device_vertex_lists (round 6: the neighbour lists of scipy's gradient estimator made on the device from the
+    triangulator's own slots, amt_delaunay_slots) against amt_delaunay_vertex_neighbours: the same CSR — point clouds, a lattice
+    with ties, duplicate points (which have no neighbours), and the parallel build of a large cloud."""
+    import ctypes as C
+    from auromat_amd._native import Context, lib, to_host
+    from auromat_amd.resample import device_vertex_lists
+    ctx = Context.current()
+    L = lib()
+    rng = np.random.RandomState(4)
+    g = np.column_stack([a.ravel() for a in np.mgrid[0:30, 0:41].astype(float)])
+    clouds = [rng.uniform(0, 1, (2000, 2)), g + 0.01 * rng.standard_normal(g.shape), g, np.vstack((rng.uniform(0, 1, (500, 2)),) * 2),
+              rng.uniform(0, 1, (300000, 2))]
+    for k, pts in enumerate(clouds):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        n = len(pts)
+        h = C.c_void_p()
+        assert L.amt_delaunay_create_threads(pts.ctypes.data_as(C.c_void_p), n, 4, 50000, C.byref(h)) == 0
+        try:
+            indptr, indices = device_vertex_lists(ctx, L, h, n)
+            nt, nn, nd = C.c_int64(), C.c_int64(), C.c_int64()
+            assert L.amt_delaunay_sizes(h, C.byref(nt), C.byref(nn), C.byref(nd)) == 0
+            want_p, want_i = np.empty(n + 1, np.int64), np.empty(nn.value, np.int32)
+            assert L.amt_delaunay_vertex_neighbours(h, want_p.ctypes.data_as(C.c_void_p), want_i.ctypes.data_as(C.c_void_p)) == 0
+        finally:
+            L.amt_delaunay_destroy(h)
+        assert np.array_equal(to_host(indptr, dtype=np.int64), want_p), k
+        assert np.array_equal(to_host(indices, dtype=np.int32), want_i), k
+        if k == 3:
+            assert nd.value == 500 and (np.diff(want_p) == 0).sum() == 500          # the duplicates: no neighbours
