@@ -837,6 +837,70 @@ def test_direction_array_single_pass_full_size_equals_the_camera_model():
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize('padded', [False, True])
+def test_direction_arrays_three_frames_per_launch_equal_single_launches(padded):
+    """amt_pipe_launch_dirs_many (FramePipeline.georef_many(dirs=...), the form bench.py's directions_in leg runs): three
+    DIFFERENT frames and images in one launch of k_georef_rows<DIRS_IN, BIN> against one run(dirs=...) per frame — every
+    grid and every kept coordinate array bit for bit, in both row layouts; then the entry point's argument checks."""
+    import ctypes as C
+    import torch
+    from auromat_amd._native import NativeError
+    from auromat_amd.coordinates.wcs import pix2world
+    from auromat_amd.mapping.astrometry import frame_params
+    from auromat_amd.pipeline import FramePipeline
+    from auromat_amd.synthetic import frame_image, sequence_frame
+    w, h = 1061, 707
+    frames, imgs = [], []
+    for k in range(3):
+        hdr, cam, t, _ = sequence_frame(40 + 9 * k, w, h)
+        imgs.append(frame_image(w, h, seed=20 + k))
+        frames.append((hdr, cam, t))
+    pipes = [FramePipeline(w, h, padded=padded) for _ in range(3)]
+    ctx = pipes[0].ctx
+    ps = [frame_params(hdr, 110, cam, t, True, magnetic=False) for hdr, cam, t in frames]
+    ds = [pix2world(hdr, w, h, corner=True, ascartesian=True, device=ctx.device) for hdr, cam, t in frames]
+    single = []
+    one = FramePipeline(w, h, padded=False)
+    for (hdr, cam, t), p, d, img in zip(frames, ps, ds, imgs):
+        r = one.run(None, 110, cam, t, img=img, fast=True, min_elevation=10, pxPerDeg=9, fuse=True, params=p, dirs=d)
+        assert one.last_plan == 'single-pass'
+        r['coords'] = {k: one.fd.host(k).copy() for k in ('lat', 'lon', 'lat_c', 'lon_c', 'elev')}
+        single.append(r)
+    for q, p, d, img in zip(pipes, ps, ds, imgs):
+        q.use_image(torch.from_numpy(np.ascontiguousarray(img).view(np.int16)).to(ctx.device))
+        q.start_coarse(p, 10, False, dirs=d)
+    FramePipeline.georef_many(pipes, ps, 110, 10, (9, 9), False, dirs=ds, pole_in_view=0)
+    assert ctx.last_variant()[1] == 2
+    ready = [q.fused_ready((9, 9), False) for q in pipes]
+    assert all(r is not None for r in ready)
+    out = FramePipeline.finalize_many(pipes, ready, (9, 9), False)
+    for q, a, b in zip(pipes, out, single):
+        assert q.last_plan == 'single-pass'
+        for k in ('mean', 'count', 'img', 'mask', 'lat', 'lon'):
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+        for k, v in b['coords'].items():
+            assert np.array_equal(q.fd.host(k), v, equal_nan=True), k
+    # argument checks: more frames than a launch holds, a driver twice, a NULL direction array
+    lib = ctx._lib
+    n = 3
+    handles = (C.c_void_p * n)(*[q._pipe() for q in pipes])
+    pp = (C.c_void_p * n)(*[C.addressof(p) for p in ps])
+    oo = (C.c_void_p * n)(*[C.addressof(q._out) for q in pipes])
+    ii = (C.c_void_p * n)(*[q.fd.img.data_ptr() for q in pipes])
+    dd = (C.c_void_p * n)(*[d.data_ptr() for d in ds])
+    code = pipes[0].fd.img_dtype_code
+    assert lib.amt_pipe_launch_dirs_many(handles, 99, pp, dd, oo, ii, code, 10.0, 9.0, 9.0, 0, 0) < 0
+    assert b'AMT_PIPE_MAX_BATCH' in lib.amt_last_error(ctx.handle)
+    twice = (C.c_void_p * n)(handles[0], handles[1], handles[0])
+    assert lib.amt_pipe_launch_dirs_many(twice, n, pp, dd, oo, ii, code, 10.0, 9.0, 9.0, 0, 0) < 0
+    hole = (C.c_void_p * n)(dd[0], None, dd[2])
+    assert lib.amt_pipe_launch_dirs_many(handles, n, pp, hole, oo, ii, code, 10.0, 9.0, 9.0, 0, 0) < 0
+    assert lib.amt_pipe_launch_dirs_many(handles, n, pp, None, oo, ii, code, 10.0, 9.0, 9.0, 0, 0) < 0
+    for q in pipes:
+        q.join()
+    ctx.synchronize()
+
+
 @pytest.mark.parametrize('proj', ['TAN', 'SIN', 'ARC', 'STG', 'ZEA'])
 def test_device_generator_for_zenithal_headers_equals_the_numpy_restatement(proj):
     """amt_directions_zenithal (what getMapping runs for a header that is not plain TAN — the reference hands those to
