@@ -441,6 +441,12 @@ def timed_run(frames, warmup, steps, fast, plan, magnetic, batch, streams, use_h
     n_timed = (steps + TIMING_EVERY - 1) // TIMING_EVERY
     for _ in range(repeats):
         results = extra = None                  # (the previous region's arenas go back to the allocator)
+        if regions and warmup > 0:
+            # every region starts from the state the first one starts from — behind the W warm-up frames, the timed frames'
+            # predecessors in the sequence — instead of behind its own last frame (whose successor the first timed frame is
+            # not: six frames of such a region run the coarse pre-pass, profiles/r6/b2_region_timeline_driver_command.txt)
+            warm = seq.process(frames[:warmup])
+            del warm
         ctx.timing_enable(TIMING_EVERY)
         fence()
         t0 = time.perf_counter()
@@ -849,8 +855,9 @@ def main(argv=None):
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             # value / ms_per_step are those of the MEDIAN of `repeats` timed regions of `steps` steps each, run back to back
-            # (ms_per_step x steps = that one region); the spread of the regions beside it
-            'repeats': len(region_times), 'ms_per_step_min': min(region_times) / args.steps * 1e3,
+            # (ms_per_step x steps = that one region); the spread of the regions beside it.  Every region runs behind the same
+            # `warmup` untimed frames (the timed frames' predecessors in the sequence), like the first one
+            'repeats': len(region_times), 'untimed_frames_before_every_region': args.warmup, 'ms_per_step_min': min(region_times) / args.steps * 1e3,
             'ms_per_step_max': max(region_times) / args.steps * 1e3,
             'regions_ms': [t * 1e3 for t in region_times],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
