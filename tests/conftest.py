@@ -27,6 +27,28 @@ def header_from(z):
     return hdr
 
 
+_ORACLE_FRAMES = {}
+
+
+def oracle_frame(hdr, altitude, cam, m_geo, m_sm, fast=True):
+    """oracle.ref_numpy.georef_frame, remembered for the session: the full-size frames of the reference's tests are each asked
+    for by several test files (half a minute of NumPy per run).  Keyed by every input; the arrays come back read-only, the two
+    latest frames are kept (1.3 GB each)."""
+    from oracle import ref_numpy as O
+    key = (tuple(sorted((k, repr(v)) for k, v in hdr.items())), float(altitude), np.asarray(cam, dtype=np.float64).tobytes(),
+           np.asarray(m_geo, dtype=np.float64).tobytes(), None if m_sm is None else np.asarray(m_sm, dtype=np.float64).tobytes(),
+           bool(fast))
+    if key not in _ORACLE_FRAMES:
+        while len(_ORACLE_FRAMES) >= 2:
+            del _ORACLE_FRAMES[next(iter(_ORACLE_FRAMES))]
+        g = O.georef_frame(hdr, altitude, cam, m_geo, m_sm, fast=fast)
+        for v in g.values():
+            if isinstance(v, np.ndarray):
+                v.setflags(write=False)
+        _ORACLE_FRAMES[key] = g
+    return _ORACLE_FRAMES[key]
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

@@ -16,7 +16,7 @@ import numpy as np
 import numpy.ma as ma
 import pytest
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, load_golden, oracle_frame
 
 FRAMES = {
     'iss030': (os.path.join(GOLDEN, 'resources', 'ISS030-E-102170_dc.jpg'), os.path.join(GOLDEN, 'resources', 'ISS030-E-102170_dc.wcs')),
@@ -84,7 +84,7 @@ def test_oracle_equals_the_reference_at_the_arcsec_resolution(tag):
     from auromat_amd.resample import plateCarreeResolution_py
     zg, zs = fixture(tag, False), fixture(tag, True)
     hdr, img, cam, t = inputs(tag)
-    g = O.georef_frame(hdr, 110.0, zg['cam'], zg['m_geo'], zg['m_sm'], fast=True)
+    g = oracle_frame(hdr, 110.0, zg['cam'], zg['m_geo'], zg['m_sm'], fast=True)
     corner_mask, center_mask = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), 10)
     assert int((~center_mask).sum()) == int(zg['n_valid'])
     data = np.dstack((img.astype(np.float64), g['elev']))

@@ -12,7 +12,7 @@ import numpy as np
 import numpy.ma as ma
 import pytest
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, load_golden, oracle_frame
 
 JPG = os.path.join(GOLDEN, 'resources', 'ISS030-E-102170_dc.jpg')
 WCS = os.path.join(GOLDEN, 'resources', 'ISS030-E-102170_dc.wcs')
@@ -37,7 +37,7 @@ def test_oracle_equals_the_reference_on_its_own_test_frame():
     hdr = readHeader(WCS)
     img = loadImage(JPG)
     assert img.shape == (2832, 4256, 3) and img.dtype == np.uint8
-    g = O.georef_frame(hdr, 110.0, z['cam'], z['m_geo'], z['m_sm'], fast=True)
+    g = oracle_frame(hdr, 110.0, z['cam'], z['m_geo'], z['m_sm'], fast=True)
     corner_mask, center_mask = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), 10)
     assert int((~center_mask).sum()) == int(z['n_valid'])
     bbox, disc = O.bbox_of_corners(g['lat'], g['lon'], corner_mask)

@@ -20,7 +20,7 @@ import numpy as np
 import numpy.ma as ma
 import pytest
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, load_golden, oracle_frame
 
 JPG = os.path.join(GOLDEN, 'resources', 'south', 'ISS029-E-8492.jpg')
 WCS = os.path.join(GOLDEN, 'resources', 'south', 'ISS029-E-8492.wcs')
@@ -54,7 +54,7 @@ def test_oracle_equals_the_reference_on_the_south_frame():
     hdr, img, cam, t = south_inputs()
     assert img.shape == (2832, 4256, 3) and img.dtype == np.uint8
     assert np.array_equal(np.asarray(cam, dtype=np.float64), z['cam'])
-    g = O.georef_frame(hdr, 110.0, z['cam'], z['m_geo'], z['m_sm'], fast=True)
+    g = oracle_frame(hdr, 110.0, z['cam'], z['m_geo'], z['m_sm'], fast=True)
     corner_mask, center_mask = O.mask_by_elevation(g['elev'], np.isnan(g['lat']), 10)
     assert int((~center_mask).sum()) == int(z['n_valid'])
     data = np.dstack((img.astype(np.float64), g['elev']))
